@@ -1,0 +1,339 @@
+// dense.hip -- the correspondence (cross-attention) contraction, confidence pooling and the
+// 9-D -> SO(3) projection of DCL-Net's head.
+//
+// dcl_cross_attention replaces Aligner.forward + the extra bmm of models/Modules.py:162-169 and
+// models/DCL_Net.py:206-215: three cuBLAS batched SGEMMs and a softmax over a MATERIALISED
+// (b, Nk, Nq) attention map (4 MiB per crop per direction at N=M=1024, 96 MiB at 12288x2048).
+// Here the map never leaves registers: per 32-query x 32-key tile
+//     S  = K Q^T            fp32 MFMA 32x32x2, keys on the MFMA row axis, queries on the lane axis
+//     P  = exp(S - m_ref)   online softmax over the KEY axis; each lane owns one query column, so
+//                           the column max/sum is 16 registers + one lane^32 exchange
+//     O += [V_p;V_m] P      the S accumulator registers ARE the B operand of the second MFMA
+//                           (register e of lane-half h holds key (e&3)+8(e>>2)+4h), no shuffle/LDS
+// with a lazily updated reference maximum (rescale only when the running max grows by > kThr),
+// and one final division by the softmax denominator.  Bound: fp32 MFMA (157 TFLOP/s spec);
+// algorithmic flop = 2*(dk+dv)*Nq*Nk per crop per direction.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kKPitch = 68;        // floats per key row of the K tile in LDS: 64 ch + 4 pad (b128 conflict-free)
+constexpr float kThr = 20.0f;      // lazy-rescale threshold (e^20 ~ 5e8: far inside fp32 range)
+
+__device__ __forceinline__ int rowmap(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
+
+// All operands POINT-major: X[(b*n + p)*ld + c]  (the layout the 3-NN interpolation produces and the
+// 2-D GEMMs of the MLP stacks consume; the reference's (b,C,n) tensors are transposed views of it).
+template <int WAVES, int NVT>
+__global__ __launch_bounds__(WAVES * 64, WAVES >= 8 ? 2 : 1) void k_cross_attn(
+    int nq, int nk, const float *__restrict__ Q, int ldq, const float *__restrict__ K, int ldk,
+    const float *__restrict__ V1, int dv1, int ldv1, float *__restrict__ O1, int ldo1,
+    const float *__restrict__ V2, int dv2, int ldv2, float *__restrict__ O2, int ldo2) {
+  constexpr int T = WAVES * 64;
+  constexpr int DV = NVT * 32;
+  extern __shared__ float attn_lds[];
+  float *Ks = attn_lds;                       // [32 keys][kKPitch]
+  float *Vs = attn_lds + 32 * kKPitch;        // [32 keys][DV]
+  const int b = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int q = blockIdx.x * (WAVES * 32) + wave * 32 + r;
+  const bool qlive = q < nq;
+
+  // B operand of S: MFMA step s contracts channels {s, 32+s}; lane half h uses channel 32h+s.
+  // The wave's 32 query rows are parked in LDS (same padded layout as the K tile) to keep the
+  // register budget at 2 waves/SIMD.
+  float *Qs = Vs + 32 * DV + wave * 32 * kKPitch;
+  for (int i = lane; i < 32 * 16; i += 64) {
+    const int qr = i >> 4, c4 = (i & 15) * 4;
+    const int qq = blockIdx.x * (WAVES * 32) + wave * 32 + qr;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (qq < nq) v = *reinterpret_cast<const float4 *>(Q + ((size_t)b * nq + qq) * ldq + c4);
+    *reinterpret_cast<float4 *>(Qs + qr * kKPitch + c4) = v;
+  }
+  f32x16 O[NVT];
+#pragma unroll
+  for (int t = 0; t < NVT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) O[t][e] = 0.0f;
+  float m_ref = -INFINITY, l_part = 0.0f;
+
+  for (int kb = 0; kb < nk; kb += 32) {
+    __syncthreads();
+    // ---- stage 32 key rows: K (64 ch) and [V1|V2] (DV ch); rows past nk are zero ----
+    for (int i = tid; i < 32 * 16; i += T) {
+      const int key = i >> 4, c4 = (i & 15) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (kb + key < nk) v = *reinterpret_cast<const float4 *>(K + ((size_t)b * nk + kb + key) * ldk + c4);
+      *reinterpret_cast<float4 *>(Ks + key * kKPitch + c4) = v;
+    }
+    for (int i = tid; i < 32 * (DV / 4); i += T) {
+      const int key = i / (DV / 4), c4 = (i - key * (DV / 4)) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (kb + key < nk) {
+        const size_t row = (size_t)b * nk + kb + key;
+        v = c4 < dv1 ? *reinterpret_cast<const float4 *>(V1 + row * ldv1 + c4)
+                     : *reinterpret_cast<const float4 *>(V2 + row * ldv2 + (c4 - dv1));
+      }
+      *reinterpret_cast<float4 *>(Vs + key * DV + c4) = v;
+    }
+    __syncthreads();
+
+    // ---- S = K^T Q over 64 channels: A[i=key][k] = K[key][32h+s] ----
+    f32x16 S;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) S[e] = 0.0f;
+    {
+      const float *krow = Ks + r * kKPitch + 32 * h;
+      const float *qrow = Qs + r * kKPitch + 32 * h;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float4 a = *reinterpret_cast<const float4 *>(krow + 4 * i);
+        const float4 qv = *reinterpret_cast<const float4 *>(qrow + 4 * i);
+        S = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qv.x, S, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qv.y, S, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qv.z, S, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qv.w, S, 0, 0, 0);
+      }
+    }
+
+    // ---- online softmax over keys (column = this lane's query) ----
+    float m_tile = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      if (kb + rowmap(e, h) >= nk) S[e] = -INFINITY;
+      m_tile = fmaxf(m_tile, S[e]);
+    }
+    m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
+    if (__ballot(m_tile > m_ref + kThr) != 0ull) {       // rare, wave-uniform
+      const float m_new = fmaxf(m_ref, m_tile);
+      const float f = __expf(m_ref - m_new);             // exp(-inf) = 0 on the first tile
+      l_part *= f;
+#pragma unroll
+      for (int t = 0; t < NVT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) O[t][e] *= f;
+      m_ref = m_new;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      S[e] = __expf(S[e] - m_ref);
+      l_part += S[e];
+    }
+
+    // ---- O += V^T P : register e of S is the B operand for key rowmap(e,h); A[i=c][k] = V[key][c] ----
+#pragma unroll
+    for (int t = 0; t < NVT; ++t) {
+      const float *vcol = Vs + t * 32 + r + 4 * h * DV;
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        O[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vcol[((e & 3) + 8 * (e >> 2)) * DV], S[e], O[t], 0, 0, 0);
+    }
+  }
+
+  const float l_tot = l_part + __shfl_xor(l_part, 32, 64);
+  if (qlive) {
+    const size_t row = (size_t)b * nq + q;
+#pragma unroll
+    for (int t = 0; t < NVT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = t * 32 + 8 * g + 4 * h;            // 4 consecutive channels: e = 4g .. 4g+3
+        float4 v;
+        v.x = O[t][4 * g] / l_tot; v.y = O[t][4 * g + 1] / l_tot;
+        v.z = O[t][4 * g + 2] / l_tot; v.w = O[t][4 * g + 3] / l_tot;
+        if (c < dv1) *reinterpret_cast<float4 *>(O1 + row * ldo1 + c) = v;
+        else *reinterpret_cast<float4 *>(O2 + row * ldo2 + (c - dv1)) = v;
+      }
+  }
+}
+
+// ---- confidence pooling (models/DCL_Net.py:217-228) ------------------------------------------------
+// conf = sigmoid(cat[logit1 (b,n1), logit2 (b,n2)]); w = softmax(conf) over L = n1+n2;
+// pooled1[c] = sum_{j<n1} w_j F1[j][c], pooled2[c] = sum_{j<n2} w_{n1+j} F2[j][c] (F point-major),
+// wsum1/wsum2 = the two partial weight sums (for applying each side's trailing BatchNorm affine
+// after pooling: sum_j w_j (s*x_j + t) = s*pooled + t*wsum).
+// grid (C/64, b), 256 threads: every block recomputes the tiny softmax; lane = channel, the 4 waves
+// split the point axis and are combined in fixed order through LDS (deterministic).
+__global__ __launch_bounds__(256) void k_conf_pool(int c, int n1, int n2, const float *__restrict__ logit1,
+                                                   const float *__restrict__ logit2, const float *__restrict__ F1,
+                                                   int ld1, const float *__restrict__ F2, int ld2,
+                                                   float *__restrict__ conf, float *__restrict__ pooled1,
+                                                   float *__restrict__ pooled2, float *__restrict__ wsum) {
+  extern __shared__ float cp_lds[];            // w[L]
+  __shared__ float red[4];
+  __shared__ float part[2][4][64];
+  const int L = n1 + n2;
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  float mx = -INFINITY;
+  for (int j = tid; j < L; j += 256) {
+    const float x = j < n1 ? logit1[(size_t)b * n1 + j] : logit2[(size_t)b * n2 + (j - n1)];
+    const float s = 1.0f / (1.0f + expf(-x));
+    cp_lds[j] = s;
+    if (blockIdx.x == 0) conf[(size_t)b * L + j] = s;
+    mx = fmaxf(mx, s);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.0f;
+  for (int j = tid; j < L; j += 256) {
+    const float e = expf(cp_lds[j] - mx);
+    cp_lds[j] = e;
+    sum += e;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+  if (lane == 0) red[wave] = sum;
+  __syncthreads();
+  sum = (red[0] + red[1]) + (red[2] + red[3]);
+  const float inv = 1.0f / sum;
+  const int ch = blockIdx.x * 64 + lane;
+  float a1 = 0.0f, a2 = 0.0f;
+  if (ch < c) {
+    const float *f1 = F1 + (size_t)b * n1 * ld1 + ch;
+    for (int j = wave; j < n1; j += 4) a1 = __fmaf_rn(f1[(size_t)j * ld1], cp_lds[j] * inv, a1);
+    const float *f2 = F2 + (size_t)b * n2 * ld2 + ch;
+    for (int j = wave; j < n2; j += 4) a2 = __fmaf_rn(f2[(size_t)j * ld2], cp_lds[n1 + j] * inv, a2);
+  }
+  part[0][wave][lane] = a1; part[1][wave][lane] = a2;
+  __syncthreads();
+  if (wave == 0 && ch < c) {
+    pooled1[(size_t)b * c + ch] = (part[0][0][lane] + part[0][1][lane]) + (part[0][2][lane] + part[0][3][lane]);
+    pooled2[(size_t)b * c + ch] = (part[1][0][lane] + part[1][1][lane]) + (part[1][2][lane] + part[1][3][lane]);
+  }
+  if (blockIdx.x == 0 && wave == 1) {           // partial weight sums
+    float w1 = 0.f, w2 = 0.f;
+    for (int j = lane; j < n1; j += 64) w1 += cp_lds[j] * inv;
+    for (int j = lane; j < n2; j += 64) w2 += cp_lds[n1 + j] * inv;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { w1 += __shfl_xor(w1, d, 64); w2 += __shfl_xor(w2, d, 64); }
+    if (lane == 0) { wsum[b * 2] = w1; wsum[b * 2 + 1] = w2; }
+  }
+}
+
+// ---- ortho9d2matrix (models/DCL_Net.py:15-36) ------------------------------------------------------
+// R = U diag(1,1,det(U V^T)) V^T of the column-stacked, normalised raw vectors: one thread per crop,
+// one-sided Jacobi SVD in fp64 (the reference calls a batched LAPACK/MAGMA gesdd, ms-scale latency).
+// With A V = U Sigma:  R = u1 v1^T + u2 v2^T + det(V) (u1 x u2) v3^T   (sign-ambiguity free).
+__global__ void k_ortho9d(int b, const float *__restrict__ o9, float *__restrict__ R) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b) return;
+  double A[3][3], V[3][3];
+  for (int c = 0; c < 3; ++c) {
+    const float x = o9[i * 9 + c * 3], y = o9[i * 9 + c * 3 + 1], z = o9[i * 9 + c * 3 + 2];
+    const float mag = sqrtf((x * x + y * y) + z * z) + 1e-8f;       // utils/transform3D.py:18-20 (fp32)
+    A[0][c] = (double)(x / mag); A[1][c] = (double)(y / mag); A[2][c] = (double)(z / mag);
+    for (int r = 0; r < 3; ++r) V[r][c] = r == c ? 1.0 : 0.0;
+  }
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    double off = 0.0;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        double alpha = 0, beta = 0, gamma = 0;
+        for (int r = 0; r < 3; ++r) { alpha += A[r][p] * A[r][p]; beta += A[r][q] * A[r][q]; gamma += A[r][p] * A[r][q]; }
+        off = fmax(off, fabs(gamma) / sqrt(alpha * beta + 1e-300));
+        if (fabs(gamma) < 1e-300) continue;
+        const double zeta = (beta - alpha) / (2.0 * gamma);
+        const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+        for (int r = 0; r < 3; ++r) {
+          const double ap = A[r][p], aq = A[r][q];
+          A[r][p] = cs * ap - sn * aq; A[r][q] = sn * ap + cs * aq;
+          const double vp = V[r][p], vq = V[r][q];
+          V[r][p] = cs * vp - sn * vq; V[r][q] = sn * vp + cs * vq;
+        }
+      }
+    if (off < 1e-15) break;
+  }
+  double sig[3];
+  for (int c = 0; c < 3; ++c) sig[c] = sqrt(A[0][c] * A[0][c] + A[1][c] * A[1][c] + A[2][c] * A[2][c]);
+  int o0 = 0, o1 = 1, o2 = 2;                       // descending singular values (torch.svd order)
+  if (sig[o0] < sig[o1]) { int t = o0; o0 = o1; o1 = t; }
+  if (sig[o1] < sig[o2]) { int t = o1; o1 = o2; o2 = t; }
+  if (sig[o0] < sig[o1]) { int t = o0; o0 = o1; o1 = t; }
+  double u1[3], u2[3], u3[3];
+  for (int r = 0; r < 3; ++r) { u1[r] = A[r][o0] / sig[o0]; u2[r] = A[r][o1] / sig[o1]; }
+  u3[0] = u1[1] * u2[2] - u1[2] * u2[1];
+  u3[1] = u1[2] * u2[0] - u1[0] * u2[2];
+  u3[2] = u1[0] * u2[1] - u1[1] * u2[0];
+  const double detV = V[0][o0] * (V[1][o1] * V[2][o2] - V[2][o1] * V[1][o2]) -
+                      V[1][o0] * (V[0][o1] * V[2][o2] - V[2][o1] * V[0][o2]) +
+                      V[2][o0] * (V[0][o1] * V[1][o2] - V[1][o1] * V[0][o2]);
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c)
+      R[i * 9 + r * 3 + c] = (float)(u1[r] * V[c][o0] + u2[r] * V[c][o1] + detV * u3[r] * V[c][o2]);
+}
+
+}  // namespace
+
+DCL_API int dcl_cross_attention(int b, int nq, int nk, const float *Q, int ldq, const float *K, int ldk,
+                                const float *V1, int dv1, int ldv1, float *O1, int ldo1, const float *V2, int dv2,
+                                int ldv2, float *O2, int ldo2, dclStream_t stream) {
+  DCL_CHECK_ARG(b >= 0 && nq >= 0 && nk > 0 && dv1 > 0 && dv1 % 32 == 0 && dv2 >= 0 && dv2 % 32 == 0);
+  if (b == 0 || nq == 0) return 0;
+  DCL_CHECK_ARG(Q && K && V1 && O1 && (dv2 == 0 || (V2 && O2)) && b <= 65535);
+  DCL_CHECK_ARG(ldq >= 64 && ldk >= 64 && ldv1 >= dv1 && ldo1 >= dv1 && (dv2 == 0 || (ldv2 >= dv2 && ldo2 >= dv2)));
+  DCL_CHECK_ARG(ldq % 4 == 0 && ldk % 4 == 0 && ldv1 % 4 == 0 && ldo1 % 4 == 0 && ldv2 % 4 == 0 && ldo2 % 4 == 0);
+  DCL_CHECK_ARG((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V1 | (uintptr_t)O1 | (uintptr_t)V2 | (uintptr_t)O2) & 15) == 0);
+  const int nvt = (dv1 + dv2) / 32;
+  DCL_CHECK_ARG(nvt == 1 || nvt == 2 || nvt == 4 || nvt == 8 || nvt == 10);
+  hipStream_t s = (hipStream_t)stream;
+  // 8 waves (256 queries) share one K/V tile when that still fills the chip (2 waves/SIMD on one
+  // block per CU); small problems use 2-wave blocks, two of which fit a CU's LDS.
+  const long long blocks8 = (long long)b * dcl_div_up(nq, 256);
+  const int waves = blocks8 >= 256 ? 8 : 2;
+  const size_t lds = (size_t)(32 * kKPitch + 32 * nvt * 32 + waves * 32 * kKPitch) * sizeof(float);
+#define ATT(W, N)                                                                                              \
+  do {                                                                                                         \
+    if (lds > 48 * 1024)                                                                                       \
+      (void)hipFuncSetAttribute((const void *)k_cross_attn<W, N>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                (int)lds);                                                                     \
+    hipLaunchKernelGGL((k_cross_attn<W, N>), dim3(dcl_div_up(nq, W * 32), b), dim3(W * 64), lds, s, nq, nk, Q,  \
+                       ldq, K, ldk, V1, dv1, ldv1, O1, ldo1, V2, dv2, ldv2, O2, ldo2);                         \
+  } while (0)
+#define ATT_N(N) do { if (waves == 8) ATT(8, N); else ATT(2, N); } while (0)
+  switch (nvt) {
+    case 1: ATT_N(1); break;
+    case 2: ATT_N(2); break;
+    case 4: ATT_N(4); break;
+    case 8: ATT_N(8); break;
+    default: ATT_N(10); break;
+  }
+#undef ATT_N
+#undef ATT
+  DCL_LAUNCH_CHECK();
+  return 0;
+}
+
+DCL_API int dcl_conf_pool(int b, int c, int n1, int n2, const float *logit1, const float *logit2, const float *F1,
+                          int ld1, const float *F2, int ld2, float *conf, float *pooled1, float *pooled2,
+                          float *wsum, dclStream_t stream) {
+  DCL_CHECK_ARG(b >= 0 && c > 0 && n1 > 0 && n2 > 0 && (n1 + n2) <= 36 * 1024 && ld1 >= c && ld2 >= c);
+  if (b == 0) return 0;
+  DCL_CHECK_ARG(conf && pooled1 && pooled2 && wsum && logit1 && F1 && logit2 && F2 && b <= 65535);
+  const size_t lds = (size_t)(n1 + n2) * sizeof(float);
+  if (lds > 40 * 1024)
+    (void)hipFuncSetAttribute((const void *)k_conf_pool, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k_conf_pool, dim3(dcl_div_up(c, 64), b), dim3(256), lds, (hipStream_t)stream, c, n1, n2, logit1,
+                     logit2, F1, ld1, F2, ld2, conf, pooled1, pooled2, wsum);
+  DCL_LAUNCH_CHECK();
+  return 0;
+}
+
+DCL_API int dcl_ortho9d_to_matrix(int b, const float *o9, float *R, dclStream_t stream) {
+  DCL_CHECK_ARG(b >= 0);
+  if (b == 0) return 0;
+  DCL_CHECK_ARG(o9 && R);
+  hipLaunchKernelGGL(k_ortho9d, dim3(dcl_div_up(b, 64)), dim3(64), 0, (hipStream_t)stream, b, o9, R);
+  DCL_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,287 @@
+// interp.hip -- 3-nearest-neighbour search and inverse-distance interpolation.
+//
+// Replaces libs/pointnet_sp/src/interpolate_gpu.cu:9-122 (flat variants with a batch column, the
+// ones DCL_Net.forward uses through models/Modules.py:213-227) and the batched variants + knn of
+// libs/pointnet_lib/src/interpolate_gpu.cu:9-189.
+//
+// three_nn: one query per lane, kept in registers; the candidate index k is wave-uniform, so the
+// candidate row is fetched once per wave through the scalar cache (s_load) and broadcast -- no
+// LDS staging needed.  With `known_seg` a query scans only its own crop's rows (the reference
+// scans the whole batch and skips foreign rows: O(b^2)); results are identical because rows are
+// visited in ascending k either way.  Tie rule = the reference's strict '<' cascade.
+// three_interpolate: lanes run over channels of one point (coalesced row gathers + coalesced
+// stores; the reference maps threads to points and is fully uncoalesced).
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+struct Best3 {
+  float d1, d2, d3;
+  int i1, i2, i3;
+  __device__ __forceinline__ void init() { d1 = d2 = d3 = INFINITY; i1 = i2 = i3 = 0; }   // (float)1e40 == +inf
+  __device__ __forceinline__ void push(float d, int k) {
+    if (d < d1) { d3 = d2; i3 = i2; d2 = d1; i2 = i1; d1 = d; i1 = k; }
+    else if (d < d2) { d3 = d2; i3 = i2; d2 = d; i2 = k; }
+    else if (d < d3) { d3 = d; i3 = k; }
+  }
+};
+
+__global__ __launch_bounds__(256) void k_three_nn_sp(int n, int m, const float4 *__restrict__ unknown,
+                                                     const float4 *__restrict__ known, float *__restrict__ dist2,
+                                                     int32_t *__restrict__ idx, const int32_t *__restrict__ known_seg,
+                                                     int nbatch) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = p < n;
+  float4 u = make_float4(-1.f, 0.f, 0.f, 0.f);
+  if (live) u = unknown[p];
+  int lo = 0, hi = m;
+  if (known_seg) {
+    const int bi = (int)u.x;
+    if (live && bi >= 0 && bi < nbatch && (float)bi == u.x) { lo = known_seg[bi]; hi = known_seg[bi + 1]; }
+    else { lo = 0x7fffffff; hi = 0; }
+  } else if (!live) { lo = 0x7fffffff; hi = 0; }
+  // wave-uniform scan range = union of the lanes' ranges
+  int wlo = lo, whi = hi;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    wlo = min(wlo, __shfl_xor(wlo, d, 64));
+    whi = max(whi, __shfl_xor(whi, d, 64));
+  }
+  wlo = __builtin_amdgcn_readfirstlane(wlo);
+  whi = __builtin_amdgcn_readfirstlane(whi);
+  Best3 b; b.init();
+  for (int k = wlo; k < whi; ++k) {
+    const float4 q = known[k];                        // uniform address -> scalar load
+    if (q.x != u.x) continue;                         // interpolate_gpu.cu:36-38
+    b.push(dcl_dist2(u.y, u.z, u.w, q.y, q.z, q.w), k);
+  }
+  if (live) {
+    dist2[p * 3 + 0] = b.d1; dist2[p * 3 + 1] = b.d2; dist2[p * 3 + 2] = b.d3;
+    idx[p * 3 + 0] = b.i1; idx[p * 3 + 1] = b.i2; idx[p * 3 + 2] = b.i3;
+  }
+}
+
+// voxel centres (Ops_tensor2points, models/Modules.py:204-211): fp32, left to right.
+__global__ void k_voxel_centres(const int4 *__restrict__ indices, const int32_t *__restrict__ n_dev, int n_host,
+                                float ve, float off, float4 *__restrict__ centres) {
+  const int n = n_dev ? *n_dev : n_host;
+  const float half = 0.5f * ve;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int4 v = indices[i];
+    float4 c;
+    c.x = (float)v.x;
+    c.y = ((float)v.y * ve + off) + half;
+    c.z = ((float)v.z * ve + off) + half;
+    c.w = ((float)v.w * ve + off) + half;
+    centres[i] = c;
+  }
+}
+
+template <bool FROM_DIST2>
+__global__ void k_three_interpolate_sp(int c, int n, const float *__restrict__ points, const int32_t *__restrict__ idx,
+                                       const float *__restrict__ wsrc, float *__restrict__ out, int out_stride) {
+  const int c4 = c >> 2;
+  const long long total = (long long)n * c4;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int p = (int)(t / c4);
+    const int q = (int)(t - (long long)p * c4);
+    const int i0 = idx[p * 3], i1 = idx[p * 3 + 1], i2 = idx[p * 3 + 2];
+    float w0 = wsrc[p * 3], w1 = wsrc[p * 3 + 1], w2 = wsrc[p * 3 + 2];
+    if (FROM_DIST2) {                                   // models/Modules.py:221-224, pointnet2_utils.py:31
+      const float r0 = 1.0f / (sqrtf(w0) + 1e-8f), r1 = 1.0f / (sqrtf(w1) + 1e-8f), r2 = 1.0f / (sqrtf(w2) + 1e-8f);
+      const float norm = (r0 + r1) + r2;
+      w0 = r0 / norm; w1 = r1 / norm; w2 = r2 / norm;
+    }
+    const float4 a = reinterpret_cast<const float4 *>(points + (size_t)i0 * c)[q];
+    const float4 b = reinterpret_cast<const float4 *>(points + (size_t)i1 * c)[q];
+    const float4 d = reinterpret_cast<const float4 *>(points + (size_t)i2 * c)[q];
+    float4 o;
+    o.x = dcl_wsum3(w0, a.x, w1, b.x, w2, d.x);
+    o.y = dcl_wsum3(w0, a.y, w1, b.y, w2, d.y);
+    o.z = dcl_wsum3(w0, a.z, w1, b.z, w2, d.z);
+    o.w = dcl_wsum3(w0, a.w, w1, b.w, w2, d.w);
+    reinterpret_cast<float4 *>(out + (size_t)p * out_stride)[q] = o;
+  }
+}
+
+template <bool FROM_DIST2>
+__global__ void k_three_interpolate_sp_scalar(int c, int n, const float *__restrict__ points,
+                                              const int32_t *__restrict__ idx, const float *__restrict__ wsrc,
+                                              float *__restrict__ out, int out_stride) {
+  const long long total = (long long)n * c;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int p = (int)(t / c);
+    const int ch = (int)(t - (long long)p * c);
+    float w0 = wsrc[p * 3], w1 = wsrc[p * 3 + 1], w2 = wsrc[p * 3 + 2];
+    if (FROM_DIST2) {
+      const float r0 = 1.0f / (sqrtf(w0) + 1e-8f), r1 = 1.0f / (sqrtf(w1) + 1e-8f), r2 = 1.0f / (sqrtf(w2) + 1e-8f);
+      const float norm = (r0 + r1) + r2;
+      w0 = r0 / norm; w1 = r1 / norm; w2 = r2 / norm;
+    }
+    out[(size_t)p * out_stride + ch] =
+        dcl_wsum3(w0, points[(size_t)idx[p * 3] * c + ch], w1, points[(size_t)idx[p * 3 + 1] * c + ch], w2,
+                  points[(size_t)idx[p * 3 + 2] * c + ch]);
+  }
+}
+
+// ---- batched (pointnet_lib) variants -----------------------------------------------------------
+__global__ __launch_bounds__(256) void k_three_nn(int n, int m, const float *__restrict__ unknown,
+                                                  const float *__restrict__ known, float *__restrict__ dist2,
+                                                  int32_t *__restrict__ idx) {
+  const int bs = blockIdx.y;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = p < n;
+  const float *u = unknown + ((size_t)bs * n + (live ? p : 0)) * 3;
+  const float ux = u[0], uy = u[1], uz = u[2];
+  const float *K = known + (size_t)bs * m * 3;
+  Best3 b; b.init();
+  for (int k = 0; k < m; ++k)                           // uniform address -> scalar loads
+    b.push(dcl_dist2(ux, uy, uz, K[k * 3], K[k * 3 + 1], K[k * 3 + 2]), k);
+  if (live) {
+    const size_t o = ((size_t)bs * n + p) * 3;
+    dist2[o] = b.d1; dist2[o + 1] = b.d2; dist2[o + 2] = b.d3;
+    idx[o] = b.i1; idx[o + 1] = b.i2; idx[o + 2] = b.i3;
+  }
+}
+
+// knn, k <= 200 (interpolate_gpu.cu:9-57): sorted list with strict-'<' insertion, one query per
+// thread, list kept in a per-thread LDS column (conflict-free: slot j of thread t at j*T + t).
+constexpr int kKnnThreads = 64;
+__global__ __launch_bounds__(kKnnThreads) void k_knn(int n, int m, int k, const float *__restrict__ unknown,
+                                                     const float *__restrict__ known, float *__restrict__ dist2,
+                                                     int32_t *__restrict__ idx) {
+  extern __shared__ float knn_lds[];
+  float *bd = knn_lds;                                   // [k][T]
+  int *bi = reinterpret_cast<int *>(knn_lds + (size_t)k * kKnnThreads);
+  const int t = threadIdx.x;
+  const int bs = blockIdx.y;
+  const int p = blockIdx.x * kKnnThreads + t;
+  const bool live = p < n;
+  const float *u = unknown + ((size_t)bs * n + (live ? p : 0)) * 3;
+  const float ux = u[0], uy = u[1], uz = u[2];
+  const float *K = known + (size_t)bs * m * 3;
+  for (int j = 0; j < k; ++j) { bd[j * kKnnThreads + t] = INFINITY; bi[j * kKnnThreads + t] = 0; }
+  for (int i = 0; i < m; ++i) {
+    const float d = dcl_dist2(ux, uy, uz, K[i * 3], K[i * 3 + 1], K[i * 3 + 2]);
+    if (!(d < bd[(k - 1) * kKnnThreads + t])) continue;  // cannot enter the list
+    int j = k - 1;                                       // shift larger entries down, stable
+    while (j > 0 && d < bd[(j - 1) * kKnnThreads + t]) {
+      bd[j * kKnnThreads + t] = bd[(j - 1) * kKnnThreads + t];
+      bi[j * kKnnThreads + t] = bi[(j - 1) * kKnnThreads + t];
+      --j;
+    }
+    bd[j * kKnnThreads + t] = d;
+    bi[j * kKnnThreads + t] = i;
+  }
+  if (live)
+    for (int j = 0; j < k; ++j) {
+      dist2[((size_t)bs * n + p) * k + j] = bd[j * kKnnThreads + t];
+      idx[((size_t)bs * n + p) * k + j] = bi[j * kKnnThreads + t];
+    }
+}
+
+__global__ void k_three_interpolate(int c, int m, int n, const float *__restrict__ points,
+                                    const int32_t *__restrict__ idx, const float *__restrict__ weight,
+                                    float *__restrict__ out) {
+  const int bs = blockIdx.z, ch = blockIdx.y;
+  const float *P = points + ((size_t)bs * c + ch) * m;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+    const size_t o = ((size_t)bs * n + p) * 3;
+    out[((size_t)bs * c + ch) * n + p] =
+        dcl_wsum3(weight[o], P[idx[o]], weight[o + 1], P[idx[o + 1]], weight[o + 2], P[idx[o + 2]]);
+  }
+}
+
+}  // namespace
+
+DCL_API int dcl_three_nn_sp(int n, int m, const float *unknown, const float *known, float *dist2, int32_t *idx,
+                            const int32_t *known_seg, int nbatch, dclStream_t stream) {
+  DCL_CHECK_ARG(n >= 0 && m >= 0);
+  if (n == 0) return 0;
+  DCL_CHECK_ARG(unknown && dist2 && idx && (m == 0 || known) && (!known_seg || nbatch > 0));
+  hipLaunchKernelGGL(k_three_nn_sp, dim3(dcl_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, m,
+                     reinterpret_cast<const float4 *>(unknown), reinterpret_cast<const float4 *>(known), dist2, idx,
+                     known_seg, nbatch);
+  DCL_LAUNCH_CHECK();
+  return 0;
+}
+
+DCL_API int dcl_voxel_centres(const int32_t *indices, const int32_t *n_dev, int n_host, float ve, float off,
+                              float *centres, dclStream_t stream) {
+  DCL_CHECK_ARG(indices && centres && n_host >= 0);
+  if (n_host == 0) return 0;
+  hipLaunchKernelGGL(k_voxel_centres, dim3(dcl_grid_1d(n_host, 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const int4 *>(indices), n_dev, n_host, ve, off,
+                     reinterpret_cast<float4 *>(centres));
+  DCL_LAUNCH_CHECK();
+  return 0;
+}
+
+template <bool FROM_DIST2>
+static int launch_interp_sp(int c, int n, const float *points, const int32_t *idx, const float *w, float *out,
+                            int out_stride, hipStream_t s) {
+  if (c % 4 == 0 && out_stride % 4 == 0)
+    hipLaunchKernelGGL((k_three_interpolate_sp<FROM_DIST2>), dim3(dcl_grid_1d((long long)n * (c / 4), 256)),
+                       dim3(256), 0, s, c, n, points, idx, w, out, out_stride);
+  else
+    hipLaunchKernelGGL((k_three_interpolate_sp_scalar<FROM_DIST2>), dim3(dcl_grid_1d((long long)n * c, 256)),
+                       dim3(256), 0, s, c, n, points, idx, w, out, out_stride);
+  return 0;
+}
+
+DCL_API int dcl_three_interpolate_sp(int c, int m, int n, const float *points, const int32_t *idx,
+                                     const float *weight, float *out, int out_stride, dclStream_t stream) {
+  DCL_CHECK_ARG(c > 0 && m >= 0 && n >= 0 && out_stride >= c);
+  if (n == 0) return 0;
+  DCL_CHECK_ARG(points && idx && weight && out);
+  launch_interp_sp<false>(c, n, points, idx, weight, out, out_stride, (hipStream_t)stream);
+  DCL_LAUNCH_CHECK();
+  return 0;
+}
+
+DCL_API int dcl_three_interpolate_dist2_sp(int c, int m, int n, const float *points, const int32_t *idx,
+                                           const float *dist2, float *out, int out_stride, dclStream_t stream) {
+  DCL_CHECK_ARG(c > 0 && m >= 0 && n >= 0 && out_stride >= c);
+  if (n == 0) return 0;
+  DCL_CHECK_ARG(points && idx && dist2 && out);
+  launch_interp_sp<true>(c, n, points, idx, dist2, out, out_stride, (hipStream_t)stream);
+  DCL_LAUNCH_CHECK();
+  return 0;
+}
+
+DCL_API int dcl_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2, int32_t *idx,
+                         dclStream_t stream) {
+  DCL_CHECK_ARG(b >= 0 && n >= 0 && m >= 0);
+  if (b == 0 || n == 0) return 0;
+  DCL_CHECK_ARG(unknown && dist2 && idx && (m == 0 || known) && b <= 65535);
+  hipLaunchKernelGGL(k_three_nn, dim3(dcl_div_up(n, 256), b), dim3(256), 0, (hipStream_t)stream, n, m, unknown, known,
+                     dist2, idx);
+  DCL_LAUNCH_CHECK();
+  return 0;
+}
+
+DCL_API int dcl_knn(int b, int n, int m, int k, const float *unknown, const float *known, float *dist2, int32_t *idx,
+                    dclStream_t stream) {
+  DCL_CHECK_ARG(b >= 0 && n >= 0 && m >= 0 && k >= 1 && k <= 200);
+  if (b == 0 || n == 0) return 0;
+  DCL_CHECK_ARG(unknown && dist2 && idx && (m == 0 || known) && b <= 65535);
+  const size_t lds = (size_t)k * kKnnThreads * 8;
+  hipLaunchKernelGGL(k_knn, dim3(dcl_div_up(n, kKnnThreads), b), dim3(kKnnThreads), lds, (hipStream_t)stream, n, m, k,
+                     unknown, known, dist2, idx);
+  DCL_LAUNCH_CHECK();
+  return 0;
+}
+
+DCL_API int dcl_three_interpolate(int b, int c, int m, int n, const float *points, const int32_t *idx,
+                                  const float *weight, float *out, dclStream_t stream) {
+  DCL_CHECK_ARG(b >= 0 && c >= 0 && n >= 0 && m >= 0);
+  if (b == 0 || c == 0 || n == 0) return 0;
+  DCL_CHECK_ARG(points && idx && weight && out && b <= 65535 && c <= 65535);
+  hipLaunchKernelGGL(k_three_interpolate, dim3(dcl_grid_1d(n, 256, 64), c, b), dim3(256), 0, (hipStream_t)stream, c, m,
+                     n, points, idx, weight, out);
+  DCL_LAUNCH_CHECK();
+  return 0;
+}

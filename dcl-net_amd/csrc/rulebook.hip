@@ -1,0 +1,313 @@
+// rulebook.hip -- device-side sparse-conv rulebooks without sort, dense int grid or host sync.
+//
+// Replaces getIndicePair<3> (libs/spconv/include/spconv/spconv_ops.h:27-137) and its kernels
+// (indice.cu.h:24-208): prepareIndicePairsKernel + torch::_unique + assignGridAndIndiceOut +
+// assignIndicePairs for conv/pool, prepareSubMGrid + getSubMIndicePairs for submanifold conv.
+//
+// MI355X design: an active set lives in an occupancy BITMASK over the batch x S^3 grid
+// (64^3 bits = 32 KiB per crop, L2-resident) plus an exclusive popcount prefix per 32-bit word.
+// The rank of a voxel in ascending linear-index order -- exactly the output numbering the
+// reference obtains from sort+unique (spconv_ops.h:126) -- is then
+//     wprefix[word] + popc(mask[word] & lowbits)
+// so output ids need no sort, no 4 B/cell dense grid (1 MiB per crop in the reference) and no
+// count read-back.  Rulebooks are emitted in GATHER form (nbr[k][o] = input row or -1), which
+// lets the conv/pool kernels accumulate offsets k = 0..26 in the reference's order in registers,
+// without scatter atomics.  All work is integer/bit traffic: HBM/L2-bound, no MFMA.
+#include "common.h"
+
+namespace {
+
+constexpr int kScanWords = 1024;  // mask words per scan block (256 threads x 4)
+
+__device__ __forceinline__ int wave_incl_scan(int v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    int t = __shfl_up(v, d, 64);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+// block of 256 threads: returns exclusive prefix of v, *total = block sum
+__device__ __forceinline__ int block_excl_scan_256(int v, int *total) {
+  __shared__ int wsum[4];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  int inc = wave_incl_scan(v);
+  if (lane == 63) wsum[wid] = inc;
+  __syncthreads();
+  int base = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) base += (i < wid) ? wsum[i] : 0;
+  *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  __syncthreads();
+  return base + inc - v;
+}
+
+__global__ void k_block_popc(const uint32_t *__restrict__ mask, int nwords, int32_t *__restrict__ block_sums) {
+  const int w0 = blockIdx.x * kScanWords + threadIdx.x * 4;
+  int s = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) s += (w0 + j < nwords) ? __popc(mask[w0 + j]) : 0;
+  int total;
+  block_excl_scan_256(s, &total);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+__global__ void k_scan_words(const uint32_t *__restrict__ mask, int nwords,
+                             const int32_t *__restrict__ block_sums, int32_t *__restrict__ wprefix) {
+  int part = 0;
+  for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) part += block_sums[i];
+  int base;
+  block_excl_scan_256(part, &base);
+  const int w0 = blockIdx.x * kScanWords + threadIdx.x * 4;
+  int c[4], s = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    c[j] = (w0 + j < nwords) ? __popc(mask[w0 + j]) : 0;
+    s += c[j];
+  }
+  int total;
+  int ex = block_excl_scan_256(s, &total) + base;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (w0 + j < nwords) wprefix[w0 + j] = ex;
+    ex += c[j];
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) wprefix[nwords] = base + total;
+}
+
+__device__ __forceinline__ int grid_lookup(const uint32_t *__restrict__ mask, const int32_t *__restrict__ wprefix,
+                                           const int32_t *__restrict__ perm, int lin) {
+  const int w = lin >> 5;
+  const uint32_t m = mask[w];
+  const uint32_t bit = 1u << (lin & 31);
+  if (!(m & bit)) return -1;
+  const int r = wprefix[w] + __popc(m & (bit - 1));
+  return perm ? perm[r] : r;
+}
+
+__global__ void k_mark_rows(const int32_t *__restrict__ indices, int n, int S, uint32_t *__restrict__ mask) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int4 p = reinterpret_cast<const int4 *>(indices)[i];
+    const int lin = ((p.x * S + p.y) * S + p.z) * S + p.w;
+    atomicOr(&mask[lin >> 5], 1u << (lin & 31));
+  }
+}
+
+__global__ void k_fill_perm(const int32_t *__restrict__ indices, int n, int S, const uint32_t *__restrict__ mask,
+                            const int32_t *__restrict__ wprefix, int32_t *__restrict__ perm) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int4 p = reinterpret_cast<const int4 *>(indices)[i];
+    const int lin = ((p.x * S + p.y) * S + p.z) * S + p.w;
+    perm[grid_lookup(mask, wprefix, nullptr, lin)] = i;
+  }
+}
+
+// every input voxel marks the outputs it reaches: o = (p + pad - k) / stride when divisible
+// (the set getValidOutPos enumerates, geometry.h:23-85, for dilation 1).
+__global__ void k_mark_conv_outputs(const int32_t *__restrict__ in_indices, const int32_t *__restrict__ n_dev,
+                                    int n_host, int S_out, int ks, int stride, int pad,
+                                    uint32_t *__restrict__ out_mask) {
+  const int n = n_dev ? *n_dev : n_host;
+  const int kvol = ks * ks * ks;
+  const long long total = (long long)n * kvol;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(t / kvol);
+    const int k = (int)(t - (long long)i * kvol);
+    const int kx = k / (ks * ks), ky = (k / ks) % ks, kz = k % ks;
+    const int4 p = reinterpret_cast<const int4 *>(in_indices)[i];
+    const int tx = p.y + pad - kx, ty = p.z + pad - ky, tz = p.w + pad - kz;
+    if (tx < 0 || ty < 0 || tz < 0) continue;
+    if (tx % stride || ty % stride || tz % stride) continue;
+    const int ox = tx / stride, oy = ty / stride, oz = tz / stride;
+    if (ox >= S_out || oy >= S_out || oz >= S_out) continue;
+    const int lin = ((p.x * S_out + ox) * S_out + oy) * S_out + oz;
+    atomicOr(&out_mask[lin >> 5], 1u << (lin & 31));
+  }
+}
+
+// decode every set bit into its (b,x,y,z) row at its rank (assignGridAndIndiceOutKernel,
+// indice.cu.h:112-128, without the sort that precedes it).
+__global__ void k_enumerate(const uint32_t *__restrict__ mask, const int32_t *__restrict__ wprefix, int nwords,
+                            int S, int32_t *__restrict__ out_indices, int cap, int32_t *__restrict__ n_out_dev) {
+  for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += gridDim.x * blockDim.x) {
+    uint32_t m = mask[w];
+    int r = wprefix[w];
+    while (m) {
+      const int bit = __ffs(m) - 1;
+      m &= m - 1;
+      int lin = (w << 5) + bit;
+      int4 o;
+      o.w = lin % S; lin /= S;
+      o.z = lin % S; lin /= S;
+      o.y = lin % S; lin /= S;
+      o.x = lin;
+      if (r < cap) reinterpret_cast<int4 *>(out_indices)[r] = o;
+      ++r;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && n_out_dev) *n_out_dev = wprefix[nwords];
+}
+
+// gather-form rulebook: for output o and offset k the feeding input sits at p = o*stride - pad + k.
+__global__ void k_build_nbr(const int32_t *__restrict__ out_indices, const int32_t *__restrict__ n_out_dev,
+                            int n_out_host, const uint32_t *__restrict__ in_mask,
+                            const int32_t *__restrict__ in_wprefix, const int32_t *__restrict__ in_perm,
+                            int S_in, int ks, int stride, int pad, int32_t *__restrict__ nbr, int cap) {
+  int n = n_out_dev ? *n_out_dev : n_out_host;
+  n = n < cap ? n : cap;
+  const int kvol = ks * ks * ks;
+  for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < n; o += gridDim.x * blockDim.x) {
+    const int4 q = reinterpret_cast<const int4 *>(out_indices)[o];
+    const int bx = q.y * stride - pad, by = q.z * stride - pad, bz = q.w * stride - pad;
+    int k = 0;
+    for (int kx = 0; kx < ks; ++kx) {
+      const int px = bx + kx;
+      for (int ky = 0; ky < ks; ++ky) {
+        const int py = by + ky;
+        for (int kz = 0; kz < ks; ++kz, ++k) {
+          const int pz = bz + kz;
+          int v = -1;
+          if ((unsigned)px < (unsigned)S_in && (unsigned)py < (unsigned)S_in && (unsigned)pz < (unsigned)S_in)
+            v = grid_lookup(in_mask, in_wprefix, in_perm, ((q.x * S_in + px) * S_in + py) * S_in + pz);
+          nbr[(size_t)k * cap + o] = v;
+        }
+      }
+    }
+    (void)kvol;
+  }
+}
+
+__global__ void k_pairs_init(int32_t *__restrict__ pairs, long long n, int32_t *__restrict__ indice_num, int kvol) {
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x)
+    pairs[t] = -1;
+  if (blockIdx.x == 0 && (int)threadIdx.x < kvol) indice_num[threadIdx.x] = 0;
+}
+
+__global__ void k_pairs_export(const int32_t *__restrict__ nbr, int cap, const int32_t *__restrict__ n_out_dev,
+                               int n_out_host, int kvol, int32_t *__restrict__ pairs, int n_in_cap,
+                               int32_t *__restrict__ indice_num) {
+  int n = n_out_dev ? *n_out_dev : n_out_host;
+  n = n < cap ? n : cap;
+  const long long total = (long long)n * kvol;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(t / n);
+    const int o = (int)(t - (long long)k * n);
+    const int v = nbr[(size_t)k * cap + o];
+    if (v < 0) continue;
+    const int c = atomicAdd(&indice_num[k], 1);
+    if (c < n_in_cap) {
+      pairs[((size_t)k * 2 + 0) * n_in_cap + c] = v;
+      pairs[((size_t)k * 2 + 1) * n_in_cap + c] = o;
+    }
+  }
+}
+
+int scan_mask(const uint32_t *mask, int nwords, int32_t *wprefix, int32_t *scratch, hipStream_t s) {
+  const int nblocks = dcl_div_up(nwords, kScanWords);
+  hipLaunchKernelGGL(k_block_popc, dim3(nblocks), dim3(256), 0, s, mask, nwords, scratch);
+  hipLaunchKernelGGL(k_scan_words, dim3(nblocks), dim3(256), 0, s, mask, nwords, scratch, wprefix);
+  return 0;
+}
+
+inline long long grid_words(int batch, int S) { return ((long long)batch * S * S * S + 31) / 32; }
+
+}  // namespace
+
+DCL_API int dcl_grid_from_indices(const int32_t *indices, int n_rows, int batch, int S, uint32_t *mask,
+                                  int32_t *wprefix, int32_t *perm, int32_t *scratch, dclStream_t stream) {
+  DCL_CHECK_ARG(batch > 0 && S > 0 && n_rows >= 0 && mask && wprefix && scratch);
+  DCL_CHECK_ARG(grid_words(batch, S) < (1ll << 26));
+  hipStream_t s = (hipStream_t)stream;
+  const int nwords = (int)grid_words(batch, S);
+  hipError_t e = hipMemsetAsync(mask, 0, sizeof(uint32_t) * (size_t)nwords, s);
+  if (e != hipSuccess) { dcl_set_error("dcl_grid_from_indices: memset: %s", hipGetErrorString(e)); return (int)e; }
+  if (n_rows > 0) {
+    DCL_CHECK_ARG(indices);
+    hipLaunchKernelGGL(k_mark_rows, dim3(dcl_grid_1d(n_rows, 256)), dim3(256), 0, s, indices, n_rows, S, mask);
+  }
+  scan_mask(mask, nwords, wprefix, scratch, s);
+  if (perm && n_rows > 0)
+    hipLaunchKernelGGL(k_fill_perm, dim3(dcl_grid_1d(n_rows, 256)), dim3(256), 0, s, indices, n_rows, S, mask,
+                       wprefix, perm);
+  DCL_LAUNCH_CHECK();
+  return 0;
+}
+
+DCL_API int dcl_conv_out_grid(const int32_t *in_indices, const int32_t *n_in_dev, int n_in_host, int batch,
+                              int S_in, int ksize, int stride, int padding, uint32_t *out_mask,
+                              int32_t *out_wprefix, int32_t *out_indices, int32_t *n_out_dev, int cap_out,
+                              int32_t *scratch, dclStream_t stream) {
+  DCL_CHECK_ARG(batch > 0 && S_in > 0 && ksize >= 1 && ksize <= 3 && stride >= 1 && padding >= 0);
+  DCL_CHECK_ARG(in_indices && out_mask && out_wprefix && out_indices && scratch && cap_out > 0 && n_in_host >= 0);
+  const int S_out = (S_in + 2 * padding - (ksize - 1) - 1) / stride + 1;   // spconv/ops.py:19-30
+  DCL_CHECK_ARG(S_out > 0 && grid_words(batch, S_out) < (1ll << 26));
+  hipStream_t s = (hipStream_t)stream;
+  const int nwords = (int)grid_words(batch, S_out);
+  hipError_t e = hipMemsetAsync(out_mask, 0, sizeof(uint32_t) * (size_t)nwords, s);
+  if (e != hipSuccess) { dcl_set_error("dcl_conv_out_grid: memset: %s", hipGetErrorString(e)); return (int)e; }
+  const int kvol = ksize * ksize * ksize;
+  const long long in_work = (long long)n_in_host * kvol;                  // n_in_host bounds *n_in_dev
+  hipLaunchKernelGGL(k_mark_conv_outputs, dim3(dcl_grid_1d(in_work > 0 ? in_work : 1, 256)), dim3(256), 0, s,
+                     in_indices, n_in_dev, n_in_host, S_out, ksize, stride, padding, out_mask);
+  scan_mask(out_mask, nwords, out_wprefix, scratch, s);
+  hipLaunchKernelGGL(k_enumerate, dim3(dcl_grid_1d(nwords, 256)), dim3(256), 0, s, out_mask, out_wprefix, nwords,
+                     S_out, out_indices, cap_out, n_out_dev);
+  DCL_LAUNCH_CHECK();
+  return 0;
+}
+
+DCL_API int dcl_rulebook_gather(const int32_t *out_indices, const int32_t *n_out_dev, int n_out_host,
+                                const uint32_t *in_mask, const int32_t *in_wprefix, const int32_t *in_perm,
+                                int batch, int S_in, int ksize, int stride, int padding, int32_t *nbr, int cap,
+                                dclStream_t stream) {
+  DCL_CHECK_ARG(batch > 0 && S_in > 0 && ksize >= 1 && ksize <= 3 && stride >= 1 && padding >= 0 && cap > 0);
+  DCL_CHECK_ARG(out_indices && in_mask && in_wprefix && nbr && n_out_host >= 0 && n_out_host <= cap);
+  const int rows = n_out_dev ? cap : n_out_host;
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(k_build_nbr, dim3(dcl_grid_1d(rows, 256)), dim3(256), 0, (hipStream_t)stream, out_indices,
+                     n_out_dev, n_out_host, in_mask, in_wprefix, in_perm, S_in, ksize, stride, padding, nbr, cap);
+  DCL_LAUNCH_CHECK();
+  return 0;
+}
+
+DCL_API int dcl_rulebook_conv(const int32_t *in_indices, const int32_t *n_in_dev, int n_in_host,
+                              const uint32_t *in_mask, const int32_t *in_wprefix, const int32_t *in_perm,
+                              int batch, int S_in, int ksize, int stride, int padding,
+                              uint32_t *out_mask, int32_t *out_wprefix, int32_t *out_indices,
+                              int32_t *n_out_dev, int32_t *nbr, int cap_out, int32_t *scratch,
+                              dclStream_t stream) {
+  DCL_CHECK_ARG(in_mask && in_wprefix && nbr);
+  int rc = dcl_conv_out_grid(in_indices, n_in_dev, n_in_host, batch, S_in, ksize, stride, padding, out_mask,
+                             out_wprefix, out_indices, n_out_dev, cap_out, scratch, stream);
+  if (rc) return rc;
+  const int S_out = (S_in + 2 * padding - (ksize - 1) - 1) / stride + 1;
+  const int nwords = (int)grid_words(batch, S_out);
+  return dcl_rulebook_gather(out_indices, out_wprefix + nwords, 0, in_mask, in_wprefix, in_perm, batch, S_in, ksize,
+                             stride, padding, nbr, cap_out, stream);
+}
+
+DCL_API int dcl_rulebook_subm(const int32_t *indices, const int32_t *n_dev, int n_host,
+                              const uint32_t *mask, const int32_t *wprefix, const int32_t *perm,
+                              int batch, int S, int ksize, int32_t *nbr, int cap, dclStream_t stream) {
+  DCL_CHECK_ARG(ksize == 1 || ksize == 3);
+  return dcl_rulebook_gather(indices, n_dev, n_host, mask, wprefix, perm, batch, S, ksize, 1, ksize / 2, nbr, cap,
+                             stream);                                       // spconv_ops.h:76-79
+}
+
+DCL_API int dcl_rulebook_to_pairs(const int32_t *nbr, int cap, const int32_t *n_out_dev, int n_out_host,
+                                  int kvol, int32_t *indice_pairs, int n_in_cap, int32_t *indice_num,
+                                  dclStream_t stream) {
+  DCL_CHECK_ARG(nbr && indice_pairs && indice_num && cap > 0 && kvol > 0 && kvol <= 27 && n_in_cap >= 0);
+  hipStream_t s = (hipStream_t)stream;
+  const long long np = (long long)kvol * 2 * n_in_cap;
+  hipLaunchKernelGGL(k_pairs_init, dim3(dcl_grid_1d(np > 0 ? np : 1, 256)), dim3(256), 0, s, indice_pairs, np,
+                     indice_num, kvol);
+  hipLaunchKernelGGL(k_pairs_export, dim3(dcl_grid_1d((long long)cap * kvol, 256)), dim3(256), 0, s, nbr, cap,
+                     n_out_dev, n_out_host, kvol, indice_pairs, n_in_cap, indice_num);
+  DCL_LAUNCH_CHECK();
+  return 0;
+}

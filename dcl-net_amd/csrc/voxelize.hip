@@ -1,0 +1,38 @@
+// voxelize.hip -- point -> voxel feature pooling (replaces voxelize_fp_cuda_,
+// libs/pointgroup_ops/src/voxelize/voxelize.cu:9-31).
+//
+// One thread per (voxel row, plane).  The reference accumulates with atomicAdd from one
+// thread per plane, i.e. a serial fp32 sum in rule order: ((0 + m*x1) + m*x2) + ...;
+// this kernel keeps that order in a register and stores once (no atomics, no pre-zeroing).
+// HBM-bound: 4*(V*(1+maxActive) + N*C + V*C) bytes; rows are consecutive so the rule reads
+// of neighbouring threads of a row hit the same cache line.
+#include "common.h"
+
+__global__ void voxelize_fp_kernel(const float *__restrict__ feats, const int32_t *__restrict__ rules,
+                                   float *__restrict__ out, int n_rows, int max_active, int n_planes,
+                                   int average) {
+  const long long total = (long long)n_rows * n_planes;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int row = (int)(t / n_planes);
+    const int plane = (int)(t - (long long)row * n_planes);
+    const int32_t *r = rules + (size_t)row * (max_active + 1);
+    const int n_active = r[0];
+    const float mult = (average && n_active > 0) ? 1.0f / (float)n_active : 1.0f;
+    float acc = 0.0f;
+    for (int i = 1; i <= n_active; ++i) acc = acc + mult * feats[(size_t)r[i] * n_planes + plane];
+    out[t] = acc;
+  }
+}
+
+DCL_API int dcl_voxelize_fp(const float *feats, const int32_t *rules, float *out, int n_rows,
+                            int max_active, int n_planes, int average, dclStream_t stream) {
+  DCL_CHECK_ARG(n_rows >= 0 && max_active >= 0 && n_planes > 0);
+  if (n_rows == 0) return 0;
+  DCL_CHECK_ARG(feats && rules && out);
+  const long long total = (long long)n_rows * n_planes;
+  hipLaunchKernelGGL(voxelize_fp_kernel, dim3(dcl_grid_1d(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, feats, rules, out, n_rows, max_active, n_planes, average);
+  DCL_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,125 @@
+"""Stage-2 pose refiner: drop-in for the reference's models/refiner.py:57-95 (same 18-key state_dict),
+plus the iterative refinement loop of tools/test_YCBV_stage2.py:204-225 as a reusable function.
+
+fused path: point-major GEMMs with bias+ReLU epilogues for MLP_share (259->512->512->1024), the
+un-renormalised softmax slice (refiner.py:81) and the weighted sum as one GEMV-shaped reduction,
+on-device 3x3 SVD.  Shapes are static, so `refine_loop(..., graph=True)` captures the loop body in a
+hipGraph (torch.cuda.CUDAGraph) and replays it.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .Modules import Head_MultiLayerPerceptron
+
+
+def ortho9d2matrix(x_raw, y_raw, z_raw):
+    return ops.ortho9d_to_matrix(torch.cat([x_raw, y_raw, z_raw], dim=1))
+
+
+class Refiner(nn.Module):
+    def __init__(self, cfg=None):
+        super().__init__()
+        self.MLP_share = Head_MultiLayerPerceptron([256 + 3, 512, 512, 1024], ["relu"] * 3, [False] * 3, [0.0] * 3)
+        self.regressor_rot2 = Head_MultiLayerPerceptron([1024, 512, 128, 9], ["relu", "relu", "none"], [False] * 3,
+                                                        [0.0] * 3)
+        self.regressor_trans2 = Head_MultiLayerPerceptron([1024, 512, 128, 3], ["relu", "relu", "none"], [False] * 3,
+                                                          [0.0] * 3)
+        self._folded = None
+
+    def _apply(self, fn, *a, **k):
+        self._folded = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._folded = None
+        return super().load_state_dict(*a, **k)
+
+    def _fold(self):
+        if self._folded is None:
+            with torch.no_grad():
+                f = {}
+                for name in ("MLP_share", "regressor_rot2", "regressor_trans2"):
+                    L = getattr(self, name).layers
+                    f[name] = [(L[i].weight[:, :, 0].t().contiguous(), L[i].bias.contiguous()) for i in (0, 2, 4)]
+                # split the 259-row first weight: rows 0..2 act on xyz, rows 3.. on F_Xo_p
+                Wt, bias = f["MLP_share"][0]
+                f["share0_xyz"], f["share0_feat"] = Wt[:3].contiguous(), Wt[3:].contiguous()
+            self._folded = f
+        return self._folded
+
+    def forward_pm(self, xyz_pm, feat_term, conf_w):
+        """Point-major core: xyz_pm (b*n,3) canonicalised points, feat_term (b*n,512) = F_Xo_p @ W0[3:] + b0
+        (constant over refinement iterations), conf_w (b,n) softmax slice.  -> (delta_t (b,3), delta_R (b,3,3))."""
+        f = self._fold()
+        b, n = conf_w.shape
+        h = torch.relu(torch.addmm(feat_term, xyz_pm, f["share0_xyz"]))
+        h = torch._addmm_activation(f["MLP_share"][1][1], h, f["MLP_share"][1][0])
+        h = torch._addmm_activation(f["MLP_share"][2][1], h, f["MLP_share"][2][0])          # (b*n, 1024)
+        shared = torch.bmm(conf_w.unsqueeze(1), h.view(b, n, -1)).squeeze(1)                 # (b, 1024)
+
+        def head(x, layers):
+            x = torch._addmm_activation(layers[0][1], x, layers[0][0])
+            x = torch._addmm_activation(layers[1][1], x, layers[1][0])
+            return torch.addmm(layers[2][1], x, layers[2][0])
+        o9 = head(shared, f["regressor_rot2"])
+        return head(shared, f["regressor_trans2"]), ops.ortho9d_to_matrix(o9)
+
+    def forward(self, input_dict):
+        """reference contract: {"input_features" (b,259,n), "conf" (b,n+m), "obj_idx"} ->
+        {"trans_pred" (b,3), "rot_pred" (b,3,3)}."""
+        x = input_dict["input_features"]
+        conf = input_dict["conf"]
+        if not x.is_cuda:
+            raise RuntimeError("dcl-net_amd.Refiner runs on the GPU only (no CPU fallback)")
+        with torch.no_grad():
+            f = self._fold()
+            b, _, n = x.shape
+            conf_w = torch.softmax(conf.unsqueeze(1), dim=2)[:, 0, :1024].contiguous()       # refiner.py:81
+            pm = x.transpose(1, 2).reshape(b * n, -1)
+            feat_term = torch.addmm(f["MLP_share"][0][1], pm[:, 3:], f["share0_feat"])
+            dt, dR = self.forward_pm(pm[:, :3].contiguous(), feat_term, conf_w)
+        return {"trans_pred": dt, "rot_pred": dR}
+
+
+def refine_loop(refiner, pred, points_inp, iteration=2, graph=False):
+    """Iterative refinement of tools/test_YCBV_stage2.py:204-225 on the outputs of Network.forward:
+    pred {"rot_pred","trans_pred","F_Xo_p" (b,256,n),"conf"}, points_inp (b,n,3) -> (rot (b,3,3), trans (b,3)).
+    With graph=True the whole loop is captured once per shape into a hipGraph and replayed."""
+    f = refiner._fold()
+    rot0, trans0, conf = pred["rot_pred"], pred["trans_pred"], pred["conf"]
+    F_pm = pred["F_Xo_p"].transpose(1, 2)                                 # (b,n,256) (a view when fused)
+    b, n, _ = F_pm.shape
+
+    def body(rot, trans, F_pm, conf, pts):
+        conf_w = torch.softmax(conf.unsqueeze(1), dim=2)[:, 0, :1024].contiguous()
+        feat_term = torch.addmm(f["MLP_share"][0][1], F_pm.reshape(b * n, -1), f["share0_feat"])
+        for _ in range(iteration):
+            cur = torch.bmm(pts - trans.unsqueeze(1), rot).reshape(b * n, 3)
+            dt, dR = refiner.forward_pm(cur, feat_term, conf_w)
+            trans = (rot @ dt.unsqueeze(2)).squeeze(2) + trans
+            rot = rot @ dR
+        return rot, trans
+
+    with torch.no_grad():
+        if not graph:
+            return body(rot0, trans0, F_pm, conf, points_inp)
+        key = (b, n, iteration, conf.shape[1])
+        cache = refiner.__dict__.setdefault("_graphs", {})
+        if key not in cache:
+            static = [t.clone() for t in (rot0, trans0, F_pm.contiguous(), conf, points_inp)]
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(2):                                        # warm-up (allocator, lazy inits)
+                    body(*static)
+            torch.cuda.current_stream().wait_stream(s)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = body(*static)
+            cache[key] = (g, static, out)
+        g, static, out = cache[key]
+        for dst, src in zip(static, (rot0, trans0, F_pm, conf, points_inp)):
+            dst.copy_(src)
+        g.replay()
+        return out[0].clone(), out[1].clone()

@@ -1,0 +1,334 @@
+"""Thin torch-tensor front end of the C ABI (include/dclnet_hip.h).
+
+Every function takes/returns CUDA tensors (PyTorch is the allocator and stream provider), checks
+arguments the way the reference's Python wrappers do (contiguity, dtypes) and calls the HIP
+library on torch's current stream.  No function here has a CPU fallback.
+"""
+import ctypes as C
+
+import torch
+
+from . import _native as N
+
+_c_int = C.c_int
+_c_float = C.c_float
+
+
+def _i32_ptr_or_null(t):
+    return N.ptr(t) if t is not None else N.vp(0)
+
+
+# ------------------------------------------------------------------------------------ PG_OP
+def voxelize_idx(coords, batch_size, mode=4):
+    """PG_OP.voxelize_idx (libs/pointgroup_ops/functions/pointgroup_ops.py:11-39): HOST op.
+    coords long (N, 3|4) CPU -> (output_coords long (M,ncol), input_map int (N), output_map int (M,1+maxActive))."""
+    if coords.is_cuda:
+        raise RuntimeError("voxelize_idx is a host (DataLoader-side) op: pass a CPU tensor")
+    assert coords.is_contiguous() and coords.dtype == torch.int64 and coords.dim() == 2
+    n, ncol = coords.shape
+    input_map = torch.zeros(n, dtype=torch.int32)
+    na, ma = C.c_int32(0), C.c_int32(0)
+    N.check(N.lib().dcl_voxelize_idx_count(N.ptr(coords), n, ncol, int(batch_size), int(mode), N.ptr(input_map),
+                                           C.byref(na), C.byref(ma)), "voxelize_idx_count")
+    out_coords = torch.zeros((na.value, ncol), dtype=torch.int64)
+    out_map = torch.zeros((na.value, ma.value + 1), dtype=torch.int32)
+    N.check(N.lib().dcl_voxelize_idx_fill(N.ptr(coords), n, ncol, N.ptr(input_map), na.value, ma.value,
+                                          N.ptr(out_coords), N.ptr(out_map)), "voxelize_idx_fill")
+    return out_coords, input_map, out_map
+
+
+def voxelize_fp(feats, map_rule, mode=4):
+    """PG_OP.voxelize_fp (pointgroup_ops.py:42-62): feats (N,C) f32, map_rule (M,1+maxActive) i32 -> (M,C)."""
+    N.need_cuda(feats, map_rule)
+    assert feats.is_contiguous() and map_rule.is_contiguous()
+    assert feats.dtype == torch.float32 and map_rule.dtype == torch.int32
+    M, ma = map_rule.shape[0], map_rule.shape[1] - 1
+    out = torch.empty((M, feats.shape[1]), dtype=torch.float32, device=feats.device)
+    N.check(N.lib().dcl_voxelize_fp(N.ptr(feats), N.ptr(map_rule), N.ptr(out), M, ma, feats.shape[1],
+                                    int(mode == 4), N.stream()), "voxelize_fp")
+    return out
+
+
+# ------------------------------------------------------------------------------------ rulebooks
+def grid_words(batch, S):
+    return (batch * S * S * S + 31) // 32
+
+
+def scan_scratch(nwords, device):
+    return torch.empty(((nwords + 1023) // 1024) + 1, dtype=torch.int32, device=device)
+
+
+class ActiveSet(object):
+    """Device-side description of an active voxel set (see include/dclnet_hip.h, spconv section)."""
+    __slots__ = ("indices", "n", "n_dev", "cap", "mask", "wprefix", "perm", "S", "batch")
+
+    def __init__(self, indices, n, n_dev, cap, mask, wprefix, perm, S, batch):
+        self.indices, self.n, self.n_dev, self.cap = indices, n, n_dev, cap
+        self.mask, self.wprefix, self.perm, self.S, self.batch = mask, wprefix, perm, S, batch
+
+    def segments(self):
+        """i32[batch+1]: rows of crop b are [seg[b], seg[b+1]) (rows are in ascending linear index
+        unless perm is set)."""
+        wpc = (self.S ** 3) // 32
+        assert wpc * 32 == self.S ** 3 and self.perm is None
+        return self.wprefix[::wpc].contiguous()
+
+
+def grid_from_indices(indices, batch, S):
+    """ActiveSet of an explicit voxel list (rows in any order)."""
+    N.need_cuda(indices)
+    assert indices.dtype == torch.int32 and indices.is_contiguous() and indices.shape[1] == 4
+    V = indices.shape[0]
+    dev = indices.device
+    nw = grid_words(batch, S)
+    mask = torch.empty(nw, dtype=torch.int32, device=dev)
+    wprefix = torch.empty(nw + 1, dtype=torch.int32, device=dev)
+    perm = torch.empty(max(V, 1), dtype=torch.int32, device=dev)
+    N.check(N.lib().dcl_grid_from_indices(N.ptr(indices), V, batch, S, N.ptr(mask), N.ptr(wprefix), N.ptr(perm),
+                                          N.ptr(scan_scratch(nw, dev)), N.stream()), "grid_from_indices")
+    return ActiveSet(indices, V, None, V, mask, wprefix, perm, S, batch)
+
+
+def conv_out_size(S, k, s, p):
+    return (S + 2 * p - (k - 1) - 1) // s + 1
+
+
+def conv_out_grid(inp, ksize, stride, padding, cap=None):
+    """Output active set of a non-submanifold conv/pool over `inp` (count stays on the device)."""
+    S_out = conv_out_size(inp.S, ksize, stride, padding)
+    dev = inp.indices.device
+    bound = inp.batch * S_out ** 3
+    if cap is None:
+        cap = min(inp.cap * ksize ** 3, bound)
+    cap = max(int(cap), 1)
+    nw = grid_words(inp.batch, S_out)
+    mask = torch.empty(nw, dtype=torch.int32, device=dev)
+    wprefix = torch.empty(nw + 1, dtype=torch.int32, device=dev)
+    out_idx = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+    n_in_dev = inp.n_dev if inp.n is None else None
+    n_in_host = inp.cap if inp.n is None else inp.n
+    N.check(N.lib().dcl_conv_out_grid(N.ptr(inp.indices), _i32_ptr_or_null(n_in_dev), int(n_in_host), inp.batch,
+                                      inp.S, ksize, stride, padding, N.ptr(mask), N.ptr(wprefix), N.ptr(out_idx),
+                                      N.ptr(wprefix[nw:]), cap, N.ptr(scan_scratch(nw, dev)), N.stream()),
+            "conv_out_grid")
+    return ActiveSet(out_idx, None, wprefix[nw:], cap, mask, wprefix, None, S_out, inp.batch)
+
+
+def rulebook_gather(out, inp, ksize, stride, padding):
+    """Gather-form rulebook nbr i32 (kvol, rows(out)) of `out` rows against the `inp` set."""
+    dev = out.indices.device
+    rows = out.cap if out.n is None else out.n
+    rows_alloc = max(rows, 1)
+    nbr = torch.empty((ksize ** 3, rows_alloc), dtype=torch.int32, device=dev)
+    n_dev = out.n_dev if out.n is None else None
+    N.check(N.lib().dcl_rulebook_gather(N.ptr(out.indices), _i32_ptr_or_null(n_dev), int(rows if out.n is not None else 0),
+                                        N.ptr(inp.mask), N.ptr(inp.wprefix), _i32_ptr_or_null(inp.perm), inp.batch,
+                                        inp.S, ksize, stride, padding, N.ptr(nbr), rows_alloc, N.stream()),
+            "rulebook_gather")
+    return nbr
+
+
+def rulebook_to_pairs(nbr, n_out, n_in):
+    """Reference-format rulebook: indice_pairs i32 (kvol,2,n_in) (-1 padded), indice_num i32 (kvol)."""
+    kvol, cap = nbr.shape
+    pairs = torch.empty((kvol, 2, max(n_in, 1)), dtype=torch.int32, device=nbr.device)
+    num = torch.empty(kvol, dtype=torch.int32, device=nbr.device)
+    N.check(N.lib().dcl_rulebook_to_pairs(N.ptr(nbr), cap, N.vp(0), int(n_out), kvol, N.ptr(pairs), int(n_in),
+                                          N.ptr(num), N.stream()), "rulebook_to_pairs")
+    return pairs[:, :, :n_in], num
+
+
+def sparse_conv(feat, nbr, n_out, W, subm, scale=None, shift=None, relu=False):
+    """indice_conv_fp32 (+ folded BatchNorm1d(eval) + ReLU).  feat (V_in,Cin); W (kvol,Cin,Cout)."""
+    N.need_cuda(feat, nbr, W)
+    kvol, cap = nbr.shape
+    cin, cout = W.shape[-2], W.shape[-1]
+    assert feat.is_contiguous() and W.is_contiguous() and feat.shape[1] == cin
+    out = torch.empty((n_out, cout), dtype=torch.float32, device=feat.device)
+    if n_out == 0:
+        return out
+    N.check(N.lib().dcl_sparse_conv_fwd(N.ptr(feat), N.ptr(nbr), cap, N.vp(0), int(n_out), N.ptr(W), cin, cout, kvol,
+                                        int(bool(subm)), N.ptr(scale), N.ptr(shift), int(bool(relu)), N.ptr(out),
+                                        N.stream()), "sparse_conv_fwd")
+    return out
+
+
+def sparse_avgpool(feat, nbr, n_out, want_rf=False):
+    """indiceSummaryRF + indice_avgpool_fp32 (use_gs=False)."""
+    N.need_cuda(feat, nbr)
+    kvol, cap = nbr.shape
+    c = feat.shape[1]
+    out = torch.empty((n_out, c), dtype=torch.float32, device=feat.device)
+    rf = torch.empty(max(n_out, 1), dtype=torch.int32, device=feat.device) if want_rf else None
+    if n_out:
+        N.check(N.lib().dcl_sparse_avgpool_fwd(N.ptr(feat), N.ptr(nbr), cap, N.vp(0), int(n_out), c, kvol, N.ptr(out),
+                                               N.ptr(rf), N.stream()), "sparse_avgpool_fwd")
+    return (out, rf[:n_out]) if want_rf else out
+
+
+# ------------------------------------------------------------------------------------ pointnet_sp
+def three_nn_sp(unknown, known, known_seg=None):
+    """pointnet2_cuda.three_nn_wrapper of libs/pointnet_sp: returns (dist2 (N,3), idx (N,3) i32)."""
+    N.need_cuda(unknown, known)
+    assert unknown.is_contiguous() and known.is_contiguous()
+    assert unknown.shape[1] == 4 and known.shape[1] == 4
+    n, m = unknown.shape[0], known.shape[0]
+    dist2 = torch.empty((n, 3), dtype=torch.float32, device=unknown.device)
+    idx = torch.empty((n, 3), dtype=torch.int32, device=unknown.device)
+    nb = 0 if known_seg is None else known_seg.numel() - 1
+    N.check(N.lib().dcl_three_nn_sp(n, m, N.ptr(unknown), N.ptr(known), N.ptr(dist2), N.ptr(idx),
+                                    _i32_ptr_or_null(known_seg), nb, N.stream()), "three_nn_sp")
+    return dist2, idx
+
+
+def three_interpolate_sp(features, idx, weight, out=None, from_dist2=False):
+    """three_interpolate_wrapper of libs/pointnet_sp: features (M,C), idx (n,3), weight (n,3) -> (n,C).
+    `out` may be a column block of a wider row-major buffer (its row stride is honoured);
+    from_dist2=True treats `weight` as three_nn's dist2 and forms the weights in-kernel."""
+    N.need_cuda(features, idx, weight)
+    assert features.is_contiguous() and idx.is_contiguous() and weight.is_contiguous()
+    m, c = features.shape
+    n = idx.shape[0]
+    if out is None:
+        out = torch.empty((n, c), dtype=torch.float32, device=features.device)
+    assert out.shape == (n, c) and out.stride(1) == 1
+    fn = N.lib().dcl_three_interpolate_dist2_sp if from_dist2 else N.lib().dcl_three_interpolate_sp
+    N.check(fn(c, m, n, N.ptr(features), N.ptr(idx), N.ptr(weight), N.ptr(out), out.stride(0) if n > 1 else c,
+               N.stream()), "three_interpolate_sp")
+    return out
+
+
+def voxel_centres(aset_or_indices, ve, off, n=None):
+    """Ops_tensor2points (models/Modules.py:204-211) on device."""
+    ind = aset_or_indices
+    n = ind.shape[0] if n is None else n
+    out = torch.empty((max(n, 1), 4), dtype=torch.float32, device=ind.device)
+    N.check(N.lib().dcl_voxel_centres(N.ptr(ind), N.vp(0), int(n), _c_float(ve), _c_float(off), N.ptr(out), N.stream()),
+            "voxel_centres")
+    return out[:n]
+
+
+# ------------------------------------------------------------------------------------ pointnet_lib
+def ball_query(radius, nsample, xyz, new_xyz):
+    N.need_cuda(xyz, new_xyz)
+    assert xyz.is_contiguous() and new_xyz.is_contiguous()
+    B, n, _ = xyz.shape
+    m = new_xyz.shape[1]
+    idx = torch.empty((B, m, nsample), dtype=torch.int32, device=xyz.device)
+    N.check(N.lib().dcl_ball_query(B, n, m, _c_float(radius), int(nsample), N.ptr(new_xyz), N.ptr(xyz), N.ptr(idx),
+                                   N.stream()), "ball_query")
+    return idx
+
+
+def group_points(features, idx):
+    N.need_cuda(features, idx)
+    assert features.is_contiguous() and idx.is_contiguous() and idx.dtype == torch.int32
+    B, c, n = features.shape
+    _, npoint, ns = idx.shape
+    out = torch.empty((B, c, npoint, ns), dtype=torch.float32, device=features.device)
+    N.check(N.lib().dcl_group_points(B, c, n, npoint, ns, N.ptr(features), N.ptr(idx), N.ptr(out), N.stream()),
+            "group_points")
+    return out
+
+
+def gather_points(features, idx):
+    N.need_cuda(features, idx)
+    assert features.is_contiguous() and idx.is_contiguous() and idx.dtype == torch.int32
+    B, c, n = features.shape
+    m = idx.shape[1]
+    out = torch.empty((B, c, m), dtype=torch.float32, device=features.device)
+    N.check(N.lib().dcl_gather_points(B, c, n, m, N.ptr(features), N.ptr(idx), N.ptr(out), N.stream()), "gather_points")
+    return out
+
+
+def furthest_point_sampling(xyz, npoint):
+    N.need_cuda(xyz)
+    assert xyz.is_contiguous()
+    B, n, _ = xyz.shape
+    temp = torch.full((B, n), 1e10, dtype=torch.float32, device=xyz.device)
+    idx = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
+    N.check(N.lib().dcl_furthest_point_sampling(B, n, int(npoint), N.ptr(xyz), N.ptr(temp), N.ptr(idx), N.stream()),
+            "furthest_point_sampling")
+    return idx
+
+
+def knn(k, unknown, known):
+    N.need_cuda(unknown, known)
+    assert unknown.is_contiguous() and known.is_contiguous()
+    B, n, _ = unknown.shape
+    m = known.shape[1]
+    dist2 = torch.empty((B, n, k), dtype=torch.float32, device=unknown.device)
+    idx = torch.empty((B, n, k), dtype=torch.int32, device=unknown.device)
+    N.check(N.lib().dcl_knn(B, n, m, int(k), N.ptr(unknown), N.ptr(known), N.ptr(dist2), N.ptr(idx), N.stream()), "knn")
+    return dist2, idx
+
+
+def three_nn(unknown, known):
+    N.need_cuda(unknown, known)
+    assert unknown.is_contiguous() and known.is_contiguous()
+    B, n, _ = unknown.shape
+    m = known.shape[1]
+    dist2 = torch.empty((B, n, 3), dtype=torch.float32, device=unknown.device)
+    idx = torch.empty((B, n, 3), dtype=torch.int32, device=unknown.device)
+    N.check(N.lib().dcl_three_nn(B, n, m, N.ptr(unknown), N.ptr(known), N.ptr(dist2), N.ptr(idx), N.stream()),
+            "three_nn")
+    return dist2, idx
+
+
+def three_interpolate(features, idx, weight):
+    N.need_cuda(features, idx, weight)
+    assert features.is_contiguous() and idx.is_contiguous() and weight.is_contiguous()
+    B, c, m = features.shape
+    n = idx.shape[1]
+    out = torch.empty((B, c, n), dtype=torch.float32, device=features.device)
+    N.check(N.lib().dcl_three_interpolate(B, c, m, n, N.ptr(features), N.ptr(idx), N.ptr(weight), N.ptr(out),
+                                          N.stream()), "three_interpolate")
+    return out
+
+
+# ------------------------------------------------------------------------------------ dense path
+def _ld(t):
+    assert t.dim() == 2 and t.stride(1) == 1
+    return t.stride(0) if t.shape[0] > 1 else t.shape[1]
+
+
+def cross_attention(b, Q, K, V1, O1, V2=None, O2=None):
+    """One direction of the correspondence attention on POINT-major 2-D operands (row = point):
+    Q (b*nq, 64), K (b*nk, 64), V1 (b*nk, dv1) -> O1 (b*nq, dv1) [, V2 -> O2].  Operands may be
+    column blocks of wider buffers (row stride honoured)."""
+    N.need_cuda(Q, K, V1, O1, V2, O2)
+    nq, nk = Q.shape[0] // b, K.shape[0] // b
+    assert Q.shape[1] == 64 and K.shape[1] == 64 and V1.shape[0] == K.shape[0] and O1.shape[0] == Q.shape[0]
+    dv1 = V1.shape[1]
+    dv2 = 0 if V2 is None else V2.shape[1]
+    N.check(N.lib().dcl_cross_attention(b, nq, nk, N.ptr(Q), _ld(Q), N.ptr(K), _ld(K), N.ptr(V1), dv1, _ld(V1),
+                                        N.ptr(O1), _ld(O1), N.ptr(V2), dv2, 0 if V2 is None else _ld(V2), N.ptr(O2),
+                                        0 if O2 is None else _ld(O2), N.stream()), "cross_attention")
+    return O1, O2
+
+
+def conf_pool(b, logit1, logit2, F1, F2):
+    """Confidence pooling: logits (b*n1,)/(b*n2,), F1 (b*n1,C), F2 (b*n2,C) point-major ->
+    conf (b,n1+n2), pooled1 (b,C), pooled2 (b,C), wsum (b,2)."""
+    N.need_cuda(logit1, logit2, F1, F2)
+    n1, n2 = F1.shape[0] // b, F2.shape[0] // b
+    c = F1.shape[1]
+    assert logit1.is_contiguous() and logit2.is_contiguous() and logit1.numel() == b * n1 and logit2.numel() == b * n2
+    dev = F1.device
+    conf = torch.empty((b, n1 + n2), dtype=torch.float32, device=dev)
+    p1 = torch.empty((b, c), dtype=torch.float32, device=dev)
+    p2 = torch.empty((b, c), dtype=torch.float32, device=dev)
+    ws = torch.empty((b, 2), dtype=torch.float32, device=dev)
+    N.check(N.lib().dcl_conf_pool(b, c, n1, n2, N.ptr(logit1), N.ptr(logit2), N.ptr(F1), _ld(F1), N.ptr(F2), _ld(F2),
+                                  N.ptr(conf), N.ptr(p1), N.ptr(p2), N.ptr(ws), N.stream()), "conf_pool")
+    return conf, p1, p2, ws
+
+
+def ortho9d_to_matrix(o9):
+    """ortho9d2matrix (models/DCL_Net.py:15-36): (b,9) -> (b,3,3)."""
+    N.need_cuda(o9)
+    o9 = o9.contiguous()
+    b = o9.shape[0]
+    R = torch.empty((b, 3, 3), dtype=torch.float32, device=o9.device)
+    N.check(N.lib().dcl_ortho9d_to_matrix(b, N.ptr(o9), N.ptr(R), N.stream()), "ortho9d_to_matrix")
+    return R

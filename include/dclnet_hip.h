@@ -1,0 +1,209 @@
+/*
+ * dclnet_hip.h -- C ABI of libdclnet_hip.so: the MI355X (gfx950) kernels of
+ * DCL-Net's per-crop RGB-D -> 6-DoF pose forward.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); every
+ *     call only enqueues work on it -- no allocation, no synchronisation, no
+ *     host read-back (graph-capture safe) unless stated;
+ *   - return value: 0 on success, otherwise a hipError_t (>0) or
+ *     DCL_EINVAL (-1) for bad arguments; dcl_last_error() gives the text.
+ *     (The reference's launchers print to stderr and exit(-1), e.g.
+ *     libs/pointnet_lib/src/ball_query_gpu.cu:62-66; a library must not.)
+ *   - layouts are the reference's: row-major fp32 / int32.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative
+ * to the upstream repository).  INTEGRATION.md shows the binding a maintainer
+ * would add on the reference side.
+ */
+#ifndef DCLNET_HIP_H_
+#define DCLNET_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCL_EINVAL (-1)
+typedef void *dclStream_t;
+
+const char *dcl_last_error(void);
+int dcl_abi_version(void);
+
+/* ------------------------------------------------------------------ PG_OP ---
+ * voxelize_idx: libs/pointgroup_ops/src/pointgroup_ops_api.cpp:6 ->
+ * src/voxelize/voxelize.cpp:10-152.  HOST function (the reference runs it in
+ * DataLoader workers, YCBV/dataloader_test_YCBV.py:217,223).  Two calls, like
+ * the reference's resize-in-place protocol split in two: _count fills
+ * input_map and returns sizes, _fill writes the caller-allocated (zeroed)
+ * outputs.  mode 3 (sum) / 4 (mean) only.                                      */
+int dcl_voxelize_idx_count(const int64_t *coords_host, int n, int ncol, int batch_size, int mode,
+                           int32_t *input_map_host, int32_t *n_active_host, int32_t *max_active_host);
+int dcl_voxelize_idx_fill(const int64_t *coords_host, int n, int ncol, const int32_t *input_map_host,
+                          int n_active, int max_active, int64_t *output_coords_host,
+                          int32_t *output_map_host);
+
+/* voxelize_fp: pointgroup_ops_api.cpp:8 -> src/voxelize/voxelize.cu:9-31.
+ * feats (N,C), rules (V,1+maxActive) -> out (V,C); out need not be zeroed.     */
+int dcl_voxelize_fp(const float *feats, const int32_t *rules, float *out, int n_rows, int max_active,
+                    int n_planes, int average, dclStream_t stream);
+
+/* --------------------------------------------------------------- spconv ----
+ * Replaces torch.ops.spconv.get_indice_pairs_3d / indice_conv_fp32 /
+ * indiceSummaryRF / indice_avgpool_fp32 (libs/spconv/src/spconv/all.cc:19-42;
+ * include/spconv/spconv_ops.h:27-137,253-349; pool_ops.h:141-208).
+ *
+ * An active set on a batch x S^3 grid is described on the device by
+ *   mask    u32[batch*S^3/32]   occupancy bits, linear index ((b*S+x)*S+y)*S+z
+ *   wprefix i32[batch*S^3/32+1] exclusive popcount prefix (last = #active)
+ *   perm    i32[V] or NULL      rank (ascending linear index) -> feature row;
+ *                               NULL = rows already in ascending order
+ * Output voxels of conv/pool are numbered in ascending linear index, the
+ * order the reference's GPU path produces (torch::_unique, spconv_ops.h:126).
+ * The rulebook is kept in gather form: nbr[k*cap + o] = input row feeding
+ * output row o through kernel offset k (or -1); k = kz + 3*ky + 9*kx as in
+ * geometry.h:61-70.  All counts stay on the device.                            */
+
+/* scratch: i32[(nwords+1023)/1024 + 1].  Builds mask/wprefix/perm from an explicit voxel list
+ * (rows in any order, e.g. voxelize_idx's first-encounter order).              */
+int dcl_grid_from_indices(const int32_t *indices, int n_rows, int batch, int S, uint32_t *mask,
+                          int32_t *wprefix, int32_t *perm, int32_t *scratch, dclStream_t stream);
+
+/* Step 1 of a non-submanifold conv / pool rulebook: the OUTPUT active set only
+ * (prepareIndicePairsKernel + torch::_unique + assignGridAndIndiceOutKernel, indice.cu.h:24-65,
+ * 112-128): out mask/wprefix on the S_out grid, out_indices (cap_out,4) in ascending linear
+ * index, n_out_dev[0].  n_in is *n_in_dev if non-NULL (n_in_host then only bounds the launch).
+ * scratch as above, sized for the S_out grid.                                   */
+int dcl_conv_out_grid(const int32_t *in_indices, const int32_t *n_in_dev, int n_in_host, int batch,
+                      int S_in, int ksize, int stride, int padding, uint32_t *out_mask,
+                      int32_t *out_wprefix, int32_t *out_indices, int32_t *n_out_dev, int cap_out,
+                      int32_t *scratch, dclStream_t stream);
+
+/* Step 2: the gather-form rulebook nbr i32[kvol*cap] of output rows `out_indices` against the
+ * input set (in_mask, in_wprefix, in_perm) on the S_in grid: the input feeding output o through
+ * offset k sits at o*stride - padding + k.  Submanifold conv = out set == in set, stride 1,
+ * padding ksize/2.                                                              */
+int dcl_rulebook_gather(const int32_t *out_indices, const int32_t *n_out_dev, int n_out_host,
+                        const uint32_t *in_mask, const int32_t *in_wprefix, const int32_t *in_perm,
+                        int batch, int S_in, int ksize, int stride, int padding, int32_t *nbr, int cap,
+                        dclStream_t stream);
+
+/* Non-submanifold conv / pool rulebook (ksize^3 offsets, stride, padding, dilation 1):
+ * in_indices (n_in rows; n_in read from n_in_dev if non-NULL else n_in_host) ->
+ * out mask/wprefix on the S_out grid, out_indices (cap_out,4), n_out_dev[0],
+ * nbr i32[27*cap_out].  Rows beyond n_out are untouched.                      */
+int dcl_rulebook_conv(const int32_t *in_indices, const int32_t *n_in_dev, int n_in_host,
+                      const uint32_t *in_mask, const int32_t *in_wprefix, const int32_t *in_perm,
+                      int batch, int S_in, int ksize, int stride, int padding,
+                      uint32_t *out_mask, int32_t *out_wprefix, int32_t *out_indices,
+                      int32_t *n_out_dev, int32_t *nbr, int cap_out, int32_t *scratch,
+                      dclStream_t stream);
+
+/* Submanifold rulebook: out set = in set (same rows).  nbr i32[27*cap].        */
+int dcl_rulebook_subm(const int32_t *indices, const int32_t *n_dev, int n_host,
+                      const uint32_t *mask, const int32_t *wprefix, const int32_t *perm,
+                      int batch, int S, int ksize, int32_t *nbr, int cap, dclStream_t stream);
+
+/* Export a gather-form rulebook in the reference's format: indice_pairs
+ * i32[27][2][n_in_cap] (-1 padded) + indice_num i32[27] (spconv_ops.h:55-60).
+ * Pair order inside an offset is unspecified, as in the reference.             */
+int dcl_rulebook_to_pairs(const int32_t *nbr, int cap, const int32_t *n_out_dev, int n_out_host,
+                          int kvol, int32_t *indice_pairs, int n_in_cap, int32_t *indice_num,
+                          dclStream_t stream);
+
+/* indice_conv_fp32 (+ the BatchNorm1d(eval)+ReLU that SparseSequential applies next,
+ * models/Modules.py:36-40): out[o] = act( (sum_k feat[nbr[k][o]] * W[k]) * scale + shift ).
+ * W (27,Cin,Cout); scale/shift (Cout) or NULL; subm != 0 accumulates the centre offset
+ * first (spconv_ops.h:289-299).                                                */
+int dcl_sparse_conv_fwd(const float *feat, const int32_t *nbr, int cap, const int32_t *n_out_dev,
+                        int n_out_host, const float *W, int cin, int cout, int kvol, int subm,
+                        const float *scale, const float *shift, int relu, float *out,
+                        dclStream_t stream);
+
+/* indiceSummaryRF + indice_avgpool_fp32 (use_gs=False): rf[o] = #valid offsets,
+ * out[o] = sum_k asc feat[nbr[k][o]] / (float)rf[o].  rf may be NULL.          */
+int dcl_sparse_avgpool_fwd(const float *feat, const int32_t *nbr, int cap, const int32_t *n_out_dev,
+                           int n_out_host, int c, int kvol, float *out, int32_t *rf,
+                           dclStream_t stream);
+
+/* ----------------------------------------------------------- pointnet_sp ---
+ * three_nn_wrapper(n, m, unknown(N,4), known(M,4), dist2(N,3), idx(N,3)):
+ * libs/pointnet_sp/src/pointnet2_api.cpp:7 -> interpolate_gpu.cu:9-77.
+ * known_seg (i32[nbatch+1], optional): known rows of batch b are exactly
+ * [known_seg[b], known_seg[b+1]) -- lets a query scan only its own crop; NULL
+ * scans all m rows comparing the batch column like the reference.              */
+int dcl_three_nn_sp(int n, int m, const float *unknown, const float *known, float *dist2,
+                    int32_t *idx, const int32_t *known_seg, int nbatch, dclStream_t stream);
+
+/* three_interpolate_wrapper(c, m, n, points(M,C), idx, weight, out(N,C)):
+ * pointnet2_api.cpp:8 -> interpolate_gpu.cu:80-122.  out_stride (>= c, in floats) lets the
+ * caller write straight into a column block of the 480-channel concat.         */
+int dcl_three_interpolate_sp(int c, int m, int n, const float *points, const int32_t *idx,
+                             const float *weight, float *out, int out_stride, dclStream_t stream);
+
+/* three_interpolate with the weights of Ops_nearest_neighbor_interpolate computed in-kernel
+ * (models/Modules.py:221-224: dist = sqrt(dist2); w = (1/(dist+1e-8)) / sum) -- takes the dist2
+ * that dcl_three_nn_sp returns.                                                */
+int dcl_three_interpolate_dist2_sp(int c, int m, int n, const float *points, const int32_t *idx,
+                                   const float *dist2, float *out, int out_stride,
+                                   dclStream_t stream);
+
+/* Ops_tensor2points (models/Modules.py:204-211): voxel rows (V,4) i32 [b,x,y,z] -> centres (V,4)
+ * f32 [b, x*ve+off+0.5*ve, ...] (fp32, left to right).  n from n_dev if non-NULL (n_host = bound). */
+int dcl_voxel_centres(const int32_t *indices, const int32_t *n_dev, int n_host, float ve, float off,
+                      float *centres, dclStream_t stream);
+
+/* ---------------------------------------------------------- pointnet_lib ---
+ * libs/pointnet_lib/src/pointnet2_api.cpp:10-25.  Same argument order.         */
+int dcl_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                   const float *xyz, int32_t *idx, dclStream_t stream);       /* idx fully written */
+int dcl_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
+                     const int32_t *idx, float *out, dclStream_t stream);
+int dcl_gather_points(int b, int c, int n, int npoints, const float *points, const int32_t *idx,
+                      float *out, dclStream_t stream);
+/* temp (B,N) must be pre-filled with 1e10 (pointnet2_utils.py:27); updated in place. */
+int dcl_furthest_point_sampling(int b, int n, int m, const float *dataset, float *temp,
+                                int32_t *idxs, dclStream_t stream);
+int dcl_knn(int b, int n, int m, int k, const float *unknown, const float *known, float *dist2,
+            int32_t *idx, dclStream_t stream);                                 /* k <= 200 */
+int dcl_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2,
+                 int32_t *idx, dclStream_t stream);
+int dcl_three_interpolate(int b, int c, int m, int n, const float *points, const int32_t *idx,
+                          const float *weight, float *out, dclStream_t stream);
+
+/* ------------------------------------------------------------ dense path ---
+ * All dense operands are POINT-major: X[(b*n + p)*ld + c] (row = point, ld = row stride in
+ * floats).  That is the layout the 3-NN interpolation emits and 2-D GEMMs consume; the
+ * reference's (b,C,n) tensors are transposed views of it.
+ *
+ * Cross-attention of Aligner.forward + the extra bmm (models/Modules.py:162-169;
+ * models/DCL_Net.py:206-215), one direction per call, without materialising A:
+ *   S[j,i] = <K[j,:], Q[i,:]> over 64 channels, A = softmax over the KEY axis j,
+ *   O1[i,:] = sum_j A[j,i] V1[j,:]  (dv1 ch),  O2 likewise from V2 (dv2 ch; may be NULL/0)
+ * Q (b*nq rows), K, V1, V2 (b*nk rows), O1, O2 (b*nq rows).  fp32 MFMA, online softmax.
+ * dv1, dv2 multiples of 32 with (dv1+dv2)/32 in {1,2,4,8,10}; all ld % 4 == 0, 16-B aligned.   */
+int dcl_cross_attention(int b, int nq, int nk, const float *Q, int ldq, const float *K, int ldk,
+                        const float *V1, int dv1, int ldv1, float *O1, int ldo1, const float *V2,
+                        int dv2, int ldv2, float *O2, int ldo2, dclStream_t stream);
+
+/* Confidence pooling (models/DCL_Net.py:217-228): conf = sigmoid(cat[logit1 (b,n1), logit2
+ * (b,n2)]) -> conf (b,n1+n2); w = softmax(conf);
+ * pooled1 (b,C) = sum_{j<n1} w[j] F1[b,j,:], pooled2 (b,C) = sum_{j<n2} w[n1+j] F2[b,j,:],
+ * wsum (b,2) = the two partial sums of w.  (pooled of the reference = pooled1 + pooled2 when
+ * F1/F2 already carry their trailing BatchNorm; else s1*pooled1 + t1*wsum1 + s2*pooled2 + t2*wsum2.) */
+int dcl_conf_pool(int b, int c, int n1, int n2, const float *logit1, const float *logit2,
+                  const float *F1, int ld1, const float *F2, int ld2, float *conf, float *pooled1,
+                  float *pooled2, float *wsum, dclStream_t stream);
+
+/* ortho9d2matrix (models/DCL_Net.py:15-36): o9 (b,9) -> R (b,3,3).             */
+int dcl_ortho9d_to_matrix(int b, const float *o9, float *R, dclStream_t stream);
+
+/* Test hook: route every dcl_sparse_conv_fwd through the plain VALU kernel (A/B check of the MFMA one). */
+void dcl_debug_force_valu_conv(int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCLNET_HIP_H_ */

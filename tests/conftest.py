@@ -1,0 +1,46 @@
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def dcl():
+    """the product package (its directory name has a hyphen)"""
+    return importlib.import_module("dcl-net_amd")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import native
+    native.build()
+    return native
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return os.path.join(ROOT, "tests", "golden")
+
+
+def load_golden_data(path):
+    """tests/golden/dclnet_*.npz -> (loader-style data dict of torch CPU tensors, expected outputs, meta)"""
+    import torch
+    z = np.load(path)
+    b, n_inp, n_tmp, wseed = [int(v) for v in z["meta"]]
+    data = {"labels": {}, "batch_offsets": (torch.arange(b + 1) * n_inp).int(),
+            "voxel_num_limit": torch.tensor([64, 64, 64]), "flags": torch.IntTensor([-1])}
+    for side in ("inp", "tmp"):
+        data[side] = {k: torch.from_numpy(z["%s_%s" % (side, k)]) for k in
+                      ("feats", "occupied_voxels", "p2v_maps", "v2p_maps")}
+    exp = {k: z[k] for k in ("trans_pred", "rot_pred", "conf", "F_Xo_p_sub", "F_Xo_p_sum")}
+    return data, exp, (b, n_inp, n_tmp, wseed)

@@ -1,0 +1,61 @@
+"""The oracle's graph restatement (oracle/graph.py) against vectors produced by the REFERENCE's own
+models/*.py (tests/golden/make_golden.py, run in the build container)."""
+import os
+
+import numpy as np
+import torch
+
+from conftest import load_golden_data
+from oracle import graph as G
+
+
+def _state(dcl, cfg, seed, cls):
+    net = cls(cfg, mode="test") if cfg is not None else cls()
+    return dcl.synth.synth_state_dict(net, seed)
+
+
+def test_forward_matches_reference_graph(dcl, oracle, golden_dir):
+    data, exp, (b, n_inp, n_tmp, wseed) = load_golden_data(os.path.join(golden_dir, "dclnet_b2_n256.npz"))
+    cfg = dcl.synth.default_cfg(n_inp, n_tmp)
+    sd = _state(dcl, cfg, wseed, dcl.DCL_Net.Network)
+    pred = G.forward(sd, dict(cfg), data, mode="test")
+    # same natives, same torch build: the two graphs differ only in dense-op call shapes (conv3d vs conv1d)
+    assert np.abs(pred["rot_pred"].numpy() - exp["rot_pred"]).max() <= 1e-4
+    assert np.abs(pred["trans_pred"].numpy() - exp["trans_pred"]).max() <= 1e-5
+    assert np.abs(pred["conf"].numpy() - exp["conf"]).max() <= 1e-5
+    ref_sub = exp["F_Xo_p_sub"]
+    got_sub = pred["F_Xo_p"][:, ::8, ::8].numpy()
+    assert np.abs(got_sub - ref_sub).max() <= 1e-4 * max(1.0, np.abs(ref_sub).max())
+    assert data["labels"]["points_inp"].shape == (b, n_inp, 3) and data["labels"]["points_tmp"].shape == (b, n_tmp, 3)
+
+
+def test_synth_inputs_are_reproducible(dcl, oracle, golden_dir):
+    """the procedural crops regenerate bit-identically (fixture inputs == synth.make_batch)."""
+    data, _, (b, n_inp, n_tmp, _) = load_golden_data(os.path.join(golden_dir, "dclnet_b2_n256.npz"))
+    again = dcl.synth.make_batch(b, n_inp, n_tmp, voxelize_idx=lambda c, bs, mode: tuple(
+        torch.from_numpy(a) for a in oracle.voxelize_idx(c.numpy(), bs, mode)))
+    for side in ("inp", "tmp"):
+        for k in ("feats", "occupied_voxels", "p2v_maps", "v2p_maps"):
+            assert torch.equal(again[side][k], data[side][k]), (side, k)
+
+
+def test_refiner_matches_reference(dcl, golden_dir):
+    z = np.load(os.path.join(golden_dir, "refiner_b2.npz"))
+    sd = _state(dcl, None, 2, dcl.refiner.Refiner)
+    g = torch.Generator().manual_seed(int(z["gen_seed"][0]))
+    bb, n = 2, 1024
+    F = torch.randn(bb, 256, n, generator=g)
+    pts = torch.randn(bb, n, 3, generator=g) * 0.05
+    conf = torch.rand(bb, 2 * n, generator=g)
+    o9 = torch.randn(bb, 9, generator=g)
+    assert np.allclose(o9.numpy(), z["o9"])
+    rot0 = G.ortho9d2matrix(o9[:, :3], o9[:, 3:6], o9[:, 6:])
+    assert np.abs(rot0.numpy() - z["rot0"]).max() <= 1e-6
+    trans0 = torch.from_numpy(z["trans0"])
+    cur = torch.bmm(pts - trans0.unsqueeze(1), rot0)
+    first = G.refiner_forward(sd, torch.cat([cur.transpose(1, 2), F], 1), conf)
+    assert np.abs(first["trans_pred"].numpy() - z["dt_first"]).max() <= 1e-5
+    assert np.abs(first["rot_pred"].numpy() - z["dR_first"]).max() <= 1e-4
+    rot, trans = G.refine_loop(sd, {"rot_pred": rot0, "trans_pred": trans0, "F_Xo_p": F, "conf": conf}, pts, 2)
+    assert np.abs(rot.numpy() - z["rot_final"]).max() <= 1e-4
+    assert np.abs(trans.numpy() - z["trans_final"]).max() <= 1e-5
