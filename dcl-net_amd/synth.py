@@ -151,6 +151,8 @@ def synth_state_dict(model, seed=1):
             v = rng.normal(0, np.sqrt(2.0 / (9 * shape[3])), shape)
         else:                                                          # (Cout, Cin, 1[,1,1])
             v = rng.normal(0, np.sqrt(2.0 / shape[1]), shape)
+        if name.startswith(("regressor_trans.layers.4", "regressor_trans2.layers.4")):
+            v = v * 0.02          # keep translations at the centimetre scale of real crops (tolerances are in metres)
         sd[name] = torch.from_numpy(np.asarray(v)).to(ref.dtype)
     return sd
 

@@ -1,0 +1,137 @@
+"""End-to-end GPU parity of Network.forward / Refiner against the reference-generated golden vectors and
+against the CPU oracle graph on fresh seeded crops.  Tolerances are BASELINE.json's: |dR| <= 1e-4,
+|dt| <= 1e-5 m; integer outputs (voxel ids) bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden_data
+
+pytestmark = pytest.mark.gpu
+
+R_TOL, T_TOL = 1e-4, 1e-5
+
+
+def _net(dcl, n_inp, n_tmp, seed, fused=True):
+    cfg = dcl.synth.default_cfg(n_inp, n_tmp)
+    net = dcl.DCL_Net.Network(cfg, mode="test", fused=fused)
+    sd = dcl.synth.synth_state_dict(net, seed)
+    net.load_state_dict(sd)
+    return net.cuda().eval(), sd, cfg
+
+
+def _check(pred, exp_R, exp_t, exp_conf):
+    assert np.abs(pred["rot_pred"].cpu().numpy() - exp_R).max() <= R_TOL
+    assert np.abs(pred["trans_pred"].cpu().numpy() - exp_t).max() <= T_TOL
+    assert np.abs(pred["conf"].cpu().numpy() - exp_conf).max() <= 1e-4
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_forward_matches_reference_golden(dcl, golden_dir, fused):
+    data, exp, (b, n_inp, n_tmp, wseed) = load_golden_data(os.path.join(golden_dir, "dclnet_b2_n256.npz"))
+    net, _, _ = _net(dcl, n_inp, n_tmp, wseed, fused)
+    with torch.no_grad():
+        pred = net(data)
+    _check(pred, exp["rot_pred"], exp["trans_pred"], exp["conf"])
+    F = pred["F_Xo_p"]
+    assert tuple(F.shape) == (b, 256, n_inp)
+    sub = F[:, ::8, ::8].cpu().numpy()
+    assert np.abs(sub - exp["F_Xo_p_sub"]).max() <= 1e-4 * max(1.0, np.abs(exp["F_Xo_p_sub"]).max())
+    assert np.abs(F.double().sum(dim=2).cpu().numpy() - exp["F_Xo_p_sum"]).max() <= 1e-3 * max(
+        1.0, np.abs(exp["F_Xo_p_sum"]).max())
+    assert tuple(data["labels"]["points_inp"].shape) == (b, n_inp, 3)
+    assert tuple(data["labels"]["points_tmp"].shape) == (b, n_tmp, 3)
+
+
+@pytest.mark.parametrize("b,n_inp,n_tmp,unit", [(3, 1024, 1024, 0.006), (1, 2048, 500, 0.005), (5, 512, 1024, 0.006)])
+def test_forward_matches_oracle_graph(dcl, oracle, b, n_inp, n_tmp, unit):
+    """fresh crops at the reference shape (N=M=1024), the plumbing shape S0 (N=2048, M=500, 5 mm) and a ragged one"""
+    from oracle import graph as G
+    cfg = dcl.synth.default_cfg(n_inp, n_tmp, unit)
+    net = dcl.DCL_Net.Network(cfg, mode="test")
+    sd = dcl.synth.synth_state_dict(net, 3)
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    data = dcl.synth.make_batch(b, n_inp, n_tmp, unit=unit, first=40)
+    ref_data = {k: ({kk: vv.clone() for kk, vv in v.items()} if isinstance(v, dict) else v) for k, v in data.items()}
+    want = G.forward(sd, dict(cfg), ref_data, mode="test")
+    with torch.no_grad():
+        pred = net(data)
+    _check(pred, want["rot_pred"].numpy(), want["trans_pred"].numpy(), want["conf"].numpy())
+    got_F, want_F = pred["F_Xo_p"].cpu(), want["F_Xo_p"]
+    assert float((got_F - want_F).abs().max()) <= 1e-4 * max(1.0, float(want_F.abs().max()))
+
+
+def test_backbone_levels_and_indices_bit_exact(dcl, oracle):
+    """voxel ids of every pooled level are bit-exact; features within fp32 GEMM tolerance"""
+    from oracle import graph as G
+    b, n = 2, 1024
+    net, sd, cfg = _net(dcl, n, n, 4)
+    data = dcl.synth.make_batch(b, n, n, first=7)
+    occ = data["inp"]["occupied_voxels"].int()
+    vox = oracle.voxelize_fp(data["inp"]["feats"].numpy(), data["inp"]["v2p_maps"].numpy(), 4)
+    want = G.backbone(sd, "backbone_inp", vox, occ.numpy(), [64] * 3, b)
+    sets = net._geometry_a(occ.cuda().contiguous(), b, 64)
+    flat = [a for (_, c, p) in sets for a in (c, p)]
+    for a, cnt in zip(flat, torch.cat([a.n_dev for a in flat]).cpu().tolist()):
+        a.n, a.cap, a.indices = int(cnt), max(int(cnt), 1), a.indices[:int(cnt)]
+    books = net._geometry_b(sets)
+    x = dcl.ops.voxelize_fp(data["inp"]["feats"].cuda(), data["inp"]["v2p_maps"].cuda(), 4)
+    assert np.array_equal(x.cpu().numpy(), vox)
+    levels = net._backbone_feats(net._fold()["backbone_inp"], x, sets, books)
+    for (gx, gp), (wx, wi) in zip(levels, want):
+        assert np.array_equal(gp.indices.cpu().numpy(), wi)
+        assert np.abs(gx.cpu().numpy() - wx).max() <= 1e-4 * max(1.0, np.abs(wx).max())
+
+
+def test_refiner_matches_reference_golden(dcl, golden_dir):
+    z = np.load(os.path.join(golden_dir, "refiner_b2.npz"))
+    ref = dcl.refiner.Refiner()
+    ref.load_state_dict(dcl.synth.synth_state_dict(ref, 2))
+    ref = ref.cuda().eval()
+    g = torch.Generator().manual_seed(int(z["gen_seed"][0]))
+    bb, n = 2, 1024
+    F = torch.randn(bb, 256, n, generator=g).cuda()
+    pts = (torch.randn(bb, n, 3, generator=g) * 0.05).cuda()
+    conf = torch.rand(bb, 2 * n, generator=g).cuda()
+    rot0, trans0 = torch.from_numpy(z["rot0"]).cuda(), torch.from_numpy(z["trans0"]).cuda()
+    cur = torch.bmm(pts - trans0.unsqueeze(1), rot0)
+    out = ref({"input_features": torch.cat([cur.transpose(1, 2), F], 1), "conf": conf, "obj_idx": None})
+    assert np.abs(out["trans_pred"].cpu().numpy() - z["dt_first"]).max() <= T_TOL
+    assert np.abs(out["rot_pred"].cpu().numpy() - z["dR_first"]).max() <= R_TOL
+    pred = {"rot_pred": rot0, "trans_pred": trans0, "F_Xo_p": F, "conf": conf}
+    for graph in (False, True, True):                        # eager, capture, replay
+        rot, trans = dcl.refiner.refine_loop(ref, pred, pts, 2, graph=graph)
+        assert np.abs(rot.cpu().numpy() - z["rot_final"]).max() <= R_TOL
+        assert np.abs(trans.cpu().numpy() - z["trans_final"]).max() <= T_TOL
+
+
+def test_full_size_properties(dcl):
+    """BASELINE-size batch (b=32, N=M=1024): size-independent properties -- valid rotations, softmax-normalised
+    confidences, determinism, and batch-composition invariance (crop i's pose does not depend on its batch mates)."""
+    b, n = 32, 1024
+    net, _, _ = _net(dcl, n, n, 1)
+    data = dcl.synth.make_batch(b, n, n)
+    with torch.no_grad():
+        p1 = net(data)
+        p2 = net(dcl.synth.make_batch(b, n, n))
+    R = p1["rot_pred"].double()
+    assert float((R @ R.transpose(1, 2) - torch.eye(3, dtype=torch.float64, device="cuda")).abs().max()) <= 1e-5
+    assert float((torch.linalg.det(R) - 1).abs().max()) <= 1e-5
+    assert bool(((p1["conf"] > 0) & (p1["conf"] < 1)).all())
+    assert torch.equal(p1["rot_pred"], p2["rot_pred"]) and torch.equal(p1["trans_pred"], p2["trans_pred"])
+    with torch.no_grad():
+        sub = net(dcl.synth.make_batch(4, n, n, first=8))
+    assert float((sub["rot_pred"] - p1["rot_pred"][8:12]).abs().max()) <= R_TOL
+    assert float((sub["trans_pred"] - p1["trans_pred"][8:12]).abs().max()) <= T_TOL
+
+
+def test_ops_refuse_cpu_tensors(dcl):
+    with pytest.raises(RuntimeError):
+        dcl.ops.voxelize_fp(torch.zeros(4, 7), torch.zeros(2, 3, dtype=torch.int32))
+    cfg = dcl.synth.default_cfg(64, 64)
+    net = dcl.DCL_Net.Network(cfg, mode="test").eval()        # not moved to the GPU
+    with pytest.raises(RuntimeError):
+        net(dcl.synth.make_batch(1, 64, 64))

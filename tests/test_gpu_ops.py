@@ -1,0 +1,338 @@
+"""GPU parity of every C-ABI kernel against the CPU oracle (oracle/native.py), same seeded inputs.
+Index / integer outputs must be bit-exact; float outputs bit-exact where the arithmetic order is pinned
+(voxelize_fp, avg-pool, interpolation, distances), else within the stated fp32 tolerance (GEMM-shaped sums)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def cuda(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def rand_voxels(rng, b, S, n_per):
+    """unsorted unique voxel rows per crop, batch-sorted like the loaders produce"""
+    rows = []
+    for bi in range(b):
+        lin = rng.choice(S ** 3, size=n_per, replace=False)
+        xyz = np.stack([lin // (S * S), (lin // S) % S, lin % S], 1)
+        rows.append(np.concatenate([np.full((n_per, 1), bi), xyz], 1))
+    return np.concatenate(rows, 0).astype(np.int32)
+
+
+def pair_sets(pairs, num):
+    return [set(zip(pairs[k, 0, :num[k]].tolist(), pairs[k, 1, :num[k]].tolist())) for k in range(pairs.shape[0])]
+
+
+# ------------------------------------------------------------------------------------------- voxelize
+def test_voxelize_idx_host_matches_oracle(dcl, oracle):
+    rng = np.random.default_rng(0)
+    coords = np.concatenate([np.repeat(np.arange(3), 500)[:, None], rng.integers(0, 12, (1500, 3))], 1).astype(np.int64)
+    oc, im, om = dcl.ops.voxelize_idx(torch.from_numpy(coords), 3, 4)
+    rc, rm, rom = oracle.voxelize_idx(coords, 3, 4)
+    assert np.array_equal(oc.numpy(), rc) and np.array_equal(im.numpy(), rm) and np.array_equal(om.numpy(), rom)
+
+
+def test_voxelize_fp_bit_exact(dcl, oracle):
+    rng = np.random.default_rng(1)
+    coords = np.concatenate([np.repeat(np.arange(2), 700)[:, None], rng.integers(0, 9, (1400, 3))], 1).astype(np.int64)
+    _, _, rules = oracle.voxelize_idx(coords, 2, 4)
+    feats = rng.normal(size=(1400, 7)).astype(np.float32)
+    for mode in (4, 3):
+        got = dcl.ops.voxelize_fp(cuda(feats), cuda(rules), mode).cpu().numpy()
+        assert np.array_equal(got, oracle.voxelize_fp(feats, rules, mode))
+
+
+# ------------------------------------------------------------------------------------------- rulebooks
+@pytest.mark.parametrize("S,ks,st,pad,subm", [(16, 3, 1, 1, False), (16, 3, 2, 1, False), (8, 3, 1, 1, True),
+                                               (64, 3, 1, 1, False), (64, 3, 2, 1, False), (4, 3, 2, 1, False)])
+def test_rulebook_matches_oracle(dcl, oracle, S, ks, st, pad, subm):
+    rng = np.random.default_rng(S * 10 + st)
+    b = 3
+    idx = rand_voxels(rng, b, S, min(S ** 3 // 3, 300))
+    aset = dcl.ops.grid_from_indices(cuda(idx), b, S)
+    out, nbr = dcl.spconv.ops.build_rulebook(aset, ks, st, pad, subm)
+    r_out, r_pairs, r_num, _ = oracle.get_indice_pairs(idx, b, [S] * 3, ks, st, pad, 1, subm=subm)
+    n_out = idx.shape[0] if subm else out.n
+    assert n_out == r_out.shape[0]
+    got_idx = (aset.indices if subm else out.indices).cpu().numpy()
+    assert np.array_equal(got_idx, r_out)                      # ascending linear index == sort+unique order
+    pairs, num = dcl.ops.rulebook_to_pairs(nbr, n_out, idx.shape[0])
+    pairs, num = pairs.cpu().numpy(), num.cpu().numpy()
+    assert np.array_equal(num, r_num)
+    assert pair_sets(pairs, num) == pair_sets(r_pairs, r_num)
+    # gather table <-> pair list consistency
+    nb = nbr.cpu().numpy()
+    for k in range(ks ** 3):
+        assert (nb[k, :n_out] >= 0).sum() == r_num[k]
+
+
+def test_rulebook_empty_and_single(dcl, oracle):
+    one = np.array([[0, 5, 5, 5]], np.int32)
+    aset = dcl.ops.grid_from_indices(cuda(one), 1, 16)
+    out, nbr = dcl.spconv.ops.build_rulebook(aset, 3, 1, 1, False)
+    assert out.n == 27
+    out2, _ = dcl.spconv.ops.build_rulebook(aset, 3, 2, 1, False)
+    assert out2.n == 8                                        # odd coordinates reach 2 outputs per axis
+    corner = np.array([[0, 0, 0, 0]], np.int32)
+    o3, _ = dcl.spconv.ops.build_rulebook(dcl.ops.grid_from_indices(cuda(corner), 1, 16), 3, 1, 1, False)
+    assert o3.n == 8
+
+
+# ------------------------------------------------------------------------------------------- sparse conv / pool
+@pytest.mark.parametrize("cin,cout,subm", [(7, 16, False), (16, 32, True), (32, 32, False), (64, 128, True),
+                                           (128, 256, True), (128, 128, False)])
+def test_sparse_conv_matches_oracle(dcl, oracle, cin, cout, subm):
+    rng = np.random.default_rng(cin + cout)
+    b, S = 2, 8
+    idx = rand_voxels(rng, b, S, 150)
+    feat = rng.normal(size=(idx.shape[0], cin)).astype(np.float32)
+    W = (rng.normal(size=(3, 3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
+    aset = dcl.ops.grid_from_indices(cuda(idx), b, S)
+    out, nbr = dcl.spconv.ops.build_rulebook(aset, 3, 1, 1, subm)
+    n_out = idx.shape[0] if subm else out.n
+    r_out, r_pairs, r_num, _ = oracle.get_indice_pairs(idx, b, [S] * 3, 3, 1, 1, 1, subm=subm)
+    want = oracle.indice_conv(feat, W, r_pairs, r_num, n_out, subm=subm)
+    Wd = cuda(W).reshape(27, cin, cout).contiguous()
+    got = dcl.ops.sparse_conv(cuda(feat), nbr, n_out, Wd, subm).cpu().numpy()
+    tol = 2e-5 * max(1.0, np.abs(want).max())                  # fp32, different summation association
+    assert np.abs(got - want).max() <= tol
+    # MFMA kernel vs plain VALU kernel on the device (A/B)
+    lib = dcl._native.lib()
+    lib.dcl_debug_force_valu_conv(1)
+    try:
+        valu = dcl.ops.sparse_conv(cuda(feat), nbr, n_out, Wd, subm).cpu().numpy()
+    finally:
+        lib.dcl_debug_force_valu_conv(0)
+    assert np.abs(valu - want).max() <= tol
+    # folded BN + ReLU epilogue
+    s = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    t = rng.normal(size=cout).astype(np.float32)
+    got2 = dcl.ops.sparse_conv(cuda(feat), nbr, n_out, Wd, subm, cuda(s), cuda(t), True).cpu().numpy()
+    assert np.abs(got2 - np.maximum(want * s + t, 0)).max() <= 2 * tol
+
+
+@pytest.mark.parametrize("c", [32, 7])
+def test_sparse_avgpool_bit_exact(dcl, oracle, c):
+    rng = np.random.default_rng(c)
+    b, S = 3, 16
+    idx = rand_voxels(rng, b, S, 400)
+    feat = rng.normal(size=(idx.shape[0], c)).astype(np.float32)
+    aset = dcl.ops.grid_from_indices(cuda(idx), b, S)
+    out, nbr = dcl.spconv.ops.build_rulebook(aset, 3, 2, 1, False)
+    r_out, r_pairs, r_num, _ = oracle.get_indice_pairs(idx, b, [S] * 3, 3, 2, 1, 1)
+    want, want_rf = oracle.indice_avgpool(feat, r_pairs, r_num, r_out.shape[0])
+    got, rf = dcl.ops.sparse_avgpool(cuda(feat), nbr, out.n, want_rf=True)
+    assert np.array_equal(rf.cpu().numpy(), want_rf)
+    assert np.array_equal(got.cpu().numpy(), want)             # same divide-then-add order, k ascending
+
+
+# ------------------------------------------------------------------------------------------- pointnet_sp
+def _sp_case(rng, b, n, m, dup=True):
+    unk = np.concatenate([np.repeat(np.arange(b), n)[:, None], rng.uniform(-0.2, 0.2, (b * n, 3))], 1).astype(np.float32)
+    grid = rng.integers(0, 8, (b * m, 3)).astype(np.float32) * 0.05 - 0.2      # lattice => many exact ties
+    kn = np.concatenate([np.repeat(np.arange(b), m)[:, None], grid], 1).astype(np.float32)
+    return unk, kn
+
+
+def test_three_nn_sp_bit_exact(dcl, oracle):
+    rng = np.random.default_rng(3)
+    b, n, m = 4, 300, 90
+    unk, kn = _sp_case(rng, b, n, m)
+    want_d2, want_idx = oracle.three_nn_sp(unk, kn)
+    d2, idx = dcl.ops.three_nn_sp(cuda(unk), cuda(kn))
+    assert np.array_equal(idx.cpu().numpy(), want_idx) and np.array_equal(d2.cpu().numpy(), want_d2)
+    seg = torch.arange(b + 1, dtype=torch.int32).cuda() * m
+    d2s, idxs = dcl.ops.three_nn_sp(cuda(unk), cuda(kn), seg)
+    assert np.array_equal(idxs.cpu().numpy(), want_idx) and np.array_equal(d2s.cpu().numpy(), want_d2)
+
+
+def test_three_nn_sp_edge_cases(dcl, oracle):
+    rng = np.random.default_rng(4)
+    unk, kn = _sp_case(rng, 3, 70, 5)
+    kn = kn[kn[:, 0] != 1]                    # crop 1 has no voxels, crops 0/2 have 5
+    kn = np.concatenate([kn[:2], kn[5:]])      # crop 0 has only 2 (< 3 neighbours)
+    want_d2, want_idx = oracle.three_nn_sp(unk, kn)
+    d2, idx = dcl.ops.three_nn_sp(cuda(unk), cuda(kn))
+    assert np.array_equal(idx.cpu().numpy(), want_idx)
+    assert np.array_equal(d2.cpu().numpy(), want_d2)           # unmatched slots: idx 0, dist2 +inf
+    assert np.isinf(want_d2).any()
+    seg = cuda(np.array([0, 2, 2, 7], np.int32))
+    d2s, idxs = dcl.ops.three_nn_sp(cuda(unk), cuda(kn), seg)
+    assert np.array_equal(idxs.cpu().numpy(), want_idx) and np.array_equal(d2s.cpu().numpy(), want_d2)
+
+
+def test_three_interpolate_sp_bit_exact(dcl, oracle):
+    rng = np.random.default_rng(5)
+    b, n, m = 2, 257, 64
+    unk, kn = _sp_case(rng, b, n, m)
+    d2, idx = oracle.three_nn_sp(unk, kn)
+    dist = np.sqrt(d2)
+    r = (1.0 / (dist + np.float32(1e-8))).astype(np.float32)
+    w = (r / ((r[:, 0] + r[:, 1]) + r[:, 2])[:, None]).astype(np.float32)
+    for c in (32, 7):
+        feats = rng.normal(size=(b * m, c)).astype(np.float32)
+        want = oracle.three_interpolate_sp(feats, idx, w)
+        got = dcl.ops.three_interpolate_sp(cuda(feats), cuda(idx), cuda(w)).cpu().numpy()
+        assert np.array_equal(got, want)
+        fused = dcl.ops.three_interpolate_sp(cuda(feats), cuda(idx), cuda(d2), from_dist2=True).cpu().numpy()
+        assert np.array_equal(fused, want)
+    big = torch.zeros((b * n, 96), device="cuda")
+    feats = rng.normal(size=(b * m, 32)).astype(np.float32)
+    dcl.ops.three_interpolate_sp(cuda(feats), cuda(idx), cuda(w), out=big[:, 32:64])
+    assert np.array_equal(big[:, 32:64].cpu().numpy(), oracle.three_interpolate_sp(feats, idx, w))
+    assert float(big[:, :32].abs().sum()) == 0.0 and float(big[:, 64:].abs().sum()) == 0.0
+
+
+def test_voxel_centres_match_torch_expression(dcl):
+    rng = np.random.default_rng(6)
+    idx = np.concatenate([rng.integers(0, 4, (500, 1)), rng.integers(0, 32, (500, 3))], 1).astype(np.int32)
+    unit = 0.006
+    for scale in (2, 4, 6, 8):
+        ve, off = np.float32(unit * scale), np.float32(-0.5 * unit * 64)
+        ind = torch.from_numpy(idx).float()
+        ind[:, 1:] = ind[:, 1:] * torch.tensor(ve) + torch.tensor(off) + .5 * torch.tensor(ve)   # Modules.py:204-211
+        got = dcl.ops.voxel_centres(cuda(idx), float(ve), float(off)).cpu()
+        assert torch.equal(got, ind)
+
+
+# ------------------------------------------------------------------------------------------- pointnet_lib
+def _cloud(rng, b, n, dup=0.2):
+    x = rng.uniform(-0.15, 0.15, (b, n, 3)).astype(np.float32)
+    k = int(n * dup)
+    if k:
+        x[:, rng.choice(n, k, replace=False)] = x[:, rng.choice(n, k, replace=True)]     # duplicates => exact ties
+    return x
+
+
+@pytest.mark.parametrize("n,m,ns,r", [(1000, 300, 16, 0.05), (4096, 512, 64, 0.03), (333, 77, 5, 0.2), (500, 64, 200, 0.05)])
+def test_ball_query_bit_exact(dcl, oracle, n, m, ns, r):
+    rng = np.random.default_rng(n + ns)
+    xyz = _cloud(rng, 3, n)
+    new = xyz[:, rng.choice(n, m, replace=False)] + rng.normal(0, 1e-3, (3, m, 3)).astype(np.float32)
+    new[:, 0] = 9.0                                            # a centre with no neighbour at all -> zeros
+    want = oracle.ball_query(r, ns, xyz, new)
+    got = dcl.ops.ball_query(r, ns, cuda(xyz), cuda(new)).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+def test_group_and_gather_bit_exact(dcl, oracle):
+    rng = np.random.default_rng(8)
+    b, c, n, npo, ns = 3, 20, 700, 50, 16
+    feats = rng.normal(size=(b, c, n)).astype(np.float32)
+    idx = rng.integers(0, n, (b, npo, ns)).astype(np.int32)
+    assert np.array_equal(dcl.ops.group_points(cuda(feats), cuda(idx)).cpu().numpy(), oracle.group_points(feats, idx))
+    idx3 = rng.integers(0, n, (b, npo, 3)).astype(np.int32)     # nsample not a multiple of 4 -> scalar kernel
+    assert np.array_equal(dcl.ops.group_points(cuda(feats), cuda(idx3)).cpu().numpy(), oracle.group_points(feats, idx3))
+    gi = rng.integers(0, n, (b, 123)).astype(np.int32)
+    assert np.array_equal(dcl.ops.gather_points(cuda(feats), cuda(gi)).cpu().numpy(), oracle.gather_points(feats, gi))
+
+
+@pytest.mark.parametrize("n,m", [(1024, 128), (12288, 64), (777, 100), (100, 20), (40, 10), (2048, 33)])
+def test_fps_bit_exact_with_ties(dcl, oracle, n, m):
+    rng = np.random.default_rng(n)
+    xyz = _cloud(rng, 2, n, dup=0.3)
+    want = oracle.furthest_point_sample(xyz, m)
+    got = dcl.ops.furthest_point_sampling(cuda(xyz), m).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+def test_fps_lattice_ties(dcl, oracle):
+    """integer lattice: massive exact distance ties exercise the reduction-tree tie rule"""
+    g = np.stack(np.meshgrid(np.arange(8), np.arange(8), np.arange(8), indexing="ij"), -1).reshape(-1, 3)
+    rng = np.random.default_rng(0)
+    xyz = np.stack([g[rng.permutation(512)], g[rng.permutation(512)]]).astype(np.float32)
+    want = oracle.furthest_point_sample(xyz, 64)
+    got = dcl.ops.furthest_point_sampling(cuda(xyz), 64).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+def test_knn_three_nn_three_interpolate_batched(dcl, oracle):
+    rng = np.random.default_rng(9)
+    unk, kn = _cloud(rng, 2, 150), _cloud(rng, 2, 260)
+    for k in (1, 5, 200):
+        wd, wi = oracle.knn(k, unk, kn)
+        d2, idx = dcl.ops.knn(k, cuda(unk), cuda(kn))
+        assert np.array_equal(idx.cpu().numpy(), wi) and np.array_equal(d2.cpu().numpy(), wd)
+    wd, wi = oracle.three_nn(unk, kn)
+    d2, idx = dcl.ops.three_nn(cuda(unk), cuda(kn))
+    assert np.array_equal(idx.cpu().numpy(), wi) and np.array_equal(d2.cpu().numpy(), wd)
+    feats = rng.normal(size=(2, 9, 260)).astype(np.float32)
+    w = rng.uniform(size=(2, 150, 3)).astype(np.float32)
+    assert np.array_equal(dcl.ops.three_interpolate(cuda(feats), cuda(wi), cuda(w)).cpu().numpy(),
+                          oracle.three_interpolate(feats, wi, w))
+
+
+# ------------------------------------------------------------------------------------------- dense kernels
+def _attn_ref(Q, K, V):
+    """torch fp64 reference of Aligner (models/Modules.py:166-169) on point-major operands"""
+    S = torch.einsum("bjc,bic->bji", K.double(), Q.double())          # (b, nk, nq)
+    A = torch.softmax(S, dim=1)
+    return torch.einsum("bji,bjc->bic", A, V.double())
+
+
+@pytest.mark.parametrize("b,nq,nk,scale", [(2, 256, 256, 1.0), (1, 200, 500, 1.0), (3, 64, 96, 6.0), (1, 1000, 132, 0.3)])
+def test_cross_attention_matches_fp64(dcl, b, nq, nk, scale):
+    g = torch.Generator().manual_seed(nq + nk)
+    Q = (torch.randn(b, nq, 64, generator=g) * scale).cuda()
+    K = torch.randn(b, nk, 64, generator=g).cuda()
+    V1 = torch.randn(b, nk, 256, generator=g).cuda()
+    V2 = torch.randn(b, nk, 64, generator=g).cuda()
+    O1 = torch.empty(b * nq, 256, device="cuda")
+    O2 = torch.empty(b * nq, 64, device="cuda")
+    dcl.ops.cross_attention(b, Q.reshape(-1, 64), K.reshape(-1, 64), V1.reshape(-1, 256), O1, V2.reshape(-1, 64), O2)
+    want = _attn_ref(Q, K, torch.cat([V1, V2], 2))
+    got = torch.cat([O1.view(b, nq, 256), O2.view(b, nq, 64)], 2).double()
+    assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+
+
+def test_cross_attention_forced_rescale(dcl):
+    """spike one key against the queries late in the key axis so the running max jumps past the lazy-rescale
+    threshold at a chosen tile (guide rule 26)."""
+    b, nq, nk = 1, 96, 320
+    g = torch.Generator().manual_seed(0)
+    Q = torch.randn(b, nq, 64, generator=g)
+    K = torch.randn(b, nk, 64, generator=g) * 0.1
+    K[0, 200] = Q[0, 5] * 3.0                      # huge score for query 5 in tile 6
+    K[0, 300] = Q[0, 40] * 5.0
+    V = torch.randn(b, nk, 64, generator=g)
+    O = torch.empty(b * nq, 64, device="cuda")
+    dcl.ops.cross_attention(b, Q.cuda().reshape(-1, 64), K.cuda().reshape(-1, 64), V.cuda().reshape(-1, 64), O)
+    want = _attn_ref(Q, K, V)[0]
+    assert float((O.cpu().double() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+
+
+def test_conf_pool_matches_torch(dcl):
+    g = torch.Generator().manual_seed(1)
+    b, n1, n2, c = 3, 300, 170, 1024
+    l1, l2 = torch.randn(b, n1, generator=g) * 3, torch.randn(b, n2, generator=g) * 3
+    F1, F2 = torch.randn(b, n1, c, generator=g), torch.randn(b, n2, c, generator=g)
+    conf, p1, p2, ws = dcl.ops.conf_pool(b, l1.cuda().reshape(-1), l2.cuda().reshape(-1), F1.cuda().reshape(-1, c),
+                                         F2.cuda().reshape(-1, c))
+    cw = torch.sigmoid(torch.cat([l1, l2], 1).double())
+    w = torch.softmax(cw, dim=1)
+    assert float((conf.cpu().double() - cw).abs().max()) <= 1e-6
+    want = torch.einsum("bjc,bj->bc", torch.cat([F1, F2], 1).double(), w)
+    assert float(((p1 + p2).cpu().double() - want).abs().max()) <= 1e-5
+    assert float((ws.cpu().double().sum(1) - 1).abs().max()) <= 1e-6
+    assert float((ws[:, 0].cpu().double() - w[:, :n1].sum(1)).abs().max()) <= 1e-6
+
+
+def test_ortho9d_matches_torch_svd(dcl):
+    g = torch.Generator().manual_seed(2)
+    o9 = torch.randn(64, 9, generator=g)
+    o9[0] = torch.tensor([1., 0, 0, 0, 1, 0, 0, 0, -1])        # reflection: det fix path
+    o9[1] = torch.tensor([1., 0, 0, 0, 1, 0, 0, 0, 1])         # identity: repeated singular values
+    o9[2, 6:] = o9[2, :3] * 0.999 + 1e-3 * o9[2, 3:6]          # nearly rank-2
+    from oracle import graph as G
+    want = G.ortho9d2matrix(o9[:, :3], o9[:, 3:6], o9[:, 6:])
+    got = dcl.ops.ortho9d_to_matrix(o9.cuda()).cpu()
+    sel = [i for i in range(64) if i != 2]
+    assert float((got[sel] - want[sel]).abs().max()) <= 1e-5
+    assert float((torch.linalg.det(got.double()) - 1).abs().max()) <= 1e-5
+    assert float((got.double() @ got.double().transpose(1, 2) - torch.eye(3, dtype=torch.float64)).abs().max()) <= 1e-5
