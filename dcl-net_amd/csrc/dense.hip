@@ -135,6 +135,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES >= 8 ? 2 : 1) void k_cross_attn(
     }
   }
 
+  asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");     // MFMA -> VALU read of the accumulators
   const float l_tot = l_part + __shfl_xor(l_part, 32, 64);
   if (qlive) {
     const size_t row = (size_t)b * nq + q;
@@ -157,25 +158,21 @@ __global__ __launch_bounds__(WAVES * 64, WAVES >= 8 ? 2 : 1) void k_cross_attn(
 // pooled1[c] = sum_{j<n1} w_j F1[j][c], pooled2[c] = sum_{j<n2} w_{n1+j} F2[j][c] (F point-major),
 // wsum1/wsum2 = the two partial weight sums (for applying each side's trailing BatchNorm affine
 // after pooling: sum_j w_j (s*x_j + t) = s*pooled + t*wsum).
-// grid (C/64, b), 256 threads: every block recomputes the tiny softmax; lane = channel, the 4 waves
-// split the point axis and are combined in fixed order through LDS (deterministic).
-__global__ __launch_bounds__(256) void k_conf_pool(int c, int n1, int n2, const float *__restrict__ logit1,
-                                                   const float *__restrict__ logit2, const float *__restrict__ F1,
-                                                   int ld1, const float *__restrict__ F2, int ld2,
-                                                   float *__restrict__ conf, float *__restrict__ pooled1,
-                                                   float *__restrict__ pooled2, float *__restrict__ wsum) {
-  extern __shared__ float cp_lds[];            // w[L]
+// Two kernels: (1) one block per crop: sigmoid, max, exp, sum -> w (b,L) + conf + wsum;
+// (2) HBM-streaming weighted column sums: block = 256 channels (float4 per lane, 1 KiB per wave per point row)
+// x one slice of the point axis; slice partials are combined in a fixed order by the caller (deterministic).
+__global__ __launch_bounds__(256) void k_conf_softmax(int n1, int n2, const float *__restrict__ logit1,
+                                                      const float *__restrict__ logit2, float *__restrict__ conf,
+                                                      float *__restrict__ w, float *__restrict__ wsum) {
   __shared__ float red[4];
-  __shared__ float part[2][4][64];
   const int L = n1 + n2;
-  const int b = blockIdx.y, tid = threadIdx.x;
+  const int b = blockIdx.x, tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   float mx = -INFINITY;
   for (int j = tid; j < L; j += 256) {
     const float x = j < n1 ? logit1[(size_t)b * n1 + j] : logit2[(size_t)b * n2 + (j - n1)];
     const float s = 1.0f / (1.0f + expf(-x));
-    cp_lds[j] = s;
-    if (blockIdx.x == 0) conf[(size_t)b * L + j] = s;
+    conf[(size_t)b * L + j] = s;
     mx = fmaxf(mx, s);
   }
 #pragma unroll
@@ -186,8 +183,8 @@ __global__ __launch_bounds__(256) void k_conf_pool(int c, int n1, int n2, const 
   __syncthreads();
   float sum = 0.0f;
   for (int j = tid; j < L; j += 256) {
-    const float e = expf(cp_lds[j] - mx);
-    cp_lds[j] = e;
+    const float e = expf(conf[(size_t)b * L + j] - mx);      // own writes: same thread wrote conf[j]
+    w[(size_t)b * L + j] = e;
     sum += e;
   }
 #pragma unroll
@@ -195,28 +192,52 @@ __global__ __launch_bounds__(256) void k_conf_pool(int c, int n1, int n2, const 
   if (lane == 0) red[wave] = sum;
   __syncthreads();
   sum = (red[0] + red[1]) + (red[2] + red[3]);
+  __syncthreads();
   const float inv = 1.0f / sum;
-  const int ch = blockIdx.x * 64 + lane;
-  float a1 = 0.0f, a2 = 0.0f;
-  if (ch < c) {
-    const float *f1 = F1 + (size_t)b * n1 * ld1 + ch;
-    for (int j = wave; j < n1; j += 4) a1 = __fmaf_rn(f1[(size_t)j * ld1], cp_lds[j] * inv, a1);
-    const float *f2 = F2 + (size_t)b * n2 * ld2 + ch;
-    for (int j = wave; j < n2; j += 4) a2 = __fmaf_rn(f2[(size_t)j * ld2], cp_lds[n1 + j] * inv, a2);
+  float w1 = 0.f, w2 = 0.f;
+  for (int j = tid; j < L; j += 256) {
+    const float v = w[(size_t)b * L + j] * inv;
+    w[(size_t)b * L + j] = v;
+    if (j < n1) w1 += v; else w2 += v;
   }
-  part[0][wave][lane] = a1; part[1][wave][lane] = a2;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { w1 += __shfl_xor(w1, d, 64); w2 += __shfl_xor(w2, d, 64); }
+  __shared__ float r1[4], r2[4];
+  if (lane == 0) { r1[wave] = w1; r2[wave] = w2; }
+  __syncthreads();
+  if (tid == 0) { wsum[b * 2] = (r1[0] + r1[1]) + (r1[2] + r1[3]); wsum[b * 2 + 1] = (r2[0] + r2[1]) + (r2[2] + r2[3]); }
+}
+
+// part[b][slice][c] = sum over this slice's points of w[j] * F[j][c]
+__global__ __launch_bounds__(256) void k_weighted_colsum(int c, int n, int nslices, const float *__restrict__ w,
+                                                         int w_stride, int w_off, const float *__restrict__ F, int ld,
+                                                         float *__restrict__ part) {
+  __shared__ float4 red[4][64];
+  const int b = blockIdx.z, slice = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ch = blockIdx.x * 256 + lane * 4;
+  const int per = (n + nslices - 1) / nslices;
+  const int j0 = slice * per, j1 = min(n, j0 + per);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ch < c) {
+    const float *wp = w + (size_t)b * w_stride + w_off;
+    const float *fp = F + (size_t)b * n * ld + ch;
+    for (int j = j0 + wave; j < j1; j += 4) {
+      const float wj = wp[j];
+      const float4 f = *reinterpret_cast<const float4 *>(fp + (size_t)j * ld);
+      acc.x = __fmaf_rn(f.x, wj, acc.x); acc.y = __fmaf_rn(f.y, wj, acc.y);
+      acc.z = __fmaf_rn(f.z, wj, acc.z); acc.w = __fmaf_rn(f.w, wj, acc.w);
+    }
+  }
+  red[wave][lane] = acc;
   __syncthreads();
   if (wave == 0 && ch < c) {
-    pooled1[(size_t)b * c + ch] = (part[0][0][lane] + part[0][1][lane]) + (part[0][2][lane] + part[0][3][lane]);
-    pooled2[(size_t)b * c + ch] = (part[1][0][lane] + part[1][1][lane]) + (part[1][2][lane] + part[1][3][lane]);
-  }
-  if (blockIdx.x == 0 && wave == 1) {           // partial weight sums
-    float w1 = 0.f, w2 = 0.f;
-    for (int j = lane; j < n1; j += 64) w1 += cp_lds[j] * inv;
-    for (int j = lane; j < n2; j += 64) w2 += cp_lds[n1 + j] * inv;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { w1 += __shfl_xor(w1, d, 64); w2 += __shfl_xor(w2, d, 64); }
-    if (lane == 0) { wsum[b * 2] = w1; wsum[b * 2 + 1] = w2; }
+    float4 o;
+    o.x = (red[0][lane].x + red[1][lane].x) + (red[2][lane].x + red[3][lane].x);
+    o.y = (red[0][lane].y + red[1][lane].y) + (red[2][lane].y + red[3][lane].y);
+    o.z = (red[0][lane].z + red[1][lane].z) + (red[2][lane].z + red[3][lane].z);
+    o.w = (red[0][lane].w + red[1][lane].w) + (red[2][lane].w + red[3][lane].w);
+    *reinterpret_cast<float4 *>(part + ((size_t)b * nslices + slice) * c + ch) = o;
   }
 }
 
@@ -315,16 +336,19 @@ DCL_API int dcl_cross_attention(int b, int nq, int nk, const float *Q, int ldq, 
 }
 
 DCL_API int dcl_conf_pool(int b, int c, int n1, int n2, const float *logit1, const float *logit2, const float *F1,
-                          int ld1, const float *F2, int ld2, float *conf, float *pooled1, float *pooled2,
-                          float *wsum, dclStream_t stream) {
-  DCL_CHECK_ARG(b >= 0 && c > 0 && n1 > 0 && n2 > 0 && (n1 + n2) <= 36 * 1024 && ld1 >= c && ld2 >= c);
+                          int ld1, const float *F2, int ld2, float *conf, float *w_scratch, int nslices,
+                          float *part1, float *part2, float *wsum, dclStream_t stream) {
+  DCL_CHECK_ARG(b >= 0 && c > 0 && c % 4 == 0 && n1 > 0 && n2 > 0 && ld1 >= c && ld2 >= c && ld1 % 4 == 0 &&
+                ld2 % 4 == 0 && nslices >= 1);
   if (b == 0) return 0;
-  DCL_CHECK_ARG(conf && pooled1 && pooled2 && wsum && logit1 && F1 && logit2 && F2 && b <= 65535);
-  const size_t lds = (size_t)(n1 + n2) * sizeof(float);
-  if (lds > 40 * 1024)
-    (void)hipFuncSetAttribute((const void *)k_conf_pool, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k_conf_pool, dim3(dcl_div_up(c, 64), b), dim3(256), lds, (hipStream_t)stream, c, n1, n2, logit1,
-                     logit2, F1, ld1, F2, ld2, conf, pooled1, pooled2, wsum);
+  DCL_CHECK_ARG(conf && w_scratch && part1 && part2 && wsum && logit1 && F1 && logit2 && F2 && b <= 65535 &&
+                nslices <= 65535);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_conf_softmax, dim3(b), dim3(256), 0, s, n1, n2, logit1, logit2, conf, w_scratch, wsum);
+  hipLaunchKernelGGL(k_weighted_colsum, dim3(dcl_div_up(c, 256), nslices, b), dim3(256), 0, s, c, n1, nslices,
+                     w_scratch, n1 + n2, 0, F1, ld1, part1);
+  hipLaunchKernelGGL(k_weighted_colsum, dim3(dcl_div_up(c, 256), nslices, b), dim3(256), 0, s, c, n2, nslices,
+                     w_scratch, n1 + n2, n1, F2, ld2, part2);
   DCL_LAUNCH_CHECK();
   return 0;
 }

@@ -4,9 +4,8 @@
 // ones DCL_Net.forward uses through models/Modules.py:213-227) and the batched variants + knn of
 // libs/pointnet_lib/src/interpolate_gpu.cu:9-189.
 //
-// three_nn: one query per lane, kept in registers; the candidate index k is wave-uniform, so the
-// candidate row is fetched once per wave through the scalar cache (s_load) and broadcast -- no
-// LDS staging needed.  With `known_seg` a query scans only its own crop's rows (the reference
+// three_nn: one query per lane, kept in registers; the candidate range is wave-uniform, candidates
+// are staged through a small LDS tile and broadcast-read.  With `known_seg` a query scans only its own crop's rows (the reference
 // scans the whole batch and skips foreign rows: O(b^2)); results are identical because rows are
 // visited in ascending k either way.  Tie rule = the reference's strict '<' cascade.
 // three_interpolate: lanes run over channels of one point (coalesced row gathers + coalesced
@@ -27,11 +26,34 @@ struct Best3 {
   }
 };
 
-__global__ __launch_bounds__(256) void k_three_nn_sp(int n, int m, const float4 *__restrict__ unknown,
-                                                     const float4 *__restrict__ known, float *__restrict__ dist2,
-                                                     int32_t *__restrict__ idx, const int32_t *__restrict__ known_seg,
-                                                     int nbatch) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+// Branch-free top-3: a candidate is the 64-bit key (bits(d2) << 32) | k.  d2 >= +0 so its bit pattern orders like
+// the float, and equal distances order by k -- exactly the reference's strict-'<' cascade over ascending k.
+// Empty slots hold (bits(+inf) << 32) | 0, i.e. dist2 = (float)1e40 = +inf, idx = 0.
+typedef unsigned long long u64;
+constexpr u64 kEmptyKey = 0x7f80000000000000ull;
+struct Top3 {
+  u64 k1, k2, k3;
+  __device__ __forceinline__ void init() { k1 = k2 = k3 = kEmptyKey; }
+  __device__ __forceinline__ void push(u64 key) {
+    u64 t = key < k1 ? key : k1; key = key < k1 ? k1 : key; k1 = t;
+    t = key < k2 ? key : k2; key = key < k2 ? k2 : key; k2 = t;
+    k3 = key < k3 ? key : k3;
+  }
+};
+__device__ __forceinline__ u64 make_key(float d, int k) { return ((u64)__float_as_uint(d) << 32) | (unsigned)k; }
+
+// 16 queries per wave, 4 lanes per query: lane sub-id s scans candidates j = s (mod 4) of the wave-uniform range,
+// staged through an LDS tile; the 4 partial top-3 lists are merged with two shuffle rounds (exact: keys are a
+// total order).  No global-memory latency and no divergent branch in the inner loop.
+constexpr int kNNTile = 512;
+__global__ __launch_bounds__(64) void k_three_nn_sp(int n, int m, const float4 *__restrict__ unknown,
+                                                    const float4 *__restrict__ known, float *__restrict__ dist2,
+                                                    int32_t *__restrict__ idx, const int32_t *__restrict__ known_seg,
+                                                    int nbatch) {
+  __shared__ float4 tile[kNNTile];
+  const int lane = threadIdx.x;
+  const int sub = lane & 3;
+  const int p = blockIdx.x * 16 + (lane >> 2);
   const bool live = p < n;
   float4 u = make_float4(-1.f, 0.f, 0.f, 0.f);
   if (live) u = unknown[p];
@@ -41,8 +63,7 @@ __global__ __launch_bounds__(256) void k_three_nn_sp(int n, int m, const float4 
     if (live && bi >= 0 && bi < nbatch && (float)bi == u.x) { lo = known_seg[bi]; hi = known_seg[bi + 1]; }
     else { lo = 0x7fffffff; hi = 0; }
   } else if (!live) { lo = 0x7fffffff; hi = 0; }
-  // wave-uniform scan range = union of the lanes' ranges
-  int wlo = lo, whi = hi;
+  int wlo = lo, whi = hi;                               // wave-uniform scan range = union of the lanes' ranges
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
     wlo = min(wlo, __shfl_xor(wlo, d, 64));
@@ -50,15 +71,30 @@ __global__ __launch_bounds__(256) void k_three_nn_sp(int n, int m, const float4 
   }
   wlo = __builtin_amdgcn_readfirstlane(wlo);
   whi = __builtin_amdgcn_readfirstlane(whi);
-  Best3 b; b.init();
-  for (int k = wlo; k < whi; ++k) {
-    const float4 q = known[k];                        // uniform address -> scalar load
-    if (q.x != u.x) continue;                         // interpolate_gpu.cu:36-38
-    b.push(dcl_dist2(u.y, u.z, u.w, q.y, q.z, q.w), k);
+  Top3 b; b.init();
+  for (int base = wlo; base < whi; base += kNNTile) {
+    const int cnt = min(kNNTile, whi - base);
+    __syncthreads();
+    for (int j = lane; j < cnt; j += 64) tile[j] = known[base + j];
+    __syncthreads();
+#pragma unroll 4
+    for (int j = sub; j < cnt; j += 4) {
+      const float4 q = tile[j];
+      const float d = dcl_dist2(u.y, u.z, u.w, q.y, q.z, q.w);
+      b.push(q.x == u.x ? make_key(d, base + j) : ~0ull);            // interpolate_gpu.cu:36-38
+    }
   }
-  if (live) {
-    dist2[p * 3 + 0] = b.d1; dist2[p * 3 + 1] = b.d2; dist2[p * 3 + 2] = b.d3;
-    idx[p * 3 + 0] = b.i1; idx[p * 3 + 1] = b.i2; idx[p * 3 + 2] = b.i3;
+  // merge the 4 sub-lane lists
+#pragma unroll
+  for (int d = 1; d <= 2; d <<= 1) {
+    const u64 o1 = __shfl_xor(b.k1, d, 64), o2 = __shfl_xor(b.k2, d, 64), o3 = __shfl_xor(b.k3, d, 64);
+    b.push(o1); b.push(o2); b.push(o3);
+  }
+  if (live && sub == 0) {
+    dist2[p * 3 + 0] = __uint_as_float((unsigned)(b.k1 >> 32));
+    dist2[p * 3 + 1] = __uint_as_float((unsigned)(b.k2 >> 32));
+    dist2[p * 3 + 2] = __uint_as_float((unsigned)(b.k3 >> 32));
+    idx[p * 3 + 0] = (int)(unsigned)b.k1; idx[p * 3 + 1] = (int)(unsigned)b.k2; idx[p * 3 + 2] = (int)(unsigned)b.k3;
   }
 }
 
@@ -202,7 +238,7 @@ DCL_API int dcl_three_nn_sp(int n, int m, const float *unknown, const float *kno
   DCL_CHECK_ARG(n >= 0 && m >= 0);
   if (n == 0) return 0;
   DCL_CHECK_ARG(unknown && dist2 && idx && (m == 0 || known) && (!known_seg || nbatch > 0));
-  hipLaunchKernelGGL(k_three_nn_sp, dim3(dcl_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, m,
+  hipLaunchKernelGGL(k_three_nn_sp, dim3(dcl_div_up(n, 16)), dim3(64), 0, (hipStream_t)stream, n, m,
                      reinterpret_cast<const float4 *>(unknown), reinterpret_cast<const float4 *>(known), dist2, idx,
                      known_seg, nbatch);
   DCL_LAUNCH_CHECK();

@@ -128,6 +128,55 @@ __global__ void k_mark_conv_outputs(const int32_t *__restrict__ in_indices, cons
   }
 }
 
+// ---- mask-driven output sets (no atomics, no input row list) ------------------------------------------------------
+// A z-row of the grid is S <= 64 bits; conv(k3,s1,p1) dilates by one cell on every axis, pool(k3,s2,p1) maps
+// inputs {2o-1, 2o, 2o+1} to output o.  Both are pure bit operations on rows: one thread per OUTPUT word.
+__device__ __forceinline__ unsigned long long load_zrow(const uint32_t *__restrict__ mask, int b, int x, int y, int S) {
+  if ((unsigned)x >= (unsigned)S || (unsigned)y >= (unsigned)S) return 0ull;
+  const long long off = (((long long)b * S + x) * S + y) * S;          // bit offset, a multiple of S
+  const int w = (int)(off >> 5);
+  if (S == 64) return (unsigned long long)mask[w] | ((unsigned long long)mask[w + 1] << 32);
+  return ((unsigned long long)mask[w] >> (off & 31)) & ((1ull << S) - 1ull);
+}
+
+__device__ __forceinline__ unsigned long long compress_even_bits(unsigned long long x) {
+  x &= 0x5555555555555555ull;
+  x = (x | (x >> 1)) & 0x3333333333333333ull;
+  x = (x | (x >> 2)) & 0x0f0f0f0f0f0f0f0full;
+  x = (x | (x >> 4)) & 0x00ff00ff00ff00ffull;
+  x = (x | (x >> 8)) & 0x0000ffff0000ffffull;
+  x = (x | (x >> 16)) & 0x00000000ffffffffull;
+  return x;
+}
+
+template <int STRIDE>   // 1: conv k3 s1 p1 (S_out = S_in);  2: pool k3 s2 p1 (S_out = S_in / 2)
+__global__ void k_out_mask_k3(const uint32_t *__restrict__ in_mask, int batch, int S_in, int S_out, int nwords_out,
+                              uint32_t *__restrict__ out_mask) {
+  const int rows_per_word = S_out >= 32 ? 1 : 32 / S_out;
+  const unsigned long long in_rowmask = S_in == 64 ? ~0ull : ((1ull << S_in) - 1ull);
+  for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < nwords_out; w += gridDim.x * blockDim.x) {
+    uint32_t word = 0;
+    for (int rr = 0; rr < rows_per_word; ++rr) {
+      const long long bit0 = (long long)w * 32 + (long long)rr * S_out;   // first bit of this output row (part)
+      const long long row = bit0 / S_out;                                   // = (b*S_out + ox)*S_out + oy
+      const int oy = (int)(row % S_out);
+      const int ox = (int)((row / S_out) % S_out);
+      const int b = (int)(row / ((long long)S_out * S_out));
+      if (b >= batch) break;
+      unsigned long long u = 0ull;
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx)
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) u |= load_zrow(in_mask, b, ox * STRIDE + dx, oy * STRIDE + dy, S_in);
+      unsigned long long t = (u | (u << 1) | (u >> 1)) & in_rowmask;
+      if (STRIDE == 2) t = compress_even_bits(t);
+      if (S_out == 64) word = (uint32_t)(t >> ((w & 1) * 32));
+      else word |= (uint32_t)t << (rr * S_out);
+    }
+    out_mask[w] = word;
+  }
+}
+
 // decode every set bit into its (b,x,y,z) row at its rank (assignGridAndIndiceOutKernel,
 // indice.cu.h:112-128, without the sort that precedes it).
 __global__ void k_enumerate(const uint32_t *__restrict__ mask, const int32_t *__restrict__ wprefix, int nwords,
@@ -237,7 +286,8 @@ DCL_API int dcl_grid_from_indices(const int32_t *indices, int n_rows, int batch,
   return 0;
 }
 
-DCL_API int dcl_conv_out_grid(const int32_t *in_indices, const int32_t *n_in_dev, int n_in_host, int batch,
+DCL_API int dcl_conv_out_grid(const int32_t *in_indices, const int32_t *n_in_dev, int n_in_host,
+                              const uint32_t *in_mask, int batch,
                               int S_in, int ksize, int stride, int padding, uint32_t *out_mask,
                               int32_t *out_wprefix, int32_t *out_indices, int32_t *n_out_dev, int cap_out,
                               int32_t *scratch, dclStream_t stream) {
@@ -247,12 +297,23 @@ DCL_API int dcl_conv_out_grid(const int32_t *in_indices, const int32_t *n_in_dev
   DCL_CHECK_ARG(S_out > 0 && grid_words(batch, S_out) < (1ll << 26));
   hipStream_t s = (hipStream_t)stream;
   const int nwords = (int)grid_words(batch, S_out);
-  hipError_t e = hipMemsetAsync(out_mask, 0, sizeof(uint32_t) * (size_t)nwords, s);
-  if (e != hipSuccess) { dcl_set_error("dcl_conv_out_grid: memset: %s", hipGetErrorString(e)); return (int)e; }
-  const int kvol = ksize * ksize * ksize;
-  const long long in_work = (long long)n_in_host * kvol;                  // n_in_host bounds *n_in_dev
-  hipLaunchKernelGGL(k_mark_conv_outputs, dim3(dcl_grid_1d(in_work > 0 ? in_work : 1, 256)), dim3(256), 0, s,
-                     in_indices, n_in_dev, n_in_host, S_out, ksize, stride, padding, out_mask);
+  const bool pow2 = (S_in & (S_in - 1)) == 0 && S_in >= 4 && S_in <= 64;
+  if (in_mask && pow2 && ksize == 3 && padding == 1 && (stride == 1 || stride == 2)) {
+    // bit-parallel path: the output mask is a function of the input MASK alone
+    if (stride == 1)
+      hipLaunchKernelGGL((k_out_mask_k3<1>), dim3(dcl_grid_1d(nwords, 256)), dim3(256), 0, s, in_mask, batch, S_in,
+                         S_out, nwords, out_mask);
+    else
+      hipLaunchKernelGGL((k_out_mask_k3<2>), dim3(dcl_grid_1d(nwords, 256)), dim3(256), 0, s, in_mask, batch, S_in,
+                         S_out, nwords, out_mask);
+  } else {
+    hipError_t e = hipMemsetAsync(out_mask, 0, sizeof(uint32_t) * (size_t)nwords, s);
+    if (e != hipSuccess) { dcl_set_error("dcl_conv_out_grid: memset: %s", hipGetErrorString(e)); return (int)e; }
+    const int kvol = ksize * ksize * ksize;
+    const long long in_work = (long long)n_in_host * kvol;                  // n_in_host bounds *n_in_dev
+    hipLaunchKernelGGL(k_mark_conv_outputs, dim3(dcl_grid_1d(in_work > 0 ? in_work : 1, 256)), dim3(256), 0, s,
+                       in_indices, n_in_dev, n_in_host, S_out, ksize, stride, padding, out_mask);
+  }
   scan_mask(out_mask, nwords, out_wprefix, scratch, s);
   hipLaunchKernelGGL(k_enumerate, dim3(dcl_grid_1d(nwords, 256)), dim3(256), 0, s, out_mask, out_wprefix, nwords,
                      S_out, out_indices, cap_out, n_out_dev);
@@ -281,7 +342,7 @@ DCL_API int dcl_rulebook_conv(const int32_t *in_indices, const int32_t *n_in_dev
                               int32_t *n_out_dev, int32_t *nbr, int cap_out, int32_t *scratch,
                               dclStream_t stream) {
   DCL_CHECK_ARG(in_mask && in_wprefix && nbr);
-  int rc = dcl_conv_out_grid(in_indices, n_in_dev, n_in_host, batch, S_in, ksize, stride, padding, out_mask,
+  int rc = dcl_conv_out_grid(in_indices, n_in_dev, n_in_host, in_mask, batch, S_in, ksize, stride, padding, out_mask,
                              out_wprefix, out_indices, n_out_dev, cap_out, scratch, stream);
   if (rc) return rc;
   const int S_out = (S_in + 2 * padding - (ksize - 1) - 1) / stride + 1;

@@ -56,19 +56,21 @@ __global__ void k_sparse_conv_valu(const float *__restrict__ feat, const int32_t
   }
 }
 
-// ---- MFMA kernel: Cin % 8 == 0, Cout == 32*NT --------------------------------------------------
+// ---- MFMA kernel: Cin % 8 == 0, Cout % (32*NT) == 0 ---------------------------------------------
+// wave = 32 output rows x (32*NT) output channels; grid.y walks the channel tiles so that small
+// (deep) layers still put >= 2-3 waves on every SIMD.
 template <int NT>
 __global__ __launch_bounds__(256) void k_sparse_conv_mfma(
     const float *__restrict__ feat, const int32_t *__restrict__ nbr, int cap, const int32_t *__restrict__ n_out_dev,
-    int n_out_host, const float *__restrict__ W, int cin, int kvol, int subm, const float *__restrict__ scale,
-    const float *__restrict__ shift, int relu, float *__restrict__ out) {
-  constexpr int cout = 32 * NT;
+    int n_out_host, const float *__restrict__ W, int cin, int cout, int kvol, int subm,
+    const float *__restrict__ scale, const float *__restrict__ shift, int relu, float *__restrict__ out) {
   int n = n_out_dev ? *n_out_dev : n_out_host;
   n = n < cap ? n : cap;
   const int lane = threadIdx.x & 63;
   const int r = lane & 31, h = lane >> 5;
   const int waves_per_block = blockDim.x >> 6;
   const int ntiles = (n + 31) >> 5;
+  const int col0 = blockIdx.y * (32 * NT);
   for (int tile = blockIdx.x * waves_per_block + (threadIdx.x >> 6); tile < ntiles;
        tile += gridDim.x * waves_per_block) {
     const int row = tile * 32 + r;
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(256) void k_sparse_conv_mfma(
       const int v = valid ? nbr[(size_t)k * cap + row] : -1;
       if (__ballot(v >= 0) == 0ull) continue;                       // nobody in this tile uses offset k
       const float *fp = feat + (size_t)(v >= 0 ? v : 0) * cin + h * 4;
-      const float *wp = W + (size_t)k * cin * cout + r;
+      const float *wp = W + (size_t)k * cin * cout + col0 + r;
       for (int c8 = 0; c8 < cin; c8 += 8) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
         if (v >= 0) a = *reinterpret_cast<const float4 *>(fp + c8);
@@ -99,10 +101,11 @@ __global__ __launch_bounds__(256) void k_sparse_conv_mfma(
         }
       }
     }
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // MFMA -> VALU read of the accumulator (see k_sparse_conv_lds)
     // C/D layout: col = lane&31 (cout within tile), row = (e&3) + 8*(e>>2) + 4*(lane>>5)
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const int co = j * 32 + r;
+      const int co = col0 + j * 32 + r;
       const float sc = scale ? scale[co] : 1.0f;
       const float sh = scale ? shift[co] : 0.0f;
 #pragma unroll
@@ -116,6 +119,129 @@ __global__ __launch_bounds__(256) void k_sparse_conv_mfma(
         }
       }
     }
+  }
+}
+
+// ---- MFMA kernel, weights through LDS: Cin in {16,32,64,128}, Cout % (32*NT) == 0 -------------------------
+// workgroup = 4 waves = 128 consecutive output rows x (32*NT) output channels.  Per kernel offset k that ANY of
+// the 128 rows uses (27-bit workgroup mask; the rest are skipped), the W[k] tile (Cin x 32NT floats) is staged
+// once in LDS and shared by the 4 waves -- double-buffered: the next used offset's tile is fetched into
+// registers while the current one feeds the MFMAs.  Each lane pulls its own gathered input row (A operand)
+// for the whole offset with Cin/8 independent 16-B loads issued back to back, so their latency overlaps.
+template <int CIN, int NT>
+__global__ __launch_bounds__(256, 2) void k_sparse_conv_lds(
+    const float *__restrict__ feat, const int32_t *__restrict__ nbr, int cap, const int32_t *__restrict__ n_out_dev,
+    int n_out_host, const float *__restrict__ W, int cout, int kvol, int subm, const float *__restrict__ scale,
+    const float *__restrict__ shift, int relu, float *__restrict__ out) {
+  constexpr int BN = 32 * NT;                    // output channels per workgroup
+  constexpr int TILE = CIN * BN;                 // floats per staged W[k] tile
+  constexpr int LD4 = TILE / 4 / 256 > 0 ? TILE / 4 / 256 : 1;   // float4 per thread per tile
+  __shared__ __attribute__((aligned(16))) float Bs[2][TILE];
+  __shared__ unsigned s_kmask;
+  int n = n_out_dev ? *n_out_dev : n_out_host;
+  n = n < cap ? n : cap;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int col0 = blockIdx.y * BN;
+  const int nblk = (n + 127) >> 7;
+  for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int row = blk * 128 + wave * 32 + r;
+    const bool valid = row < n;
+    // which offsets does this workgroup need?
+    unsigned mymask = 0;
+    if (valid)
+      for (int k = 0; k < kvol; ++k) mymask |= (nbr[(size_t)k * cap + row] >= 0 ? 1u : 0u) << k;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mymask |= __shfl_xor(mymask, d, 64);
+    if (tid == 0) s_kmask = 0;
+    __syncthreads();
+    if (lane == 0 && mymask) atomicOr(&s_kmask, mymask);
+    __syncthreads();
+    const unsigned kmask = s_kmask;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][e] = 0.0f;
+
+    // ordered list of used offsets is walked with a step cursor
+    int s = 0;
+    auto next_used = [&](int from) {
+      int q = from;
+      while (q < kvol && !((kmask >> offset_at(q, kvol, subm)) & 1u)) ++q;
+      return q;
+    };
+    s = next_used(0);
+    float4 breg[LD4];
+    // float4 slot of this thread inside the tile (clamped: when the tile has < 256 slots the surplus threads
+    // re-load / re-store the last slot, which keeps the staging registers branch-free)
+    auto slot = [&](int i) { const int f4 = tid + i * 256; return f4 < TILE / 4 ? f4 : TILE / 4 - 1; };
+    auto fetch_tile = [&](int k) {
+      const float *wp = W + (size_t)k * CIN * cout + col0;
+#pragma unroll
+      for (int i = 0; i < LD4; ++i) {
+        const int f4 = slot(i);
+        const int ci = f4 / (BN / 4), c4 = (f4 - ci * (BN / 4)) * 4;
+        breg[i] = *reinterpret_cast<const float4 *>(wp + (size_t)ci * cout + c4);
+      }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+      for (int i = 0; i < LD4; ++i) *reinterpret_cast<float4 *>(&Bs[buf][slot(i) * 4]) = breg[i];
+    };
+    int cur = 0;
+    if (s < kvol) { fetch_tile(offset_at(s, kvol, subm)); store_tile(0); }
+    __syncthreads();
+    while (s < kvol) {
+      const int k = offset_at(s, kvol, subm);
+      const int s_next = next_used(s + 1);
+      if (s_next < kvol) fetch_tile(offset_at(s_next, kvol, subm));       // global loads in flight during the MFMAs
+      const int v = valid ? nbr[(size_t)k * cap + row] : -1;
+      if (__ballot(v >= 0) != 0ull) {                                       // this wave's 32 rows use offset k
+        float4 a[CIN / 8];
+        const float *fp = feat + (size_t)(v >= 0 ? v : 0) * CIN + h * 4;
+#pragma unroll
+        for (int i = 0; i < CIN / 8; ++i) {
+          a[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (v >= 0) a[i] = *reinterpret_cast<const float4 *>(fp + 8 * i);
+        }
+        const float *bp = &Bs[cur][(h * 4) * BN + r];
+#pragma unroll
+        for (int i = 0; i < CIN / 8; ++i) {
+          const float av[4] = {a[i].x, a[i].y, a[i].z, a[i].w};
+#pragma unroll
+          for (int t = 0; t < 4; ++t)                 // MFMA step contracts channels {8i+t, 8i+4+t}
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bp[(8 * i + t) * BN + j * 32], acc[j], 0, 0, 0);
+        }
+        // hipcc (ROCm 7.2) re-reads the accumulator at the loop header right behind the barrier without the
+        // MFMA -> VALU wait states for its last register (seen as stale acc[15] on ~0.5 % of rows): pad here.
+        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+      }
+      if (s_next < kvol) store_tile(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+      s = s_next;
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int co = col0 + j * 32 + r;
+      const float sc = scale ? scale[co] : 1.0f;
+      const float sh = scale ? shift[co] : 0.0f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int orow = blk * 128 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (orow < n) {
+          float x = acc[j][e];
+          if (scale) x = x * sc + sh;
+          if (relu) x = fmaxf(x, 0.0f);
+          out[(size_t)orow * cout + co] = x;
+        }
+      }
+    }
+    __syncthreads();                                   // s_kmask / Bs are reused by the next row block
   }
 }
 
@@ -173,7 +299,7 @@ __global__ void k_sparse_avgpool_scalar(const float *__restrict__ feat, const in
 
 }  // namespace
 
-static int g_force_valu = 0;   // test hook: dcl_debug_force_valu_conv(1) routes every conv through the VALU kernel
+static int g_force_valu = 0;   // test hook: 1 = plain VALU kernel for every conv, 2 = MFMA kernel without LDS staging
 DCL_API void dcl_debug_force_valu_conv(int on) { g_force_valu = on; }
 
 DCL_API int dcl_sparse_conv_fwd(const float *feat, const int32_t *nbr, int cap, const int32_t *n_out_dev,
@@ -186,21 +312,36 @@ DCL_API int dcl_sparse_conv_fwd(const float *feat, const int32_t *nbr, int cap, 
   const int rows = n_out_dev ? cap : n_out_host;
   if (rows == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  const bool mfma_ok = !g_force_valu && (cin % 8 == 0) && (cout % 32 == 0) && cout <= 256 &&
-                       (cout == 32 || cout == 64 || cout == 128 || cout == 256);
-  if (mfma_ok) {
-    const int ntiles = dcl_div_up(rows, 32);
-    const int blocks = dcl_grid_1d(ntiles, 4, 256 * 8);
-#define LAUNCH_MFMA(NT)                                                                                       \
-  hipLaunchKernelGGL((k_sparse_conv_mfma<NT>), dim3(blocks), dim3(256), 0, s, feat, nbr, cap, n_out_dev,      \
-                     n_out_host, W, cin, kvol, subm, scale, shift, relu, out)
-    switch (cout) {
-      case 32: LAUNCH_MFMA(1); break;
-      case 64: LAUNCH_MFMA(2); break;
-      case 128: LAUNCH_MFMA(4); break;
-      default: LAUNCH_MFMA(8); break;
+  const bool mfma_ok = !g_force_valu && (cin % 8 == 0) && (cout % 32 == 0);
+  const bool lds_ok = mfma_ok && g_force_valu != 2 && (cin == 16 || cin == 32 || cin == 64 || cin == 128);
+  if (lds_ok) {
+    const int nblk = dcl_div_up(rows, 128);
+    // 64 output channels per workgroup when that still leaves >= ~3 workgroups per CU, else 32
+    const int nt = (cout % 64 == 0 && (long long)nblk * (cout / 64) >= 768) ? 2 : 1;
+    const dim3 grid(nblk < 65535 ? nblk : 65535, cout / (32 * nt));
+#define CONV_LDS(C, T)                                                                                          \
+  hipLaunchKernelGGL((k_sparse_conv_lds<C, T>), grid, dim3(256), 0, s, feat, nbr, cap, n_out_dev, n_out_host, W, \
+                     cout, kvol, subm, scale, shift, relu, out)
+#define CONV_LDS_C(C) do { if (nt == 2) CONV_LDS(C, 2); else CONV_LDS(C, 1); } while (0)
+    switch (cin) {
+      case 16: CONV_LDS_C(16); break;
+      case 32: CONV_LDS_C(32); break;
+      case 64: CONV_LDS_C(64); break;
+      default: CONV_LDS_C(128); break;
     }
-#undef LAUNCH_MFMA
+#undef CONV_LDS_C
+#undef CONV_LDS
+  } else if (mfma_ok) {
+    const int ntiles = dcl_div_up(rows, 32);
+    const int nt = (cout % 64 == 0 && (long long)ntiles * (cout / 64) >= 4096) ? 2 : 1;
+    const int ytiles = cout / (32 * nt);
+    const int blocks = dcl_grid_1d(ntiles, 4, 256 * 8);
+    if (nt == 2)
+      hipLaunchKernelGGL((k_sparse_conv_mfma<2>), dim3(blocks, ytiles), dim3(256), 0, s, feat, nbr, cap, n_out_dev,
+                         n_out_host, W, cin, cout, kvol, subm, scale, shift, relu, out);
+    else
+      hipLaunchKernelGGL((k_sparse_conv_mfma<1>), dim3(blocks, ytiles), dim3(256), 0, s, feat, nbr, cap, n_out_dev,
+                         n_out_host, W, cin, cout, kvol, subm, scale, shift, relu, out);
   } else {
     hipLaunchKernelGGL(k_sparse_conv_valu, dim3(dcl_grid_1d((long long)rows * cout, 256)), dim3(256), 0, s, feat,
                        nbr, cap, n_out_dev, n_out_host, W, cin, cout, kvol, subm, scale, shift, relu, out);

@@ -13,6 +13,10 @@ from . import _native as N
 _c_int = C.c_int
 _c_float = C.c_float
 
+# bench.py sets this to a list to collect (name, start_event, end_event) around selected launches on torch's
+# current stream (the stream the kernels are launched on); None = off.
+PROFILE_EVENTS = None
+
 
 def _i32_ptr_or_null(t):
     return N.ptr(t) if t is not None else N.vp(0)
@@ -107,8 +111,8 @@ def conv_out_grid(inp, ksize, stride, padding, cap=None):
     out_idx = torch.empty((cap, 4), dtype=torch.int32, device=dev)
     n_in_dev = inp.n_dev if inp.n is None else None
     n_in_host = inp.cap if inp.n is None else inp.n
-    N.check(N.lib().dcl_conv_out_grid(N.ptr(inp.indices), _i32_ptr_or_null(n_in_dev), int(n_in_host), inp.batch,
-                                      inp.S, ksize, stride, padding, N.ptr(mask), N.ptr(wprefix), N.ptr(out_idx),
+    N.check(N.lib().dcl_conv_out_grid(N.ptr(inp.indices), _i32_ptr_or_null(n_in_dev), int(n_in_host),
+                                      N.ptr(inp.mask), inp.batch, inp.S, ksize, stride, padding, N.ptr(mask), N.ptr(wprefix), N.ptr(out_idx),
                                       N.ptr(wprefix[nw:]), cap, N.ptr(scan_scratch(nw, dev)), N.stream()),
             "conv_out_grid")
     return ActiveSet(out_idx, None, wprefix[nw:], cap, mask, wprefix, None, S_out, inp.batch)
@@ -301,9 +305,16 @@ def cross_attention(b, Q, K, V1, O1, V2=None, O2=None):
     assert Q.shape[1] == 64 and K.shape[1] == 64 and V1.shape[0] == K.shape[0] and O1.shape[0] == Q.shape[0]
     dv1 = V1.shape[1]
     dv2 = 0 if V2 is None else V2.shape[1]
+    ev = None
+    if PROFILE_EVENTS is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     N.check(N.lib().dcl_cross_attention(b, nq, nk, N.ptr(Q), _ld(Q), N.ptr(K), _ld(K), N.ptr(V1), dv1, _ld(V1),
                                         N.ptr(O1), _ld(O1), N.ptr(V2), dv2, 0 if V2 is None else _ld(V2), N.ptr(O2),
                                         0 if O2 is None else _ld(O2), N.stream()), "cross_attention")
+    if ev is not None:
+        ev[1].record()
+        PROFILE_EVENTS.append(("cross_attention", ev[0], ev[1]))
     return O1, O2
 
 
@@ -315,13 +326,17 @@ def conf_pool(b, logit1, logit2, F1, F2):
     c = F1.shape[1]
     assert logit1.is_contiguous() and logit2.is_contiguous() and logit1.numel() == b * n1 and logit2.numel() == b * n2
     dev = F1.device
+    # enough (crop, channel-chunk, slice) blocks to fill 256 CUs several times over
+    nslices = max(1, min(64, 2048 // max(1, b * ((c + 255) // 256))))
     conf = torch.empty((b, n1 + n2), dtype=torch.float32, device=dev)
-    p1 = torch.empty((b, c), dtype=torch.float32, device=dev)
-    p2 = torch.empty((b, c), dtype=torch.float32, device=dev)
+    w = torch.empty((b, n1 + n2), dtype=torch.float32, device=dev)
+    part1 = torch.empty((b, nslices, c), dtype=torch.float32, device=dev)
+    part2 = torch.empty((b, nslices, c), dtype=torch.float32, device=dev)
     ws = torch.empty((b, 2), dtype=torch.float32, device=dev)
     N.check(N.lib().dcl_conf_pool(b, c, n1, n2, N.ptr(logit1), N.ptr(logit2), N.ptr(F1), _ld(F1), N.ptr(F2), _ld(F2),
-                                  N.ptr(conf), N.ptr(p1), N.ptr(p2), N.ptr(ws), N.stream()), "conf_pool")
-    return conf, p1, p2, ws
+                                  N.ptr(conf), N.ptr(w), nslices, N.ptr(part1), N.ptr(part2), N.ptr(ws), N.stream()),
+            "conf_pool")
+    return conf, part1.sum(dim=1), part2.sum(dim=1), ws
 
 
 def ortho9d_to_matrix(o9):

@@ -76,7 +76,8 @@ int dcl_grid_from_indices(const int32_t *indices, int n_rows, int batch, int S, 
  * 112-128): out mask/wprefix on the S_out grid, out_indices (cap_out,4) in ascending linear
  * index, n_out_dev[0].  n_in is *n_in_dev if non-NULL (n_in_host then only bounds the launch).
  * scratch as above, sized for the S_out grid.                                   */
-int dcl_conv_out_grid(const int32_t *in_indices, const int32_t *n_in_dev, int n_in_host, int batch,
+int dcl_conv_out_grid(const int32_t *in_indices, const int32_t *n_in_dev, int n_in_host,
+                      const uint32_t *in_mask /* optional: enables the bit-parallel path */, int batch,
                       int S_in, int ksize, int stride, int padding, uint32_t *out_mask,
                       int32_t *out_wprefix, int32_t *out_indices, int32_t *n_out_dev, int cap_out,
                       int32_t *scratch, dclStream_t stream);
@@ -189,13 +190,14 @@ int dcl_cross_attention(int b, int nq, int nk, const float *Q, int ldq, const fl
                         int dv2, int ldv2, float *O2, int ldo2, dclStream_t stream);
 
 /* Confidence pooling (models/DCL_Net.py:217-228): conf = sigmoid(cat[logit1 (b,n1), logit2
- * (b,n2)]) -> conf (b,n1+n2); w = softmax(conf);
- * pooled1 (b,C) = sum_{j<n1} w[j] F1[b,j,:], pooled2 (b,C) = sum_{j<n2} w[n1+j] F2[b,j,:],
- * wsum (b,2) = the two partial sums of w.  (pooled of the reference = pooled1 + pooled2 when
- * F1/F2 already carry their trailing BatchNorm; else s1*pooled1 + t1*wsum1 + s2*pooled2 + t2*wsum2.) */
+ * (b,n2)]) -> conf (b,n1+n2); w = softmax(conf) -> w_scratch (b,n1+n2);
+ * part1 (b,nslices,C): slice partials of sum_{j<n1} w[j] F1[b,j,:]; part2 likewise over F2 with
+ * w[n1+j]; wsum (b,2) = the two partial sums of w.  The caller adds the slices in index order
+ * (deterministic).  pooled of the reference = sum(part1)+sum(part2) when F1/F2 already carry their
+ * trailing BatchNorm, else s1*P1 + t1*wsum1 + s2*P2 + t2*wsum2.  C % 4 == 0.                    */
 int dcl_conf_pool(int b, int c, int n1, int n2, const float *logit1, const float *logit2,
-                  const float *F1, int ld1, const float *F2, int ld2, float *conf, float *pooled1,
-                  float *pooled2, float *wsum, dclStream_t stream);
+                  const float *F1, int ld1, const float *F2, int ld2, float *conf, float *w_scratch,
+                  int nslices, float *part1, float *part2, float *wsum, dclStream_t stream);
 
 /* ortho9d2matrix (models/DCL_Net.py:15-36): o9 (b,9) -> R (b,3,3).             */
 int dcl_ortho9d_to_matrix(int b, const float *o9, float *R, dclStream_t stream);

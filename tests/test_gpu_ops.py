@@ -104,12 +104,13 @@ def test_sparse_conv_matches_oracle(dcl, oracle, cin, cout, subm):
     assert np.abs(got - want).max() <= tol
     # MFMA kernel vs plain VALU kernel on the device (A/B)
     lib = dcl._native.lib()
-    lib.dcl_debug_force_valu_conv(1)
-    try:
-        valu = dcl.ops.sparse_conv(cuda(feat), nbr, n_out, Wd, subm).cpu().numpy()
-    finally:
-        lib.dcl_debug_force_valu_conv(0)
-    assert np.abs(valu - want).max() <= tol
+    for mode in (1, 2):                                        # 1: VALU kernel, 2: MFMA kernel without LDS staging
+        lib.dcl_debug_force_valu_conv(mode)
+        try:
+            alt = dcl.ops.sparse_conv(cuda(feat), nbr, n_out, Wd, subm).cpu().numpy()
+        finally:
+            lib.dcl_debug_force_valu_conv(0)
+        assert np.abs(alt - want).max() <= tol
     # folded BN + ReLU epilogue
     s = rng.uniform(0.5, 1.5, cout).astype(np.float32)
     t = rng.normal(size=cout).astype(np.float32)
