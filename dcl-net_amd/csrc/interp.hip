@@ -49,7 +49,7 @@ constexpr int kNNTile = 512;
 __global__ __launch_bounds__(64) void k_three_nn_sp(int n, int m, const float4 *__restrict__ unknown,
                                                     const float4 *__restrict__ known, float *__restrict__ dist2,
                                                     int32_t *__restrict__ idx, const int32_t *__restrict__ known_seg,
-                                                    int nbatch) {
+                                                    int nbatch, int seg_stride) {
   __shared__ float4 tile[kNNTile];
   const int lane = threadIdx.x;
   const int sub = lane & 3;
@@ -60,8 +60,9 @@ __global__ __launch_bounds__(64) void k_three_nn_sp(int n, int m, const float4 *
   int lo = 0, hi = m;
   if (known_seg) {
     const int bi = (int)u.x;
-    if (live && bi >= 0 && bi < nbatch && (float)bi == u.x) { lo = known_seg[bi]; hi = known_seg[bi + 1]; }
-    else { lo = 0x7fffffff; hi = 0; }
+    if (live && bi >= 0 && bi < nbatch && (float)bi == u.x) {
+      lo = known_seg[(size_t)bi * seg_stride]; hi = known_seg[(size_t)(bi + 1) * seg_stride];
+    } else { lo = 0x7fffffff; hi = 0; }
   } else if (!live) { lo = 0x7fffffff; hi = 0; }
   int wlo = lo, whi = hi;                               // wave-uniform scan range = union of the lanes' ranges
 #pragma unroll
@@ -233,16 +234,22 @@ __global__ void k_three_interpolate(int c, int m, int n, const float *__restrict
 
 }  // namespace
 
-DCL_API int dcl_three_nn_sp(int n, int m, const float *unknown, const float *known, float *dist2, int32_t *idx,
-                            const int32_t *known_seg, int nbatch, dclStream_t stream) {
+// internal: known_seg[b * seg_stride] (lets the backbone runner use a wprefix array in place)
+int dcl_three_nn_sp_strided(int n, int m, const float *unknown, const float *known, float *dist2, int32_t *idx,
+                            const int32_t *known_seg, int nbatch, int seg_stride, dclStream_t stream) {
   DCL_CHECK_ARG(n >= 0 && m >= 0);
   if (n == 0) return 0;
-  DCL_CHECK_ARG(unknown && dist2 && idx && (m == 0 || known) && (!known_seg || nbatch > 0));
+  DCL_CHECK_ARG(unknown && dist2 && idx && (m == 0 || known) && (!known_seg || (nbatch > 0 && seg_stride > 0)));
   hipLaunchKernelGGL(k_three_nn_sp, dim3(dcl_div_up(n, 16)), dim3(64), 0, (hipStream_t)stream, n, m,
                      reinterpret_cast<const float4 *>(unknown), reinterpret_cast<const float4 *>(known), dist2, idx,
-                     known_seg, nbatch);
+                     known_seg, nbatch, seg_stride);
   DCL_LAUNCH_CHECK();
   return 0;
+}
+
+DCL_API int dcl_three_nn_sp(int n, int m, const float *unknown, const float *known, float *dist2, int32_t *idx,
+                            const int32_t *known_seg, int nbatch, dclStream_t stream) {
+  return dcl_three_nn_sp_strided(n, m, unknown, known, dist2, idx, known_seg, nbatch, 1, stream);
 }
 
 DCL_API int dcl_voxel_centres(const int32_t *indices, const int32_t *n_dev, int n_host, float ve, float off,

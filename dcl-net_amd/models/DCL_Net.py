@@ -116,6 +116,8 @@ class Network(nn.Module):
                         W = conv.weight.reshape(-1, conv.in_channels, conv.out_channels).contiguous()
                         layers.append((W, s.contiguous(), t.contiguous(), conv.subm))
                 f[bb] = layers
+                f[bb + "_ptrs"] = (ops._ptr_array([l[0] for l in layers]), ops._ptr_array([l[1] for l in layers]),
+                                   ops._ptr_array([l[2] for l in layers]))
             for side in ("Xc", "Yo"):
                 W1, t1, second = [], [], []
                 for tag in ("p1", "m1", "p2", "m2"):
@@ -149,51 +151,6 @@ class Network(nn.Module):
 
     # ------------------------------------------------------------------ fused pipeline
     @staticmethod
-    def _geometry_a(occ, b, S):
-        a0 = ops.grid_from_indices(occ, b, S)
-        sets, cur = [], a0
-        for _ in range(4):
-            c = ops.conv_out_grid(cur, 3, 1, 1)
-            p = ops.conv_out_grid(c, 3, 2, 1)
-            sets.append((cur, c, p))
-            cur = p
-        return sets
-
-    @staticmethod
-    def _geometry_b(sets):
-        books = []
-        for cur, c, p in sets:
-            books.append((ops.rulebook_gather(c, cur, 3, 1, 1), ops.rulebook_gather(c, c, 3, 1, 1),
-                          ops.rulebook_gather(p, c, 3, 2, 1)))
-        return books
-
-    def _backbone_feats(self, layers, x, sets, books):
-        levels = []
-        for m in range(4):
-            (_, c, p), (nb_c, nb_s, nb_p) = sets[m], books[m]
-            W, s, t, _ = layers[2 * m]
-            x = ops.sparse_conv(x, nb_c, c.n, W, False, s, t, True)
-            W, s, t, _ = layers[2 * m + 1]
-            x = ops.sparse_conv(x, nb_s, c.n, W, True, s, t, True)
-            x = ops.sparse_avgpool(x, nb_p, p.n)
-            levels.append((x, p))
-        return levels
-
-    def _point_feats(self, points_b4, levels):
-        unit = self.unit_voxel_extent
-        assert unit[0] == unit[1] == unit[2], "anisotropic voxels: use fused=False"
-        off = float(np.float32(-0.5 * unit[0] * VOXEL_NUM_LIMIT[0]))
-        F = torch.empty((points_b4.shape[0], 480), dtype=torch.float32, device=points_b4.device)
-        c0 = 0
-        for l, (x, p) in enumerate(levels):
-            centres = ops.voxel_centres(p.indices, float(np.float32(unit[0] * SCALE_LISTS[l])), off, p.n)
-            d2, idx = ops.three_nn_sp(points_b4, centres, p.segments())
-            C = x.shape[1]
-            ops.three_interpolate_sp(x, idx, d2, out=F[:, c0:c0 + C], from_dist2=True)
-            c0 += C
-        return F
-
-    @staticmethod
     def _lin_relu(x, Wt, bias):
         return torch._addmm_activation(bias, x, Wt)          # relu(x @ Wt + bias), one GEMM with epilogue
 
@@ -215,21 +172,23 @@ class Network(nn.Module):
             side_in[side] = (d["feats"].to(dev, non_blocking=True).float().contiguous(),
                              d["v2p_maps"].to(dev, non_blocking=True).int().contiguous(),
                              d["occupied_voxels"].to(dev, non_blocking=True).int().contiguous())
-        sets = {s: self._geometry_a(side_in[s][2], b, S) for s in ("inp", "tmp")}
-        flat = [a for s in ("inp", "tmp") for (_, c, p) in sets[s] for a in (c, p)]
-        counts = torch.cat([a.n_dev for a in flat]).cpu().tolist()       # the forward's single host sync
-        for a, n in zip(flat, counts):
-            a.n, a.cap, a.indices = int(n), max(int(n), 1), a.indices[:int(n)]
+        runs = {s: ops.BackboneRun(side_in[s][2], b, S) for s in ("inp", "tmp")}
+        counts = torch.cat([runs["inp"].counts_dev, runs["tmp"].counts_dev]).cpu().tolist()   # the single host sync
+        runs["inp"].set_counts(counts[:8])
+        runs["tmp"].set_counts(counts[8:])
+        unit = self.unit_voxel_extent
+        assert unit[0] == unit[1] == unit[2], "anisotropic voxels: use fused=False"
+        off = float(np.float32(-0.5 * unit[0] * VOXEL_NUM_LIMIT[0]))
+        extents = [float(np.float32(unit[0] * sc)) for sc in SCALE_LISTS]
         pf = {}
         pts = {}
         for side, bb, n in (("inp", "backbone_inp", self.n_inp), ("tmp", "backbone_tmp", self.n_tmp)):
             feats, v2p, _ = side_in[side]
-            books = self._geometry_b(sets[side])
             x = ops.voxelize_fp(feats, v2p, self.voxelization_mode)
-            levels = self._backbone_feats(f[bb], x, sets[side], books)
+            runs[side].features(x, *f[bb + "_ptrs"])
             xyz = feats[:, 4:7]
             bid = torch.arange(b, device=dev, dtype=torch.float32).repeat_interleave(n).unsqueeze(1)
-            pf[side] = self._point_feats(torch.cat([bid, xyz], 1).contiguous(), levels)
+            pf[side] = runs[side].point_features(torch.cat([bid, xyz], 1).contiguous(), extents, off)
             pts[side] = xyz.reshape(b, n, 3)
 
         act = {}

@@ -170,6 +170,73 @@ def sparse_avgpool(feat, nbr, n_out, want_rf=False):
     return (out, rf[:n_out]) if want_rf else out
 
 
+# ------------------------------------------------------------------------------------ native backbone runner
+BACKBONE_CHANNELS = (7, 16, 32, 32, 64, 64, 128, 128, 256)
+
+
+def _ptr_array(tensors):
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+class BackboneRun(object):
+    """State of one backbone pass driven by the native runner (csrc/backbone.hip)."""
+
+    def __init__(self, occ, batch, S):
+        N.need_cuda(occ)
+        assert occ.dtype == torch.int32 and occ.is_contiguous()
+        self.occ, self.batch, self.S, self.V0 = occ, int(batch), int(S), occ.shape[0]
+        nbytes = C.c_int64(0)
+        N.check(N.lib().dcl_backbone_ws_bytes(self.batch, self.S, self.V0, C.byref(nbytes)), "backbone_ws_bytes")
+        self.ws = torch.empty(nbytes.value, dtype=torch.uint8, device=occ.device)
+        self.counts_dev = torch.empty(8, dtype=torch.int32, device=occ.device)
+        self.chan = (C.c_int32 * 9)(*BACKBONE_CHANNELS)
+        N.check(N.lib().dcl_backbone_geometry(N.ptr(occ), self.V0, self.batch, self.S, N.ptr(self.ws), nbytes.value,
+                                              N.ptr(self.counts_dev), N.stream()), "backbone_geometry")
+        self.counts = None
+        self.levels = None
+
+    def set_counts(self, counts):
+        self.counts = [int(c) for c in counts]
+        self.ccounts = (C.c_int32 * 8)(*self.counts)
+
+    def features(self, vox_feats, weights_arr, scales_arr, shifts_arr):
+        """-> list of 4 level feature tensors (n_pool_m, C_m)."""
+        dev = vox_feats.device
+        nbytes = C.c_int64(0)
+        N.check(N.lib().dcl_backbone_ws2_bytes(self.ccounts, self.chan, C.byref(nbytes)), "backbone_ws2_bytes")
+        ws2 = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+        self.levels = [torch.empty((self.counts[2 * m + 1], BACKBONE_CHANNELS[2 * m + 2]), dtype=torch.float32,
+                                   device=dev) for m in range(4)]
+        N.check(N.lib().dcl_backbone_features(N.ptr(self.occ), self.V0, self.batch, self.S, N.ptr(self.ws), self.ccounts,
+                                              self.chan, N.ptr(vox_feats), weights_arr, scales_arr, shifts_arr,
+                                              N.ptr(ws2), nbytes.value, _ptr_array(self.levels), N.stream()),
+                "backbone_features")
+        return self.levels
+
+    def level_indices(self, m):
+        """(n_pool_m, 4) int32 view of pooled level m's voxel rows inside the workspace."""
+        off, wp, Sl = C.c_int64(0), C.c_int64(0), C.c_int32(0)
+        N.check(N.lib().dcl_backbone_level_info(self.batch, self.S, self.V0, m, C.byref(off), C.byref(wp), C.byref(Sl)),
+                "backbone_level_info")
+        n = self.counts[2 * m + 1]
+        return self.ws[off.value:off.value + 16 * n].view(torch.int32).view(n, 4)
+
+    def point_features(self, points_b4, voxel_extents, offset, out=None):
+        """points_b4 (n,4) -> (n,480) interpolated multi-scale features."""
+        n = points_b4.shape[0]
+        dev = points_b4.device
+        if out is None:
+            out = torch.empty((n, 480), dtype=torch.float32, device=dev)
+        max_rows = max(1, max(self.counts[1::2]))
+        tmp_bytes = 2 * (((n * 12) + 255) // 256 * 256) + 16 * max_rows
+        tmp = torch.empty(tmp_bytes, dtype=torch.uint8, device=dev)
+        ve = (C.c_float * 4)(*[float(v) for v in voxel_extents])
+        N.check(N.lib().dcl_point_features(n, N.ptr(points_b4), self.batch, self.S, self.V0, N.ptr(self.ws), self.ccounts,
+                                           self.chan, _ptr_array(self.levels), ve, _c_float(offset), N.ptr(out),
+                                           out.stride(0), N.ptr(tmp), tmp_bytes, N.stream()), "point_features")
+        return out
+
+
 # ------------------------------------------------------------------------------------ pointnet_sp
 def three_nn_sp(unknown, known, known_seg=None):
     """pointnet2_cuda.three_nn_wrapper of libs/pointnet_sp: returns (dist2 (N,3), idx (N,3) i32)."""

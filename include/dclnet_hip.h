@@ -129,6 +129,33 @@ int dcl_sparse_avgpool_fwd(const float *feat, const int32_t *nbr, int cap, const
                            int n_out_host, int c, int kvol, float *out, int32_t *rf,
                            dclStream_t stream);
 
+/* ---------------------------------------------------- native backbone runner ---
+ * One sparse backbone of DCL-Net (Backbone_SPCONV.forward, models/Modules.py:153-159: 4 x [SparseConv3d k3 s1 p1
+ * + BN + ReLU, SubMConv3d k3 + BN + ReLU, SparseAvgPool3d k3 s2 p1]) and its point read-out
+ * (Ops_GetPointFeat_spconv.forward, :236-251) as three enqueue-only calls with ONE host read-back of the 8 level
+ * sizes in between (the reference: ~2.5k launches, 32 blocking copies).  Workspaces are caller-allocated;
+ * `channels_host` = the 9 backbone dims [7,16,32,32,64,64,128,128,256]; counts = [n_conv1, n_pool1, ..., n_pool4].   */
+int dcl_backbone_ws_bytes(int batch, int S, int V0, int64_t *bytes_host);
+int dcl_backbone_geometry(const int32_t *occ, int V0, int batch, int S, void *ws, int64_t ws_bytes,
+                          int32_t *counts_dev /* i32[8] */, dclStream_t stream);
+int dcl_backbone_ws2_bytes(const int32_t *counts_host, const int32_t *channels_host, int64_t *bytes_host);
+/* weights_host[8]/scales_host[8]/shifts_host[8]: HOST arrays of device pointers ((27,Cin,Cout) / (Cout));
+ * level_out_host[4]: HOST array of device pointers, level m = (counts[2m+1], channels[2m+2]) floats.            */
+int dcl_backbone_features(const int32_t *occ, int V0, int batch, int S, void *ws, const int32_t *counts_host,
+                          const int32_t *channels_host, const float *vox_feats,
+                          const float *const *weights_host, const float *const *scales_host,
+                          const float *const *shifts_host, void *ws2, int64_t ws2_bytes,
+                          float *const *level_out_host, dclStream_t stream);
+/* byte offsets (inside ws) of pooled level `level`'s (b,x,y,z) rows and mask-word prefix, and its grid size */
+int dcl_backbone_level_info(int batch, int S, int V0, int level, int64_t *indices_off_host,
+                            int64_t *wprefix_off_host, int32_t *S_level_host);
+/* points_b4 (n,4) [b,x,y,z] -> out (n, ld): levels' channels side by side.  voxel_extent_host[4] = unit*scale per
+ * level (fp32), offset = -0.5*unit*64.  tmp >= 2*align256(12n) + 16*max_level_rows bytes.                         */
+int dcl_point_features(int n, const float *points_b4, int batch, int S, int V0, void *ws,
+                       const int32_t *counts_host, const int32_t *channels_host,
+                       const float *const *level_feats_host, const float *voxel_extent_host, float offset,
+                       float *out, int ld, void *tmp, int64_t tmp_bytes, dclStream_t stream);
+
 /* ----------------------------------------------------------- pointnet_sp ---
  * three_nn_wrapper(n, m, unknown(N,4), known(M,4), dist2(N,3), idx(N,3)):
  * libs/pointnet_sp/src/pointnet2_api.cpp:7 -> interpolate_gpu.cu:9-77.

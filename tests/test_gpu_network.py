@@ -73,16 +73,13 @@ def test_backbone_levels_and_indices_bit_exact(dcl, oracle):
     occ = data["inp"]["occupied_voxels"].int()
     vox = oracle.voxelize_fp(data["inp"]["feats"].numpy(), data["inp"]["v2p_maps"].numpy(), 4)
     want = G.backbone(sd, "backbone_inp", vox, occ.numpy(), [64] * 3, b)
-    sets = net._geometry_a(occ.cuda().contiguous(), b, 64)
-    flat = [a for (_, c, p) in sets for a in (c, p)]
-    for a, cnt in zip(flat, torch.cat([a.n_dev for a in flat]).cpu().tolist()):
-        a.n, a.cap, a.indices = int(cnt), max(int(cnt), 1), a.indices[:int(cnt)]
-    books = net._geometry_b(sets)
+    run = dcl.ops.BackboneRun(occ.cuda().contiguous(), b, 64)
+    run.set_counts(run.counts_dev.cpu().tolist())
     x = dcl.ops.voxelize_fp(data["inp"]["feats"].cuda(), data["inp"]["v2p_maps"].cuda(), 4)
     assert np.array_equal(x.cpu().numpy(), vox)
-    levels = net._backbone_feats(net._fold()["backbone_inp"], x, sets, books)
-    for (gx, gp), (wx, wi) in zip(levels, want):
-        assert np.array_equal(gp.indices.cpu().numpy(), wi)
+    levels = run.features(x, *net._fold()["backbone_inp_ptrs"])
+    for m, (gx, (wx, wi)) in enumerate(zip(levels, want)):
+        assert np.array_equal(run.level_indices(m).cpu().numpy(), wi)
         assert np.abs(gx.cpu().numpy() - wx).max() <= 1e-4 * max(1.0, np.abs(wx).max())
 
 
