@@ -27,8 +27,166 @@ __device__ __forceinline__ int rowmap(int e, int h) { return (e & 3) + 8 * (e >>
 
 // All operands POINT-major: X[(b*n + p)*ld + c]  (the layout the 3-NN interpolation produces and the
 // 2-D GEMMs of the MLP stacks consume; the reference's (b,C,n) tensors are transposed views of it).
+//
+// Workgroup = 4 waves = 128 queries of one crop, one wave per SIMD with the whole register file:
+// O (NVT x 16 accumulators) and the wave's Q rows stay in registers for the entire key sweep.  K/V tiles
+// of 32 keys are double-buffered in LDS: the global loads of tile t+1 are issued into staging registers
+// BEFORE the MFMAs of tile t and written to the other buffer after them, so HBM/L2 latency hides under
+// ~12k cycles of matrix work and there is one barrier per tile.
+template <int NVT>
+__global__ __launch_bounds__(256, 1) void k_cross_attn(
+    int nq, int nk, const float *__restrict__ Q, int ldq, const float *__restrict__ K, int ldk,
+    const float *__restrict__ V1, int dv1, int ldv1, float *__restrict__ O1, int ldo1,
+    const float *__restrict__ V2, int dv2, int ldv2, float *__restrict__ O2, int ldo2) {
+  constexpr int T = 256;
+  constexpr int DV = NVT * 32;
+  constexpr int KT = 32 * kKPitch;            // floats of one K tile  [32 keys][kKPitch]
+  constexpr int TILE = KT + 32 * DV;          // + V tile [32 keys][DV]
+  constexpr int NVS = (32 * (DV / 4) + T - 1) / T;   // V float4 per thread per tile
+  extern __shared__ float attn_lds[];         // [2][TILE]
+  const int b = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int q = blockIdx.x * 128 + wave * 32 + r;
+  const bool qlive = q < nq;
+
+  // B operand of S: MFMA step s contracts channels {s, 32+s}; lane half h holds channel 32h+s.
+  float Qreg[32];
+  {
+    const float4 *qp = reinterpret_cast<const float4 *>(Q + ((size_t)b * nq + (qlive ? q : 0)) * ldq + 32 * h);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float4 v = qp[i];
+      if (!qlive) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      Qreg[4 * i] = v.x; Qreg[4 * i + 1] = v.y; Qreg[4 * i + 2] = v.z; Qreg[4 * i + 3] = v.w;
+    }
+  }
+  f32x16 O[NVT];
+#pragma unroll
+  for (int t = 0; t < NVT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) O[t][e] = 0.0f;
+  float m_ref = -INFINITY, l_part = 0.0f;
+
+  static_assert((32 * (DV / 4)) % T == 0, "V tile must split evenly over the workgroup");
+  // Rows past nk are fetched from the last valid row instead of being zero-filled (branch-free loads): their
+  // scores are masked to -inf below, so their P is exactly 0 and finite V rows contribute nothing.
+  float4 kst[2], vst[NVS];
+  const int last_key = nk - 1;
+  auto stage_load = [&](int kb) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + i * T, key = min(kb + (idx >> 4), last_key), c4 = (idx & 15) * 4;
+      kst[i] = *reinterpret_cast<const float4 *>(K + ((size_t)b * nk + key) * ldk + c4);
+    }
+#pragma unroll
+    for (int i = 0; i < NVS; ++i) {
+      const int idx = tid + i * T, kk = idx / (DV / 4), c4 = (idx - kk * (DV / 4)) * 4;
+      const size_t row = (size_t)b * nk + min(kb + kk, last_key);
+      const float *src = c4 < dv1 ? V1 + row * ldv1 + c4 : V2 + row * ldv2 + (c4 - dv1);
+      vst[i] = *reinterpret_cast<const float4 *>(src);
+    }
+  };
+  auto stage_write = [&](float *buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + i * T, key = idx >> 4, c4 = (idx & 15) * 4;
+      *reinterpret_cast<float4 *>(buf + key * kKPitch + c4) = kst[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NVS; ++i) {
+      const int idx = tid + i * T, key = idx / (DV / 4), c4 = (idx - key * (DV / 4)) * 4;
+      *reinterpret_cast<float4 *>(buf + KT + key * DV + c4) = vst[i];
+    }
+  };
+
+  stage_load(0);
+  stage_write(attn_lds);
+  __syncthreads();
+  int cur = 0;
+  for (int kb = 0; kb < nk; kb += 32) {
+    const bool more = kb + 32 < nk;
+    if (more) stage_load(kb + 32);                       // in flight during this tile's MFMAs
+    const float *Ks = attn_lds + cur * TILE;
+    const float *Vs = Ks + KT;
+
+    // ---- S = K Q^T over 64 channels: A[i=key][k] = K[key][32h+s] ----
+    f32x16 S;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) S[e] = 0.0f;
+    {
+      const float *krow = Ks + r * kKPitch + 32 * h;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float4 a = *reinterpret_cast<const float4 *>(krow + 4 * i);
+        S = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, Qreg[4 * i + 0], S, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, Qreg[4 * i + 1], S, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, Qreg[4 * i + 2], S, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, Qreg[4 * i + 3], S, 0, 0, 0);
+      }
+    }
+
+    // ---- online softmax over keys (column = this lane's query) ----
+    float m_tile = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      if (kb + rowmap(e, h) >= nk) S[e] = -INFINITY;
+      m_tile = fmaxf(m_tile, S[e]);
+    }
+    m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
+    if (__ballot(m_tile > m_ref + kThr) != 0ull) {       // rare, wave-uniform
+      const float m_new = fmaxf(m_ref, m_tile);
+      const float f = __expf(m_ref - m_new);             // exp(-inf) = 0 on the first tile
+      l_part *= f;
+#pragma unroll
+      for (int t = 0; t < NVT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) O[t][e] *= f;
+      m_ref = m_new;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      S[e] = __expf(S[e] - m_ref);
+      l_part += S[e];
+    }
+
+    // ---- O += V^T P : register e of S is the B operand for key rowmap(e,h); A[i=c][k] = V[key][c] ----
+#pragma unroll
+    for (int t = 0; t < NVT; ++t) {
+      const float *vcol = Vs + t * 32 + r + 4 * h * DV;
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        O[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vcol[((e & 3) + 8 * (e >> 2)) * DV], S[e], O[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);                  // keep the LDS reads of tile t+1.. from piling up in VGPRs
+    }
+    if (more) stage_write(attn_lds + (cur ^ 1) * TILE);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");     // MFMA -> VALU read of the accumulators
+  const float l_tot = l_part + __shfl_xor(l_part, 32, 64);
+  if (qlive) {
+    const size_t row = (size_t)b * nq + q;
+#pragma unroll
+    for (int t = 0; t < NVT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = t * 32 + 8 * g + 4 * h;            // 4 consecutive channels: e = 4g .. 4g+3
+        float4 v;
+        v.x = O[t][4 * g] / l_tot; v.y = O[t][4 * g + 1] / l_tot;
+        v.z = O[t][4 * g + 2] / l_tot; v.w = O[t][4 * g + 3] / l_tot;
+        if (c < dv1) *reinterpret_cast<float4 *>(O1 + row * ldo1 + c) = v;
+        else *reinterpret_cast<float4 *>(O2 + row * ldo2 + (c - dv1)) = v;
+      }
+  }
+}
+
+// Variant for LARGE problems: 8 waves (256 queries) share one single-buffered K/V tile; the wave's Q rows are
+// parked in LDS so that two waves fit each SIMD and one wave's softmax / LDS phase overlaps the other's MFMAs.
 template <int WAVES, int NVT>
-__global__ __launch_bounds__(WAVES * 64, WAVES >= 8 ? 2 : 1) void k_cross_attn(
+__global__ __launch_bounds__(WAVES * 64, WAVES >= 8 ? 2 : 1) void k_cross_attn_shared(
     int nq, int nk, const float *__restrict__ Q, int ldq, const float *__restrict__ K, int ldk,
     const float *__restrict__ V1, int dv1, int ldv1, float *__restrict__ O1, int ldo1,
     const float *__restrict__ V2, int dv2, int ldv2, float *__restrict__ O2, int ldo2) {
@@ -296,6 +454,9 @@ __global__ void k_ortho9d(int b, const float *__restrict__ o9, float *__restrict
 
 }  // namespace
 
+static int g_attn_variant = 0;   // test hook: 1 = always the shared-tile 8-wave kernel when legal, 2 = always the 4-wave one
+DCL_API void dcl_debug_attention_variant(int v) { g_attn_variant = v; }
+
 DCL_API int dcl_cross_attention(int b, int nq, int nk, const float *Q, int ldq, const float *K, int ldk,
                                 const float *V1, int dv1, int ldv1, float *O1, int ldo1, const float *V2, int dv2,
                                 int ldv2, float *O2, int ldo2, dclStream_t stream) {
@@ -308,29 +469,44 @@ DCL_API int dcl_cross_attention(int b, int nq, int nk, const float *Q, int ldq, 
   const int nvt = (dv1 + dv2) / 32;
   DCL_CHECK_ARG(nvt == 1 || nvt == 2 || nvt == 4 || nvt == 8 || nvt == 10);
   hipStream_t s = (hipStream_t)stream;
-  // 8 waves (256 queries) share one K/V tile when that still fills the chip (2 waves/SIMD on one
-  // block per CU); small problems use 2-wave blocks, two of which fit a CU's LDS.
+  // Large grids: 8-wave workgroups sharing a K/V tile (2 waves/SIMD).  Small grids (fewer than one 8-wave
+  // workgroup per CU): 4-wave workgroups with double-buffered tiles, one per CU.
   const long long blocks8 = (long long)b * dcl_div_up(nq, 256);
-  const int waves = blocks8 >= 256 ? 8 : 2;
-  const size_t lds = (size_t)(32 * kKPitch + 32 * nvt * 32 + waves * 32 * kKPitch) * sizeof(float);
-#define ATT(W, N)                                                                                              \
+  if ((blocks8 >= 256 && g_attn_variant != 2) || g_attn_variant == 1) {
+    const size_t lds = (size_t)(32 * kKPitch + 32 * nvt * 32 + 8 * 32 * kKPitch) * sizeof(float);
+#define ATT8(N)                                                                                                \
   do {                                                                                                         \
-    if (lds > 48 * 1024)                                                                                       \
-      (void)hipFuncSetAttribute((const void *)k_cross_attn<W, N>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                (int)lds);                                                                     \
-    hipLaunchKernelGGL((k_cross_attn<W, N>), dim3(dcl_div_up(nq, W * 32), b), dim3(W * 64), lds, s, nq, nk, Q,  \
+    (void)hipFuncSetAttribute((const void *)k_cross_attn_shared<8, N>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)lds);                                                                       \
+    hipLaunchKernelGGL((k_cross_attn_shared<8, N>), dim3(dcl_div_up(nq, 256), b), dim3(512), lds, s, nq, nk, Q, \
                        ldq, K, ldk, V1, dv1, ldv1, O1, ldo1, V2, dv2, ldv2, O2, ldo2);                         \
   } while (0)
-#define ATT_N(N) do { if (waves == 8) ATT(8, N); else ATT(2, N); } while (0)
-  switch (nvt) {
-    case 1: ATT_N(1); break;
-    case 2: ATT_N(2); break;
-    case 4: ATT_N(4); break;
-    case 8: ATT_N(8); break;
-    default: ATT_N(10); break;
-  }
-#undef ATT_N
+    switch (nvt) {
+      case 1: ATT8(1); break;
+      case 2: ATT8(2); break;
+      case 4: ATT8(4); break;
+      case 8: ATT8(8); break;
+      default: ATT8(10); break;
+    }
+#undef ATT8
+  } else {
+    const size_t lds = (size_t)2 * (32 * kKPitch + 32 * nvt * 32) * sizeof(float);
+#define ATT(N)                                                                                                 \
+  do {                                                                                                         \
+    (void)hipFuncSetAttribute((const void *)k_cross_attn<N>, hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                              (int)lds);                                                                       \
+    hipLaunchKernelGGL((k_cross_attn<N>), dim3(dcl_div_up(nq, 128), b), dim3(256), lds, s, nq, nk, Q, ldq, K,   \
+                       ldk, V1, dv1, ldv1, O1, ldo1, V2, dv2, ldv2, O2, ldo2);                                 \
+  } while (0)
+    switch (nvt) {
+      case 1: ATT(1); break;
+      case 2: ATT(2); break;
+      case 4: ATT(4); break;
+      case 8: ATT(8); break;
+      default: ATT(10); break;
+    }
 #undef ATT
+  }
   DCL_LAUNCH_CHECK();
   return 0;
 }

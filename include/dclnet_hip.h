@@ -231,6 +231,8 @@ int dcl_ortho9d_to_matrix(int b, const float *o9, float *R, dclStream_t stream);
 
 /* Test hook: route every dcl_sparse_conv_fwd through the plain VALU kernel (A/B check of the MFMA one). */
 void dcl_debug_force_valu_conv(int on);
+/* Test hook: 0 = automatic choice of the attention kernel, 1 = shared-tile 8-wave variant, 2 = double-buffered 4-wave. */
+void dcl_debug_attention_variant(int v);
 
 #ifdef __cplusplus
 }

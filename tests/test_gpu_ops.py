@@ -284,12 +284,19 @@ def test_cross_attention_matches_fp64(dcl, b, nq, nk, scale):
     K = torch.randn(b, nk, 64, generator=g).cuda()
     V1 = torch.randn(b, nk, 256, generator=g).cuda()
     V2 = torch.randn(b, nk, 64, generator=g).cuda()
-    O1 = torch.empty(b * nq, 256, device="cuda")
-    O2 = torch.empty(b * nq, 64, device="cuda")
-    dcl.ops.cross_attention(b, Q.reshape(-1, 64), K.reshape(-1, 64), V1.reshape(-1, 256), O1, V2.reshape(-1, 64), O2)
     want = _attn_ref(Q, K, torch.cat([V1, V2], 2))
-    got = torch.cat([O1.view(b, nq, 256), O2.view(b, nq, 64)], 2).double()
-    assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+    lib = dcl._native.lib()
+    for variant in (0, 1, 2):                  # automatic, shared-tile 8-wave kernel, double-buffered 4-wave kernel
+        O1 = torch.empty(b * nq, 256, device="cuda")
+        O2 = torch.empty(b * nq, 64, device="cuda")
+        lib.dcl_debug_attention_variant(variant)
+        try:
+            dcl.ops.cross_attention(b, Q.reshape(-1, 64), K.reshape(-1, 64), V1.reshape(-1, 256), O1,
+                                    V2.reshape(-1, 64), O2)
+        finally:
+            lib.dcl_debug_attention_variant(0)
+        got = torch.cat([O1.view(b, nq, 256), O2.view(b, nq, 64)], 2).double()
+        assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max())), variant
 
 
 def test_cross_attention_forced_rescale(dcl):
@@ -302,10 +309,16 @@ def test_cross_attention_forced_rescale(dcl):
     K[0, 200] = Q[0, 5] * 3.0                      # huge score for query 5 in tile 6
     K[0, 300] = Q[0, 40] * 5.0
     V = torch.randn(b, nk, 64, generator=g)
-    O = torch.empty(b * nq, 64, device="cuda")
-    dcl.ops.cross_attention(b, Q.cuda().reshape(-1, 64), K.cuda().reshape(-1, 64), V.cuda().reshape(-1, 64), O)
     want = _attn_ref(Q, K, V)[0]
-    assert float((O.cpu().double() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+    lib = dcl._native.lib()
+    for variant in (1, 2):
+        O = torch.empty(b * nq, 64, device="cuda")
+        lib.dcl_debug_attention_variant(variant)
+        try:
+            dcl.ops.cross_attention(b, Q.cuda().reshape(-1, 64), K.cuda().reshape(-1, 64), V.cuda().reshape(-1, 64), O)
+        finally:
+            lib.dcl_debug_attention_variant(0)
+        assert float((O.cpu().double() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max())), variant
 
 
 def test_conf_pool_matches_torch(dcl):

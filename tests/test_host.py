@@ -1,0 +1,110 @@
+"""Host logic on CPU: frame sharding + exact metric reduction (2-process gloo), the AUC closed form against the literal
+VOCap restatement, synthetic-data determinism, config loading, state_dict layout."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_closed_form_auc_equals_vocap(dcl):
+    from oracle import graph as G
+    rng = np.random.default_rng(0)
+    for trial in range(300):
+        n = int(rng.integers(1, 40))
+        d = rng.uniform(0, 0.16, n)
+        d[rng.uniform(size=n) < 0.15] = np.inf                          # missed detections
+        if trial % 7 == 0:
+            d[:] = np.inf
+        if trial % 5 == 0 and n > 3:
+            d[1] = d[2]                                                  # ties
+        t = dcl.sharding.AddsTable()
+        for x in d:
+            t.add(3, float(x))
+        _, _, auc, acc = t.finalize()
+        want_auc, want_acc = G.vocap_auc(list(d))
+        assert abs(auc[3] - want_auc) <= 1e-4 and abs(acc[3] - want_acc) <= 1e-9, (trial, auc[3], want_auc)
+
+
+def test_shard_indices_partition():
+    dcl_sh = __import__("importlib").import_module("dcl-net_amd").sharding
+    for n, w in ((10, 3), (8, 8), (5, 8), (0, 2)):
+        parts = [dcl_sh.shard_indices(n, r, w) for r in range(w)]
+        assert sorted(sum(parts, [])) == list(range(n))
+
+
+WORKER = textwrap.dedent('''
+    import importlib, os, sys
+    import numpy as np, torch, torch.distributed as dist
+    sys.path.insert(0, %r)
+    dcl = importlib.import_module("dcl-net_amd")
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(7)
+    cls = rng.integers(0, 21, 200); d = rng.uniform(0, 0.14, 200); d[rng.uniform(size=200) < 0.1] = np.inf
+    full = dcl.sharding.AddsTable()
+    for c, x in zip(cls, d): full.add(int(c), float(x))
+    mine = dcl.sharding.AddsTable()
+    for i in dcl.sharding.shard_indices(200, rank, world): mine.add(int(cls[i]), float(d[i]))
+    mine.reduce()
+    a, b = mine.finalize(), full.finalize()
+    assert a[0] == b[0] and a[1] == b[1], (a[:2], b[:2])
+    assert np.allclose(a[2], b[2], atol=1e-9) and np.allclose(a[3], b[3])
+    dist.destroy_process_group()
+    print("rank", rank, "ok", a[0], a[1])
+''')
+
+
+def test_metric_allreduce_two_processes_gloo(tmp_path):
+    """N>1 path: world_size 2 on CPU (gloo stands in for RCCL); sharded tables reduce to the single-process result"""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("ok" in o for o in outs)
+
+
+def test_state_dict_layout_matches_survey_appendix_a(dcl):
+    net = dcl.DCL_Net.Network(dcl.synth.default_cfg(), mode="test")
+    sd = net.state_dict()
+    assert len(sd) == 270
+    assert sum(v.numel() for k, v in sd.items() if "running" not in k and "num_batches" not in k) == 8393972
+    assert tuple(sd["backbone_inp.module1.0.layers.0.weight"].shape) == (3, 3, 3, 7, 16)
+    assert tuple(sd["backbone_tmp.module4.1.layers.0.weight"].shape) == (3, 3, 3, 128, 256)
+    assert tuple(sd["disengage_Xc_m1.1.layers.0.weight"].shape) == (64, 256, 1, 1, 1)
+    assert tuple(sd["neck_fuser.layers.6.weight"].shape) == (1024, 512, 1)
+    assert tuple(sd["regressor_rot.layers.4.weight"].shape) == (9, 128, 1)
+    ref = dcl.refiner.Refiner()
+    assert len(ref.state_dict()) == 18
+    assert sum(v.numel() for v in ref.state_dict().values()) == 2103564
+    assert tuple(ref.state_dict()["MLP_share.layers.0.weight"].shape) == (512, 259, 1)
+
+
+def test_yaml_config_loader(dcl, tmp_path):
+    p = tmp_path / "cfg.yaml"
+    p.write_text("model:\n  voxelization_mode: 4\n  unit_voxel_extent: [0.006, 0.006, 0.006]\n  n_inp: 1024\n"
+                 "  n_tmp: 1024\n  backbone:\n    downsample_by_pooling: True\n    kernel_size: 3\n    bias: False\n")
+    cfg = dcl.synth.load_yaml_cfg(str(p))
+    net = dcl.DCL_Net.Network(cfg.model, mode="test")
+    assert net.n_inp == 1024 and cfg.model.backbone.kernel_size == 3
+
+
+def test_synth_batch_contract(dcl):
+    d = dcl.synth.make_batch(3, 128, 96)
+    assert d["inp"]["feats"].shape == (3 * 128, 7) and d["tmp"]["feats"].shape == (3 * 96, 7)
+    for side in ("inp", "tmp"):
+        occ, v2p, p2v = d[side]["occupied_voxels"], d[side]["v2p_maps"], d[side]["p2v_maps"]
+        assert occ.dtype == torch.int64 and v2p.dtype == torch.int32 and p2v.dtype == torch.int32
+        assert int(occ.min()) >= 0 and int(occ[:, 1:].max()) < 64
+        assert int(v2p[:, 0].sum()) == d[side]["feats"].shape[0]          # every point in exactly one voxel
+        assert bool((occ[:-1, 0] <= occ[1:, 0]).all())                    # batch-sorted (loaders guarantee it)
+    assert torch.equal(d["inp"]["feats"][:, 0], torch.ones(3 * 128))
+    again = dcl.synth.make_batch(3, 128, 96)
+    assert torch.equal(again["inp"]["feats"], d["inp"]["feats"])
