@@ -30,6 +30,27 @@ PEAK_HBM = 8000.0              # GB/s spec
 SHAPES = {"stress": (12288, 2048), "ref": (1024, 1024)}
 
 
+def pmc_traffic_bytes(kernel_substr):
+    """HBM bytes per launch of a kernel from the committed PMC passes (profiles/r*_pmc_summary.csv, separate
+    rocprofv3 --pmc runs of this same bench at the stress shape): FETCH_SIZE is doubled (gfx950 reports half of a wide
+    coalesced read, MI355X_MICROARCH.md HBM section), both counters are KiB.  None if no summary is committed."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.csv")))
+    if not files:
+        return None
+    fetch = write = None
+    for r in csv.DictReader(open(files[-1])):
+        if kernel_substr in r["kernel"]:
+            if r["counter"] == "FETCH_SIZE":
+                fetch = float(r["avg_value"])
+            elif r["counter"] == "WRITE_SIZE":
+                write = float(r["avg_value"])
+    if fetch is None or write is None:
+        return None
+    return int((2.0 * fetch + write) * 1024)
+
+
 def to_device(data, dev):
     out = {}
     for k, v in data.items():
@@ -161,7 +182,8 @@ def main():
     att_avg_ms = float(np.mean(att_ms)) if att_ms else float("nan")
     achieved = flop_dir[0] / (att_avg_ms * 1e-3) / 1e12 if att_ms else float("nan")
     roofline = {"kernel": "k_cross_attn", "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_MFMA_F32,
-                "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_F32, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_F32, 4),
+                "traffic": pmc_traffic_bytes("k_cross_attn") if args.shape == "stress" else None,
                 "avg_launch_ms": round(att_avg_ms, 4), "launches_timed": len(att_ms),
                 "flop_per_launch": flop_dir[0]}
 
