@@ -245,6 +245,158 @@ __global__ __launch_bounds__(256, 2) void k_sparse_conv_lds(
   }
 }
 
+// ---- implicit-GEMM MFMA kernel: gathered A tile AND weight tile through LDS ------------------------------------
+// The 27 offsets x Cin input channels form one long contraction axis of "virtual channels"; it is walked in chunks of
+// KC virtual channels (= G = KC/Cin whole offsets, visited in the reference's order).  Per chunk the workgroup stages
+//   As[BM rows][KC]  gathered input rows -- each row segment is read by Cin/4 consecutive lanes (full 16-B-per-lane
+//                    coalescing; the per-lane row gather of k_sparse_conv_lds used 32 B of every 128-B line it pulled)
+//   Bs[KC][BN]       the matching W rows
+// through registers (global loads for chunk j+1 are in flight during chunk j's MFMAs), then every wave feeds its 32x32
+// output tile from LDS (A: ds_read_b128, B: ds_read_b32, both conflict-free).  Chunks whose offsets no row of the
+// workgroup uses are skipped.  WC = waves along the channel axis: BM = 32*(4/WC) rows, BN = 32*WC channels.
+template <int CIN, int WC, int KC>
+__global__ __launch_bounds__(256, 2) void k_sparse_conv_tile(
+    const float *__restrict__ feat, const int32_t *__restrict__ nbr, int cap, const int32_t *__restrict__ n_out_dev,
+    int n_out_host, const float *__restrict__ W, int cout, int kvol, int subm, const float *__restrict__ scale,
+    const float *__restrict__ shift, int relu, float *__restrict__ out) {
+  constexpr int WR = 4 / WC;
+  constexpr int BM = 32 * WR, BN = 32 * WC;
+  constexpr int G = KC / CIN;                      // whole offsets per chunk
+  constexpr int AP = KC + 4;                       // A row pitch (floats): conflict-free ds_read_b128 across rows
+  constexpr int NA = BM * KC / 4 / 256;            // float4 of A per thread per chunk
+  constexpr int NB = KC * BN / 4 / 256;            // float4 of B per thread per chunk
+  static_assert(KC % CIN == 0 && NA >= 1 && NB >= 1, "tile shape");
+  extern __shared__ __attribute__((aligned(16))) float conv_lds[];
+  float *As = conv_lds;                            // [BM][AP]
+  float *Bs = conv_lds + BM * AP;                  // [KC][BN]
+  int32_t *Ns = reinterpret_cast<int32_t *>(Bs + KC * BN);   // [27][BM] neighbour rows of this row block
+  __shared__ unsigned s_kmask;
+
+  int n = n_out_dev ? *n_out_dev : n_out_host;
+  n = n < cap ? n : cap;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wr = wave / WC, wc = wave % WC;
+  const int col0 = blockIdx.y * BN;
+  const int nblk = (n + BM - 1) / BM;
+  const int nchunks = (kvol + G - 1) / G;
+
+  for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int row0 = blk * BM;
+    if (tid == 0) s_kmask = 0;
+    __syncthreads();
+    // neighbour table of the row block + which offsets it uses at all
+    unsigned mymask = 0;
+    for (int e = tid; e < kvol * BM; e += 256) {
+      const int k = e / BM, rr = e - k * BM;
+      const int v = (row0 + rr < n) ? nbr[(size_t)k * cap + row0 + rr] : -1;
+      Ns[e] = v;
+      mymask |= (v >= 0 ? 1u : 0u) << k;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mymask |= __shfl_xor(mymask, d, 64);
+    if (lane == 0 && mymask) atomicOr(&s_kmask, mymask);
+    __syncthreads();
+    const unsigned kmask = s_kmask;
+    auto chunk_used = [&](int j) {
+      unsigned m = 0;
+      for (int g = 0; g < G; ++g) {
+        const int s = j * G + g;
+        if (s < kvol) m |= (kmask >> offset_at(s, kvol, subm)) & 1u;
+      }
+      return m != 0;
+    };
+    auto next_used = [&](int from) { int q = from; while (q < nchunks && !chunk_used(q)) ++q; return q; };
+
+    float4 areg[NA], breg[NB];
+    auto fetch = [&](int j) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int f = tid + i * 256;
+        const int rr = f / (KC / 4), vc = (f - rr * (KC / 4)) * 4;
+        const int g = vc / CIN, ch = vc - g * CIN;
+        const int s = j * G + g;
+        int v = -1;
+        if (s < kvol) v = Ns[offset_at(s, kvol, subm) * BM + rr];
+        areg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (v >= 0) areg[i] = *reinterpret_cast<const float4 *>(feat + (size_t)v * CIN + ch);
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int f = tid + i * 256;
+        const int vc = f / (BN / 4), c4 = (f - vc * (BN / 4)) * 4;
+        const int g = vc / CIN, ch = vc - g * CIN;
+        const int s = j * G + g;
+        breg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s < kvol)
+          breg[i] = *reinterpret_cast<const float4 *>(W + ((size_t)offset_at(s, kvol, subm) * CIN + ch) * cout + col0 + c4);
+      }
+    };
+    auto stash = [&]() {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int f = tid + i * 256;
+        const int rr = f / (KC / 4), vc = (f - rr * (KC / 4)) * 4;
+        *reinterpret_cast<float4 *>(As + rr * AP + vc) = areg[i];
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) *reinterpret_cast<float4 *>(Bs + (tid + i * 256) * 4) = breg[i];
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    int j = next_used(0);
+    if (j < nchunks) fetch(j);
+    while (j < nchunks) {
+      __syncthreads();                                   // everyone is done reading the previous chunk's tiles
+      stash();
+      __syncthreads();
+      const int jn = next_used(j + 1);
+      if (jn < nchunks) fetch(jn);                       // in flight during the MFMAs below
+      const float *ap = As + (wr * 32 + r) * AP + 4 * h;
+      const float *bp = Bs + (4 * h) * BN + wc * 32 + r;
+#pragma unroll
+      for (int i = 0; i < KC / 8; ++i) {
+        const float4 a = *reinterpret_cast<const float4 *>(ap + 8 * i);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bp[(8 * i + 0) * BN], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bp[(8 * i + 1) * BN], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bp[(8 * i + 2) * BN], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bp[(8 * i + 3) * BN], acc, 0, 0, 0);
+      }
+      asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // MFMA -> VALU hazard pad (see k_sparse_conv_lds)
+      j = jn;
+    }
+    const int co = col0 + wc * 32 + r;
+    const float sc = scale ? scale[co] : 1.0f;
+    const float sh = scale ? shift[co] : 0.0f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int orow = row0 + wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (orow < n) {
+        float x = acc[e];
+        if (scale) x = x * sc + sh;
+        if (relu) x = fmaxf(x, 0.0f);
+        out[(size_t)orow * cout + co] = x;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int CIN, int WC, int KC>
+static void launch_conv_tile(int rows, const float *feat, const int32_t *nbr, int cap, const int32_t *n_out_dev,
+                             int n_out_host, const float *W, int cout, int kvol, int subm, const float *scale,
+                             const float *shift, int relu, float *out, hipStream_t s) {
+  constexpr int WR = 4 / WC, BM = 32 * WR, BN = 32 * WC;
+  const size_t lds = (size_t)(BM * (KC + 4) + KC * BN + 27 * BM) * sizeof(float);
+  (void)hipFuncSetAttribute((const void *)k_sparse_conv_tile<CIN, WC, KC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+  const int nblk = dcl_div_up(rows, BM);
+  hipLaunchKernelGGL((k_sparse_conv_tile<CIN, WC, KC>), dim3(nblk < 65535 ? nblk : 65535, cout / BN), dim3(256), lds, s,
+                     feat, nbr, cap, n_out_dev, n_out_host, W, cout, kvol, subm, scale, shift, relu, out);
+}
+
 // ---- sparse average pool ------------------------------------------------------------------------
 // thread = (output row, 4 channels): rf = #valid offsets (summaryRF.cu:39), then
 // out = ((0 + f_k0/rf) + f_k1/rf) + ... in ascending offset order (avgpool.cu:130).
@@ -299,7 +451,7 @@ __global__ void k_sparse_avgpool_scalar(const float *__restrict__ feat, const in
 
 }  // namespace
 
-static int g_force_valu = 0;   // test hook: 1 = plain VALU kernel for every conv, 2 = MFMA kernel without LDS staging
+static int g_force_valu = 0;   // test hook: 1 = plain VALU kernel for every conv, 2 = MFMA kernel without LDS staging, 3 = LDS-weights kernel
 DCL_API void dcl_debug_force_valu_conv(int on) { g_force_valu = on; }
 
 DCL_API int dcl_sparse_conv_fwd(const float *feat, const int32_t *nbr, int cap, const int32_t *n_out_dev,
@@ -314,7 +466,26 @@ DCL_API int dcl_sparse_conv_fwd(const float *feat, const int32_t *nbr, int cap, 
   hipStream_t s = (hipStream_t)stream;
   const bool mfma_ok = !g_force_valu && (cin % 8 == 0) && (cout % 32 == 0);
   const bool lds_ok = mfma_ok && g_force_valu != 2 && (cin == 16 || cin == 32 || cin == 64 || cin == 128);
-  if (lds_ok) {
+  if (lds_ok && g_force_valu != 3) {
+    // implicit-GEMM tile kernel: 64x64 tiles (KC=128) when Cout allows, else 128x32 tiles (KC=64)
+#define TILE_ARGS rows, feat, nbr, cap, n_out_dev, n_out_host, W, cout, kvol, subm, scale, shift, relu, out, s
+    if (cout % 64 == 0) {
+      switch (cin) {
+        case 16: launch_conv_tile<16, 2, 128>(TILE_ARGS); break;
+        case 32: launch_conv_tile<32, 2, 128>(TILE_ARGS); break;
+        case 64: launch_conv_tile<64, 2, 128>(TILE_ARGS); break;
+        default: launch_conv_tile<128, 2, 128>(TILE_ARGS); break;
+      }
+    } else {
+      switch (cin) {
+        case 16: launch_conv_tile<16, 1, 64>(TILE_ARGS); break;
+        case 32: launch_conv_tile<32, 1, 64>(TILE_ARGS); break;
+        case 64: launch_conv_tile<64, 1, 64>(TILE_ARGS); break;
+        default: launch_conv_tile<128, 1, 128>(TILE_ARGS); break;
+      }
+    }
+#undef TILE_ARGS
+  } else if (lds_ok) {
     const int nblk = dcl_div_up(rows, 128);
     // 64 output channels per workgroup when that still leaves >= ~3 workgroups per CU, else 32
     const int nt = (cout % 64 == 0 && (long long)nblk * (cout / 64) >= 768) ? 2 : 1;
