@@ -20,46 +20,124 @@
 namespace {
 
 // ------------------------------------------------------------------------------------ ball query
-template <int T>
-__global__ __launch_bounds__(T) void k_ball_query(int n, int m, float radius2, int nsample,
-                                                  const float *__restrict__ new_xyz, const float *__restrict__ xyz,
-                                                  int32_t *__restrict__ idx) {
-  extern __shared__ int32_t bq_lds[];          // hits[nsample][T+1], then cnt[T]
+// FOUR lanes per centre.  Per 256-candidate tile (staged in LDS as x[]/y[]/z[] arrays, broadcast read, packed f32x2 math)
+// each of the 4 lanes tests a contiguous 64-candidate quarter and builds a 64-bit hit mask -- branch-free, no
+// stores; the quarter masks, taken in order, list the hits in ascending index, so the group's leader appends the
+// first `nsample` of them to its LDS column ([slot][centre], +1 padded) at a cost proportional to the HITS, not the
+// candidates.  A workgroup (one wave, 16 centres) leaves as soon as all its centres are full; rows go out coalesced,
+// padded with the first hit (ball_query_gpu.cu:35-39).
+constexpr int kBQTile = 256;
+constexpr int kBQCentres = 16;                 // centres per workgroup = one wave: it leaves as soon as ITS 16 are full
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(64) void k_ball_query(int n, int m, float radius2, int nsample,
+                                                   const float *__restrict__ new_xyz, const float *__restrict__ xyz,
+                                                   int32_t *__restrict__ idx) {
+  extern __shared__ int32_t bq_lds[];          // hits[nsample][17], cnt[16], tile x[256] y[256] z[256]
+  constexpr int P = kBQCentres + 1;
   int32_t *hits = bq_lds;
-  int32_t *cnts = bq_lds + (size_t)nsample * (T + 1);
+  int32_t *cnts = bq_lds + (size_t)nsample * P;
+  float *tx = reinterpret_cast<float *>(bq_lds + (((size_t)nsample * P + kBQCentres + 3) & ~(size_t)3));
+  float *ty = tx + kBQTile, *tz = ty + kBQTile;
   const int bs = blockIdx.y;
   const int t = threadIdx.x;
-  const int p = blockIdx.x * T + t;
+  const int sub = t & 3, cs = t >> 2;
+  const int p = blockIdx.x * kBQCentres + cs;
   const bool live = p < m;
   const float *c = new_xyz + ((size_t)bs * m + (live ? p : 0)) * 3;
-  const float cx = c[0], cy = c[1], cz = c[2];
+  const f32x2 cx = {c[0], c[0]}, cy = {c[1], c[1]}, cz = {c[2], c[2]};
   const float *X = xyz + (size_t)bs * n * 3;
-  int cnt = live ? 0 : nsample;
-  for (int k = 0; k < n; ++k) {
-    if (__ballot(cnt < nsample) == 0ull) break;          // every centre of this wave is full
-    const float d2 = dcl_dist2(cx, cy, cz, X[k * 3], X[k * 3 + 1], X[k * 3 + 2]);
-    if (d2 < radius2 && cnt < nsample) {
-      hits[(size_t)cnt * (T + 1) + t] = k;
-      ++cnt;
+  int cnt = live ? 0 : nsample;                // kept identical in the 4 lanes of a group
+  for (int base = 0; base < n; base += kBQTile) {
+    if (__ballot(cnt < nsample) == 0ull) break;          // all 16 centres of this wave are full
+    const int tn = min(kBQTile, n - base);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kBQTile / 64; ++i) {
+      const int j = t + i * 64;
+      float x = 3.0e38f, y = 3.0e38f, z = 3.0e38f;       // padding rows: never within any radius
+      if (j < tn) { const float *q = X + (size_t)(base + j) * 3; x = q[0]; y = q[1]; z = q[2]; }
+      tx[j] = x; ty[j] = y; tz[j] = z;
     }
+    __syncthreads();
+    // two candidates per packed instruction; same fma association as dcl_dist2, per component
+    unsigned mlo = 0u, mhi = 0u;
+    const f32x2 *px = reinterpret_cast<const f32x2 *>(tx + sub * 64);
+    const f32x2 *py = reinterpret_cast<const f32x2 *>(ty + sub * 64);
+    const f32x2 *pz = reinterpret_cast<const f32x2 *>(tz + sub * 64);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const f32x2 dx = cx - px[i], dy = cy - py[i], dz = cz - pz[i];
+      const f32x2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));
+      const unsigned b0 = d2.x < radius2 ? 1u : 0u, b1 = d2.y < radius2 ? 1u : 0u;
+      if (i < 16) mlo |= (b0 << (2 * i)) | (b1 << (2 * i + 1));
+      else mhi |= (b0 << (2 * i - 32)) | (b1 << (2 * i - 31));
+    }
+    const unsigned long long mask = ((unsigned long long)mhi << 32) | mlo;
+    // the leader (sub 0) walks the 4 quarter masks in index order
+    const int lead = t & ~3;
+    unsigned long long mq[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) mq[s] = __shfl(mask, lead + s, 64);
+    if (sub == 0) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        unsigned long long mm = mq[s];
+        while (mm != 0ull && cnt < nsample) {
+          const int bit = __ffsll((long long)mm) - 1;
+          mm &= mm - 1ull;
+          hits[(size_t)cnt * P + cs] = base + s * 64 + bit;
+          ++cnt;
+        }
+      }
+    }
+    cnt = __shfl(cnt, lead, 64);
   }
-  cnts[t] = live ? cnt : 0;
+  if (sub == 0) cnts[cs] = live ? cnt : 0;
   __syncthreads();
-  // coalesced write-out: pad with the first hit (ball_query_gpu.cu:35-39), zeros if none
-  const int p0 = blockIdx.x * T;
-  const int rows = min(T, m - p0);
+  const int p0 = blockIdx.x * kBQCentres;
+  const int rows = min(kBQCentres, m - p0);
   int32_t *o = idx + ((size_t)bs * m + p0) * nsample;
-  for (int e = t; e < rows * nsample; e += T) {
+  for (int e = t; e < rows * nsample; e += 64) {
     const int r = e / nsample, s = e - r * nsample;
     const int cr = cnts[r];
     int v = 0;
-    if (cr > 0) v = hits[(size_t)(s < cr ? s : 0) * (T + 1) + r];
+    if (cr > 0) v = hits[(size_t)(s < cr ? s : 0) * P + r];
     o[e] = v;
   }
 }
 
 // ---------------------------------------------------------------------------- group / gather
-// thread = 4 consecutive outputs of one (b, p*ns+s) run, looped over a chunk of channels.
+// LDS-staged gather: a workgroup owns CC channel rows of one cloud (CC*N floats in LDS, filled with coalesced 16-B
+// loads) and streams the whole (npoints*nsample) index list against them: indices are read once per CC channels,
+// every output leaves as a 16-B store, and the random reads hit LDS instead of the vector-memory path.
+template <int CC>
+__global__ __launch_bounds__(1024) void k_group_points_lds(int c, int n, int nps, const float *__restrict__ points,
+                                                          const int32_t *__restrict__ idx, float *__restrict__ out) {
+  extern __shared__ float gp_lds[];            // [CC][n]
+  const int bs = blockIdx.z;
+  const int c0 = blockIdx.y * CC;
+  const int ncc = min(CC, c - c0);
+  const float *P = points + ((size_t)bs * c + c0) * n;
+  for (int j = threadIdx.x; j < ncc * n; j += 1024) gp_lds[j] = P[j];
+  __syncthreads();
+  const int nq = nps >> 2;
+  const int4 *I = reinterpret_cast<const int4 *>(idx + (size_t)bs * nps);
+  float *O = out + ((size_t)bs * c + c0) * nps;
+#pragma unroll 2
+  for (int q = blockIdx.x * 1024 + threadIdx.x; q < nq; q += gridDim.x * 1024) {
+    const int4 id = I[q];
+#pragma unroll
+    for (int j = 0; j < CC; ++j) {
+      if (j >= ncc) break;
+      const float *row = gp_lds + j * n;
+      float4 v;
+      v.x = row[id.x]; v.y = row[id.y]; v.z = row[id.z]; v.w = row[id.w];
+      reinterpret_cast<float4 *>(O + (size_t)j * nps)[q] = v;
+    }
+  }
+}
+
+// direct-gather variant (rows too long for LDS, or npoints*nsample not a multiple of 4)
 template <int CCHUNK>
 __global__ void k_group_points(int c, int n, int nps /* npoints*nsample */, const float *__restrict__ points,
                                const int32_t *__restrict__ idx, float *__restrict__ out) {
@@ -238,21 +316,12 @@ DCL_API int dcl_ball_query(int b, int n, int m, float radius, int nsample, const
   DCL_CHECK_ARG(new_xyz && idx && (n == 0 || xyz) && b <= 65535);
   hipStream_t s = (hipStream_t)stream;
   const float r2 = radius * radius;
-  // LDS: nsample*(T+1) + T ints; pick the largest T in {256,128,64} that fits 160 KiB / 2 blocks
-  const size_t budget = 80 * 1024;
-  int T = 256;
-  while (T > 64 && ((size_t)nsample * (T + 1) + T) * 4 > budget) T >>= 1;
-  const size_t lds = ((size_t)nsample * (T + 1) + T) * 4;
+  const size_t lds = ((((size_t)nsample * (kBQCentres + 1) + kBQCentres + 3) & ~(size_t)3)) * 4 + (size_t)kBQTile * 12;
   DCL_CHECK_ARG(lds <= 160 * 1024);
-#define BQ(TT)                                                                                                 \
-  do {                                                                                                         \
-    if (lds > 48 * 1024)                                                                                       \
-      (void)hipFuncSetAttribute((const void *)k_ball_query<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL((k_ball_query<TT>), dim3(dcl_div_up(m, TT), b), dim3(TT), lds, s, n, m, r2, nsample,     \
-                       new_xyz, xyz, idx);                                                                     \
-  } while (0)
-  if (T == 256) BQ(256); else if (T == 128) BQ(128); else BQ(64);
-#undef BQ
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute((const void *)k_ball_query, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k_ball_query, dim3(dcl_div_up(m, kBQCentres), b), dim3(64), lds, s, n, m, r2, nsample, new_xyz,
+                     xyz, idx);
   DCL_LAUNCH_CHECK();
   return 0;
 }
@@ -264,7 +333,27 @@ DCL_API int dcl_group_points(int b, int c, int n, int npoints, int nsample, cons
   if (b == 0 || c == 0 || nps == 0) return 0;
   DCL_CHECK_ARG(points && idx && out && b <= 65535 && c <= 65535 && nps < (1ll << 31));
   hipStream_t s = (hipStream_t)stream;
-  if (nps % 4 == 0) {
+  if (nps % 4 == 0 && n <= 36 * 1024 && nps >= 4096) {
+    // LDS-staged rows: as many channel rows per workgroup as fit ~144 KiB (1 workgroup of 512 threads per CU)
+    const int cc = (int)((144 * 1024) / ((size_t)n * 4));
+    const size_t lds = (size_t)(cc >= 4 ? 4 : cc >= 3 ? 3 : cc >= 2 ? 2 : 1) * n * 4;
+    const int ccu = cc >= 4 ? 4 : cc >= 3 ? 3 : cc >= 2 ? 2 : 1;
+    const int ychunks = dcl_div_up(c, ccu);
+    // enough x-blocks to give every CU work, few enough that the row fill stays a small fraction
+    int xb = dcl_div_up(256 * 2, ychunks * b);
+    if (xb < 1) xb = 1;
+    const int max_xb = dcl_div_up(nps / 4, 1024 * 8);
+    if (xb > max_xb) xb = max_xb > 0 ? max_xb : 1;
+#define GPL(CCU)                                                                                               \
+  do {                                                                                                         \
+    (void)hipFuncSetAttribute((const void *)k_group_points_lds<CCU>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)lds);                                                                       \
+    hipLaunchKernelGGL((k_group_points_lds<CCU>), dim3(xb, ychunks, b), dim3(1024), lds, s, c, n, (int)nps, points, \
+                       idx, out);                                                                              \
+  } while (0)
+    if (ccu == 4) GPL(4); else if (ccu == 3) GPL(3); else if (ccu == 2) GPL(2); else GPL(1);
+#undef GPL
+  } else if (nps % 4 == 0) {
     constexpr int CC = 8;
     hipLaunchKernelGGL((k_group_points<CC>), dim3(dcl_div_up(nps / 4, 256), dcl_div_up(c, CC), b), dim3(256), 0, s, c,
                        n, (int)nps, points, idx, out);
