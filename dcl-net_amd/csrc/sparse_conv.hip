@@ -56,6 +56,55 @@ __global__ void k_sparse_conv_valu(const float *__restrict__ feat, const int32_t
   }
 }
 
+// ---- stem kernel: small Cin/Cout known at compile time (DCL-Net: 7 -> 16) ------------------------------------
+// one thread per output row, all COUT channels in registers; W (kvol x CIN x COUT) lives in LDS and is read as
+// wave-uniform broadcasts.  Same summation order as the generic kernel (per offset an ascending-ci fmaf chain, then one add).
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void k_sparse_conv_stem(const float *__restrict__ feat, const int32_t *__restrict__ nbr,
+                                                          int cap, const int32_t *__restrict__ n_out_dev, int n_out_host,
+                                                          const float *__restrict__ W, int kvol, int subm,
+                                                          const float *__restrict__ scale, const float *__restrict__ shift,
+                                                          int relu, float *__restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float Ws[27 * CIN * COUT];
+  int n = n_out_dev ? *n_out_dev : n_out_host;
+  n = n < cap ? n : cap;
+  for (int i = threadIdx.x; i < kvol * CIN * COUT; i += 256) Ws[i] = W[i];
+  __syncthreads();
+  for (int row = blockIdx.x * 256 + threadIdx.x; row < n; row += gridDim.x * 256) {
+    float acc[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] = 0.0f;
+    for (int s = 0; s < kvol; ++s) {
+      const int k = offset_at(s, kvol, subm);
+      const int v = nbr[(size_t)k * cap + row];
+      if (v < 0) continue;
+      float f[CIN];
+#pragma unroll
+      for (int ci = 0; ci < CIN; ++ci) f[ci] = feat[(size_t)v * CIN + ci];
+      const float *w = Ws + k * CIN * COUT;
+      float part[COUT];
+#pragma unroll
+      for (int co = 0; co < COUT; ++co) part[co] = 0.0f;
+#pragma unroll
+      for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) part[co] = __fmaf_rn(f[ci], w[ci * COUT + co], part[co]);
+#pragma unroll
+      for (int co = 0; co < COUT; ++co) acc[co] = acc[co] + part[co];
+    }
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+      float x = acc[co];
+      if (scale) x = x * scale[co] + shift[co];
+      if (relu) x = fmaxf(x, 0.0f);
+      acc[co] = x;
+    }
+    float4 *o = reinterpret_cast<float4 *>(out + (size_t)row * COUT);
+#pragma unroll
+    for (int q = 0; q < COUT / 4; ++q) o[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+  }
+}
+
 // ---- MFMA kernel: Cin % 8 == 0, Cout % (32*NT) == 0 ---------------------------------------------
 // wave = 32 output rows x (32*NT) output channels; grid.y walks the channel tiles so that small
 // (deep) layers still put >= 2-3 waves on every SIMD.
@@ -354,8 +403,16 @@ __global__ __launch_bounds__(256, 2) void k_sparse_conv_tile(
       __syncthreads();
       const int jn = next_used(j + 1);
       if (jn < nchunks) fetch(jn);                       // in flight during the MFMAs below
+      // wave-level skip: none of this wave's 32 rows has a neighbour under any offset of the chunk
+      bool mine = false;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const int sg = j * G + g;
+        if (sg < kvol) mine |= Ns[offset_at(sg, kvol, subm) * BM + wr * 32 + r] >= 0;
+      }
       const float *ap = As + (wr * 32 + r) * AP + 4 * h;
       const float *bp = Bs + (4 * h) * BN + wc * 32 + r;
+      if (__ballot(mine) != 0ull)
 #pragma unroll
       for (int i = 0; i < KC / 8; ++i) {
         const float4 a = *reinterpret_cast<const float4 *>(ap + 8 * i);
@@ -513,6 +570,9 @@ DCL_API int dcl_sparse_conv_fwd(const float *feat, const int32_t *nbr, int cap, 
     else
       hipLaunchKernelGGL((k_sparse_conv_mfma<1>), dim3(blocks, ytiles), dim3(256), 0, s, feat, nbr, cap, n_out_dev,
                          n_out_host, W, cin, cout, kvol, subm, scale, shift, relu, out);
+  } else if (cin == 7 && cout == 16 && kvol <= 27 && g_force_valu != 1) {
+    hipLaunchKernelGGL((k_sparse_conv_stem<7, 16>), dim3(dcl_grid_1d(rows, 256)), dim3(256), 0, s, feat, nbr, cap,
+                       n_out_dev, n_out_host, W, kvol, subm, scale, shift, relu, out);
   } else {
     hipLaunchKernelGGL(k_sparse_conv_valu, dim3(dcl_grid_1d((long long)rows * cout, 256)), dim3(256), 0, s, feat,
                        nbr, cap, n_out_dev, n_out_host, W, cin, cout, kvol, subm, scale, shift, relu, out);
