@@ -311,6 +311,169 @@ __global__ __launch_bounds__(WAVES * 64, WAVES >= 8 ? 2 : 1) void k_cross_attn_s
   }
 }
 
+// Variant for LARGE problems with DCL-Net's own channel split (V1 = 256 ch, V2 = 64 ch): the shared-tile kernel above
+// plus an asynchronous tile pipeline.  The V tile (40 of the 48 KiB per 32 keys) is double-buffered in LDS and filled
+// by LDS-DMA (global_load_lds_dwordx4: no staging registers; each wave-instruction lands 1 KiB = one V1 row or four
+// V2 rows), issued right after the barrier that retires the buffer's previous readers, so it has a whole tile of MFMA
+// work (~10 us) to land.  K (8 KiB) goes through one float4 register per thread, loaded before P.V and written after it.
+// Two barriers per tile as before, but no global-memory latency between them:
+//   A (__syncthreads: drains this wave's DMA + K write)  ->  issue DMA V(t+1)  ->  S = K Q^T, softmax
+//   B (raw s_barrier, lgkmcnt only: K tile free)         ->  load K(t+1)       ->  O += V^T P  ->  write K(t+1)
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+// One LDS-DMA wave-instruction: 64 lanes x 16 B from per-lane global addresses to LDS at (wave-uniform) lds_byte_addr +
+// lane*16.  Inline asm on purpose: issued through the builtin, hipcc drains it (vmcnt(0)) before the next ds_read of the
+// same LDS array, which would serialise the pipeline; an asm load is not in the compiler's counters, so the kernel waits
+// for it itself (s_waitcnt vmcnt(0) before barrier A).  M0 is saved/restored inside the statement (guide section 5.7).
+__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_byte_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_byte_addr)
+               : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const float *p) {
+  return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void_t *)p);
+}
+
+__global__ __launch_bounds__(512, 2) void k_cross_attn_dma(
+    int nq, int nk, const float *__restrict__ Q, int ldq, const float *__restrict__ K, int ldk,
+    const float *__restrict__ V1, int ldv1, float *__restrict__ O1, int ldo1,
+    const float *__restrict__ V2, int ldv2, float *__restrict__ O2, int ldo2) {
+  constexpr int NVT = 10;
+  constexpr int KT = 32 * kKPitch;                 // K tile floats
+  constexpr int V1T = 32 * 256, V2T = 32 * 64;     // per-buffer floats
+  extern __shared__ float attn_lds[];              // [K][V1 x2][V2 x2][Q x8]  (one array: see guide, LDS-DMA traps)
+  float *Ks = attn_lds;
+  float *V1s = Ks + KT;
+  float *V2s = V1s + 2 * V1T;
+  const int b = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int q = blockIdx.x * 256 + wave * 32 + r;
+  const bool qlive = q < nq;
+  float *Qs = V2s + 2 * V2T + wave * 32 * kKPitch;
+  for (int i = lane; i < 32 * 16; i += 64) {
+    const int qr = i >> 4, c4 = (i & 15) * 4;
+    const int qq = blockIdx.x * 256 + wave * 32 + qr;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (qq < nq) v = *reinterpret_cast<const float4 *>(Q + ((size_t)b * nq + qq) * ldq + c4);
+    *reinterpret_cast<float4 *>(Qs + qr * kKPitch + c4) = v;
+  }
+  const int last_key = nk - 1;
+  const size_t krow0 = (size_t)b * nk;
+  // this wave's share of a V tile: V1 rows 4w..4w+3 (one 1-KiB DMA each), V2 rows 4w..4w+3 (one DMA for all four)
+  auto dma_v = [&](int kb, int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int key = wave * 4 + i;
+      const float *src = V1 + (krow0 + min(kb + key, last_key)) * ldv1 + lane * 4;
+      glds16(src, lds_addr_of(V1s + buf * V1T + key * 256));
+    }
+    const int key2 = wave * 4 + (lane >> 4);
+    const float *src2 = V2 + (krow0 + min(kb + key2, last_key)) * ldv2 + (lane & 15) * 4;
+    glds16(src2, lds_addr_of(V2s + buf * V2T + wave * 4 * 64));
+  };
+  const int kkey = tid >> 4, kc4 = (tid & 15) * 4;           // this thread's float4 of the K tile
+  auto load_k = [&](int kb) {
+    return *reinterpret_cast<const float4 *>(K + (krow0 + min(kb + kkey, last_key)) * ldk + kc4);
+  };
+
+  f32x16 O[NVT];
+#pragma unroll
+  for (int t = 0; t < NVT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) O[t][e] = 0.0f;
+  float m_ref = -INFINITY, l_part = 0.0f;
+
+  *reinterpret_cast<float4 *>(Ks + kkey * kKPitch + kc4) = load_k(0);
+  dma_v(0, 0);
+  int cur = 0;
+  for (int kb = 0; kb < nk; kb += 32) {
+    const bool more = kb + 32 < nk;
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): this wave's DMA pieces of tile t have landed (a
+                                                           // builtin, so hipcc's own counters see the drain too)
+    __syncthreads();                                       // A
+    if (more) dma_v(kb + 32, cur ^ 1);
+
+    f32x16 S;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) S[e] = 0.0f;
+    {
+      const float *krow = Ks + r * kKPitch + 32 * h;
+      const float *qrow = Qs + r * kKPitch + 32 * h;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float4 a = *reinterpret_cast<const float4 *>(krow + 4 * i);
+        const float4 qv = *reinterpret_cast<const float4 *>(qrow + 4 * i);
+        S = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qv.x, S, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qv.y, S, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qv.z, S, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qv.w, S, 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);                    // lgkmcnt(0) only: the DMA stays in flight
+    __builtin_amdgcn_s_barrier();                          // B: every wave is done with the K tile
+    float4 knext = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (more) knext = load_k(kb + 32);
+
+    float m_tile = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      if (kb + rowmap(e, h) >= nk) S[e] = -INFINITY;
+      m_tile = fmaxf(m_tile, S[e]);
+    }
+    m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
+    if (__ballot(m_tile > m_ref + kThr) != 0ull) {
+      const float m_new = fmaxf(m_ref, m_tile);
+      const float f = __expf(m_ref - m_new);
+      l_part *= f;
+#pragma unroll
+      for (int t = 0; t < NVT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) O[t][e] *= f;
+      m_ref = m_new;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      S[e] = __expf(S[e] - m_ref);
+      l_part += S[e];
+    }
+
+    const float *v1b = V1s + cur * V1T + 4 * h * 256 + r;
+    const float *v2b = V2s + cur * V2T + 4 * h * 64 + r;
+#pragma unroll
+    for (int t = 0; t < NVT; ++t) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int krow = (e & 3) + 8 * (e >> 2);
+        const float a = t < 8 ? v1b[krow * 256 + t * 32] : v2b[krow * 64 + (t - 8) * 32];
+        O[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, S[e], O[t], 0, 0, 0);
+      }
+    }
+    if (more) *reinterpret_cast<float4 *>(Ks + kkey * kKPitch + kc4) = knext;
+    cur ^= 1;
+  }
+
+  asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+  const float l_tot = l_part + __shfl_xor(l_part, 32, 64);
+  if (qlive) {
+    const size_t row = (size_t)b * nq + q;
+#pragma unroll
+    for (int t = 0; t < NVT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = t * 32 + 8 * g + 4 * h;
+        float4 v;
+        v.x = O[t][4 * g] / l_tot; v.y = O[t][4 * g + 1] / l_tot;
+        v.z = O[t][4 * g + 2] / l_tot; v.w = O[t][4 * g + 3] / l_tot;
+        if (c < 256) *reinterpret_cast<float4 *>(O1 + row * ldo1 + c) = v;
+        else *reinterpret_cast<float4 *>(O2 + row * ldo2 + (c - 256)) = v;
+      }
+  }
+}
+
 // ---- confidence pooling (models/DCL_Net.py:217-228) ------------------------------------------------
 // conf = sigmoid(cat[logit1 (b,n1), logit2 (b,n2)]); w = softmax(conf) over L = n1+n2;
 // pooled1[c] = sum_{j<n1} w_j F1[j][c], pooled2[c] = sum_{j<n2} w_{n1+j} F2[j][c] (F point-major),
@@ -454,7 +617,7 @@ __global__ void k_ortho9d(int b, const float *__restrict__ o9, float *__restrict
 
 }  // namespace
 
-static int g_attn_variant = 0;   // test hook: 1 = always the shared-tile 8-wave kernel when legal, 2 = always the 4-wave one
+static int g_attn_variant = 0;   // test hook: 1 = shared-tile 8-wave kernel, 2 = 4-wave double-buffered, 3 = 8-wave LDS-DMA pipeline
 DCL_API void dcl_debug_attention_variant(int v) { g_attn_variant = v; }
 
 DCL_API int dcl_cross_attention(int b, int nq, int nk, const float *Q, int ldq, const float *K, int ldk,
@@ -472,7 +635,12 @@ DCL_API int dcl_cross_attention(int b, int nq, int nk, const float *Q, int ldq, 
   // Large grids: 8-wave workgroups sharing a K/V tile (2 waves/SIMD).  Small grids (fewer than one 8-wave
   // workgroup per CU): 4-wave workgroups with double-buffered tiles, one per CU.
   const long long blocks8 = (long long)b * dcl_div_up(nq, 256);
-  if ((blocks8 >= 256 && g_attn_variant != 2) || g_attn_variant == 1) {
+  if (dv1 == 256 && dv2 == 64 && ((blocks8 >= 256 && g_attn_variant == 0) || g_attn_variant == 3)) {
+    const size_t lds = (size_t)(32 * kKPitch + 2 * 32 * 256 + 2 * 32 * 64 + 8 * 32 * kKPitch) * sizeof(float);
+    (void)hipFuncSetAttribute((const void *)k_cross_attn_dma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_cross_attn_dma, dim3(dcl_div_up(nq, 256), b), dim3(512), lds, s, nq, nk, Q, ldq, K, ldk, V1,
+                       ldv1, O1, ldo1, V2, ldv2, O2, ldo2);
+  } else if ((blocks8 >= 256 && g_attn_variant != 2) || g_attn_variant == 1) {
     const size_t lds = (size_t)(32 * kKPitch + 32 * nvt * 32 + 8 * 32 * kKPitch) * sizeof(float);
 #define ATT8(N)                                                                                                \
   do {                                                                                                         \

@@ -286,7 +286,7 @@ def test_cross_attention_matches_fp64(dcl, b, nq, nk, scale):
     V2 = torch.randn(b, nk, 64, generator=g).cuda()
     want = _attn_ref(Q, K, torch.cat([V1, V2], 2))
     lib = dcl._native.lib()
-    for variant in (0, 1, 2):                  # automatic, shared-tile 8-wave kernel, double-buffered 4-wave kernel
+    for variant in (0, 1, 2, 3):               # automatic, shared-tile 8-wave, double-buffered 4-wave, 8-wave LDS-DMA
         O1 = torch.empty(b * nq, 256, device="cuda")
         O2 = torch.empty(b * nq, 64, device="cuda")
         lib.dcl_debug_attention_variant(variant)
@@ -319,6 +319,31 @@ def test_cross_attention_forced_rescale(dcl):
         finally:
             lib.dcl_debug_attention_variant(0)
         assert float((O.cpu().double() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max())), variant
+
+
+def test_cross_attention_dma_variant_ragged_and_rescale(dcl):
+    """the LDS-DMA pipeline (variant 3, DCL-Net's 256+64 channel split): key count not a multiple of 32, query count not
+    a multiple of 256, and a forced late rescale"""
+    b, nq, nk = 2, 300, 1000 + 13
+    g = torch.Generator().manual_seed(11)
+    Q = torch.randn(b, nq, 64, generator=g)
+    K = torch.randn(b, nk, 64, generator=g) * 0.2
+    K[0, 900] = Q[0, 7] * 4.0
+    K[1, 1012] = Q[1, 299] * 6.0                      # spike in the very last (partial) tile
+    V1, V2 = torch.randn(b, nk, 256, generator=g), torch.randn(b, nk, 64, generator=g)
+    want = _attn_ref(Q, K, torch.cat([V1, V2], 2))
+    lib = dcl._native.lib()
+    O1 = torch.empty(b * nq, 256, device="cuda")
+    O2 = torch.empty(b * nq, 64, device="cuda")
+    lib.dcl_debug_attention_variant(3)
+    try:
+        for _ in range(3):                              # repeated launches: races in the tile pipeline would show as flakiness
+            dcl.ops.cross_attention(b, Q.cuda().reshape(-1, 64), K.cuda().reshape(-1, 64), V1.cuda().reshape(-1, 256), O1,
+                                    V2.cuda().reshape(-1, 64), O2)
+            got = torch.cat([O1.view(b, nq, 256), O2.view(b, nq, 64)], 2).cpu().double()
+            assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+    finally:
+        lib.dcl_debug_attention_variant(0)
 
 
 def test_conf_pool_matches_torch(dcl):
