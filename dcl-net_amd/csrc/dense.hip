@@ -336,7 +336,8 @@ __device__ __forceinline__ unsigned lds_addr_of(const float *p) {
   return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void_t *)p);
 }
 
-__global__ __launch_bounds__(512, 2) void k_cross_attn_dma(
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_cross_attn_dma(
     int nq, int nk, const float *__restrict__ Q, int ldq, const float *__restrict__ K, int ldk,
     const float *__restrict__ V1, int ldv1, float *__restrict__ O1, int ldo1,
     const float *__restrict__ V2, int ldv2, float *__restrict__ O2, int ldo2) {
@@ -351,33 +352,51 @@ __global__ __launch_bounds__(512, 2) void k_cross_attn_dma(
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
-  const int q = blockIdx.x * 256 + wave * 32 + r;
+  constexpr int QB = WAVES * 32;                   // queries per workgroup
+  const int q = blockIdx.x * QB + wave * 32 + r;
   const bool qlive = q < nq;
   float *Qs = V2s + 2 * V2T + wave * 32 * kKPitch;
   for (int i = lane; i < 32 * 16; i += 64) {
     const int qr = i >> 4, c4 = (i & 15) * 4;
-    const int qq = blockIdx.x * 256 + wave * 32 + qr;
+    const int qq = blockIdx.x * QB + wave * 32 + qr;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (qq < nq) v = *reinterpret_cast<const float4 *>(Q + ((size_t)b * nq + qq) * ldq + c4);
     *reinterpret_cast<float4 *>(Qs + qr * kKPitch + c4) = v;
   }
   const int last_key = nk - 1;
   const size_t krow0 = (size_t)b * nk;
-  // this wave's share of a V tile: V1 rows 4w..4w+3 (one 1-KiB DMA each), V2 rows 4w..4w+3 (one DMA for all four)
+  // this wave's share of a V tile: RPW = 32/WAVES V1 rows (one 1-KiB DMA each) and the same V2 rows (4 rows per DMA)
+  constexpr int RPW = 32 / WAVES;
   auto dma_v = [&](int kb, int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int key = wave * 4 + i;
+    for (int i = 0; i < RPW; ++i) {
+      const int key = wave * RPW + i;
       const float *src = V1 + (krow0 + min(kb + key, last_key)) * ldv1 + lane * 4;
       glds16(src, lds_addr_of(V1s + buf * V1T + key * 256));
     }
-    const int key2 = wave * 4 + (lane >> 4);
-    const float *src2 = V2 + (krow0 + min(kb + key2, last_key)) * ldv2 + (lane & 15) * 4;
-    glds16(src2, lds_addr_of(V2s + buf * V2T + wave * 4 * 64));
+#pragma unroll
+    for (int i = 0; i < RPW / 4; ++i) {
+      const int key2 = wave * RPW + i * 4 + (lane >> 4);
+      const float *src2 = V2 + (krow0 + min(kb + key2, last_key)) * ldv2 + (lane & 15) * 4;
+      glds16(src2, lds_addr_of(V2s + buf * V2T + (wave * RPW + i * 4) * 64));
+    }
   };
-  const int kkey = tid >> 4, kc4 = (tid & 15) * 4;           // this thread's float4 of the K tile
-  auto load_k = [&](int kb) {
-    return *reinterpret_cast<const float4 *>(K + (krow0 + min(kb + kkey, last_key)) * ldk + kc4);
+  // this thread's float4(s) of the K tile: 512 per tile over WAVES*64 threads
+  constexpr int KPT = 512 / (WAVES * 64);
+  auto k_slot = [&](int i, int &key, int &c4) { const int idx = tid + i * WAVES * 64; key = idx >> 4; c4 = (idx & 15) * 4; };
+  auto load_k = [&](int kb, float4 *dst) {
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      int key, c4; k_slot(i, key, c4);
+      dst[i] = *reinterpret_cast<const float4 *>(K + (krow0 + min(kb + key, last_key)) * ldk + c4);
+    }
+  };
+  auto store_k = [&](const float4 *src) {
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      int key, c4; k_slot(i, key, c4);
+      *reinterpret_cast<float4 *>(Ks + key * kKPitch + c4) = src[i];
+    }
   };
 
   f32x16 O[NVT];
@@ -387,7 +406,9 @@ __global__ __launch_bounds__(512, 2) void k_cross_attn_dma(
     for (int e = 0; e < 16; ++e) O[t][e] = 0.0f;
   float m_ref = -INFINITY, l_part = 0.0f;
 
-  *reinterpret_cast<float4 *>(Ks + kkey * kKPitch + kc4) = load_k(0);
+  float4 knext[KPT];
+  load_k(0, knext);
+  store_k(knext);
   dma_v(0, 0);
   int cur = 0;
   for (int kb = 0; kb < nk; kb += 32) {
@@ -415,8 +436,7 @@ __global__ __launch_bounds__(512, 2) void k_cross_attn_dma(
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);                    // lgkmcnt(0) only: the DMA stays in flight
     __builtin_amdgcn_s_barrier();                          // B: every wave is done with the K tile
-    float4 knext = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (more) knext = load_k(kb + 32);
+    if (more) load_k(kb + 32, knext);
 
     float m_tile = -INFINITY;
 #pragma unroll
@@ -452,7 +472,7 @@ __global__ __launch_bounds__(512, 2) void k_cross_attn_dma(
         O[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, S[e], O[t], 0, 0, 0);
       }
     }
-    if (more) *reinterpret_cast<float4 *>(Ks + kkey * kKPitch + kc4) = knext;
+    if (more) store_k(knext);
     cur ^= 1;
   }
 
@@ -617,7 +637,7 @@ __global__ void k_ortho9d(int b, const float *__restrict__ o9, float *__restrict
 
 }  // namespace
 
-static int g_attn_variant = 0;   // test hook: 1 = shared-tile 8-wave kernel, 2 = 4-wave double-buffered, 3 = 8-wave LDS-DMA pipeline
+static int g_attn_variant = 0;   // test hook: 1 = shared-tile 8-wave kernel, 2 = 4-wave register-staged, 3 / 4 = LDS-DMA pipeline with 8 / 4 waves
 DCL_API void dcl_debug_attention_variant(int v) { g_attn_variant = v; }
 
 DCL_API int dcl_cross_attention(int b, int nq, int nk, const float *Q, int ldq, const float *K, int ldk,
@@ -635,11 +655,20 @@ DCL_API int dcl_cross_attention(int b, int nq, int nk, const float *Q, int ldq, 
   // Large grids: 8-wave workgroups sharing a K/V tile (2 waves/SIMD).  Small grids (fewer than one 8-wave
   // workgroup per CU): 4-wave workgroups with double-buffered tiles, one per CU.
   const long long blocks8 = (long long)b * dcl_div_up(nq, 256);
-  if (dv1 == 256 && dv2 == 64 && ((blocks8 >= 256 && g_attn_variant == 0) || g_attn_variant == 3)) {
-    const size_t lds = (size_t)(32 * kKPitch + 2 * 32 * 256 + 2 * 32 * 64 + 8 * 32 * kKPitch) * sizeof(float);
-    (void)hipFuncSetAttribute((const void *)k_cross_attn_dma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_cross_attn_dma, dim3(dcl_div_up(nq, 256), b), dim3(512), lds, s, nq, nk, Q, ldq, K, ldk, V1,
-                       ldv1, O1, ldo1, V2, ldv2, O2, ldo2);
+  if (dv1 == 256 && dv2 == 64 && (g_attn_variant == 0 || g_attn_variant == 3 || g_attn_variant == 4)) {
+    // LDS-DMA pipeline: 8 waves (256 queries) per workgroup when that fills the chip, else 4 waves (128 queries)
+    const bool w8 = g_attn_variant == 3 || (g_attn_variant == 0 && blocks8 >= 256);
+    const int W = w8 ? 8 : 4;
+    const size_t lds = (size_t)(32 * kKPitch + 2 * 32 * 256 + 2 * 32 * 64 + W * 32 * kKPitch) * sizeof(float);
+    if (w8) {
+      (void)hipFuncSetAttribute((const void *)k_cross_attn_dma<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(k_cross_attn_dma<8>, dim3(dcl_div_up(nq, 256), b), dim3(512), lds, s, nq, nk, Q, ldq, K, ldk, V1,
+                         ldv1, O1, ldo1, V2, ldv2, O2, ldo2);
+    } else {
+      (void)hipFuncSetAttribute((const void *)k_cross_attn_dma<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(k_cross_attn_dma<4>, dim3(dcl_div_up(nq, 128), b), dim3(256), lds, s, nq, nk, Q, ldq, K, ldk, V1,
+                         ldv1, O1, ldo1, V2, ldv2, O2, ldo2);
+    }
   } else if ((blocks8 >= 256 && g_attn_variant != 2) || g_attn_variant == 1) {
     const size_t lds = (size_t)(32 * kKPitch + 32 * nvt * 32 + 8 * 32 * kKPitch) * sizeof(float);
 #define ATT8(N)                                                                                                \

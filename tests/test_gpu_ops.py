@@ -286,7 +286,7 @@ def test_cross_attention_matches_fp64(dcl, b, nq, nk, scale):
     V2 = torch.randn(b, nk, 64, generator=g).cuda()
     want = _attn_ref(Q, K, torch.cat([V1, V2], 2))
     lib = dcl._native.lib()
-    for variant in (0, 1, 2, 3):               # automatic, shared-tile 8-wave, double-buffered 4-wave, 8-wave LDS-DMA
+    for variant in (0, 1, 2, 3, 4):            # auto, shared-tile 8-wave, register-staged 4-wave, LDS-DMA 8 / 4 waves
         O1 = torch.empty(b * nq, 256, device="cuda")
         O2 = torch.empty(b * nq, 64, device="cuda")
         lib.dcl_debug_attention_variant(variant)
