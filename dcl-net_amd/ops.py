@@ -414,3 +414,21 @@ def ortho9d_to_matrix(o9):
     R = torch.empty((b, 3, 3), dtype=torch.float32, device=o9.device)
     N.check(N.lib().dcl_ortho9d_to_matrix(b, N.ptr(o9), N.ptr(R), N.stream()), "ortho9d_to_matrix")
     return R
+
+
+def add_s(cld, R_pred, t_pred, R_gt, t_gt, cls=None):
+    """ADD-S per object (tools/test_YCBV_stage1.py:186-189) without the (b,P,P,3) intermediate.
+    cld (n_clouds,P,3) f32; cls (b,) int32 picks each object's cloud (None: cloud o for object o) -> (b,) f32."""
+    N.need_cuda(cld, R_pred, t_pred, R_gt, t_gt, cls)
+    cld, R_pred, t_pred = N.f32c(cld), N.f32c(R_pred), N.f32c(t_pred)
+    R_gt, t_gt = N.f32c(R_gt), N.f32c(t_gt)
+    b, P = R_pred.shape[0], cld.shape[1]
+    if cls is not None:
+        cls = N.i32c(cls)
+    else:
+        assert cld.shape[0] == b
+    part = torch.empty((b, (P + 255) // 256), dtype=torch.float32, device=cld.device)
+    out = torch.empty(b, dtype=torch.float32, device=cld.device)
+    N.check(N.lib().dcl_add_s(b, P, N.ptr(cld), N.ptr(cls), N.ptr(R_pred), N.ptr(t_pred), N.ptr(R_gt), N.ptr(t_gt),
+                              N.ptr(part), N.ptr(out), N.stream()), "add_s")
+    return out

@@ -21,7 +21,10 @@ def shard_indices(n_items, rank, world):
 
 def add_s(cld, R_pred, t_pred, R_gt, t_gt, chunk=512):
     """ADD-S per object (tools/test_YCBV_stage1.py:186-189): cld (b,P,3); mean_i min_j |pred_i - gt_j|.
-    Tiled over i so the (b,P,P,3) intermediate of the reference (82 MB/object) is never built."""
+    CUDA tensors go to the fused HIP kernel (ops.add_s); the torch form below is the CPU-side helper of the gloo tests."""
+    if cld.is_cuda:
+        from . import ops
+        return ops.add_s(cld, R_pred, t_pred, R_gt, t_gt)
     pred = torch.bmm(cld, R_pred.transpose(1, 2)) + t_pred.unsqueeze(1)
     gt = torch.bmm(cld, R_gt.transpose(1, 2)) + t_gt.unsqueeze(1)
     mins = []

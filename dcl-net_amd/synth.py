@@ -178,3 +178,13 @@ def load_yaml_cfg(path):
         return x
     with open(path) as fh:
         return wrap(yaml.safe_load(fh))
+
+
+def load_checkpoint(model, filename, map_location="cpu"):
+    """Loads a reference checkpoint (gorilla.solver.save_checkpoint layout {"model": state_dict, "optimizer": ...,
+    "meta": ...}, tools/train_YCBV_stage1.py:102-104) or a bare state_dict into `model`."""
+    ckpt = torch.load(filename, map_location=map_location)
+    sd = ckpt.get("model", ckpt.get("state_dict", ckpt)) if isinstance(ckpt, dict) else ckpt
+    sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}      # nn.DataParallel prefix
+    model.load_state_dict(sd)
+    return ckpt.get("meta", {}) if isinstance(ckpt, dict) else {}

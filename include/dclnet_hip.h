@@ -229,6 +229,13 @@ int dcl_conf_pool(int b, int c, int n1, int n2, const float *logit1, const float
 /* ortho9d2matrix (models/DCL_Net.py:15-36): o9 (b,9) -> R (b,3,3).             */
 int dcl_ortho9d_to_matrix(int b, const float *o9, float *R, dclStream_t stream);
 
+/* ------------------------------------------------------------ eval metric ---
+ * ADD-S per object (tools/test_YCBV_stage1.py:186-189): out[o] = mean_i min_j |R_pred x_i + t_pred - (R_gt x_j + t_gt)|
+ * over the P points of the object's class cloud.  cld (n_clouds, P, 3); cls i32[b] selects the cloud of object o
+ * (NULL: cloud o).  partial_scratch: b * ceil(P/256) floats.  No (b,P,P,3) intermediate.                           */
+int dcl_add_s(int b, int P, const float *cld, const int32_t *cls, const float *R_pred, const float *t_pred,
+              const float *R_gt, const float *t_gt, float *partial_scratch, float *out, dclStream_t stream);
+
 /* Test hook: route every dcl_sparse_conv_fwd through the plain VALU kernel (A/B check of the MFMA one). */
 void dcl_debug_force_valu_conv(int on);
 /* Test hook: 0 = automatic choice of the attention kernel, 1 = shared-tile 8-wave variant, 2 = double-buffered 4-wave. */

@@ -375,3 +375,23 @@ def test_ortho9d_matches_torch_svd(dcl):
     assert float((got[sel] - want[sel]).abs().max()) <= 1e-5
     assert float((torch.linalg.det(got.double()) - 1).abs().max()) <= 1e-5
     assert float((got.double() @ got.double().transpose(1, 2) - torch.eye(3, dtype=torch.float64)).abs().max()) <= 1e-5
+
+
+def test_add_s_matches_reference_expression(dcl):
+    """fused ADD-S vs the harness expression (tools/test_YCBV_stage1.py:186-189) evaluated in fp64"""
+    g = torch.Generator().manual_seed(3)
+    b, P = 5, 2620
+    clouds = torch.randn(7, P, 3, generator=g) * 0.05
+    cls = torch.tensor([3, 0, 6, 6, 1], dtype=torch.int32)
+    from oracle import graph as G
+    Rp = G.ortho9d2matrix(*torch.randn(3, b, 3, generator=g))
+    Rg = G.ortho9d2matrix(*torch.randn(3, b, 3, generator=g))
+    tp, tg = torch.randn(b, 3, generator=g) * 0.02, torch.randn(b, 3, generator=g) * 0.02
+    cur = clouds[cls.long()].double()
+    pred = torch.bmm(cur, Rp.double().transpose(1, 2)) + tp.double().unsqueeze(1)
+    gt = torch.bmm(cur, Rg.double().transpose(1, 2)) + tg.double().unsqueeze(1)
+    want = torch.mean(torch.min(torch.norm(pred.unsqueeze(2) - gt.unsqueeze(1), dim=3), 2)[0], dim=1)
+    got = dcl.ops.add_s(clouds.cuda(), Rp.cuda(), tp.cuda(), Rg.cuda(), tg.cuda(), cls.cuda()).cpu().double()
+    assert float((got - want).abs().max()) <= 1e-6
+    same = dcl.ops.add_s(clouds[:b].cuda(), Rp.cuda(), tp.cuda(), Rp.cuda(), tp.cuda()).cpu()
+    assert float(same.abs().max()) == 0.0                      # identical poses: every point matches itself exactly
