@@ -266,6 +266,11 @@ inline long long grid_words(int batch, int S) { return ((long long)batch * S * S
 
 }  // namespace
 
+// library-internal (hidden visibility): exclusive popcount prefix of a bitmask, wprefix[nwords] = total
+int dcl_internal_scan_mask(const uint32_t *mask, int nwords, int32_t *wprefix, int32_t *scratch, hipStream_t s) {
+  return scan_mask(mask, nwords, wprefix, scratch, s);
+}
+
 DCL_API int dcl_grid_from_indices(const int32_t *indices, int n_rows, int batch, int S, uint32_t *mask,
                                   int32_t *wprefix, int32_t *perm, int32_t *scratch, dclStream_t stream) {
   DCL_CHECK_ARG(batch > 0 && S > 0 && n_rows >= 0 && mask && wprefix && scratch);

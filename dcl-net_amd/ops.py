@@ -41,6 +41,30 @@ def voxelize_idx(coords, batch_size, mode=4):
     return out_coords, input_map, out_map
 
 
+def voxelize_idx_gpu(coords, batch_size, S=64, mode=4):
+    """Device version of voxelize_idx for coords (N,4) int64 CUDA inside a batch x S^3 grid: identical outputs
+    (first-encounter voxel ids, ascending point lists), one host read-back of {V, maxActive}."""
+    N.need_cuda(coords)
+    assert coords.is_contiguous() and coords.dtype == torch.int64 and coords.shape[1] == 4
+    n, dev = coords.shape[0], coords.device
+    nbytes = C.c_int64(0)
+    N.check(N.lib().dcl_voxelize_idx_gpu_ws_bytes(n, int(batch_size), int(S), C.byref(nbytes)), "voxelize_idx_gpu_ws_bytes")
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+    input_map = torch.empty(max(n, 1), dtype=torch.int32, device=dev)[:n]
+    info = torch.empty(3, dtype=torch.int32, device=dev)
+    N.check(N.lib().dcl_voxelize_idx_gpu_count(N.ptr(coords), n, int(batch_size), int(S), int(mode), N.ptr(ws), nbytes.value,
+                                               N.ptr(input_map), N.ptr(info), N.stream()), "voxelize_idx_gpu_count")
+    V, ma, err = info.cpu().tolist()
+    if err:
+        raise RuntimeError("voxelize_idx_gpu: a coordinate lies outside the batch x S^3 grid")
+    ma = max(ma, 1)
+    out_coords = torch.empty((V, 4), dtype=torch.int64, device=dev)
+    out_map = torch.empty((V, ma + 1), dtype=torch.int32, device=dev)
+    N.check(N.lib().dcl_voxelize_idx_gpu_fill(N.ptr(coords), n, int(batch_size), int(S), N.ptr(ws), N.ptr(input_map), V, ma,
+                                              N.ptr(out_coords), N.ptr(out_map), N.stream()), "voxelize_idx_gpu_fill")
+    return out_coords, input_map, out_map
+
+
 def voxelize_fp(feats, map_rule, mode=4):
     """PG_OP.voxelize_fp (pointgroup_ops.py:42-62): feats (N,C) f32, map_rule (M,1+maxActive) i32 -> (M,C)."""
     N.need_cuda(feats, map_rule)

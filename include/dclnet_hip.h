@@ -45,6 +45,16 @@ int dcl_voxelize_idx_fill(const int64_t *coords_host, int n, int ncol, const int
                           int n_active, int max_active, int64_t *output_coords_host,
                           int32_t *output_map_host);
 
+/* DEVICE voxelize_idx (same results as the host one, coords on the GPU inside a batch x S^3 grid).
+ * _count: input_map (n) and info_dev = {n_active, max_active, error flag (coordinate out of range)}; the caller reads
+ * info back (one sync) to allocate output_coords (V,4) i64 / output_map (V, max_active+1) i32, then calls _fill.     */
+int dcl_voxelize_idx_gpu_ws_bytes(int n, int batch, int S, int64_t *bytes_host);
+int dcl_voxelize_idx_gpu_count(const int64_t *coords, int n, int batch, int S, int mode, void *ws, int64_t ws_bytes,
+                               int32_t *input_map, int32_t *info_dev, dclStream_t stream);
+int dcl_voxelize_idx_gpu_fill(const int64_t *coords, int n, int batch, int S, void *ws, const int32_t *input_map,
+                              int n_active, int max_active, int64_t *output_coords, int32_t *output_map,
+                              dclStream_t stream);
+
 /* voxelize_fp: pointgroup_ops_api.cpp:8 -> src/voxelize/voxelize.cu:9-31.
  * feats (N,C), rules (V,1+maxActive) -> out (V,C); out need not be zeroed.     */
 int dcl_voxelize_fp(const float *feats, const int32_t *rules, float *out, int n_rows, int max_active,

@@ -38,6 +38,27 @@ def test_voxelize_idx_host_matches_oracle(dcl, oracle):
     assert np.array_equal(oc.numpy(), rc) and np.array_equal(im.numpy(), rm) and np.array_equal(om.numpy(), rom)
 
 
+def test_voxelize_idx_gpu_bit_exact(dcl, oracle):
+    """device voxelize_idx == host/oracle hashing: first-encounter ids, ascending point lists, first-point coords"""
+    rng = np.random.default_rng(5)
+    for b, n, S, spread in ((3, 500, 64, 12), (2, 4000, 64, 20), (4, 257, 16, 16), (1, 1, 8, 1)):
+        coords = np.concatenate([np.repeat(np.arange(b), n)[:, None], rng.integers(0, spread, (b * n, 3))], 1).astype(np.int64)
+        oc, im, om = dcl.ops.voxelize_idx_gpu(torch.from_numpy(coords).cuda(), b, S, 4)
+        rc, rm, rom = oracle.voxelize_idx(coords, b, 4)
+        assert np.array_equal(im.cpu().numpy(), rm)
+        assert np.array_equal(oc.cpu().numpy(), rc)
+        assert np.array_equal(om.cpu().numpy(), rom)
+    d = dcl.synth.make_batch(3, 1024, 1024)                    # and on real synthetic crops, through the loader contract
+    coords = torch.cat([torch.repeat_interleave(torch.arange(3), 1024)[:, None],
+                        ((d["inp"]["feats"][:, 4:7] + 0.192) / 0.006).long()], 1).contiguous()
+    oc, im, om = dcl.ops.voxelize_idx_gpu(coords.cuda(), 3, 64, 4)
+    assert torch.equal(oc.cpu(), d["inp"]["occupied_voxels"]) and torch.equal(im.cpu(), d["inp"]["p2v_maps"])
+    assert torch.equal(om.cpu(), d["inp"]["v2p_maps"])
+    with pytest.raises(RuntimeError):
+        bad = torch.tensor([[0, 1, 2, 99]], dtype=torch.int64).cuda()
+        dcl.ops.voxelize_idx_gpu(bad, 1, 64, 4)
+
+
 def test_voxelize_fp_bit_exact(dcl, oracle):
     rng = np.random.default_rng(1)
     coords = np.concatenate([np.repeat(np.arange(2), 700)[:, None], rng.integers(0, 9, (1400, 3))], 1).astype(np.int64)
