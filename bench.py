@@ -130,6 +130,32 @@ def primitives_roofline(dcl, reps=5):
     return out
 
 
+def refiner_bench(dcl, dev, b, iters=2, reps=20):
+    """BASELINE config 5 (S4): the stage-2 refine loop (2 iterations, tools/test_YCBV_stage2.py:214-225) on b crops of
+    1024 points, eager vs hipGraph-captured; ms per loop and crops/s."""
+    ref = dcl.refiner.Refiner()
+    ref.load_state_dict(dcl.synth.synth_state_dict(ref, 2))
+    ref = ref.to(dev).eval()
+    g = torch.Generator().manual_seed(0)
+    n = 1024
+    pred = {"F_Xo_p": torch.randn(b, 256, n, generator=g).to(dev), "conf": torch.rand(b, 2 * n, generator=g).to(dev),
+            "rot_pred": dcl.ops.ortho9d_to_matrix(torch.randn(b, 9, generator=g).to(dev)),
+            "trans_pred": (torch.randn(b, 3, generator=g) * 0.02).to(dev)}
+    pts = (torch.randn(b, n, 3, generator=g) * 0.05).to(dev)
+    out = {}
+    for name, graph in (("eager", False), ("hipgraph", True)):
+        for _ in range(3):
+            dcl.refiner.refine_loop(ref, pred, pts, iters, graph=graph)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            dcl.refiner.refine_loop(ref, pred, pts, iters, graph=graph)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        out[name] = {"ms_per_loop": round(ms, 4), "crops_per_s": round(b / ms * 1e3, 1)}
+    return out
+
+
 def cpu_baseline(dcl, sd, cfg, n_inp, n_tmp, crops=2):
     """the CPU oracle (kind 'port': the reference has no runnable CPU path) on a bounded sample of
     the same workload, host cores of this box."""
@@ -225,6 +251,7 @@ def main():
                                  "attention_TFLOPs": round(rflop / (np.mean(ratt) * 1e-3) / 1e12, 2) if ratt else None}
             del rnet, rdata
         line["primitives"] = primitives_roofline(dcl)
+        line["refiner"] = refiner_bench(dcl, dev, b)
         line["cpu_baseline"] = cpu_baseline(dcl, sd, cfg, n_inp, n_tmp)
     if rank == 0:
         print(json.dumps(line), flush=True)
