@@ -45,9 +45,11 @@ def test_forward_matches_reference_golden(dcl, golden_dir, fused):
     assert tuple(data["labels"]["points_tmp"].shape) == (b, n_tmp, 3)
 
 
-@pytest.mark.parametrize("b,n_inp,n_tmp,unit", [(3, 1024, 1024, 0.006), (1, 2048, 500, 0.005), (5, 512, 1024, 0.006)])
+@pytest.mark.parametrize("b,n_inp,n_tmp,unit", [(3, 1024, 1024, 0.006), (1, 2048, 500, 0.005), (5, 512, 1024, 0.006),
+                                               (8, 1024, 1024, 0.005), (1, 12288, 2048, 0.006)])
 def test_forward_matches_oracle_graph(dcl, oracle, b, n_inp, n_tmp, unit):
-    """fresh crops at the reference shape (N=M=1024), the plumbing shape S0 (N=2048, M=500, 5 mm) and a ragged one"""
+    """fresh crops at the reference shape (N=M=1024), the plumbing shape S0 (N=2048, M=500, 5 mm), a ragged one, the
+    LineMOD config (5 mm voxels, config_LM.yaml) and one crop of the BASELINE stress shape (N=12288, M=2048)"""
     from oracle import graph as G
     cfg = dcl.synth.default_cfg(n_inp, n_tmp, unit)
     net = dcl.DCL_Net.Network(cfg, mode="test")
@@ -123,6 +125,23 @@ def test_full_size_properties(dcl):
         sub = net(dcl.synth.make_batch(4, n, n, first=8))
     assert float((sub["rot_pred"] - p1["rot_pred"][8:12]).abs().max()) <= R_TOL
     assert float((sub["trans_pred"] - p1["trans_pred"][8:12]).abs().max()) <= T_TOL
+
+
+def test_stress_shape_batch_invariance(dcl):
+    """BASELINE stress shape (N=12288, M=2048): a 6-crop batch takes the 8-wave LDS-DMA attention kernel, single crops
+    take the 4-wave one; each crop's pose must not depend on its batch mates or on the kernel variant"""
+    n_inp, n_tmp = 12288, 2048
+    cfg = dcl.synth.default_cfg(n_inp, n_tmp)
+    net = dcl.DCL_Net.Network(cfg, mode="test")
+    net.load_state_dict(dcl.synth.synth_state_dict(net, 1))
+    net = net.cuda().eval()
+    with torch.no_grad():
+        full = net(dcl.synth.make_batch(6, n_inp, n_tmp, first=20))
+        for i in (0, 5):
+            one = net(dcl.synth.make_batch(1, n_inp, n_tmp, first=20 + i))
+            assert float((one["rot_pred"][0] - full["rot_pred"][i]).abs().max()) <= R_TOL
+            assert float((one["trans_pred"][0] - full["trans_pred"][i]).abs().max()) <= T_TOL
+            assert float((one["conf"][0] - full["conf"][i]).abs().max()) <= 1e-4
 
 
 def test_ops_refuse_cpu_tensors(dcl):
