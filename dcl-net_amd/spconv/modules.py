@@ -1,4 +1,5 @@
-"""SparseModule / SparseSequential (libs/spconv/spconv/modules.py:40-130)."""
+"""Containers of the spconv-shaped front end: SparseModule (marker) and SparseSequential, the subset of
+libs/spconv/spconv/modules.py:40-130 that DCL-Net's BasicBlock_SPCONV relies on (models/Modules.py:36-56)."""
 from collections import OrderedDict
 
 from torch import nn
@@ -7,8 +8,7 @@ from .tensor import SparseConvTensor
 
 
 class SparseModule(nn.Module):
-    """marker base class: modules that take a SparseConvTensor inside SparseSequential."""
-    pass
+    """Base class of layers that consume and produce a SparseConvTensor."""
 
 
 def is_spconv_module(module):
@@ -16,48 +16,36 @@ def is_spconv_module(module):
 
 
 class SparseSequential(SparseModule):
-    def __init__(self, *args, **kwargs):
-        super(SparseSequential, self).__init__()
-        if len(args) == 1 and isinstance(args[0], OrderedDict):
-            for key, module in args[0].items():
-                self.add_module(key, module)
-        else:
-            for i, module in enumerate(args):
-                self.add_module(str(i), module)
-        for name, module in kwargs.items():
-            if name in self._modules:
-                raise ValueError("name exists.")
-            self.add_module(name, module)
-        self._sparity_dict = {}
+    """Runs its children in order.  Sparse layers get the tensor object; dense layers (BatchNorm1d, ReLU, ...) are
+    applied to `.features` only, and are skipped while the tensor has no active voxel -- the reference's rule
+    (modules.py:118-130), which keeps BatchNorm from seeing an empty batch."""
 
-    def __getitem__(self, idx):
-        if not (-len(self) <= idx < len(self)):
-            raise IndexError("index {} is out of range".format(idx))
-        return list(self._modules.values())[idx]
+    def __init__(self, *layers, **named_layers):
+        super().__init__()
+        if len(layers) == 1 and isinstance(layers[0], OrderedDict):
+            named = list(layers[0].items())
+        else:
+            named = [(str(i), m) for i, m in enumerate(layers)]
+        for name, m in named + list(named_layers.items()):
+            if name in self._modules:
+                raise ValueError("duplicate layer name %r" % name)
+            self.add_module(name, m)
 
     def __len__(self):
         return len(self._modules)
 
-    @property
-    def sparity_dict(self):
-        return self._sparity_dict
+    def __getitem__(self, i):
+        return list(self._modules.values())[i]
 
-    def add(self, module, name=None):
-        if name is None:
-            name = str(len(self._modules))
-            if name in self._modules:
-                raise KeyError("name exists")
-        self.add_module(name, module)
-
-    def forward(self, input):
-        for k, module in self._modules.items():
-            if is_spconv_module(module):
-                assert isinstance(input, SparseConvTensor)
-                self._sparity_dict[k] = input.sparity
-                input = module(input)
-            elif isinstance(input, SparseConvTensor):
-                if input.indices.shape[0] != 0:           # modules.py:125-127
-                    input.features = module(input.features)
+    def forward(self, x):
+        for layer in self._modules.values():
+            if is_spconv_module(layer):
+                if not isinstance(x, SparseConvTensor):
+                    raise TypeError("sparse layer fed with a dense tensor")
+                x = layer(x)
+            elif isinstance(x, SparseConvTensor):
+                if x.indices.shape[0]:
+                    x.features = layer(x.features)
             else:
-                input = module(input)
-        return input
+                x = layer(x)
+        return x
