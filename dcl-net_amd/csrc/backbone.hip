@@ -15,10 +15,17 @@
 // dcl_backbone_ws_bytes / dcl_backbone_ws2_bytes.
 #include "common.h"
 
+int dcl_internal_grid_from_indices(const int32_t *indices, const int32_t *n_rows_dev, int n_rows, int batch, int S,
+                                   uint32_t *mask, int32_t *wprefix, int32_t *perm, int32_t *scratch,
+                                   dclStream_t stream);
 int dcl_three_nn_sp_strided(int n, int m, const float *unknown, const float *known, float *dist2, int32_t *idx,
                             const int32_t *known_seg, int nbatch, int seg_stride, dclStream_t stream);
 
+#include <stdlib.h>
 namespace {
+
+// debugging aid: DCL_DBG_FEATURE_STEPS=N enqueues only the first N kernels of dcl_backbone_features*
+inline int dbg_steps() { const char *e = getenv("DCL_DBG_FEATURE_STEPS"); return e ? atoi(e) : 1 << 30; }
 
 constexpr int kLevels = 4;
 constexpr size_t kAlign = 256;
@@ -103,17 +110,32 @@ DCL_API int dcl_backbone_ws_bytes(int batch, int S, int V0, int64_t *bytes_host)
   return 0;
 }
 
+static int backbone_geometry(const int32_t *occ, const int32_t *V0_dev, int V0, int batch, int S, void *ws,
+                             int64_t ws_bytes, int32_t *counts_dev, dclStream_t stream);
+
 DCL_API int dcl_backbone_geometry(const int32_t *occ, int V0, int batch, int S, void *ws, int64_t ws_bytes,
                                   int32_t *counts_dev, dclStream_t stream) {
+  return backbone_geometry(occ, nullptr, V0, batch, S, ws, ws_bytes, counts_dev, stream);
+}
+
+// capacity mode: occ has V0_cap rows of which the first *V0_dev are live (enqueue-only, shapes independent of the data)
+DCL_API int dcl_backbone_geometry_cap(const int32_t *occ, const int32_t *V0_dev, int V0_cap, int batch, int S, void *ws,
+                                      int64_t ws_bytes, int32_t *counts_dev, dclStream_t stream) {
+  DCL_CHECK_ARG(V0_dev);
+  return backbone_geometry(occ, V0_dev, V0_cap, batch, S, ws, ws_bytes, counts_dev, stream);
+}
+
+static int backbone_geometry(const int32_t *occ, const int32_t *V0_dev, int V0, int batch, int S, void *ws,
+                             int64_t ws_bytes, int32_t *counts_dev, dclStream_t stream) {
   GeoLayout L;
   DCL_CHECK_ARG(ws && counts_dev && make_geo_layout(batch, S, V0, &L) && ws_bytes >= (int64_t)L.total);
   DCL_CHECK_ARG(V0 == 0 || occ);
   int32_t *scratch = at<int32_t>(ws, L.scratch);
-  int rc = dcl_grid_from_indices(occ, V0, batch, S, at<uint32_t>(ws, L.mask0), at<int32_t>(ws, L.wprefix0),
-                                 at<int32_t>(ws, L.perm0), scratch, stream);
+  int rc = dcl_internal_grid_from_indices(occ, V0_dev, V0, batch, S, at<uint32_t>(ws, L.mask0),
+                                          at<int32_t>(ws, L.wprefix0), at<int32_t>(ws, L.perm0), scratch, stream);
   if (rc) return rc;
   const int32_t *in_idx = occ;
-  const int32_t *in_n_dev = nullptr;
+  const int32_t *in_n_dev = V0_dev;
   int in_n_host = V0;
   const uint32_t *in_mask = at<uint32_t>(ws, L.mask0);
   int s = S;
@@ -146,10 +168,46 @@ DCL_API int dcl_backbone_ws2_bytes(const int32_t *counts_host, const int32_t *ch
 // weights[2m], weights[2m+1]: (27,Cin,Cout) of module m's conv / subm conv; scale/shift: folded BatchNorm1d.
 // level_out[m]: caller-allocated (counts[2m+1], channels[2m+2]).  level_idx_out[m] (optional): receives a pointer
 // into `ws` (the level's (b,x,y,z) rows).
+static int backbone_features(const int32_t *occ, int V0, int batch, int S, void *ws, const int32_t *counts_host,
+                             const int32_t *counts_dev, const int32_t *channels_host, const float *vox_feats,
+                             const float *const *weights, const float *const *scales, const float *const *shifts,
+                             void *ws2, int64_t ws2_bytes, float *const *level_out, dclStream_t stream);
+
 DCL_API int dcl_backbone_features(const int32_t *occ, int V0, int batch, int S, void *ws, const int32_t *counts_host,
                                   const int32_t *channels_host, const float *vox_feats, const float *const *weights,
                                   const float *const *scales, const float *const *shifts, void *ws2, int64_t ws2_bytes,
                                   float *const *level_out, dclStream_t stream) {
+  DCL_CHECK_ARG(counts_host);
+  return backbone_features(occ, V0, batch, S, ws, counts_host, nullptr, channels_host, vox_feats, weights, scales, shifts,
+                           ws2, ws2_bytes, level_out, stream);
+}
+
+// capacity mode: every buffer is sized by the layout's capacities (dcl_backbone_caps), the live row counts are read
+// from counts_dev by the kernels; no host value depends on the data (graph-capture safe).
+DCL_API int dcl_backbone_caps(int batch, int S, int V0_cap, int32_t *caps_host /* i32[8]: conv1,pool1,... */) {
+  GeoLayout L;
+  DCL_CHECK_ARG(caps_host && make_geo_layout(batch, S, V0_cap, &L));
+  for (int m = 0; m < kLevels; ++m) { caps_host[2 * m] = L.conv[m].cap; caps_host[2 * m + 1] = L.pool[m].cap; }
+  return 0;
+}
+
+DCL_API int dcl_backbone_features_cap(const int32_t *occ, int V0_cap, int batch, int S, void *ws,
+                                      const int32_t *counts_dev, const int32_t *channels_host, const float *vox_feats,
+                                      const float *const *weights, const float *const *scales,
+                                      const float *const *shifts, void *ws2, int64_t ws2_bytes,
+                                      float *const *level_out, dclStream_t stream) {
+  int32_t caps[8];
+  DCL_CHECK_ARG(counts_dev);
+  int rc = dcl_backbone_caps(batch, S, V0_cap, caps);
+  if (rc) return rc;
+  return backbone_features(occ, V0_cap, batch, S, ws, caps, counts_dev, channels_host, vox_feats, weights, scales, shifts,
+                           ws2, ws2_bytes, level_out, stream);
+}
+
+static int backbone_features(const int32_t *occ, int V0, int batch, int S, void *ws, const int32_t *counts_host,
+                             const int32_t *counts_dev, const int32_t *channels_host, const float *vox_feats,
+                             const float *const *weights, const float *const *scales, const float *const *shifts,
+                             void *ws2, int64_t ws2_bytes, float *const *level_out, dclStream_t stream) {
   GeoLayout L;
   FeatLayout F;
   DCL_CHECK_ARG(ws && ws2 && counts_host && channels_host && weights && scales && shifts && level_out);
@@ -157,6 +215,7 @@ DCL_API int dcl_backbone_features(const int32_t *occ, int V0, int batch, int S, 
                 ws2_bytes >= (int64_t)F.total);
   for (int m = 0; m < kLevels; ++m)
     DCL_CHECK_ARG(counts_host[2 * m] <= L.conv[m].cap && counts_host[2 * m + 1] <= L.pool[m].cap);
+  (void)occ;
   int32_t *nbr = at<int32_t>(ws2, F.nbr);
   float *x1 = at<float>(ws2, F.x1), *x2 = at<float>(ws2, F.x2);
   const float *x = vox_feats;
@@ -164,31 +223,41 @@ DCL_API int dcl_backbone_features(const int32_t *occ, int V0, int batch, int S, 
   const int32_t *in_wp = at<int32_t>(ws, L.wprefix0);
   const int32_t *in_perm = at<int32_t>(ws, L.perm0);
   int s = S, rc;
+  int steps_left = dbg_steps();
+#define DBG_STEP() do { if (--steps_left < 0) return 0; } while (0)
   for (int m = 0; m < kLevels; ++m) {
     const SetLayout &c = L.conv[m], &p = L.pool[m];
-    const int nc = counts_host[2 * m], np = counts_host[2 * m + 1];
+    const int nc = counts_host[2 * m], np = counts_host[2 * m + 1];     // live counts, or capacities in capacity mode
+    const int32_t *nc_dev = counts_dev ? counts_dev + 2 * m : nullptr;
+    const int32_t *np_dev = counts_dev ? counts_dev + 2 * m + 1 : nullptr;
     const int c0 = channels_host[2 * m], c1 = channels_host[2 * m + 1], c2 = channels_host[2 * m + 2];
     if (nc > 0) {
       // conv (k3,s1,p1): out rows = conv set, inputs looked up in the previous level's set
-      rc = dcl_rulebook_gather(at<int32_t>(ws, c.indices), nullptr, nc, in_mask, in_wp, in_perm, batch, s, 3, 1, 1, nbr,
-                               nc, stream);
+      DBG_STEP();
+      rc = dcl_rulebook_gather(at<int32_t>(ws, c.indices), nc_dev, nc_dev ? 0 : nc, in_mask, in_wp, in_perm, batch, s, 3,
+                               1, 1, nbr, nc, stream);
       if (rc) return rc;
-      rc = dcl_sparse_conv_fwd(x, nbr, nc, nullptr, nc, weights[2 * m], c0, c1, 27, 0, scales[2 * m], shifts[2 * m], 1,
-                               x1, stream);
+      DBG_STEP();
+      rc = dcl_sparse_conv_fwd(x, nbr, nc, nc_dev, nc_dev ? 0 : nc, weights[2 * m], c0, c1, 27, 0, scales[2 * m],
+                               shifts[2 * m], 1, x1, stream);
       if (rc) return rc;
       // submanifold conv on the conv set
-      rc = dcl_rulebook_gather(at<int32_t>(ws, c.indices), nullptr, nc, at<uint32_t>(ws, c.mask),
+      DBG_STEP();
+      rc = dcl_rulebook_gather(at<int32_t>(ws, c.indices), nc_dev, nc_dev ? 0 : nc, at<uint32_t>(ws, c.mask),
                                at<int32_t>(ws, c.wprefix), nullptr, batch, s, 3, 1, 1, nbr, nc, stream);
       if (rc) return rc;
-      rc = dcl_sparse_conv_fwd(x1, nbr, nc, nullptr, nc, weights[2 * m + 1], c1, c2, 27, 1, scales[2 * m + 1],
-                               shifts[2 * m + 1], 1, x2, stream);
+      DBG_STEP();
+      rc = dcl_sparse_conv_fwd(x1, nbr, nc, nc_dev, nc_dev ? 0 : nc, weights[2 * m + 1], c1, c2, 27, 1,
+                               scales[2 * m + 1], shifts[2 * m + 1], 1, x2, stream);
       if (rc) return rc;
     }
     if (np > 0) {
-      rc = dcl_rulebook_gather(at<int32_t>(ws, p.indices), nullptr, np, at<uint32_t>(ws, c.mask),
+      DBG_STEP();
+      rc = dcl_rulebook_gather(at<int32_t>(ws, p.indices), np_dev, np_dev ? 0 : np, at<uint32_t>(ws, c.mask),
                                at<int32_t>(ws, c.wprefix), nullptr, batch, s, 3, 2, 1, nbr, np, stream);
       if (rc) return rc;
-      rc = dcl_sparse_avgpool_fwd(x2, nbr, np, nullptr, np, c2, 27, level_out[m], nullptr, stream);
+      DBG_STEP();
+      rc = dcl_sparse_avgpool_fwd(x2, nbr, np, np_dev, np_dev ? 0 : np, c2, 27, level_out[m], nullptr, stream);
       if (rc) return rc;
     }
     x = level_out[m];
@@ -214,10 +283,35 @@ DCL_API int dcl_backbone_level_info(int batch, int S, int V0, int level, int64_t
 // Ops_GetPointFeat_spconv.forward (models/Modules.py:236-251) over the 4 pooled levels.
 // points_b4 (n,4) [b,x,y,z]; level_feats[m] (counts[2m+1], channels[2m+2]); out (n, ld) with the 4 levels'
 // channels side by side (ld >= sum); tmp: caller scratch of n*24 + max_level_rows*16 bytes.
+static int point_features(int n, const float *points_b4, int batch, int S, int V0, void *ws,
+                          const int32_t *counts_host, const int32_t *counts_dev, const int32_t *channels_host,
+                          const float *const *level_feats, const float *voxel_extent_host, float offset, float *out,
+                          int ld, void *tmp, int64_t tmp_bytes, dclStream_t stream);
+
 DCL_API int dcl_point_features(int n, const float *points_b4, int batch, int S, int V0, void *ws,
                                const int32_t *counts_host, const int32_t *channels_host,
                                const float *const *level_feats, const float *voxel_extent_host /*4*/, float offset,
                                float *out, int ld, void *tmp, int64_t tmp_bytes, dclStream_t stream) {
+  return point_features(n, points_b4, batch, S, V0, ws, counts_host, nullptr, channels_host, level_feats,
+                        voxel_extent_host, offset, out, ld, tmp, tmp_bytes, stream);
+}
+
+DCL_API int dcl_point_features_cap(int n, const float *points_b4, int batch, int S, int V0_cap, void *ws,
+                                   const int32_t *counts_dev, const int32_t *channels_host,
+                                   const float *const *level_feats, const float *voxel_extent_host, float offset,
+                                   float *out, int ld, void *tmp, int64_t tmp_bytes, dclStream_t stream) {
+  int32_t caps[8];
+  DCL_CHECK_ARG(counts_dev);
+  int rc = dcl_backbone_caps(batch, S, V0_cap, caps);
+  if (rc) return rc;
+  return point_features(n, points_b4, batch, S, V0_cap, ws, caps, counts_dev, channels_host, level_feats,
+                        voxel_extent_host, offset, out, ld, tmp, tmp_bytes, stream);
+}
+
+static int point_features(int n, const float *points_b4, int batch, int S, int V0, void *ws,
+                          const int32_t *counts_host, const int32_t *counts_dev, const int32_t *channels_host,
+                          const float *const *level_feats, const float *voxel_extent_host, float offset, float *out,
+                          int ld, void *tmp, int64_t tmp_bytes, dclStream_t stream) {
   GeoLayout L;
   DCL_CHECK_ARG(n >= 0 && points_b4 && ws && counts_host && channels_host && level_feats && voxel_extent_host && out &&
                 tmp && make_geo_layout(batch, S, V0, &L));
@@ -235,7 +329,8 @@ DCL_API int dcl_point_features(int n, const float *points_b4, int batch, int S, 
     const SetLayout &p = L.pool[m];
     const int np = counts_host[2 * m + 1], c = channels_host[2 * m + 2];
     DCL_CHECK_ARG(col + c <= ld);
-    rc = dcl_voxel_centres(at<int32_t>(ws, p.indices), nullptr, np, voxel_extent_host[m], offset, centres, stream);
+    rc = dcl_voxel_centres(at<int32_t>(ws, p.indices), counts_dev ? counts_dev + 2 * m + 1 : nullptr, np,
+                           voxel_extent_host[m], offset, centres, stream);
     if (rc) return rc;
     const int wpc = p.S * p.S * p.S / 32;           // mask words per crop (S >= 4 -> >= 2)
     rc = dcl_three_nn_sp_strided(n, np, points_b4, centres, dist2, idx, at<int32_t>(ws, p.wprefix), batch, wpc, stream);

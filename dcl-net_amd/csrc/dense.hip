@@ -384,18 +384,23 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_cross_attn_dma(
   // this thread's float4(s) of the K tile: 512 per tile over WAVES*64 threads
   constexpr int KPT = 512 / (WAVES * 64);
   auto k_slot = [&](int i, int &key, int &c4) { const int idx = tid + i * WAVES * 64; key = idx >> 4; c4 = (idx & 15) * 4; };
-  auto load_k = [&](int kb, float4 *dst) {
-#pragma unroll
-    for (int i = 0; i < KPT; ++i) {
-      int key, c4; k_slot(i, key, c4);
-      dst[i] = *reinterpret_cast<const float4 *>(K + (krow0 + min(kb + key, last_key)) * ldk + c4);
+  float4 knext0 = make_float4(0.f, 0.f, 0.f, 0.f), knext1 = knext0;       // named registers: no stack object
+  auto load_k = [&](int kb) {
+    int key, c4;
+    k_slot(0, key, c4);
+    knext0 = *reinterpret_cast<const float4 *>(K + (krow0 + min(kb + key, last_key)) * ldk + c4);
+    if (KPT > 1) {
+      k_slot(1, key, c4);
+      knext1 = *reinterpret_cast<const float4 *>(K + (krow0 + min(kb + key, last_key)) * ldk + c4);
     }
   };
-  auto store_k = [&](const float4 *src) {
-#pragma unroll
-    for (int i = 0; i < KPT; ++i) {
-      int key, c4; k_slot(i, key, c4);
-      *reinterpret_cast<float4 *>(Ks + key * kKPitch + c4) = src[i];
+  auto store_k = [&]() {
+    int key, c4;
+    k_slot(0, key, c4);
+    *reinterpret_cast<float4 *>(Ks + key * kKPitch + c4) = knext0;
+    if (KPT > 1) {
+      k_slot(1, key, c4);
+      *reinterpret_cast<float4 *>(Ks + key * kKPitch + c4) = knext1;
     }
   };
 
@@ -406,9 +411,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_cross_attn_dma(
     for (int e = 0; e < 16; ++e) O[t][e] = 0.0f;
   float m_ref = -INFINITY, l_part = 0.0f;
 
-  float4 knext[KPT];
-  load_k(0, knext);
-  store_k(knext);
+  load_k(0);
+  store_k();
   dma_v(0, 0);
   int cur = 0;
   for (int kb = 0; kb < nk; kb += 32) {
@@ -436,7 +440,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_cross_attn_dma(
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);                    // lgkmcnt(0) only: the DMA stays in flight
     __builtin_amdgcn_s_barrier();                          // B: every wave is done with the K tile
-    if (more) load_k(kb + 32, knext);
+    if (more) load_k(kb + 32);
 
     float m_tile = -INFINITY;
 #pragma unroll
@@ -472,7 +476,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_cross_attn_dma(
         O[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, S[e], O[t], 0, 0, 0);
       }
     }
-    if (more) store_k(knext);
+    if (more) store_k();
     cur ^= 1;
   }
 
@@ -590,23 +594,29 @@ __global__ void k_ortho9d(int b, const float *__restrict__ o9, float *__restrict
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= b) return;
   double A[3][3], V[3][3];
+#pragma unroll
   for (int c = 0; c < 3; ++c) {
     const float x = o9[i * 9 + c * 3], y = o9[i * 9 + c * 3 + 1], z = o9[i * 9 + c * 3 + 2];
     const float mag = sqrtf((x * x + y * y) + z * z) + 1e-8f;       // utils/transform3D.py:18-20 (fp32)
     A[0][c] = (double)(x / mag); A[1][c] = (double)(y / mag); A[2][c] = (double)(z / mag);
+#pragma unroll
     for (int r = 0; r < 3; ++r) V[r][c] = r == c ? 1.0 : 0.0;
   }
   for (int sweep = 0; sweep < 30; ++sweep) {
     double off = 0.0;
+#pragma unroll
     for (int p = 0; p < 2; ++p)
+#pragma unroll
       for (int q = p + 1; q < 3; ++q) {
         double alpha = 0, beta = 0, gamma = 0;
+#pragma unroll
         for (int r = 0; r < 3; ++r) { alpha += A[r][p] * A[r][p]; beta += A[r][q] * A[r][q]; gamma += A[r][p] * A[r][q]; }
         off = fmax(off, fabs(gamma) / sqrt(alpha * beta + 1e-300));
         if (fabs(gamma) < 1e-300) continue;
         const double zeta = (beta - alpha) / (2.0 * gamma);
         const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
         const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+#pragma unroll
         for (int r = 0; r < 3; ++r) {
           const double ap = A[r][p], aq = A[r][q];
           A[r][p] = cs * ap - sn * aq; A[r][q] = sn * ap + cs * aq;
@@ -616,23 +626,38 @@ __global__ void k_ortho9d(int b, const float *__restrict__ o9, float *__restrict
       }
     if (off < 1e-15) break;
   }
-  double sig[3];
-  for (int c = 0; c < 3; ++c) sig[c] = sqrt(A[0][c] * A[0][c] + A[1][c] * A[1][c] + A[2][c] * A[2][c]);
-  int o0 = 0, o1 = 1, o2 = 2;                       // descending singular values (torch.svd order)
-  if (sig[o0] < sig[o1]) { int t = o0; o0 = o1; o1 = t; }
-  if (sig[o1] < sig[o2]) { int t = o1; o1 = o2; o2 = t; }
-  if (sig[o0] < sig[o1]) { int t = o0; o0 = o1; o1 = t; }
+  // sort the three (column of A, column of V) pairs by descending singular value with explicit swaps -- no
+  // dynamically indexed local arrays, so the kernel needs no scratch memory
+  double a0[3] = {A[0][0], A[1][0], A[2][0]}, a1[3] = {A[0][1], A[1][1], A[2][1]}, a2[3] = {A[0][2], A[1][2], A[2][2]};
+  double v0[3] = {V[0][0], V[1][0], V[2][0]}, v1[3] = {V[0][1], V[1][1], V[2][1]}, v2[3] = {V[0][2], V[1][2], V[2][2]};
+  double s0 = sqrt(a0[0] * a0[0] + a0[1] * a0[1] + a0[2] * a0[2]);
+  double s1 = sqrt(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]);
+  double s2 = sqrt(a2[0] * a2[0] + a2[1] * a2[1] + a2[2] * a2[2]);
+#define DCL_SWAP_COLS(sa, sb, aa, ab, va, vb)                                  \
+  if (sa < sb) {                                                               \
+    double t_ = sa; sa = sb; sb = t_;                                          \
+    for (int r_ = 0; r_ < 3; ++r_) {                                           \
+      t_ = aa[r_]; aa[r_] = ab[r_]; ab[r_] = t_;                               \
+      t_ = va[r_]; va[r_] = vb[r_]; vb[r_] = t_;                               \
+    }                                                                          \
+  }
+  DCL_SWAP_COLS(s0, s1, a0, a1, v0, v1)
+  DCL_SWAP_COLS(s1, s2, a1, a2, v1, v2)
+  DCL_SWAP_COLS(s0, s1, a0, a1, v0, v1)
+#undef DCL_SWAP_COLS
   double u1[3], u2[3], u3[3];
-  for (int r = 0; r < 3; ++r) { u1[r] = A[r][o0] / sig[o0]; u2[r] = A[r][o1] / sig[o1]; }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) { u1[r] = a0[r] / s0; u2[r] = a1[r] / s1; }
   u3[0] = u1[1] * u2[2] - u1[2] * u2[1];
   u3[1] = u1[2] * u2[0] - u1[0] * u2[2];
   u3[2] = u1[0] * u2[1] - u1[1] * u2[0];
-  const double detV = V[0][o0] * (V[1][o1] * V[2][o2] - V[2][o1] * V[1][o2]) -
-                      V[1][o0] * (V[0][o1] * V[2][o2] - V[2][o1] * V[0][o2]) +
-                      V[2][o0] * (V[0][o1] * V[1][o2] - V[1][o1] * V[0][o2]);
+  const double detV = v0[0] * (v1[1] * v2[2] - v1[2] * v2[1]) - v0[1] * (v1[0] * v2[2] - v1[2] * v2[0]) +
+                      v0[2] * (v1[0] * v2[1] - v1[1] * v2[0]);
+#pragma unroll
   for (int r = 0; r < 3; ++r)
+#pragma unroll
     for (int c = 0; c < 3; ++c)
-      R[i * 9 + r * 3 + c] = (float)(u1[r] * V[c][o0] + u2[r] * V[c][o1] + detV * u3[r] * V[c][o2]);
+      R[i * 9 + r * 3 + c] = (float)(u1[r] * v0[c] + u2[r] * v1[c] + detV * u3[r] * v2[c]);
 }
 
 }  // namespace

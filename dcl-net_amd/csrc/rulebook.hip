@@ -87,7 +87,9 @@ __device__ __forceinline__ int grid_lookup(const uint32_t *__restrict__ mask, co
   return perm ? perm[r] : r;
 }
 
-__global__ void k_mark_rows(const int32_t *__restrict__ indices, int n, int S, uint32_t *__restrict__ mask) {
+__global__ void k_mark_rows(const int32_t *__restrict__ indices, const int32_t *__restrict__ n_dev, int n_host, int S,
+                            uint32_t *__restrict__ mask) {
+  const int n = n_dev ? min(*n_dev, n_host) : n_host;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int4 p = reinterpret_cast<const int4 *>(indices)[i];
     const int lin = ((p.x * S + p.y) * S + p.z) * S + p.w;
@@ -95,8 +97,10 @@ __global__ void k_mark_rows(const int32_t *__restrict__ indices, int n, int S, u
   }
 }
 
-__global__ void k_fill_perm(const int32_t *__restrict__ indices, int n, int S, const uint32_t *__restrict__ mask,
-                            const int32_t *__restrict__ wprefix, int32_t *__restrict__ perm) {
+__global__ void k_fill_perm(const int32_t *__restrict__ indices, const int32_t *__restrict__ n_dev, int n_host, int S,
+                            const uint32_t *__restrict__ mask, const int32_t *__restrict__ wprefix,
+                            int32_t *__restrict__ perm) {
+  const int n = n_dev ? min(*n_dev, n_host) : n_host;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int4 p = reinterpret_cast<const int4 *>(indices)[i];
     const int lin = ((p.x * S + p.y) * S + p.z) * S + p.w;
@@ -266,27 +270,52 @@ inline long long grid_words(int batch, int S) { return ((long long)batch * S * S
 
 }  // namespace
 
+// library-internal: zero `nwords` 32-bit words with a kernel (a plain kernel node when the stream is being captured;
+// memset nodes are avoided in the whole-forward graph)
+__global__ void k_zero_words(uint32_t *__restrict__ p, long long nwords) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  uint4 *p4 = reinterpret_cast<uint4 *>(p);
+  const long long n4 = ((reinterpret_cast<uintptr_t>(p) & 15) == 0) ? nwords >> 2 : 0;
+  for (long long j = i; j < n4; j += stride) p4[j] = make_uint4(0u, 0u, 0u, 0u);
+  for (long long j = 4 * n4 + i; j < nwords; j += stride) p[j] = 0u;
+}
+void dcl_internal_zero_words(void *p, long long nwords, hipStream_t s) {
+  if (nwords <= 0) return;
+  hipLaunchKernelGGL(k_zero_words, dim3(dcl_grid_1d((nwords + 3) / 4, 256, 2048)), dim3(256), 0, s, (uint32_t *)p, nwords);
+}
+
 // library-internal (hidden visibility): exclusive popcount prefix of a bitmask, wprefix[nwords] = total
 int dcl_internal_scan_mask(const uint32_t *mask, int nwords, int32_t *wprefix, int32_t *scratch, hipStream_t s) {
   return scan_mask(mask, nwords, wprefix, scratch, s);
 }
 
+// n_rows_dev (optional): the live row count on the device; n_rows then only bounds it (capacity mode, graph capture)
+int dcl_internal_grid_from_indices(const int32_t *indices, const int32_t *n_rows_dev, int n_rows, int batch, int S,
+                                   uint32_t *mask, int32_t *wprefix, int32_t *perm, int32_t *scratch,
+                                   dclStream_t stream);
+
 DCL_API int dcl_grid_from_indices(const int32_t *indices, int n_rows, int batch, int S, uint32_t *mask,
                                   int32_t *wprefix, int32_t *perm, int32_t *scratch, dclStream_t stream) {
+  return dcl_internal_grid_from_indices(indices, nullptr, n_rows, batch, S, mask, wprefix, perm, scratch, stream);
+}
+
+int dcl_internal_grid_from_indices(const int32_t *indices, const int32_t *n_rows_dev, int n_rows, int batch, int S,
+                                   uint32_t *mask, int32_t *wprefix, int32_t *perm, int32_t *scratch,
+                                   dclStream_t stream) {
   DCL_CHECK_ARG(batch > 0 && S > 0 && n_rows >= 0 && mask && wprefix && scratch);
   DCL_CHECK_ARG(grid_words(batch, S) < (1ll << 26));
   hipStream_t s = (hipStream_t)stream;
   const int nwords = (int)grid_words(batch, S);
-  hipError_t e = hipMemsetAsync(mask, 0, sizeof(uint32_t) * (size_t)nwords, s);
-  if (e != hipSuccess) { dcl_set_error("dcl_grid_from_indices: memset: %s", hipGetErrorString(e)); return (int)e; }
+  dcl_internal_zero_words(mask, nwords, s);
   if (n_rows > 0) {
     DCL_CHECK_ARG(indices);
-    hipLaunchKernelGGL(k_mark_rows, dim3(dcl_grid_1d(n_rows, 256)), dim3(256), 0, s, indices, n_rows, S, mask);
+    hipLaunchKernelGGL(k_mark_rows, dim3(dcl_grid_1d(n_rows, 256)), dim3(256), 0, s, indices, n_rows_dev, n_rows, S, mask);
   }
   scan_mask(mask, nwords, wprefix, scratch, s);
   if (perm && n_rows > 0)
-    hipLaunchKernelGGL(k_fill_perm, dim3(dcl_grid_1d(n_rows, 256)), dim3(256), 0, s, indices, n_rows, S, mask,
-                       wprefix, perm);
+    hipLaunchKernelGGL(k_fill_perm, dim3(dcl_grid_1d(n_rows, 256)), dim3(256), 0, s, indices, n_rows_dev, n_rows, S,
+                       mask, wprefix, perm);
   DCL_LAUNCH_CHECK();
   return 0;
 }
@@ -312,8 +341,7 @@ DCL_API int dcl_conv_out_grid(const int32_t *in_indices, const int32_t *n_in_dev
       hipLaunchKernelGGL((k_out_mask_k3<2>), dim3(dcl_grid_1d(nwords, 256)), dim3(256), 0, s, in_mask, batch, S_in,
                          S_out, nwords, out_mask);
   } else {
-    hipError_t e = hipMemsetAsync(out_mask, 0, sizeof(uint32_t) * (size_t)nwords, s);
-    if (e != hipSuccess) { dcl_set_error("dcl_conv_out_grid: memset: %s", hipGetErrorString(e)); return (int)e; }
+    dcl_internal_zero_words(out_mask, nwords, s);
     const int kvol = ksize * ksize * ksize;
     const long long in_work = (long long)n_in_host * kvol;                  // n_in_host bounds *n_in_dev
     hipLaunchKernelGGL(k_mark_conv_outputs, dim3(dcl_grid_1d(in_work > 0 ? in_work : 1, 256)), dim3(256), 0, s,

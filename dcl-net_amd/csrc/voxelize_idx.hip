@@ -11,6 +11,7 @@
 //   5. unordered append of every point to its voxel's row, then a per-voxel insertion sort (rows are short)
 #include "common.h"
 
+void dcl_internal_zero_words(void *p, long long nwords, hipStream_t s);
 int dcl_internal_scan_mask(const uint32_t *mask, int nwords, int32_t *wprefix, int32_t *scratch, hipStream_t s);
 
 namespace {
@@ -133,11 +134,11 @@ DCL_API int dcl_voxelize_idx_gpu_count(const int64_t *coords, int n, int batch, 
   DCL_CHECK_ARG((mode == 3 || mode == 4) && ws && input_map && info_dev && vi_layout(n, batch, S, &L) &&
                 ws_bytes >= (int64_t)L.total && (n == 0 || coords));
   hipStream_t s = (hipStream_t)stream;
-  (void)hipMemsetAsync(at<uint32_t>(ws, L.vmask), 0, 4 * (size_t)L.nvw, s);
-  (void)hipMemsetAsync(at<uint32_t>(ws, L.pmask), 0, 4 * (size_t)L.npw, s);
-  (void)hipMemsetAsync(at<int32_t>(ws, L.counts), 0, 4 * (size_t)(n > 0 ? n : 1), s);
-  (void)hipMemsetAsync(at<int32_t>(ws, L.cursor), 0, 4 * (size_t)(n > 0 ? n : 1), s);
-  (void)hipMemsetAsync(info_dev, 0, 12, s);
+  dcl_internal_zero_words(at<uint32_t>(ws, L.vmask), L.nvw, s);
+  dcl_internal_zero_words(at<uint32_t>(ws, L.pmask), L.npw, s);
+  dcl_internal_zero_words(at<int32_t>(ws, L.counts), n > 0 ? n : 1, s);
+  dcl_internal_zero_words(at<int32_t>(ws, L.cursor), n > 0 ? n : 1, s);
+  dcl_internal_zero_words(info_dev, 3, s);
   const int g = dcl_grid_1d(n > 0 ? n : 1, 256);
   hipLaunchKernelGGL(k_vi_fill, dim3(g), dim3(256), 0, s, at<int32_t>(ws, L.firstpt), n, 0x7fffffff);
   hipLaunchKernelGGL(k_vi_mark, dim3(g), dim3(256), 0, s, coords, n, S, batch, at<uint32_t>(ws, L.vmask), info_dev + 2);

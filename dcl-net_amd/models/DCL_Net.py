@@ -18,6 +18,7 @@ Two execution paths over the same parameters:
   fused=False -- composes the mirrored modules exactly like the reference graph (materialised attention
       map, per-layer rulebooks); kept as an executable specification and cross-check.
 """
+import os
 from functools import partial
 
 import numpy as np
@@ -191,6 +192,17 @@ class Network(nn.Module):
             pf[side] = runs[side].point_features(torch.cat([bid, xyz], 1).contiguous(), extents, off)
             pts[side] = xyz.reshape(b, n, 3)
 
+        prediction = self._dense(f, pf["inp"], pf["tmp"], b, dev)
+        if self.mode != "test":
+            prediction["sym_flag"] = data["flags"].to(dev)
+        data["labels"]["points_tmp"] = pts["tmp"]
+        data["labels"]["points_inp"] = pts["inp"]
+        return prediction
+
+    def _dense(self, f, pf_inp, pf_tmp, b, dev):
+        """dense half of the fused pipeline on point-major activations: disengage stacks, correspondence attention,
+        confidence + fuser heads, pooling, pose heads.  Static shapes only (graph-capturable)."""
+        pf = {"inp": pf_inp, "tmp": pf_tmp}
         act = {}
         for side, key in (("Xc", "inp"), ("Yo", "tmp")):
             W1t, t1, second = f["dis_" + side]
@@ -224,12 +236,91 @@ class Network(nn.Module):
         prediction = {"trans_pred": trans_pred, "rot_pred": rot_pred, "conf": conf, "F_Xo_p": F_Xo_p}
         if self.mode != "test":
             F_Yc_p = fuse2[:, :256]
-            prediction["sym_flag"] = data["flags"].to(dev)
             prediction["Xo_pred"] = self._mlp(fuse1[:, 256:], f["regressor_Xo"]).reshape(b, self.n_inp, 3)
             prediction["Yc_pred"] = self._mlp(F_Yc_p, f["regressor_Yc"]).reshape(b, self.n_tmp, 3)
-        data["labels"]["points_tmp"] = pts["tmp"]
-        data["labels"]["points_inp"] = pts["inp"]
         return prediction
+
+
+    # ------------------------------------------------------------------ whole-forward hipGraph (small-batch latency)
+    def forward_graphed(self, data):
+        """Same results as forward() (eval mode), but the whole forward -- sparse backbones in capacity mode (device-side
+        row counts, no host read-back), dense part, heads -- is captured once per (b, N, M) into a hipGraph and replayed.
+        Meant for the reference's actual eval regime (one image = a handful of crops per call), where the eager path is
+        bound by ~350 launches + Python, not by the GPU.  Buffers are sized for the worst case of the shape, so keep it
+        to small batches."""
+        assert not self.training and self.fused
+        f = self._fold()
+        dev = self.regressor_rot.layers[0].weight.device
+        b = int(data["batch_offsets"].size(0)) - 1
+        S = int(np.asarray(data["voxel_num_limit"]).astype(np.int64)[0])
+        need_ma = {s: int(data[s]["v2p_maps"].shape[1]) - 1 for s in ("inp", "tmp")}
+        key = (b, self.n_inp, self.n_tmp, S)
+        cache = self.__dict__.setdefault("_graphs", {})
+        ent = cache.get(key)
+        if ent is None or any(need_ma[s] > ent["ma"][s] for s in ("inp", "tmp")):
+            ent = self._capture(f, dev, b, S, {s: max(32, 2 * need_ma[s]) for s in ("inp", "tmp")})
+            cache[key] = ent
+        for s, n in (("inp", self.n_inp), ("tmp", self.n_tmp)):
+            st, d = ent[s], data[s]
+            v0 = int(d["occupied_voxels"].shape[0])
+            st["feats"].copy_(d["feats"], non_blocking=True)
+            st["occ"][:v0].copy_(d["occupied_voxels"], non_blocking=True)
+            st["v2p"].zero_()
+            st["v2p"][:v0, :need_ma[s] + 1].copy_(d["v2p_maps"], non_blocking=True)
+            st["v0"].fill_(v0)
+        if ent["graph"] is None:                       # DCL_NO_GRAPH=1: run the capacity-mode body eagerly (debugging aid)
+            with torch.no_grad():
+                ent["out"] = ent["body"]()
+        else:
+            ent["graph"].replay()
+        out = {k: v.clone() for k, v in ent["out"].items()}
+        data["labels"]["points_tmp"] = ent["tmp"]["feats"][:, 4:7].reshape(b, self.n_tmp, 3).clone()
+        data["labels"]["points_inp"] = ent["inp"]["feats"][:, 4:7].reshape(b, self.n_inp, 3).clone()
+        return out
+
+    def _capture(self, f, dev, b, S, ma):
+        unit = self.unit_voxel_extent
+        assert unit[0] == unit[1] == unit[2]
+        off = float(np.float32(-0.5 * unit[0] * VOXEL_NUM_LIMIT[0]))
+        extents = [float(np.float32(unit[0] * sc)) for sc in SCALE_LISTS]
+        ent = {"ma": ma}
+        for s, n in (("inp", self.n_inp), ("tmp", self.n_tmp)):
+            st = {"feats": torch.zeros((b * n, 7), dtype=torch.float32, device=dev),
+                  "occ": torch.zeros((b * n, 4), dtype=torch.int32, device=dev),
+                  "v2p": torch.zeros((b * n, ma[s] + 1), dtype=torch.int32, device=dev),
+                  "v0": torch.zeros(1, dtype=torch.int32, device=dev)}
+            st["run"] = ops.BackboneRunCap(st["occ"], st["v0"], b, S)
+            st["pf"] = torch.zeros((b * n, 480), dtype=torch.float32, device=dev)
+            st["tmpbuf"] = torch.empty(st["run"].tmp_bytes(b * n), dtype=torch.uint8, device=dev)
+            st["bid"] = torch.arange(b, device=dev, dtype=torch.float32).repeat_interleave(n).unsqueeze(1)
+            ent[s] = st
+
+        def body():
+            for s, bb in (("inp", "backbone_inp"), ("tmp", "backbone_tmp")):
+                st = ent[s]
+                st["run"].geometry()
+                x = ops.voxelize_fp(st["feats"], st["v2p"], self.voxelization_mode)
+                st["run"].features(x, *f[bb + "_ptrs"])
+                pb4 = torch.cat([st["bid"], st["feats"][:, 4:7]], 1).contiguous()
+                st["run"].point_features(pb4, extents, off, st["pf"], st["tmpbuf"])
+            return self._dense(f, ent["inp"]["pf"], ent["tmp"]["pf"], b, dev)
+
+        ent["body"] = body
+        if os.environ.get("DCL_NO_GRAPH") == "1":
+            ent["graph"], ent["out"] = None, None
+            return ent
+        with torch.no_grad():
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):                                         # warm-up: lazy inits, allocator, hipBLASLt plans
+                    body()
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = body()
+        ent["graph"], ent["out"] = g, out
+        return ent
 
     # ------------------------------------------------------------------ compatibility path
     def _forward_compat(self, data):

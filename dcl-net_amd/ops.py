@@ -261,6 +261,57 @@ class BackboneRun(object):
         return out
 
 
+class BackboneRunCap(object):
+    """Capacity-mode backbone pass (whole-forward hipGraph capture): every buffer is sized from (batch, S, V0_cap) alone,
+    live row counts stay on the device, no host read-back.  `occ` is a STATIC (V0_cap,4) buffer whose first *v0_dev rows
+    are live.  All methods only enqueue work, so they can run under torch.cuda.graph()."""
+
+    def __init__(self, occ, v0_dev, batch, S):
+        N.need_cuda(occ, v0_dev)
+        assert occ.dtype == torch.int32 and occ.is_contiguous() and v0_dev.dtype == torch.int32
+        self.occ, self.v0_dev, self.batch, self.S, self.V0 = occ, v0_dev, int(batch), int(S), occ.shape[0]
+        dev = occ.device
+        nbytes = C.c_int64(0)
+        N.check(N.lib().dcl_backbone_ws_bytes(self.batch, self.S, self.V0, C.byref(nbytes)), "backbone_ws_bytes")
+        self.ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+        self.ws_bytes = nbytes.value
+        self.counts_dev = torch.zeros(8, dtype=torch.int32, device=dev)
+        self.chan = (C.c_int32 * 9)(*BACKBONE_CHANNELS)
+        self.caps = (C.c_int32 * 8)()
+        N.check(N.lib().dcl_backbone_caps(self.batch, self.S, self.V0, self.caps), "backbone_caps")
+        n2 = C.c_int64(0)
+        N.check(N.lib().dcl_backbone_ws2_bytes(self.caps, self.chan, C.byref(n2)), "backbone_ws2_bytes")
+        self.ws2 = torch.empty(n2.value, dtype=torch.uint8, device=dev)
+        self.ws2_bytes = n2.value
+        self.levels = [torch.empty((self.caps[2 * m + 1], BACKBONE_CHANNELS[2 * m + 2]), dtype=torch.float32, device=dev)
+                       for m in range(4)]
+        self.level_ptrs = _ptr_array(self.levels)
+
+    def geometry(self):
+        N.check(N.lib().dcl_backbone_geometry_cap(N.ptr(self.occ), N.ptr(self.v0_dev), self.V0, self.batch, self.S,
+                                                  N.ptr(self.ws), self.ws_bytes, N.ptr(self.counts_dev), N.stream()),
+                "backbone_geometry_cap")
+
+    def features(self, vox_feats, weights_arr, scales_arr, shifts_arr):
+        N.check(N.lib().dcl_backbone_features_cap(N.ptr(self.occ), self.V0, self.batch, self.S, N.ptr(self.ws),
+                                                  N.ptr(self.counts_dev), self.chan, N.ptr(vox_feats), weights_arr,
+                                                  scales_arr, shifts_arr, N.ptr(self.ws2), self.ws2_bytes,
+                                                  self.level_ptrs, N.stream()), "backbone_features_cap")
+        return self.levels
+
+    def point_features(self, points_b4, voxel_extents, offset, out, tmp):
+        n = points_b4.shape[0]
+        ve = (C.c_float * 4)(*[float(v) for v in voxel_extents])
+        N.check(N.lib().dcl_point_features_cap(n, N.ptr(points_b4), self.batch, self.S, self.V0, N.ptr(self.ws),
+                                               N.ptr(self.counts_dev), self.chan, self.level_ptrs, ve, _c_float(offset),
+                                               N.ptr(out), out.stride(0), N.ptr(tmp), tmp.numel(), N.stream()),
+                "point_features_cap")
+        return out
+
+    def tmp_bytes(self, n):
+        return 2 * (((n * 12) + 255) // 256 * 256) + 16 * max(1, max(self.caps[1::2]))
+
+
 # ------------------------------------------------------------------------------------ pointnet_sp
 def three_nn_sp(unknown, known, known_seg=None):
     """pointnet2_cuda.three_nn_wrapper of libs/pointnet_sp: returns (dist2 (N,3), idx (N,3) i32)."""

@@ -156,6 +156,21 @@ int dcl_backbone_features(const int32_t *occ, int V0, int batch, int S, void *ws
                           const float *const *weights_host, const float *const *scales_host,
                           const float *const *shifts_host, void *ws2, int64_t ws2_bytes,
                           float *const *level_out_host, dclStream_t stream);
+/* Capacity mode of the three calls (whole-forward hipGraph capture): nothing on the host depends on the data.
+ * occ holds V0_cap rows, the first *V0_dev live; buffers (level_out, ws2) are sized by dcl_backbone_caps' row
+ * capacities (pass them as counts to dcl_backbone_ws2_bytes); kernels read the live counts from counts_dev.        */
+int dcl_backbone_caps(int batch, int S, int V0_cap, int32_t *caps_host /* i32[8] */);
+int dcl_backbone_geometry_cap(const int32_t *occ, const int32_t *V0_dev, int V0_cap, int batch, int S, void *ws,
+                              int64_t ws_bytes, int32_t *counts_dev, dclStream_t stream);
+int dcl_backbone_features_cap(const int32_t *occ, int V0_cap, int batch, int S, void *ws, const int32_t *counts_dev,
+                              const int32_t *channels_host, const float *vox_feats, const float *const *weights_host,
+                              const float *const *scales_host, const float *const *shifts_host, void *ws2,
+                              int64_t ws2_bytes, float *const *level_out_host, dclStream_t stream);
+int dcl_point_features_cap(int n, const float *points_b4, int batch, int S, int V0_cap, void *ws,
+                           const int32_t *counts_dev, const int32_t *channels_host,
+                           const float *const *level_feats_host, const float *voxel_extent_host, float offset,
+                           float *out, int ld, void *tmp, int64_t tmp_bytes, dclStream_t stream);
+
 /* byte offsets (inside ws) of pooled level `level`'s (b,x,y,z) rows and mask-word prefix, and its grid size */
 int dcl_backbone_level_info(int batch, int S, int V0, int level, int64_t *indices_off_host,
                             int64_t *wprefix_off_host, int32_t *S_level_host);
