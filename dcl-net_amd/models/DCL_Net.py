@@ -160,6 +160,15 @@ class Network(nn.Module):
         x = self._lin_relu(x, *layers[1])
         return torch.addmm(layers[2][1], x, layers[2][0])
 
+    def _side_stream(self, dev):
+        """second stream for the template-side backbone (DCL_SINGLE_STREAM=1: everything on the current stream)"""
+        if os.environ.get("DCL_SINGLE_STREAM") == "1":
+            return torch.cuda.current_stream(dev)
+        st = self.__dict__.get("_side")
+        if st is None:
+            st = self.__dict__["_side"] = torch.cuda.Stream(dev)
+        return st
+
     def _forward_fused(self, data):
         f = self._fold()
         dev = self.regressor_rot.layers[0].weight.device
@@ -173,7 +182,16 @@ class Network(nn.Module):
             side_in[side] = (d["feats"].to(dev, non_blocking=True).float().contiguous(),
                              d["v2p_maps"].to(dev, non_blocking=True).int().contiguous(),
                              d["occupied_voxels"].to(dev, non_blocking=True).int().contiguous())
-        runs = {s: ops.BackboneRun(side_in[s][2], b, S) for s in ("inp", "tmp")}
+        # the two backbones are independent until the correspondence attention: the template side runs on a second
+        # HIP stream so that its (small, latency-bound) kernels fill the CUs the observed side leaves idle
+        main, side_stream = torch.cuda.current_stream(dev), self._side_stream(dev)
+        streams = {"inp": main, "tmp": side_stream}
+        side_stream.wait_stream(main)
+        runs = {}
+        for s in ("inp", "tmp"):
+            with torch.cuda.stream(streams[s]):
+                runs[s] = ops.BackboneRun(side_in[s][2], b, S)
+        main.wait_stream(side_stream)
         counts = torch.cat([runs["inp"].counts_dev, runs["tmp"].counts_dev]).cpu().tolist()   # the single host sync
         runs["inp"].set_counts(counts[:8])
         runs["tmp"].set_counts(counts[8:])
@@ -183,14 +201,17 @@ class Network(nn.Module):
         extents = [float(np.float32(unit[0] * sc)) for sc in SCALE_LISTS]
         pf = {}
         pts = {}
+        side_stream.wait_stream(main)
         for side, bb, n in (("inp", "backbone_inp", self.n_inp), ("tmp", "backbone_tmp", self.n_tmp)):
-            feats, v2p, _ = side_in[side]
-            x = ops.voxelize_fp(feats, v2p, self.voxelization_mode)
-            runs[side].features(x, *f[bb + "_ptrs"])
-            xyz = feats[:, 4:7]
-            bid = torch.arange(b, device=dev, dtype=torch.float32).repeat_interleave(n).unsqueeze(1)
-            pf[side] = runs[side].point_features(torch.cat([bid, xyz], 1).contiguous(), extents, off)
-            pts[side] = xyz.reshape(b, n, 3)
+            with torch.cuda.stream(streams[side]):
+                feats, v2p, _ = side_in[side]
+                x = ops.voxelize_fp(feats, v2p, self.voxelization_mode)
+                runs[side].features(x, *f[bb + "_ptrs"])
+                xyz = feats[:, 4:7]
+                bid = torch.arange(b, device=dev, dtype=torch.float32).repeat_interleave(n).unsqueeze(1)
+                pf[side] = runs[side].point_features(torch.cat([bid, xyz], 1).contiguous(), extents, off)
+                pts[side] = xyz.reshape(b, n, 3)
+        main.wait_stream(side_stream)
 
         prediction = self._dense(f, pf["inp"], pf["tmp"], b, dev)
         if self.mode != "test":
@@ -296,13 +317,18 @@ class Network(nn.Module):
             ent[s] = st
 
         def body():
-            for s, bb in (("inp", "backbone_inp"), ("tmp", "backbone_tmp")):
-                st = ent[s]
-                st["run"].geometry()
-                x = ops.voxelize_fp(st["feats"], st["v2p"], self.voxelization_mode)
-                st["run"].features(x, *f[bb + "_ptrs"])
-                pb4 = torch.cat([st["bid"], st["feats"][:, 4:7]], 1).contiguous()
-                st["run"].point_features(pb4, extents, off, st["pf"], st["tmpbuf"])
+            main, side_stream = torch.cuda.current_stream(dev), self._side_stream(dev)
+            side_stream.wait_stream(main)                                  # fork: two parallel branches in the graph
+            for s, bb, stream in (("inp", "backbone_inp", main), ("tmp", "backbone_tmp", side_stream)):
+                with torch.cuda.stream(stream):
+                    st = ent[s]
+                    st["run"].geometry()
+                    x = ops.voxelize_fp(st["feats"], st["v2p"], self.voxelization_mode)
+                    st["run"].features(x, *f[bb + "_ptrs"])
+                    pb4 = torch.cat([st["bid"], st["feats"][:, 4:7]], 1).contiguous()
+                    st["run"].point_features(pb4, extents, off, st["pf"], st["tmpbuf"])
+                    st["keep"] = (x, pb4)
+            main.wait_stream(side_stream)                                  # join
             return self._dense(f, ent["inp"]["pf"], ent["tmp"]["pf"], b, dev)
 
         ent["body"] = body
