@@ -5,99 +5,120 @@
 //   gather_points sampling_gpu.cu:8-24      out[b,c,m]   = points[b,c,idx[b,m]]
 //   furthest_point_sampling sampling_gpu.cu:86-253
 //
-// MI355X mapping.  ball_query: one centre per lane, candidate index wave-uniform (scalar loads
-// broadcast the candidate), wave-level early exit by ballot once all 64 lanes are full; hits are
-// staged in LDS ([slot][thread], +1 padded) so the final (B,M,nsample) rows leave as coalesced
-// 256-B stores instead of one dword per lane per hit.  group_points/gather_points: pure HBM
-// streaming, write-dominated -- each lane owns 4 consecutive outputs (one 16-B store), reuses its
-// 4 indices over a chunk of channels, source rows stay in L2.  FPS: one workgroup per cloud,
-// points + running min-distance held in REGISTERS for the whole run (the reference re-reads
-// dataset[] and temp[] from global memory every iteration), wave argmax by DPP/shuffle, one LDS
-// exchange + two barriers per iteration.
+// MI355X mapping.  ball_query: 16 lanes per centre over LDS-staged 1024-candidate super-tiles, branch-free packed
+// distance tests into 64-bit hit masks, prefix-sum compaction, workgroup-level early exit once its 16 centres are
+// full; hits are staged in LDS ([slot][centre], +1 padded) so the final (B,M,nsample) rows leave as coalesced stores.
+// group_points/gather_points: pure HBM streaming, write-dominated -- channel rows of a cloud staged in LDS, each lane
+// owns 4 consecutive outputs (one 16-B store).  FPS: one workgroup per cloud, points + running min-distance held in
+// REGISTERS for the whole run (the reference re-reads dataset[] and temp[] from global memory every iteration), wave
+// argmax by DPP/shuffle, one LDS exchange + two barriers per iteration.
 #include "common.h"
 #include <math.h>
 
 namespace {
 
 // ------------------------------------------------------------------------------------ ball query
-// FOUR lanes per centre.  Per 256-candidate tile (staged in LDS as x[]/y[]/z[] arrays, broadcast read, packed f32x2 math)
-// each of the 4 lanes tests a contiguous 64-candidate quarter and builds a 64-bit hit mask -- branch-free, no
-// stores; the quarter masks, taken in order, list the hits in ascending index, so the group's leader appends the
-// first `nsample` of them to its LDS column ([slot][centre], +1 padded) at a cost proportional to the HITS, not the
-// candidates.  A workgroup (one wave, 16 centres) leaves as soon as all its centres are full; rows go out coalesced,
-// padded with the first hit (ball_query_gpu.cu:35-39).
-constexpr int kBQTile = 256;
-constexpr int kBQCentres = 16;                 // centres per workgroup = one wave: it leaves as soon as ITS 16 are full
+// A workgroup (4 waves) owns 16 centres; SIXTEEN lanes per centre.  The cloud is walked in super-tiles of 1024
+// candidates staged in LDS as x[]/y[]/z[] arrays (16 segments of 64, pitch 66 floats: the 16 segment readers of a
+// ds_read_b64 fall on 16 different bank pairs, the 4 centres sharing a segment broadcast).  Each lane tests ITS 64-candidate
+// segment with packed f32x2 math and builds a 64-bit hit mask -- branch-free, no stores: the hit bit is the sign of
+// (d2 - r2), shifted in with one v_alignbit per candidate.  A 16-lane prefix sum over the popcounts gives every segment
+// its first output slot, so all 16 lanes append their own hits in parallel (cost ~ hits/16, not candidates) to the LDS
+// column of the centre ([slot][centre], +1 padded).  The workgroup leaves as soon as all its 16 centres are full; rows go
+// out coalesced, padded with the first hit (ball_query_gpu.cu:35-39).  Sparse clouds (few hits, whole-cloud scans) keep
+// 4x the lanes per centre of the earlier one-wave layout busy, which is what bounded the kernel (tail of slow waves).
+constexpr int kBQSuper = 1024;                 // candidates per staged super-tile
+constexpr int kBQSegPitch = 66;                // floats between the 64-candidate segments
+constexpr int kBQCentres = 16;                 // centres per workgroup
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-__global__ __launch_bounds__(64) void k_ball_query(int n, int m, float radius2, int nsample,
-                                                   const float *__restrict__ new_xyz, const float *__restrict__ xyz,
-                                                   int32_t *__restrict__ idx) {
-  extern __shared__ int32_t bq_lds[];          // hits[nsample][17], cnt[16], tile x[256] y[256] z[256]
+__global__ __launch_bounds__(256) void k_ball_query(int n, int m, float radius2, int nsample,
+                                                    const float *__restrict__ new_xyz, const float *__restrict__ xyz,
+                                                    int32_t *__restrict__ idx) {
+  extern __shared__ int32_t bq_lds[];          // hits[nsample][17], cnt[16], flags[4], x[16*66] y[] z[]
   constexpr int P = kBQCentres + 1;
   int32_t *hits = bq_lds;
   int32_t *cnts = bq_lds + (size_t)nsample * P;
-  float *tx = reinterpret_cast<float *>(bq_lds + (((size_t)nsample * P + kBQCentres + 3) & ~(size_t)3));
-  float *ty = tx + kBQTile, *tz = ty + kBQTile;
+  int32_t *flags = cnts + kBQCentres;
+  float *tx = reinterpret_cast<float *>(bq_lds + (((size_t)nsample * P + kBQCentres + 4 + 3) & ~(size_t)3));
+  float *ty = tx + 16 * kBQSegPitch, *tz = ty + 16 * kBQSegPitch;
   const int bs = blockIdx.y;
-  const int t = threadIdx.x;
-  const int sub = t & 3, cs = t >> 2;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int seg = t & 15, cs = t >> 4;
   const int p = blockIdx.x * kBQCentres + cs;
   const bool live = p < m;
   const float *c = new_xyz + ((size_t)bs * m + (live ? p : 0)) * 3;
   const f32x2 cx = {c[0], c[0]}, cy = {c[1], c[1]}, cz = {c[2], c[2]};
+  const f32x2 r2v = {radius2, radius2};
   const float *X = xyz + (size_t)bs * n * 3;
-  int cnt = live ? 0 : nsample;                // kept identical in the 4 lanes of a group
-  for (int base = 0; base < n; base += kBQTile) {
-    if (__ballot(cnt < nsample) == 0ull) break;          // all 16 centres of this wave are full
-    const int tn = min(kBQTile, n - base);
-    __syncthreads();
+  const bool vec_ok = ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+  int cnt = live ? 0 : nsample;                // kept identical in the 16 lanes of a centre
+  for (int base = 0; base < n; base += kBQSuper) {
+    const unsigned long long open = __ballot(cnt < nsample);
+    if (lane == 0) flags[wave] = open != 0ull;
+    __syncthreads();                                     // also: everyone is done with the previous super-tile
+    if ((flags[0] | flags[1] | flags[2] | flags[3]) == 0) break;          // all 16 centres are full
+    {
+      // stage 4 consecutive candidates per thread (12 floats); rows past n: never within any radius
+      const int j0 = base + 4 * t;
+      float v[12];
+      if (vec_ok && j0 + 4 <= n) {
+        const float4 *q = reinterpret_cast<const float4 *>(X + (size_t)j0 * 3);
+        const float4 a = q[0], b4 = q[1], c4 = q[2];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b4.x; v[5] = b4.y; v[6] = b4.z; v[7] = b4.w;
+        v[8] = c4.x; v[9] = c4.y; v[10] = c4.z; v[11] = c4.w;
+      } else {
 #pragma unroll
-    for (int i = 0; i < kBQTile / 64; ++i) {
-      const int j = t + i * 64;
-      float x = 3.0e38f, y = 3.0e38f, z = 3.0e38f;       // padding rows: never within any radius
-      if (j < tn) { const float *q = X + (size_t)(base + j) * 3; x = q[0]; y = q[1]; z = q[2]; }
-      tx[j] = x; ty[j] = y; tz[j] = z;
+        for (int k = 0; k < 12; ++k) v[k] = (j0 + k / 3 < n) ? X[(size_t)j0 * 3 + k] : 3.0e38f;
+      }
+      const int o = (t >> 4) * kBQSegPitch + ((4 * t) & 63);             // segment of candidate 4t, offset inside it
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { tx[o + u] = v[3 * u]; ty[o + u] = v[3 * u + 1]; tz[o + u] = v[3 * u + 2]; }
     }
     __syncthreads();
     // two candidates per packed instruction; same fma association as dcl_dist2, per component
     unsigned mlo = 0u, mhi = 0u;
-    const f32x2 *px = reinterpret_cast<const f32x2 *>(tx + sub * 64);
-    const f32x2 *py = reinterpret_cast<const f32x2 *>(ty + sub * 64);
-    const f32x2 *pz = reinterpret_cast<const f32x2 *>(tz + sub * 64);
+    const f32x2 *px = reinterpret_cast<const f32x2 *>(tx + seg * kBQSegPitch);
+    const f32x2 *py = reinterpret_cast<const f32x2 *>(ty + seg * kBQSegPitch);
+    const f32x2 *pz = reinterpret_cast<const f32x2 *>(tz + seg * kBQSegPitch);
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
       const f32x2 dx = cx - px[i], dy = cy - py[i], dz = cz - pz[i];
       const f32x2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));
-      const unsigned b0 = d2.x < radius2 ? 1u : 0u, b1 = d2.y < radius2 ? 1u : 0u;
-      if (i < 16) mlo |= (b0 << (2 * i)) | (b1 << (2 * i + 1));
-      else mhi |= (b0 << (2 * i - 32)) | (b1 << (2 * i - 31));
-    }
-    const unsigned long long mask = ((unsigned long long)mhi << 32) | mlo;
-    // the leader (sub 0) walks the 4 quarter masks in index order
-    const int lead = t & ~3;
-    unsigned long long mq[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) mq[s] = __shfl(mask, lead + s, 64);
-    if (sub == 0) {
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        unsigned long long mm = mq[s];
-        while (mm != 0ull && cnt < nsample) {
-          const int bit = __ffsll((long long)mm) - 1;
-          mm &= mm - 1ull;
-          hits[(size_t)cnt * P + cs] = base + s * 64 + bit;
-          ++cnt;
-        }
+      const f32x2 sg = d2 - r2v;                         // sign bit set <=> d2 < r2 (exact for finite/inf operands)
+      if (i < 16) {
+        mlo = __builtin_amdgcn_alignbit(mlo, __float_as_uint(sg.x), 31);
+        mlo = __builtin_amdgcn_alignbit(mlo, __float_as_uint(sg.y), 31);
+      } else {
+        mhi = __builtin_amdgcn_alignbit(mhi, __float_as_uint(sg.x), 31);
+        mhi = __builtin_amdgcn_alignbit(mhi, __float_as_uint(sg.y), 31);
       }
     }
-    cnt = __shfl(cnt, lead, 64);
+    unsigned long long mask = ((unsigned long long)__brev(mhi) << 32) | __brev(mlo);   // bit j = candidate j of the segment
+    // first output slot of this segment: 16-lane exclusive prefix of the hit counts
+    const int pc = __popcll(mask);
+    int incl = pc;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+      const int up = __shfl_up(incl, d, 16);
+      if (seg >= d) incl += up;
+    }
+    const int total = __shfl(incl, 15, 16);
+    int slot = cnt + incl - pc;
+    const int j0 = base + seg * 64;
+    while (mask != 0ull && slot < nsample) {
+      const int bit = __ffsll((long long)mask) - 1;
+      mask &= mask - 1ull;
+      hits[(size_t)slot * P + cs] = j0 + bit;
+      ++slot;
+    }
+    cnt = min(cnt + total, nsample);
   }
-  if (sub == 0) cnts[cs] = live ? cnt : 0;
+  if (seg == 0) cnts[cs] = live ? cnt : 0;
   __syncthreads();
   const int p0 = blockIdx.x * kBQCentres;
   const int rows = min(kBQCentres, m - p0);
   int32_t *o = idx + ((size_t)bs * m + p0) * nsample;
-  for (int e = t; e < rows * nsample; e += 64) {
+  for (int e = t; e < rows * nsample; e += 256) {
     const int r = e / nsample, s = e - r * nsample;
     const int cr = cnts[r];
     int v = 0;
@@ -110,21 +131,29 @@ __global__ __launch_bounds__(64) void k_ball_query(int n, int m, float radius2, 
 // LDS-staged gather: a workgroup owns CC channel rows of one cloud (CC*N floats in LDS, filled with coalesced 16-B
 // loads) and streams the whole (npoints*nsample) index list against them: indices are read once per CC channels,
 // every output leaves as a 16-B store, and the random reads hit LDS instead of the vector-memory path.
-template <int CC>
+template <int CC, bool NT>
 __global__ __launch_bounds__(1024) void k_group_points_lds(int c, int n, int nps, const float *__restrict__ points,
                                                           const int32_t *__restrict__ idx, float *__restrict__ out) {
-  extern __shared__ float gp_lds[];            // [CC][n]
+  extern __shared__ __attribute__((aligned(16))) float gp_lds[];            // [CC][n]
   const int bs = blockIdx.z;
   const int c0 = blockIdx.y * CC;
   const int ncc = min(CC, c - c0);
+  const int nthr = blockDim.x;
   const float *P = points + ((size_t)bs * c + c0) * n;
-  for (int j = threadIdx.x; j < ncc * n; j += 1024) gp_lds[j] = P[j];
+  const int tot = ncc * n;
+  if ((reinterpret_cast<uintptr_t>(P) & 15) == 0) {
+    for (int j = threadIdx.x; j < (tot >> 2); j += nthr)
+      reinterpret_cast<float4 *>(gp_lds)[j] = reinterpret_cast<const float4 *>(P)[j];
+    for (int j = (tot & ~3) + threadIdx.x; j < tot; j += nthr) gp_lds[j] = P[j];
+  } else {
+    for (int j = threadIdx.x; j < tot; j += nthr) gp_lds[j] = P[j];
+  }
   __syncthreads();
   const int nq = nps >> 2;
   const int4 *I = reinterpret_cast<const int4 *>(idx + (size_t)bs * nps);
   float *O = out + ((size_t)bs * c + c0) * nps;
 #pragma unroll 2
-  for (int q = blockIdx.x * 1024 + threadIdx.x; q < nq; q += gridDim.x * 1024) {
+  for (int q = blockIdx.x * nthr + threadIdx.x; q < nq; q += gridDim.x * nthr) {
     const int4 id = I[q];
 #pragma unroll
     for (int j = 0; j < CC; ++j) {
@@ -132,7 +161,14 @@ __global__ __launch_bounds__(1024) void k_group_points_lds(int c, int n, int nps
       const float *row = gp_lds + j * n;
       float4 v;
       v.x = row[id.x]; v.y = row[id.y]; v.z = row[id.z]; v.w = row[id.w];
-      reinterpret_cast<float4 *>(O + (size_t)j * nps)[q] = v;
+      float4 *dst = reinterpret_cast<float4 *>(O + (size_t)j * nps) + q;
+      if (NT) {
+        typedef float f32x4_t __attribute__((ext_vector_type(4)));
+        const f32x4_t nv = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(nv, reinterpret_cast<f32x4_t *>(dst));
+      } else {
+        *dst = v;
+      }
     }
   }
 }
@@ -316,14 +352,20 @@ DCL_API int dcl_ball_query(int b, int n, int m, float radius, int nsample, const
   DCL_CHECK_ARG(new_xyz && idx && (n == 0 || xyz) && b <= 65535);
   hipStream_t s = (hipStream_t)stream;
   const float r2 = radius * radius;
-  const size_t lds = ((((size_t)nsample * (kBQCentres + 1) + kBQCentres + 3) & ~(size_t)3)) * 4 + (size_t)kBQTile * 12;
+  const size_t lds = ((((size_t)nsample * (kBQCentres + 1) + kBQCentres + 4 + 3) & ~(size_t)3)) * 4 +
+                     (size_t)3 * 16 * kBQSegPitch * 4;
   DCL_CHECK_ARG(lds <= 160 * 1024);
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute((const void *)k_ball_query, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k_ball_query, dim3(dcl_div_up(m, kBQCentres), b), dim3(64), lds, s, n, m, r2, nsample, new_xyz,
+  hipLaunchKernelGGL(k_ball_query, dim3(dcl_div_up(m, kBQCentres), b), dim3(256), lds, s, n, m, r2, nsample, new_xyz,
                      xyz, idx);
   DCL_LAUNCH_CHECK();
   return 0;
+}
+
+static int g_gp_cfg[4] = {0, 0, 0, 0};   // tuning hook: rows per workgroup, x-blocks, threads, stores (2 = plain); 0 = default
+DCL_API void dcl_debug_group_points_cfg(int cc, int xb, int threads, int nontemporal) {
+  g_gp_cfg[0] = cc; g_gp_cfg[1] = xb; g_gp_cfg[2] = threads; g_gp_cfg[3] = nontemporal;
 }
 
 DCL_API int dcl_group_points(int b, int c, int n, int npoints, int nsample, const float *points, const int32_t *idx,
@@ -334,24 +376,31 @@ DCL_API int dcl_group_points(int b, int c, int n, int npoints, int nsample, cons
   DCL_CHECK_ARG(points && idx && out && b <= 65535 && c <= 65535 && nps < (1ll << 31));
   hipStream_t s = (hipStream_t)stream;
   if (nps % 4 == 0 && n <= 36 * 1024 && nps >= 4096) {
-    // LDS-staged rows: as many channel rows per workgroup as fit ~144 KiB (1 workgroup of 512 threads per CU)
-    const int cc = (int)((144 * 1024) / ((size_t)n * 4));
-    const size_t lds = (size_t)(cc >= 4 ? 4 : cc >= 3 ? 3 : cc >= 2 ? 2 : 1) * n * 4;
-    const int ccu = cc >= 4 ? 4 : cc >= 3 ? 3 : cc >= 2 ? 2 : 1;
+    // LDS-staged rows: ~48 KiB of channel rows per workgroup, so that 2 workgroups of 1024 threads share a CU and one
+    // fills its rows while the other streams (measured best at the north-star shape: 1 row of 12288 floats, 5.97 TB/s)
+    const int cc = (int)((48 * 1024) / ((size_t)n * 4));
+    int ccu = cc >= 4 ? 4 : cc >= 3 ? 3 : cc >= 2 ? 2 : 1;
+    if (g_gp_cfg[0] > 0 && g_gp_cfg[0] <= 4 && (size_t)g_gp_cfg[0] * n * 4 <= 144 * 1024) ccu = g_gp_cfg[0];
+    const size_t lds = (size_t)ccu * n * 4;
+    const int threads = g_gp_cfg[2] > 0 ? g_gp_cfg[2] : 1024;
     const int ychunks = dcl_div_up(c, ccu);
     // enough x-blocks to give every CU work, few enough that the row fill stays a small fraction
     int xb = dcl_div_up(256 * 2, ychunks * b);
     if (xb < 1) xb = 1;
     const int max_xb = dcl_div_up(nps / 4, 1024 * 8);
     if (xb > max_xb) xb = max_xb > 0 ? max_xb : 1;
-#define GPL(CCU)                                                                                               \
+    if (g_gp_cfg[1] > 0) xb = g_gp_cfg[1];
+    const bool nt = g_gp_cfg[3] != 2;                  // nontemporal (streaming) stores unless the hook says 2 = plain
+#define GPL(CCU, NTB)                                                                                               \
   do {                                                                                                         \
-    (void)hipFuncSetAttribute((const void *)k_group_points_lds<CCU>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+    (void)hipFuncSetAttribute((const void *)k_group_points_lds<CCU, NTB>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               (int)lds);                                                                       \
-    hipLaunchKernelGGL((k_group_points_lds<CCU>), dim3(xb, ychunks, b), dim3(1024), lds, s, c, n, (int)nps, points, \
+    hipLaunchKernelGGL((k_group_points_lds<CCU, NTB>), dim3(xb, ychunks, b), dim3(threads), lds, s, c, n, (int)nps, points, \
                        idx, out);                                                                              \
   } while (0)
-    if (ccu == 4) GPL(4); else if (ccu == 3) GPL(3); else if (ccu == 2) GPL(2); else GPL(1);
+#define GPL2(CCU) do { if (nt) GPL(CCU, true); else GPL(CCU, false); } while (0)
+    if (ccu == 4) GPL2(4); else if (ccu == 3) GPL2(3); else if (ccu == 2) GPL2(2); else GPL2(1);
+#undef GPL2
 #undef GPL
   } else if (nps % 4 == 0) {
     constexpr int CC = 8;

@@ -265,6 +265,9 @@ int dcl_add_s(int b, int P, const float *cld, const int32_t *cls, const float *R
 void dcl_debug_force_valu_conv(int on);
 /* Test hook: 0 = automatic choice of the attention kernel, 1 = shared-tile 8-wave variant, 2 = double-buffered 4-wave. */
 void dcl_debug_attention_variant(int v);
+/* Tuning hook for dcl_group_points' LDS-staged kernel: channel rows per workgroup, x-blocks, threads per workgroup,
+ * store kind (2 = plain instead of nontemporal); 0 = built-in choice for each. */
+void dcl_debug_group_points_cfg(int cc, int xb, int threads, int nontemporal);
 
 #ifdef __cplusplus
 }

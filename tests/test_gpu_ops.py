@@ -232,7 +232,8 @@ def _cloud(rng, b, n, dup=0.2):
     return x
 
 
-@pytest.mark.parametrize("n,m,ns,r", [(1000, 300, 16, 0.05), (4096, 512, 64, 0.03), (333, 77, 5, 0.2), (500, 64, 200, 0.05)])
+@pytest.mark.parametrize("n,m,ns,r", [(1000, 300, 16, 0.05), (4096, 512, 64, 0.03), (333, 77, 5, 0.2), (500, 64, 200, 0.05),
+                                       (3001, 50, 64, 0.02)])
 def test_ball_query_bit_exact(dcl, oracle, n, m, ns, r):
     rng = np.random.default_rng(n + ns)
     xyz = _cloud(rng, 3, n)
