@@ -123,10 +123,11 @@ def primitives_roofline(dcl, reps=5):
                                       "unit": "GB/s", "frac": round(tot_b / tot_ms / 1e6 / PEAK_HBM, 4)}
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    dcl.ops.furthest_point_sampling(xyz, NP)
+    for _ in range(3):
+        dcl.ops.furthest_point_sampling(xyz, NP)
     b.record()
     torch.cuda.synchronize()
-    out["fps_ms"] = round(a.elapsed_time(b), 3)
+    out["fps_ms"] = round(a.elapsed_time(b) / 3, 3)
     return out
 
 

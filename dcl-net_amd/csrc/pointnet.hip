@@ -213,76 +213,101 @@ __device__ __forceinline__ Cand better(const Cand &a, const Cand &b) {
   return (b.d > a.d || (b.d == a.d && b.key < a.key)) ? b : a;
 }
 
-template <int R>   // R = points per thread (registers), block = TR threads
+// Register-resident kernel.  The (larger d, then smaller brev(t)) order is one unsigned 64-bit maximum over
+//   key64 = bits(d) << 32 | (TR-1 - brev(t)) << 22 | k        (d >= 0, so its bit pattern is monotonic; k < 2^22)
+// reduced with DPP inside the 16-lane rows, one LDS exchange of the 4 row winners of every wave, ONE barrier per
+// iteration (the exchange buffer alternates), then every wave reduces the <= 64 row winners itself, so nobody waits for
+// a broadcast.  The winner's coordinates come from an LDS copy of the cloud (n*12 B, up to ~13k points; beyond that from
+// global memory) instead of a dependent global load on the critical path.
+__device__ __forceinline__ unsigned long long dpp_max_u64(unsigned long long v, const int ctrl_sel) {
+  unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32), olo, ohi;
+  switch (ctrl_sel) {                                              // dpp_ctrl must be an immediate
+    case 0: olo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, false); ohi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, false); break;   // quad_perm [1,0,3,2]
+    case 1: olo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xF, 0xF, false); ohi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xF, 0xF, false); break;   // quad_perm [2,3,0,1]
+    case 2: olo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xF, 0xF, false); ohi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xF, 0xF, false); break; // row_half_mirror
+    default: olo = __builtin_amdgcn_update_dpp(lo, lo, 0x140, 0xF, 0xF, false); ohi = __builtin_amdgcn_update_dpp(hi, hi, 0x140, 0xF, 0xF, false); break; // row_mirror
+  }
+  const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+  return o > v ? o : v;
+}
+__device__ __forceinline__ unsigned long long row_max_u64(unsigned long long v) {   // all 16 lanes of a row get the row maximum
+  v = dpp_max_u64(v, 0); v = dpp_max_u64(v, 1); v = dpp_max_u64(v, 2); v = dpp_max_u64(v, 3);
+  return v;
+}
+__device__ __forceinline__ unsigned long long wave_max_of_rows_u64(unsigned long long v) {   // v uniform per row -> wave maximum (uniform)
+  unsigned long long m = 0ull;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, 16 * r), hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), 16 * r);
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+    m = o > m ? o : m;
+  }
+  return m;
+}
+
+template <int R, bool PTS_IN_LDS>   // R = points per thread (registers), block = TR threads (TR >= 64)
 __global__ __launch_bounds__(1024) void k_fps(int n, int m, int TR, int log2TR, const float *__restrict__ dataset,
                                               float *__restrict__ temp, int32_t *__restrict__ idxs) {
-  __shared__ float s_d[16];
-  __shared__ int s_i[16];
-  __shared__ unsigned s_k[16];
-  __shared__ float s_old[3];
-  __shared__ int s_oldi;
+  extern __shared__ __attribute__((aligned(16))) unsigned char fps_lds[];
+  unsigned long long *xch = reinterpret_cast<unsigned long long *>(fps_lds);        // [2][64] row winners
+  float *pts = reinterpret_cast<float *>(fps_lds + 2 * 64 * sizeof(unsigned long long));   // [n][3] when PTS_IN_LDS
   const int bs = blockIdx.x;
-  const int t = threadIdx.x;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const float *X = dataset + (size_t)bs * n * 3;
   float *tp = temp + (size_t)bs * n;
   int32_t *out = idxs + (size_t)bs * m;
-  float px[R], py[R], pz[R], td[R];
+  constexpr int R2 = (R + 1) / 2;
+  f32x2 px[R2], py[R2], pz[R2], td[R2];                // points r and r+1 share a register pair (packed math below)
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
+  for (int r = 0; r < 2 * R2; ++r) {
     const int k = t + r * TR;
-    if (k < n) { px[r] = X[k * 3]; py[r] = X[k * 3 + 1]; pz[r] = X[k * 3 + 2]; td[r] = tp[k]; }
-    else { px[r] = py[r] = pz[r] = 0.f; td[r] = 0.f; }
+    float x = 0.f, y = 0.f, z = 0.f, d = -1.0f;          // slots past n: min-distance -1 never beats a real one (>= 0)
+    if (r < R && k < n) { x = X[k * 3]; y = X[k * 3 + 1]; z = X[k * 3 + 2]; d = tp[k]; }
+    px[r >> 1][r & 1] = x; py[r >> 1][r & 1] = y; pz[r >> 1][r & 1] = z; td[r >> 1][r & 1] = d;
   }
-  const unsigned key = __brev((unsigned)t) >> (32 - (log2TR > 0 ? log2TR : 1));
-  if (t == 0) { out[0] = 0; s_old[0] = X[0]; s_old[1] = X[1]; s_old[2] = X[2]; }
+  if (PTS_IN_LDS)
+    for (int j = t; j < 3 * n; j += TR) pts[j] = X[j];
+  for (int q = t; q < 128; q += TR) xch[q] = 0ull;    // rows of waves that do not exist never win
+  const unsigned key = __brev((unsigned)t) >> (32 - log2TR);
+  const unsigned low_base = ((unsigned)(TR - 1) - key) << 22;
+  if (t == 0) out[0] = 0;
   __syncthreads();
-  const int nw = TR >> 6 ? TR >> 6 : 1;
+  float x1 = X[0], y1 = X[1], z1 = X[2];
   for (int j = 1; j < m; ++j) {
-    const float x1 = s_old[0], y1 = s_old[1], z1 = s_old[2];
-    Cand c; c.d = -1.0f; c.i = 0; c.key = log2TR > 0 ? key : 0u;
+    float bd = -1.0f;
+    int bi = 0;
+    {
+      // two points per packed instruction, dcl_dist2's association per component
+      const f32x2 x2 = {x1, x1}, y2 = {y1, y1}, z2 = {z1, z1};
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int k = t + r * TR;
-      if (k < n) {
-        const float d = dcl_dist2(px[r], py[r], pz[r], x1, y1, z1);
-        const float d2 = fminf(d, td[r]);
-        td[r] = d2;
-        if (d2 > c.d) { c.d = d2; c.i = k; }
+      for (int q = 0; q < R2; ++q) {
+        const f32x2 dx = px[q] - x2, dy = py[q] - y2, dz = pz[q] - z2;
+        const f32x2 d = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));
+        const float da = fminf(d.x, td[q].x), db = fminf(d.y, td[q].y);
+        const int ka = t + 2 * q * TR, kb = ka + TR;     // branch-free: padded slots carry -1 and never win
+        td[q].x = da; td[q].y = db;
+        if (da > bd) { bd = da; bi = ka; }
+        if (db > bd) { bd = db; bi = kb; }
       }
     }
-    // wave argmax
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) {
-      Cand o;
-      o.d = __shfl_xor(c.d, s, 64); o.i = __shfl_xor(c.i, s, 64); o.key = __shfl_xor(c.key, s, 64);
-      c = better(c, o);
-    }
-    __syncthreads();                                   // previous iteration's readers of s_* are done
-    if ((t & 63) == 0) { s_d[t >> 6] = c.d; s_i[t >> 6] = c.i; s_k[t >> 6] = c.key; }
+    unsigned long long v = bd >= 0.0f ? (((unsigned long long)__float_as_uint(bd) << 32) | (low_base | (unsigned)bi)) : 0ull;
+    v = row_max_u64(v);
+    unsigned long long *buf = xch + (j & 1) * 64;
+    if ((lane & 15) == 0) buf[wave * 4 + (lane >> 4)] = v;
     __syncthreads();
-    if (t < 64) {
-      Cand w;
-      if (t < nw) { w.d = s_d[t]; w.i = s_i[t]; w.key = s_k[t]; } else { w.d = -2.0f; w.i = 0; w.key = 0xffffffffu; }
-#pragma unroll
-      for (int s = 8; s >= 1; s >>= 1) {
-        Cand o;
-        o.d = __shfl_xor(w.d, s, 64); o.i = __shfl_xor(w.i, s, 64); o.key = __shfl_xor(w.key, s, 64);
-        w = better(w, o);
-      }
-      if (t == 0) {
-        s_oldi = w.i; out[j] = w.i;
-        s_old[0] = X[w.i * 3]; s_old[1] = X[w.i * 3 + 1]; s_old[2] = X[w.i * 3 + 2];
-      }
-    }
-    __syncthreads();
+    unsigned long long w = row_max_u64(buf[lane]);
+    w = wave_max_of_rows_u64(w);
+    const int wi = (int)((unsigned)w & 0x3fffffu);
+    if (PTS_IN_LDS) { x1 = pts[wi * 3]; y1 = pts[wi * 3 + 1]; z1 = pts[wi * 3 + 2]; }
+    else { x1 = X[wi * 3]; y1 = X[wi * 3 + 1]; z1 = X[wi * 3 + 2]; }
+    if (t == 0) out[j] = wi;
   }
   // the reference leaves the running min-distances in temp[]
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int k = t + r * TR;
-    if (k < n) tp[k] = td[r];
+    if (k < n) tp[k] = td[r >> 1][r & 1];
   }
-  (void)s_oldi;
 }
 
 // generic fallback: any n, distances kept in global temp[] (like the reference)
@@ -432,9 +457,18 @@ DCL_API int dcl_furthest_point_sampling(int b, int n, int m, const float *datase
   const int R = dcl_div_up(n, TR);
   const int block = TR < 64 ? 64 : TR;
   if (TR >= 64 && R <= 16) {
-#define FPS(RR) hipLaunchKernelGGL((k_fps<RR>), dim3(b), dim3(TR), 0, s, n, m, TR, log2TR, dataset, temp, idxs)
+    const bool in_lds = (size_t)n * 12 + 1024 <= 156 * 1024;
+    const size_t lds = 1024 + (in_lds ? (size_t)n * 12 : 0);
+#define FPS_L(RR, L)                                                                                                  \
+  do {                                                                                                                \
+    if (lds > 48 * 1024)                                                                                              \
+      (void)hipFuncSetAttribute((const void *)k_fps<RR, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
+    hipLaunchKernelGGL((k_fps<RR, L>), dim3(b), dim3(TR), lds, s, n, m, TR, log2TR, dataset, temp, idxs);             \
+  } while (0)
+#define FPS(RR) do { if (in_lds) FPS_L(RR, true); else FPS_L(RR, false); } while (0)
     if (R <= 1) FPS(1); else if (R <= 2) FPS(2); else if (R <= 4) FPS(4); else if (R <= 8) FPS(8);
     else if (R <= 12) FPS(12); else FPS(16);
+#undef FPS_L
 #undef FPS
   } else {
     hipLaunchKernelGGL(k_fps_generic, dim3(b), dim3(block), 0, s, n, m, TR, log2TR, dataset, temp, idxs);
