@@ -412,14 +412,30 @@ __global__ __launch_bounds__(256, 2) void k_sparse_conv_tile(
       }
       const float *ap = As + (wr * 32 + r) * AP + 4 * h;
       const float *bp = Bs + (4 * h) * BN + wc * 32 + r;
-      if (__ballot(mine) != 0ull)
+      if (__ballot(mine) != 0ull) {
+        // operands of step i+1 are read from LDS while step i's four MFMAs run (two register sets, order pinned with
+        // sched_group_barrier: 5 DS reads, then 4 MFMAs) -- otherwise every group of MFMAs starts with the LDS latency
+        float4 a_cur = *reinterpret_cast<const float4 *>(ap);
+        float b_cur[4] = {bp[0], bp[BN], bp[2 * BN], bp[3 * BN]};
 #pragma unroll
-      for (int i = 0; i < KC / 8; ++i) {
-        const float4 a = *reinterpret_cast<const float4 *>(ap + 8 * i);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bp[(8 * i + 0) * BN], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bp[(8 * i + 1) * BN], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bp[(8 * i + 2) * BN], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bp[(8 * i + 3) * BN], acc, 0, 0, 0);
+        for (int i = 0; i < KC / 8; ++i) {
+          float4 a_nxt = a_cur;
+          float b_nxt[4] = {b_cur[0], b_cur[1], b_cur[2], b_cur[3]};
+          if (i + 1 < KC / 8) {
+            a_nxt = *reinterpret_cast<const float4 *>(ap + 8 * (i + 1));
+#pragma unroll
+            for (int t = 0; t < 4; ++t) b_nxt[t] = bp[(8 * (i + 1) + t) * BN];
+            __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+          }
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, b_cur[0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.y, b_cur[1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.z, b_cur[2], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.w, b_cur[3], acc, 0, 0, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+          a_cur = a_nxt;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) b_cur[t] = b_nxt[t];
+        }
       }
       asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // MFMA -> VALU hazard pad (see k_sparse_conv_lds)
       j = jn;
@@ -521,7 +537,7 @@ DCL_API int dcl_sparse_conv_fwd(const float *feat, const int32_t *nbr, int cap, 
   const int rows = n_out_dev ? cap : n_out_host;
   if (rows == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  const bool mfma_ok = !g_force_valu && (cin % 8 == 0) && (cout % 32 == 0);
+  const bool mfma_ok = g_force_valu != 1 && (cin % 8 == 0) && (cout % 32 == 0);
   const bool lds_ok = mfma_ok && g_force_valu != 2 && (cin == 16 || cin == 32 || cin == 64 || cin == 128);
   if (lds_ok && g_force_valu != 3) {
     // implicit-GEMM tile kernel: 64x64 tiles (KC=128) when Cout allows, else 128x32 tiles (KC=64)
