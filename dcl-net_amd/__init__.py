@@ -9,14 +9,15 @@ Package layout (only what the hot path needs):
   models/          DCL_Net.Network, Modules, refiner.Refiner: drop-ins for the reference's models/*.py
   synth.py         procedural YCB-V-shaped crops + seeded weights (no datasets/checkpoints offline)
   sharding.py      frame sharding across ranks + exact ADD-S metric reduction
+  crops.py         device-side crop builder (the loader step in front of forward): image -> the `data` dict in HBM
 
 The directory name contains a hyphen (it is the project's name); import it with
     import importlib; dcl = importlib.import_module("dcl-net_amd")
 """
 from . import _native, ops  # noqa: F401
 from . import spconv  # noqa: F401
-from . import synth, sharding  # noqa: F401
+from . import synth, sharding, crops  # noqa: F401
 from .models import DCL_Net, Modules, refiner  # noqa: F401
 
 build = _native.build
-__all__ = ["ops", "spconv", "DCL_Net", "Modules", "refiner", "synth", "sharding", "build"]
+__all__ = ["ops", "spconv", "DCL_Net", "Modules", "refiner", "synth", "sharding", "crops", "build"]

@@ -1,0 +1,128 @@
+"""Device-side crop builder: what `YCBDataset.__getitem__` does per image (YCBV/dataloader_test_YCBV.py:99-258), with
+the per-pixel work on the GPU (csrc/crops.hip) and the result already resident in HBM for `Network.forward`.
+
+    builder = CropBuilder(cfg, cad_points_mm, cad_colors)            # cfg: input_size, tmp_size, unit_voxel_extent, ...
+    data = builder.build(img_u8, depth_u16, label, rois, gt_obj, poses)     # the loader's dict, CUDA tensors
+
+The sampling draws stay `np.random.choice` on the host, made in the reference's order with the reference's arguments, so
+a seeded run consumes the global numpy RNG stream exactly like the original loader and produces the same crops.  That
+needs the per-instance point counts on the host: the one read-back of the builder (plus the {V, maxActive} read-back of
+each voxelize_idx).  No CPU fallback: the arrays are uploaded and everything else happens on the device.
+"""
+import numpy as np
+import torch
+
+from . import ops
+
+RGB_MEAN = (0.485, 0.456, 0.406)                                     # dataloader_test_YCBV.py:57,145
+YCBV_CAMERA = (312.9869, 241.3109, 1066.778, 1067.487, 10000.0)      # cx, cy, fx, fy, depth scale (:77-81)
+MIN_VALID = 32                                                        # :163
+
+
+def snap_box(rois, row, img_h=480, img_w=640):
+    """`get_bbox` (dataloader_test_YCBV.py:266-303): the detection's box grown to sides that are multiples of 40 px
+    (0 -> 40), kept centred and pushed back inside the image.  Returns (rmin, rmax, cmin, cmax)."""
+    r0, r1 = max(int(rois[row][3]) + 1, 0), min(int(rois[row][5]) - 1, img_h)
+    c0, c1 = max(int(rois[row][2]) + 1, 0), min(int(rois[row][4]) - 1, img_w)
+
+    def grow(v):                       # open intervals between the borders -1, 40, 80, ... 680 round up to the next border
+        return (v // 40 + 1) * 40 if -1 < v < 680 and (v % 40 != 0 or v == 0) else v
+    hr, hc = int(grow(r1 - r0) / 2), int(grow(c1 - c0) / 2)
+    mr, mc = int((r0 + r1) / 2), int((c0 + c1) / 2)
+    r0, r1, c0, c1 = mr - hr, mr + hr, mc - hc, mc + hc
+    if r0 < 0:
+        r0, r1 = 0, r1 - r0
+    if c0 < 0:
+        c0, c1 = 0, c1 - c0
+    if r1 > img_h:
+        r0, r1 = r0 - (r1 - img_h), img_h
+    if c1 > img_w:
+        c0, c1 = c0 - (c1 - img_w), img_w
+    return r0, r1, c0, c1
+
+
+class CropBuilder(object):
+    def __init__(self, cfg, cad_points_mm, cad_colors, camera=YCBV_CAMERA, device="cuda"):
+        """cfg: mapping with input_size, tmp_size, unit_voxel_extent, voxel_num_limit, voxelization_mode (the `test`
+        block of configs/config_YCBV_bs32.yaml).  cad_points_mm / cad_colors: {class id: (tmp_size,3) float64}, the
+        loader's list_pc_CAD / list_rgb_CAD (millimetres; colours already mean-subtracted, :57-58)."""
+        self.n_inp, self.n_tmp = int(cfg["input_size"]), int(cfg["tmp_size"])
+        self.unit = np.array(cfg["unit_voxel_extent"]).astype(float)
+        self.limit = np.array(cfg["voxel_num_limit"]).astype(float)
+        self.extent = self.limit * self.unit
+        self.mode = int(cfg["voxelization_mode"])
+        self.camera = tuple(camera)
+        self.dev = torch.device(device)
+        if self.dev.type != "cuda":
+            raise RuntimeError("dcl-net_amd.CropBuilder runs on the GPU only")
+        # template side (:179-183): constant per class -> feats rows and voxel coordinates once, on the device
+        self.cls_ids = sorted(cad_points_mm.keys())
+        self.cls_row = {c: i for i, c in enumerate(self.cls_ids)}
+        pts = torch.stack([torch.FloatTensor(np.asarray(cad_points_mm[c]) / 1000.0) for c in self.cls_ids]).to(self.dev)
+        col = torch.stack([torch.FloatTensor(np.asarray(cad_colors[c])) for c in self.cls_ids]).to(self.dev)
+        assert pts.shape[1] == self.n_tmp
+        feats, coords = ops.crop_sample(pts.contiguous(), col.contiguous(), None, None, self.extent[0] * 0.5, self.unit,
+                                        int(self.limit[0]))
+        self.tmp_feats = feats.view(len(self.cls_ids), self.n_tmp, 7)
+        self.tmp_vox = coords.view(len(self.cls_ids), self.n_tmp, 4)[:, :, 1:].contiguous()
+
+    def build(self, img, depth, label, rois, gt_obj, poses=None):
+        """img (H,W,3|4) u8, depth (H,W) u16, label (H,W) integer, rois (k,>=6), gt_obj (n) class ids, poses (3,4,n) or
+        None -- numpy arrays as the loader reads them.  Returns the loader's dict with CUDA tensors (instances without a
+        detection or with an empty mask are dropped and flagged 0 in `all_flags`, :116,134)."""
+        H, W = depth.shape
+        gt_obj = np.asarray(gt_obj).astype(np.int32)
+        rois = np.asarray(rois)
+        cand, boxes = [], []
+        for i, cls in enumerate(gt_obj):
+            hit = np.where(rois[:, 1] == cls)[0]
+            if hit.size:
+                r0, r1, c0, c1 = snap_box(rois, hit[0], H, W)
+                cand.append(i)
+                boxes.append((max(r0, 0), min(r1, H), max(c0, 0), min(c1, W)))      # numpy slice clipping (:132)
+        dev = self.dev
+        flags = np.zeros(len(gt_obj), np.int8)
+        if not cand:
+            raise ValueError("no object instance of this image has a detection")
+        d_t = torch.from_numpy(np.ascontiguousarray(depth).astype(np.uint16).view(np.int16)).to(dev)
+        l_t = torch.from_numpy(np.ascontiguousarray(label).astype(np.int32)).to(dev)
+        i_t = torch.from_numpy(np.ascontiguousarray(img)).to(dev)
+        b_t = torch.tensor(boxes, dtype=torch.int32, device=dev)
+        o_t = torch.from_numpy(gt_obj[cand]).to(dev)
+        xyz, col, centroid, counts = ops.crop_points(d_t, l_t, i_t, b_t, o_t, self.camera, RGB_MEAN, self.extent * 0.5,
+                                                     MIN_VALID)
+        cnt = counts.cpu().numpy()                                                  # the builder's host read-back
+        keep = [k for k in range(len(cand)) if cnt[k, 0] > 0]
+        if not keep:
+            raise ValueError("every object mask of this image is empty")
+        picks = []
+        for k in keep:                                                              # :166-169, the loader's RNG calls
+            m = int(cnt[k, 2])
+            picks.append(np.random.choice(m, self.n_inp, replace=False) if m > self.n_inp
+                         else np.random.choice(m, self.n_inp))
+            flags[cand[k]] = 1
+        kt = torch.tensor(keep, device=dev)
+        if len(keep) != len(cand):
+            xyz, col, centroid, counts = xyz[kt].contiguous(), col[kt].contiguous(), centroid[kt], counts[kt].contiguous()
+        pick_t = torch.from_numpy(np.stack(picks).astype(np.int64)).to(dev)
+        feats_inp, coords_inp = ops.crop_sample(xyz, col, pick_t, counts, self.extent[0] * 0.5, self.unit,
+                                                int(self.limit[0]), min_valid=MIN_VALID)
+        b = len(keep)
+        cls_rows = torch.tensor([self.cls_row[int(gt_obj[cand[k]])] for k in keep], device=dev)
+        feats_tmp = self.tmp_feats[cls_rows].reshape(b * self.n_tmp, 7)
+        ids = torch.arange(b, device=dev).view(b, 1, 1).expand(b, self.n_tmp, 1)
+        coords_tmp = torch.cat([ids, self.tmp_vox[cls_rows]], 2).reshape(b * self.n_tmp, 4).contiguous()
+        data = {"batch_offsets": (torch.arange(b + 1) * 1024).int(), "voxel_num_limit": torch.tensor(self.limit),
+                "obj_idx": torch.IntTensor(gt_obj - 1), "all_flags": torch.IntTensor(flags),
+                "flags": torch.IntTensor([-1]), "all_centroids": centroid, "labels": {}, "counts": cnt[keep]}
+        if poses is not None:
+            cen = centroid.cpu().numpy()
+            rot = [torch.FloatTensor(np.array(poses[:, :, cand[k]][:, 0:3])) for k in keep]
+            trans = [torch.FloatTensor(np.array([poses[:, :, cand[k]][:, 3:4].flatten()]).reshape(3) - cen[j])
+                     for j, k in enumerate(keep)]
+            data["labels"] = {"rot_gt": torch.stack(rot), "trans_gt": torch.stack(trans)}
+        S = int(self.limit[0])
+        for side, feats, coords in (("inp", feats_inp, coords_inp), ("tmp", feats_tmp, coords_tmp)):
+            occ, p2v, v2p = ops.voxelize_idx_gpu(coords, b, S, self.mode)
+            data[side] = {"feats": feats, "coords": coords, "occupied_voxels": occ, "p2v_maps": p2v, "v2p_maps": v2p}
+        return data

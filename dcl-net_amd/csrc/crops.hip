@@ -1,0 +1,226 @@
+// crops.hip -- the crop builder that runs in front of DCL_Net.forward, on the device.
+//
+// The reference builds every object crop of an image on the CPU inside the DataLoader workers
+// (YCBV/dataloader_test_YCBV.py:124-183; LineMOD's loader has the same arithmetic): mask the detection box, back-project
+// the depth pixels, subtract the centroid, drop points outside the voxel grid, sample N of them, emit the (N,7) feature
+// rows and the integer voxel coordinates that voxelize_idx consumes.  Here one workgroup per object instance does the
+// data-dependent part in one launch, in the reference's ORDER (ascending flat pixel index inside the box), and with
+// the reference's float32 / float64 arithmetic step by step, so that the results are bit-identical:
+//
+//   dcl_crop_points   box mask -> ordered compaction -> back-projection -> sequential float32 centroid (numpy's
+//                     mean(axis=0) is a row-order running sum, verified in tests) -> box filter -> ordered compaction
+//   [host: np.random.choice(count, N) -- the sampling indices stay the caller's, it owns the RNG stream]
+//   dcl_crop_sample   gather the sampled points, write feats rows [1,r,g,b,x,y,z] and (batch,x,y,z) voxel coordinates
+#include "common.h"
+
+namespace {
+
+constexpr int kCropThreads = 256;
+constexpr int kCropChunk = 1024;               // pixels / rows per block step (4 consecutive per thread)
+
+// exclusive prefix of one small count per thread over the workgroup (order = thread id); returns the block total
+__device__ __forceinline__ int block_excl_scan(int v, int *s_wave /* [4] */, int &total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += up;
+  }
+  __syncthreads();                             // s_wave may still be read from the previous call
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  int base = 0;
+  total = 0;
+#pragma unroll
+  for (int w = 0; w < kCropThreads / 64; ++w) {
+    const int t = s_wave[w];
+    if (w < wave) base += t;
+    total += t;
+  }
+  return base + incl - v;
+}
+
+struct CropCam { float cx, cy, fx, fy, scale; };
+
+__global__ __launch_bounds__(kCropThreads) void k_crop_points(
+    const uint16_t *__restrict__ depth, const int32_t *__restrict__ label, const uint8_t *__restrict__ rgb, int H, int W,
+    int rgb_channels, const int32_t *__restrict__ boxes /* (n,4) rmin,rmax,cmin,cmax */,
+    const int32_t *__restrict__ obj_ids, CropCam cam, double mean_r, double mean_g, double mean_b, float hx, float hy,
+    float hz, int min_valid, int cap, float *__restrict__ raw_xyz, float *__restrict__ raw_rgb,
+    float *__restrict__ out_xyz, float *__restrict__ out_rgb, float *__restrict__ centroid,
+    int32_t *__restrict__ counts /* (n,3): masked pixels, inside the grid, rows written */) {
+  __shared__ int s_wave[kCropThreads / 64];
+  __shared__ float s_stage[kCropChunk * 3];
+  __shared__ float s_cen[3];
+  const int inst = blockIdx.x, t = threadIdx.x;
+  const int rmin = boxes[inst * 4], rmax = boxes[inst * 4 + 1], cmin = boxes[inst * 4 + 2], cmax = boxes[inst * 4 + 3];
+  const int bh = max(rmax - rmin, 0), bw = max(cmax - cmin, 0);
+  const int area = min(bh * bw, cap);
+  const int obj = obj_ids[inst];
+  float *rx = raw_xyz + (size_t)inst * cap * 3, *rc = raw_rgb + (size_t)inst * cap * 3;
+  float *ox = out_xyz + (size_t)inst * cap * 3, *oc = out_rgb + (size_t)inst * cap * 3;
+
+  // ---- 1. masked pixels of the box in flat order (dataloader_test_YCBV.py:128-133), back-projection (:147-154)
+  int n = 0;
+  for (int base = 0; base < area; base += kCropChunk) {
+    bool keep[4];
+    int cnt = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int f = base + 4 * t + u;
+      keep[u] = false;
+      if (f < area) {
+        const int r = rmin + f / bw, c = cmin + f % bw;
+        if (r >= 0 && r < H && c >= 0 && c < W)
+          keep[u] = label[(size_t)r * W + c] == obj && depth[(size_t)r * W + c] != 0;
+      }
+      cnt += keep[u];
+    }
+    int total;
+    int o = n + block_excl_scan(cnt, s_wave, total);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (!keep[u]) continue;
+      const int f = base + 4 * t + u;
+      const int r = rmin + f / bw, c = cmin + f % bw;
+      const size_t pix = (size_t)r * W + c;
+      const float pt2 = (float)depth[pix] / cam.scale;
+      const float pt0 = ((float)c - cam.cx) * pt2 / cam.fx;
+      const float pt1 = ((float)r - cam.cy) * pt2 / cam.fy;
+      rx[(size_t)o * 3] = pt0; rx[(size_t)o * 3 + 1] = pt1; rx[(size_t)o * 3 + 2] = pt2;
+      // img/255.0 in float32, minus the float64 mean, rounded to float32 when the FloatTensor is made (:143-145,168)
+      const uint8_t *px = rgb + pix * rgb_channels;
+      rc[(size_t)o * 3] = (float)((double)((float)px[0] / 255.0f) - mean_r);
+      rc[(size_t)o * 3 + 1] = (float)((double)((float)px[1] / 255.0f) - mean_g);
+      rc[(size_t)o * 3 + 2] = (float)((double)((float)px[2] / 255.0f) - mean_b);
+      ++o;
+    }
+    n += total;
+  }
+  __syncthreads();
+  if (n == 0) {                                 // empty mask: the reference skips the instance (:135-143)
+    if (t < 3) { counts[inst * 3 + t] = 0; centroid[inst * 3 + t] = 0.0f; }
+    return;
+  }
+
+  // ---- 2. centroid = np.mean(cloud, axis=0): running float32 sum in row order, one division (:156)
+  float acc = 0.0f;
+  for (int base = 0; base < n; base += kCropChunk) {
+    const int rows = min(kCropChunk, n - base);
+    __syncthreads();
+    for (int j = t; j < rows * 3; j += kCropThreads) s_stage[j] = rx[(size_t)base * 3 + j];
+    __syncthreads();
+    if (t < 3)
+      for (int i = 0; i < rows; ++i) acc = acc + s_stage[i * 3 + t];
+  }
+  if (t < 3) { const float cen = acc / (float)n; s_cen[t] = cen; centroid[inst * 3 + t] = cen; }
+  __syncthreads();
+  const float cx = s_cen[0], cy = s_cen[1], cz = s_cen[2];
+
+  // ---- 3. points inside the voxel grid (:160-161)
+  int valid = 0;
+  for (int base = 0; base < n; base += kCropThreads) {
+    const int i = base + t;
+    int v = 0;
+    if (i < n) {
+      const float x = rx[(size_t)i * 3] - cx, y = rx[(size_t)i * 3 + 1] - cy, z = rx[(size_t)i * 3 + 2] - cz;
+      v = fabsf(x) < hx && fabsf(y) < hy && fabsf(z) < hz;
+    }
+    valid += v;
+  }
+  {
+    int total;
+    (void)block_excl_scan(valid, s_wave, total);
+    valid = total;
+  }
+  const bool filter = valid > min_valid;        // `if valid_num > 32` (:163)
+
+  // ---- 4. keep them (in order), centred
+  int m = 0;
+  for (int base = 0; base < n; base += kCropChunk) {
+    bool keep[4];
+    float p[4][3];
+    int cnt = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = base + 4 * t + u;
+      keep[u] = false;
+      if (i < n) {
+        p[u][0] = rx[(size_t)i * 3] - cx; p[u][1] = rx[(size_t)i * 3 + 1] - cy; p[u][2] = rx[(size_t)i * 3 + 2] - cz;
+        keep[u] = !filter || (fabsf(p[u][0]) < hx && fabsf(p[u][1]) < hy && fabsf(p[u][2]) < hz);
+      }
+      cnt += keep[u];
+    }
+    int total;
+    int o = m + block_excl_scan(cnt, s_wave, total);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (!keep[u]) continue;
+      const int i = base + 4 * t + u;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { ox[(size_t)o * 3 + j] = p[u][j]; oc[(size_t)o * 3 + j] = rc[(size_t)i * 3 + j]; }
+      ++o;
+    }
+    m += total;
+  }
+  if (t == 0) { counts[inst * 3] = n; counts[inst * 3 + 1] = valid; counts[inst * 3 + 2] = m; }
+}
+
+// feats row [1, r, g, b, x, y, z] and voxel coordinate row [batch, ix, iy, iz] of every sampled point (:170-176,186-190):
+//   voxel = trunc((xyz + half_extent0) / unit) in float32, clamped to [0, limit-1] first when the crop had <= 32 points
+//   inside the grid.  sample_idx == nullptr: identity (template clouds, :179-182).
+__global__ void k_crop_sample(int n_inst, int npoint, int cap, const float *__restrict__ xyz, const float *__restrict__ rgb,
+                              const int64_t *__restrict__ sample_idx, const int32_t *__restrict__ counts, int min_valid,
+                              float half0, float ux, float uy, float uz, float limit, float *__restrict__ feats,
+                              int64_t *__restrict__ coords) {
+  const long long total = (long long)n_inst * npoint;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int inst = (int)(e / npoint);
+    const long long i = sample_idx ? sample_idx[e] : (e - (long long)inst * npoint);
+    const float *p = xyz + ((size_t)inst * cap + i) * 3, *c = rgb + ((size_t)inst * cap + i) * 3;
+    const float x = p[0], y = p[1], z = p[2];
+    float *f = feats + e * 7;
+    f[0] = 1.0f; f[1] = c[0]; f[2] = c[1]; f[3] = c[2]; f[4] = x; f[5] = y; f[6] = z;
+    float vx = (x + half0) / ux, vy = (y + half0) / uy, vz = (z + half0) / uz;
+    if (counts && counts[inst * 3 + 1] <= min_valid) {
+      vx = fminf(fmaxf(vx, 0.0f), limit - 1.0f); vy = fminf(fmaxf(vy, 0.0f), limit - 1.0f);
+      vz = fminf(fmaxf(vz, 0.0f), limit - 1.0f);
+    }
+    int64_t *o = coords + e * 4;
+    o[0] = inst; o[1] = (int64_t)vx; o[2] = (int64_t)vy; o[3] = (int64_t)vz;
+  }
+}
+
+}  // namespace
+
+DCL_API int dcl_crop_points(const uint16_t *depth, const int32_t *label, const uint8_t *rgb, int H, int W, int rgb_channels,
+                            int n_inst, const int32_t *boxes, const int32_t *obj_ids, const float *cam_host /*5*/,
+                            const double *rgb_mean_host /*3*/, const float *half_extent_host /*3*/, int min_valid, int cap,
+                            float *raw_xyz, float *raw_rgb, float *out_xyz, float *out_rgb, float *centroid,
+                            int32_t *counts, dclStream_t stream) {
+  DCL_CHECK_ARG(n_inst >= 0 && H > 0 && W > 0 && rgb_channels >= 3 && cap > 0);
+  if (n_inst == 0) return 0;
+  DCL_CHECK_ARG(depth && label && rgb && boxes && obj_ids && cam_host && rgb_mean_host && half_extent_host && raw_xyz &&
+                raw_rgb && out_xyz && out_rgb && centroid && counts);
+  const CropCam cam = {cam_host[0], cam_host[1], cam_host[2], cam_host[3], cam_host[4]};
+  hipLaunchKernelGGL(k_crop_points, dim3(n_inst), dim3(kCropThreads), 0, (hipStream_t)stream, depth, label, rgb, H, W,
+                     rgb_channels, boxes, obj_ids, cam, rgb_mean_host[0], rgb_mean_host[1], rgb_mean_host[2],
+                     half_extent_host[0], half_extent_host[1], half_extent_host[2], min_valid, cap, raw_xyz, raw_rgb,
+                     out_xyz, out_rgb, centroid, counts);
+  DCL_LAUNCH_CHECK();
+  return 0;
+}
+
+DCL_API int dcl_crop_sample(int n_inst, int npoint, int cap, const float *xyz, const float *rgb, const int64_t *sample_idx,
+                            const int32_t *counts, int min_valid, float half_extent0, const float *unit_host /*3*/,
+                            int voxel_limit, float *feats, int64_t *coords, dclStream_t stream) {
+  DCL_CHECK_ARG(n_inst >= 0 && npoint >= 0 && cap > 0 && voxel_limit > 0);
+  if (n_inst == 0 || npoint == 0) return 0;
+  DCL_CHECK_ARG(xyz && rgb && unit_host && feats && coords);
+  hipLaunchKernelGGL(k_crop_sample, dim3(dcl_grid_1d((long long)n_inst * npoint, 256)), dim3(256), 0, (hipStream_t)stream,
+                     n_inst, npoint, cap, xyz, rgb, sample_idx, counts, min_valid, half_extent0, unit_host[0],
+                     unit_host[1], unit_host[2], (float)voxel_limit, feats, coords);
+  DCL_LAUNCH_CHECK();
+  return 0;
+}

@@ -507,3 +507,55 @@ def add_s(cld, R_pred, t_pred, R_gt, t_gt, cls=None):
     N.check(N.lib().dcl_add_s(b, P, N.ptr(cld), N.ptr(cls), N.ptr(R_pred), N.ptr(t_pred), N.ptr(R_gt), N.ptr(t_gt),
                               N.ptr(part), N.ptr(out), N.stream()), "add_s")
     return out
+
+
+# ------------------------------------------------------------------------------------ crop builder
+def crop_points(depth, label, rgb, boxes, obj_ids, cam, rgb_mean, half_extent, min_valid=32):
+    """Masked back-projection + centring + grid filter of every object instance of one image
+    (YCBV/dataloader_test_YCBV.py:124-165).  depth (H,W) u16 viewed as int16 storage, label (H,W) i32, rgb (H,W,C) u8,
+    boxes (n,4) i32 [rmin,rmax,cmin,cmax], obj_ids (n) i32 -- all CUDA.  cam = (cx,cy,fx,fy,scale).
+    -> xyz (n,cap,3), rgb (n,cap,3), centroid (n,3), counts (n,3) i32 [masked, inside grid, rows]."""
+    N.need_cuda(depth, label, rgb, boxes, obj_ids)
+    assert depth.dtype in (torch.int16, torch.uint16) and label.dtype == torch.int32 and rgb.dtype == torch.uint8
+    assert depth.is_contiguous() and label.is_contiguous() and rgb.is_contiguous()
+    assert boxes.dtype == torch.int32 and obj_ids.dtype == torch.int32 and boxes.is_contiguous()
+    H, W = depth.shape
+    n = boxes.shape[0]
+    dev = depth.device
+    bx = boxes.cpu()
+    cap = int(max(1, ((bx[:, 1] - bx[:, 0]).clamp(min=0) * (bx[:, 3] - bx[:, 2]).clamp(min=0)).max().item())) if n else 1
+    raw_xyz = torch.empty((n, cap, 3), dtype=torch.float32, device=dev)
+    raw_rgb = torch.empty((n, cap, 3), dtype=torch.float32, device=dev)
+    xyz = torch.empty((n, cap, 3), dtype=torch.float32, device=dev)
+    col = torch.empty((n, cap, 3), dtype=torch.float32, device=dev)
+    centroid = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    counts = torch.zeros((n, 3), dtype=torch.int32, device=dev)
+    cam_a = (C.c_float * 5)(*[float(v) for v in cam])
+    mean_a = (C.c_double * 3)(*[float(v) for v in rgb_mean])
+    he_a = (C.c_float * 3)(*[float(v) for v in half_extent])
+    N.check(N.lib().dcl_crop_points(N.ptr(depth), N.ptr(label), N.ptr(rgb), H, W, rgb.shape[2], n, N.ptr(boxes),
+                                    N.ptr(obj_ids), cam_a, mean_a, he_a, int(min_valid), cap, N.ptr(raw_xyz),
+                                    N.ptr(raw_rgb), N.ptr(xyz), N.ptr(col), N.ptr(centroid), N.ptr(counts), N.stream()),
+            "crop_points")
+    return xyz, col, centroid, counts
+
+
+def crop_sample(xyz, rgb, sample_idx, counts, half_extent0, unit, voxel_limit, npoint=None, min_valid=32):
+    """Sampled points -> feats (n*npoint,7) [1,rgb,xyz] and voxelize_idx input rows (n*npoint,4) i64 [instance,ix,iy,iz]
+    (dataloader_test_YCBV.py:166-177,186-190).  sample_idx (n,npoint) i64 CUDA or None (identity, template clouds)."""
+    N.need_cuda(xyz, rgb, sample_idx, counts)
+    assert xyz.is_contiguous() and rgb.is_contiguous() and xyz.dtype == torch.float32 and rgb.dtype == torch.float32
+    n, cap = xyz.shape[0], xyz.shape[1]
+    if sample_idx is not None:
+        assert sample_idx.dtype == torch.int64 and sample_idx.is_contiguous() and sample_idx.shape[0] == n
+        npoint = sample_idx.shape[1]
+    else:
+        npoint = cap if npoint is None else npoint
+    dev = xyz.device
+    feats = torch.empty((n * npoint, 7), dtype=torch.float32, device=dev)
+    coords = torch.empty((n * npoint, 4), dtype=torch.int64, device=dev)
+    unit_a = (C.c_float * 3)(*[float(v) for v in unit])
+    N.check(N.lib().dcl_crop_sample(n, npoint, cap, N.ptr(xyz), N.ptr(rgb), N.ptr(sample_idx), N.ptr(counts),
+                                    int(min_valid), _c_float(half_extent0), unit_a, int(voxel_limit), N.ptr(feats),
+                                    N.ptr(coords), N.stream()), "crop_sample")
+    return feats, coords

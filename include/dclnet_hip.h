@@ -254,6 +254,32 @@ int dcl_conf_pool(int b, int c, int n1, int n2, const float *logit1, const float
 /* ortho9d2matrix (models/DCL_Net.py:15-36): o9 (b,9) -> R (b,3,3).             */
 int dcl_ortho9d_to_matrix(int b, const float *o9, float *R, dclStream_t stream);
 
+/* ------------------------------------------------------------ crop builder ---
+ * The per-object crop construction of the data loaders (YCBV/dataloader_test_YCBV.py:124-183), on the device, in the
+ * reference's pixel order and float32/float64 arithmetic (results bit-identical to the numpy/torch code).
+ *
+ * dcl_crop_points (one workgroup per instance): pixels of box [rmin,rmax) x [cmin,cmax) with label == obj_ids[i] and
+ * depth != 0, in ascending flat order (:128-133); back-projection pt2 = d/scale, pt0 = (col-cx)*pt2/fx,
+ * pt1 = (row-cy)*pt2/fy (:147-154); rgb = float(double(float(v)/255) - mean) (:143-145); centroid = row-order running
+ * float32 sum / n (np.mean(axis=0), :156); points centred; those with |x|,|y|,|z| < half_extent kept when more than
+ * min_valid (32) of them exist, else all (:160-165).
+ *   depth (H,W) u16, label (H,W) i32, rgb (H,W,rgb_channels) u8 -- device; boxes (n,4) i32 rmin,rmax,cmin,cmax (clipped
+ *   to the image) and obj_ids (n) i32 -- device; cam_host = {cx, cy, fx, fy, scale}; cap >= every box area.
+ *   raw_xyz/raw_rgb: scratch (n,cap,3); out_xyz/out_rgb (n,cap,3); centroid (n,3);
+ *   counts (n,3) = {masked pixels, points inside the grid, rows written} (all zero: the reference skips the instance). */
+int dcl_crop_points(const uint16_t *depth, const int32_t *label, const uint8_t *rgb, int H, int W, int rgb_channels,
+                    int n_inst, const int32_t *boxes, const int32_t *obj_ids, const float *cam_host,
+                    const double *rgb_mean_host, const float *half_extent_host, int min_valid, int cap,
+                    float *raw_xyz, float *raw_rgb, float *out_xyz, float *out_rgb, float *centroid,
+                    int32_t *counts, dclStream_t stream);
+/* Sampled points -> feats rows [1,r,g,b,x,y,z] (n*npoint,7) and voxelize_idx input rows [instance,ix,iy,iz] (n*npoint,4)
+ * i64 (:166-176,186-190): voxel = trunc((xyz + half_extent0)/unit) in float32, clamped to [0,voxel_limit-1] first for
+ * instances with counts[i][1] <= min_valid.  sample_idx (n,npoint) i64 = the caller's np.random.choice draws (NULL:
+ * identity, for the template clouds :179-182; then counts may be NULL).  xyz/rgb (n,cap,3).                          */
+int dcl_crop_sample(int n_inst, int npoint, int cap, const float *xyz, const float *rgb, const int64_t *sample_idx,
+                    const int32_t *counts, int min_valid, float half_extent0, const float *unit_host, int voxel_limit,
+                    float *feats, int64_t *coords, dclStream_t stream);
+
 /* ------------------------------------------------------------ eval metric ---
  * ADD-S per object (tools/test_YCBV_stage1.py:186-189): out[o] = mean_i min_j |R_pred x_i + t_pred - (R_gt x_j + t_gt)|
  * over the P points of the object's class cloud.  cld (n_clouds, P, 3); cls i32[b] selects the cloud of object o

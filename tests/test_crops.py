@@ -1,0 +1,100 @@
+"""Crop builder: oracle / host logic on CPU, device builder vs oracle bit-exact on the GPU."""
+import numpy as np
+import pytest
+import torch
+
+from crop_scene import make_scene
+
+CFG = dict(input_size=96, tmp_size=64, unit_voxel_extent=[0.006] * 3, voxel_num_limit=[64] * 3, voxelization_mode=4)
+
+
+def _oracle_build(sc, cfg, seed):
+    from oracle import crops as oc
+    np.random.seed(seed)
+    return oc.build_image(sc["img"], sc["depth"], sc["label"], sc["rois"], sc["gt_obj"], sc["cad_pts"], sc["cad_col"], cfg,
+                          poses=sc["poses"])
+
+
+def test_numpy_mean_axis0_is_a_row_order_running_sum():
+    """the device centroid relies on it (oracle/crops.py, csrc/crops.hip step 2)"""
+    rng = np.random.default_rng(0)
+    for n in (1, 7, 1000, 33333):
+        a = (rng.normal(size=(n, 3)) * 0.05 + np.array([0.1, -0.2, 0.9])).astype(np.float32)
+        s = np.zeros(3, np.float32)
+        for i in range(n):
+            s = s + a[i]
+        assert np.array_equal(np.mean(a, axis=0), (s / np.float32(n)).astype(np.float32))
+
+
+def test_snap_box_matches_oracle(dcl):
+    from oracle import crops as oc
+    rng = np.random.default_rng(1)
+    for _ in range(3000):
+        x1, y1 = rng.integers(-30, 640), rng.integers(-30, 480)
+        roi = np.array([[0, 1, x1, y1, x1 + rng.integers(1, 700), y1 + rng.integers(1, 600)]], np.float64)
+        assert dcl.crops.snap_box(roi, 0) == oc.get_bbox(roi, 0)
+    for side in (0, 1, 39, 40, 41, 80, 679, 680, 681):                       # the border values themselves
+        roi = np.array([[0, 1, 99, 99, 101 + side, 101 + side]], np.float64)
+        assert dcl.crops.snap_box(roi, 0) == oc.get_bbox(roi, 0)
+
+
+def test_oracle_crops_are_well_formed():
+    sc = make_scene(3, n_obj=4, tmp_size=CFG["tmp_size"], tiny=1, empty=2, undetected=3)
+    d = _oracle_build(sc, CFG, 5)
+    assert d["all_flags"].tolist() == [1, 1, 0, 0]
+    b = 2
+    assert d["inp"]["feats"].shape == (b * CFG["input_size"], 7) and d["tmp"]["feats"].shape == (b * CFG["tmp_size"], 7)
+    assert d["counts"][1][1] <= 32 and d["counts"][1][2] == d["counts"][1][0]      # tiny instance: nothing filtered
+    assert d["counts"][0][1] > 32 and d["counts"][0][2] == d["counts"][0][1]
+    c = d["inp"]["coords"]
+    assert int(c[:, 1:].min()) >= 0 and int(c[:, 1:].max()) <= 63
+    assert torch.equal(d["inp"]["feats"][:, 0], torch.ones(b * CFG["input_size"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,kw", [(11, {}), (12, dict(tiny=0)), (13, dict(empty=1, undetected=2, rgba=True)),
+                                      (14, dict(n_obj=6, tiny=5))])
+def test_device_crop_builder_bit_exact(dcl, seed, kw):
+    cfg = dict(CFG)
+    if seed == 14:
+        cfg["input_size"] = 4000                                             # more samples than points: replace=True path
+    sc = make_scene(seed, tmp_size=cfg["tmp_size"], **kw)
+    want = _oracle_build(sc, cfg, 100 + seed)
+    builder = dcl.crops.CropBuilder(cfg, sc["cad_pts"], sc["cad_col"])
+    np.random.seed(100 + seed)
+    got = builder.build(sc["img"], sc["depth"], sc["label"], sc["rois"], sc["gt_obj"], poses=sc["poses"])
+    after_device = np.random.random()                      # both builders must leave the global RNG stream at the same place
+    _oracle_build(sc, cfg, 100 + seed)
+    assert after_device == np.random.random()
+    assert np.array_equal(got["counts"], want["counts"])
+    assert got["all_flags"].tolist() == want["all_flags"].tolist()
+    assert torch.equal(got["all_centroids"].cpu(), want["all_centroids"])
+    for side in ("inp", "tmp"):
+        for k in ("feats", "coords", "occupied_voxels", "p2v_maps", "v2p_maps"):
+            assert torch.equal(got[side][k].cpu(), want[side][k]), (side, k)
+    assert torch.equal(got["labels"]["rot_gt"], want["labels"]["rot_gt"])
+    assert torch.equal(got["labels"]["trans_gt"], want["labels"]["trans_gt"])
+
+
+@pytest.mark.gpu
+def test_built_crops_run_through_the_network(dcl):
+    """image -> device crop builder -> Network.forward, everything resident on the GPU"""
+    cfg = dict(CFG, input_size=256, tmp_size=256)
+    sc = make_scene(21, n_obj=3, tmp_size=256)
+    for c in sc["cad_pts"]:
+        sc["cad_pts"][c] = sc["cad_pts"][c] * 0.8
+    builder = dcl.crops.CropBuilder(cfg, sc["cad_pts"], sc["cad_col"])
+    np.random.seed(7)
+    data = builder.build(sc["img"], sc["depth"], sc["label"], sc["rois"], sc["gt_obj"])
+    net = dcl.DCL_Net.Network(dcl.synth.default_cfg(256, 256), mode="test")
+    net.load_state_dict(dcl.synth.synth_state_dict(net, 1))
+    net = net.cuda().eval()
+    with torch.no_grad():
+        out = net(data)
+    b = int(data["all_flags"].sum())
+    assert out["rot_pred"].shape == (b, 3, 3) and torch.isfinite(out["rot_pred"]).all()
+    want = _oracle_build(sc, cfg, 7)
+    with torch.no_grad():
+        ref = net({k: v for k, v in want.items()})
+    assert float((out["rot_pred"] - ref["rot_pred"]).abs().max()) <= 1e-6
+    assert float((out["trans_pred"] - ref["trans_pred"]).abs().max()) <= 1e-6
