@@ -32,6 +32,11 @@ def lib():
                 "or `make -C dcl-net_amd/csrc`.  There is no CPU fallback." % SO_PATH)
         L = C.CDLL(SO_PATH)
         L.dcl_last_error.restype = C.c_char_p
+        # A/B switches for profiling runs (kernel-variant hooks of include/dclnet_hip.h)
+        if os.environ.get("DCL_CONV_VARIANT"):
+            L.dcl_debug_force_valu_conv(int(os.environ["DCL_CONV_VARIANT"]))
+        if os.environ.get("DCL_CONV_SPLIT"):
+            L.dcl_debug_conv_split(int(os.environ["DCL_CONV_SPLIT"]))
         _LIB = L
     return _LIB
 

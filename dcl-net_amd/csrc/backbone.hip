@@ -77,23 +77,34 @@ bool make_geo_layout(int batch, int S, int V0, GeoLayout *L) {
 }
 
 struct FeatLayout {
-  size_t nbr, x1, x2, total;
+  size_t nbr, x1, x2, scratch, scratch_floats, total;
 };
 
 bool make_feat_layout(const int32_t *counts, const int *chan /*9*/, FeatLayout *L) {
-  size_t max_rows = 1, x1 = 4, x2 = 4;
+  size_t max_rows = 1, x1 = 4, x2 = 4, scratch = 0;
   for (int m = 0; m < kLevels; ++m) {
     const size_t nc = (size_t)(counts[2 * m] > 0 ? counts[2 * m] : 0), np = (size_t)(counts[2 * m + 1] > 0 ? counts[2 * m + 1] : 0);
     if (nc > max_rows) max_rows = nc;
     if (np > max_rows) max_rows = np;
     if (nc * chan[2 * m + 1] * 4 > x1) x1 = nc * chan[2 * m + 1] * 4;
     if (nc * chan[2 * m + 2] * 4 > x2) x2 = nc * chan[2 * m + 2] * 4;
+    // split-K scratch of the two convs (only layers with few 128-row tiles split; see launch_conv_dma)
+    for (int q = 1; q <= 2; ++q) {
+      const size_t cout = (size_t)chan[2 * m + q];
+      if (cout % 64 != 0 || nc == 0) continue;
+      const size_t tiles = ((nc + 127) / 128) * (cout % 128 == 0 ? cout / 128 : cout / 64);
+      size_t split = (1024 + tiles - 1) / tiles;
+      if (split > 8) split = 8;
+      if (split > 1 && split * nc * cout > scratch) scratch = split * nc * cout;
+    }
   }
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
   L->nbr = take(sizeof(int32_t) * 27 * max_rows);
   L->x1 = take(x1);
   L->x2 = take(x2);
+  L->scratch = take(scratch * sizeof(float));
+  L->scratch_floats = scratch;
   L->total = off;
   return true;
 }
@@ -238,8 +249,9 @@ static int backbone_features(const int32_t *occ, int V0, int batch, int S, void 
                                1, 1, nbr, nc, stream);
       if (rc) return rc;
       DBG_STEP();
-      rc = dcl_sparse_conv_fwd(x, nbr, nc, nc_dev, nc_dev ? 0 : nc, weights[2 * m], c0, c1, 27, 0, scales[2 * m],
-                               shifts[2 * m], 1, x1, stream);
+      rc = dcl_sparse_conv_fwd_ws(x, nbr, nc, nc_dev, nc_dev ? 0 : nc, weights[2 * m], c0, c1, 27, 0, scales[2 * m],
+                                  shifts[2 * m], 1, x1, F.scratch_floats ? at<float>(ws2, F.scratch) : nullptr,
+                                  (int64_t)F.scratch_floats, stream);
       if (rc) return rc;
       // submanifold conv on the conv set
       DBG_STEP();
@@ -247,8 +259,9 @@ static int backbone_features(const int32_t *occ, int V0, int batch, int S, void 
                                at<int32_t>(ws, c.wprefix), nullptr, batch, s, 3, 1, 1, nbr, nc, stream);
       if (rc) return rc;
       DBG_STEP();
-      rc = dcl_sparse_conv_fwd(x1, nbr, nc, nc_dev, nc_dev ? 0 : nc, weights[2 * m + 1], c1, c2, 27, 1,
-                               scales[2 * m + 1], shifts[2 * m + 1], 1, x2, stream);
+      rc = dcl_sparse_conv_fwd_ws(x1, nbr, nc, nc_dev, nc_dev ? 0 : nc, weights[2 * m + 1], c1, c2, 27, 1,
+                                  scales[2 * m + 1], shifts[2 * m + 1], 1, x2,
+                                  F.scratch_floats ? at<float>(ws2, F.scratch) : nullptr, (int64_t)F.scratch_floats, stream);
       if (rc) return rc;
     }
     if (np > 0) {

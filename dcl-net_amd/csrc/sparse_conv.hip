@@ -457,6 +457,236 @@ __global__ __launch_bounds__(256, 2) void k_sparse_conv_tile(
   }
 }
 
+// ---- implicit-GEMM MFMA kernel fed by LDS-DMA (Cout % 64 == 0): same 64x64 output tile and virtual-channel walk as
+// k_sparse_conv_tile, but both operand tiles of a 64-channel chunk go global -> LDS with global_load_lds_dwordx4 (no
+// staging registers, no ds_write), double-buffered: the DMA of the next used chunk is issued right after the ONE barrier
+// per chunk and has the whole chunk of MFMAs to land.  A rows are gathered by the DMA itself (per-lane global address
+// = the neighbour's feature row, or a zero line for a missing neighbour); since a DMA instruction fills 1 KiB of
+// contiguous LDS, bank conflicts are avoided by swizzling instead of padding: the 16-B column c of row r is stored at
+// column c ^ (r & 15) (A), and W rows with bit 2 of their index set swap their 32-column halves (B).
+__device__ float4 g_conv_zero_line = {0.f, 0.f, 0.f, 0.f};
+typedef __attribute__((address_space(3))) void conv_lds_void_t;
+__device__ __forceinline__ void conv_glds16(const void *gsrc, unsigned lds_byte_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_byte_addr)
+               : "memory");
+}
+__device__ __forceinline__ unsigned conv_lds_addr(const float *p) {
+  return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(conv_lds_void_t *)p);
+}
+
+// Tile shape: WR x WCW waves, each 32 rows x (32*NT) channels => BM = 32*WR rows, BN = 32*NT*WCW channels per workgroup,
+// KC = 32 virtual channels per chunk.  What bounds this kernel is the L2 -> LDS operand traffic (2*BM*BN*KC flop per
+// (BM+BN)*KC*4 bytes), not LDS or the MFMA pipe: 64x64 tiles (16 flop/B) saturated at ~45 % of the MFMA peak, hence
+// 128x128 (Cout % 128 == 0, 8 waves, 32 flop/B) and 128x64 (4 waves) here.
+template <int CIN, int WR, int WCW, int NT>
+__global__ __launch_bounds__(64 * WR * WCW, 2) void k_sparse_conv_dma(
+    const float *__restrict__ feat, const int32_t *__restrict__ nbr, int cap, const int32_t *__restrict__ n_out_dev,
+    int n_out_host, const float *__restrict__ W, int cout, int kvol, int subm, const float *__restrict__ scale,
+    const float *__restrict__ shift, int relu, float *__restrict__ out, float *__restrict__ partial, int nsplit) {
+  constexpr int NW = WR * WCW, NTHR = 64 * NW;
+  constexpr int BM = 32 * WR, BN = 32 * NT * WCW, KC = 32;
+  constexpr int AT = BM * KC, BT = KC * BN, ST = AT + BT;      // floats per stage
+  constexpr int A_INSTR = BM / 8;                              // 1-KiB DMA instructions per A tile (8 rows of 128 B each)
+  constexpr int B_ROWS_PER = 256 / BN;                         // W rows per 1-KiB DMA instruction
+  constexpr int B_INSTR = KC / B_ROWS_PER;
+  static_assert(A_INSTR % NW == 0 && B_INSTR % NW == 0 && (BN == 64 || BN == 128), "tile shape");
+  extern __shared__ __attribute__((aligned(16))) float conv_lds[];   // [stage 0: A|B][stage 1: A|B][Ns 27*BM][kmask]
+  int32_t *Ns = reinterpret_cast<int32_t *>(conv_lds + 2 * ST);
+  unsigned *s_kmask = reinterpret_cast<unsigned *>(Ns + 27 * BM);
+
+  int n = n_out_dev ? *n_out_dev : n_out_host;
+  n = n < cap ? n : cap;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int wr = wave / WCW, wc = wave % WCW;
+  const int col0 = blockIdx.y * BN;
+  const int nblk = (n + BM - 1) / BM;
+  // split-K: blockIdx.z owns a contiguous range of chunks and writes raw partial sums (k_conv_split_reduce adds them
+  // in split order and applies the epilogue) -- more workgroups for the deep layers whose row count alone cannot fill the GPU
+  const int nchunks_all = (kvol * CIN + KC - 1) / KC;
+  const int j_begin = (int)((long long)blockIdx.z * nchunks_all / nsplit);
+  const int nchunks = (int)((long long)(blockIdx.z + 1) * nchunks_all / nsplit);
+  const float *zero = reinterpret_cast<const float *>(&g_conv_zero_line);
+
+  for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int row0 = blk * BM;
+    if (tid == 0) *s_kmask = 0;
+    __syncthreads();
+    unsigned mymask = 0;
+    for (int e = tid; e < kvol * BM; e += NTHR) {
+      const int k = e / BM, rr = e - k * BM;
+      const int v = (row0 + rr < n) ? nbr[(size_t)k * cap + row0 + rr] : -1;
+      Ns[e] = v;
+      mymask |= (v >= 0 ? 1u : 0u) << k;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mymask |= __shfl_xor(mymask, d, 64);
+    if (lane == 0 && mymask) atomicOr(s_kmask, mymask);
+    __syncthreads();
+    const unsigned kmask = *s_kmask;
+    auto chunk_used = [&](int j) {
+      const int s_lo = (j * KC) / CIN, s_hi = (j * KC + KC - 1) / CIN;
+      unsigned m = 0;
+      for (int sx = s_lo; sx <= s_hi; ++sx)
+        if (sx < kvol) m |= (kmask >> offset_at(sx, kvol, subm)) & 1u;
+      return m != 0;
+    };
+    auto next_used = [&](int from) { int q = from; while (q < nchunks && !chunk_used(q)) ++q; return q; };
+
+    // A row = 32 floats = 8 blocks of 16 B, block c of row q stored at c ^ ((q >> 1) & 7): 16 consecutive rows read with
+    // ds_read_b128 then cover all 64 banks once.  W row kk with bit 2 set swaps its 32-float halves (the two lane
+    // halves of an MFMA read rows 4 apart).
+    auto issue = [&](int j, int stage) {
+      float *As = conv_lds + stage * ST, *Bs = As + AT;
+#pragma unroll
+      for (int i = 0; i < A_INSTR / NW; ++i) {
+        const int g = wave * (A_INSTR / NW) + i;
+        const int row = g * 8 + (lane >> 3), pcol = lane & 7;
+        const int vc = j * KC + ((pcol ^ ((row >> 1) & 7)) << 2);
+        const int sx = vc / CIN, ch = vc - sx * CIN;
+        int v = -1;
+        if (sx < kvol) v = Ns[offset_at(sx, kvol, subm) * BM + row];
+        const float *src = v >= 0 ? feat + (size_t)v * CIN + ch : zero;
+        conv_glds16(src, conv_lds_addr(As + g * 256));
+      }
+#pragma unroll
+      for (int i = 0; i < B_INSTR / NW; ++i) {
+        const int g = wave * (B_INSTR / NW) + i;
+        constexpr int LPR = BN / 4;                                  // lanes per W row
+        const int kk = g * B_ROWS_PER + lane / LPR, pcol = lane % LPR;
+        const int lcol = pcol ^ (((kk >> 2) & 1) << 3);
+        const int vc = j * KC + kk;
+        const int sx = vc / CIN, ch = vc - sx * CIN;
+        const float *src = sx < kvol ? W + ((size_t)offset_at(sx, kvol, subm) * CIN + ch) * cout + col0 + (lcol << 2) : zero;
+        conv_glds16(src, conv_lds_addr(Bs + g * 256));
+      }
+    };
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
+    int j = next_used(j_begin), cur = 0;
+    if (j < nchunks) issue(j, 0);
+    while (j < nchunks) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this wave's DMA pieces of chunk j have landed
+      __syncthreads();                                   // ... everyone's have, and stage cur^1 has no reader left
+      const int jn = next_used(j + 1);
+      if (jn < nchunks) issue(jn, cur ^ 1);
+      // wave-level skip: none of this wave's 32 rows has a neighbour under any offset of the chunk
+      bool mine = false;
+      {
+        const int s_lo = (j * KC) / CIN, s_hi = (j * KC + KC - 1) / CIN;
+        for (int sx = s_lo; sx <= s_hi; ++sx)
+          if (sx < kvol) mine |= Ns[offset_at(sx, kvol, subm) * BM + wr * 32 + r] >= 0;
+      }
+      if (__ballot(mine) != 0ull) {
+        const float *arow = conv_lds + cur * ST + (wr * 32 + r) * KC;
+        const float *bcol = nullptr;
+        const int sw = (r >> 1) & 7;
+        // B operand of column tile t: logical column wc*32*NT + 32*t + r; the XOR with 32*h commutes with + 32*t only
+        // through the XOR itself, so the tile offset is applied as an XOR too (32*t has no bits below 32)
+#pragma unroll
+        for (int i = 0; i < KC / 8; ++i) {
+          const float4 a = *reinterpret_cast<const float4 *>(arow + (((2 * i + h) ^ sw) << 2));
+          const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              const float bv = conv_lds[cur * ST + AT + (8 * i + 4 * h + q) * BN + ((wc * 32 * NT + 32 * t + r) ^ (32 * h))];
+              acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv, acc[t], 0, 0, 0);
+            }
+        }
+        (void)bcol;
+      }
+      asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // MFMA -> VALU hazard pad (see k_sparse_conv_lds)
+      j = jn;
+      cur ^= 1;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int co = col0 + wc * 32 * NT + 32 * t + r;
+      const float sc = scale ? scale[co] : 1.0f;
+      const float sh = scale ? shift[co] : 0.0f;
+      float *dst = nsplit > 1 ? partial + (size_t)blockIdx.z * cap * cout : out;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int orow = row0 + wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (orow < n) {
+          float x = acc[t][e];
+          if (nsplit == 1) {
+            if (scale) x = x * sc + sh;
+            if (relu) x = fmaxf(x, 0.0f);
+          }
+          dst[(size_t)orow * cout + co] = x;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// out = act(scale * (P_0 + P_1 + ... ) + shift), partial sums added in split order; thread = 4 channels of a row
+__global__ void k_conv_split_reduce(const float *__restrict__ partial, int nsplit, int cap, const int32_t *__restrict__ n_out_dev,
+                                    int n_out_host, int cout, const float *__restrict__ scale,
+                                    const float *__restrict__ shift, int relu, float *__restrict__ out) {
+  int n = n_out_dev ? *n_out_dev : n_out_host;
+  n = n < cap ? n : cap;
+  const int c4 = cout >> 2;
+  const long long total = (long long)n * c4;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(t % c4);
+    float4 a = reinterpret_cast<const float4 *>(partial)[t];
+    for (int z = 1; z < nsplit; ++z) {
+      const float4 b = reinterpret_cast<const float4 *>(partial + (size_t)z * cap * cout)[t];
+      a.x = a.x + b.x; a.y = a.y + b.y; a.z = a.z + b.z; a.w = a.w + b.w;
+    }
+    if (scale) {
+      const float4 sc = reinterpret_cast<const float4 *>(scale)[q], sh = reinterpret_cast<const float4 *>(shift)[q];
+      a.x = a.x * sc.x + sh.x; a.y = a.y * sc.y + sh.y; a.z = a.z * sc.z + sh.z; a.w = a.w * sc.w + sh.w;
+    }
+    if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+    reinterpret_cast<float4 *>(out)[t] = a;
+  }
+}
+
+constexpr int kConvMaxSplit = 8;
+static int g_conv_split = 0;           // tuning hook: 0 = automatic, n = force n-way split-K when scratch allows
+
+template <int CIN, int WR, int WCW, int NT>
+static void launch_conv_dma(int rows, const float *feat, const int32_t *nbr, int cap, const int32_t *n_out_dev,
+                            int n_out_host, const float *W, int cout, int kvol, int subm, const float *scale,
+                            const float *shift, int relu, float *out, float *scratch, long long scratch_floats,
+                            hipStream_t s) {
+  constexpr int BM = 32 * WR, BN = 32 * NT * WCW, KC = 32;
+  const size_t lds = (size_t)(2 * (BM * KC + KC * BN) + 27 * BM + 4) * sizeof(float);
+  (void)hipFuncSetAttribute((const void *)k_sparse_conv_dma<CIN, WR, WCW, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+  const int nblk = dcl_div_up(rows, BM);
+  const int tiles = nblk * (cout / BN);
+  // split-K until ~4 workgroups per CU are in the grid (2 resident + 2 waiting), each split keeping >= 8 chunks
+  const int nchunks = dcl_div_up(kvol * CIN, KC);
+  int nsplit = 1;
+  if (scratch) {
+    nsplit = g_conv_split > 0 ? g_conv_split : dcl_div_up(1024, tiles);
+    if (nsplit > kConvMaxSplit) nsplit = kConvMaxSplit;
+    if (nsplit > nchunks / 8) nsplit = nchunks / 8;
+    while (nsplit > 1 && (long long)nsplit * cap * cout > scratch_floats) --nsplit;
+    if (nsplit < 1) nsplit = 1;
+  }
+  hipLaunchKernelGGL((k_sparse_conv_dma<CIN, WR, WCW, NT>), dim3(nblk < 65535 ? nblk : 65535, cout / BN, nsplit),
+                     dim3(64 * WR * WCW), lds, s, feat, nbr, cap, n_out_dev, n_out_host, W, cout, kvol, subm, scale, shift,
+                     relu, out, scratch, nsplit);
+  if (nsplit > 1)
+    hipLaunchKernelGGL(k_conv_split_reduce, dim3(dcl_grid_1d((long long)rows * (cout / 4), 256)), dim3(256), 0, s, scratch,
+                       nsplit, cap, n_out_dev, n_out_host, cout, scale, shift, relu, out);
+}
+
 template <int CIN, int WC, int KC>
 static void launch_conv_tile(int rows, const float *feat, const int32_t *nbr, int cap, const int32_t *n_out_dev,
                              int n_out_host, const float *W, int cout, int kvol, int subm, const float *scale,
@@ -524,13 +754,29 @@ __global__ void k_sparse_avgpool_scalar(const float *__restrict__ feat, const in
 
 }  // namespace
 
-static int g_force_valu = 0;   // test hook: 1 = plain VALU kernel for every conv, 2 = MFMA kernel without LDS staging, 3 = LDS-weights kernel
+static int g_force_valu = 0;   // test hook: 1 = plain VALU kernel for every conv, 2 = MFMA kernel without LDS staging, 3 = LDS-weights kernel, 4 = register-staged tile kernel instead of the LDS-DMA one
 DCL_API void dcl_debug_force_valu_conv(int on) { g_force_valu = on; }
+
+DCL_API void dcl_debug_conv_split(int n) { g_conv_split = n; }
+
+DCL_API int dcl_sparse_conv_scratch_floats(int rows_cap, int cout, int64_t *floats_host) {
+  DCL_CHECK_ARG(rows_cap >= 0 && cout > 0 && floats_host);
+  *floats_host = (int64_t)kConvMaxSplit * rows_cap * cout;
+  return 0;
+}
 
 DCL_API int dcl_sparse_conv_fwd(const float *feat, const int32_t *nbr, int cap, const int32_t *n_out_dev,
                                 int n_out_host, const float *W, int cin, int cout, int kvol, int subm,
                                 const float *scale, const float *shift, int relu, float *out,
                                 dclStream_t stream) {
+  return dcl_sparse_conv_fwd_ws(feat, nbr, cap, n_out_dev, n_out_host, W, cin, cout, kvol, subm, scale, shift, relu, out,
+                                nullptr, 0, stream);
+}
+
+DCL_API int dcl_sparse_conv_fwd_ws(const float *feat, const int32_t *nbr, int cap, const int32_t *n_out_dev,
+                                   int n_out_host, const float *W, int cin, int cout, int kvol, int subm,
+                                   const float *scale, const float *shift, int relu, float *out, float *scratch,
+                                   int64_t scratch_floats, dclStream_t stream) {
   DCL_CHECK_ARG(feat && nbr && W && out && cap > 0 && cin > 0 && cout > 0 && kvol > 0 && kvol <= 27);
   DCL_CHECK_ARG((scale == nullptr) == (shift == nullptr));
   DCL_CHECK_ARG(n_out_dev || (n_out_host >= 0 && n_out_host <= cap));
@@ -542,7 +788,23 @@ DCL_API int dcl_sparse_conv_fwd(const float *feat, const int32_t *nbr, int cap, 
   if (lds_ok && g_force_valu != 3) {
     // implicit-GEMM tile kernel: 64x64 tiles (KC=128) when Cout allows, else 128x32 tiles (KC=64)
 #define TILE_ARGS rows, feat, nbr, cap, n_out_dev, n_out_host, W, cout, kvol, subm, scale, shift, relu, out, s
-    if (cout % 64 == 0) {
+#define DMA_ARGS rows, feat, nbr, cap, n_out_dev, n_out_host, W, cout, kvol, subm, scale, shift, relu, out, scratch, \
+                 (long long)scratch_floats, s
+    if (cout % 128 == 0 && g_force_valu != 4) {
+      switch (cin) {
+        case 16: launch_conv_dma<16, 4, 2, 2>(DMA_ARGS); break;
+        case 32: launch_conv_dma<32, 4, 2, 2>(DMA_ARGS); break;
+        case 64: launch_conv_dma<64, 4, 2, 2>(DMA_ARGS); break;
+        default: launch_conv_dma<128, 4, 2, 2>(DMA_ARGS); break;
+      }
+    } else if (cout % 64 == 0 && g_force_valu != 4) {
+      switch (cin) {
+        case 16: launch_conv_dma<16, 4, 1, 2>(DMA_ARGS); break;
+        case 32: launch_conv_dma<32, 4, 1, 2>(DMA_ARGS); break;
+        case 64: launch_conv_dma<64, 4, 1, 2>(DMA_ARGS); break;
+        default: launch_conv_dma<128, 4, 1, 2>(DMA_ARGS); break;
+      }
+    } else if (cout % 64 == 0) {
       switch (cin) {
         case 16: launch_conv_tile<16, 2, 128>(TILE_ARGS); break;
         case 32: launch_conv_tile<32, 2, 128>(TILE_ARGS); break;
@@ -557,6 +819,7 @@ DCL_API int dcl_sparse_conv_fwd(const float *feat, const int32_t *nbr, int cap, 
         default: launch_conv_tile<128, 1, 128>(TILE_ARGS); break;
       }
     }
+#undef DMA_ARGS
 #undef TILE_ARGS
   } else if (lds_ok) {
     const int nblk = dcl_div_up(rows, 128);

@@ -133,6 +133,15 @@ int dcl_sparse_conv_fwd(const float *feat, const int32_t *nbr, int cap, const in
                         const float *scale, const float *shift, int relu, float *out,
                         dclStream_t stream);
 
+/* Same, with caller scratch: layers whose row count cannot fill the GPU split the 27*Cin contraction over up to 8
+ * workgroup groups (partial sums in `scratch`, added in split order by a second kernel, then the epilogue).
+ * scratch_floats >= dcl_sparse_conv_scratch_floats(cap, cout) enables every split; NULL = dcl_sparse_conv_fwd.   */
+int dcl_sparse_conv_fwd_ws(const float *feat, const int32_t *nbr, int cap, const int32_t *n_out_dev,
+                           int n_out_host, const float *W, int cin, int cout, int kvol, int subm,
+                           const float *scale, const float *shift, int relu, float *out, float *scratch,
+                           int64_t scratch_floats, dclStream_t stream);
+int dcl_sparse_conv_scratch_floats(int rows_cap, int cout, int64_t *floats_host);
+
 /* indiceSummaryRF + indice_avgpool_fp32 (use_gs=False): rf[o] = #valid offsets,
  * out[o] = sum_k asc feat[nbr[k][o]] / (float)rf[o].  rf may be NULL.          */
 int dcl_sparse_avgpool_fwd(const float *feat, const int32_t *nbr, int cap, const int32_t *n_out_dev,
@@ -291,6 +300,8 @@ int dcl_add_s(int b, int P, const float *cld, const int32_t *cls, const float *R
 void dcl_debug_force_valu_conv(int on);
 /* Test hook: 0 = automatic choice of the attention kernel, 1 = shared-tile 8-wave variant, 2 = double-buffered 4-wave. */
 void dcl_debug_attention_variant(int v);
+/* Tuning hook: 0 = automatic split-K choice in dcl_sparse_conv_fwd_ws, n = force n splits (when the scratch allows). */
+void dcl_debug_conv_split(int n);
 /* Tuning hook for dcl_group_points' LDS-staged kernel: channel rows per workgroup, x-blocks, threads per workgroup,
  * store kind (2 = plain instead of nontemporal); 0 = built-in choice for each. */
 void dcl_debug_group_points_cfg(int cc, int xb, int threads, int nontemporal);

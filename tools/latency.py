@@ -11,7 +11,7 @@ cfg = dcl.synth.default_cfg(n, n)
 net = dcl.DCL_Net.Network(cfg, mode="test")
 net.load_state_dict(dcl.synth.synth_state_dict(net, 1))
 net = net.cuda().eval()
-for b in (1, 4, 8):
+for b in (1, 4, 8, 32):
     data = dcl.synth.make_batch(b, n, n)
     res = {}
     for name, fn in (("eager", lambda: net(data)), ("hipgraph", lambda: net.forward_graphed(data))):
