@@ -16,7 +16,7 @@ The directory name contains a hyphen (it is the project's name); import it with
 """
 from . import _native, ops  # noqa: F401
 from . import spconv  # noqa: F401
-from . import synth, sharding, crops  # noqa: F401
+from . import synth, sharding, crops, autograd  # noqa: F401
 from .models import DCL_Net, Modules, refiner  # noqa: F401
 
 build = _native.build

@@ -2,6 +2,7 @@
 import torch
 
 from .... import ops as _ops
+from ....autograd import VoxelizationFn
 
 
 def voxelization_idx(coords, batchsize, mode=4):
@@ -15,4 +16,4 @@ def voxelization(feats, map_rule, mode=4):
     """Voxelization.apply: feats cuda float (N,C), map_rule cuda int (M, maxActive+1) -> cuda float (M,C)."""
     assert map_rule.is_contiguous()
     assert feats.is_contiguous()
-    return _ops.voxelize_fp(feats, map_rule, mode)
+    return VoxelizationFn.apply(feats, map_rule, mode)

@@ -2,6 +2,7 @@
 import torch
 
 from ... import ops as _ops
+from ...autograd import ThreeInterpolateFn
 
 
 def three_nn(unknown, known, known_seg=None):
@@ -18,4 +19,4 @@ def three_interpolate(features, idx, weight):
     assert features.is_contiguous()
     assert idx.is_contiguous()
     assert weight.is_contiguous()
-    return _ops.three_interpolate_sp(features, idx, weight)
+    return ThreeInterpolateFn.apply(features, idx, weight)

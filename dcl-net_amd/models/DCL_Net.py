@@ -41,8 +41,17 @@ def normalize_vector(v):
 
 
 def ortho9d2matrix(x_raw, y_raw, z_raw):
-    """Rotation from three raw axes (reference models/DCL_Net.py:15-36): on-device 3x3 SVD kernel."""
-    return ops.ortho9d_to_matrix(torch.cat([x_raw, y_raw, z_raw], dim=1))
+    """Rotation from three raw axes (reference models/DCL_Net.py:15-36): on-device 3x3 SVD kernel.  When a gradient is
+    needed (training) the same projection is composed from differentiable torch ops -- normalised axes as columns,
+    U diag(1, 1, det(U V^T)) V^T -- with the batched 3x3 SVD on the host (b tiny matrices)."""
+    if not (torch.is_grad_enabled() and (x_raw.requires_grad or y_raw.requires_grad or z_raw.requires_grad)):
+        return ops.ortho9d_to_matrix(torch.cat([x_raw, y_raw, z_raw], dim=1))
+    dev = x_raw.device
+    m = torch.stack([normalize_vector(x_raw), normalize_vector(y_raw), normalize_vector(z_raw)], dim=2).cpu()
+    U, _, Vh = torch.linalg.svd(m)
+    ones = torch.ones(m.shape[0], dtype=m.dtype)
+    sigma = torch.diag_embed(torch.stack([ones, ones, torch.det(U @ Vh)], dim=1))
+    return (U @ sigma @ Vh).to(dev)
 
 
 def _mlp3(dims):

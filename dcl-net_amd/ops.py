@@ -564,3 +564,73 @@ def crop_sample(xyz, rgb, sample_idx, counts, half_extent0, unit, voxel_limit, n
                                     int(min_valid), _c_float(half_extent0), unit_a, int(voxel_limit), N.ptr(feats),
                                     N.ptr(coords), N.stream()), "crop_sample")
     return feats, coords
+
+
+# ------------------------------------------------------------------------------------ training-side kernels
+def rulebook_transpose(nbr, n_out, cap_in):
+    """inv[k][i] = o for nbr[k][o] = i (csrc/backward.hip); nbr (kvol, cap_out) i32 -> (kvol, cap_in) i32."""
+    N.need_cuda(nbr)
+    kvol, cap_out = nbr.shape
+    inv = torch.empty((kvol, max(cap_in, 1)), dtype=torch.int32, device=nbr.device)
+    N.check(N.lib().dcl_rulebook_transpose(N.ptr(nbr), cap_out, N.vp(0), int(n_out), kvol, N.ptr(inv), max(cap_in, 1),
+                                           N.stream()), "rulebook_transpose")
+    return inv
+
+
+def sparse_conv_backward(feat, W, dout, nbr, n_out, subm, need_dx=True):
+    """indice_conv_backward_fp32 (spconv_ops.h:351-438): -> (d_feat (V_in,Cin) or None, dW (kvol,Cin,Cout))."""
+    N.need_cuda(feat, W, dout, nbr)
+    kvol, cap = nbr.shape
+    cin, cout = W.shape[-2], W.shape[-1]
+    n_in = feat.shape[0]
+    dev = feat.device
+    dout = dout.contiguous()
+    dW = torch.zeros((kvol, cin, cout), dtype=torch.float32, device=dev)
+    dx = None
+    if n_out > 0:
+        splits = C.c_int32(0)
+        N.check(N.lib().dcl_sparse_conv_wgrad_splits(int(n_out), C.byref(splits)), "wgrad_splits")
+        partial = torch.empty(splits.value * kvol * cin * cout, dtype=torch.float32, device=dev)
+        N.check(N.lib().dcl_sparse_conv_wgrad(N.ptr(feat), N.ptr(nbr), cap, int(n_out), N.ptr(dout), cin, cout, kvol,
+                                              N.ptr(partial), N.ptr(dW), N.stream()), "sparse_conv_wgrad")
+    if need_dx:
+        if n_in == 0 or n_out == 0:
+            dx = torch.zeros((n_in, cin), dtype=torch.float32, device=dev)
+        else:
+            inv = rulebook_transpose(nbr, n_out, n_in)
+            Wt = W.reshape(kvol, cin, cout).transpose(1, 2).contiguous()          # per-offset W^T: (kvol, Cout, Cin)
+            dx = sparse_conv(dout, inv, n_in, Wt, subm)
+    return dx, dW
+
+
+def sparse_avgpool_backward(dout, nbr, n_out, n_in, rf):
+    """indice_avgpool_backward_fp32 (avgpool.cu:178-206) -> d_feat (V_in, C)."""
+    N.need_cuda(dout, nbr, rf)
+    c = dout.shape[1]
+    din = torch.zeros((n_in, c), dtype=torch.float32, device=dout.device)
+    if n_in == 0 or n_out == 0:
+        return din
+    inv = rulebook_transpose(nbr, n_out, n_in)
+    N.check(N.lib().dcl_sparse_avgpool_bwd(N.ptr(dout.contiguous()), N.ptr(inv), inv.shape[1], int(n_in), N.ptr(rf), c,
+                                           nbr.shape[0], N.ptr(din), N.stream()), "sparse_avgpool_bwd")
+    return din
+
+
+def three_interpolate_grad_sp(grad_out, idx, weight, m):
+    """three_interpolate_grad_wrapper of libs/pointnet_sp -> grad_points (m, C)."""
+    N.need_cuda(grad_out, idx, weight)
+    n, c = grad_out.shape
+    gp = torch.zeros((m, c), dtype=torch.float32, device=grad_out.device)
+    N.check(N.lib().dcl_three_interpolate_grad_sp(c, n, m, N.ptr(grad_out.contiguous()), N.ptr(idx), N.ptr(weight), N.ptr(gp),
+                                                  N.stream()), "three_interpolate_grad_sp")
+    return gp
+
+
+def voxelize_bp(d_out, map_rule, n_points, mode=4):
+    """PG_OP.voxelize_bp (pointgroup_ops.py:65-73) -> d_feats (N, C)."""
+    N.need_cuda(d_out, map_rule)
+    M, c = d_out.shape
+    d_feats = torch.zeros((n_points, c), dtype=torch.float32, device=d_out.device)
+    N.check(N.lib().dcl_voxelize_bp(N.ptr(d_out.contiguous()), N.ptr(map_rule), N.ptr(d_feats), M, map_rule.shape[1] - 1, c,
+                                    int(mode == 4), N.stream()), "voxelize_bp")
+    return d_feats

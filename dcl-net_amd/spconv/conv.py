@@ -7,6 +7,7 @@ from torch.nn import init
 from torch.nn.parameter import Parameter
 
 from .. import ops as _ops
+from ..autograd import SparseConvFn
 from . import ops
 from .modules import SparseModule
 from .tensor import SparseConvTensor
@@ -71,7 +72,7 @@ class SparseConvolution(SparseModule):
             input.indice_dict[self.indice_key] = (out_set, indices, nbr, None, input.spatial_shape)
         n_out = indices.shape[0] if self.subm else out_set.n
         W = self.weight.view(-1, self.in_channels, self.out_channels)
-        out_features = _ops.sparse_conv(features.contiguous(), nbr, n_out, W, self.subm)
+        out_features = SparseConvFn.apply(features.contiguous(), W.contiguous(), nbr, n_out, self.subm)
         if self.bias is not None:
             out_features += self.bias
         out_tensor = SparseConvTensor(out_features, indices if self.subm else out_set.indices, out_shape,

@@ -1,5 +1,6 @@
 """SparseAvgPool / SparseAvgPool3d (the DCL-Net authors' addition, libs/spconv/spconv/pool.py:198-279)."""
 from .. import ops as _ops
+from ..autograd import SparseAvgPoolFn
 from . import ops
 from .modules import SparseModule
 from .tensor import SparseConvTensor
@@ -32,7 +33,7 @@ class SparseAvgPool(SparseModule):
                                                  self.dilation)
         out_set, nbr = ops.build_rulebook(input.active_set(), k, s, p, self.subm)
         n_out = input.indices.shape[0] if self.subm else out_set.n
-        out_features = _ops.sparse_avgpool(input.features.contiguous(), nbr, n_out)
+        out_features = SparseAvgPoolFn.apply(input.features.contiguous(), nbr, n_out)
         out_tensor = SparseConvTensor(out_features, input.indices if self.subm else out_set.indices, out_shape,
                                       input.batch_size)
         out_tensor._aset = out_set

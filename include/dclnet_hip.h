@@ -263,6 +263,26 @@ int dcl_conf_pool(int b, int c, int n1, int n2, const float *logit1, const float
 /* ortho9d2matrix (models/DCL_Net.py:15-36): o9 (b,9) -> R (b,3,3).             */
 int dcl_ortho9d_to_matrix(int b, const float *o9, float *R, dclStream_t stream);
 
+/* ------------------------------------------------------------ training-side kernels (csrc/backward.hip) ---
+ * Transposed rulebook: inv[k][i] = o for every nbr[k][o] = i >= 0, -1 elsewhere (inv: i32[kvol][cap_in]).  With it the
+ * input gradient of indice_conv (spconv_ops.h:351-438) is dcl_sparse_conv_fwd(dOut, inv, W^T per offset).            */
+int dcl_rulebook_transpose(const int32_t *nbr, int cap_out, const int32_t *n_out_dev, int n_out_host, int kvol,
+                           int32_t *inv, int cap_in, dclStream_t stream);
+/* Filter gradient of indice_conv: dW[k] = sum_o feat[nbr[k][o]]^T dout[o] (spconv_ops.h:413-417).  partial: scratch of
+ * splits*kvol*cin*cout floats with splits = dcl_sparse_conv_wgrad_splits(n_out); partial sums are added in split order. */
+int dcl_sparse_conv_wgrad_splits(int n_out, int32_t *splits_host);
+int dcl_sparse_conv_wgrad(const float *feat, const int32_t *nbr, int cap, int n_out, const float *dout, int cin, int cout,
+                          int kvol, float *partial, float *dW, dclStream_t stream);
+/* indice_avgpool backward (avgpool.cu:178-206): din[i] = sum_k asc dout[inv[k][i]] / (float)rf[inv[k][i]].  C % 4 == 0. */
+int dcl_sparse_avgpool_bwd(const float *dout, const int32_t *inv, int cap_in, int n_in, const int32_t *rf, int c, int kvol,
+                           float *din, dclStream_t stream);
+/* three_interpolate_grad of libs/pointnet_sp (interpolate_gpu.cu:124-148): atomic scatter into a ZEROED (m,c) buffer.  */
+int dcl_three_interpolate_grad_sp(int c, int n, int m, const float *grad_out, const int32_t *idx, const float *weight,
+                                  float *grad_points_zeroed, dclStream_t stream);
+/* voxelize_bp (voxelize.cu:35-50): d_feats[rules[v][1+i]] += (average ? 1/n_v : 1) * d_out[v]; d_feats ZEROED (N,C).   */
+int dcl_voxelize_bp(const float *d_out, const int32_t *rules, float *d_feats_zeroed, int n_rows, int max_active, int c,
+                    int average, dclStream_t stream);
+
 /* ------------------------------------------------------------ crop builder ---
  * The per-object crop construction of the data loaders (YCBV/dataloader_test_YCBV.py:124-183), on the device, in the
  * reference's pixel order and float32/float64 arithmetic (results bit-identical to the numpy/torch code).

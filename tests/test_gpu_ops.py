@@ -125,7 +125,7 @@ def test_sparse_conv_matches_oracle(dcl, oracle, cin, cout, subm):
     assert np.abs(got - want).max() <= tol
     # MFMA kernel vs plain VALU kernel on the device (A/B)
     lib = dcl._native.lib()
-    for mode in (1, 2, 3):                                     # 1: VALU, 2: MFMA no LDS, 3: MFMA + LDS weights
+    for mode in (1, 2, 3, 4):                                  # 1: VALU, 2: MFMA no LDS, 3: MFMA + LDS weights, 4: reg-staged tiles
         lib.dcl_debug_force_valu_conv(mode)
         try:
             alt = dcl.ops.sparse_conv(cuda(feat), nbr, n_out, Wd, subm).cpu().numpy()
