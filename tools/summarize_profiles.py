@@ -14,11 +14,11 @@ rnd = sys.argv[1] if len(sys.argv) > 1 else "r1"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
-for shape in ("stress", "ref"):
+for shape, tag in (("stress", "stress"), ("ref", "ref"), ("prim", "primitives")):
     for f in glob.glob(os.path.join(root, "gpurun_out", "%s_%s" % (rnd, shape), "*", "*kernel_stats.csv")):
-        shutil.copy(f, os.path.join(out, "%s_%s_kernel_stats.csv" % (rnd, shape)))
+        shutil.copy(f, os.path.join(out, "%s_%s_kernel_stats.csv" % (rnd, tag)))
 rows_out = []
-for d in sorted(glob.glob(os.path.join(root, "gpurun_out", "%s_pmc_*" % rnd))):
+for d in sorted(glob.glob(os.path.join(root, "gpurun_out", "%s_pmc*" % rnd))):   # r1_pmc_* (bench, stress), r1_pmcprim_*, r1_pmcconv_*
     if not os.path.isdir(d):
         continue
     for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
