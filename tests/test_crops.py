@@ -98,3 +98,25 @@ def test_built_crops_run_through_the_network(dcl):
         ref = net({k: v for k, v in want.items()})
     assert float((out["rot_pred"] - ref["rot_pred"]).abs().max()) <= 1e-6
     assert float((out["trans_pred"] - ref["trans_pred"]).abs().max()) <= 1e-6
+
+
+@pytest.mark.gpu
+def test_device_crop_builder_timing(dcl, capsys):
+    """reported number: device builder vs the CPU restatement of the loader on one 6-object frame"""
+    import time
+    cfg = dict(CFG, input_size=1024, tmp_size=1024)
+    sc = make_scene(5, n_obj=6, tmp_size=1024)
+    builder = dcl.crops.CropBuilder(cfg, sc["cad_pts"], sc["cad_col"])
+    res = {}
+    for name, fn, reps in (("device", lambda: builder.build(sc["img"], sc["depth"], sc["label"], sc["rois"], sc["gt_obj"]), 20),
+                           ("cpu", lambda: _oracle_build(sc, cfg, 1), 3)):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        res[name] = (time.perf_counter() - t0) / reps * 1e3
+    with capsys.disabled():
+        print("\ncrop builder: device %.2f ms, CPU restatement %.2f ms per frame" % (res["device"], res["cpu"]))
+    assert res["device"] < res["cpu"]
