@@ -131,6 +131,29 @@ def primitives_roofline(dcl, reps=5):
     return out
 
 
+def lm_stream_bench(dcl, dev, reps=30):
+    """BASELINE config 4 (S3): LineMOD eval stream -- one object crop per call (tools/test_LM.py:104-112), N=M=1024,
+    5 mm voxels (configs/config_LM.yaml:17-20); forward() vs the whole-forward hipGraph replay, inputs resident in HBM."""
+    cfg = dcl.synth.default_cfg(1024, 1024, unit=0.005)
+    net = dcl.DCL_Net.Network(cfg, mode="test")
+    net.load_state_dict(dcl.synth.synth_state_dict(net, 1))
+    net = net.to(dev).eval()
+    out = {"workload": "LineMOD stream: 1 crop per call, N=M=1024, 64^3 x 5 mm voxels"}
+    data = to_device(dcl.synth.make_batch(1, 1024, 1024, unit=0.005), dev)
+    for name, fn in (("eager", lambda: net(data)), ("hipgraph", lambda: net.forward_graphed(data))):
+        with torch.no_grad():
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        out[name] = {"ms_per_frame": round(ms, 3), "frames_per_s": round(1e3 / ms, 1)}
+    return out
+
+
 def refiner_bench(dcl, dev, b, iters=2, reps=20):
     """BASELINE config 5 (S4): the stage-2 refine loop (2 iterations, tools/test_YCBV_stage2.py:214-225) on b crops of
     1024 points, eager vs hipGraph-captured; ms per loop and crops/s."""
@@ -251,6 +274,7 @@ def main():
                                  "ms_per_step": round(rdt / rsteps * 1e3, 3),
                                  "attention_TFLOPs": round(rflop / (np.mean(ratt) * 1e-3) / 1e12, 2) if ratt else None}
             del rnet, rdata
+        line["lm_stream"] = lm_stream_bench(dcl, dev)
         line["primitives"] = primitives_roofline(dcl)
         line["refiner"] = refiner_bench(dcl, dev, b)
         line["cpu_baseline"] = cpu_baseline(dcl, sd, cfg, n_inp, n_tmp)
