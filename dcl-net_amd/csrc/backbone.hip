@@ -15,8 +15,8 @@
 // dcl_backbone_ws_bytes / dcl_backbone_ws2_bytes.
 #include "common.h"
 
-int dcl_internal_grid_from_indices(const int32_t *indices, const int32_t *n_rows_dev, int n_rows, int batch, int S,
-                                   uint32_t *mask, int32_t *wprefix, int32_t *perm, int32_t *scratch,
+int dcl_internal_grid_from_indices(const int32_t *indices, const int32_t *n_rows_dev, int n_rows, int batch_lo, int batch,
+                                   int S, uint32_t *mask, int32_t *wprefix, int32_t *perm, int32_t *scratch,
                                    dclStream_t stream);
 int dcl_three_nn_sp_strided(int n, int m, const float *unknown, const float *known, float *dist2, int32_t *idx,
                             const int32_t *known_seg, int nbatch, int seg_stride, dclStream_t stream);
@@ -121,28 +121,36 @@ DCL_API int dcl_backbone_ws_bytes(int batch, int S, int V0, int64_t *bytes_host)
   return 0;
 }
 
-static int backbone_geometry(const int32_t *occ, const int32_t *V0_dev, int V0, int batch, int S, void *ws,
+static int backbone_geometry(const int32_t *occ, const int32_t *V0_dev, int V0, int batch_lo, int batch, int S, void *ws,
                              int64_t ws_bytes, int32_t *counts_dev, dclStream_t stream);
 
 DCL_API int dcl_backbone_geometry(const int32_t *occ, int V0, int batch, int S, void *ws, int64_t ws_bytes,
                                   int32_t *counts_dev, dclStream_t stream) {
-  return backbone_geometry(occ, nullptr, V0, batch, S, ws, ws_bytes, counts_dev, stream);
+  return backbone_geometry(occ, nullptr, V0, 0, batch, S, ws, ws_bytes, counts_dev, stream);
+}
+
+// batch window: only the voxels of crops batch_lo .. batch_lo+batch-1 of `occ` enter this pass (re-based to crop 0), so
+// several passes over sub-batches can share one occupied-voxel array / one voxelised feature array (pipelined forward)
+DCL_API int dcl_backbone_geometry_window(const int32_t *occ, int V0, int batch_lo, int batch, int S, void *ws,
+                                         int64_t ws_bytes, int32_t *counts_dev, dclStream_t stream) {
+  DCL_CHECK_ARG(batch_lo >= 0);
+  return backbone_geometry(occ, nullptr, V0, batch_lo, batch, S, ws, ws_bytes, counts_dev, stream);
 }
 
 // capacity mode: occ has V0_cap rows of which the first *V0_dev are live (enqueue-only, shapes independent of the data)
 DCL_API int dcl_backbone_geometry_cap(const int32_t *occ, const int32_t *V0_dev, int V0_cap, int batch, int S, void *ws,
                                       int64_t ws_bytes, int32_t *counts_dev, dclStream_t stream) {
   DCL_CHECK_ARG(V0_dev);
-  return backbone_geometry(occ, V0_dev, V0_cap, batch, S, ws, ws_bytes, counts_dev, stream);
+  return backbone_geometry(occ, V0_dev, V0_cap, 0, batch, S, ws, ws_bytes, counts_dev, stream);
 }
 
-static int backbone_geometry(const int32_t *occ, const int32_t *V0_dev, int V0, int batch, int S, void *ws,
+static int backbone_geometry(const int32_t *occ, const int32_t *V0_dev, int V0, int batch_lo, int batch, int S, void *ws,
                              int64_t ws_bytes, int32_t *counts_dev, dclStream_t stream) {
   GeoLayout L;
   DCL_CHECK_ARG(ws && counts_dev && make_geo_layout(batch, S, V0, &L) && ws_bytes >= (int64_t)L.total);
   DCL_CHECK_ARG(V0 == 0 || occ);
   int32_t *scratch = at<int32_t>(ws, L.scratch);
-  int rc = dcl_internal_grid_from_indices(occ, V0_dev, V0, batch, S, at<uint32_t>(ws, L.mask0),
+  int rc = dcl_internal_grid_from_indices(occ, V0_dev, V0, batch_lo, batch, S, at<uint32_t>(ws, L.mask0),
                                           at<int32_t>(ws, L.wprefix0), at<int32_t>(ws, L.perm0), scratch, stream);
   if (rc) return rc;
   const int32_t *in_idx = occ;

@@ -87,23 +87,29 @@ __device__ __forceinline__ int grid_lookup(const uint32_t *__restrict__ mask, co
   return perm ? perm[r] : r;
 }
 
+// rows whose batch index lies in [b_lo, b_lo + nb) enter the grid, re-based to batch 0 (a batch window lets several
+// backbone passes share one occupied-voxel array)
 __global__ void k_mark_rows(const int32_t *__restrict__ indices, const int32_t *__restrict__ n_dev, int n_host, int S,
-                            uint32_t *__restrict__ mask) {
+                            int b_lo, int nb, uint32_t *__restrict__ mask) {
   const int n = n_dev ? min(*n_dev, n_host) : n_host;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int4 p = reinterpret_cast<const int4 *>(indices)[i];
-    const int lin = ((p.x * S + p.y) * S + p.z) * S + p.w;
+    const int bb = p.x - b_lo;
+    if ((unsigned)bb >= (unsigned)nb) continue;
+    const int lin = ((bb * S + p.y) * S + p.z) * S + p.w;
     atomicOr(&mask[lin >> 5], 1u << (lin & 31));
   }
 }
 
 __global__ void k_fill_perm(const int32_t *__restrict__ indices, const int32_t *__restrict__ n_dev, int n_host, int S,
-                            const uint32_t *__restrict__ mask, const int32_t *__restrict__ wprefix,
+                            int b_lo, int nb, const uint32_t *__restrict__ mask, const int32_t *__restrict__ wprefix,
                             int32_t *__restrict__ perm) {
   const int n = n_dev ? min(*n_dev, n_host) : n_host;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int4 p = reinterpret_cast<const int4 *>(indices)[i];
-    const int lin = ((p.x * S + p.y) * S + p.z) * S + p.w;
+    const int bb = p.x - b_lo;
+    if ((unsigned)bb >= (unsigned)nb) continue;
+    const int lin = ((bb * S + p.y) * S + p.z) * S + p.w;
     perm[grid_lookup(mask, wprefix, nullptr, lin)] = i;
   }
 }
@@ -291,17 +297,17 @@ int dcl_internal_scan_mask(const uint32_t *mask, int nwords, int32_t *wprefix, i
 }
 
 // n_rows_dev (optional): the live row count on the device; n_rows then only bounds it (capacity mode, graph capture)
-int dcl_internal_grid_from_indices(const int32_t *indices, const int32_t *n_rows_dev, int n_rows, int batch, int S,
-                                   uint32_t *mask, int32_t *wprefix, int32_t *perm, int32_t *scratch,
+int dcl_internal_grid_from_indices(const int32_t *indices, const int32_t *n_rows_dev, int n_rows, int batch_lo, int batch,
+                                   int S, uint32_t *mask, int32_t *wprefix, int32_t *perm, int32_t *scratch,
                                    dclStream_t stream);
 
 DCL_API int dcl_grid_from_indices(const int32_t *indices, int n_rows, int batch, int S, uint32_t *mask,
                                   int32_t *wprefix, int32_t *perm, int32_t *scratch, dclStream_t stream) {
-  return dcl_internal_grid_from_indices(indices, nullptr, n_rows, batch, S, mask, wprefix, perm, scratch, stream);
+  return dcl_internal_grid_from_indices(indices, nullptr, n_rows, 0, batch, S, mask, wprefix, perm, scratch, stream);
 }
 
-int dcl_internal_grid_from_indices(const int32_t *indices, const int32_t *n_rows_dev, int n_rows, int batch, int S,
-                                   uint32_t *mask, int32_t *wprefix, int32_t *perm, int32_t *scratch,
+int dcl_internal_grid_from_indices(const int32_t *indices, const int32_t *n_rows_dev, int n_rows, int batch_lo, int batch,
+                                   int S, uint32_t *mask, int32_t *wprefix, int32_t *perm, int32_t *scratch,
                                    dclStream_t stream) {
   DCL_CHECK_ARG(batch > 0 && S > 0 && n_rows >= 0 && mask && wprefix && scratch);
   DCL_CHECK_ARG(grid_words(batch, S) < (1ll << 26));
@@ -310,12 +316,13 @@ int dcl_internal_grid_from_indices(const int32_t *indices, const int32_t *n_rows
   dcl_internal_zero_words(mask, nwords, s);
   if (n_rows > 0) {
     DCL_CHECK_ARG(indices);
-    hipLaunchKernelGGL(k_mark_rows, dim3(dcl_grid_1d(n_rows, 256)), dim3(256), 0, s, indices, n_rows_dev, n_rows, S, mask);
+    hipLaunchKernelGGL(k_mark_rows, dim3(dcl_grid_1d(n_rows, 256)), dim3(256), 0, s, indices, n_rows_dev, n_rows, S,
+                       batch_lo, batch, mask);
   }
   scan_mask(mask, nwords, wprefix, scratch, s);
   if (perm && n_rows > 0)
     hipLaunchKernelGGL(k_fill_perm, dim3(dcl_grid_1d(n_rows, 256)), dim3(256), 0, s, indices, n_rows_dev, n_rows, S,
-                       mask, wprefix, perm);
+                       batch_lo, batch, mask, wprefix, perm);
   DCL_LAUNCH_CHECK();
   return 0;
 }

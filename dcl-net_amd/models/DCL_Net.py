@@ -169,14 +169,24 @@ class Network(nn.Module):
         x = self._lin_relu(x, *layers[1])
         return torch.addmm(layers[2][1], x, layers[2][0])
 
-    def _side_stream(self, dev):
-        """second stream for the template-side backbone (DCL_SINGLE_STREAM=1: everything on the current stream)"""
+    def _side_stream(self, dev, which=0):
+        """per-side streams of the sparse half (DCL_SINGLE_STREAM=1: everything on the current stream)"""
         if os.environ.get("DCL_SINGLE_STREAM") == "1":
             return torch.cuda.current_stream(dev)
-        st = self.__dict__.get("_side")
-        if st is None:
-            st = self.__dict__["_side"] = torch.cuda.Stream(dev)
-        return st
+        sts = self.__dict__.setdefault("_side", {})
+        if which not in sts:
+            sts[which] = torch.cuda.Stream(dev)
+        return sts[which]
+
+    def _pipeline_chunks(self, b):
+        """number of crop chunks of the sparse/disengage software pipeline.  Measured on MI355X (bs 32): K = 1/2/4 ->
+        25.2/26.0/27.8 ms at N=12288 and 5.3/6.3/8.0 ms at N=1024 -- the sparse passes are latency-bound, so K passes over
+        b/K crops cost almost K times one pass over b crops and the overlap cannot pay for that.  Default 1 (the two
+        backbones still overlap each other and the first disengage GEMMs); DCL_CHUNKS=k keeps the experiment runnable."""
+        k = int(os.environ.get("DCL_CHUNKS", "1"))
+        while k > 1 and (b % k != 0 or b // k < 4):
+            k -= 1
+        return max(k, 1)
 
     def _forward_fused(self, data):
         f = self._fold()
@@ -191,54 +201,93 @@ class Network(nn.Module):
             side_in[side] = (d["feats"].to(dev, non_blocking=True).float().contiguous(),
                              d["v2p_maps"].to(dev, non_blocking=True).int().contiguous(),
                              d["occupied_voxels"].to(dev, non_blocking=True).int().contiguous())
-        # the two backbones are independent until the correspondence attention: the template side runs on a second
-        # HIP stream so that its (small, latency-bound) kernels fill the CUs the observed side leaves idle
-        main, side_stream = torch.cuda.current_stream(dev), self._side_stream(dev)
-        streams = {"inp": main, "tmp": side_stream}
-        side_stream.wait_stream(main)
+        # Schedule.  (1) The two backbones are independent until the correspondence attention: each side has its own HIP
+        # stream.  (2) The sparse half of the forward is latency/L2-bound and the disengage GEMMs behind it MFMA-bound, so
+        # the batch is cut into K chunks of crops and the sparse half of chunk c+1 (side streams) runs underneath the
+        # disengage GEMMs of chunk c (main stream): every chunk is its own backbone pass over a batch WINDOW of the shared
+        # voxel arrays.  Attention and heads run on the whole batch (their launches need >= 256 workgroups).  One host
+        # read-back of all K*16 level sizes, as before.  DCL_SINGLE_STREAM=1 / DCL_CHUNKS=1 switch the overlap off.
+        main = torch.cuda.current_stream(dev)
+        sstream = {"inp": self._side_stream(dev, 0), "tmp": self._side_stream(dev, 1)}
+        K = self._pipeline_chunks(b)
+        bc = b // K
+        for st in sstream.values():
+            st.wait_stream(main)
         runs = {}
-        for s in ("inp", "tmp"):
-            with torch.cuda.stream(streams[s]):
-                runs[s] = ops.BackboneRun(side_in[s][2], b, S)
-        main.wait_stream(side_stream)
-        counts = torch.cat([runs["inp"].counts_dev, runs["tmp"].counts_dev]).cpu().tolist()   # the single host sync
-        runs["inp"].set_counts(counts[:8])
-        runs["tmp"].set_counts(counts[8:])
+        for c in range(K):
+            for s in ("inp", "tmp"):
+                with torch.cuda.stream(sstream[s]):
+                    runs[s, c] = ops.BackboneRun(side_in[s][2], bc, S, batch_lo=c * bc)
+        for st in sstream.values():
+            main.wait_stream(st)
+        counts = torch.cat([runs[s, c].counts_dev for c in range(K) for s in ("inp", "tmp")]).cpu().tolist()   # host sync
+        for i, key in enumerate((s, c) for c in range(K) for s in ("inp", "tmp")):
+            runs[key[0], key[1]].set_counts(counts[8 * i:8 * i + 8])
         unit = self.unit_voxel_extent
         assert unit[0] == unit[1] == unit[2], "anisotropic voxels: use fused=False"
         off = float(np.float32(-0.5 * unit[0] * VOXEL_NUM_LIMIT[0]))
         extents = [float(np.float32(unit[0] * sc)) for sc in SCALE_LISTS]
-        pf = {}
-        pts = {}
-        side_stream.wait_stream(main)
-        for side, bb, n in (("inp", "backbone_inp", self.n_inp), ("tmp", "backbone_tmp", self.n_tmp)):
-            with torch.cuda.stream(streams[side]):
+        npts = {"inp": self.n_inp, "tmp": self.n_tmp}
+        pf = {s: torch.empty((b * npts[s], 480), dtype=torch.float32, device=dev) for s in ("inp", "tmp")}
+        pts = {s: side_in[s][0][:, 4:7].reshape(b, npts[s], 3) for s in ("inp", "tmp")}
+        act = {}
+        for side, key in (("Xc", "inp"), ("Yo", "tmp")):
+            act.update(self._disengage_buffers(side, b * npts[key], dev))
+        done = {}
+        for st in sstream.values():
+            st.wait_stream(main)
+        for side, bb in (("inp", "backbone_inp"), ("tmp", "backbone_tmp")):
+            n = npts[side]
+            with torch.cuda.stream(sstream[side]):
                 feats, v2p, _ = side_in[side]
-                x = ops.voxelize_fp(feats, v2p, self.voxelization_mode)
-                runs[side].features(x, *f[bb + "_ptrs"])
-                xyz = feats[:, 4:7]
-                bid = torch.arange(b, device=dev, dtype=torch.float32).repeat_interleave(n).unsqueeze(1)
-                pf[side] = runs[side].point_features(torch.cat([bid, xyz], 1).contiguous(), extents, off)
-                pts[side] = xyz.reshape(b, n, 3)
-        main.wait_stream(side_stream)
-
-        prediction = self._dense(f, pf["inp"], pf["tmp"], b, dev)
+                x = ops.voxelize_fp(feats, v2p, self.voxelization_mode)        # all crops at once; chunks index into it
+                bid = torch.arange(bc, device=dev, dtype=torch.float32).repeat_interleave(n).unsqueeze(1)
+                for c in range(K):
+                    rows = slice(c * bc * n, (c + 1) * bc * n)
+                    runs[side, c].features(x, *f[bb + "_ptrs"])
+                    runs[side, c].point_features(torch.cat([bid, feats[rows, 4:7]], 1).contiguous(), extents, off,
+                                                 out=pf[side][rows])
+                    done[side, c] = torch.cuda.Event()
+                    done[side, c].record(sstream[side])
+        for c in range(K):                                                     # dense stage 1, chunk by chunk on main
+            for side, key in (("Xc", "inp"), ("Yo", "tmp")):
+                main.wait_event(done[key, c])
+                rows = slice(c * bc * npts[key], (c + 1) * bc * npts[key])
+                self._disengage(f, side, pf[key][rows], act, rows)
+        for st in sstream.values():
+            main.wait_stream(st)
+        prediction = self._dense_tail(f, act, b, dev)
         if self.mode != "test":
             prediction["sym_flag"] = data["flags"].to(dev)
         data["labels"]["points_tmp"] = pts["tmp"]
         data["labels"]["points_inp"] = pts["inp"]
         return prediction
 
+    _DIS_TAGS = (("p1", 256), ("m1", 64), ("p2", 256), ("m2", 64))
+
+    def _disengage_buffers(self, side, rows, dev):
+        return {side + tag: torch.empty((rows, c), dtype=torch.float32, device=dev) for tag, c in self._DIS_TAGS}
+
+    def _disengage(self, f, side, pf_rows, act, rows=slice(None)):
+        """the four disengage stacks of one side on a block of points: one shared 480->1024 GEMM (BN folded), then the four
+        second layers, written into rows `rows` of the activation buffers in `act`"""
+        W1t, t1, second = f["dis_" + side]
+        H = self._lin_relu(pf_rows, W1t, t1)                                # (rows, 1024): 4 stacks at once
+        for j, (tag, _) in enumerate(self._DIS_TAGS):
+            Wt, bias = second[j]
+            torch._addmm_activation(bias, H[:, 256 * j:256 * (j + 1)], Wt, out=act[side + tag][rows])
+
     def _dense(self, f, pf_inp, pf_tmp, b, dev):
         """dense half of the fused pipeline on point-major activations: disengage stacks, correspondence attention,
         confidence + fuser heads, pooling, pose heads.  Static shapes only (graph-capturable)."""
-        pf = {"inp": pf_inp, "tmp": pf_tmp}
         act = {}
-        for side, key in (("Xc", "inp"), ("Yo", "tmp")):
-            W1t, t1, second = f["dis_" + side]
-            H = self._lin_relu(pf[key], W1t, t1)                            # (b*n, 1024): 4 stacks at once
-            for j, tag in enumerate(("p1", "m1", "p2", "m2")):
-                act[side + tag] = self._lin_relu(H[:, 256 * j:256 * (j + 1)], *second[j])
+        for side, pfs in (("Xc", pf_inp), ("Yo", pf_tmp)):
+            act.update(self._disengage_buffers(side, pfs.shape[0], dev))
+            self._disengage(f, side, pfs, act)
+        return self._dense_tail(f, act, b, dev)
+
+    def _dense_tail(self, f, act, b, dev):
+        """everything behind the disengage stacks (needs the whole batch: the attention launches want >= 256 workgroups)"""
         nN, nM = b * self.n_inp, b * self.n_tmp
         fuse1 = torch.empty((nN, 512), dtype=torch.float32, device=dev)      # cat[F_Xc_p1, F_Xo_p]
         conf_in1 = torch.empty((nN, 128), dtype=torch.float32, device=dev)   # cat[F_Xc_m1, F_Xo_m]

@@ -210,7 +210,9 @@ def _ptr_array(tensors):
 class BackboneRun(object):
     """State of one backbone pass driven by the native runner (csrc/backbone.hip)."""
 
-    def __init__(self, occ, batch, S):
+    def __init__(self, occ, batch, S, batch_lo=0):
+        """occ (V0,4) i32 [b,x,y,z]; batch_lo > 0 (or batch < number of crops in occ): pass over the crop window
+        batch_lo .. batch_lo+batch-1 only (its crops are re-based to 0)."""
         N.need_cuda(occ)
         assert occ.dtype == torch.int32 and occ.is_contiguous()
         self.occ, self.batch, self.S, self.V0 = occ, int(batch), int(S), occ.shape[0]
@@ -219,8 +221,9 @@ class BackboneRun(object):
         self.ws = torch.empty(nbytes.value, dtype=torch.uint8, device=occ.device)
         self.counts_dev = torch.empty(8, dtype=torch.int32, device=occ.device)
         self.chan = (C.c_int32 * 9)(*BACKBONE_CHANNELS)
-        N.check(N.lib().dcl_backbone_geometry(N.ptr(occ), self.V0, self.batch, self.S, N.ptr(self.ws), nbytes.value,
-                                              N.ptr(self.counts_dev), N.stream()), "backbone_geometry")
+        N.check(N.lib().dcl_backbone_geometry_window(N.ptr(occ), self.V0, int(batch_lo), self.batch, self.S, N.ptr(self.ws),
+                                                     nbytes.value, N.ptr(self.counts_dev), N.stream()),
+                "backbone_geometry")
         self.counts = None
         self.levels = None
 

@@ -157,6 +157,11 @@ int dcl_sparse_avgpool_fwd(const float *feat, const int32_t *nbr, int cap, const
 int dcl_backbone_ws_bytes(int batch, int S, int V0, int64_t *bytes_host);
 int dcl_backbone_geometry(const int32_t *occ, int V0, int batch, int S, void *ws, int64_t ws_bytes,
                           int32_t *counts_dev /* i32[8] */, dclStream_t stream);
+/* Same over a batch window: only the voxels of crops batch_lo .. batch_lo+batch-1 of `occ` (all V0 rows are scanned)
+ * enter the pass, re-based to crop 0.  Sub-batch passes can then share one occupied-voxel / voxel-feature array, which is
+ * how Network.forward pipelines the sparse half of chunk c+1 under the dense half of chunk c.  ws sized for (batch, S, V0). */
+int dcl_backbone_geometry_window(const int32_t *occ, int V0, int batch_lo, int batch, int S, void *ws, int64_t ws_bytes,
+                                 int32_t *counts_dev, dclStream_t stream);
 int dcl_backbone_ws2_bytes(const int32_t *counts_host, const int32_t *channels_host, int64_t *bytes_host);
 /* weights_host[8]/scales_host[8]/shifts_host[8]: HOST arrays of device pointers ((27,Cin,Cout) / (Cout));
  * level_out_host[4]: HOST array of device pointers, level m = (counts[2m+1], channels[2m+2]) floats.            */
