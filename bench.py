@@ -128,6 +128,26 @@ def primitives_roofline(dcl, reps=5):
     b.record()
     torch.cuda.synchronize()
     out["fps_ms"] = round(a.elapsed_time(b) / 3, 3)
+    # the remaining pointnet_lib primitives of SURVEY 8a row a17 (feature propagation direction: N unknown <- np known)
+    d2, nn_idx = dcl.ops.three_nn(xyz, new_xyz)
+    w = 1.0 / (d2.sqrt() + 1e-8)
+    w = (w / w.sum(2, keepdim=True)).contiguous()
+    kfeats = torch.randn(B, C, NP, device="cuda")
+    for name, fn, nbytes in (
+            ("gather_points", lambda: dcl.ops.gather_points(feats, fps), 4 * B * C * N + 4 * B * NP + 4 * B * C * NP),
+            ("three_nn", lambda: dcl.ops.three_nn(xyz, new_xyz), 12 * B * (N + NP) + 24 * B * N),
+            ("three_interpolate", lambda: dcl.ops.three_interpolate(kfeats, nn_idx, w), 4 * B * C * NP + 24 * B * N + 4 * B * C * N),
+            ("knn16", lambda: dcl.ops.knn(16, new_xyz, xyz), 12 * B * (N + NP) + 8 * B * NP * 16)):
+        fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / reps
+        out[name] = {"ms": round(ms, 4), "GBps": round(nbytes / ms / 1e6, 1), "bytes": nbytes}
     return out
 
 

@@ -28,6 +28,7 @@ import torch.nn as nn
 from .. import ops
 from .. import spconv
 from ..libs.pointgroup_ops.functions import pointgroup_ops
+from .losses import losses  # noqa: F401  (reference: models/DCL_Net.py::losses)
 from .Modules import (Aligner, Backbone_SPCONV, BasicBlock_3DCONV, Head_MultiLayerPerceptron,
                       Ops_GetPointFeat_spconv)
 

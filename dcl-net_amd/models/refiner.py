@@ -11,6 +11,7 @@ import torch.nn as nn
 
 from .. import ops
 from .Modules import Head_MultiLayerPerceptron
+from .losses import losses_refiner  # noqa: F401  (reference: models/refiner.py::losses_refiner)
 
 
 def ortho9d2matrix(x_raw, y_raw, z_raw):

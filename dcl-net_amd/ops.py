@@ -411,6 +411,11 @@ def knn(k, unknown, known):
     assert unknown.is_contiguous() and known.is_contiguous()
     B, n, _ = unknown.shape
     m = known.shape[1]
+    if k <= 3:
+        # the sorted strict-'<' list of length k is the first k entries of the 3-NN cascade (same tie rule, same
+        # defaults for missing neighbours): use the tiled three_nn kernel (DCL-Net only calls knn with k = 1)
+        d2, idx = three_nn(unknown, known)
+        return d2[:, :, :k].contiguous(), idx[:, :, :k].contiguous()
     dist2 = torch.empty((B, n, k), dtype=torch.float32, device=unknown.device)
     idx = torch.empty((B, n, k), dtype=torch.int32, device=unknown.device)
     N.check(N.lib().dcl_knn(B, n, m, int(k), N.ptr(unknown), N.ptr(known), N.ptr(dist2), N.ptr(idx), N.stream()), "knn")

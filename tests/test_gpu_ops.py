@@ -278,10 +278,13 @@ def test_fps_lattice_ties(dcl, oracle):
 def test_knn_three_nn_three_interpolate_batched(dcl, oracle):
     rng = np.random.default_rng(9)
     unk, kn = _cloud(rng, 2, 150), _cloud(rng, 2, 260)
-    for k in (1, 5, 200):
+    for k in (1, 2, 3, 5, 200):                                # k <= 3 runs on the tiled three_nn kernel
         wd, wi = oracle.knn(k, unk, kn)
         d2, idx = dcl.ops.knn(k, cuda(unk), cuda(kn))
         assert np.array_equal(idx.cpu().numpy(), wi) and np.array_equal(d2.cpu().numpy(), wd)
+    wd, wi = oracle.knn(3, unk, kn[:, :2].copy())                # fewer known points than k: (inf, 0) fillers
+    d2, idx = dcl.ops.knn(3, cuda(unk), cuda(kn[:, :2].copy()))
+    assert np.array_equal(idx.cpu().numpy(), wi) and np.array_equal(d2.cpu().numpy(), wd)
     wd, wi = oracle.three_nn(unk, kn)
     d2, idx = dcl.ops.three_nn(cuda(unk), cuda(kn))
     assert np.array_equal(idx.cpu().numpy(), wi) and np.array_equal(d2.cpu().numpy(), wd)
