@@ -95,17 +95,30 @@ class Network(nn.Module):
         self._folded = None
 
     # ------------------------------------------------------------------ parameter folding (eval mode)
-    def train(self, mode=True):
+    def _invalidate(self):
+        """folded weights and captured graphs (which have the folded tensors' addresses baked in) follow the parameters"""
         self._folded = None
+        self.__dict__.pop("_graphs", None)
+
+    def train(self, mode=True):
+        self._invalidate()
         return super().train(mode)
 
     def _apply(self, fn, *a, **k):
-        self._folded = None
+        self._invalidate()
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
-        self._folded = None
+        self._invalidate()
         return super().load_state_dict(*a, **k)
+
+    def __getstate__(self):
+        """copy.deepcopy / pickling: streams, graphs and folded tensors are per-instance runtime state"""
+        state = dict(self.__dict__)
+        for k in ("_side", "_graphs"):
+            state.pop(k, None)
+        state["_folded"] = None
+        return state
 
     @staticmethod
     def _bn_affine(bn):

@@ -28,13 +28,28 @@ class Refiner(nn.Module):
                                                           [0.0] * 3)
         self._folded = None
 
-    def _apply(self, fn, *a, **k):
+    def _invalidate(self):
+        """folded weights and captured refine-loop graphs (folded tensors' addresses baked in) follow the parameters"""
         self._folded = None
+        self.__dict__.pop("_graphs", None)
+
+    def train(self, mode=True):
+        self._invalidate()
+        return super().train(mode)
+
+    def _apply(self, fn, *a, **k):
+        self._invalidate()
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
-        self._folded = None
+        self._invalidate()
         return super().load_state_dict(*a, **k)
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop("_graphs", None)
+        state["_folded"] = None
+        return state
 
     def _fold(self):
         if self._folded is None:

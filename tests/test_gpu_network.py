@@ -173,6 +173,25 @@ def test_whole_forward_hipgraph_matches_eager(dcl):
         assert float((got["trans_pred"] - wants[first]["trans_pred"]).abs().max()) <= T_TOL
 
 
+def test_graph_cache_follows_the_weights(dcl):
+    """a captured forward must not outlive the weights it was captured with; the model stays deep-copyable"""
+    import copy
+    b, n = 2, 256
+    net, _, _ = _net(dcl, n, n, 1)
+    data = dcl.synth.make_batch(b, n, n)
+    first = net.forward_graphed(data)
+    net.load_state_dict(dcl.synth.synth_state_dict(net, 2))                 # new weights -> graphs and folds dropped
+    with torch.no_grad():
+        want = net(dcl.synth.make_batch(b, n, n))
+    got = net.forward_graphed(dcl.synth.make_batch(b, n, n))
+    assert float((got["rot_pred"] - want["rot_pred"]).abs().max()) <= R_TOL
+    assert float((got["rot_pred"] - first["rot_pred"]).abs().max()) > 1e-3   # really different weights
+    twin = copy.deepcopy(net)
+    with torch.no_grad():
+        again = twin(dcl.synth.make_batch(b, n, n))
+    assert float((again["rot_pred"] - want["rot_pred"]).abs().max()) <= 1e-6
+
+
 def test_ops_refuse_cpu_tensors(dcl):
     with pytest.raises(RuntimeError):
         dcl.ops.voxelize_fp(torch.zeros(4, 7), torch.zeros(2, 3, dtype=torch.int32))
