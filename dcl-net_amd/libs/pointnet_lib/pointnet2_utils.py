@@ -38,3 +38,62 @@ def grouping_operation(features, idx):
 def ball_query(radius, nsample, xyz, new_xyz):
     """xyz (B,N,3), new_xyz (B,npoint,3) -> idx (B,npoint,nsample) int32."""
     return _ops.ball_query(radius, nsample, xyz.contiguous(), new_xyz.contiguous())
+
+
+# ---- grouping modules (libs/pointnet_lib/pointnet2_utils.py:274-386); forward passes only, like the ops above
+class QueryAndGroup(torch.nn.Module):
+    """Ball query around `new_xyz`, then the neighbours' centre-relative coordinates and/or features:
+    (B, 3 + C, npoint, nsample) with use_xyz, features first then xyz -- the reference's channel order (:292-307)."""
+
+    def __init__(self, radius, nsample, use_xyz=True):
+        super().__init__()
+        self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
+
+    def forward(self, xyz, new_xyz, features=None):
+        idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
+        grouped_xyz = grouping_operation(xyz.transpose(1, 2).contiguous(), idx)            # (B,3,npoint,nsample)
+        grouped_xyz -= new_xyz.transpose(1, 2).unsqueeze(-1)
+        if features is None:
+            assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
+            return grouped_xyz
+        grouped_features = grouping_operation(features, idx)
+        return torch.cat([grouped_features, grouped_xyz], dim=1) if self.use_xyz else grouped_features
+
+
+class GroupAll(torch.nn.Module):
+    """One group holding every point: (B, 3 + C, 1, N), xyz first (:310-333)."""
+
+    def __init__(self, use_xyz=True):
+        super().__init__()
+        self.use_xyz = use_xyz
+
+    def forward(self, xyz, new_xyz, features=None):
+        grouped_xyz = xyz.transpose(1, 2).unsqueeze(2)
+        if features is None:
+            return grouped_xyz
+        grouped_features = features.unsqueeze(2)
+        return torch.cat([grouped_xyz, grouped_features], dim=1) if self.use_xyz else grouped_features
+
+
+class KNNAndGroup(torch.nn.Module):
+    """k-nearest-neighbour grouping (:335-386): xyz first, then features.  The reference builds `idx` with
+    `knn(xyz, new_xyz, radius, nsample)`, which does not match its own `knn(k, unknown, known)`; here a missing `idx` is
+    the `nsample` nearest points of `xyz` around every `new_xyz` centre."""
+
+    def __init__(self, radius, nsample, use_xyz=True):
+        super().__init__()
+        self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
+
+    def forward(self, xyz, new_xyz=None, idx=None, features=None):
+        if new_xyz is None:
+            new_xyz = xyz
+        if idx is None:
+            _, idx = knn(self.nsample, new_xyz, xyz)
+        idx = idx.detach()
+        grouped_xyz = grouping_operation(xyz.transpose(1, 2).contiguous(), idx)
+        grouped_xyz -= new_xyz.transpose(1, 2).unsqueeze(-1)
+        if features is None:
+            assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
+            return grouped_xyz
+        grouped_features = grouping_operation(features, idx)
+        return torch.cat([grouped_xyz, grouped_features], dim=1) if self.use_xyz else grouped_features

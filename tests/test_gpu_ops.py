@@ -256,6 +256,29 @@ def test_group_and_gather_bit_exact(dcl, oracle):
     assert np.array_equal(dcl.ops.gather_points(cuda(feats), cuda(gi)).cpu().numpy(), oracle.gather_points(feats, gi))
 
 
+def test_grouping_modules_match_the_composed_oracle(dcl, oracle):
+    """QueryAndGroup / GroupAll / KNNAndGroup of the pointnet_lib mirror (forward composition of the primitives)"""
+    import importlib
+    pu = importlib.import_module("dcl-net_amd.libs.pointnet_lib.pointnet2_utils")
+    rng = np.random.default_rng(21)
+    B, N, NP, C, ns, r = 2, 900, 64, 12, 16, 0.06
+    xyz = _cloud(rng, B, N)
+    new = xyz[:, rng.choice(N, NP, replace=False)].copy()
+    feats = rng.normal(size=(B, C, N)).astype(np.float32)
+    idx = oracle.ball_query(r, ns, xyz, new)
+    gx = oracle.group_points(np.ascontiguousarray(xyz.transpose(0, 2, 1)), idx) - new.transpose(0, 2, 1)[..., None]
+    want = np.concatenate([oracle.group_points(feats, idx), gx], 1)
+    got = pu.QueryAndGroup(r, ns)(cuda(xyz), cuda(new), cuda(feats)).cpu().numpy()
+    assert np.array_equal(got, want)
+    assert np.array_equal(pu.QueryAndGroup(r, ns)(cuda(xyz), cuda(new)).cpu().numpy(), gx)
+    ga = pu.GroupAll()(cuda(xyz), None, cuda(feats)).cpu().numpy()
+    assert ga.shape == (B, 3 + C, 1, N) and np.array_equal(ga[:, :3, 0], xyz.transpose(0, 2, 1)) and np.array_equal(ga[:, 3:, 0], feats)
+    _, kidx = oracle.knn(ns, new, xyz)
+    kx = oracle.group_points(np.ascontiguousarray(xyz.transpose(0, 2, 1)), kidx) - new.transpose(0, 2, 1)[..., None]
+    wantk = np.concatenate([kx, oracle.group_points(feats, kidx)], 1)
+    assert np.array_equal(pu.KNNAndGroup(r, ns)(cuda(xyz), cuda(new), None, cuda(feats)).cpu().numpy(), wantk)
+
+
 @pytest.mark.parametrize("n,m", [(1024, 128), (12288, 64), (777, 100), (100, 20), (40, 10), (2048, 33)])
 def test_fps_bit_exact_with_ties(dcl, oracle, n, m):
     rng = np.random.default_rng(n)
