@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void k_ball_query(int n, int m, float radius2,
 // loads) and streams the whole (npoints*nsample) index list against them: indices are read once per CC channels,
 // every output leaves as a 16-B store, and the random reads hit LDS instead of the vector-memory path.
 template <int CC, bool NT>
-__global__ __launch_bounds__(1024) void k_group_points_lds(int c, int n, int nps, const float *__restrict__ points,
+__global__ __launch_bounds__(1024) void k_group_points_lds(int c, int n, int nps, int oc, const float *__restrict__ points,
                                                           const int32_t *__restrict__ idx, float *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float gp_lds[];            // [CC][n]
   const int bs = blockIdx.z;
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(1024) void k_group_points_lds(int c, int n, int nps
   __syncthreads();
   const int nq = nps >> 2;
   const int4 *I = reinterpret_cast<const int4 *>(idx + (size_t)bs * nps);
-  float *O = out + ((size_t)bs * c + c0) * nps;
+  float *O = out + ((size_t)bs * oc + c0) * nps;          // oc = channels per batch entry of the output tensor (>= c)
 #pragma unroll 2
   for (int q = blockIdx.x * nthr + threadIdx.x; q < nq; q += gridDim.x * nthr) {
     const int4 id = I[q];
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(1024) void k_group_points_lds(int c, int n, int nps
 
 // direct-gather variant (rows too long for LDS, or npoints*nsample not a multiple of 4)
 template <int CCHUNK>
-__global__ void k_group_points(int c, int n, int nps /* npoints*nsample */, const float *__restrict__ points,
+__global__ void k_group_points(int c, int n, int nps /* npoints*nsample */, int oc, const float *__restrict__ points,
                                const int32_t *__restrict__ idx, float *__restrict__ out) {
   const int bs = blockIdx.z;
   const int c0 = blockIdx.y * CCHUNK;
@@ -183,7 +183,7 @@ __global__ void k_group_points(int c, int n, int nps /* npoints*nsample */, cons
   if (q * 4 >= nps) return;
   const int4 id = reinterpret_cast<const int4 *>(idx + (size_t)bs * nps)[q];
   const float *P = points + ((size_t)bs * c + c0) * n;
-  float *O = out + ((size_t)bs * c + c0) * nps;
+  float *O = out + ((size_t)bs * oc + c0) * nps;
 #pragma unroll
   for (int j = 0; j < CCHUNK; ++j) {
     if (c0 + j >= c) break;
@@ -194,12 +194,12 @@ __global__ void k_group_points(int c, int n, int nps /* npoints*nsample */, cons
   }
 }
 
-__global__ void k_group_points_scalar(int c, int n, int nps, const float *__restrict__ points,
+__global__ void k_group_points_scalar(int c, int n, int nps, int oc, const float *__restrict__ points,
                                       const int32_t *__restrict__ idx, float *__restrict__ out) {
   const int bs = blockIdx.z, ch = blockIdx.y;
   const float *P = points + ((size_t)bs * c + ch) * n;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nps; e += gridDim.x * blockDim.x)
-    out[((size_t)bs * c + ch) * nps + e] = P[idx[(size_t)bs * nps + e]];
+    out[((size_t)bs * oc + ch) * nps + e] = P[idx[(size_t)bs * nps + e]];
 }
 
 // ------------------------------------------------------------------------------------------ FPS
@@ -395,7 +395,12 @@ DCL_API void dcl_debug_group_points_cfg(int cc, int xb, int threads, int nontemp
 
 DCL_API int dcl_group_points(int b, int c, int n, int npoints, int nsample, const float *points, const int32_t *idx,
                              float *out, dclStream_t stream) {
-  DCL_CHECK_ARG(b >= 0 && c >= 0 && n >= 0 && npoints >= 0 && nsample >= 0);
+  return dcl_group_points_into(b, c, n, npoints, nsample, points, idx, out, c, stream);
+}
+
+DCL_API int dcl_group_points_into(int b, int c, int n, int npoints, int nsample, const float *points, const int32_t *idx,
+                                  float *out, int oc, dclStream_t stream) {
+  DCL_CHECK_ARG(b >= 0 && c >= 0 && n >= 0 && npoints >= 0 && nsample >= 0 && oc >= c);
   const long long nps = (long long)npoints * nsample;
   if (b == 0 || c == 0 || nps == 0) return 0;
   DCL_CHECK_ARG(points && idx && out && b <= 65535 && c <= 65535 && nps < (1ll << 31));
@@ -420,7 +425,7 @@ DCL_API int dcl_group_points(int b, int c, int n, int npoints, int nsample, cons
   do {                                                                                                         \
     (void)hipFuncSetAttribute((const void *)k_group_points_lds<CCU, NTB>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               (int)lds);                                                                       \
-    hipLaunchKernelGGL((k_group_points_lds<CCU, NTB>), dim3(xb, ychunks, b), dim3(threads), lds, s, c, n, (int)nps, points, \
+    hipLaunchKernelGGL((k_group_points_lds<CCU, NTB>), dim3(xb, ychunks, b), dim3(threads), lds, s, c, n, (int)nps, oc, points, \
                        idx, out);                                                                              \
   } while (0)
 #define GPL2(CCU) do { if (nt) GPL(CCU, true); else GPL(CCU, false); } while (0)
@@ -430,10 +435,10 @@ DCL_API int dcl_group_points(int b, int c, int n, int npoints, int nsample, cons
   } else if (nps % 4 == 0) {
     constexpr int CC = 8;
     hipLaunchKernelGGL((k_group_points<CC>), dim3(dcl_div_up(nps / 4, 256), dcl_div_up(c, CC), b), dim3(256), 0, s, c,
-                       n, (int)nps, points, idx, out);
+                       n, (int)nps, oc, points, idx, out);
   } else {
     hipLaunchKernelGGL(k_group_points_scalar, dim3(dcl_grid_1d(nps, 256, 1024), c, b), dim3(256), 0, s, c, n, (int)nps,
-                       points, idx, out);
+                       oc, points, idx, out);
   }
   DCL_LAUNCH_CHECK();
   return 0;

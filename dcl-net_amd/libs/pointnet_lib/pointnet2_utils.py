@@ -51,13 +51,20 @@ class QueryAndGroup(torch.nn.Module):
 
     def forward(self, xyz, new_xyz, features=None):
         idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
-        grouped_xyz = grouping_operation(xyz.transpose(1, 2).contiguous(), idx)            # (B,3,npoint,nsample)
-        grouped_xyz -= new_xyz.transpose(1, 2).unsqueeze(-1)
         if features is None:
             assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
-            return grouped_xyz
-        grouped_features = grouping_operation(features, idx)
-        return torch.cat([grouped_features, grouped_xyz], dim=1) if self.use_xyz else grouped_features
+        if features is not None and not self.use_xyz:
+            return grouping_operation(features, idx)
+        # both blocks are gathered straight into the result (no torch.cat copy of the (B,C+3,npoint,nsample) tensor)
+        B, npoint, ns = idx.shape
+        c = 0 if features is None else features.shape[1]
+        out = torch.empty((B, c + 3, npoint, ns), dtype=torch.float32, device=xyz.device)
+        if c:
+            _ops.group_points(features.contiguous(), idx, out=out[:, :c])
+        gx = out[:, c:]
+        _ops.group_points(xyz.transpose(1, 2).contiguous(), idx, out=gx)
+        gx -= new_xyz.transpose(1, 2).unsqueeze(-1)
+        return out
 
 
 class GroupAll(torch.nn.Module):

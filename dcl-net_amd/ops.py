@@ -374,14 +374,20 @@ def ball_query(radius, nsample, xyz, new_xyz):
     return idx
 
 
-def group_points(features, idx):
-    N.need_cuda(features, idx)
+def group_points(features, idx, out=None):
+    """out (optional): a channel block out_full[:, c0:c0+c] of a contiguous (B, C_total, npoint, nsample) tensor, filled
+    in place (no concatenation copy afterwards)."""
+    N.need_cuda(features, idx, out)
     assert features.is_contiguous() and idx.is_contiguous() and idx.dtype == torch.int32
     B, c, n = features.shape
     _, npoint, ns = idx.shape
-    out = torch.empty((B, c, npoint, ns), dtype=torch.float32, device=features.device)
-    N.check(N.lib().dcl_group_points(B, c, n, npoint, ns, N.ptr(features), N.ptr(idx), N.ptr(out), N.stream()),
-            "group_points")
+    if out is None:
+        out = torch.empty((B, c, npoint, ns), dtype=torch.float32, device=features.device)
+    assert out.shape == (B, c, npoint, ns) and out.stride(3) == 1 and out.stride(2) == ns and out.stride(1) == npoint * ns
+    oc = out.stride(0) // (npoint * ns) if B > 1 else c
+    assert B == 1 or out.stride(0) == oc * npoint * ns
+    N.check(N.lib().dcl_group_points_into(B, c, n, npoint, ns, N.ptr(features), N.ptr(idx), N.ptr(out), int(oc),
+                                          N.stream()), "group_points")
     return out
 
 

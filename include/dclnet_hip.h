@@ -228,6 +228,10 @@ int dcl_ball_query(int b, int n, int m, float radius, int nsample, const float *
                    const float *xyz, int32_t *idx, dclStream_t stream);       /* idx fully written */
 int dcl_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
                      const int32_t *idx, float *out, dclStream_t stream);
+/* Same, writing channel block [0,c) of an output whose batch entries hold out_batch_channels >= c channels (pass `out`
+ * already offset to the first channel to fill): lets QueryAndGroup fill its (B, C+3, npoint, nsample) result in place. */
+int dcl_group_points_into(int b, int c, int n, int npoints, int nsample, const float *points, const int32_t *idx,
+                          float *out, int out_batch_channels, dclStream_t stream);
 int dcl_gather_points(int b, int c, int n, int npoints, const float *points, const int32_t *idx,
                       float *out, dclStream_t stream);
 /* temp (B,N) must be pre-filled with 1e10 (pointnet2_utils.py:27); updated in place. */
