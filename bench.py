@@ -200,7 +200,7 @@ def refiner_bench(dcl, dev, b, iters=2, reps=20):
     return out
 
 
-def cpu_baseline(dcl, sd, cfg, n_inp, n_tmp, crops=2):
+def cpu_baseline(dcl, sd, cfg, n_inp, n_tmp, crops=1):
     """the CPU oracle (kind 'port': the reference has no runnable CPU path) on a bounded sample of
     the same workload, host cores of this box."""
     from oracle import graph as G
