@@ -320,6 +320,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES >= 8 ? 2 : 1) void k_cross_attn_s
 //   A (__syncthreads: drains this wave's DMA + K write)  ->  issue DMA V(t+1)  ->  S = K Q^T, softmax
 //   B (raw s_barrier, lgkmcnt only: K tile free)         ->  load K(t+1)       ->  O += V^T P  ->  write K(t+1)
 typedef __attribute__((address_space(3))) void lds_void_t;
+constexpr int kAttnPartPitch = 324;                // floats per (key split, query) partial record: 320 channels, m, l, pad
 
 // One LDS-DMA wave-instruction: 64 lanes x 16 B from per-lane global addresses to LDS at (wave-uniform) lds_byte_addr +
 // lane*16.  Inline asm on purpose: issued through the builtin, hipcc drains it (vmcnt(0)) before the next ds_read of the
@@ -340,7 +341,7 @@ template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_cross_attn_dma(
     int nq, int nk, const float *__restrict__ Q, int ldq, const float *__restrict__ K, int ldk,
     const float *__restrict__ V1, int ldv1, float *__restrict__ O1, int ldo1,
-    const float *__restrict__ V2, int ldv2, float *__restrict__ O2, int ldo2) {
+    const float *__restrict__ V2, int ldv2, float *__restrict__ O2, int ldo2, float *__restrict__ part) {
   constexpr int NVT = 10;
   constexpr int KT = 32 * kKPitch;                 // K tile floats
   constexpr int V1T = 32 * 256, V2T = 32 * 64;     // per-buffer floats
@@ -411,12 +412,17 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_cross_attn_dma(
     for (int e = 0; e < 16; ++e) O[t][e] = 0.0f;
   float m_ref = -INFINITY, l_part = 0.0f;
 
-  load_k(0);
+  // key split (gridDim.z > 1): this workgroup owns a contiguous range of 32-key tiles and leaves unnormalised partial
+  // sums + (running max, weight sum) per query for k_cross_attn_combine -- fills the GPU when b * nq/128 alone cannot
+  const int ntiles = (nk + 31) >> 5;
+  const int kb_begin = (int)((long long)blockIdx.z * ntiles / gridDim.z) * 32;
+  const int kb_end = min((int)((long long)(blockIdx.z + 1) * ntiles / gridDim.z) * 32, nk);
+  load_k(kb_begin);
   store_k();
-  dma_v(0, 0);
+  dma_v(kb_begin, 0);
   int cur = 0;
-  for (int kb = 0; kb < nk; kb += 32) {
-    const bool more = kb + 32 < nk;
+  for (int kb = kb_begin; kb < kb_end; kb += 32) {
+    const bool more = kb + 32 < kb_end;
     __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): this wave's DMA pieces of tile t have landed (a
                                                            // builtin, so hipcc's own counters see the drain too)
     __syncthreads();                                       // A
@@ -482,7 +488,18 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_cross_attn_dma(
 
   asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
   const float l_tot = l_part + __shfl_xor(l_part, 32, 64);
-  if (qlive) {
+  if (qlive && gridDim.z > 1) {
+    // partial record of this key range: [320 unnormalised channels | m | l] per (split, query)
+    const size_t rows = (size_t)gridDim.y * nq;
+    float *P = part + ((size_t)blockIdx.z * rows + (size_t)b * nq + q) * kAttnPartPitch;
+#pragma unroll
+    for (int t = 0; t < NVT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4 *>(P + t * 32 + 8 * g + 4 * h) =
+            make_float4(O[t][4 * g], O[t][4 * g + 1], O[t][4 * g + 2], O[t][4 * g + 3]);
+    if (h == 0) { P[320] = m_ref; P[321] = l_tot; }
+  } else if (qlive) {
     const size_t row = (size_t)b * nq + q;
 #pragma unroll
     for (int t = 0; t < NVT; ++t)
@@ -495,6 +512,30 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_cross_attn_dma(
         if (c < 256) *reinterpret_cast<float4 *>(O1 + row * ldo1 + c) = v;
         else *reinterpret_cast<float4 *>(O2 + row * ldo2 + (c - 256)) = v;
       }
+  }
+}
+
+// out[row][c] = sum_z e^{m_z - m} O_z[c] / sum_z e^{m_z - m} l_z, m = max_z m_z (splits in index order); thread = 4 channels
+__global__ void k_cross_attn_combine(int rows, int nsplit, const float *__restrict__ part, float *__restrict__ O1, int ldo1,
+                                     float *__restrict__ O2, int ldo2) {
+  const long long total = (long long)rows * 80;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    const size_t row = (size_t)(t / 80);
+    const int c = (int)(t - (long long)row * 80) * 4;
+    float m = -INFINITY;
+    for (int z = 0; z < nsplit; ++z) m = fmaxf(m, part[((size_t)z * rows + row) * kAttnPartPitch + 320]);
+    float4 num = make_float4(0.f, 0.f, 0.f, 0.f);
+    float den = 0.0f;
+    for (int z = 0; z < nsplit; ++z) {
+      const float *P = part + ((size_t)z * rows + row) * kAttnPartPitch;
+      const float f = __expf(P[320] - m);
+      const float4 o = *reinterpret_cast<const float4 *>(P + c);
+      num.x += f * o.x; num.y += f * o.y; num.z += f * o.z; num.w += f * o.w;
+      den += f * P[321];
+    }
+    const float4 v = make_float4(num.x / den, num.y / den, num.z / den, num.w / den);
+    if (c < 256) *reinterpret_cast<float4 *>(O1 + row * ldo1 + c) = v;
+    else *reinterpret_cast<float4 *>(O2 + row * ldo2 + (c - 256)) = v;
   }
 }
 
@@ -663,11 +704,27 @@ __global__ void k_ortho9d(int b, const float *__restrict__ o9, float *__restrict
 }  // namespace
 
 static int g_attn_variant = 0;   // test hook: 1 = shared-tile 8-wave kernel, 2 = 4-wave register-staged, 3 / 4 = LDS-DMA pipeline with 8 / 4 waves
+static int g_attn_split = 0;            // tuning hook: 0 = automatic key split of small attention launches, n = force n
+DCL_API void dcl_debug_attention_split(int n) { g_attn_split = n; }
 DCL_API void dcl_debug_attention_variant(int v) { g_attn_variant = v; }
 
 DCL_API int dcl_cross_attention(int b, int nq, int nk, const float *Q, int ldq, const float *K, int ldk,
                                 const float *V1, int dv1, int ldv1, float *O1, int ldo1, const float *V2, int dv2,
                                 int ldv2, float *O2, int ldo2, dclStream_t stream) {
+  return dcl_cross_attention_ws(b, nq, nk, Q, ldq, K, ldk, V1, dv1, ldv1, O1, ldo1, V2, dv2, ldv2, O2, ldo2, nullptr, 0,
+                                stream);
+}
+
+DCL_API int dcl_cross_attention_scratch_floats(int b, int nq, int64_t *floats_host) {
+  DCL_CHECK_ARG(b >= 0 && nq >= 0 && floats_host);
+  *floats_host = (int64_t)8 * b * nq * kAttnPartPitch;
+  return 0;
+}
+
+DCL_API int dcl_cross_attention_ws(int b, int nq, int nk, const float *Q, int ldq, const float *K, int ldk,
+                                   const float *V1, int dv1, int ldv1, float *O1, int ldo1, const float *V2, int dv2,
+                                   int ldv2, float *O2, int ldo2, float *scratch, int64_t scratch_floats,
+                                   dclStream_t stream) {
   DCL_CHECK_ARG(b >= 0 && nq >= 0 && nk > 0 && dv1 > 0 && dv1 % 32 == 0 && dv2 >= 0 && dv2 % 32 == 0);
   if (b == 0 || nq == 0) return 0;
   DCL_CHECK_ARG(Q && K && V1 && O1 && (dv2 == 0 || (V2 && O2)) && b <= 65535);
@@ -688,11 +745,25 @@ DCL_API int dcl_cross_attention(int b, int nq, int nk, const float *Q, int ldq, 
     if (w8) {
       (void)hipFuncSetAttribute((const void *)k_cross_attn_dma<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(k_cross_attn_dma<8>, dim3(dcl_div_up(nq, 256), b), dim3(512), lds, s, nq, nk, Q, ldq, K, ldk, V1,
-                         ldv1, O1, ldo1, V2, ldv2, O2, ldo2);
+                         ldv1, O1, ldo1, V2, ldv2, O2, ldo2, (float *)nullptr);
     } else {
+      // few workgroups (small batches): split the keys over up to 8 workgroups per query block, >= 2 tiles per split
+      const long long blocks4 = (long long)b * dcl_div_up(nq, 128);
+      int nsplit = 1;
+      if (scratch && blocks4 < 192) {
+        nsplit = g_attn_split > 0 ? g_attn_split : (int)dcl_div_up(256, blocks4);
+        const int ntiles = dcl_div_up(nk, 32);
+        if (nsplit > 8) nsplit = 8;
+        if (nsplit > ntiles / 2) nsplit = ntiles / 2;
+        while (nsplit > 1 && (long long)nsplit * b * nq * kAttnPartPitch > scratch_floats) --nsplit;
+        if (nsplit < 1) nsplit = 1;
+      }
       (void)hipFuncSetAttribute((const void *)k_cross_attn_dma<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(k_cross_attn_dma<4>, dim3(dcl_div_up(nq, 128), b), dim3(256), lds, s, nq, nk, Q, ldq, K, ldk, V1,
-                         ldv1, O1, ldo1, V2, ldv2, O2, ldo2);
+      hipLaunchKernelGGL(k_cross_attn_dma<4>, dim3(dcl_div_up(nq, 128), b, nsplit), dim3(256), lds, s, nq, nk, Q, ldq, K,
+                         ldk, V1, ldv1, O1, ldo1, V2, ldv2, O2, ldo2, scratch);
+      if (nsplit > 1)
+        hipLaunchKernelGGL(k_cross_attn_combine, dim3(dcl_grid_1d((long long)b * nq * 80, 256)), dim3(256), 0, s, b * nq,
+                           nsplit, scratch, O1, ldo1, O2, ldo2);
     }
   } else if ((blocks8 >= 256 && g_attn_variant != 2) || g_attn_variant == 1) {
     const size_t lds = (size_t)(32 * kKPitch + 32 * nvt * 32 + 8 * 32 * kKPitch) * sizeof(float);

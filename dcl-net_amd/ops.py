@@ -470,9 +470,14 @@ def cross_attention(b, Q, K, V1, O1, V2=None, O2=None):
     if PROFILE_EVENTS is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-    N.check(N.lib().dcl_cross_attention(b, nq, nk, N.ptr(Q), _ld(Q), N.ptr(K), _ld(K), N.ptr(V1), dv1, _ld(V1),
-                                        N.ptr(O1), _ld(O1), N.ptr(V2), dv2, 0 if V2 is None else _ld(V2), N.ptr(O2),
-                                        0 if O2 is None else _ld(O2), N.stream()), "cross_attention")
+    scratch = None
+    if b * ((nq + 127) // 128) < 192 and dv1 == 256 and dv2 == 64:          # small launch: key-split partial records
+        scratch = torch.empty(8 * b * nq * 324, dtype=torch.float32, device=Q.device)
+    N.check(N.lib().dcl_cross_attention_ws(b, nq, nk, N.ptr(Q), _ld(Q), N.ptr(K), _ld(K), N.ptr(V1), dv1, _ld(V1),
+                                           N.ptr(O1), _ld(O1), N.ptr(V2), dv2, 0 if V2 is None else _ld(V2), N.ptr(O2),
+                                           0 if O2 is None else _ld(O2), N.ptr(scratch),
+                                           C.c_int64(0 if scratch is None else scratch.numel()), N.stream()),
+            "cross_attention")
     if ev is not None:
         ev[1].record()
         PROFILE_EVENTS.append(("cross_attention", ev[0], ev[1]))

@@ -258,6 +258,14 @@ int dcl_three_interpolate(int b, int c, int m, int n, const float *points, const
 int dcl_cross_attention(int b, int nq, int nk, const float *Q, int ldq, const float *K, int ldk,
                         const float *V1, int dv1, int ldv1, float *O1, int ldo1, const float *V2,
                         int dv2, int ldv2, float *O2, int ldo2, dclStream_t stream);
+/* Same with caller scratch: launches with few workgroups (small batches) split the keys over up to 8 workgroups per query
+ * block; the partial (unnormalised sums, running max, weight sum) records in `scratch` are merged by a second kernel.
+ * scratch_floats >= dcl_cross_attention_scratch_floats(b, nq) enables every split; NULL = dcl_cross_attention.         */
+int dcl_cross_attention_ws(int b, int nq, int nk, const float *Q, int ldq, const float *K, int ldk,
+                           const float *V1, int dv1, int ldv1, float *O1, int ldo1,
+                           const float *V2, int dv2, int ldv2, float *O2, int ldo2,
+                           float *scratch, int64_t scratch_floats, dclStream_t stream);
+int dcl_cross_attention_scratch_floats(int b, int nq, int64_t *floats_host);
 
 /* Confidence pooling (models/DCL_Net.py:217-228): conf = sigmoid(cat[logit1 (b,n1), logit2
  * (b,n2)]) -> conf (b,n1+n2); w = softmax(conf) -> w_scratch (b,n1+n2);
@@ -329,6 +337,8 @@ int dcl_add_s(int b, int P, const float *cld, const int32_t *cls, const float *R
 void dcl_debug_force_valu_conv(int on);
 /* Test hook: 0 = automatic choice of the attention kernel, 1 = shared-tile 8-wave variant, 2 = double-buffered 4-wave. */
 void dcl_debug_attention_variant(int v);
+/* Tuning hook: 0 = automatic key split of small attention launches (dcl_cross_attention_ws), n = force n splits. */
+void dcl_debug_attention_split(int n);
 /* Tuning hook: 0 = automatic split-K choice in dcl_sparse_conv_fwd_ws, n = force n splits (when the scratch allows). */
 void dcl_debug_conv_split(int n);
 /* Tuning hook for dcl_group_points' LDS-staged kernel: channel rows per workgroup, x-blocks, threads per workgroup,

@@ -369,6 +369,31 @@ def test_cross_attention_forced_rescale(dcl):
         assert float((O.cpu().double() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max())), variant
 
 
+def test_cross_attention_key_split(dcl):
+    """small launches split the keys over several workgroups and merge (max, sum, partial output) records: forced split
+    counts, ragged key / query counts, a score spike inside one split's range"""
+    b, nq, nk = 2, 200, 1000 + 13
+    g = torch.Generator().manual_seed(5)
+    Q = torch.randn(b, nq, 64, generator=g)
+    K = torch.randn(b, nk, 64, generator=g) * 0.3
+    K[0, 700] = Q[0, 3] * 5.0
+    K[1, 1010] = Q[1, 199] * 6.0
+    V1, V2 = torch.randn(b, nk, 256, generator=g), torch.randn(b, nk, 64, generator=g)
+    want = _attn_ref(Q, K, torch.cat([V1, V2], 2))
+    lib = dcl._native.lib()
+    try:
+        for split in (0, 1, 2, 3, 5, 8):
+            lib.dcl_debug_attention_split(split)
+            O1 = torch.empty(b * nq, 256, device="cuda")
+            O2 = torch.empty(b * nq, 64, device="cuda")
+            dcl.ops.cross_attention(b, Q.cuda().reshape(-1, 64), K.cuda().reshape(-1, 64), V1.cuda().reshape(-1, 256), O1,
+                                    V2.cuda().reshape(-1, 64), O2)
+            got = torch.cat([O1.view(b, nq, 256), O2.view(b, nq, 64)], 2).double().cpu()
+            assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max())), split
+    finally:
+        lib.dcl_debug_attention_split(0)
+
+
 def test_cross_attention_dma_variant_ragged_and_rescale(dcl):
     """the LDS-DMA pipeline (variant 3, DCL-Net's 256+64 channel split): key count not a multiple of 32, query count not
     a multiple of 256, and a forced late rescale"""
