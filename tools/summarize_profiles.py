@@ -14,7 +14,7 @@ rnd = sys.argv[1] if len(sys.argv) > 1 else "r1"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
-for shape, tag in (("stress", "stress"), ("ref", "ref"), ("prim", "primitives")):
+for shape, tag in (("stress", "stress"), ("ref", "ref"), ("prim", "primitives"), ("stream", "stream_b1_graph")):
     for f in glob.glob(os.path.join(root, "gpurun_out", "%s_%s" % (rnd, shape), "*", "*kernel_stats.csv")):
         shutil.copy(f, os.path.join(out, "%s_%s_kernel_stats.csv" % (rnd, tag)))
 rows_out = []
