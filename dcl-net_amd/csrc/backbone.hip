@@ -18,6 +18,12 @@
 int dcl_internal_grid_from_indices(const int32_t *indices, const int32_t *n_rows_dev, int n_rows, int batch_lo, int batch,
                                    int S, uint32_t *mask, int32_t *wprefix, int32_t *perm, int32_t *scratch,
                                    dclStream_t stream);
+int dcl_internal_sparse_conv_fwd(const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev,
+                                 int n_out_host, const float *W, int cin, int cout, int kvol, int subm, const float *scale,
+                                 const float *shift, int relu, float *out, float *scratch, int64_t scratch_floats,
+                                 dclStream_t stream);
+int dcl_internal_sparse_avgpool_fwd(const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev,
+                                    int n_out_host, int c, int kvol, float *out, int32_t *rf, dclStream_t stream);
 int dcl_three_nn_sp_strided(int n, int m, const float *unknown, const float *known, float *dist2, int32_t *idx,
                             const int32_t *known_seg, int nbatch, int seg_stride, dclStream_t stream);
 
@@ -243,6 +249,7 @@ static int backbone_features(const int32_t *occ, int V0, int batch, int S, void 
   const int32_t *in_perm = at<int32_t>(ws, L.perm0);
   int s = S, rc;
   int steps_left = dbg_steps();
+  const bool explicit_nbr = getenv("DCL_EXPLICIT_NBR") != nullptr && atoi(getenv("DCL_EXPLICIT_NBR")) != 0;
 #define DBG_STEP() do { if (--steps_left < 0) return 0; } while (0)
   for (int m = 0; m < kLevels; ++m) {
     const SetLayout &c = L.conv[m], &p = L.pool[m];
@@ -250,35 +257,47 @@ static int backbone_features(const int32_t *occ, int V0, int batch, int S, void 
     const int32_t *nc_dev = counts_dev ? counts_dev + 2 * m : nullptr;
     const int32_t *np_dev = counts_dev ? counts_dev + 2 * m + 1 : nullptr;
     const int c0 = channels_host[2 * m], c1 = channels_host[2 * m + 1], c2 = channels_host[2 * m + 2];
+    float *scr = F.scratch_floats ? at<float>(ws2, F.scratch) : nullptr;
+    // The kernels derive their neighbour rows from the input set's occupancy grid themselves (DclNbrSrc, no gather
+    // table and no k_build_nbr launch); DCL_EXPLICIT_NBR=1 keeps the table path for A/B runs.
+    auto source = [&](const int32_t *out_idx, const int32_t *n_dev, int n_host, const uint32_t *mask,
+                      const int32_t *wp, const int32_t *perm, int stride, DclNbrSrc *src) -> int {
+      if (explicit_nbr) {
+        const int rc2 = dcl_rulebook_gather(out_idx, n_dev, n_dev ? 0 : n_host, mask, wp, perm, batch, s, 3, stride, 1, nbr,
+                                            n_host, stream);
+        *src = DclNbrSrc{nbr, nullptr, nullptr, nullptr, nullptr, 0, 1, 0};
+        return rc2;
+      }
+      *src = DclNbrSrc{nullptr, out_idx, mask, wp, perm, s, stride, 1};
+      return 0;
+    };
+    DclNbrSrc src;
     if (nc > 0) {
       // conv (k3,s1,p1): out rows = conv set, inputs looked up in the previous level's set
       DBG_STEP();
-      rc = dcl_rulebook_gather(at<int32_t>(ws, c.indices), nc_dev, nc_dev ? 0 : nc, in_mask, in_wp, in_perm, batch, s, 3,
-                               1, 1, nbr, nc, stream);
+      rc = source(at<int32_t>(ws, c.indices), nc_dev, nc, in_mask, in_wp, in_perm, 1, &src);
       if (rc) return rc;
       DBG_STEP();
-      rc = dcl_sparse_conv_fwd_ws(x, nbr, nc, nc_dev, nc_dev ? 0 : nc, weights[2 * m], c0, c1, 27, 0, scales[2 * m],
-                                  shifts[2 * m], 1, x1, F.scratch_floats ? at<float>(ws2, F.scratch) : nullptr,
-                                  (int64_t)F.scratch_floats, stream);
+      rc = dcl_internal_sparse_conv_fwd(x, src, nc, nc_dev, nc_dev ? 0 : nc, weights[2 * m], c0, c1, 27, 0, scales[2 * m],
+                                        shifts[2 * m], 1, x1, scr, (int64_t)F.scratch_floats, stream);
       if (rc) return rc;
       // submanifold conv on the conv set
       DBG_STEP();
-      rc = dcl_rulebook_gather(at<int32_t>(ws, c.indices), nc_dev, nc_dev ? 0 : nc, at<uint32_t>(ws, c.mask),
-                               at<int32_t>(ws, c.wprefix), nullptr, batch, s, 3, 1, 1, nbr, nc, stream);
+      rc = source(at<int32_t>(ws, c.indices), nc_dev, nc, at<uint32_t>(ws, c.mask), at<int32_t>(ws, c.wprefix), nullptr, 1,
+                  &src);
       if (rc) return rc;
       DBG_STEP();
-      rc = dcl_sparse_conv_fwd_ws(x1, nbr, nc, nc_dev, nc_dev ? 0 : nc, weights[2 * m + 1], c1, c2, 27, 1,
-                                  scales[2 * m + 1], shifts[2 * m + 1], 1, x2,
-                                  F.scratch_floats ? at<float>(ws2, F.scratch) : nullptr, (int64_t)F.scratch_floats, stream);
+      rc = dcl_internal_sparse_conv_fwd(x1, src, nc, nc_dev, nc_dev ? 0 : nc, weights[2 * m + 1], c1, c2, 27, 1,
+                                        scales[2 * m + 1], shifts[2 * m + 1], 1, x2, scr, (int64_t)F.scratch_floats, stream);
       if (rc) return rc;
     }
     if (np > 0) {
       DBG_STEP();
-      rc = dcl_rulebook_gather(at<int32_t>(ws, p.indices), np_dev, np_dev ? 0 : np, at<uint32_t>(ws, c.mask),
-                               at<int32_t>(ws, c.wprefix), nullptr, batch, s, 3, 2, 1, nbr, np, stream);
+      rc = source(at<int32_t>(ws, p.indices), np_dev, np, at<uint32_t>(ws, c.mask), at<int32_t>(ws, c.wprefix), nullptr, 2,
+                  &src);
       if (rc) return rc;
       DBG_STEP();
-      rc = dcl_sparse_avgpool_fwd(x2, nbr, np, np_dev, np_dev ? 0 : np, c2, 27, level_out[m], nullptr, stream);
+      rc = dcl_internal_sparse_avgpool_fwd(x2, src, np, np_dev, np_dev ? 0 : np, c2, 27, level_out[m], nullptr, stream);
       if (rc) return rc;
     }
     x = level_out[m];

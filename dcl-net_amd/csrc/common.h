@@ -40,6 +40,34 @@ __device__ __forceinline__ float dcl_dist2(float ax, float ay, float az, float b
   float dx = ax - bx, dy = ay - by, dz = az - bz;
   return __fmaf_rn(dz, dz, __fmaf_rn(dx, dx, dy * dy));
 }
+// Where a kernel gets nbr[k][o] (the input row feeding output row o under kernel offset k) from: an explicit gather table
+// (dcl_rulebook_gather; the spconv shim and the training path keep it) or, inside the native backbone runner, the input
+// set's occupancy grid directly -- p = o*stride - pad + k looked up by bitmask rank (no table, no k_build_nbr launch).
+struct DclNbrSrc {
+  const int32_t *nbr;              // explicit table, row stride `cap`; nullptr = implicit
+  const int32_t *out_indices;      // (rows,4) [b,x,y,z] of the output set
+  const uint32_t *in_mask;         // input set occupancy bits
+  const int32_t *in_wprefix;       // exclusive popcount prefix per mask word
+  const int32_t *in_perm;          // rank -> feature row (level 0) or nullptr
+  int S_in, stride, pad;
+};
+#if defined(__HIPCC__)
+__device__ __forceinline__ int dcl_nbr_at(const DclNbrSrc &s, int cap, int k, int row) {
+  if (s.nbr) return s.nbr[(size_t)k * cap + row];
+  const int4 q = reinterpret_cast<const int4 *>(s.out_indices)[row];
+  const int kx = k / 9, ky = (k - 9 * kx) / 3, kz = k - 9 * kx - 3 * ky;             // 3x3x3 offsets: k = kz + 3 ky + 9 kx
+  const int px = q.y * s.stride - s.pad + kx, py = q.z * s.stride - s.pad + ky, pz = q.w * s.stride - s.pad + kz;
+  if ((unsigned)px >= (unsigned)s.S_in || (unsigned)py >= (unsigned)s.S_in || (unsigned)pz >= (unsigned)s.S_in) return -1;
+  const int lin = ((q.x * s.S_in + px) * s.S_in + py) * s.S_in + pz;
+  const int w = lin >> 5;
+  const uint32_t m = s.in_mask[w];
+  const uint32_t bit = 1u << (lin & 31);
+  if (!(m & bit)) return -1;
+  const int r = s.in_wprefix[w] + __popc(m & (bit - 1));
+  return s.in_perm ? s.in_perm[r] : r;
+}
+#endif
+
 // a*b + c*d + e*f under the same policy.
 __device__ __forceinline__ float dcl_wsum3(float a, float b, float c, float d, float e, float f) {
   return __fmaf_rn(e, f, __fmaf_rn(a, b, c * d));

@@ -14,6 +14,13 @@
 // the epilogue.  Bound: MFMA fp32 (2*pairs*Cin*Cout flop); features and weights are L2-resident.
 #include "common.h"
 
+int dcl_internal_sparse_conv_fwd(const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev,
+                                 int n_out_host, const float *W, int cin, int cout, int kvol, int subm, const float *scale,
+                                 const float *shift, int relu, float *out, float *scratch, int64_t scratch_floats,
+                                 dclStream_t stream);
+int dcl_internal_sparse_avgpool_fwd(const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev,
+                                    int n_out_host, int c, int kvol, float *out, int32_t *rf, dclStream_t stream);
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -27,7 +34,7 @@ __device__ __forceinline__ int offset_at(int step, int kvol, int subm) {
 }
 
 // ---- generic VALU kernel: any Cin/Cout (used for the 7->16 stem and as an A/B check) -------------
-__global__ void k_sparse_conv_valu(const float *__restrict__ feat, const int32_t *__restrict__ nbr, int cap,
+__global__ void k_sparse_conv_valu(const float *__restrict__ feat, const DclNbrSrc src, int cap,
                                    const int32_t *__restrict__ n_out_dev, int n_out_host,
                                    const float *__restrict__ W, int cin, int cout, int kvol, int subm,
                                    const float *__restrict__ scale, const float *__restrict__ shift, int relu,
@@ -42,7 +49,7 @@ __global__ void k_sparse_conv_valu(const float *__restrict__ feat, const int32_t
     float acc = 0.0f;
     for (int s = 0; s < kvol; ++s) {
       const int k = offset_at(s, kvol, subm);
-      const int v = nbr[(size_t)k * cap + row];
+      const int v = dcl_nbr_at(src, cap, k, row);
       if (v < 0) continue;
       const float *f = feat + (size_t)v * cin;
       const float *w = W + (size_t)k * cin * cout + co;
@@ -60,7 +67,7 @@ __global__ void k_sparse_conv_valu(const float *__restrict__ feat, const int32_t
 // one thread per output row, all COUT channels in registers; W (kvol x CIN x COUT) lives in LDS and is read as
 // wave-uniform broadcasts.  Same summation order as the generic kernel (per offset an ascending-ci fmaf chain, then one add).
 template <int CIN, int COUT>
-__global__ __launch_bounds__(256) void k_sparse_conv_stem(const float *__restrict__ feat, const int32_t *__restrict__ nbr,
+__global__ __launch_bounds__(256) void k_sparse_conv_stem(const float *__restrict__ feat, const DclNbrSrc src,
                                                           int cap, const int32_t *__restrict__ n_out_dev, int n_out_host,
                                                           const float *__restrict__ W, int kvol, int subm,
                                                           const float *__restrict__ scale, const float *__restrict__ shift,
@@ -76,7 +83,7 @@ __global__ __launch_bounds__(256) void k_sparse_conv_stem(const float *__restric
     for (int co = 0; co < COUT; ++co) acc[co] = 0.0f;
     for (int s = 0; s < kvol; ++s) {
       const int k = offset_at(s, kvol, subm);
-      const int v = nbr[(size_t)k * cap + row];
+      const int v = dcl_nbr_at(src, cap, k, row);
       if (v < 0) continue;
       float f[CIN];
 #pragma unroll
@@ -110,7 +117,7 @@ __global__ __launch_bounds__(256) void k_sparse_conv_stem(const float *__restric
 // (deep) layers still put >= 2-3 waves on every SIMD.
 template <int NT>
 __global__ __launch_bounds__(256) void k_sparse_conv_mfma(
-    const float *__restrict__ feat, const int32_t *__restrict__ nbr, int cap, const int32_t *__restrict__ n_out_dev,
+    const float *__restrict__ feat, const DclNbrSrc src, int cap, const int32_t *__restrict__ n_out_dev,
     int n_out_host, const float *__restrict__ W, int cin, int cout, int kvol, int subm,
     const float *__restrict__ scale, const float *__restrict__ shift, int relu, float *__restrict__ out) {
   int n = n_out_dev ? *n_out_dev : n_out_host;
@@ -132,7 +139,7 @@ __global__ __launch_bounds__(256) void k_sparse_conv_mfma(
 
     for (int s = 0; s < kvol; ++s) {
       const int k = offset_at(s, kvol, subm);
-      const int v = valid ? nbr[(size_t)k * cap + row] : -1;
+      const int v = valid ? dcl_nbr_at(src, cap, k, row) : -1;
       if (__ballot(v >= 0) == 0ull) continue;                       // nobody in this tile uses offset k
       const float *fp = feat + (size_t)(v >= 0 ? v : 0) * cin + h * 4;
       const float *wp = W + (size_t)k * cin * cout + col0 + r;
@@ -179,7 +186,7 @@ __global__ __launch_bounds__(256) void k_sparse_conv_mfma(
 // for the whole offset with Cin/8 independent 16-B loads issued back to back, so their latency overlaps.
 template <int CIN, int NT>
 __global__ __launch_bounds__(256, 2) void k_sparse_conv_lds(
-    const float *__restrict__ feat, const int32_t *__restrict__ nbr, int cap, const int32_t *__restrict__ n_out_dev,
+    const float *__restrict__ feat, const DclNbrSrc src, int cap, const int32_t *__restrict__ n_out_dev,
     int n_out_host, const float *__restrict__ W, int cout, int kvol, int subm, const float *__restrict__ scale,
     const float *__restrict__ shift, int relu, float *__restrict__ out) {
   constexpr int BN = 32 * NT;                    // output channels per workgroup
@@ -199,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void k_sparse_conv_lds(
     // which offsets does this workgroup need?
     unsigned mymask = 0;
     if (valid)
-      for (int k = 0; k < kvol; ++k) mymask |= (nbr[(size_t)k * cap + row] >= 0 ? 1u : 0u) << k;
+      for (int k = 0; k < kvol; ++k) mymask |= (dcl_nbr_at(src, cap, k, row) >= 0 ? 1u : 0u) << k;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) mymask |= __shfl_xor(mymask, d, 64);
     if (tid == 0) s_kmask = 0;
@@ -246,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void k_sparse_conv_lds(
       const int k = offset_at(s, kvol, subm);
       const int s_next = next_used(s + 1);
       if (s_next < kvol) fetch_tile(offset_at(s_next, kvol, subm));       // global loads in flight during the MFMAs
-      const int v = valid ? nbr[(size_t)k * cap + row] : -1;
+      const int v = valid ? dcl_nbr_at(src, cap, k, row) : -1;
       if (__ballot(v >= 0) != 0ull) {                                       // this wave's 32 rows use offset k
         float4 a[CIN / 8];
         const float *fp = feat + (size_t)(v >= 0 ? v : 0) * CIN + h * 4;
@@ -305,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void k_sparse_conv_lds(
 // workgroup uses are skipped.  WC = waves along the channel axis: BM = 32*(4/WC) rows, BN = 32*WC channels.
 template <int CIN, int WC, int KC>
 __global__ __launch_bounds__(256, 2) void k_sparse_conv_tile(
-    const float *__restrict__ feat, const int32_t *__restrict__ nbr, int cap, const int32_t *__restrict__ n_out_dev,
+    const float *__restrict__ feat, const DclNbrSrc src, int cap, const int32_t *__restrict__ n_out_dev,
     int n_out_host, const float *__restrict__ W, int cout, int kvol, int subm, const float *__restrict__ scale,
     const float *__restrict__ shift, int relu, float *__restrict__ out) {
   constexpr int WR = 4 / WC;
@@ -338,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void k_sparse_conv_tile(
     unsigned mymask = 0;
     for (int e = tid; e < kvol * BM; e += 256) {
       const int k = e / BM, rr = e - k * BM;
-      const int v = (row0 + rr < n) ? nbr[(size_t)k * cap + row0 + rr] : -1;
+      const int v = (row0 + rr < n) ? dcl_nbr_at(src, cap, k, row0 + rr) : -1;
       Ns[e] = v;
       mymask |= (v >= 0 ? 1u : 0u) << k;
     }
@@ -483,7 +490,7 @@ __device__ __forceinline__ unsigned conv_lds_addr(const float *p) {
 // 128x128 (Cout % 128 == 0, 8 waves, 32 flop/B) and 128x64 (4 waves) here.
 template <int CIN, int WR, int WCW, int NT>
 __global__ __launch_bounds__(64 * WR * WCW, 2) void k_sparse_conv_dma(
-    const float *__restrict__ feat, const int32_t *__restrict__ nbr, int cap, const int32_t *__restrict__ n_out_dev,
+    const float *__restrict__ feat, const DclNbrSrc src, int cap, const int32_t *__restrict__ n_out_dev,
     int n_out_host, const float *__restrict__ W, int cout, int kvol, int subm, const float *__restrict__ scale,
     const float *__restrict__ shift, int relu, float *__restrict__ out, float *__restrict__ partial, int nsplit) {
   constexpr int NW = WR * WCW, NTHR = 64 * NW;
@@ -518,7 +525,7 @@ __global__ __launch_bounds__(64 * WR * WCW, 2) void k_sparse_conv_dma(
     unsigned mymask = 0;
     for (int e = tid; e < kvol * BM; e += NTHR) {
       const int k = e / BM, rr = e - k * BM;
-      const int v = (row0 + rr < n) ? nbr[(size_t)k * cap + row0 + rr] : -1;
+      const int v = (row0 + rr < n) ? dcl_nbr_at(src, cap, k, row0 + rr) : -1;
       Ns[e] = v;
       mymask |= (v >= 0 ? 1u : 0u) << k;
     }
@@ -659,7 +666,7 @@ constexpr int kConvMaxSplit = 8;
 static int g_conv_split = 0;           // tuning hook: 0 = automatic, n = force n-way split-K when scratch allows
 
 template <int CIN, int WR, int WCW, int NT>
-static void launch_conv_dma(int rows, const float *feat, const int32_t *nbr, int cap, const int32_t *n_out_dev,
+static void launch_conv_dma(int rows, const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev,
                             int n_out_host, const float *W, int cout, int kvol, int subm, const float *scale,
                             const float *shift, int relu, float *out, float *scratch, long long scratch_floats,
                             hipStream_t s) {
@@ -688,7 +695,7 @@ static void launch_conv_dma(int rows, const float *feat, const int32_t *nbr, int
 }
 
 template <int CIN, int WC, int KC>
-static void launch_conv_tile(int rows, const float *feat, const int32_t *nbr, int cap, const int32_t *n_out_dev,
+static void launch_conv_tile(int rows, const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev,
                              int n_out_host, const float *W, int cout, int kvol, int subm, const float *scale,
                              const float *shift, int relu, float *out, hipStream_t s) {
   constexpr int WR = 4 / WC, BM = 32 * WR, BN = 32 * WC;
@@ -703,25 +710,34 @@ static void launch_conv_tile(int rows, const float *feat, const int32_t *nbr, in
 // ---- sparse average pool ------------------------------------------------------------------------
 // thread = (output row, 4 channels): rf = #valid offsets (summaryRF.cu:39), then
 // out = ((0 + f_k0/rf) + f_k1/rf) + ... in ascending offset order (avgpool.cu:130).
-__global__ void k_sparse_avgpool(const float *__restrict__ feat, const int32_t *__restrict__ nbr, int cap,
-                                 const int32_t *__restrict__ n_out_dev, int n_out_host, int c, int kvol,
-                                 float *__restrict__ out, int32_t *__restrict__ rf_out) {
+__global__ __launch_bounds__(256) void k_sparse_avgpool(const float *__restrict__ feat, const DclNbrSrc src, int cap,
+                                                        const int32_t *__restrict__ n_out_dev, int n_out_host, int c, int kvol,
+                                                        float *__restrict__ out, int32_t *__restrict__ rf_out) {
+  // the c/4 threads of an output row share its 27 neighbour rows through LDS (one lookup per (row, offset) per block)
+  __shared__ int32_t s_v[64 * 27];
   int n = n_out_dev ? *n_out_dev : n_out_host;
   n = n < cap ? n : cap;
-  const int c4 = c >> 2;
-  const long long total = (long long)n * c4;
-  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
-       t += (long long)gridDim.x * blockDim.x) {
-    const int row = (int)(t / c4);
-    const int q = (int)(t - (long long)row * c4);
+  const int c4 = c >> 2;                                   // 4..64 and a divisor of 256 (checked by the launcher)
+  const int rpb = 256 / c4;                                // output rows per block step
+  const int tid = threadIdx.x;
+  const int rr = tid / c4, q = tid - rr * c4;
+  for (int row0 = blockIdx.x * rpb; row0 < n; row0 += gridDim.x * rpb) {
+    __syncthreads();
+    for (int e = tid; e < rpb * kvol; e += 256) {
+      const int r2 = e / kvol, k = e - r2 * kvol;
+      s_v[r2 * 27 + k] = row0 + r2 < n ? dcl_nbr_at(src, cap, k, row0 + r2) : -1;
+    }
+    __syncthreads();
+    const int row = row0 + rr;
+    if (row >= n) continue;
+    const int32_t *v = s_v + rr * 27;
     int rf = 0;
-    for (int k = 0; k < kvol; ++k) rf += nbr[(size_t)k * cap + row] >= 0;
+    for (int k = 0; k < kvol; ++k) rf += v[k] >= 0;
     const float d = (float)rf;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int k = 0; k < kvol; ++k) {
-      const int v = nbr[(size_t)k * cap + row];
-      if (v < 0) continue;
-      const float4 f = reinterpret_cast<const float4 *>(feat + (size_t)v * c)[q];
+      if (v[k] < 0) continue;
+      const float4 f = reinterpret_cast<const float4 *>(feat + (size_t)v[k] * c)[q];
       acc.x = acc.x + f.x / d; acc.y = acc.y + f.y / d; acc.z = acc.z + f.z / d; acc.w = acc.w + f.w / d;
     }
     reinterpret_cast<float4 *>(out + (size_t)row * c)[q] = acc;
@@ -729,7 +745,7 @@ __global__ void k_sparse_avgpool(const float *__restrict__ feat, const int32_t *
   }
 }
 
-__global__ void k_sparse_avgpool_scalar(const float *__restrict__ feat, const int32_t *__restrict__ nbr, int cap,
+__global__ void k_sparse_avgpool_scalar(const float *__restrict__ feat, const DclNbrSrc src, int cap,
                                         const int32_t *__restrict__ n_out_dev, int n_out_host, int c, int kvol,
                                         float *__restrict__ out, int32_t *__restrict__ rf_out) {
   int n = n_out_dev ? *n_out_dev : n_out_host;
@@ -740,11 +756,11 @@ __global__ void k_sparse_avgpool_scalar(const float *__restrict__ feat, const in
     const int row = (int)(t / c);
     const int ch = (int)(t - (long long)row * c);
     int rf = 0;
-    for (int k = 0; k < kvol; ++k) rf += nbr[(size_t)k * cap + row] >= 0;
+    for (int k = 0; k < kvol; ++k) rf += dcl_nbr_at(src, cap, k, row) >= 0;
     const float d = (float)rf;
     float acc = 0.f;
     for (int k = 0; k < kvol; ++k) {
-      const int v = nbr[(size_t)k * cap + row];
+      const int v = dcl_nbr_at(src, cap, k, row);
       if (v >= 0) acc = acc + feat[(size_t)v * c + ch] / d;
     }
     out[t] = acc;
@@ -777,7 +793,19 @@ DCL_API int dcl_sparse_conv_fwd_ws(const float *feat, const int32_t *nbr, int ca
                                    int n_out_host, const float *W, int cin, int cout, int kvol, int subm,
                                    const float *scale, const float *shift, int relu, float *out, float *scratch,
                                    int64_t scratch_floats, dclStream_t stream) {
-  DCL_CHECK_ARG(feat && nbr && W && out && cap > 0 && cin > 0 && cout > 0 && kvol > 0 && kvol <= 27);
+  DCL_CHECK_ARG(nbr);
+  const DclNbrSrc src = {nbr, nullptr, nullptr, nullptr, nullptr, 0, 1, 0};
+  return dcl_internal_sparse_conv_fwd(feat, src, cap, n_out_dev, n_out_host, W, cin, cout, kvol, subm, scale, shift, relu,
+                                      out, scratch, scratch_floats, stream);
+}
+
+// library-internal: `nbr` may be an implicit rulebook (native backbone runner)
+int dcl_internal_sparse_conv_fwd(const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev,
+                                 int n_out_host, const float *W, int cin, int cout, int kvol, int subm, const float *scale,
+                                 const float *shift, int relu, float *out, float *scratch, int64_t scratch_floats,
+                                 dclStream_t stream) {
+  DCL_CHECK_ARG(feat && (nbr.nbr || (nbr.out_indices && nbr.in_mask && nbr.in_wprefix && kvol == 27)) && W && out && cap > 0 &&
+                cin > 0 && cout > 0 && kvol > 0 && kvol <= 27);
   DCL_CHECK_ARG((scale == nullptr) == (shift == nullptr));
   DCL_CHECK_ARG(n_out_dev || (n_out_host >= 0 && n_out_host <= cap));
   const int rows = n_out_dev ? cap : n_out_host;
@@ -863,13 +891,22 @@ DCL_API int dcl_sparse_conv_fwd_ws(const float *feat, const int32_t *nbr, int ca
 DCL_API int dcl_sparse_avgpool_fwd(const float *feat, const int32_t *nbr, int cap, const int32_t *n_out_dev,
                                    int n_out_host, int c, int kvol, float *out, int32_t *rf,
                                    dclStream_t stream) {
-  DCL_CHECK_ARG(feat && nbr && out && cap > 0 && c > 0 && kvol > 0 && kvol <= 27);
+  DCL_CHECK_ARG(nbr);
+  const DclNbrSrc src = {nbr, nullptr, nullptr, nullptr, nullptr, 0, 1, 0};
+  return dcl_internal_sparse_avgpool_fwd(feat, src, cap, n_out_dev, n_out_host, c, kvol, out, rf, stream);
+}
+
+int dcl_internal_sparse_avgpool_fwd(const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev,
+                                    int n_out_host, int c, int kvol, float *out, int32_t *rf, dclStream_t stream) {
+  DCL_CHECK_ARG(feat && (nbr.nbr || (nbr.out_indices && nbr.in_mask && nbr.in_wprefix && kvol == 27)) && out && cap > 0 &&
+                c > 0 && kvol > 0 && kvol <= 27);
   DCL_CHECK_ARG(n_out_dev || (n_out_host >= 0 && n_out_host <= cap));
   const int rows = n_out_dev ? cap : n_out_host;
   if (rows == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  if (c % 4 == 0)
-    hipLaunchKernelGGL(k_sparse_avgpool, dim3(dcl_grid_1d((long long)rows * (c / 4), 256)), dim3(256), 0, s, feat,
+  const int c4 = c / 4;
+  if (c % 4 == 0 && c4 >= 4 && c4 <= 64 && 256 % c4 == 0)
+    hipLaunchKernelGGL(k_sparse_avgpool, dim3(dcl_grid_1d((long long)rows * c4, 256, 2048)), dim3(256), 0, s, feat,
                        nbr, cap, n_out_dev, n_out_host, c, kvol, out, rf);
   else
     hipLaunchKernelGGL(k_sparse_avgpool_scalar, dim3(dcl_grid_1d((long long)rows * c, 256)), dim3(256), 0, s, feat,
