@@ -24,6 +24,9 @@ int dcl_internal_sparse_conv_fwd(const float *feat, const DclNbrSrc &nbr, int ca
                                  dclStream_t stream);
 int dcl_internal_sparse_avgpool_fwd(const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev,
                                     int n_out_host, int c, int kvol, float *out, int32_t *rf, dclStream_t stream);
+int dcl_three_nn_sp_voxels(int n, int m, const float *unknown, const int32_t *known_indices, float ve, float off,
+                           float *dist2, int32_t *idx, const int32_t *known_seg, int nbatch, int seg_stride,
+                           dclStream_t stream);
 int dcl_three_nn_sp_strided(int n, int m, const float *unknown, const float *known, float *dist2, int32_t *idx,
                             const int32_t *known_seg, int nbatch, int seg_stride, dclStream_t stream);
 
@@ -363,17 +366,15 @@ static int point_features(int n, const float *points_b4, int batch, int S, int V
   DCL_CHECK_ARG(tmp_bytes >= (int64_t)need);
   float *dist2 = at<float>(tmp, 0);
   int32_t *idx = at<int32_t>(tmp, align_up((size_t)n * 12));
-  float *centres = at<float>(tmp, align_up((size_t)n * 12) * 2);
   int col = 0, rc;
   for (int m = 0; m < kLevels; ++m) {
     const SetLayout &p = L.pool[m];
     const int np = counts_host[2 * m + 1], c = channels_host[2 * m + 2];
     DCL_CHECK_ARG(col + c <= ld);
-    rc = dcl_voxel_centres(at<int32_t>(ws, p.indices), counts_dev ? counts_dev + 2 * m + 1 : nullptr, np,
-                           voxel_extent_host[m], offset, centres, stream);
-    if (rc) return rc;
     const int wpc = p.S * p.S * p.S / 32;           // mask words per crop (S >= 4 -> >= 2)
-    rc = dcl_three_nn_sp_strided(n, np, points_b4, centres, dist2, idx, at<int32_t>(ws, p.wprefix), batch, wpc, stream);
+    // voxel centres are formed inside the 3-NN kernel while it stages its tiles (no k_voxel_centres launch)
+    rc = dcl_three_nn_sp_voxels(n, np, points_b4, at<int32_t>(ws, p.indices), voxel_extent_host[m], offset, dist2, idx,
+                                at<int32_t>(ws, p.wprefix), batch, wpc, stream);
     if (rc) return rc;
     rc = dcl_three_interpolate_dist2_sp(c, np, n, level_feats[m], idx, dist2, out + col, ld, stream);
     if (rc) return rc;

@@ -46,10 +46,22 @@ __device__ __forceinline__ u64 make_key(float d, int k) { return ((u64)__float_a
 // staged through an LDS tile; the 4 partial top-3 lists are merged with two shuffle rounds (exact: keys are a
 // total order).  No global-memory latency and no divergent branch in the inner loop.
 constexpr int kNNTile = 512;
+// voxel centre of a grid row (Ops_tensor2points, models/Modules.py:204-211): fp32, left to right
+__device__ __forceinline__ float4 voxel_centre(const int4 v, float ve, float off, float half) {
+  float4 c;
+  c.x = (float)v.x;
+  c.y = ((float)v.y * ve + off) + half;
+  c.z = ((float)v.z * ve + off) + half;
+  c.w = ((float)v.w * ve + off) + half;
+  return c;
+}
+
+// FROM_INDICES: `known` holds the voxel rows (b,x,y,z) i32 and the centres are formed while the tile is staged
+template <bool FROM_INDICES>
 __global__ __launch_bounds__(64) void k_three_nn_sp(int n, int m, const float4 *__restrict__ unknown,
                                                     const float4 *__restrict__ known, float *__restrict__ dist2,
                                                     int32_t *__restrict__ idx, const int32_t *__restrict__ known_seg,
-                                                    int nbatch, int seg_stride) {
+                                                    int nbatch, int seg_stride, float ve, float off) {
   __shared__ float4 tile[kNNTile];
   const int lane = threadIdx.x;
   const int sub = lane & 3;
@@ -76,7 +88,9 @@ __global__ __launch_bounds__(64) void k_three_nn_sp(int n, int m, const float4 *
   for (int base = wlo; base < whi; base += kNNTile) {
     const int cnt = min(kNNTile, whi - base);
     __syncthreads();
-    for (int j = lane; j < cnt; j += 64) tile[j] = known[base + j];
+    for (int j = lane; j < cnt; j += 64)
+      tile[j] = FROM_INDICES ? voxel_centre(reinterpret_cast<const int4 *>(known)[base + j], ve, off, 0.5f * ve)
+                             : known[base + j];
     __syncthreads();
 #pragma unroll 4
     for (int j = sub; j < cnt; j += 4) {
@@ -104,15 +118,8 @@ __global__ void k_voxel_centres(const int4 *__restrict__ indices, const int32_t 
                                 float ve, float off, float4 *__restrict__ centres) {
   const int n = n_dev ? *n_dev : n_host;
   const float half = 0.5f * ve;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const int4 v = indices[i];
-    float4 c;
-    c.x = (float)v.x;
-    c.y = ((float)v.y * ve + off) + half;
-    c.z = ((float)v.z * ve + off) + half;
-    c.w = ((float)v.w * ve + off) + half;
-    centres[i] = c;
-  }
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    centres[i] = voxel_centre(indices[i], ve, off, half);
 }
 
 template <bool FROM_DIST2>
@@ -240,9 +247,23 @@ int dcl_three_nn_sp_strided(int n, int m, const float *unknown, const float *kno
   DCL_CHECK_ARG(n >= 0 && m >= 0);
   if (n == 0) return 0;
   DCL_CHECK_ARG(unknown && dist2 && idx && (m == 0 || known) && (!known_seg || (nbatch > 0 && seg_stride > 0)));
-  hipLaunchKernelGGL(k_three_nn_sp, dim3(dcl_div_up(n, 16)), dim3(64), 0, (hipStream_t)stream, n, m,
+  hipLaunchKernelGGL(k_three_nn_sp<false>, dim3(dcl_div_up(n, 16)), dim3(64), 0, (hipStream_t)stream, n, m,
                      reinterpret_cast<const float4 *>(unknown), reinterpret_cast<const float4 *>(known), dist2, idx,
-                     known_seg, nbatch, seg_stride);
+                     known_seg, nbatch, seg_stride, 0.0f, 0.0f);
+  DCL_LAUNCH_CHECK();
+  return 0;
+}
+
+// internal: the known set is given as voxel rows (b,x,y,z) i32; their centres idx*ve + off + ve/2 are formed in the kernel
+int dcl_three_nn_sp_voxels(int n, int m, const float *unknown, const int32_t *known_indices, float ve, float off,
+                           float *dist2, int32_t *idx, const int32_t *known_seg, int nbatch, int seg_stride,
+                           dclStream_t stream) {
+  DCL_CHECK_ARG(n >= 0 && m >= 0);
+  if (n == 0) return 0;
+  DCL_CHECK_ARG(unknown && dist2 && idx && (m == 0 || known_indices) && (!known_seg || (nbatch > 0 && seg_stride > 0)));
+  hipLaunchKernelGGL(k_three_nn_sp<true>, dim3(dcl_div_up(n, 16)), dim3(64), 0, (hipStream_t)stream, n, m,
+                     reinterpret_cast<const float4 *>(unknown), reinterpret_cast<const float4 *>(known_indices), dist2, idx,
+                     known_seg, nbatch, seg_stride, ve, off);
   DCL_LAUNCH_CHECK();
   return 0;
 }
