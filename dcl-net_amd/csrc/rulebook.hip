@@ -77,6 +77,35 @@ __global__ void k_scan_words(const uint32_t *__restrict__ mask, int nwords,
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) wprefix[nwords] = base + total;
 }
 
+// small masks (<= 32 scan blocks): one launch -- every block counts the bits in front of it itself instead of reading
+// block sums written by a separate k_block_popc launch (the whole mask is at most 128 KiB and L2-resident)
+__global__ void k_scan_words_fused(const uint32_t *__restrict__ mask, int nwords, int32_t *__restrict__ wprefix) {
+  int part = 0;
+  const int before = (int)blockIdx.x * kScanWords;              // multiple of 4 words, mask is 16-B aligned
+  const uint4 *m4 = reinterpret_cast<const uint4 *>(mask);
+  for (int i = threadIdx.x; i < (before >> 2); i += 256) {
+    const uint4 v = m4[i];
+    part += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+  }
+  int base;
+  block_excl_scan_256(part, &base);
+  const int w0 = blockIdx.x * kScanWords + threadIdx.x * 4;
+  int c[4], s = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    c[j] = (w0 + j < nwords) ? __popc(mask[w0 + j]) : 0;
+    s += c[j];
+  }
+  int total;
+  int ex = block_excl_scan_256(s, &total) + base;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (w0 + j < nwords) wprefix[w0 + j] = ex;
+    ex += c[j];
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) wprefix[nwords] = base + total;
+}
+
 __device__ __forceinline__ int grid_lookup(const uint32_t *__restrict__ mask, const int32_t *__restrict__ wprefix,
                                            const int32_t *__restrict__ perm, int lin) {
   const int w = lin >> 5;
@@ -267,6 +296,10 @@ __global__ void k_pairs_export(const int32_t *__restrict__ nbr, int cap, const i
 
 int scan_mask(const uint32_t *mask, int nwords, int32_t *wprefix, int32_t *scratch, hipStream_t s) {
   const int nblocks = dcl_div_up(nwords, kScanWords);
+  if (nblocks <= 32 && (reinterpret_cast<uintptr_t>(mask) & 15) == 0) {
+    hipLaunchKernelGGL(k_scan_words_fused, dim3(nblocks), dim3(256), 0, s, mask, nwords, wprefix);
+    return 0;
+  }
   hipLaunchKernelGGL(k_block_popc, dim3(nblocks), dim3(256), 0, s, mask, nwords, scratch);
   hipLaunchKernelGGL(k_scan_words, dim3(nblocks), dim3(256), 0, s, mask, nwords, scratch, wprefix);
   return 0;
