@@ -64,8 +64,11 @@ def _fuser():
 
 
 class Network(nn.Module):
-    def __init__(self, cfg, mode="train", fused=True):
+    def __init__(self, cfg, mode="train", fused=True, graph_max_batch=0):
+        """graph_max_batch > 0: eval-mode calls with at most that many crops go through forward_graphed (one whole-forward
+        hipGraph per batch size) -- the one-image-at-a-time eval loops of the reference are launch-bound otherwise."""
         super().__init__()
+        self.graph_max_batch = int(graph_max_batch)
         self.voxelization_mode = cfg.voxelization_mode
         self.unit_voxel_extent = np.array(cfg.unit_voxel_extent)
         self.mode = mode
@@ -468,6 +471,8 @@ class Network(nn.Module):
 
     def forward(self, data):
         if self.fused and not self.training:
+            if 0 < int(data["batch_offsets"].size(0)) - 1 <= self.graph_max_batch:
+                return self.forward_graphed(data)
             with torch.no_grad():
                 return self._forward_fused(data)
         return self._forward_compat(data)

@@ -173,6 +173,24 @@ def test_whole_forward_hipgraph_matches_eager(dcl):
         assert float((got["trans_pred"] - wants[first]["trans_pred"]).abs().max()) <= T_TOL
 
 
+def test_forward_routes_small_batches_through_the_graph(dcl):
+    b, n = 2, 256
+    cfg = dcl.synth.default_cfg(n, n)
+    net = dcl.DCL_Net.Network(cfg, mode="test", graph_max_batch=4)
+    net.load_state_dict(dcl.synth.synth_state_dict(net, 1))
+    net = net.cuda().eval()
+    plain, _, _ = _net(dcl, n, n, 1)
+    for first in (0, 7):
+        got = net(dcl.synth.make_batch(b, n, n, first=first))
+        with torch.no_grad():
+            want = plain(dcl.synth.make_batch(b, n, n, first=first))
+        assert float((got["rot_pred"] - want["rot_pred"]).abs().max()) <= R_TOL
+        assert float((got["trans_pred"] - want["trans_pred"]).abs().max()) <= T_TOL
+    assert len(net._graphs) == 1
+    net(dcl.synth.make_batch(6, n, n))                                       # above the limit: eager path
+    assert len(net._graphs) == 1
+
+
 def test_graph_cache_follows_the_weights(dcl):
     """a captured forward must not outlive the weights it was captured with; the model stays deep-copyable"""
     import copy
