@@ -15,8 +15,10 @@ import torch
 from . import ops
 
 RGB_MEAN = (0.485, 0.456, 0.406)                                     # dataloader_test_YCBV.py:57,145
-YCBV_CAMERA = (312.9869, 241.3109, 1066.778, 1067.487, 10000.0)      # cx, cy, fx, fy, depth scale (:77-81)
+YCBV_CAMERA = (312.9869, 241.3109, 1066.778, 1067.487, 10000.0, 1.0)  # cx, cy, fx, fy, depth scale (:77-81), post-division
+LM_CAMERA = (325.26110, 242.04899, 572.41140, 573.57043, 1.0, 1000.0)  # LM/dataloader_test_LM.py:104-107,153-160
 MIN_VALID = 32                                                        # :163
+LM_MIN_VALID = 128                                                    # LM/dataloader_test_LM.py:197
 
 
 def snap_box(rois, row, img_h=480, img_w=640):
@@ -26,6 +28,30 @@ def snap_box(rois, row, img_h=480, img_w=640):
     c0, c1 = max(int(rois[row][2]) + 1, 0), min(int(rois[row][4]) - 1, img_w)
 
     def grow(v):                       # open intervals between the borders -1, 40, 80, ... 680 round up to the next border
+        return (v // 40 + 1) * 40 if -1 < v < 680 and (v % 40 != 0 or v == 0) else v
+    hr, hc = int(grow(r1 - r0) / 2), int(grow(c1 - c0) / 2)
+    mr, mc = int((r0 + r1) / 2), int((c0 + c1) / 2)
+    r0, r1, c0, c1 = mr - hr, mr + hr, mc - hc, mc + hc
+    if r0 < 0:
+        r0, r1 = 0, r1 - r0
+    if c0 < 0:
+        c0, c1 = 0, c1 - c0
+    if r1 > img_h:
+        r0, r1 = r0 - (r1 - img_h), img_h
+    if c1 > img_w:
+        c0, c1 = c0 - (c1 - img_w), img_w
+    return r0, r1, c0, c1
+
+
+def lm_box(obj_bb, img_h=480, img_w=640):
+    """`get_bbox` of the LineMOD loader (LM/dataloader_test_LM.py:287-333): [x, y, w, h] -> (rmin, rmax, cmin, cmax) with
+    sides grown to multiples of 40 px like `snap_box`."""
+    r0, r1, c0, c1 = obj_bb[1], obj_bb[1] + obj_bb[3], obj_bb[0], obj_bb[0] + obj_bb[2]
+    r0, c0 = max(r0, 0), max(c0, 0)
+    r1 = img_h - 1 if r1 >= img_h else r1
+    c1 = img_w - 1 if c1 >= img_w else c1
+
+    def grow(v):
         return (v // 40 + 1) * 40 if -1 < v < 680 and (v % 40 != 0 or v == 0) else v
     hr, hc = int(grow(r1 - r0) / 2), int(grow(c1 - c0) / 2)
     mr, mc = int((r0 + r1) / 2), int((c0 + c1) / 2)
@@ -126,3 +152,28 @@ class CropBuilder(object):
             occ, p2v, v2p = ops.voxelize_idx_gpu(coords, b, S, self.mode)
             data[side] = {"feats": feats, "coords": coords, "occupied_voxels": occ, "p2v_maps": p2v, "v2p_maps": v2p}
         return data
+
+    def build_lm(self, img, depth, mask_label, obj_bb, obj, eval_mode=False):
+        """One LineMOD sample (`PoseDataset.__getitem__`, LM/dataloader_test_LM.py:116-214, test / eval modes): img (H,W,3+) u8,
+        depth (H,W) u16 in millimetres, mask_label (H,W) bool object mask (the loader's `mask_label`), obj_bb [x,y,w,h],
+        obj = class id.  The builder must have been made with camera=LM_CAMERA.  Returns (feat_inp (N,7), voxel_inp (N,3) i64,
+        feat_tmp (M,7), voxel_tmp (M,3) i64, centroid (3,)) as CUDA tensors, or None where the loader returns its all-zero
+        dummy sample (empty mask; in test mode also when at most 128 points fall inside the voxel grid)."""
+        H, W = depth.shape
+        r0, r1, c0, c1 = lm_box(obj_bb, H, W)
+        dev = self.dev
+        d_t = torch.from_numpy(np.ascontiguousarray(depth).astype(np.uint16).view(np.int16)).to(dev)
+        l_t = torch.from_numpy(np.ascontiguousarray(mask_label).astype(np.int32)).to(dev)
+        i_t = torch.from_numpy(np.ascontiguousarray(img)).to(dev)
+        b_t = torch.tensor([[max(r0, 0), min(r1, H), max(c0, 0), min(c1, W)]], dtype=torch.int32, device=dev)
+        o_t = torch.ones(1, dtype=torch.int32, device=dev)
+        xyz, col, centroid, counts = ops.crop_points(d_t, l_t, i_t, b_t, o_t, self.camera, RGB_MEAN, self.extent * 0.5,
+                                                     LM_MIN_VALID, always_filter=eval_mode)
+        n_mask, n_valid, m = counts.cpu().numpy()[0]
+        if n_mask == 0 or not (n_valid > LM_MIN_VALID or eval_mode):
+            return None
+        pick = np.random.choice(m, self.n_inp, replace=False) if m > self.n_inp else np.random.choice(m, self.n_inp)
+        pick_t = torch.from_numpy(pick.astype(np.int64)).view(1, -1).to(dev)
+        feats, coords = ops.crop_sample(xyz, col, pick_t, None, self.extent[0] * 0.5, self.unit, int(self.limit[0]))
+        row = self.cls_row[int(obj)]
+        return feats, coords[:, 1:].contiguous(), self.tmp_feats[row], self.tmp_vox[row], centroid[0]

@@ -41,13 +41,13 @@ __device__ __forceinline__ int block_excl_scan(int v, int *s_wave /* [4] */, int
   return base + incl - v;
 }
 
-struct CropCam { float cx, cy, fx, fy, scale; };
+struct CropCam { float cx, cy, fx, fy, scale, post_div; };
 
 __global__ __launch_bounds__(kCropThreads) void k_crop_points(
     const uint16_t *__restrict__ depth, const int32_t *__restrict__ label, const uint8_t *__restrict__ rgb, int H, int W,
     int rgb_channels, const int32_t *__restrict__ boxes /* (n,4) rmin,rmax,cmin,cmax */,
     const int32_t *__restrict__ obj_ids, CropCam cam, double mean_r, double mean_g, double mean_b, float hx, float hy,
-    float hz, int min_valid, int cap, float *__restrict__ raw_xyz, float *__restrict__ raw_rgb,
+    float hz, int min_valid, int always_filter, int cap, float *__restrict__ raw_xyz, float *__restrict__ raw_rgb,
     float *__restrict__ out_xyz, float *__restrict__ out_rgb, float *__restrict__ centroid,
     int32_t *__restrict__ counts /* (n,3): masked pixels, inside the grid, rows written */) {
   __shared__ int s_wave[kCropThreads / 64];
@@ -88,7 +88,9 @@ __global__ __launch_bounds__(kCropThreads) void k_crop_points(
       const float pt2 = (float)depth[pix] / cam.scale;
       const float pt0 = ((float)c - cam.cx) * pt2 / cam.fx;
       const float pt1 = ((float)r - cam.cy) * pt2 / cam.fy;
-      rx[(size_t)o * 3] = pt0; rx[(size_t)o * 3 + 1] = pt1; rx[(size_t)o * 3 + 2] = pt2;
+      // LineMOD's loader converts millimetres afterwards, `cloud = cloud / 1000.0` (LM/dataloader_test_LM.py:160); x / 1.0f
+      // is the identity for the YCB-V loader
+      rx[(size_t)o * 3] = pt0 / cam.post_div; rx[(size_t)o * 3 + 1] = pt1 / cam.post_div; rx[(size_t)o * 3 + 2] = pt2 / cam.post_div;
       // img/255.0 in float32, minus the float64 mean, rounded to float32 when the FloatTensor is made (:143-145,168)
       const uint8_t *px = rgb + pix * rgb_channels;
       rc[(size_t)o * 3] = (float)((double)((float)px[0] / 255.0f) - mean_r);
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(kCropThreads) void k_crop_points(
     (void)block_excl_scan(valid, s_wave, total);
     valid = total;
   }
-  const bool filter = valid > min_valid;        // `if valid_num > 32` (:163)
+  const bool filter = valid > min_valid || always_filter;   // `if valid_num > 32` (:163); LM eval mode filters always (:197)
 
   // ---- 4. keep them (in order), centred
   int m = 0;
@@ -195,18 +197,21 @@ __global__ void k_crop_sample(int n_inst, int npoint, int cap, const float *__re
 }  // namespace
 
 DCL_API int dcl_crop_points(const uint16_t *depth, const int32_t *label, const uint8_t *rgb, int H, int W, int rgb_channels,
-                            int n_inst, const int32_t *boxes, const int32_t *obj_ids, const float *cam_host /*5*/,
-                            const double *rgb_mean_host /*3*/, const float *half_extent_host /*3*/, int min_valid, int cap,
+                            int n_inst, const int32_t *boxes, const int32_t *obj_ids, const float *cam_host /*6*/,
+                            const double *rgb_mean_host /*3*/, const float *half_extent_host /*3*/, int min_valid,
+                            int always_filter, int cap,
                             float *raw_xyz, float *raw_rgb, float *out_xyz, float *out_rgb, float *centroid,
                             int32_t *counts, dclStream_t stream) {
   DCL_CHECK_ARG(n_inst >= 0 && H > 0 && W > 0 && rgb_channels >= 3 && cap > 0);
   if (n_inst == 0) return 0;
   DCL_CHECK_ARG(depth && label && rgb && boxes && obj_ids && cam_host && rgb_mean_host && half_extent_host && raw_xyz &&
                 raw_rgb && out_xyz && out_rgb && centroid && counts);
-  const CropCam cam = {cam_host[0], cam_host[1], cam_host[2], cam_host[3], cam_host[4]};
+  const CropCam cam = {cam_host[0], cam_host[1], cam_host[2], cam_host[3], cam_host[4], cam_host[5]};
+  DCL_CHECK_ARG(cam.scale != 0.0f && cam.post_div != 0.0f);
   hipLaunchKernelGGL(k_crop_points, dim3(n_inst), dim3(kCropThreads), 0, (hipStream_t)stream, depth, label, rgb, H, W,
                      rgb_channels, boxes, obj_ids, cam, rgb_mean_host[0], rgb_mean_host[1], rgb_mean_host[2],
-                     half_extent_host[0], half_extent_host[1], half_extent_host[2], min_valid, cap, raw_xyz, raw_rgb,
+                     half_extent_host[0], half_extent_host[1], half_extent_host[2], min_valid, always_filter, cap, raw_xyz,
+                     raw_rgb,
                      out_xyz, out_rgb, centroid, counts);
   DCL_LAUNCH_CHECK();
   return 0;

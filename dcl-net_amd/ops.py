@@ -534,10 +534,10 @@ def add_s(cld, R_pred, t_pred, R_gt, t_gt, cls=None):
 
 
 # ------------------------------------------------------------------------------------ crop builder
-def crop_points(depth, label, rgb, boxes, obj_ids, cam, rgb_mean, half_extent, min_valid=32):
+def crop_points(depth, label, rgb, boxes, obj_ids, cam, rgb_mean, half_extent, min_valid=32, always_filter=False):
     """Masked back-projection + centring + grid filter of every object instance of one image
     (YCBV/dataloader_test_YCBV.py:124-165).  depth (H,W) u16 viewed as int16 storage, label (H,W) i32, rgb (H,W,C) u8,
-    boxes (n,4) i32 [rmin,rmax,cmin,cmax], obj_ids (n) i32 -- all CUDA.  cam = (cx,cy,fx,fy,scale).
+    boxes (n,4) i32 [rmin,rmax,cmin,cmax], obj_ids (n) i32 -- all CUDA.  cam = (cx,cy,fx,fy,scale[,post_div]).
     -> xyz (n,cap,3), rgb (n,cap,3), centroid (n,3), counts (n,3) i32 [masked, inside grid, rows]."""
     N.need_cuda(depth, label, rgb, boxes, obj_ids)
     assert depth.dtype in (torch.int16, torch.uint16) and label.dtype == torch.int32 and rgb.dtype == torch.uint8
@@ -554,11 +554,12 @@ def crop_points(depth, label, rgb, boxes, obj_ids, cam, rgb_mean, half_extent, m
     col = torch.empty((n, cap, 3), dtype=torch.float32, device=dev)
     centroid = torch.empty((n, 3), dtype=torch.float32, device=dev)
     counts = torch.zeros((n, 3), dtype=torch.int32, device=dev)
-    cam_a = (C.c_float * 5)(*[float(v) for v in cam])
+    cam_a = (C.c_float * 6)(*([float(v) for v in cam] + [1.0])[:6])
     mean_a = (C.c_double * 3)(*[float(v) for v in rgb_mean])
     he_a = (C.c_float * 3)(*[float(v) for v in half_extent])
     N.check(N.lib().dcl_crop_points(N.ptr(depth), N.ptr(label), N.ptr(rgb), H, W, rgb.shape[2], n, N.ptr(boxes),
-                                    N.ptr(obj_ids), cam_a, mean_a, he_a, int(min_valid), cap, N.ptr(raw_xyz),
+                                    N.ptr(obj_ids), cam_a, mean_a, he_a, int(min_valid), int(bool(always_filter)), cap,
+                                    N.ptr(raw_xyz),
                                     N.ptr(raw_rgb), N.ptr(xyz), N.ptr(col), N.ptr(centroid), N.ptr(counts), N.stream()),
             "crop_points")
     return xyz, col, centroid, counts

@@ -310,12 +310,14 @@ int dcl_voxelize_bp(const float *d_out, const int32_t *rules, float *d_feats_zer
  * float32 sum / n (np.mean(axis=0), :156); points centred; those with |x|,|y|,|z| < half_extent kept when more than
  * min_valid (32) of them exist, else all (:160-165).
  *   depth (H,W) u16, label (H,W) i32, rgb (H,W,rgb_channels) u8 -- device; boxes (n,4) i32 rmin,rmax,cmin,cmax (clipped
- *   to the image) and obj_ids (n) i32 -- device; cam_host = {cx, cy, fx, fy, scale}; cap >= every box area.
+ *   to the image) and obj_ids (n) i32 -- device; cam_host = {cx, cy, fx, fy, scale, post_div}: the cloud is divided by
+ *   post_div after back-projection (1000 for LineMOD, LM/dataloader_test_LM.py:156-160; 1 for YCB-V); always_filter: apply
+ *   the grid filter whatever the count (LM eval mode, :197); cap >= every box area.
  *   raw_xyz/raw_rgb: scratch (n,cap,3); out_xyz/out_rgb (n,cap,3); centroid (n,3);
  *   counts (n,3) = {masked pixels, points inside the grid, rows written} (all zero: the reference skips the instance). */
 int dcl_crop_points(const uint16_t *depth, const int32_t *label, const uint8_t *rgb, int H, int W, int rgb_channels,
                     int n_inst, const int32_t *boxes, const int32_t *obj_ids, const float *cam_host,
-                    const double *rgb_mean_host, const float *half_extent_host, int min_valid, int cap,
+                    const double *rgb_mean_host, const float *half_extent_host, int min_valid, int always_filter, int cap,
                     float *raw_xyz, float *raw_rgb, float *out_xyz, float *out_rgb, float *centroid,
                     int32_t *counts, dclStream_t stream);
 /* Sampled points -> feats rows [1,r,g,b,x,y,z] (n*npoint,7) and voxelize_idx input rows [instance,ix,iy,iz] (n*npoint,4)

@@ -124,3 +124,86 @@ def build_image(img, depth, label, rois, gt_obj, cad_points_mm, cad_colors, cfg,
         data[side] = {"feats": feats, "coords": coords, "occupied_voxels": torch.from_numpy(occ),
                       "p2v_maps": torch.from_numpy(p2v), "v2p_maps": torch.from_numpy(v2p)}
     return data
+
+
+LM_CAM = dict(cx=325.26110, cy=242.04899, fx=572.41140, fy=573.57043)                # LM/dataloader_test_LM.py:104-107
+
+
+def lm_get_bbox(bbox, img_h=480, img_w=640):
+    """LM/dataloader_test_LM.py:287-333."""
+    bbx = [bbox[1], bbox[1] + bbox[3], bbox[0], bbox[0] + bbox[2]]
+    if bbx[0] < 0:
+        bbx[0] = 0
+    if bbx[1] >= img_h:
+        bbx[1] = img_h - 1
+    if bbx[2] < 0:
+        bbx[2] = 0
+    if bbx[3] >= img_w:
+        bbx[3] = img_w - 1
+    rmin, rmax, cmin, cmax = bbx
+
+    def snap(v):
+        for lo, hi in zip(BORDERS[:-1], BORDERS[1:]):
+            if lo < v < hi:
+                return hi
+        return v
+    r_b, c_b = snap(rmax - rmin), snap(cmax - cmin)
+    cr, cc = int((rmin + rmax) / 2), int((cmin + cmax) / 2)
+    rmin, rmax = cr - int(r_b / 2), cr + int(r_b / 2)
+    cmin, cmax = cc - int(c_b / 2), cc + int(c_b / 2)
+    if rmin < 0:
+        rmin, rmax = 0, rmax - rmin
+    if cmin < 0:
+        cmin, cmax = 0, cmax - cmin
+    if rmax > img_h:
+        rmin, rmax = rmin - (rmax - img_h), img_h
+    if cmax > img_w:
+        cmin, cmax = cmin - (cmax - img_w), img_w
+    return rmin, rmax, cmin, cmax
+
+
+def build_lm_sample(img, depth, mask_label, obj_bb, obj, cad_points_mm, cad_colors, cfg, eval_mode=False):
+    """`__getitem__` of the LineMOD loader (LM/dataloader_test_LM.py:116-214; test/eval modes, i.e. without the training
+    augmentation): returns (feat_inp, voxel_inp, feat_tmp, voxel_tmp, centroid) or None for its all-zero dummy sample."""
+    npoint_inp = cfg["input_size"]
+    unit = np.array(cfg["unit_voxel_extent"]).astype(float)
+    extent = np.array(cfg["voxel_num_limit"]).astype(float) * unit
+    H, W = depth.shape
+    xmap = np.array([[j for _ in range(W)] for j in range(H)])
+    ymap = np.array([[i for i in range(W)] for _ in range(H)])
+    mask = mask_label * ma.getmaskarray(ma.masked_not_equal(depth, 0))                     # :130-135
+    rmin, rmax, cmin, cmax = lm_get_bbox(obj_bb, H, W)
+    choose = mask[rmin:rmax, cmin:cmax].flatten().nonzero()[0]                             # :147
+    if len(choose) == 0:
+        return None
+    img_masked = np.array(img)[:, :, :3][rmin:rmax, cmin:cmax, :].astype(np.float32).reshape((-1, 3))[choose, :]
+    img_masked = img_masked / 255.0 - RGB_MEAN[np.newaxis, :]
+    depth_masked = depth[rmin:rmax, cmin:cmax].flatten()[choose][:, np.newaxis].astype(np.float32)
+    xmap_masked = xmap[rmin:rmax, cmin:cmax].flatten()[choose][:, np.newaxis].astype(np.float32)
+    ymap_masked = ymap[rmin:rmax, cmin:cmax].flatten()[choose][:, np.newaxis].astype(np.float32)
+    cam_scale = 1.0                                                                        # :155-160
+    pt2 = depth_masked / cam_scale
+    pt0 = (ymap_masked - LM_CAM["cx"]) * pt2 / LM_CAM["fx"]
+    pt1 = (xmap_masked - LM_CAM["cy"]) * pt2 / LM_CAM["fy"]
+    cloud = np.concatenate((pt0, pt1, pt2), axis=1)
+    cloud = cloud / 1000.0
+    assert cloud.dtype == np.float32
+    centroid = np.mean(cloud, axis=0)
+    cloud = cloud - centroid[np.newaxis, :]
+    inside = (np.abs(cloud[:, 0]) < extent[0] * 0.5) & (np.abs(cloud[:, 1]) < extent[1] * 0.5) & \
+             (np.abs(cloud[:, 2]) < extent[2] * 0.5)                                       # :196
+    if not (np.sum(inside) > 128 or eval_mode):                                            # :197
+        return None
+    cloud, img_masked = cloud[inside, :], img_masked[inside, :]
+    if cloud.shape[0] > npoint_inp:
+        pick = np.random.choice(cloud.shape[0], npoint_inp, replace=False)
+    else:
+        pick = np.random.choice(cloud.shape[0], npoint_inp)
+    cloud_t, rgb_t = torch.FloatTensor(cloud[pick, :]), torch.FloatTensor(img_masked[pick, :])
+    feat_inp = torch.cat([torch.ones(npoint_inp, 1), rgb_t, cloud_t], 1)
+    vox_inp = ((cloud_t + extent[0] * 0.5) / torch.FloatTensor(unit)).long()
+    model_points = torch.FloatTensor(cad_points_mm[obj] / 1000.0)
+    model_colors = torch.FloatTensor(cad_colors[obj])
+    feat_tmp = torch.cat([torch.ones(cfg["tmp_size"], 1), model_colors, model_points], 1)
+    vox_tmp = ((model_points + extent[0] * 0.5) / torch.FloatTensor(unit)).long()
+    return feat_inp, vox_inp, feat_tmp, vox_tmp, torch.FloatTensor(centroid)

@@ -76,6 +76,38 @@ def test_device_crop_builder_bit_exact(dcl, seed, kw):
     assert torch.equal(got["labels"]["trans_gt"], want["labels"]["trans_gt"])
 
 
+def test_lm_box_matches_oracle(dcl):
+    from oracle import crops as oc
+    rng = np.random.default_rng(2)
+    for _ in range(3000):
+        bb = [int(rng.integers(-20, 640)), int(rng.integers(-20, 480)), int(rng.integers(1, 700)), int(rng.integers(1, 600))]
+        assert dcl.crops.lm_box(bb) == oc.lm_get_bbox(bb)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,eval_mode,small", [(31, False, False), (32, True, False), (33, False, True), (34, True, True)])
+def test_device_lm_sample_bit_exact(dcl, seed, eval_mode, small):
+    """LineMOD loader arithmetic (millimetre depth, /1000 after back-projection, 128-point rule, eval-mode filtering)"""
+    from oracle import crops as oc
+    cfg = dict(CFG, unit_voxel_extent=[0.005] * 3, input_size=128)
+    sc = make_scene(seed, n_obj=1, tmp_size=cfg["tmp_size"], tiny=0 if small else None)
+    cls = int(sc["gt_obj"][0])
+    mask_label = sc["label"] == cls
+    depth = (sc["depth"].astype(np.float64) / 10).astype(np.uint16)              # ~0.6-1.4 m in millimetres
+    ys, xs = np.nonzero(mask_label)
+    bb = [int(xs.min()) - 3, int(ys.min()) - 2, int(xs.max() - xs.min()) + 7, int(ys.max() - ys.min()) + 5]
+    builder = dcl.crops.CropBuilder(cfg, sc["cad_pts"], sc["cad_col"], camera=dcl.crops.LM_CAMERA)
+    np.random.seed(seed)
+    want = oc.build_lm_sample(sc["img"], depth, mask_label, bb, cls, sc["cad_pts"], sc["cad_col"], cfg, eval_mode)
+    np.random.seed(seed)
+    got = builder.build_lm(sc["img"], depth, mask_label, bb, cls, eval_mode)
+    if want is None:
+        assert got is None and small and not eval_mode
+        return
+    for g, w in zip(got, want):
+        assert torch.equal(g.cpu(), w)
+
+
 @pytest.mark.gpu
 def test_built_crops_run_through_the_network(dcl):
     """image -> device crop builder -> Network.forward, everything resident on the GPU"""
