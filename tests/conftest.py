@@ -42,5 +42,8 @@ def load_golden_data(path):
     for side in ("inp", "tmp"):
         data[side] = {k: torch.from_numpy(z["%s_%s" % (side, k)]) for k in
                       ("feats", "occupied_voxels", "p2v_maps", "v2p_maps")}
-    exp = {k: z[k] for k in ("trans_pred", "rot_pred", "conf", "F_Xo_p_sub", "F_Xo_p_sum")}
+    exp = {k: z[k] for k in z.files if not k.startswith(("inp_", "tmp_")) and k != "meta"}
+    if "flags" in exp:                                    # train-mode fixtures carry the symmetry flags and the gt poses
+        data["flags"] = torch.from_numpy(exp["flags"])
+        data["labels"] = {"rot_gt": torch.from_numpy(exp["rot_gt"]), "trans_gt": torch.from_numpy(exp["trans_gt"])}
     return data, exp, (b, n_inp, n_tmp, wseed)

@@ -9,7 +9,8 @@ feeds it the seeded synthetic crops + seeded weights of dcl-net_amd/synth.py, an
 tests/test_oracle_golden.py then checks oracle/graph.py (the restatement that travels to the GPU box)
 against these vectors; the GPU parity tests check the HIP path against both.
 
-    python tests/golden/make_golden.py        # rewrites tests/golden/dclnet_b2_n256.npz, refiner_b2.npz
+    python tests/golden/make_golden.py        # rewrites tests/golden/dclnet_b2_n256.npz, refiner_b2.npz,
+                                              # dclnet_s0_train.npz, dclnet_nm384_train.npz
 """
 import importlib
 import os
@@ -209,6 +210,39 @@ def main():
                         dt_first=first["trans_pred"].numpy(), dR_first=first["rot_pred"].numpy(),
                         rot_final=rot.numpy(), trans_final=trans.numpy())
     print("golden written:", {k: v.shape for k, v in out.items() if k != "meta"})
+
+    # ---- mode='train' outputs on (a) BASELINE config 0's shape (LineMOD-style crop: N=2048 observed, M=500 template,
+    # 5 mm voxels) and (b) an N=M crop, where the reference's own objectives are defined (`losses`,
+    # models/DCL_Net.py:261-304 needs N == M in CD_Dis; `losses_refiner`, models/refiner.py:98-125)
+    for tag, b2, n_inp, n_tmp, first, with_losses in (("s0", 2, 2048, 500, 9, False), ("nm384", 2, 384, 384, 4, True)):
+        cfg2 = dcl.synth.default_cfg(n_inp, n_tmp, unit=0.005)
+        ref2 = ref_net_mod.Network(attr(dict(cfg2)), mode="train")
+        ref2.load_state_dict(dcl.synth.synth_state_dict(ref2, seed=3))
+        ref2.eval()
+        data2 = dcl.synth.make_batch(b2, n_inp, n_tmp, unit=0.005, first=first, voxelize_idx=lambda c, bs, mode: tuple(
+            torch.from_numpy(a) for a in K.voxelize_idx(c.numpy(), bs, mode)))
+        data2["flags"] = torch.tensor([0.0, 1.0])
+        in2 = clone_data(data2)
+        with torch.no_grad():
+            p2 = ref2(data2)
+        out2 = {"trans_pred": p2["trans_pred"].numpy(), "rot_pred": p2["rot_pred"].numpy(), "conf": p2["conf"].numpy(),
+                "Xo_pred": p2["Xo_pred"].numpy(), "Yc_pred": p2["Yc_pred"].numpy(),
+                "F_Xo_p_sum": p2["F_Xo_p"].double().sum(dim=2).numpy(),
+                "rot_gt": in2["labels"]["rot_gt"].numpy(), "trans_gt": in2["labels"]["trans_gt"].numpy(),
+                "flags": in2["flags"].numpy(), "meta": np.array([b2, n_inp, n_tmp, 3], np.int64)}
+        if with_losses:
+            with torch.no_grad():
+                lo = ref_net_mod.losses(None)(p2, data2["labels"])
+                pr = {"rot_pred": p2["rot_pred"].transpose(1, 2).contiguous(), "trans_pred": -p2["trans_pred"] * 0.5}
+                lr = ref_refiner_mod.losses_refiner(None)(pr, p2["trans_pred"], p2["rot_pred"],
+                                                          data2["labels"]["points_tmp"], p2["sym_flag"], data2["labels"])
+            out2["losses"] = np.array([float(lo[k]) for k in ("loss_pose", "loss_Xo", "loss_Yc", "loss_conf", "loss_all")])
+            out2["loss_refiner"] = np.array([float(lr["loss_all"])])
+        for side in ("inp", "tmp"):
+            for k in ("feats", "occupied_voxels", "p2v_maps", "v2p_maps"):
+                out2["%s_%s" % (side, k)] = in2[side][k].numpy()
+        np.savez_compressed(os.path.join(ROOT, "tests", "golden", "dclnet_%s_train.npz" % tag), **out2)
+        print("golden written: dclnet_%s_train.npz" % tag, out2.get("losses"), out2.get("loss_refiner"))
 
 
 if __name__ == "__main__":

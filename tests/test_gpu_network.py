@@ -45,6 +45,28 @@ def test_forward_matches_reference_golden(dcl, golden_dir, fused):
     assert tuple(data["labels"]["points_tmp"].shape) == (b, n_tmp, 3)
 
 
+@pytest.mark.parametrize("fixture", ["dclnet_s0_train.npz", "dclnet_nm384_train.npz"])
+@pytest.mark.parametrize("fused", [True, False])
+def test_train_mode_outputs_match_reference_golden(dcl, golden_dir, fixture, fused):
+    """mode='train' forward (eval-mode BatchNorm) incl. Xo_pred / Yc_pred at BASELINE config 0's shape (N=2048, M=500, 5 mm
+    voxels) and at N=M=384; on the latter the objectives reproduce the reference's loss values"""
+    data, exp, (b, n_inp, n_tmp, wseed) = load_golden_data(os.path.join(golden_dir, fixture))
+    cfg = dcl.synth.default_cfg(n_inp, n_tmp, unit=0.005)
+    net = dcl.DCL_Net.Network(cfg, mode="train", fused=fused)
+    net.load_state_dict(dcl.synth.synth_state_dict(net, wseed))
+    net = net.cuda().eval()
+    with torch.no_grad():
+        pred = net(data)
+    _check(pred, exp["rot_pred"], exp["trans_pred"], exp["conf"])
+    for k in ("Xo_pred", "Yc_pred"):
+        assert tuple(pred[k].shape) == exp[k].shape
+        assert np.abs(pred[k].cpu().numpy() - exp[k]).max() <= 1e-4 * max(1.0, np.abs(exp[k]).max()), k
+    if "losses" in exp:
+        lo = dcl.DCL_Net.losses(None)(pred, data["labels"])
+        got = np.array([float(lo[k]) for k in ("loss_pose", "loss_Xo", "loss_Yc", "loss_conf", "loss_all")])
+        assert np.abs(got - exp["losses"]).max() <= 2e-4 * max(1.0, np.abs(exp["losses"]).max())
+
+
 @pytest.mark.parametrize("b,n_inp,n_tmp,unit", [(3, 1024, 1024, 0.006), (1, 2048, 500, 0.005), (5, 512, 1024, 0.006),
                                                (8, 1024, 1024, 0.005), (1, 12288, 2048, 0.006)])
 def test_forward_matches_oracle_graph(dcl, oracle, b, n_inp, n_tmp, unit):

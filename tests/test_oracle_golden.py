@@ -59,3 +59,36 @@ def test_refiner_matches_reference(dcl, golden_dir):
     rot, trans = G.refine_loop(sd, {"rot_pred": rot0, "trans_pred": trans0, "F_Xo_p": F, "conf": conf}, pts, 2)
     assert np.abs(rot.numpy() - z["rot_final"]).max() <= 1e-4
     assert np.abs(trans.numpy() - z["trans_final"]).max() <= 1e-5
+
+
+def _train_cases(golden_dir):
+    return [os.path.join(golden_dir, f) for f in ("dclnet_s0_train.npz", "dclnet_nm384_train.npz")]
+
+
+def test_train_mode_forward_matches_reference_graph(dcl, oracle, golden_dir):
+    """mode='train' outputs (Xo_pred, Yc_pred too) at BASELINE config 0's shape (N=2048, M=500, 5 mm) and at N=M=384"""
+    for path in _train_cases(golden_dir):
+        data, exp, (b, n_inp, n_tmp, wseed) = load_golden_data(path)
+        cfg = dcl.synth.default_cfg(n_inp, n_tmp, unit=0.005)
+        sd = dcl.synth.synth_state_dict(dcl.DCL_Net.Network(cfg, mode="train"), wseed)
+        pred = G.forward(sd, dict(cfg), data, mode="train")
+        assert np.abs(pred["rot_pred"].numpy() - exp["rot_pred"]).max() <= 1e-4
+        assert np.abs(pred["trans_pred"].numpy() - exp["trans_pred"]).max() <= 1e-5
+        for k in ("Xo_pred", "Yc_pred", "conf"):
+            assert np.abs(pred[k].numpy() - exp[k]).max() <= 1e-4 * max(1.0, np.abs(exp[k]).max()), k
+
+
+def test_objectives_match_the_reference_values(dcl, golden_dir):
+    """dcl losses / losses_refiner on the reference's outputs == the reference's own loss values"""
+    data, exp, (b, n_inp, n_tmp, _) = load_golden_data(os.path.join(golden_dir, "dclnet_nm384_train.npz"))
+    pred = {k: torch.from_numpy(exp[k]) for k in ("rot_pred", "trans_pred", "conf", "Xo_pred", "Yc_pred")}
+    pred["sym_flag"] = data["flags"]
+    gt = dict(data["labels"])
+    gt["points_inp"] = data["inp"]["feats"][:, 4:7].reshape(b, n_inp, 3)
+    gt["points_tmp"] = data["tmp"]["feats"][:, 4:7].reshape(b, n_tmp, 3)
+    lo = dcl.DCL_Net.losses(None)(pred, gt)
+    got = np.array([float(lo[k]) for k in ("loss_pose", "loss_Xo", "loss_Yc", "loss_conf", "loss_all")])
+    assert np.abs(got - exp["losses"]).max() <= 1e-5 * max(1.0, np.abs(exp["losses"]).max())
+    pr = {"rot_pred": pred["rot_pred"].transpose(1, 2).contiguous(), "trans_pred": -pred["trans_pred"] * 0.5}
+    lr = dcl.refiner.losses_refiner(None)(pr, pred["trans_pred"], pred["rot_pred"], gt["points_tmp"], pred["sym_flag"], gt)
+    assert abs(float(lr["loss_all"]) - float(exp["loss_refiner"][0])) <= 1e-6
