@@ -4,8 +4,10 @@ file I/O replaced by arguments.  Only tests/, __graft_entry__.smoke() and bench.
 
 Every arithmetic statement keeps the reference's operand types (float32 arrays, Python-float camera constants, the
 float64 colour mean, torch float32 voxel arithmetic) because the device builder is required to be bit-identical.
-Parity pin: the statements below ARE the reference's numpy/torch calls (same library functions, same order); there is
-no dataset in this container to run the original loader on, so this piece is "parity unpinned" beyond that.
+Parity pin: tests/golden/crops_ref.npz holds the outputs of the reference's OWN loader code -- `YCBDataset.__getitem__`
+and the LineMOD `Dataset.__getitem__`, imported unmodified in the build container with only their file I/O replaced
+(tests/golden/make_crops_golden.py) -- on the seeded synthetic frames of tests/crop_scene.py; this restatement reproduces
+them bit for bit (tests/test_crops.py).
 """
 import numpy as np
 import numpy.ma as ma

@@ -152,3 +152,74 @@ def test_device_crop_builder_timing(dcl, capsys):
     with capsys.disabled():
         print("\ncrop builder: device %.2f ms, CPU restatement %.2f ms per frame" % (res["device"], res["cpu"]))
     assert res["device"] < res["cpu"]
+
+
+# ---- pins against the REFERENCE's own loader code (tests/golden/make_crops_golden.py ran YCBDataset.__getitem__ and the
+# LineMOD Dataset.__getitem__ unmodified, file I/O stubbed, on these same seeded scenes)
+def _ref_golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "crops_ref.npz"))
+
+
+YCBV_REF = [(11, {}), (12, dict(tiny=0)), (13, dict(empty=1, undetected=2))]
+LM_REF = [(31, False, False), (32, True, False), (33, False, True), (34, True, True)]
+
+
+def _check_ycbv(got, z, tag):
+    for side in ("inp", "tmp"):
+        for k in ("feats", "occupied_voxels", "p2v_maps", "v2p_maps"):
+            assert np.array_equal(got[side][k].cpu().numpy(), z[tag + side + "_" + k]), (tag, side, k)
+    assert np.array_equal(got["all_centroids"].cpu().numpy(), z[tag + "centroids"])
+    assert np.array_equal(got["all_flags"].numpy(), z[tag + "flags"])
+    assert np.array_equal(got["labels"]["rot_gt"].numpy(), z[tag + "rot_gt"])
+    assert np.array_equal(got["labels"]["trans_gt"].numpy(), z[tag + "trans_gt"])
+
+
+@pytest.mark.parametrize("seed,kw", YCBV_REF)
+def test_oracle_ycbv_crops_equal_the_reference_loader(seed, kw):
+    sc = make_scene(seed, tmp_size=CFG["tmp_size"], **kw)
+    _check_ycbv(_oracle_build(sc, CFG, 100 + seed), _ref_golden(), "ycbv%d_" % seed)
+
+
+def _lm_case(seed, small):
+    cfg = dict(CFG, unit_voxel_extent=[0.005] * 3, input_size=128)
+    sc = make_scene(seed, n_obj=1, tmp_size=cfg["tmp_size"], tiny=0 if small else None)
+    cls = int(sc["gt_obj"][0])
+    mask_label = sc["label"] == cls
+    depth = (sc["depth"].astype(np.float64) / 10).astype(np.uint16)
+    ys, xs = np.nonzero(mask_label)
+    bb = [int(xs.min()) - 3, int(ys.min()) - 2, int(xs.max() - xs.min()) + 7, int(ys.max() - ys.min()) + 5]
+    return cfg, sc, cls, mask_label, depth, bb
+
+
+def _check_lm(got, z, tag):
+    if float(z[tag + "flag"][0]) == -1:
+        assert got is None
+        return
+    for g, k in zip(got, ("feat_inp", "vox_inp", "feat_tmp", "vox_tmp", "centroid")):
+        assert np.array_equal(g.cpu().numpy(), z[tag + k]), (tag, k)
+
+
+@pytest.mark.parametrize("seed,eval_mode,small", LM_REF)
+def test_oracle_lm_sample_equals_the_reference_loader(seed, eval_mode, small):
+    from oracle import crops as oc
+    cfg, sc, cls, mask_label, depth, bb = _lm_case(seed, small)
+    np.random.seed(seed)
+    got = oc.build_lm_sample(sc["img"], depth, mask_label, bb, cls, sc["cad_pts"], sc["cad_col"], cfg, eval_mode)
+    _check_lm(got, _ref_golden(), "lm%d_" % seed)
+
+
+@pytest.mark.gpu
+def test_device_builders_equal_the_reference_loaders(dcl):
+    z = _ref_golden()
+    for seed, kw in YCBV_REF:
+        sc = make_scene(seed, tmp_size=CFG["tmp_size"], **kw)
+        builder = dcl.crops.CropBuilder(CFG, sc["cad_pts"], sc["cad_col"])
+        np.random.seed(100 + seed)
+        _check_ycbv(builder.build(sc["img"], sc["depth"], sc["label"], sc["rois"], sc["gt_obj"], poses=sc["poses"]), z,
+                    "ycbv%d_" % seed)
+    for seed, eval_mode, small in LM_REF:
+        cfg, sc, cls, mask_label, depth, bb = _lm_case(seed, small)
+        builder = dcl.crops.CropBuilder(cfg, sc["cad_pts"], sc["cad_col"], camera=dcl.crops.LM_CAMERA)
+        np.random.seed(seed)
+        _check_lm(builder.build_lm(sc["img"], depth, mask_label, bb, cls, eval_mode), z, "lm%d_" % seed)
