@@ -108,3 +108,19 @@ def test_synth_batch_contract(dcl):
     assert torch.equal(d["inp"]["feats"][:, 0], torch.ones(3 * 128))
     again = dcl.synth.make_batch(3, 128, 96)
     assert torch.equal(again["inp"]["feats"], d["inp"]["feats"])
+
+
+def test_metric_matches_reference_functions_golden(dcl, golden_dir):
+    """AddsTable's closed form vs the outputs of the reference's own cal_auc_acc / cal_metric_auc_acc
+    (tests/golden/make_metric_golden.py executed them from tools/test_YCBV_stage1.py:83-125 in the build container)"""
+    import os
+    z = np.load(os.path.join(golden_dir, "metric_ref.npz"))
+    for case in range(6):
+        d, idx = z["d%d" % case], z["idx%d" % case]
+        table = dcl.sharding.AddsTable()
+        for c, x in zip(idx, d):
+            table.add(int(c), float(x))
+        mean_auc, mean_acc, auc, acc = table.finalize()
+        assert np.abs(auc - z["auc%d" % case]).max() <= 1e-4          # the reference accumulates its ramp in float32
+        assert np.abs(acc - z["acc%d" % case]).max() <= 1e-9
+        assert abs(mean_auc - float(z["mean_auc%d" % case][0])) <= 0.0100001     # both rounded to 2 decimals
