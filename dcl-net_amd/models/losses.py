@@ -2,8 +2,7 @@
 models/refiner.py:98-139) as plain torch modules over the GPU outputs of `Network` / `Refiner`.
 
 Point-set terms: `L2_Dis` = per-point Euclidean distance between corresponding points, `CD_Dis` = symmetric
-nearest-neighbour (Chamfer) distance for symmetric objects; the pairwise matrix comes from torch.cdist in its exact
-(difference-based) mode instead of a (b,N,M,3) tensor of differences."""
+nearest-neighbour (Chamfer) distance for symmetric objects, from coordinate differences in row chunks."""
 import torch
 import torch.nn as nn
 
@@ -15,10 +14,17 @@ def l2_dis(pred, target):
     return torch.norm(pred - target, dim=2)
 
 
-def cd_dis(pred, target):
-    """(b,n,3) x (b,n,3) -> (b,n): 0.5 * (nearest target of every pred point + nearest pred point of every target point)."""
-    d = torch.cdist(pred, target, compute_mode="donot_use_mm_for_euclid_dist")
-    return 0.5 * (d.min(dim=2)[0] + d.min(dim=1)[0])
+def cd_dis(pred, target, chunk=256):
+    """(b,n,3) x (b,n,3) -> (b,n): 0.5 * (nearest target of every pred point + nearest pred point of every target point).
+    The pairwise Euclidean matrix is formed from coordinate differences (as the reference does), `chunk` pred rows at a
+    time, so the (b,N,M,3) difference tensor never exists in full."""
+    near_t, near_p = [], None
+    for s0 in range(0, pred.shape[1], chunk):
+        d = torch.norm(pred[:, s0:s0 + chunk].unsqueeze(2) - target.unsqueeze(1), dim=3)      # (b, chunk, M)
+        near_t.append(d.min(dim=2)[0])
+        m = d.min(dim=1)[0]
+        near_p = m if near_p is None else torch.minimum(near_p, m)
+    return 0.5 * (torch.cat(near_t, dim=1) + near_p)
 
 
 def get_cano_label(points_tmp, points_inp, rot_pred, trans_gt):

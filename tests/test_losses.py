@@ -73,3 +73,13 @@ def test_full_training_step_with_the_reference_objective(dcl):
     lab = dcl.DCL_Net.losses.get_cano_label(data["labels"]["points_tmp"], data["labels"]["points_inp"],
                                             pred["rot_pred"].detach(), data["labels"]["trans_gt"].cuda().float().unsqueeze(1))
     assert lab.shape == (4, n, 3)
+
+
+@pytest.mark.gpu
+def test_chamfer_term_at_the_shipped_batch_shape(dcl):
+    """bs 32 x 1024 points (config_YCBV_bs32.yaml) -- torch.cdist's exact mode refuses this launch shape on ROCm"""
+    g = torch.Generator().manual_seed(1)
+    a, c = torch.randn(32, 1024, 3, generator=g).cuda(), torch.randn(32, 1024, 3, generator=g).cuda()
+    got = dcl.DCL_Net.losses.CD_Dis(a, c)
+    want = _cd_literal(a[:2].cpu(), c[:2].cpu())
+    assert got.shape == (32, 1024) and float((got[:2].cpu() - want).abs().max()) <= 1e-6
