@@ -49,12 +49,36 @@ class BasicBlock_SPCONV(nn.Module):
         return self.layers(input)
 
 
+class _PointwiseConv3d(nn.Conv3d):
+    """nn.Conv3d whose 1x1x1 / stride 1 / no padding case (every conv of DCL-Net's dense part) is a batched GEMM
+    W (Cout,Cin) @ x (b,Cin,n) instead of a MIOpen convolution -- same parameters, same state_dict keys, differentiable."""
+
+    def forward(self, x):
+        if self.kernel_size != (1, 1, 1) or self.stride != (1, 1, 1) or self.padding != (0, 0, 0) or self.groups != 1:
+            return super().forward(x)
+        b, c = x.shape[0], x.shape[1]
+        y = torch.matmul(self.weight.view(self.out_channels, c), x.reshape(b, c, -1))
+        if self.bias is not None:
+            y = y + self.bias.view(1, -1, 1)
+        return y.view(b, self.out_channels, *x.shape[2:])
+
+
+class _PointwiseConv1d(nn.Conv1d):
+    """nn.Conv1d with kernel 1 as a batched GEMM (see _PointwiseConv3d)."""
+
+    def forward(self, x):
+        if self.kernel_size != (1,) or self.stride != (1,) or self.padding != (0,) or self.groups != 1:
+            return super().forward(x)
+        y = torch.matmul(self.weight.view(self.out_channels, self.in_channels), x)
+        return y if self.bias is None else y + self.bias.view(1, -1, 1)
+
+
 class BasicBlock_3DCONV(nn.Module):
     """Conv3d -> BatchNorm3d -> act on (b,C,n,1,1) tensors (reference Modules.py:58-97)."""
 
     def __init__(self, dim_in, dim_out, bias, size, stride, padding, norm, act, drop):
         super().__init__()
-        layers = [nn.Conv3d(dim_in, dim_out, size, stride, padding, bias=bias)]
+        layers = [_PointwiseConv3d(dim_in, dim_out, size, stride, padding, bias=bias)]
         if norm:
             layers.append(nn.BatchNorm3d(dim_out))
         a = _act_layer(act)
@@ -122,7 +146,7 @@ class Head_MultiLayerPerceptron(nn.Module):
         layers = []
         d_in = list_dim[0]
         for d, act, bn, drop in zip(list_dim[1:], list_act, list_bn, list_drop):
-            layers.append(nn.Conv1d(d_in, d, 1))
+            layers.append(_PointwiseConv1d(d_in, d, 1))
             a = _act_layer(act)
             if a is not None:
                 layers.append(a)
@@ -146,9 +170,10 @@ def Ops_tensor2points(tensor, offset=(0., -40., -3.), voxel_extent=(.1, .1, .2))
     return tensor.features, indices
 
 
-def Ops_nearest_neighbor_interpolate(target_points, query_points, query_feats):
-    """3-NN inverse-distance interpolation (reference Modules.py:213-227)."""
-    dist, idx = pointnet2_utils_sp.three_nn(target_points, query_points)
+def Ops_nearest_neighbor_interpolate(target_points, query_points, query_feats, known_seg=None):
+    """3-NN inverse-distance interpolation (reference Modules.py:213-227).  known_seg (optional, i32[nbatch+1]): row ranges
+    of `query_points` per batch id -- the search then scans a point's own crop only (same results)."""
+    dist, idx = pointnet2_utils_sp.three_nn(target_points, query_points, known_seg)
     dist_recip = 1.0 / (dist + 1e-8)
     norm = torch.sum(dist_recip, dim=1, keepdim=True)
     weight = dist_recip / norm
@@ -171,5 +196,8 @@ class Ops_GetPointFeat_spconv(nn.Module):
         outs = []
         for scale, feats in zip(self.scale_lists, (feats1, feats2, feats3, feats4)):
             vx_feats, vx_points = Ops_tensor2points(feats, self.offset, self.unit_voxel_extent * scale)
-            outs.append(Ops_nearest_neighbor_interpolate(points, vx_points.contiguous(), vx_feats))
+            # voxel rows of a SparseConvTensor are sorted by crop: per-crop row ranges, computed on the device
+            edges = torch.arange(int(feats.batch_size) + 1, device=vx_points.device, dtype=vx_points.dtype)
+            seg = torch.searchsorted(vx_points[:, 0].contiguous(), edges).int()
+            outs.append(Ops_nearest_neighbor_interpolate(points, vx_points.contiguous(), vx_feats, seg))
         return torch.cat(outs, dim=1)
