@@ -335,9 +335,12 @@ int dcl_crop_sample(int n_inst, int npoint, int cap, const float *xyz, const flo
 int dcl_add_s(int b, int P, const float *cld, const int32_t *cls, const float *R_pred, const float *t_pred,
               const float *R_gt, const float *t_gt, float *partial_scratch, float *out, dclStream_t stream);
 
-/* Test hook: route every dcl_sparse_conv_fwd through the plain VALU kernel (A/B check of the MFMA one). */
+/* Test hook, sparse-conv kernel variant: 0 = automatic (LDS-DMA implicit GEMM where Cout % 64 == 0), 1 = plain VALU
+ * kernel for every layer (A/B check of the MFMA ones), 2 = MFMA without LDS staging, 3 = MFMA with LDS weights,
+ * 4 = register-staged tile kernel instead of the LDS-DMA one. */
 void dcl_debug_force_valu_conv(int on);
-/* Test hook: 0 = automatic choice of the attention kernel, 1 = shared-tile 8-wave variant, 2 = double-buffered 4-wave. */
+/* Test hook, attention kernel: 0 = automatic, 1 = shared-tile 8-wave variant, 2 = double-buffered 4-wave register
+ * staging, 3 / 4 = LDS-DMA pipeline with 8 / 4 waves. */
 void dcl_debug_attention_variant(int v);
 /* Tuning hook: 0 = automatic key split of small attention launches (dcl_cross_attention_ws), n = force n splits. */
 void dcl_debug_attention_split(int n);
