@@ -222,6 +222,7 @@ def main():
     ap.add_argument("--shape", choices=list(SHAPES), default="stress")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--no-extras", action="store_true", help="skip ref-shape / primitives / cpu baseline legs")
+    ap.add_argument("--sync-calls", action="store_true", help="no pipelining across forward calls (async_inputs=False)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -236,7 +237,9 @@ def main():
     b = args.batch
     n_inp, n_tmp = SHAPES[args.shape]
     cfg = dcl.synth.default_cfg(n_inp, n_tmp)
-    net = dcl.DCL_Net.Network(cfg, mode="test")
+    # inputs are resident in HBM before the timed region and never rewritten: back-to-back calls may pipeline (the sparse
+    # half of call k+1 under the dense half of call k); --sync-calls restores strictly serial calls
+    net = dcl.DCL_Net.Network(cfg, mode="test", async_inputs=not args.sync_calls)
     sd = dcl.synth.synth_state_dict(net, 1)
     net.load_state_dict(sd)
     net = net.to(dev).eval()
@@ -275,14 +278,16 @@ def main():
             "config": {"workload": "YCB-V bs=32 (config_YCBV_bs32.yaml), N=%d observed / M=%d model points per crop, "
                                    "64^3 x 6 mm voxels; shape=%s" % (n_inp, n_tmp, args.shape),
                        "global_batch": world * b, "frames_per_step_per_gpu": b, "parallelism": "frames sharded x%d" % world,
-                       "weights": "seeded random (no checkpoints offline)"},
+                       "weights": "seeded random (no checkpoints offline)",
+                       "calls": "serial" if args.sync_calls else "pipelined (async_inputs: sparse half of call k+1 under the "
+                                                                 "dense half of call k; every call's full work is inside the timed region)"},
             "roofline": roofline,
             "adds_auc_synthetic_weights": auc, "metric_frames_reduced": int(table.sums[:, 0].sum())}
     if rank == 0 and world == 1 and not args.no_extras:
         if args.shape != "ref":
             rn, rm = SHAPES["ref"]
             rcfg = dcl.synth.default_cfg(rn, rm)
-            rnet = dcl.DCL_Net.Network(rcfg, mode="test")
+            rnet = dcl.DCL_Net.Network(rcfg, mode="test", async_inputs=not args.sync_calls)
             rnet.load_state_dict(dcl.synth.synth_state_dict(rnet, 1))
             rnet = rnet.to(dev).eval()
             rdata = to_device(dcl.synth.make_batch(b, rn, rm), dev)

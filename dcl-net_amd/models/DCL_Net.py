@@ -64,11 +64,16 @@ def _fuser():
 
 
 class Network(nn.Module):
-    def __init__(self, cfg, mode="train", fused=True, graph_max_batch=0):
+    def __init__(self, cfg, mode="train", fused=True, graph_max_batch=0, async_inputs=False):
         """graph_max_batch > 0: eval-mode calls with at most that many crops go through forward_graphed (one whole-forward
-        hipGraph per batch size) -- the one-image-at-a-time eval loops of the reference are launch-bound otherwise."""
+        hipGraph per batch size) -- the one-image-at-a-time eval loops of the reference are launch-bound otherwise.
+        async_inputs=True: the caller guarantees that `data`'s CUDA tensors are complete when forward() is called (or hands
+        over data["ready_event"]) and are not overwritten until the results have been consumed.  The sparse half of a call
+        (side streams) then does not wait for the dense half of the previous call still running on the current stream, so
+        back-to-back calls pipeline: backbones of batch k+1 underneath the GEMMs / attention of batch k."""
         super().__init__()
         self.graph_max_batch = int(graph_max_batch)
+        self.async_inputs = bool(async_inputs)
         self.voxelization_mode = cfg.voxelization_mode
         self.unit_voxel_extent = np.array(cfg.unit_voxel_extent)
         self.mode = mode
@@ -212,32 +217,36 @@ class Network(nn.Module):
             raise RuntimeError("dcl-net_amd.Network runs on the GPU only: call .cuda() first (no CPU fallback)")
         b = int(data["batch_offsets"].size(0)) - 1
         S = int(np.asarray(data["voxel_num_limit"]).astype(np.int64)[0])
-        side_in = {}
-        for side in ("inp", "tmp"):
-            d = data[side]
-            side_in[side] = (d["feats"].to(dev, non_blocking=True).float().contiguous(),
-                             d["v2p_maps"].to(dev, non_blocking=True).int().contiguous(),
-                             d["occupied_voxels"].to(dev, non_blocking=True).int().contiguous())
         # Schedule.  (1) The two backbones are independent until the correspondence attention: each side has its own HIP
-        # stream.  (2) The sparse half of the forward is latency/L2-bound and the disengage GEMMs behind it MFMA-bound, so
-        # the batch is cut into K chunks of crops and the sparse half of chunk c+1 (side streams) runs underneath the
-        # disengage GEMMs of chunk c (main stream): every chunk is its own backbone pass over a batch WINDOW of the shared
-        # voxel arrays.  Attention and heads run on the whole batch (their launches need >= 256 workgroups).  One host
-        # read-back of all K*16 level sizes, as before.  DCL_SINGLE_STREAM=1 / DCL_CHUNKS=1 switch the overlap off.
+        # stream (input conversion, geometry, features, point read-out); the dense half runs on the caller's stream and
+        # starts a side's disengage GEMMs as soon as that side is done.  (2) With async_inputs the side streams do not wait
+        # for the caller's stream at all, so the sparse half of this call overlaps the dense half of the previous one.
+        # (3) Optional chunking of the sparse half (DCL_CHUNKS, measured slower).  One host read-back of the level sizes,
+        # made on a side stream.  DCL_SINGLE_STREAM=1 switches all overlap off.
         main = torch.cuda.current_stream(dev)
         sstream = {"inp": self._side_stream(dev, 0), "tmp": self._side_stream(dev, 1)}
+        single = sstream["inp"] is main
         K = self._pipeline_chunks(b)
         bc = b // K
+        on_device = all(data[s][k].is_cuda for s in ("inp", "tmp") for k in ("feats", "v2p_maps", "occupied_voxels"))
+        decoupled = self.async_inputs and on_device and not single
         for st in sstream.values():
-            st.wait_stream(main)
-        runs = {}
-        for c in range(K):
-            for s in ("inp", "tmp"):
-                with torch.cuda.stream(sstream[s]):
+            if not decoupled:
+                st.wait_stream(main)
+            elif data.get("ready_event") is not None:
+                st.wait_event(data["ready_event"])
+        side_in, runs = {}, {}
+        for s in ("inp", "tmp"):
+            with torch.cuda.stream(sstream[s]):
+                d = data[s]
+                side_in[s] = (d["feats"].to(dev, non_blocking=True).float().contiguous(),
+                              d["v2p_maps"].to(dev, non_blocking=True).int().contiguous(),
+                              d["occupied_voxels"].to(dev, non_blocking=True).int().contiguous())
+                for c in range(K):
                     runs[s, c] = ops.BackboneRun(side_in[s][2], bc, S, batch_lo=c * bc)
-        for st in sstream.values():
-            main.wait_stream(st)
-        counts = torch.cat([runs[s, c].counts_dev for c in range(K) for s in ("inp", "tmp")]).cpu().tolist()   # host sync
+        with torch.cuda.stream(sstream["inp"]):                       # the host waits for the two side streams only
+            sstream["inp"].wait_stream(sstream["tmp"])
+            counts = torch.cat([runs[s, c].counts_dev for c in range(K) for s in ("inp", "tmp")]).cpu().tolist()
         for i, key in enumerate((s, c) for c in range(K) for s in ("inp", "tmp")):
             runs[key[0], key[1]].set_counts(counts[8 * i:8 * i + 8])
         unit = self.unit_voxel_extent
@@ -245,14 +254,18 @@ class Network(nn.Module):
         off = float(np.float32(-0.5 * unit[0] * VOXEL_NUM_LIMIT[0]))
         extents = [float(np.float32(unit[0] * sc)) for sc in SCALE_LISTS]
         npts = {"inp": self.n_inp, "tmp": self.n_tmp}
-        pf = {s: torch.empty((b * npts[s], 480), dtype=torch.float32, device=dev) for s in ("inp", "tmp")}
-        pts = {s: side_in[s][0][:, 4:7].reshape(b, npts[s], 3) for s in ("inp", "tmp")}
+        pf, pts = {}, {}
+        for s in ("inp", "tmp"):
+            with torch.cuda.stream(sstream[s]):                        # written on the side stream, read on `main`
+                pf[s] = torch.empty((b * npts[s], 480), dtype=torch.float32, device=dev)
+            if not single:
+                pf[s].record_stream(main)
+                side_in[s][0].record_stream(main)                      # `pts` below is handed to the caller
+            pts[s] = side_in[s][0][:, 4:7].reshape(b, npts[s], 3)
         act = {}
         for side, key in (("Xc", "inp"), ("Yo", "tmp")):
             act.update(self._disengage_buffers(side, b * npts[key], dev))
         done = {}
-        for st in sstream.values():
-            st.wait_stream(main)
         for side, bb in (("inp", "backbone_inp"), ("tmp", "backbone_tmp")):
             n = npts[side]
             with torch.cuda.stream(sstream[side]):

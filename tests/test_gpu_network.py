@@ -213,6 +213,33 @@ def test_forward_routes_small_batches_through_the_graph(dcl):
     assert len(net._graphs) == 1
 
 
+def test_pipelined_calls_give_the_same_results(dcl):
+    """async_inputs=True: back-to-back calls overlap on the GPU (sparse half of call k+1 under the dense half of call k);
+    every call must still return exactly what a serial call returns"""
+    n = 512
+    cfg = dcl.synth.default_cfg(n, n)
+    nets = {}
+    for flag in (False, True):
+        net = dcl.DCL_Net.Network(cfg, mode="test", async_inputs=flag)
+        net.load_state_dict(dcl.synth.synth_state_dict(net, 1))
+        nets[flag] = net.cuda().eval()
+    dev = torch.device("cuda")
+
+    def on_device(d):
+        return {k: ({kk: (vv.to(dev) if torch.is_tensor(vv) else vv) for kk, vv in v.items()} if isinstance(v, dict)
+                    else (v.to(dev) if torch.is_tensor(v) and k != "voxel_num_limit" else v)) for k, v in d.items()}
+    batches = [on_device(dcl.synth.make_batch(b, n, n, first=f)) for b, f in ((8, 0), (3, 20), (16, 33), (8, 60), (1, 90))]
+    torch.cuda.synchronize()
+    outs = {}
+    for flag in (False, True):
+        with torch.no_grad():
+            outs[flag] = [nets[flag](d) for _ in range(3) for d in batches]       # 15 calls in flight, no sync in between
+        torch.cuda.synchronize()
+    for a, c in zip(outs[False], outs[True]):
+        for k in ("rot_pred", "trans_pred", "conf", "F_Xo_p"):
+            assert torch.equal(a[k], c[k]), k
+
+
 def test_graph_cache_follows_the_weights(dcl):
     """a captured forward must not outlive the weights it was captured with; the model stays deep-copyable"""
     import copy
