@@ -716,8 +716,21 @@ DCL_API int dcl_cross_attention(int b, int nq, int nk, const float *Q, int ldq, 
 }
 
 DCL_API int dcl_cross_attention_scratch_floats(int b, int nq, int64_t *floats_host) {
+  // upper bound of what dcl_cross_attention_ws can use for (b, nq): small launches split up to 8 ways, large ones only
+  // while the records stay below 128 Mi floats
   DCL_CHECK_ARG(b >= 0 && nq >= 0 && floats_host);
-  *floats_host = (int64_t)8 * b * nq * kAttnPartPitch;
+  const long long per = (long long)b * nq * kAttnPartPitch;
+  const long long blocks8 = (long long)b * dcl_div_up(nq > 0 ? nq : 1, 256);
+  long long z = 8;
+  if (blocks8 >= 256) {
+    z = 1;
+    double best = (double)dcl_div_up(blocks8, 256);
+    for (int c = 2; c <= 8; c *= 2) {
+      const double cost = (double)dcl_div_up(blocks8 * c, 256) / c;
+      if (cost <= best - 0.2 && c * per <= (128ll << 20)) { best = cost; z = c; }
+    }
+  }
+  *floats_host = z > 1 ? z * per : 0;
   return 0;
 }
 
@@ -743,9 +756,33 @@ DCL_API int dcl_cross_attention_ws(int b, int nq, int nk, const float *Q, int ld
     const int W = w8 ? 8 : 4;
     const size_t lds = (size_t)(32 * kKPitch + 2 * 32 * 256 + 2 * 32 * 64 + W * 32 * kKPitch) * sizeof(float);
     if (w8) {
+      // wave quantisation: blocks8 workgroups run in ceil(blocks8/256) rounds of one per CU.  When the last round is
+      // mostly empty (e.g. 320 workgroups = 2 rounds for 1.25 rounds of work) a key split of Z makes the rounds Z times
+      // shorter: cost(Z) = ceil(blocks8*Z/256)/Z full-workgroup times; taken when it saves >= 0.2 of one and the partial
+      // records stay below ~512 MiB
+      int nsplit = 1;
+      if (scratch) {
+        if (g_attn_split > 0) {
+          nsplit = g_attn_split;
+        } else {
+          double best = (double)dcl_div_up(blocks8, 256);
+          for (int z = 2; z <= 8; z *= 2) {
+            const double cost = (double)dcl_div_up(blocks8 * z, 256) / z;
+            if (cost <= best - 0.2 && (long long)z * b * nq * kAttnPartPitch <= (128ll << 20)) { best = cost; nsplit = z; }
+          }
+        }
+        const int ntiles = dcl_div_up(nk, 32);
+        if (nsplit > 8) nsplit = 8;
+        if (nsplit > ntiles / 2) nsplit = ntiles / 2;
+        while (nsplit > 1 && (long long)nsplit * b * nq * kAttnPartPitch > scratch_floats) --nsplit;
+        if (nsplit < 1) nsplit = 1;
+      }
       (void)hipFuncSetAttribute((const void *)k_cross_attn_dma<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(k_cross_attn_dma<8>, dim3(dcl_div_up(nq, 256), b), dim3(512), lds, s, nq, nk, Q, ldq, K, ldk, V1,
-                         ldv1, O1, ldo1, V2, ldv2, O2, ldo2, (float *)nullptr);
+      hipLaunchKernelGGL(k_cross_attn_dma<8>, dim3(dcl_div_up(nq, 256), b, nsplit), dim3(512), lds, s, nq, nk, Q, ldq, K, ldk,
+                         V1, ldv1, O1, ldo1, V2, ldv2, O2, ldo2, scratch);
+      if (nsplit > 1)
+        hipLaunchKernelGGL(k_cross_attn_combine, dim3(dcl_grid_1d((long long)b * nq * 80, 256)), dim3(256), 0, s, b * nq,
+                           nsplit, scratch, O1, ldo1, O2, ldo2);
     } else {
       // few workgroups (small batches): split the keys over up to 8 workgroups per query block, >= 2 tiles per split
       const long long blocks4 = (long long)b * dcl_div_up(nq, 128);

@@ -471,8 +471,11 @@ def cross_attention(b, Q, K, V1, O1, V2=None, O2=None):
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
     scratch = None
-    if b * ((nq + 127) // 128) < 192 and dv1 == 256 and dv2 == 64:          # small launch: key-split partial records
-        scratch = torch.empty(8 * b * nq * 324, dtype=torch.float32, device=Q.device)
+    if dv1 == 256 and dv2 == 64:          # key-split partial records (small launches, badly quantised large ones)
+        need = C.c_int64(0)
+        N.check(N.lib().dcl_cross_attention_scratch_floats(b, nq, C.byref(need)), "cross_attention_scratch_floats")
+        if need.value:
+            scratch = torch.empty(need.value, dtype=torch.float32, device=Q.device)
     N.check(N.lib().dcl_cross_attention_ws(b, nq, nk, N.ptr(Q), _ld(Q), N.ptr(K), _ld(K), N.ptr(V1), dv1, _ld(V1),
                                            N.ptr(O1), _ld(O1), N.ptr(V2), dv2, 0 if V2 is None else _ld(V2), N.ptr(O2),
                                            0 if O2 is None else _ld(O2), N.ptr(scratch),

@@ -381,17 +381,37 @@ def test_cross_attention_key_split(dcl):
     V1, V2 = torch.randn(b, nk, 256, generator=g), torch.randn(b, nk, 64, generator=g)
     want = _attn_ref(Q, K, torch.cat([V1, V2], 2))
     lib = dcl._native.lib()
+    Kd, V1d, V2d = K.cuda().reshape(-1, 64), V1.cuda().reshape(-1, 256), V2.cuda().reshape(-1, 64)
     try:
-        for split in (0, 1, 2, 3, 5, 8):
-            lib.dcl_debug_attention_split(split)
-            O1 = torch.empty(b * nq, 256, device="cuda")
-            O2 = torch.empty(b * nq, 64, device="cuda")
-            dcl.ops.cross_attention(b, Q.cuda().reshape(-1, 64), K.cuda().reshape(-1, 64), V1.cuda().reshape(-1, 256), O1,
-                                    V2.cuda().reshape(-1, 64), O2)
-            got = torch.cat([O1.view(b, nq, 256), O2.view(b, nq, 64)], 2).double().cpu()
-            assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max())), split
+        for variant in (0, 3):                     # 4-wave kernel (small launch) and the 8-wave one (badly quantised grids)
+            lib.dcl_debug_attention_variant(variant)
+            for split in (0, 1, 2, 3, 5, 8):
+                lib.dcl_debug_attention_split(split)
+                O1 = torch.empty(b * nq, 256, device="cuda")
+                O2 = torch.empty(b * nq, 64, device="cuda")
+                # the wrapper sizes the scratch for the automatic choice; forced splits get the full amount
+                scratch = torch.empty(8 * b * nq * 324, device="cuda")
+                N = dcl.ops.N
+                N.check(lib.dcl_cross_attention_ws(b, nq, nk, N.ptr(Q.cuda()), 64, N.ptr(Kd), 64, N.ptr(V1d), 256, 256,
+                                                   N.ptr(O1), 256, N.ptr(V2d), 64, 64, N.ptr(O2), 64, N.ptr(scratch),
+                                                   dcl.ops.C.c_int64(scratch.numel()), N.stream()), "attn")
+                got = torch.cat([O1.view(b, nq, 256), O2.view(b, nq, 64)], 2).double().cpu()
+                assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max())), (variant, split)
     finally:
         lib.dcl_debug_attention_split(0)
+        lib.dcl_debug_attention_variant(0)
+    # automatic choice on a badly quantised large launch: 5 query blocks x 64 crops = 320 workgroups -> split
+    b2, nq2, nk2 = 64, 1280, 96
+    g2 = torch.Generator().manual_seed(6)
+    Q2, K2 = torch.randn(b2, nq2, 64, generator=g2), torch.randn(b2, nk2, 64, generator=g2) * 0.3
+    V12, V22 = torch.randn(b2, nk2, 256, generator=g2), torch.randn(b2, nk2, 64, generator=g2)
+    O1 = torch.empty(b2 * nq2, 256, device="cuda")
+    O2 = torch.empty(b2 * nq2, 64, device="cuda")
+    dcl.ops.cross_attention(b2, Q2.cuda().reshape(-1, 64), K2.cuda().reshape(-1, 64), V12.cuda().reshape(-1, 256), O1,
+                            V22.cuda().reshape(-1, 64), O2)
+    want2 = _attn_ref(Q2[:4], K2[:4], torch.cat([V12, V22], 2)[:4])
+    got2 = torch.cat([O1.view(b2, nq2, 256), O2.view(b2, nq2, 64)], 2)[:4].double().cpu()
+    assert float((got2 - want2).abs().max()) <= 2e-5 * max(1.0, float(want2.abs().max()))
 
 
 def test_cross_attention_dma_variant_ragged_and_rescale(dcl):
