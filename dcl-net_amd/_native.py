@@ -37,6 +37,10 @@ def lib():
             L.dcl_debug_force_valu_conv(int(os.environ["DCL_CONV_VARIANT"]))
         if os.environ.get("DCL_CONV_SPLIT"):
             L.dcl_debug_conv_split(int(os.environ["DCL_CONV_SPLIT"]))
+        if os.environ.get("DCL_ATTN_SPLIT"):
+            L.dcl_debug_attention_split(int(os.environ["DCL_ATTN_SPLIT"]))
+        if os.environ.get("DCL_ATTN_VARIANT"):
+            L.dcl_debug_attention_variant(int(os.environ["DCL_ATTN_VARIANT"]))
         _LIB = L
     return _LIB
 
