@@ -279,7 +279,8 @@ def test_grouping_modules_match_the_composed_oracle(dcl, oracle):
     assert np.array_equal(pu.KNNAndGroup(r, ns)(cuda(xyz), cuda(new), None, cuda(feats)).cpu().numpy(), wantk)
 
 
-@pytest.mark.parametrize("n,m", [(1024, 128), (12288, 64), (777, 100), (100, 20), (40, 10), (2048, 33)])
+@pytest.mark.parametrize("n,m", [(1024, 128), (12288, 64), (777, 100), (100, 20), (40, 10), (2048, 33), (5000, 50), (16384, 20),
+                                 (16385, 9)])
 def test_fps_bit_exact_with_ties(dcl, oracle, n, m):
     rng = np.random.default_rng(n)
     xyz = _cloud(rng, 2, n, dup=0.3)
