@@ -489,3 +489,62 @@ def test_add_s_matches_reference_expression(dcl):
     assert float((got - want).abs().max()) <= 1e-6
     same = dcl.ops.add_s(clouds[:b].cuda(), Rp.cuda(), tp.cuda(), Rp.cuda(), tp.cuda()).cpu()
     assert float(same.abs().max()) == 0.0                      # identical poses: every point matches itself exactly
+
+
+# ------------------------------------------------------------------------------------------- native backbone runner
+def _edge_voxels(rng, S=64):
+    """crop 0: random blob touching the 0 and S-1 faces; crop 1: EMPTY; crop 2: one voxel in a corner; crop 3: dense 6^3 block
+    plus scattered voxels; crop 4: a 1-voxel-thick plane"""
+    rows = []
+    blob = rng.integers(0, S, (400, 3))
+    blob[:40, 0] = 0
+    blob[40:80, 1] = S - 1
+    blob[80:120, 2] = rng.choice([0, S - 1], 40)
+    rows.append((0, np.unique(blob, axis=0)))
+    rows.append((2, np.array([[S - 1, 0, S - 1]])))
+    g = np.stack(np.meshgrid(np.arange(6), np.arange(6), np.arange(6), indexing="ij"), -1).reshape(-1, 3) + 20
+    rows.append((3, np.unique(np.concatenate([g, rng.integers(0, S, (150, 3))]), axis=0)))
+    pl = np.stack(np.meshgrid(np.arange(10, 40), np.arange(5, 45), indexing="ij"), -1).reshape(-1, 2)
+    rows.append((4, np.concatenate([pl[:, :1], np.full((len(pl), 1), 31), pl[:, 1:]], 1)))
+    occ = np.concatenate([np.concatenate([np.full((len(v), 1), b), v], 1) for b, v in rows]).astype(np.int32)
+    out = []
+    for b, v in rows:                                    # unsorted inside a crop, crops in order (like voxelize_idx output)
+        sel = occ[occ[:, 0] == b]
+        out.append(sel[rng.permutation(len(sel))])
+    return np.concatenate(out), 5
+
+
+def test_backbone_runner_edge_cases(dcl, oracle):
+    """native runner (geometry + features + point read-out, implicit rulebooks, split-K) vs the oracle backbone on awkward
+    active sets: an empty crop inside the batch, border voxels, a single-voxel crop, a dense block, a thin plane"""
+    from oracle import graph as G
+    rng = np.random.default_rng(17)
+    occ, b = _edge_voxels(rng)
+    S = 64
+    cfg = dcl.synth.default_cfg(64, 64)
+    net = dcl.DCL_Net.Network(cfg, mode="test")
+    sd = dcl.synth.synth_state_dict(net, 5)
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    f = net._fold()
+    vox = rng.normal(size=(occ.shape[0], 7)).astype(np.float32)
+    want = G.backbone(sd, "backbone_inp", vox, occ, [S] * 3, b)
+    run = dcl.ops.BackboneRun(cuda(occ), b, S)
+    run.set_counts(run.counts_dev.cpu().tolist())
+    levels = run.features(cuda(vox), *f["backbone_inp_ptrs"])
+    for m, (wf, wi) in enumerate(want):
+        assert np.array_equal(run.level_indices(m).cpu().numpy(), wi), m
+        got = levels[m].cpu().numpy()
+        assert got.shape == wf.shape
+        assert np.abs(got - wf).max() <= 5e-5 * max(1.0, np.abs(wf).max()), m
+    # point read-out: points of every crop, including the crop that has no voxel at all (its rows stay unmatched: idx 0)
+    n_per = 50
+    pts = rng.uniform(-0.19, 0.19, (b * n_per, 3)).astype(np.float32)
+    pb4 = np.concatenate([np.repeat(np.arange(b, dtype=np.float32), n_per)[:, None], pts], 1)
+    unit = 0.006
+    off = float(np.float32(-0.5 * unit * 64))
+    extents = [float(np.float32(unit * sc)) for sc in (2, 4, 6, 8)]
+    got_pf = run.point_features(cuda(pb4), extents, off).cpu().numpy()
+    want_pf = G.point_feats(torch.from_numpy(pb4), want, [unit] * 3, [64] * 3).numpy()
+    live = pb4[:, 0] != 1                                             # crop 1 is empty: the reference interpolates garbage there
+    assert np.abs(got_pf[live] - want_pf[live]).max() <= 5e-5 * max(1.0, np.abs(want_pf[live]).max())
