@@ -522,11 +522,15 @@ __global__ __launch_bounds__(64 * WR * WCW, 2) void k_sparse_conv_dma(
     const int row0 = blk * BM;
     if (tid == 0) *s_kmask = 0;
     __syncthreads();
+    // neighbour rows of the offsets this workgroup's chunk range touches (all 27 without split-K)
     unsigned mymask = 0;
-    for (int e = tid; e < kvol * BM; e += NTHR) {
-      const int k = e / BM, rr = e - k * BM;
+    const int sx_lo = (j_begin * KC) / CIN;
+    const int sx_hi = min(kvol - 1, (nchunks * KC - 1) / CIN);
+    for (int e = tid; e < (sx_hi - sx_lo + 1) * BM; e += NTHR) {
+      const int si = e / BM, rr = e - si * BM;
+      const int k = offset_at(sx_lo + si, kvol, subm);
       const int v = (row0 + rr < n) ? dcl_nbr_at(src, cap, k, row0 + rr) : -1;
-      Ns[e] = v;
+      Ns[k * BM + rr] = v;
       mymask |= (v >= 0 ? 1u : 0u) << k;
     }
 #pragma unroll
