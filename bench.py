@@ -325,6 +325,12 @@ def main():
                                  "attention_TFLOPs": round(rflop / (np.mean(ratt) * 1e-3) / 1e12, 2) if ratt else None}
             rdata_for_pipe = (rcfg, rdata)
             del rnet
+        # the same forward fed from the loader's HOST tensors (pageable memory, H2D inside forward) -- never `value`
+        hdt, _ = run_forward_bench(dcl, net, host_data, max(3, args.steps // 2), 1, False)
+        hsteps = max(3, args.steps // 2)
+        line["h2d_inclusive"] = {"value": round(b * hsteps / hdt, 2), "unit": "frames/s",
+                                 "ms_per_step": round(hdt / hsteps * 1e3, 3),
+                                 "what": "data dict on the host (pageable), uploaded inside forward()"}
         if not args.pipelined_calls:
             line["pipelined_calls"] = pipelined_bench(dcl, dev, sd, cfg, data, b, args.steps, args.warmup, rdata_for_pipe)
         line["lm_stream"] = lm_stream_bench(dcl, dev)
