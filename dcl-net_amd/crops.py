@@ -151,6 +151,9 @@ class CropBuilder(object):
         for side, feats, coords in (("inp", feats_inp, coords_inp), ("tmp", feats_tmp, coords_tmp)):
             occ, p2v, v2p = ops.voxelize_idx_gpu(coords, b, S, self.mode)
             data[side] = {"feats": feats, "coords": coords, "occupied_voxels": occ, "p2v_maps": p2v, "v2p_maps": v2p}
+        # a Network(async_inputs=True) lets its side streams wait for exactly this point instead of the whole stream
+        data["ready_event"] = torch.cuda.Event()
+        data["ready_event"].record(torch.cuda.current_stream(dev))
         return data
 
     def build_lm(self, img, depth, mask_label, obj_bb, obj, eval_mode=False):

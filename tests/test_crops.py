@@ -125,6 +125,17 @@ def test_built_crops_run_through_the_network(dcl):
         out = net(data)
     b = int(data["all_flags"].sum())
     assert out["rot_pred"].shape == (b, 3, 3) and torch.isfinite(out["rot_pred"]).all()
+    # the same crops through a pipelining network: its side streams wait on the builder's ready_event only
+    anet = dcl.DCL_Net.Network(dcl.synth.default_cfg(256, 256), mode="test", async_inputs=True)
+    anet.load_state_dict(dcl.synth.synth_state_dict(anet, 1))
+    anet = anet.cuda().eval()
+    for _ in range(3):
+        np.random.seed(7)
+        d2 = builder.build(sc["img"], sc["depth"], sc["label"], sc["rois"], sc["gt_obj"])
+        assert d2["ready_event"] is not None
+        with torch.no_grad():
+            out2 = anet(d2)
+        assert torch.equal(out2["rot_pred"], out["rot_pred"]) and torch.equal(out2["trans_pred"], out["trans_pred"])
     want = _oracle_build(sc, cfg, 7)
     with torch.no_grad():
         ref = net({k: v for k, v in want.items()})
