@@ -341,7 +341,7 @@ template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_cross_attn_dma(
     int nq, int nk, const float *__restrict__ Q, int ldq, const float *__restrict__ K, int ldk,
     const float *__restrict__ V1, int ldv1, float *__restrict__ O1, int ldo1,
-    const float *__restrict__ V2, int ldv2, float *__restrict__ O2, int ldo2, float *__restrict__ part) {
+    const float *__restrict__ V2, int ldv2, float *__restrict__ O2, int ldo2, float *__restrict__ part, int xcd_remap) {
   constexpr int NVT = 10;
   constexpr int KT = 32 * kKPitch;                 // K tile floats
   constexpr int V1T = 32 * 256, V2T = 32 * 64;     // per-buffer floats
@@ -349,17 +349,28 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_cross_attn_dma(
   float *Ks = attn_lds;
   float *V1s = Ks + KT;
   float *V2s = V1s + 2 * V1T;
-  const int b = blockIdx.y;
+  // XCD-aware placement: consecutive workgroup ids are dealt round-robin over the 8 XCDs (each with its own L2), so the
+  // query blocks of one crop -- which all stream the same K/V -- would land on 8 different L2s.  Renumber bijectively so
+  // that the workgroups sharing an XCD walk consecutive (query block, crop) ids: a crop's K/V tiles are then fetched once
+  // per XCD group instead of once per query block (a pure speed / traffic choice, never a correctness one).
+  int bx, b;
+  {
+    const int nwg = gridDim.x * gridDim.y, id = blockIdx.x + gridDim.x * blockIdx.y;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = id & 7;
+    const int swz = !xcd_remap ? id : (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (id >> 3);
+    bx = swz % (int)gridDim.x;
+    b = swz / (int)gridDim.x;
+  }
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   constexpr int QB = WAVES * 32;                   // queries per workgroup
-  const int q = blockIdx.x * QB + wave * 32 + r;
+  const int q = bx * QB + wave * 32 + r;
   const bool qlive = q < nq;
   float *Qs = V2s + 2 * V2T + wave * 32 * kKPitch;
   for (int i = lane; i < 32 * 16; i += 64) {
     const int qr = i >> 4, c4 = (i & 15) * 4;
-    const int qq = blockIdx.x * QB + wave * 32 + qr;
+    const int qq = bx * QB + wave * 32 + qr;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (qq < nq) v = *reinterpret_cast<const float4 *>(Q + ((size_t)b * nq + qq) * ldq + c4);
     *reinterpret_cast<float4 *>(Qs + qr * kKPitch + c4) = v;
@@ -705,7 +716,9 @@ __global__ void k_ortho9d(int b, const float *__restrict__ o9, float *__restrict
 
 static int g_attn_variant = 0;   // test hook: 1 = shared-tile 8-wave kernel, 2 = 4-wave register-staged, 3 / 4 = LDS-DMA pipeline with 8 / 4 waves
 static int g_attn_split = 0;            // tuning hook: 0 = automatic key split of small attention launches, n = force n
+static int g_attn_xcd_remap = 1;        // tuning hook: 0 = plain blockIdx order (for traffic comparisons)
 DCL_API void dcl_debug_attention_split(int n) { g_attn_split = n; }
+DCL_API void dcl_debug_attention_xcd_remap(int on) { g_attn_xcd_remap = on; }
 DCL_API void dcl_debug_attention_variant(int v) { g_attn_variant = v; }
 
 DCL_API int dcl_cross_attention(int b, int nq, int nk, const float *Q, int ldq, const float *K, int ldk,
@@ -779,7 +792,7 @@ DCL_API int dcl_cross_attention_ws(int b, int nq, int nk, const float *Q, int ld
       }
       (void)hipFuncSetAttribute((const void *)k_cross_attn_dma<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(k_cross_attn_dma<8>, dim3(dcl_div_up(nq, 256), b, nsplit), dim3(512), lds, s, nq, nk, Q, ldq, K, ldk,
-                         V1, ldv1, O1, ldo1, V2, ldv2, O2, ldo2, scratch);
+                         V1, ldv1, O1, ldo1, V2, ldv2, O2, ldo2, scratch, g_attn_xcd_remap);
       if (nsplit > 1)
         hipLaunchKernelGGL(k_cross_attn_combine, dim3(dcl_grid_1d((long long)b * nq * 80, 256)), dim3(256), 0, s, b * nq,
                            nsplit, scratch, O1, ldo1, O2, ldo2);
@@ -797,7 +810,7 @@ DCL_API int dcl_cross_attention_ws(int b, int nq, int nk, const float *Q, int ld
       }
       (void)hipFuncSetAttribute((const void *)k_cross_attn_dma<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(k_cross_attn_dma<4>, dim3(dcl_div_up(nq, 128), b, nsplit), dim3(256), lds, s, nq, nk, Q, ldq, K,
-                         ldk, V1, ldv1, O1, ldo1, V2, ldv2, O2, ldo2, scratch);
+                         ldk, V1, ldv1, O1, ldo1, V2, ldv2, O2, ldo2, scratch, g_attn_xcd_remap);
       if (nsplit > 1)
         hipLaunchKernelGGL(k_cross_attn_combine, dim3(dcl_grid_1d((long long)b * nq * 80, 256)), dim3(256), 0, s, b * nq,
                            nsplit, scratch, O1, ldo1, O2, ldo2);

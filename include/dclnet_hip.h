@@ -344,6 +344,9 @@ void dcl_debug_force_valu_conv(int on);
 void dcl_debug_attention_variant(int v);
 /* Tuning hook: 0 = automatic key split of small attention launches (dcl_cross_attention_ws), n = force n splits. */
 void dcl_debug_attention_split(int n);
+/* Tuning hook: 1 (default) = the LDS-DMA attention kernel renumbers its workgroups so that the query blocks of one crop share
+ * an XCD (one L2 fetch of the crop's K/V per XCD group), 0 = plain blockIdx order (traffic A/B). */
+void dcl_debug_attention_xcd_remap(int on);
 /* Tuning hook: 0 = automatic split-K choice in dcl_sparse_conv_fwd_ws, n = force n splits (when the scratch allows). */
 void dcl_debug_conv_split(int n);
 /* Tuning hook for dcl_group_points' LDS-staged kernel: channel rows per workgroup, x-blocks, threads per workgroup,
