@@ -22,6 +22,7 @@ int dcl_internal_sparse_conv_fwd(const float *feat, const DclNbrSrc &nbr, int ca
                                  int n_out_host, const float *W, int cin, int cout, int kvol, int subm, const float *scale,
                                  const float *shift, int relu, float *out, float *scratch, int64_t scratch_floats,
                                  dclStream_t stream);
+int dcl_internal_conv_split_cap(long long rows);
 int dcl_internal_sparse_avgpool_fwd(const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev,
                                     int n_out_host, int c, int kvol, float *out, int32_t *rf, dclStream_t stream);
 int dcl_three_nn_sp_voxels(int n, int m, const float *unknown, const int32_t *known_indices, float ve, float off,
@@ -103,7 +104,8 @@ bool make_feat_layout(const int32_t *counts, const int *chan /*9*/, FeatLayout *
       if (cout % 64 != 0 || nc == 0) continue;
       const size_t tiles = ((nc + 127) / 128) * (cout % 128 == 0 ? cout / 128 : cout / 64);
       size_t split = (1024 + tiles - 1) / tiles;
-      if (split > 8) split = 8;
+      const size_t most = (size_t)dcl_internal_conv_split_cap((long long)nc);
+      if (split > most) split = most;
       if (split > 1 && split * nc * cout > scratch) scratch = split * nc * cout;
     }
   }

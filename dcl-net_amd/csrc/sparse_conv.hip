@@ -666,8 +666,10 @@ __global__ void k_conv_split_reduce(const float *__restrict__ partial, int nspli
   }
 }
 
-constexpr int kConvMaxSplit = 8;
-static int g_conv_split = 0;           // tuning hook: 0 = automatic, n = force n-way split-K when scratch allows
+constexpr int kConvMaxSplit = 8;       // K-splits of a launch with many row tiles
+constexpr int kConvFewRows = 4096;     // at most this many output rows (capacity): up to one split per kernel offset
+static int conv_split_cap(long long rows) { return rows <= kConvFewRows ? 27 : kConvMaxSplit; }
+static int g_conv_split = 0;           // tuning hook: 0 = automatic, n = force n-way split-K when scratch allows, -1 = never more than kConvMaxSplit
 
 template <int CIN, int WR, int WCW, int NT>
 static void launch_conv_dma(int rows, const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev,
@@ -680,13 +682,16 @@ static void launch_conv_dma(int rows, const float *feat, const DclNbrSrc &nbr, i
                             (int)lds);
   const int nblk = dcl_div_up(rows, BM);
   const int tiles = nblk * (cout / BN);
-  // split-K until ~4 workgroups per CU are in the grid (2 resident + 2 waiting), each split keeping >= 8 chunks
+  // split-K until ~4 workgroups per CU are in the grid (2 resident + 2 waiting), each split keeping >= 8 chunks; a
+  // handful of crops (one-image calls) is latency-bound on the chunk loop instead: split down to 4 chunks per workgroup
   const int nchunks = dcl_div_up(kvol * CIN, KC);
   int nsplit = 1;
   if (scratch) {
+    const bool few_rows = rows <= kConvFewRows && g_conv_split >= 0;
     nsplit = g_conv_split > 0 ? g_conv_split : dcl_div_up(1024, tiles);
-    if (nsplit > kConvMaxSplit) nsplit = kConvMaxSplit;
-    if (nsplit > nchunks / 8) nsplit = nchunks / 8;
+    const int most = few_rows ? 27 : kConvMaxSplit;
+    if (nsplit > most) nsplit = most;
+    if (nsplit > nchunks / (few_rows ? 4 : 8)) nsplit = nchunks / (few_rows ? 4 : 8);
     while (nsplit > 1 && (long long)nsplit * cap * cout > scratch_floats) --nsplit;
     if (nsplit < 1) nsplit = 1;
   }
@@ -779,9 +784,12 @@ DCL_API void dcl_debug_force_valu_conv(int on) { g_force_valu = on; }
 
 DCL_API void dcl_debug_conv_split(int n) { g_conv_split = n; }
 
+// most K-splits a conv launch over `rows` output rows may use (sizes the partial-sum scratch; backbone.hip)
+int dcl_internal_conv_split_cap(long long rows) { return conv_split_cap(rows); }
+
 DCL_API int dcl_sparse_conv_scratch_floats(int rows_cap, int cout, int64_t *floats_host) {
   DCL_CHECK_ARG(rows_cap >= 0 && cout > 0 && floats_host);
-  *floats_host = (int64_t)kConvMaxSplit * rows_cap * cout;
+  *floats_host = (int64_t)conv_split_cap(rows_cap) * rows_cap * cout;
   return 0;
 }
 
