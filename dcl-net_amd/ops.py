@@ -178,7 +178,9 @@ def sparse_conv(feat, nbr, n_out, W, subm, scale=None, shift=None, relu=False):
     # split-K scratch for layers with few row tiles (csrc/sparse_conv.hip::launch_conv_dma); none needed for big ones
     scratch = None
     if cout % 64 == 0 and n_out <= 128 * 1024:
-        scratch = torch.empty(8 * cap * cout, dtype=torch.float32, device=feat.device)
+        need = C.c_int64(0)
+        N.check(N.lib().dcl_sparse_conv_scratch_floats(int(cap), int(cout), C.byref(need)), "sparse_conv_scratch_floats")
+        scratch = torch.empty(need.value, dtype=torch.float32, device=feat.device)
     N.check(N.lib().dcl_sparse_conv_fwd_ws(N.ptr(feat), N.ptr(nbr), cap, N.vp(0), int(n_out), N.ptr(W), cin, cout, kvol,
                                            int(bool(subm)), N.ptr(scale), N.ptr(shift), int(bool(relu)), N.ptr(out),
                                            N.ptr(scratch), C.c_int64(0 if scratch is None else scratch.numel()),

@@ -134,7 +134,8 @@ int dcl_sparse_conv_fwd(const float *feat, const int32_t *nbr, int cap, const in
                         dclStream_t stream);
 
 /* Same, with caller scratch: layers whose row count cannot fill the GPU split the 27*Cin contraction over up to 8
- * workgroup groups (partial sums in `scratch`, added in split order by a second kernel, then the epilogue).
+ * workgroup groups -- up to 27, one per kernel offset, when cap <= 4096 rows (one-image calls are latency-bound on the
+ * contraction loop) -- with partial sums in `scratch`, added in split order by a second kernel, then the epilogue.
  * scratch_floats >= dcl_sparse_conv_scratch_floats(cap, cout) enables every split; NULL = dcl_sparse_conv_fwd.   */
 int dcl_sparse_conv_fwd_ws(const float *feat, const int32_t *nbr, int cap, const int32_t *n_out_dev,
                            int n_out_host, const float *W, int cin, int cout, int kvol, int subm,
