@@ -39,6 +39,8 @@ def lib():
             L.dcl_debug_conv_split(int(os.environ["DCL_CONV_SPLIT"]))
         if os.environ.get("DCL_ATTN_SPLIT"):
             L.dcl_debug_attention_split(int(os.environ["DCL_ATTN_SPLIT"]))
+        if os.environ.get("DCL_NN_GRID"):
+            L.dcl_debug_three_nn_grid(int(os.environ["DCL_NN_GRID"]))
         if os.environ.get("DCL_ATTN_XCD"):
             L.dcl_debug_attention_xcd_remap(int(os.environ["DCL_ATTN_XCD"]))
         if os.environ.get("DCL_ATTN_VARIANT"):

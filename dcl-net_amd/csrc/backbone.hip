@@ -27,7 +27,7 @@ int dcl_internal_sparse_avgpool_fwd(const float *feat, const DclNbrSrc &nbr, int
                                     int n_out_host, int c, int kvol, float *out, int32_t *rf, dclStream_t stream);
 int dcl_three_nn_sp_voxels(int n, int m, const float *unknown, const int32_t *known_indices, float ve, float off,
                            float *dist2, int32_t *idx, const int32_t *known_seg, int nbatch, int seg_stride,
-                           dclStream_t stream);
+                           const uint32_t *known_mask, int S, dclStream_t stream);
 int dcl_three_nn_sp_strided(int n, int m, const float *unknown, const float *known, float *dist2, int32_t *idx,
                             const int32_t *known_seg, int nbatch, int seg_stride, dclStream_t stream);
 
@@ -376,9 +376,60 @@ static int point_features(int n, const float *points_b4, int batch, int S, int V
     const int wpc = p.S * p.S * p.S / 32;           // mask words per crop (S >= 4 -> >= 2)
     // voxel centres are formed inside the 3-NN kernel while it stages its tiles (no k_voxel_centres launch)
     rc = dcl_three_nn_sp_voxels(n, np, points_b4, at<int32_t>(ws, p.indices), voxel_extent_host[m], offset, dist2, idx,
-                                at<int32_t>(ws, p.wprefix), batch, wpc, stream);
+                                at<int32_t>(ws, p.wprefix), batch, wpc, at<uint32_t>(ws, p.mask), p.S, stream);
     if (rc) return rc;
     rc = dcl_three_interpolate_dist2_sp(c, np, n, level_feats[m], idx, dist2, out + col, ld, stream);
+    if (rc) return rc;
+    col += c;
+  }
+  return 0;
+}
+
+// ---- the read-out in two halves (searches | interpolation), see include/dclnet_hip.h
+static int point_neighbours(int n, const float *points_b4, int batch, int S, int V0, void *ws,
+                            const int32_t *counts_host, const float *voxel_extent_host, float offset, float *dist2,
+                            int32_t *idx, dclStream_t stream) {
+  GeoLayout L;
+  DCL_CHECK_ARG(n >= 0 && points_b4 && ws && counts_host && voxel_extent_host && dist2 && idx &&
+                make_geo_layout(batch, S, V0, &L));
+  if (n == 0) return 0;
+  for (int m = 0; m < kLevels; ++m) {
+    const SetLayout &p = L.pool[m];
+    const int wpc = p.S * p.S * p.S / 32;
+    int rc = dcl_three_nn_sp_voxels(n, counts_host[2 * m + 1], points_b4, at<int32_t>(ws, p.indices), voxel_extent_host[m],
+                                    offset, dist2 + (size_t)m * n * 3, idx + (size_t)m * n * 3, at<int32_t>(ws, p.wprefix),
+                                    batch, wpc, at<uint32_t>(ws, p.mask), p.S, stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+DCL_API int dcl_point_neighbours(int n, const float *points_b4, int batch, int S, int V0, void *ws,
+                                 const int32_t *counts_host, const float *voxel_extent_host, float offset, float *dist2,
+                                 int32_t *idx, dclStream_t stream) {
+  return point_neighbours(n, points_b4, batch, S, V0, ws, counts_host, voxel_extent_host, offset, dist2, idx, stream);
+}
+
+DCL_API int dcl_point_neighbours_cap(int n, const float *points_b4, int batch, int S, int V0_cap, void *ws,
+                                     const float *voxel_extent_host, float offset, float *dist2, int32_t *idx,
+                                     dclStream_t stream) {
+  int32_t caps[8];
+  int rc = dcl_backbone_caps(batch, S, V0_cap, caps);
+  if (rc) return rc;
+  return point_neighbours(n, points_b4, batch, S, V0_cap, ws, caps, voxel_extent_host, offset, dist2, idx, stream);
+}
+
+DCL_API int dcl_point_interpolate(int n, const int32_t *counts_host, const int32_t *channels_host,
+                                  const float *const *level_feats, const float *dist2, const int32_t *idx, float *out,
+                                  int ld, dclStream_t stream) {
+  DCL_CHECK_ARG(n >= 0 && counts_host && channels_host && level_feats && dist2 && idx && out);
+  if (n == 0) return 0;
+  int col = 0;
+  for (int m = 0; m < kLevels; ++m) {
+    const int c = channels_host[2 * m + 2];
+    DCL_CHECK_ARG(col + c <= ld);
+    int rc = dcl_three_interpolate_dist2_sp(c, counts_host[2 * m + 1], n, level_feats[m], idx + (size_t)m * n * 3,
+                                            dist2 + (size_t)m * n * 3, out + col, ld, stream);
     if (rc) return rc;
     col += c;
   }

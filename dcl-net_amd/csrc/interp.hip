@@ -113,6 +113,75 @@ __global__ __launch_bounds__(64) void k_three_nn_sp(int n, int m, const float4 *
   }
 }
 
+// Exact 3-NN against one level of the backbone's occupancy grid (S <= 32, word-aligned z rows), one thread per query:
+// only the 5x5x5 cells around the query's own cell are visited (their rows come from the bitmask rank, their centres
+// from the cell coordinates -- the same fp32 expressions as voxel_centre / dcl_dist2, so keys are bit-identical to the
+// brute-force kernel's).  Every unvisited voxel lies >= `bound` away along one axis; if the third-best distance found
+// is below that (with a 1e-4 margin for rounding) the answer is the global one, ties included (keys order (d, row)
+// exactly like the sequential scan of interpolate_gpu.cu:36-38).  Otherwise -- isolated queries, queries outside
+// the grid -- the thread scans its crop's rows.
+__global__ __launch_bounds__(256) void k_three_nn_grid(int n, const float4 *__restrict__ unknown,
+                                                       const int4 *__restrict__ indices, const uint32_t *__restrict__ mask,
+                                                       const int32_t *__restrict__ wprefix, int nbatch, int S, int wpc,
+                                                       float ve, float off, float *__restrict__ dist2,
+                                                       int32_t *__restrict__ idx, int force_scan) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const float4 u = unknown[p];
+  const float half = 0.5f * ve;
+  Top3 b; b.init();
+  const int bi = (int)u.x;
+  if (bi >= 0 && bi < nbatch && (float)bi == u.x) {
+    const float pc[3] = {u.y, u.z, u.w};
+    int lo[3], hi[3];
+    float bound = INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float f = floorf((pc[a] - off) / ve);
+      const int ci = f >= (float)(S - 1) ? S - 1 : (f > 0.0f ? (int)f : 0);            // NaN -> 0
+      lo[a] = max(ci - 2, 0); hi[a] = min(ci + 2, S - 1);
+      if (ci - 3 >= 0) bound = fminf(bound, pc[a] - (((float)(ci - 3) * ve + off) + half));
+      if (ci + 3 <= S - 1) bound = fminf(bound, (((float)(ci + 3) * ve + off) + half) - pc[a]);
+    }
+    const uint32_t zmask = (hi[2] - lo[2] == 31) ? 0xffffffffu : ((1u << (hi[2] - lo[2] + 1)) - 1u);
+    if (!force_scan)
+      for (int x = lo[0]; x <= hi[0]; ++x) {
+        const float qx = ((float)x * ve + off) + half;
+        for (int y = lo[1]; y <= hi[1]; ++y) {
+          const int lin0 = ((bi * S + x) * S + y) * S;
+          const int w = lin0 >> 5, sh = lin0 & 31;
+          const uint32_t m = mask[w];
+          uint32_t bits = (m >> (sh + lo[2])) & zmask;
+          if (bits == 0u) continue;
+          const int pre = wprefix[w];
+          const float qy = ((float)y * ve + off) + half;
+          while (bits) {
+            const int t = __builtin_ctz(bits);
+            bits &= bits - 1u;
+            const int z = lo[2] + t, pos = sh + z;
+            const int row = pre + __popc(m & ((1u << pos) - 1u));
+            const float qz = ((float)z * ve + off) + half;
+            b.push(make_key(dcl_dist2(u.y, u.z, u.w, qx, qy, qz), row));
+          }
+        }
+      }
+    const float d3 = __uint_as_float((unsigned)(b.k3 >> 32));
+    const bool certified = !force_scan && (bound == INFINITY || d3 < bound * bound * 0.9999f) && !(bound < 0.0f);
+    if (!certified) {
+      b.init();
+      const int r0 = wprefix[(size_t)bi * wpc], r1 = wprefix[(size_t)(bi + 1) * wpc];
+      for (int j = r0; j < r1; ++j) {
+        const float4 q = voxel_centre(indices[j], ve, off, half);
+        b.push(q.x == u.x ? make_key(dcl_dist2(u.y, u.z, u.w, q.y, q.z, q.w), j) : ~0ull);
+      }
+    }
+  }
+  dist2[p * 3 + 0] = __uint_as_float((unsigned)(b.k1 >> 32));
+  dist2[p * 3 + 1] = __uint_as_float((unsigned)(b.k2 >> 32));
+  dist2[p * 3 + 2] = __uint_as_float((unsigned)(b.k3 >> 32));
+  idx[p * 3 + 0] = (int)(unsigned)b.k1; idx[p * 3 + 1] = (int)(unsigned)b.k2; idx[p * 3 + 2] = (int)(unsigned)b.k3;
+}
+
 // voxel centres (Ops_tensor2points, models/Modules.py:204-211): fp32, left to right.
 __global__ void k_voxel_centres(const int4 *__restrict__ indices, const int32_t *__restrict__ n_dev, int n_host,
                                 float ve, float off, float4 *__restrict__ centres) {
@@ -255,12 +324,25 @@ int dcl_three_nn_sp_strided(int n, int m, const float *unknown, const float *kno
 }
 
 // internal: the known set is given as voxel rows (b,x,y,z) i32; their centres idx*ve + off + ve/2 are formed in the kernel
+static int g_nn_grid = 1;   // tuning/test hook: 0 = brute-force scan per crop for every level, 2 = grid kernel with the scan forced
+DCL_API void dcl_debug_three_nn_grid(int mode) { g_nn_grid = mode; }
+
+// known_mask / S (optional): the level's occupancy bits and grid size; with them, levels of S = 16 or 32 go through the
+// grid-pruned kernel (same results)
 int dcl_three_nn_sp_voxels(int n, int m, const float *unknown, const int32_t *known_indices, float ve, float off,
                            float *dist2, int32_t *idx, const int32_t *known_seg, int nbatch, int seg_stride,
-                           dclStream_t stream) {
+                           const uint32_t *known_mask, int S, dclStream_t stream) {
   DCL_CHECK_ARG(n >= 0 && m >= 0);
   if (n == 0) return 0;
   DCL_CHECK_ARG(unknown && dist2 && idx && (m == 0 || known_indices) && (!known_seg || (nbatch > 0 && seg_stride > 0)));
+  if (g_nn_grid && known_mask && known_seg && known_indices && (S == 16 || S == 32) && seg_stride == S * S * S / 32 &&
+      ve > 0.0f) {
+    hipLaunchKernelGGL(k_three_nn_grid, dim3(dcl_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n,
+                       reinterpret_cast<const float4 *>(unknown), reinterpret_cast<const int4 *>(known_indices), known_mask,
+                       known_seg, nbatch, S, seg_stride, ve, off, dist2, idx, g_nn_grid == 2 ? 1 : 0);
+    DCL_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(k_three_nn_sp<true>, dim3(dcl_div_up(n, 16)), dim3(64), 0, (hipStream_t)stream, n, m,
                      reinterpret_cast<const float4 *>(unknown), reinterpret_cast<const float4 *>(known_indices), dist2, idx,
                      known_seg, nbatch, seg_stride, ve, off);

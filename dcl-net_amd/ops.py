@@ -270,6 +270,28 @@ class BackboneRun(object):
                                            out.stride(0), N.ptr(tmp), tmp_bytes, N.stream()), "point_features")
         return out
 
+    def point_neighbours(self, points_b4, voxel_extents, offset):
+        """first half of point_features: the four 3-NN searches (need geometry + counts only, not the level features).
+        Returns (dist2, idx), each (4, n, 3)."""
+        n = points_b4.shape[0]
+        dev = points_b4.device
+        dist2 = torch.empty((4, n, 3), dtype=torch.float32, device=dev)
+        idx = torch.empty((4, n, 3), dtype=torch.int32, device=dev)
+        ve = (C.c_float * 4)(*[float(v) for v in voxel_extents])
+        N.check(N.lib().dcl_point_neighbours(n, N.ptr(points_b4), self.batch, self.S, self.V0, N.ptr(self.ws), self.ccounts,
+                                             ve, _c_float(offset), N.ptr(dist2), N.ptr(idx), N.stream()),
+                "point_neighbours")
+        return dist2, idx
+
+    def point_interpolate(self, dist2, idx, out=None):
+        """second half of point_features: inverse-distance interpolation of the four levels' features -> (n, 480)."""
+        n = idx.shape[1]
+        if out is None:
+            out = torch.empty((n, 480), dtype=torch.float32, device=idx.device)
+        N.check(N.lib().dcl_point_interpolate(n, self.ccounts, self.chan, _ptr_array(self.levels), N.ptr(dist2),
+                                              N.ptr(idx), N.ptr(out), out.stride(0), N.stream()), "point_interpolate")
+        return out
+
 
 class BackboneRunCap(object):
     """Capacity-mode backbone pass (whole-forward hipGraph capture): every buffer is sized from (batch, S, V0_cap) alone,
@@ -320,6 +342,20 @@ class BackboneRunCap(object):
 
     def tmp_bytes(self, n):
         return 2 * (((n * 12) + 255) // 256 * 256) + 16 * max(1, max(self.caps[1::2]))
+
+    def point_neighbours(self, points_b4, voxel_extents, offset, dist2, idx):
+        """dist2 / idx: static (4, n, 3) buffers (see BackboneRun.point_neighbours)"""
+        n = points_b4.shape[0]
+        ve = (C.c_float * 4)(*[float(v) for v in voxel_extents])
+        N.check(N.lib().dcl_point_neighbours_cap(n, N.ptr(points_b4), self.batch, self.S, self.V0, N.ptr(self.ws), ve,
+                                                 _c_float(offset), N.ptr(dist2), N.ptr(idx), N.stream()),
+                "point_neighbours_cap")
+
+    def point_interpolate(self, dist2, idx, out):
+        n = idx.shape[1]
+        N.check(N.lib().dcl_point_interpolate(n, self.caps, self.chan, self.level_ptrs, N.ptr(dist2), N.ptr(idx),
+                                              N.ptr(out), out.stride(0), N.stream()), "point_interpolate")
+        return out
 
 
 # ------------------------------------------------------------------------------------ pointnet_sp

@@ -195,6 +195,18 @@ int dcl_point_features(int n, const float *points_b4, int batch, int S, int V0, 
                        const int32_t *counts_host, const int32_t *channels_host,
                        const float *const *level_feats_host, const float *voxel_extent_host, float offset,
                        float *out, int ld, void *tmp, int64_t tmp_bytes, dclStream_t stream);
+/* The same read-out in two halves, so that a caller can overlap the searches with the convolutions: the 3-NN searches
+ * need the level geometry only (dcl_backbone_geometry), the interpolation needs the level features.
+ * dist2 / idx: 4 level blocks of n*3 entries each (level-major).  Results are identical to dcl_point_features.
+ * The _cap forms take dcl_backbone_caps' V0_cap (whole-forward hipGraph capture).                                   */
+int dcl_point_neighbours(int n, const float *points_b4, int batch, int S, int V0, void *ws, const int32_t *counts_host,
+                         const float *voxel_extent_host, float offset, float *dist2, int32_t *idx, dclStream_t stream);
+int dcl_point_neighbours_cap(int n, const float *points_b4, int batch, int S, int V0_cap, void *ws,
+                             const float *voxel_extent_host, float offset, float *dist2, int32_t *idx,
+                             dclStream_t stream);
+int dcl_point_interpolate(int n, const int32_t *counts_host, const int32_t *channels_host,
+                          const float *const *level_feats_host, const float *dist2, const int32_t *idx, float *out,
+                          int ld, dclStream_t stream);
 
 /* ----------------------------------------------------------- pointnet_sp ---
  * three_nn_wrapper(n, m, unknown(N,4), known(M,4), dist2(N,3), idx(N,3)):
@@ -348,6 +360,9 @@ void dcl_debug_attention_split(int n);
 /* Tuning hook: 1 (default) = the LDS-DMA attention kernel renumbers its workgroups so that the query blocks of one crop share
  * an XCD (one L2 fetch of the crop's K/V per XCD group), 0 = plain blockIdx order (traffic A/B). */
 void dcl_debug_attention_xcd_remap(int on);
+/* Test hook, 3-NN of the point read-out: 1 (default) = grid-pruned search on the 32^3 / 16^3 levels, 0 = per-crop scan on
+ * every level, 2 = grid kernel with its scan fallback forced for every query (all three give identical results). */
+void dcl_debug_three_nn_grid(int mode);
 /* Tuning hook: 0 = automatic split-K choice in dcl_sparse_conv_fwd_ws, n = force n splits (when the scratch allows). */
 void dcl_debug_conv_split(int n);
 /* Tuning hook for dcl_group_points' LDS-staged kernel: channel rows per workgroup, x-blocks, threads per workgroup,

@@ -548,3 +548,53 @@ def test_backbone_runner_edge_cases(dcl, oracle):
     want_pf = G.point_feats(torch.from_numpy(pb4), want, [unit] * 3, [64] * 3).numpy()
     live = pb4[:, 0] != 1                                             # crop 1 is empty: the reference interpolates garbage there
     assert np.abs(got_pf[live] - want_pf[live]).max() <= 5e-5 * max(1.0, np.abs(want_pf[live]).max())
+
+
+@pytest.mark.gpu
+def test_point_neighbours_grid_search_is_exact(dcl):
+    """the grid-pruned 3-NN of the point read-out (levels with 32^3 / 16^3 cells) returns bit-for-bit what the per-crop
+    scan returns -- distances, rows and tie order -- for surface points, lattice points (8-way ties), isolated and
+    out-of-grid queries (scan fallback), an empty crop and invalid crop ids; so does the split read-out API"""
+    rng = np.random.default_rng(23)
+    occ, b = _edge_voxels(rng)
+    S, unit = 64, 0.006
+    off = float(np.float32(-0.5 * unit * 64))
+    extents = [float(np.float32(unit * sc)) for sc in (2, 4, 8, 16)]
+    run = dcl.ops.BackboneRun(cuda(occ), b, S)
+    run.set_counts(run.counts_dev.cpu().tolist())
+    q = []
+    for bi in range(b):
+        own = occ[occ[:, 0] == bi][:, 1:4].astype(np.float32)
+        if len(own):
+            pick = own[rng.integers(0, len(own), 300)]
+            q.append(np.c_[np.full(300, bi), (pick + rng.uniform(0, 1, pick.shape)) * unit + off])      # points inside occupied voxels
+            q.append(np.c_[np.full(100, bi), (pick[:100] * unit + off).astype(np.float32)])             # voxel corners: lattice ties
+            q.append(np.c_[np.full(100, bi), ((pick[:100] // 2 * 2 + 1) * unit + off)])                 # level-0 cell centres / corners
+        q.append(np.c_[np.full(60, bi), rng.uniform(-0.192, 0.192, (60, 3))])                           # anywhere in the grid
+        q.append(np.c_[np.full(20, bi), rng.uniform(-0.5, 0.5, (20, 3))])                               # partly outside the grid
+    q.append(np.c_[np.array([-1.0, b, 0.5, np.nan]), np.zeros((4, 3))])                                 # crop ids that match nothing
+    pb4 = cuda(np.concatenate(q).astype(np.float32))
+    lib = dcl.ops.N.lib()
+    res = {}
+    try:
+        for mode in (0, 1, 2):
+            lib.dcl_debug_three_nn_grid(mode)
+            d, i = run.point_neighbours(pb4, extents, off)
+            res[mode] = (d.cpu().numpy(), i.cpu().numpy())
+    finally:
+        lib.dcl_debug_three_nn_grid(1)
+    for mode in (1, 2):
+        assert np.array_equal(res[mode][1], res[0][1]), mode
+        assert np.array_equal(res[mode][0].view(np.uint32), res[0][0].view(np.uint32)), mode
+    # the searched levels really had work to do, and the fallback was exercised (isolated queries exist)
+    assert np.isfinite(res[0][0][0]).all(axis=1).sum() > 1000
+    # the two halves compose to point_features
+    vox = cuda(rng.normal(size=(occ.shape[0], 7)).astype(np.float32))
+    cfg = dcl.synth.default_cfg(64, 64)
+    net = dcl.DCL_Net.Network(cfg, mode="test")
+    net.load_state_dict(dcl.synth.synth_state_dict(net, 5))
+    f = net.cuda().eval()._fold()
+    run.features(vox, *f["backbone_inp_ptrs"])
+    whole = run.point_features(pb4, extents, off)
+    halves = run.point_interpolate(*run.point_neighbours(pb4, extents, off))
+    assert torch.equal(torch.nan_to_num(whole), torch.nan_to_num(halves))     # NaN rows: queries without any voxel
