@@ -236,12 +236,11 @@ class Network(nn.Module):
             elif data.get("ready_event") is not None:
                 st.wait_event(data["ready_event"])
         # (4) What does not depend on the level sizes -- voxel means, the points' (crop, xyz) rows, output buffers -- is
-        # issued before the read-back so that it runs underneath it; the read-back itself waits for the geometry only (on
-        # the helper stream).  (5) The 3-NN searches of the point read-out need the level geometry, not the level
-        # features: they run on a helper stream beside the convolutions, and only the interpolation follows the last
-        # convolution (DCL_SPLIT_NN=0: searches and interpolation back to back, as in the reference).
-        nstream = {"inp": self._side_stream(dev, 2), "tmp": self._side_stream(dev, 3)}
-        split_nn = os.environ.get("DCL_SPLIT_NN", "1") != "0"
+        # issued before the read-back so that it runs underneath it; the read-back itself waits for the two geometry
+        # stages only (on a helper stream).  Running the 3-NN searches of the read-out beside the convolutions (they need
+        # the geometry only) and each level's interpolation as soon as that level is pooled was built and measured: the
+        # same step time within 0.1 % -- these kernels fill the GPU, so overlap only re-divides it -- and dropped.
+        rstream = self._side_stream(dev, 2)
         npts = {"inp": self.n_inp, "tmp": self.n_tmp}
         side_in, runs, geo, vox, pb4, pf, pts = {}, {}, {}, {}, {}, {}, {}
         for s in ("inp", "tmp"):
@@ -252,16 +251,15 @@ class Network(nn.Module):
                               d["occupied_voxels"].to(dev, non_blocking=True).int().contiguous())
                 for c in range(K):
                     runs[s, c] = ops.BackboneRun(side_in[s][2], bc, S, batch_lo=c * bc)
-                bid = (torch.arange(b, device=dev) % bc).float().repeat_interleave(npts[s]).unsqueeze(1)
-                pb4[s] = torch.cat([bid, side_in[s][0][:, 4:7]], 1).contiguous()   # (crop inside its chunk, x, y, z)
                 geo[s] = torch.cuda.Event()
                 geo[s].record(sstream[s])
+                bid = (torch.arange(b, device=dev) % bc).float().repeat_interleave(npts[s]).unsqueeze(1)
+                pb4[s] = torch.cat([bid, side_in[s][0][:, 4:7]], 1).contiguous()   # (crop inside its chunk, x, y, z)
                 vox[s] = ops.voxelize_fp(side_in[s][0], side_in[s][1], self.voxelization_mode)   # all crops at once
                 pf[s] = torch.empty((b * npts[s], 480), dtype=torch.float32, device=dev)   # read on `main`
             if not single:
                 pf[s].record_stream(main)
                 side_in[s][0].record_stream(main)                      # `pts` below is handed to the caller
-                pb4[s].record_stream(nstream[s])
             pts[s] = side_in[s][0][:, 4:7].reshape(b, npts[s], 3)
         act = {}
         for side, key in (("Xc", "inp"), ("Yo", "tmp")):
@@ -270,25 +268,12 @@ class Network(nn.Module):
         assert unit[0] == unit[1] == unit[2], "anisotropic voxels: use fused=False"
         off = float(np.float32(-0.5 * unit[0] * VOXEL_NUM_LIMIT[0]))
         extents = [float(np.float32(unit[0] * sc)) for sc in SCALE_LISTS]
-        with torch.cuda.stream(nstream["inp"]):                        # the host waits for the two geometry stages only
+        with torch.cuda.stream(rstream):                               # the host waits for the two geometry stages only
             for s in ("inp", "tmp"):
-                nstream["inp"].wait_event(geo[s])
+                rstream.wait_event(geo[s])
             counts = torch.cat([runs[s, c].counts_dev for c in range(K) for s in ("inp", "tmp")]).cpu().tolist()
         for i, key in enumerate((s, c) for c in range(K) for s in ("inp", "tmp")):
             runs[key[0], key[1]].set_counts(counts[8 * i:8 * i + 8])
-        nn, nn_done = {}, {}
-        if split_nn:
-            for s in ("inp", "tmp"):
-                with torch.cuda.stream(nstream[s]):
-                    nstream[s].wait_event(geo[s])
-                    for c in range(K):
-                        rows = slice(c * bc * npts[s], (c + 1) * bc * npts[s])
-                        nn[s, c] = runs[s, c].point_neighbours(pb4[s][rows], extents, off)
-                        if not single:
-                            for t in nn[s, c]:
-                                t.record_stream(sstream[s])
-                    nn_done[s] = torch.cuda.Event()
-                    nn_done[s].record(nstream[s])
         done = {}
         for side, bb in (("inp", "backbone_inp"), ("tmp", "backbone_tmp")):
             n = npts[side]
@@ -296,12 +281,7 @@ class Network(nn.Module):
                 for c in range(K):
                     rows = slice(c * bc * n, (c + 1) * bc * n)
                     runs[side, c].features(vox[side], *f[bb + "_ptrs"])
-                    if split_nn:
-                        if c == 0:
-                            sstream[side].wait_event(nn_done[side])
-                        runs[side, c].point_interpolate(*nn[side, c], out=pf[side][rows])
-                    else:
-                        runs[side, c].point_features(pb4[side][rows], extents, off, out=pf[side][rows])
+                    runs[side, c].point_features(pb4[side][rows], extents, off, out=pf[side][rows])
                     done[side, c] = torch.cuda.Event()
                     done[side, c].record(sstream[side])
         for c in range(K):                                                     # dense stage 1, chunk by chunk on main
