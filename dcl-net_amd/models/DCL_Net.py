@@ -123,7 +123,7 @@ class Network(nn.Module):
     def __getstate__(self):
         """copy.deepcopy / pickling: streams, graphs and folded tensors are per-instance runtime state"""
         state = dict(self.__dict__)
-        for k in ("_side", "_graphs"):
+        for k in ("_side", "_graphs", "_crop_id_cache"):
             state.pop(k, None)
         state["_folded"] = None
         return state
@@ -253,8 +253,7 @@ class Network(nn.Module):
                     runs[s, c] = ops.BackboneRun(side_in[s][2], bc, S, batch_lo=c * bc)
                 geo[s] = torch.cuda.Event()
                 geo[s].record(sstream[s])
-                bid = (torch.arange(b, device=dev) % bc).float().repeat_interleave(npts[s]).unsqueeze(1)
-                pb4[s] = torch.cat([bid, side_in[s][0][:, 4:7]], 1).contiguous()   # (crop inside its chunk, x, y, z)
+                pb4[s] = torch.cat([self._crop_ids(dev, b, bc, npts[s]), side_in[s][0][:, 4:7]], 1)   # (crop in its chunk, xyz)
                 vox[s] = ops.voxelize_fp(side_in[s][0], side_in[s][1], self.voxelization_mode)   # all crops at once
                 pf[s] = torch.empty((b * npts[s], 480), dtype=torch.float32, device=dev)   # read on `main`
             if not single:
@@ -297,6 +296,17 @@ class Network(nn.Module):
         data["labels"]["points_tmp"] = pts["tmp"]
         data["labels"]["points_inp"] = pts["inp"]
         return prediction
+
+    def _crop_ids(self, dev, b, bc, n):
+        """(b*n, 1) float column: crop id (inside its chunk of bc crops) of every point row; constant per shape, cached"""
+        cache = self.__dict__.setdefault("_crop_id_cache", {})
+        key = (str(dev), b, bc, n)
+        if key not in cache:
+            if len(cache) > 16:
+                cache.clear()
+            cache[key] = (torch.arange(b, device=dev) % bc).float().repeat_interleave(n).unsqueeze(1)
+            torch.cuda.current_stream(dev).synchronize()          # built once; read from either side stream afterwards
+        return cache[key]
 
     _DIS_TAGS = (("p1", 256), ("m1", 64), ("p2", 256), ("m2", 64))
 

@@ -1,0 +1,25 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence of a round on the GPU box (run through gpurun from the repo root):
+#   tools/profile_round.sh r1        -> gpurun_out/r1_{stress,ref,prim,stream}/ (kernel trace + stats)
+#                                       gpurun_out/r1_pmc_<COUNTER>/            (one counter per pass, bench at the stress shape)
+#                                       gpurun_out/r1_pmcprim_<COUNTER>/        (north-star primitives)
+# then, back in the container: python tools/summarize_profiles.py r1  (copies the summaries into profiles/).
+# PMC passes are separate runs with --kernel-trace only, as the pool requires.
+R=${1:-r1}
+export TMPDIR=/tmp
+cd "$(dirname "$0")/.." || exit 1
+O=gpurun_out
+stats() { rocprofv3 --kernel-trace --stats -d $O/${R}_$1 -o runc --output-format csv -- "${@:2}" > $O/${R}_$1.log 2>&1; }
+pmc()   { rocprofv3 --pmc $2 --kernel-trace -d $O/${R}_$1_$2 -o runc --output-format csv -- "${@:3}" > $O/${R}_$1_$2.log 2>&1; }
+mkdir -p $O
+stats stress python3 bench.py --steps 20 --warmup 3 --no-extras
+stats ref    python3 bench.py --shape ref --steps 40 --warmup 3 --no-extras
+stats prim   python3 tools/bench_primitives.py
+stats stream python3 tools/profile_stream.py 1
+for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
+  pmc pmc $c python3 bench.py --steps 4 --warmup 2 --no-extras
+done
+for c in FETCH_SIZE WRITE_SIZE; do
+  pmc pmcprim $c python3 tools/bench_primitives.py
+done
+ls $O | grep "^${R}_" | tr '\n' ' '

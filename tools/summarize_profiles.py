@@ -15,15 +15,15 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
 for shape, tag in (("stress", "stress"), ("ref", "ref"), ("prim", "primitives"), ("stream", "stream_b1_graph")):
-    found = sorted(glob.glob(os.path.join(root, "gpurun_out", "%s_%s" % (rnd, shape), "*", "*kernel_stats.csv")),
-                   key=os.path.getmtime)
+    found = sorted(glob.glob(os.path.join(root, "gpurun_out", "%s_%s" % (rnd, shape), "**", "*kernel_stats.csv"),
+                             recursive=True), key=os.path.getmtime)
     if found:                                                   # the newest run of that shape
         shutil.copy(found[-1], os.path.join(out, "%s_%s_kernel_stats.csv" % (rnd, tag)))
 rows_out = []
 for d in sorted(glob.glob(os.path.join(root, "gpurun_out", "%s_pmc*" % rnd))):   # r1_pmc_* (bench, stress), r1_pmcprim_*, r1_pmcconv_*
     if not os.path.isdir(d):
         continue
-    for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         dur = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
