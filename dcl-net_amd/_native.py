@@ -35,6 +35,8 @@ def lib():
         # A/B switches for profiling runs (kernel-variant hooks of include/dclnet_hip.h)
         if os.environ.get("DCL_CONV_VARIANT"):
             L.dcl_debug_force_valu_conv(int(os.environ["DCL_CONV_VARIANT"]))
+        if os.environ.get("DCL_CONV_XCD"):
+            L.dcl_debug_conv_xcd_remap(int(os.environ["DCL_CONV_XCD"]))
         if os.environ.get("DCL_CONV_SPLIT"):
             L.dcl_debug_conv_split(int(os.environ["DCL_CONV_SPLIT"]))
         if os.environ.get("DCL_ATTN_SPLIT"):

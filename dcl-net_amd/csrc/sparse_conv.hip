@@ -492,7 +492,8 @@ template <int CIN, int WR, int WCW, int NT>
 __global__ __launch_bounds__(64 * WR * WCW, 2) void k_sparse_conv_dma(
     const float *__restrict__ feat, const DclNbrSrc src, int cap, const int32_t *__restrict__ n_out_dev,
     int n_out_host, const float *__restrict__ W, int cout, int kvol, int subm, const float *__restrict__ scale,
-    const float *__restrict__ shift, int relu, float *__restrict__ out, float *__restrict__ partial, int nsplit) {
+    const float *__restrict__ shift, int relu, float *__restrict__ out, float *__restrict__ partial, int nsplit,
+    int xcd_remap) {
   constexpr int NW = WR * WCW, NTHR = 64 * NW;
   constexpr int BM = 32 * WR, BN = 32 * NT * WCW, KC = 32;
   constexpr int AT = BM * KC, BT = KC * BN, ST = AT + BT;      // floats per stage
@@ -509,7 +510,18 @@ __global__ __launch_bounds__(64 * WR * WCW, 2) void k_sparse_conv_dma(
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int wr = wave / WCW, wc = wave % WCW;
-  const int col0 = blockIdx.y * BN;
+  // XCD-aware placement (speed only): workgroup ids are dealt round-robin over the 8 XCDs; renumber so that the
+  // workgroups sharing an XCD (= one L2) hold the column tiles of the same row tile and then neighbouring row tiles,
+  // whose gathered input rows overlap
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (xcd_remap) {
+    const int nwg = gridDim.x * gridDim.y, id = blockIdx.x + gridDim.x * blockIdx.y;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = id & 7;
+    const int swz = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (id >> 3);
+    by = swz % (int)gridDim.y;
+    bx = swz / (int)gridDim.y;
+  }
+  const int col0 = by * BN;
   const int nblk = (n + BM - 1) / BM;
   // split-K: blockIdx.z owns a contiguous range of chunks and writes raw partial sums (k_conv_split_reduce adds them
   // in split order and applies the epilogue) -- more workgroups for the deep layers whose row count alone cannot fill the GPU
@@ -518,7 +530,7 @@ __global__ __launch_bounds__(64 * WR * WCW, 2) void k_sparse_conv_dma(
   const int nchunks = (int)((long long)(blockIdx.z + 1) * nchunks_all / nsplit);
   const float *zero = reinterpret_cast<const float *>(&g_conv_zero_line);
 
-  for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+  for (int blk = bx; blk < nblk; blk += gridDim.x) {
     const int row0 = blk * BM;
     if (tid == 0) *s_kmask = 0;
     __syncthreads();
@@ -669,6 +681,7 @@ __global__ void k_conv_split_reduce(const float *__restrict__ partial, int nspli
 constexpr int kConvMaxSplit = 8;       // K-splits of a launch with many row tiles
 constexpr int kConvFewRows = 4096;     // at most this many output rows (capacity): up to one split per kernel offset
 static int conv_split_cap(long long rows) { return rows <= kConvFewRows ? 27 : kConvMaxSplit; }
+static int g_conv_xcd_remap = 1;       // tuning hook: 0 = plain blockIdx order
 static int g_conv_split = 0;           // tuning hook: 0 = automatic, n = force n-way split-K when scratch allows, -1 = never more than kConvMaxSplit
 
 template <int CIN, int WR, int WCW, int NT>
@@ -697,7 +710,7 @@ static void launch_conv_dma(int rows, const float *feat, const DclNbrSrc &nbr, i
   }
   hipLaunchKernelGGL((k_sparse_conv_dma<CIN, WR, WCW, NT>), dim3(nblk < 65535 ? nblk : 65535, cout / BN, nsplit),
                      dim3(64 * WR * WCW), lds, s, feat, nbr, cap, n_out_dev, n_out_host, W, cout, kvol, subm, scale, shift,
-                     relu, out, scratch, nsplit);
+                     relu, out, scratch, nsplit, g_conv_xcd_remap);
   if (nsplit > 1)
     hipLaunchKernelGGL(k_conv_split_reduce, dim3(dcl_grid_1d((long long)rows * (cout / 4), 256)), dim3(256), 0, s, scratch,
                        nsplit, cap, n_out_dev, n_out_host, cout, scale, shift, relu, out);
@@ -783,6 +796,7 @@ static int g_force_valu = 0;   // test hook: 1 = plain VALU kernel for every con
 DCL_API void dcl_debug_force_valu_conv(int on) { g_force_valu = on; }
 
 DCL_API void dcl_debug_conv_split(int n) { g_conv_split = n; }
+DCL_API void dcl_debug_conv_xcd_remap(int on) { g_conv_xcd_remap = on; }
 
 // most K-splits a conv launch over `rows` output rows may use (sizes the partial-sum scratch; backbone.hip)
 int dcl_internal_conv_split_cap(long long rows) { return conv_split_cap(rows); }

@@ -365,6 +365,9 @@ void dcl_debug_attention_xcd_remap(int on);
 void dcl_debug_three_nn_grid(int mode);
 /* Tuning hook: 0 = automatic split-K choice in dcl_sparse_conv_fwd_ws, n = force n splits (when the scratch allows). */
 void dcl_debug_conv_split(int n);
+/* Tuning hook: 1 (default) = the LDS-DMA conv kernel renumbers its workgroups XCD-aware (column tiles of a row tile and
+ * neighbouring row tiles share an L2), 0 = plain blockIdx order. */
+void dcl_debug_conv_xcd_remap(int on);
 /* Tuning hook for dcl_group_points' LDS-staged kernel: channel rows per workgroup, x-blocks, threads per workgroup,
  * store kind (2 = plain instead of nontemporal); 0 = built-in choice for each. */
 void dcl_debug_group_points_cfg(int cc, int xb, int threads, int nontemporal);
