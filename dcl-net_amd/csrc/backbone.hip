@@ -23,6 +23,9 @@ int dcl_internal_sparse_conv_fwd(const float *feat, const DclNbrSrc &nbr, int ca
                                  const float *shift, int relu, float *out, float *scratch, int64_t scratch_floats,
                                  dclStream_t stream);
 int dcl_internal_conv_split_cap(long long rows);
+int dcl_internal_out_mask_k3(const uint32_t *in_mask, int batch, int S_in, int stride, uint32_t *out_mask,
+                             dclStream_t stream);
+int dcl_internal_scan_enumerate_sets(const DclGeoSets &g, int nsets, dclStream_t stream);
 int dcl_internal_sparse_avgpool_fwd(const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev,
                                     int n_out_host, int c, int kvol, float *out, int32_t *rf, dclStream_t stream);
 int dcl_three_nn_sp_voxels(int n, int m, const float *unknown, const int32_t *known_indices, float ve, float off,
@@ -81,7 +84,11 @@ bool make_geo_layout(int batch, int S, int V0, GeoLayout *L) {
     cap_prev = cap_p;
     s = sp;
   }
-  L->scratch = take(sizeof(int32_t) * ((size_t)(nw0 + 1023) / 1024 + 2));
+  // scan scratch: block sums of the input grid, then of the 8 generated sets (batched scan, one slice per set)
+  size_t blocks = (size_t)(nw0 + 1023) / 1024 + 2;
+  for (int m = 0; m < kLevels; ++m)
+    blocks += (size_t)(words(batch, L->conv[m].S) + 1023) / 1024 + 1 + (size_t)(words(batch, L->pool[m].S) + 1023) / 1024 + 1;
+  L->scratch = take(sizeof(int32_t) * blocks);
   L->total = off;
   return true;
 }
@@ -164,28 +171,31 @@ static int backbone_geometry(const int32_t *occ, const int32_t *V0_dev, int V0, 
   int rc = dcl_internal_grid_from_indices(occ, V0_dev, V0, batch_lo, batch, S, at<uint32_t>(ws, L.mask0),
                                           at<int32_t>(ws, L.wprefix0), at<int32_t>(ws, L.perm0), scratch, stream);
   if (rc) return rc;
-  const int32_t *in_idx = occ;
-  const int32_t *in_n_dev = V0_dev;
-  int in_n_host = V0;
+  // the 8 masks depend only on each other (bit-parallel dilation / stride-2 reduction of the previous mask): chain them,
+  // then rank and decode all 8 sets in three batched launches (16 launches per pass instead of 30)
+  DclGeoSets g{};
+  size_t so = (size_t)(words(batch, S) + 1023) / 1024 + 2;
   const uint32_t *in_mask = at<uint32_t>(ws, L.mask0);
   int s = S;
   for (int m = 0; m < kLevels; ++m) {
-    const SetLayout &c = L.conv[m], &p = L.pool[m];
-    rc = dcl_conv_out_grid(in_idx, in_n_dev, in_n_host, in_mask, batch, s, 3, 1, 1, at<uint32_t>(ws, c.mask),
-                           at<int32_t>(ws, c.wprefix), at<int32_t>(ws, c.indices), counts_dev + 2 * m, c.cap, scratch,
-                           stream);
-    if (rc) return rc;
-    rc = dcl_conv_out_grid(at<int32_t>(ws, c.indices), counts_dev + 2 * m, c.cap, at<uint32_t>(ws, c.mask), batch, s,
-                           3, 2, 1, at<uint32_t>(ws, p.mask), at<int32_t>(ws, p.wprefix), at<int32_t>(ws, p.indices),
-                           counts_dev + 2 * m + 1, p.cap, scratch, stream);
-    if (rc) return rc;
-    in_idx = at<int32_t>(ws, p.indices);
-    in_n_dev = counts_dev + 2 * m + 1;
-    in_n_host = p.cap;
-    in_mask = at<uint32_t>(ws, p.mask);
-    s = p.S;
+    const SetLayout *sets[2] = {&L.conv[m], &L.pool[m]};
+    for (int q = 0; q < 2; ++q) {
+      const SetLayout &t = *sets[q];
+      rc = dcl_internal_out_mask_k3(in_mask, batch, s, q == 0 ? 1 : 2, at<uint32_t>(ws, t.mask), stream);
+      if (rc) return rc;
+      const int i = 2 * m + q, nw = (int)words(batch, t.S);
+      g.mask[i] = at<uint32_t>(ws, t.mask);
+      g.wprefix[i] = at<int32_t>(ws, t.wprefix);
+      g.indices[i] = at<int32_t>(ws, t.indices);
+      g.n_out[i] = counts_dev + i;
+      g.block_sums[i] = scratch + so;
+      g.nwords[i] = nw; g.S[i] = t.S; g.cap[i] = t.cap;
+      so += (size_t)(nw + 1023) / 1024 + 1;
+      in_mask = g.mask[i];
+      s = t.S;
+    }
   }
-  return 0;
+  return dcl_internal_scan_enumerate_sets(g, 2 * kLevels, stream);
 }
 
 DCL_API int dcl_backbone_ws2_bytes(const int32_t *counts_host, const int32_t *channels_host, int64_t *bytes_host) {

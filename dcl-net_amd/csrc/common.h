@@ -51,6 +51,16 @@ struct DclNbrSrc {
   const int32_t *in_perm;          // rank -> feature row (level 0) or nullptr
   int S_in, stride, pad;
 };
+// The 8 active sets of a backbone pass (conv / pool set of every level) for the batched scan + enumerate launches of the
+// geometry stage (rulebook.hip: dcl_internal_scan_enumerate_sets).
+struct DclGeoSets {
+  const uint32_t *mask[8];
+  int32_t *wprefix[8];      // nwords + 1 entries each
+  int32_t *indices[8];      // (cap, 4) rows [b,x,y,z]
+  int32_t *n_out[8];        // live row count (device)
+  int32_t *block_sums[8];   // scratch: one entry per 1024-word scan block
+  int nwords[8], S[8], cap[8];
+};
 #if defined(__HIPCC__)
 __device__ __forceinline__ int dcl_nbr_at(const DclNbrSrc &s, int cap, int k, int row) {
   if (s.nbr) return s.nbr[(size_t)k * cap + row];

@@ -239,6 +239,74 @@ __global__ void k_enumerate(const uint32_t *__restrict__ mask, const int32_t *__
   if (blockIdx.x == 0 && threadIdx.x == 0 && n_out_dev) *n_out_dev = wprefix[nwords];
 }
 
+// ---- the same scan + enumerate for several sets in one launch each (blockIdx.y = set): the masks of a backbone pass
+// depend only on each other, so the geometry stage first chains the 8 mask kernels and then ranks / decodes all sets at once
+__global__ void k_block_popc_sets(const DclGeoSets g) {
+  const int set = blockIdx.y, nwords = g.nwords[set];
+  if ((int)blockIdx.x * kScanWords >= nwords) return;
+  const uint32_t *__restrict__ mask = g.mask[set];
+  const int w0 = blockIdx.x * kScanWords + threadIdx.x * 4;
+  int s = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) s += (w0 + j < nwords) ? __popc(mask[w0 + j]) : 0;
+  int total;
+  block_excl_scan_256(s, &total);
+  if (threadIdx.x == 0) g.block_sums[set][blockIdx.x] = total;
+}
+
+__global__ void k_scan_words_sets(const DclGeoSets g) {
+  const int set = blockIdx.y, nwords = g.nwords[set];
+  if ((int)blockIdx.x * kScanWords >= nwords) return;
+  const uint32_t *__restrict__ mask = g.mask[set];
+  const int32_t *__restrict__ block_sums = g.block_sums[set];
+  int32_t *__restrict__ wprefix = g.wprefix[set];
+  int part = 0;
+  for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) part += block_sums[i];
+  int base;
+  block_excl_scan_256(part, &base);
+  const int w0 = blockIdx.x * kScanWords + threadIdx.x * 4;
+  int c[4], s = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    c[j] = (w0 + j < nwords) ? __popc(mask[w0 + j]) : 0;
+    s += c[j];
+  }
+  int total;
+  int ex = block_excl_scan_256(s, &total) + base;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (w0 + j < nwords) wprefix[w0 + j] = ex;
+    ex += c[j];
+  }
+  if (((int)blockIdx.x + 1) * kScanWords >= nwords && threadIdx.x == 0) {      // last block of this set
+    wprefix[nwords] = base + total;
+    if (g.n_out[set]) *g.n_out[set] = base + total;
+  }
+}
+
+__global__ void k_enumerate_sets(const DclGeoSets g) {
+  const int set = blockIdx.y, nwords = g.nwords[set], S = g.S[set], cap = g.cap[set];
+  const uint32_t *__restrict__ mask = g.mask[set];
+  const int32_t *__restrict__ wprefix = g.wprefix[set];
+  int4 *__restrict__ out = reinterpret_cast<int4 *>(g.indices[set]);
+  for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += gridDim.x * blockDim.x) {
+    uint32_t m = mask[w];
+    int r = wprefix[w];
+    while (m) {
+      const int bit = __ffs(m) - 1;
+      m &= m - 1;
+      int lin = (w << 5) + bit;
+      int4 o;
+      o.w = lin % S; lin /= S;
+      o.z = lin % S; lin /= S;
+      o.y = lin % S; lin /= S;
+      o.x = lin;
+      if (r < cap) out[r] = o;
+      ++r;
+    }
+  }
+}
+
 // gather-form rulebook: for output o and offset k the feeding input sits at p = o*stride - pad + k.
 __global__ void k_build_nbr(const int32_t *__restrict__ out_indices, const int32_t *__restrict__ n_out_dev,
                             int n_out_host, const uint32_t *__restrict__ in_mask,
@@ -390,6 +458,40 @@ DCL_API int dcl_conv_out_grid(const int32_t *in_indices, const int32_t *n_in_dev
   scan_mask(out_mask, nwords, out_wprefix, scratch, s);
   hipLaunchKernelGGL(k_enumerate, dim3(dcl_grid_1d(nwords, 256)), dim3(256), 0, s, out_mask, out_wprefix, nwords,
                      S_out, out_indices, cap_out, n_out_dev);
+  DCL_LAUNCH_CHECK();
+  return 0;
+}
+
+// internal (backbone.hip): bit-parallel output mask of a k3 p1 conv (stride 1) / pool (stride 2) from the input mask
+int dcl_internal_out_mask_k3(const uint32_t *in_mask, int batch, int S_in, int stride, uint32_t *out_mask,
+                             dclStream_t stream) {
+  DCL_CHECK_ARG(in_mask && out_mask && batch > 0 && (S_in & (S_in - 1)) == 0 && S_in >= 4 && S_in <= 64 &&
+                (stride == 1 || stride == 2));
+  const int S_out = S_in / stride;
+  const int nwords = (int)grid_words(batch, S_out);
+  if (stride == 1)
+    hipLaunchKernelGGL((k_out_mask_k3<1>), dim3(dcl_grid_1d(nwords, 256)), dim3(256), 0, (hipStream_t)stream, in_mask,
+                       batch, S_in, S_out, nwords, out_mask);
+  else
+    hipLaunchKernelGGL((k_out_mask_k3<2>), dim3(dcl_grid_1d(nwords, 256)), dim3(256), 0, (hipStream_t)stream, in_mask,
+                       batch, S_in, S_out, nwords, out_mask);
+  DCL_LAUNCH_CHECK();
+  return 0;
+}
+
+// internal (backbone.hip): word prefixes, row counts and (b,x,y,z) rows of `nsets` masks in three launches
+int dcl_internal_scan_enumerate_sets(const DclGeoSets &g, int nsets, dclStream_t stream) {
+  DCL_CHECK_ARG(nsets >= 1 && nsets <= 8);
+  int max_words = 0;
+  for (int i = 0; i < nsets; ++i) {
+    DCL_CHECK_ARG(g.mask[i] && g.wprefix[i] && g.indices[i] && g.block_sums[i] && g.nwords[i] > 0 && g.S[i] > 0);
+    if (g.nwords[i] > max_words) max_words = g.nwords[i];
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int nblk = dcl_div_up(max_words, kScanWords);
+  hipLaunchKernelGGL(k_block_popc_sets, dim3(nblk, nsets), dim3(256), 0, s, g);
+  hipLaunchKernelGGL(k_scan_words_sets, dim3(nblk, nsets), dim3(256), 0, s, g);
+  hipLaunchKernelGGL(k_enumerate_sets, dim3(dcl_grid_1d(max_words, 256), nsets), dim3(256), 0, s, g);
   DCL_LAUNCH_CHECK();
   return 0;
 }

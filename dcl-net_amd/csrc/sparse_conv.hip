@@ -513,8 +513,10 @@ __global__ __launch_bounds__(64 * WR * WCW, 2) void k_sparse_conv_dma(
   // XCD-aware placement (speed only): workgroup ids are dealt round-robin over the 8 XCDs; renumber so that the
   // workgroups sharing an XCD (= one L2) hold the column tiles of the same row tile and then neighbouring row tiles,
   // whose gathered input rows overlap
+  // (only when the grid is exactly the live tiles: in capacity mode the grid is sized by the row capacity and a chunked
+  // numbering would put all live tiles on one XCD)
   int bx = blockIdx.x, by = blockIdx.y;
-  if (xcd_remap) {
+  if (xcd_remap && n_out_dev == nullptr && (n + BM - 1) / BM == (int)gridDim.x) {
     const int nwg = gridDim.x * gridDim.y, id = blockIdx.x + gridDim.x * blockIdx.y;
     const int xq = nwg >> 3, xr = nwg & 7, xcd = id & 7;
     const int swz = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (id >> 3);
