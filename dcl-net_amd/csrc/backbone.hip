@@ -26,6 +26,11 @@ int dcl_internal_conv_split_cap(long long rows);
 int dcl_internal_out_mask_k3(const uint32_t *in_mask, int batch, int S_in, int stride, uint32_t *out_mask,
                              dclStream_t stream);
 int dcl_internal_scan_enumerate_sets(const DclGeoSets &g, int nsets, dclStream_t stream);
+bool dcl_internal_readout_fused_ok(const DclReadoutLevels &L, int ld, bool need_search);
+int dcl_internal_readout_neighbours(int n, const float *points_b4, const DclReadoutLevels &L, int nbatch, float off,
+                                    float *dist2, int32_t *idx, dclStream_t stream);
+int dcl_internal_readout_interpolate(int n, const DclReadoutLevels &L, const int32_t *idx, const float *dist2, float *out,
+                                     int ld, dclStream_t stream);
 int dcl_internal_sparse_avgpool_fwd(const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev,
                                     int n_out_host, int c, int kvol, float *out, int32_t *rf, dclStream_t stream);
 int dcl_three_nn_sp_voxels(int n, int m, const float *unknown, const int32_t *known_indices, float ve, float off,
@@ -363,6 +368,24 @@ DCL_API int dcl_point_features_cap(int n, const float *points_b4, int batch, int
                         voxel_extent_host, offset, out, ld, tmp, tmp_bytes, stream);
 }
 
+static void fill_readout_levels(const GeoLayout &L, void *ws, const int32_t *channels_host,
+                                const float *const *level_feats, const float *voxel_extent_host, DclReadoutLevels *R) {
+  int col = 0;
+  for (int m = 0; m < kLevels; ++m) {
+    const SetLayout &p = L.pool[m];
+    R->indices[m] = ws ? at<int32_t>(ws, p.indices) : nullptr;
+    R->mask[m] = ws ? at<uint32_t>(ws, p.mask) : nullptr;
+    R->wprefix[m] = ws ? at<int32_t>(ws, p.wprefix) : nullptr;
+    R->feats[m] = level_feats ? level_feats[m] : nullptr;
+    R->S[m] = p.S;
+    R->wpc[m] = p.S * p.S * p.S / 32;
+    R->c[m] = channels_host ? channels_host[2 * m + 2] : 4;
+    R->col[m] = col;
+    R->ve[m] = voxel_extent_host ? voxel_extent_host[m] : 1.0f;
+    col += R->c[m];
+  }
+}
+
 static int point_features(int n, const float *points_b4, int batch, int S, int V0, void *ws,
                           const int32_t *counts_host, const int32_t *counts_dev, const int32_t *channels_host,
                           const float *const *level_feats, const float *voxel_extent_host, float offset, float *out,
@@ -371,10 +394,19 @@ static int point_features(int n, const float *points_b4, int batch, int S, int V
   DCL_CHECK_ARG(n >= 0 && points_b4 && ws && counts_host && channels_host && level_feats && voxel_extent_host && out &&
                 tmp && make_geo_layout(batch, S, V0, &L));
   if (n == 0) return 0;
-  size_t max_rows = 1;
-  for (int m = 0; m < kLevels; ++m)
-    if ((size_t)counts_host[2 * m + 1] > max_rows) max_rows = counts_host[2 * m + 1];
-  const size_t need = align_up((size_t)n * 12) * 2 + max_rows * 16;
+  // two launches for the whole read-out when the levels qualify (they do for the backbone's own levels): all searches,
+  // then all interpolations; dist2 / idx of the 4 levels live in tmp
+  DclReadoutLevels R;
+  fill_readout_levels(L, ws, channels_host, level_feats, voxel_extent_host, &R);
+  const size_t blk = align_up((size_t)n * 48);
+  if (tmp_bytes >= (int64_t)(2 * blk) && dcl_internal_readout_fused_ok(R, ld, true)) {
+    float *d4 = at<float>(tmp, 0);
+    int32_t *i4 = at<int32_t>(tmp, blk);
+    int rc4 = dcl_internal_readout_neighbours(n, points_b4, R, batch, offset, d4, i4, stream);
+    if (rc4) return rc4;
+    return dcl_internal_readout_interpolate(n, R, i4, d4, out, ld, stream);
+  }
+  const size_t need = align_up((size_t)n * 12) * 2;               // level by level: one level's dist2 + idx at a time
   DCL_CHECK_ARG(tmp_bytes >= (int64_t)need);
   float *dist2 = at<float>(tmp, 0);
   int32_t *idx = at<int32_t>(tmp, align_up((size_t)n * 12));
@@ -403,6 +435,10 @@ static int point_neighbours(int n, const float *points_b4, int batch, int S, int
   DCL_CHECK_ARG(n >= 0 && points_b4 && ws && counts_host && voxel_extent_host && dist2 && idx &&
                 make_geo_layout(batch, S, V0, &L));
   if (n == 0) return 0;
+  DclReadoutLevels R;
+  fill_readout_levels(L, ws, nullptr, nullptr, voxel_extent_host, &R);
+  if (dcl_internal_readout_fused_ok(R, 16, true))
+    return dcl_internal_readout_neighbours(n, points_b4, R, batch, offset, dist2, idx, stream);
   for (int m = 0; m < kLevels; ++m) {
     const SetLayout &p = L.pool[m];
     const int wpc = p.S * p.S * p.S / 32;
@@ -434,6 +470,17 @@ DCL_API int dcl_point_interpolate(int n, const int32_t *counts_host, const int32
                                   int ld, dclStream_t stream) {
   DCL_CHECK_ARG(n >= 0 && counts_host && channels_host && level_feats && dist2 && idx && out);
   if (n == 0) return 0;
+  {
+    DclReadoutLevels R{};
+    int c0 = 0;
+    for (int m = 0; m < kLevels; ++m) {
+      R.feats[m] = level_feats[m];
+      R.c[m] = channels_host[2 * m + 2];
+      R.col[m] = c0;
+      c0 += R.c[m];
+    }
+    if (dcl_internal_readout_fused_ok(R, ld, false)) return dcl_internal_readout_interpolate(n, R, idx, dist2, out, ld, stream);
+  }
   int col = 0;
   for (int m = 0; m < kLevels; ++m) {
     const int c = channels_host[2 * m + 2];

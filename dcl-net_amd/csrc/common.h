@@ -61,6 +61,16 @@ struct DclGeoSets {
   int32_t *block_sums[8];   // scratch: one entry per 1024-word scan block
   int nwords[8], S[8], cap[8];
 };
+// The 4 pooled levels of a backbone pass as seen by the point read-out (interp.hip: dcl_internal_readout_*): occupancy
+// bits + ranks + rows for the 3-NN searches, features for the interpolation; out columns col[m] .. col[m]+c[m].
+struct DclReadoutLevels {
+  const int32_t *indices[4];
+  const uint32_t *mask[4];
+  const int32_t *wprefix[4];
+  const float *feats[4];
+  int S[4], wpc[4], c[4], col[4];
+  float ve[4];
+};
 #if defined(__HIPCC__)
 __device__ __forceinline__ int dcl_nbr_at(const DclNbrSrc &s, int cap, int k, int row) {
   if (s.nbr) return s.nbr[(size_t)k * cap + row];

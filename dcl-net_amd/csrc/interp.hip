@@ -120,14 +120,11 @@ __global__ __launch_bounds__(64) void k_three_nn_sp(int n, int m, const float4 *
 // is below that (with a 1e-4 margin for rounding) the answer is the global one, ties included (keys order (d, row)
 // exactly like the sequential scan of interpolate_gpu.cu:36-38).  Otherwise -- isolated queries, queries outside
 // the grid -- the thread scans its crop's rows.
-__global__ __launch_bounds__(256) void k_three_nn_grid(int n, const float4 *__restrict__ unknown,
-                                                       const int4 *__restrict__ indices, const uint32_t *__restrict__ mask,
-                                                       const int32_t *__restrict__ wprefix, int nbatch, int S, int wpc,
-                                                       float ve, float off, float *__restrict__ dist2,
-                                                       int32_t *__restrict__ idx, int force_scan) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  const float4 u = unknown[p];
+__device__ __forceinline__ void three_nn_grid_point(int p, const float4 u, const int4 *__restrict__ indices,
+                                                    const uint32_t *__restrict__ mask,
+                                                    const int32_t *__restrict__ wprefix, int nbatch, int S, int wpc,
+                                                    float ve, float off, float *__restrict__ dist2,
+                                                    int32_t *__restrict__ idx, int force_scan) {
   const float half = 0.5f * ve;
   Top3 b; b.init();
   const int bi = (int)u.x;
@@ -180,6 +177,58 @@ __global__ __launch_bounds__(256) void k_three_nn_grid(int n, const float4 *__re
   dist2[p * 3 + 1] = __uint_as_float((unsigned)(b.k2 >> 32));
   dist2[p * 3 + 2] = __uint_as_float((unsigned)(b.k3 >> 32));
   idx[p * 3 + 0] = (int)(unsigned)b.k1; idx[p * 3 + 1] = (int)(unsigned)b.k2; idx[p * 3 + 2] = (int)(unsigned)b.k3;
+}
+
+__global__ __launch_bounds__(256) void k_three_nn_grid(int n, const float4 *__restrict__ unknown,
+                                                       const int4 *__restrict__ indices, const uint32_t *__restrict__ mask,
+                                                       const int32_t *__restrict__ wprefix, int nbatch, int S, int wpc,
+                                                       float ve, float off, float *__restrict__ dist2,
+                                                       int32_t *__restrict__ idx, int force_scan) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) three_nn_grid_point(p, unknown[p], indices, mask, wprefix, nbatch, S, wpc, ve, off, dist2, idx, force_scan);
+}
+
+// all 4 levels of the read-out in one launch (blockIdx.y = level); dist2 / idx are level-major blocks of n*3
+__global__ __launch_bounds__(256) void k_three_nn_grid_levels(int n, const float4 *__restrict__ unknown,
+                                                              const DclReadoutLevels L, int nbatch, float off,
+                                                              float *__restrict__ dist2, int32_t *__restrict__ idx,
+                                                              int force_scan) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+  if (p < n)
+    three_nn_grid_point(p, unknown[p], reinterpret_cast<const int4 *>(L.indices[m]), L.mask[m], L.wprefix[m], nbatch,
+                        L.S[m], L.wpc[m], L.ve[m], off, dist2 + (size_t)m * n * 3, idx + (size_t)m * n * 3, force_scan);
+}
+
+// inverse-distance interpolation of all 4 levels into the (n, ld) row buffer in one launch: thread = 4 channels of a
+// point, levels side by side (same arithmetic as k_three_interpolate_sp<true>)
+__global__ void k_three_interpolate_levels(int n, const DclReadoutLevels L, const int32_t *__restrict__ idx,
+                                           const float *__restrict__ dist2, float *__restrict__ out, int ld) {
+  const int q0 = L.c[0] >> 2, q1 = q0 + (L.c[1] >> 2), q2 = q1 + (L.c[2] >> 2), qn = q2 + (L.c[3] >> 2);
+  const long long total = (long long)n * qn;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int p = (int)(t / qn);
+    int q = (int)(t - (long long)p * qn);
+    const int m = q < q0 ? 0 : (q < q1 ? 1 : (q < q2 ? 2 : 3));
+    q -= m == 0 ? 0 : (m == 1 ? q0 : (m == 2 ? q1 : q2));
+    const size_t o = ((size_t)m * n + p) * 3;
+    const int i0 = idx[o], i1 = idx[o + 1], i2 = idx[o + 2];
+    const float r0 = 1.0f / (sqrtf(dist2[o]) + 1e-8f), r1 = 1.0f / (sqrtf(dist2[o + 1]) + 1e-8f),
+                r2 = 1.0f / (sqrtf(dist2[o + 2]) + 1e-8f);
+    const float norm = (r0 + r1) + r2;
+    const float w0 = r0 / norm, w1 = r1 / norm, w2 = r2 / norm;
+    const int c = L.c[m];
+    const float *__restrict__ F = L.feats[m];
+    const float4 a = reinterpret_cast<const float4 *>(F + (size_t)i0 * c)[q];
+    const float4 b = reinterpret_cast<const float4 *>(F + (size_t)i1 * c)[q];
+    const float4 d = reinterpret_cast<const float4 *>(F + (size_t)i2 * c)[q];
+    float4 v;
+    v.x = dcl_wsum3(w0, a.x, w1, b.x, w2, d.x);
+    v.y = dcl_wsum3(w0, a.y, w1, b.y, w2, d.y);
+    v.z = dcl_wsum3(w0, a.z, w1, b.z, w2, d.z);
+    v.w = dcl_wsum3(w0, a.w, w1, b.w, w2, d.w);
+    reinterpret_cast<float4 *>(out + (size_t)p * ld + L.col[m])[q] = v;
+  }
 }
 
 // voxel centres (Ops_tensor2points, models/Modules.py:204-211): fp32, left to right.
@@ -346,6 +395,42 @@ int dcl_three_nn_sp_voxels(int n, int m, const float *unknown, const int32_t *kn
   hipLaunchKernelGGL(k_three_nn_sp<true>, dim3(dcl_div_up(n, 16)), dim3(64), 0, (hipStream_t)stream, n, m,
                      reinterpret_cast<const float4 *>(unknown), reinterpret_cast<const float4 *>(known_indices), dist2, idx,
                      known_seg, nbatch, seg_stride, ve, off);
+  DCL_LAUNCH_CHECK();
+  return 0;
+}
+
+// internal (backbone.hip): the whole read-out of a backbone pass in two launches -- 3-NN searches of all 4 levels
+// (grid-pruned, exact), then the interpolation of all 4 levels into the row buffer.  `fused_ok` says whether the levels
+// qualify (grids of 4..32 cells per axis, channel counts and columns in float4 units); otherwise the caller goes level
+// by level through dcl_three_nn_sp_voxels / dcl_three_interpolate_dist2_sp.
+bool dcl_internal_readout_fused_ok(const DclReadoutLevels &L, int ld, bool need_search) {
+  if (ld % 4 != 0) return false;
+  for (int m = 0; m < 4; ++m) {
+    if (L.c[m] <= 0 || L.c[m] % 4 != 0 || L.col[m] % 4 != 0 || L.col[m] + L.c[m] > ld) return false;
+    if (!need_search) continue;
+    const int S = L.S[m];
+    if (!g_nn_grid || !(S == 4 || S == 8 || S == 16 || S == 32) || L.wpc[m] != S * S * S / 32 || !(L.ve[m] > 0.0f) ||
+        !L.mask[m] || !L.wprefix[m] || !L.indices[m])
+      return false;
+  }
+  return true;
+}
+
+int dcl_internal_readout_neighbours(int n, const float *points_b4, const DclReadoutLevels &L, int nbatch, float off,
+                                    float *dist2, int32_t *idx, dclStream_t stream) {
+  DCL_CHECK_ARG(n > 0 && points_b4 && dist2 && idx && nbatch > 0);
+  hipLaunchKernelGGL(k_three_nn_grid_levels, dim3(dcl_div_up(n, 256), 4), dim3(256), 0, (hipStream_t)stream, n,
+                     reinterpret_cast<const float4 *>(points_b4), L, nbatch, off, dist2, idx, g_nn_grid == 2 ? 1 : 0);
+  DCL_LAUNCH_CHECK();
+  return 0;
+}
+
+int dcl_internal_readout_interpolate(int n, const DclReadoutLevels &L, const int32_t *idx, const float *dist2, float *out,
+                                     int ld, dclStream_t stream) {
+  DCL_CHECK_ARG(n > 0 && idx && dist2 && out);
+  const long long quads = (long long)n * ((L.c[0] + L.c[1] + L.c[2] + L.c[3]) / 4);
+  hipLaunchKernelGGL(k_three_interpolate_levels, dim3(dcl_grid_1d(quads, 256)), dim3(256), 0, (hipStream_t)stream, n, L,
+                     idx, dist2, out, ld);
   DCL_LAUNCH_CHECK();
   return 0;
 }

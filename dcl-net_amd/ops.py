@@ -261,8 +261,7 @@ class BackboneRun(object):
         dev = points_b4.device
         if out is None:
             out = torch.empty((n, 480), dtype=torch.float32, device=dev)
-        max_rows = max(1, max(self.counts[1::2]))
-        tmp_bytes = 2 * (((n * 12) + 255) // 256 * 256) + 16 * max_rows
+        tmp_bytes = 2 * (((n * 48) + 255) // 256 * 256)                       # dist2 + idx of the 4 levels
         tmp = torch.empty(tmp_bytes, dtype=torch.uint8, device=dev)
         ve = (C.c_float * 4)(*[float(v) for v in voxel_extents])
         N.check(N.lib().dcl_point_features(n, N.ptr(points_b4), self.batch, self.S, self.V0, N.ptr(self.ws), self.ccounts,
@@ -341,7 +340,7 @@ class BackboneRunCap(object):
         return out
 
     def tmp_bytes(self, n):
-        return 2 * (((n * 12) + 255) // 256 * 256) + 16 * max(1, max(self.caps[1::2]))
+        return 2 * (((n * 48) + 255) // 256 * 256)
 
     def point_neighbours(self, points_b4, voxel_extents, offset, dist2, idx):
         """dist2 / idx: static (4, n, 3) buffers (see BackboneRun.point_neighbours)"""

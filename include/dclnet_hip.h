@@ -190,7 +190,8 @@ int dcl_point_features_cap(int n, const float *points_b4, int batch, int S, int 
 int dcl_backbone_level_info(int batch, int S, int V0, int level, int64_t *indices_off_host,
                             int64_t *wprefix_off_host, int32_t *S_level_host);
 /* points_b4 (n,4) [b,x,y,z] -> out (n, ld): levels' channels side by side.  voxel_extent_host[4] = unit*scale per
- * level (fp32), offset = -0.5*unit*64.  tmp >= 2*align256(12n) + 16*max_level_rows bytes.                         */
+ * level (fp32), offset = -0.5*unit*64.  tmp >= 2*align256(48n) bytes: then the read-out is two launches (all
+ * searches, all interpolations); with only 2*align256(12n) it goes level by level.                                */
 int dcl_point_features(int n, const float *points_b4, int batch, int S, int V0, void *ws,
                        const int32_t *counts_host, const int32_t *channels_host,
                        const float *const *level_feats_host, const float *voxel_extent_host, float offset,
