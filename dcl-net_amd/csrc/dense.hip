@@ -872,6 +872,34 @@ DCL_API int dcl_conf_pool(int b, int c, int n1, int n2, const float *logit1, con
   return 0;
 }
 
+// out[b][ch] = ((sA*P1 + tA*w0) + sB*P2) + tB*w1 with P = slice partials added in slice order: the pooled feature of
+// both directions behind the fusers' trailing BatchNorms (sum_i w_i (s x_i + t) = s sum w x + t sum w), one launch
+__global__ void k_pool_finish(int c, int nslices, const float *__restrict__ part1, const float *__restrict__ part2,
+                              const float *__restrict__ wsum, const float *__restrict__ sA, const float *__restrict__ tA,
+                              const float *__restrict__ sB, const float *__restrict__ tB, float *__restrict__ out) {
+  const int b = blockIdx.y, ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  float p1 = 0.0f, p2 = 0.0f;
+  for (int s = 0; s < nslices; ++s) {
+    p1 += part1[((size_t)b * nslices + s) * c + ch];
+    p2 += part2[((size_t)b * nslices + s) * c + ch];
+  }
+  const float w0 = wsum[2 * b], w1 = wsum[2 * b + 1];
+  out[(size_t)b * c + ch] = ((sA[ch] * p1 + tA[ch] * w0) + sB[ch] * p2) + tB[ch] * w1;
+}
+
+DCL_API int dcl_pool_finish(int b, int c, int nslices, const float *part1, const float *part2, const float *wsum,
+                            const float *scale1, const float *shift1, const float *scale2, const float *shift2,
+                            float *out, dclStream_t stream) {
+  DCL_CHECK_ARG(b >= 0 && c > 0 && nslices >= 1);
+  if (b == 0) return 0;
+  DCL_CHECK_ARG(part1 && part2 && wsum && scale1 && shift1 && scale2 && shift2 && out && b <= 65535);
+  hipLaunchKernelGGL(k_pool_finish, dim3(dcl_div_up(c, 256), b), dim3(256), 0, (hipStream_t)stream, c, nslices, part1,
+                     part2, wsum, scale1, shift1, scale2, shift2, out);
+  DCL_LAUNCH_CHECK();
+  return 0;
+}
+
 DCL_API int dcl_ortho9d_to_matrix(int b, const float *o9, float *R, dclStream_t stream) {
   DCL_CHECK_ARG(b >= 0);
   if (b == 0) return 0;

@@ -351,8 +351,8 @@ class Network(nn.Module):
             Fp1 = self._lin_relu(Fp1, Wt, bias)
         for Wt, bias in l2:
             Fp2 = self._lin_relu(Fp2, Wt, bias)
-        conf, P1, P2, ws = ops.conf_pool(b, logit1.reshape(-1), logit2.reshape(-1), Fp1, Fp2)
-        F_p_wei = sA * P1 + tA * ws[:, 0:1] + sB * P2 + tB * ws[:, 1:2]      # trailing BNs, after pooling
+        # trailing BNs after pooling: F_p_wei = sA*P1 + tA*sum(w1) + sB*P2 + tB*sum(w2), finished inside the pooling op
+        conf, F_p_wei = ops.conf_pool(b, logit1.reshape(-1), logit2.reshape(-1), Fp1, Fp2, affine=(sA, tA, sB, tB))
         o9 = self._mlp(F_p_wei, f["regressor_rot"])
         rot_pred = ops.ortho9d_to_matrix(o9)
         trans_pred = self._mlp(F_p_wei, f["regressor_trans"])

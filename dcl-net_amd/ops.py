@@ -524,9 +524,11 @@ def cross_attention(b, Q, K, V1, O1, V2=None, O2=None):
     return O1, O2
 
 
-def conf_pool(b, logit1, logit2, F1, F2):
+def conf_pool(b, logit1, logit2, F1, F2, affine=None):
     """Confidence pooling: logits (b*n1,)/(b*n2,), F1 (b*n1,C), F2 (b*n2,C) point-major ->
-    conf (b,n1+n2), pooled1 (b,C), pooled2 (b,C), wsum (b,2)."""
+    conf (b,n1+n2), pooled1 (b,C), pooled2 (b,C), wsum (b,2).
+    affine = (s1, t1, s2, t2), each (C,): returns (conf, ((s1*P1 + t1*wsum1) + s2*P2) + t2*wsum2) instead -- the pooled
+    feature behind trailing BatchNorms that were not applied to F1 / F2 -- finished in one launch."""
     N.need_cuda(logit1, logit2, F1, F2)
     n1, n2 = F1.shape[0] // b, F2.shape[0] // b
     c = F1.shape[1]
@@ -542,6 +544,14 @@ def conf_pool(b, logit1, logit2, F1, F2):
     N.check(N.lib().dcl_conf_pool(b, c, n1, n2, N.ptr(logit1), N.ptr(logit2), N.ptr(F1), _ld(F1), N.ptr(F2), _ld(F2),
                                   N.ptr(conf), N.ptr(w), nslices, N.ptr(part1), N.ptr(part2), N.ptr(ws), N.stream()),
             "conf_pool")
+    if affine is not None:
+        s1, t1, s2, t2 = affine
+        N.need_cuda(s1, t1, s2, t2)
+        assert all(t.is_contiguous() and t.numel() == c and t.dtype == torch.float32 for t in affine)
+        out = torch.empty((b, c), dtype=torch.float32, device=dev)
+        N.check(N.lib().dcl_pool_finish(b, c, nslices, N.ptr(part1), N.ptr(part2), N.ptr(ws), N.ptr(s1), N.ptr(t1),
+                                        N.ptr(s2), N.ptr(t2), N.ptr(out), N.stream()), "pool_finish")
+        return conf, out
     return conf, part1.sum(dim=1), part2.sum(dim=1), ws
 
 

@@ -454,6 +454,14 @@ def test_conf_pool_matches_torch(dcl):
     assert float(((p1 + p2).cpu().double() - want).abs().max()) <= 1e-5
     assert float((ws.cpu().double().sum(1) - 1).abs().max()) <= 1e-6
     assert float((ws[:, 0].cpu().double() - w[:, :n1].sum(1)).abs().max()) <= 1e-6
+    # one-launch finish behind trailing BatchNorms: sum_i w_i (s x_i + t) over both sides
+    s1, t1, s2, t2 = [torch.randn(c, generator=g) for _ in range(4)]
+    conf2, pooled = dcl.ops.conf_pool(b, l1.cuda().reshape(-1), l2.cuda().reshape(-1), F1.cuda().reshape(-1, c),
+                                      F2.cuda().reshape(-1, c), affine=(s1.cuda(), t1.cuda(), s2.cuda(), t2.cuda()))
+    assert torch.equal(conf2, conf)
+    want2 = (torch.einsum("bjc,bj->bc", F1.double() * s1.double() + t1.double(), w[:, :n1]) +
+             torch.einsum("bjc,bj->bc", F2.double() * s2.double() + t2.double(), w[:, n1:]))
+    assert float((pooled.cpu().double() - want2).abs().max()) <= 2e-5
 
 
 def test_ortho9d_matches_torch_svd(dcl):
