@@ -872,18 +872,29 @@ DCL_API int dcl_conf_pool(int b, int c, int n1, int n2, const float *logit1, con
   return 0;
 }
 
-// out[b][ch] = ((sA*P1 + tA*w0) + sB*P2) + tB*w1 with P = slice partials added in slice order: the pooled feature of
+// out[b][ch] = ((sA*P1 + tA*w0) + sB*P2) + tB*w1 with P = slice partials added in a fixed order: the pooled feature of
 // both directions behind the fusers' trailing BatchNorms (sum_i w_i (s x_i + t) = s sum w x + t sum w), one launch
 __global__ void k_pool_finish(int c, int nslices, const float *__restrict__ part1, const float *__restrict__ part2,
                               const float *__restrict__ wsum, const float *__restrict__ sA, const float *__restrict__ tA,
                               const float *__restrict__ sB, const float *__restrict__ tB, float *__restrict__ out) {
   const int b = blockIdx.y, ch = blockIdx.x * blockDim.x + threadIdx.x;
   if (ch >= c) return;
-  float p1 = 0.0f, p2 = 0.0f;
-  for (int s = 0; s < nslices; ++s) {
-    p1 += part1[((size_t)b * nslices + s) * c + ch];
-    p2 += part2[((size_t)b * nslices + s) * c + ch];
+  // slice s goes to accumulator s % 4 (four independent load chains), the four are combined in a fixed order
+  float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+  const float *q1 = part1 + (size_t)b * nslices * c + ch, *q2 = part2 + (size_t)b * nslices * c + ch;
+  int s = 0;
+  for (; s + 4 <= nslices; s += 4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      a1[j] += q1[(size_t)(s + j) * c];
+      a2[j] += q2[(size_t)(s + j) * c];
+    }
   }
+  for (int j = 0; s < nslices; ++s, ++j) {
+    a1[j] += q1[(size_t)s * c];
+    a2[j] += q2[(size_t)s * c];
+  }
+  const float p1 = (a1[0] + a1[1]) + (a1[2] + a1[3]), p2 = (a2[0] + a2[1]) + (a2[2] + a2[3]);
   const float w0 = wsum[2 * b], w1 = wsum[2 * b + 1];
   out[(size_t)b * c + ch] = ((sA[ch] * p1 + tA[ch] * w0) + sB[ch] * p2) + tB[ch] * w1;
 }

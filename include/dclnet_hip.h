@@ -291,7 +291,7 @@ int dcl_conf_pool(int b, int c, int n1, int n2, const float *logit1, const float
                   const float *F1, int ld1, const float *F2, int ld2, float *conf, float *w_scratch,
                   int nslices, float *part1, float *part2, float *wsum, dclStream_t stream);
 /* The second form of that sum in one launch: out (b,C) = ((s1*P1 + t1*wsum1) + s2*P2) + t2*wsum2 with
- * P = the slice partials of dcl_conf_pool added in slice order (s, t: the fusers' trailing BatchNorm1d in eval form). */
+ * P = the slice partials of dcl_conf_pool added in a fixed order (s, t: the fusers' trailing BatchNorm1d in eval form). */
 int dcl_pool_finish(int b, int c, int nslices, const float *part1, const float *part2, const float *wsum,
                     const float *scale1, const float *shift1, const float *scale2, const float *shift2, float *out,
                     dclStream_t stream);
