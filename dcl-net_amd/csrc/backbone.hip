@@ -113,11 +113,11 @@ bool make_feat_layout(const int32_t *counts, const int *chan /*9*/, FeatLayout *
     // split-K scratch of the two convs (only layers with few 128-row tiles split; see launch_conv_dma)
     for (int q = 1; q <= 2; ++q) {
       const size_t cout = (size_t)chan[2 * m + q];
-      if (cout % 64 != 0 || nc == 0) continue;
-      const size_t tiles = ((nc + 127) / 128) * (cout % 128 == 0 ? cout / 128 : cout / 64);
+      if (cout % 32 != 0 || nc == 0) continue;
+      const size_t tiles = ((nc + 127) / 128) * (cout % 128 == 0 ? cout / 128 : (cout % 64 == 0 ? cout / 64 : cout / 32));
       size_t split = (1024 + tiles - 1) / tiles;
       const size_t most = (size_t)dcl_internal_conv_split_cap((long long)nc);
-      if (split > most) split = most;
+      if (split > most || nc <= 65536) split = most;      // small passes (and capacity mode) may split all the way
       if (split > 1 && split * nc * cout > scratch) scratch = split * nc * cout;
     }
   }

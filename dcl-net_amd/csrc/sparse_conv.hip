@@ -314,7 +314,7 @@ template <int CIN, int WC, int KC>
 __global__ __launch_bounds__(256, 2) void k_sparse_conv_tile(
     const float *__restrict__ feat, const DclNbrSrc src, int cap, const int32_t *__restrict__ n_out_dev,
     int n_out_host, const float *__restrict__ W, int cout, int kvol, int subm, const float *__restrict__ scale,
-    const float *__restrict__ shift, int relu, float *__restrict__ out) {
+    const float *__restrict__ shift, int relu, float *__restrict__ out, float *__restrict__ partial, int nsplit) {
   constexpr int WR = 4 / WC;
   constexpr int BM = 32 * WR, BN = 32 * WC;
   constexpr int G = KC / CIN;                      // whole offsets per chunk
@@ -335,7 +335,11 @@ __global__ __launch_bounds__(256, 2) void k_sparse_conv_tile(
   const int wr = wave / WC, wc = wave % WC;
   const int col0 = blockIdx.y * BN;
   const int nblk = (n + BM - 1) / BM;
-  const int nchunks = (kvol + G - 1) / G;
+  // split-K (gridDim.z = nsplit > 1, launches with few row tiles): this workgroup owns the chunks [j_lo, nchunks) of the
+  // walk and leaves raw partial sums for k_conv_split_reduce
+  const int nchunks_all = (kvol + G - 1) / G;
+  const int j_lo = (int)((long long)blockIdx.z * nchunks_all / nsplit);
+  const int nchunks = (int)((long long)(blockIdx.z + 1) * nchunks_all / nsplit);
 
   for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
     const int row0 = blk * BM;
@@ -343,10 +347,12 @@ __global__ __launch_bounds__(256, 2) void k_sparse_conv_tile(
     __syncthreads();
     // neighbour table of the row block + which offsets it uses at all
     unsigned mymask = 0;
-    for (int e = tid; e < kvol * BM; e += 256) {
-      const int k = e / BM, rr = e - k * BM;
+    const int s_lo = j_lo * G, s_hi = min(kvol, nchunks * G);          // this split's offsets (walk order)
+    for (int e = tid; e < (s_hi - s_lo) * BM; e += 256) {
+      const int si = e / BM, rr = e - si * BM;
+      const int k = offset_at(s_lo + si, kvol, subm);
       const int v = (row0 + rr < n) ? dcl_nbr_at(src, cap, k, row0 + rr) : -1;
-      Ns[e] = v;
+      Ns[k * BM + rr] = v;
       mymask |= (v >= 0 ? 1u : 0u) << k;
     }
 #pragma unroll
@@ -402,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void k_sparse_conv_tile(
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
-    int j = next_used(0);
+    int j = next_used(j_lo);
     if (j < nchunks) fetch(j);
     while (j < nchunks) {
       __syncthreads();                                   // everyone is done reading the previous chunk's tiles
@@ -455,9 +461,13 @@ __global__ __launch_bounds__(256, 2) void k_sparse_conv_tile(
       const int orow = row0 + wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
       if (orow < n) {
         float x = acc[e];
-        if (scale) x = x * sc + sh;
-        if (relu) x = fmaxf(x, 0.0f);
-        out[(size_t)orow * cout + co] = x;
+        if (nsplit > 1) {
+          partial[((size_t)blockIdx.z * cap + orow) * cout + co] = x;
+        } else {
+          if (scale) x = x * sc + sh;
+          if (relu) x = fmaxf(x, 0.0f);
+          out[(size_t)orow * cout + co] = x;
+        }
       }
     }
     __syncthreads();
@@ -683,6 +693,10 @@ __global__ void k_conv_split_reduce(const float *__restrict__ partial, int nspli
 constexpr int kConvMaxSplit = 8;       // K-splits of a launch with many row tiles
 constexpr int kConvFewRows = 4096;     // at most this many output rows (capacity): up to one split per kernel offset
 static int conv_split_cap(long long rows) { return rows <= kConvFewRows ? 27 : kConvMaxSplit; }
+// launches that are latency-bound on the contraction walk: few output rows -- or, in capacity mode (whole-forward
+// hipGraph, a handful of crops), a row capacity of at most two crops' worth of cells, whatever the live count turns out to be
+constexpr int kConvFewRowsCap = 65536;
+static bool conv_few_rows(int rows, bool capacity_mode) { return capacity_mode ? rows <= kConvFewRowsCap : rows <= kConvFewRows; }
 static int g_conv_xcd_remap = 1;       // tuning hook: 0 = plain blockIdx order
 static int g_conv_split = 0;           // tuning hook: 0 = automatic, n = force n-way split-K when scratch allows, -1 = never more than kConvMaxSplit
 
@@ -702,9 +716,9 @@ static void launch_conv_dma(int rows, const float *feat, const DclNbrSrc &nbr, i
   const int nchunks = dcl_div_up(kvol * CIN, KC);
   int nsplit = 1;
   if (scratch) {
-    const bool few_rows = rows <= kConvFewRows && g_conv_split >= 0;
-    nsplit = g_conv_split > 0 ? g_conv_split : dcl_div_up(1024, tiles);
-    const int most = few_rows ? 27 : kConvMaxSplit;
+    const bool few_rows = conv_few_rows(rows, n_out_dev != nullptr) && g_conv_split >= 0;
+    nsplit = g_conv_split > 0 ? g_conv_split : (n_out_dev && few_rows ? 27 : dcl_div_up(1024, tiles));
+    const int most = few_rows ? conv_split_cap(rows) : kConvMaxSplit;
     if (nsplit > most) nsplit = most;
     if (nsplit > nchunks / (few_rows ? 4 : 8)) nsplit = nchunks / (few_rows ? 4 : 8);
     while (nsplit > 1 && (long long)nsplit * cap * cout > scratch_floats) --nsplit;
@@ -721,14 +735,27 @@ static void launch_conv_dma(int rows, const float *feat, const DclNbrSrc &nbr, i
 template <int CIN, int WC, int KC>
 static void launch_conv_tile(int rows, const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev,
                              int n_out_host, const float *W, int cout, int kvol, int subm, const float *scale,
-                             const float *shift, int relu, float *out, hipStream_t s) {
+                             const float *shift, int relu, float *out, float *scratch, long long scratch_floats,
+                             hipStream_t s) {
   constexpr int WR = 4 / WC, BM = 32 * WR, BN = 32 * WC;
   const size_t lds = (size_t)(BM * (KC + 4) + KC * BN + 27 * BM) * sizeof(float);
   (void)hipFuncSetAttribute((const void *)k_sparse_conv_tile<CIN, WC, KC>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
   const int nblk = dcl_div_up(rows, BM);
-  hipLaunchKernelGGL((k_sparse_conv_tile<CIN, WC, KC>), dim3(nblk < 65535 ? nblk : 65535, cout / BN), dim3(256), lds, s,
-                     feat, nbr, cap, n_out_dev, n_out_host, W, cout, kvol, subm, scale, shift, relu, out);
+  // one-image calls: a handful of row tiles walking all 27 offsets is pure latency -- split the walk (>= 1 chunk each)
+  const int nchunks = dcl_div_up(kvol, KC / CIN);
+  int nsplit = 1;
+  if (scratch && g_conv_split >= 0 && conv_few_rows(rows, n_out_dev != nullptr)) {
+    nsplit = g_conv_split > 0 ? g_conv_split : kConvMaxSplit;
+    if (nsplit > nchunks) nsplit = nchunks;
+    while (nsplit > 1 && (long long)nsplit * cap * cout > scratch_floats) --nsplit;
+    if (nsplit < 1) nsplit = 1;
+  }
+  hipLaunchKernelGGL((k_sparse_conv_tile<CIN, WC, KC>), dim3(nblk < 65535 ? nblk : 65535, cout / BN, nsplit), dim3(256), lds,
+                     s, feat, nbr, cap, n_out_dev, n_out_host, W, cout, kvol, subm, scale, shift, relu, out, scratch, nsplit);
+  if (nsplit > 1)
+    hipLaunchKernelGGL(k_conv_split_reduce, dim3(dcl_grid_1d((long long)rows * (cout / 4), 256)), dim3(256), 0, s, scratch,
+                       nsplit, cap, n_out_dev, n_out_host, cout, scale, shift, relu, out);
 }
 
 // ---- sparse average pool ------------------------------------------------------------------------
@@ -843,7 +870,8 @@ int dcl_internal_sparse_conv_fwd(const float *feat, const DclNbrSrc &nbr, int ca
   const bool lds_ok = mfma_ok && g_force_valu != 2 && (cin == 16 || cin == 32 || cin == 64 || cin == 128);
   if (lds_ok && g_force_valu != 3) {
     // implicit-GEMM tile kernel: 64x64 tiles (KC=128) when Cout allows, else 128x32 tiles (KC=64)
-#define TILE_ARGS rows, feat, nbr, cap, n_out_dev, n_out_host, W, cout, kvol, subm, scale, shift, relu, out, s
+#define TILE_ARGS rows, feat, nbr, cap, n_out_dev, n_out_host, W, cout, kvol, subm, scale, shift, relu, out, scratch, \
+                  (long long)scratch_floats, s
 #define DMA_ARGS rows, feat, nbr, cap, n_out_dev, n_out_host, W, cout, kvol, subm, scale, shift, relu, out, scratch, \
                  (long long)scratch_floats, s
     if (cout % 128 == 0 && g_force_valu != 4) {

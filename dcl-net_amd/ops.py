@@ -177,7 +177,7 @@ def sparse_conv(feat, nbr, n_out, W, subm, scale=None, shift=None, relu=False):
         return out
     # split-K scratch for layers with few row tiles (csrc/sparse_conv.hip::launch_conv_dma); none needed for big ones
     scratch = None
-    if cout % 64 == 0 and n_out <= 128 * 1024:
+    if cout % 32 == 0 and n_out <= 128 * 1024:
         need = C.c_int64(0)
         N.check(N.lib().dcl_sparse_conv_scratch_floats(int(cap), int(cout), C.byref(need)), "sparse_conv_scratch_floats")
         scratch = torch.empty(need.value, dtype=torch.float32, device=feat.device)
