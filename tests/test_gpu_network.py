@@ -240,6 +240,37 @@ def test_pipelined_calls_give_the_same_results(dcl):
             assert torch.equal(a[k], c[k]), k
 
 
+def test_chunked_sparse_half_and_stream_switches_give_the_same_results(dcl, monkeypatch):
+    """the batch-window backbone passes (DCL_CHUNKS: crops k*b/K .. of one occupied-voxel array, re-based per pass) and
+    the single-stream mode must return what the default schedule returns"""
+    n = 384
+    cfg = dcl.synth.default_cfg(n, n)
+    net = dcl.DCL_Net.Network(cfg, mode="test")
+    net.load_state_dict(dcl.synth.synth_state_dict(net, 1))
+    net = net.cuda().eval()
+    data = dcl.synth.make_batch(8, n, n)
+    with torch.no_grad():
+        ref = net(data)
+        outs = {}
+        for name, env in (("chunks2", {"DCL_CHUNKS": "2"}), ("chunks4", {"DCL_CHUNKS": "4"}),
+                          ("single", {"DCL_SINGLE_STREAM": "1"})):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            outs[name] = net(data)
+            for k in env:
+                monkeypatch.delenv(k)
+    # one stream: the same kernels in the same order -> identical bits.  Chunked passes have other row counts per launch,
+    # hence other split-K / GEMM tilings (other summation orders): equal within the parity tolerance of the path
+    for k in ("rot_pred", "trans_pred", "conf", "F_Xo_p"):
+        assert torch.equal(ref[k], outs["single"][k]), k
+    for name in ("chunks2", "chunks4"):
+        assert float((ref["rot_pred"] - outs[name]["rot_pred"]).abs().max()) <= 1e-4, name          # the path's parity bar
+        assert float((ref["trans_pred"] - outs[name]["trans_pred"]).abs().max()) <= 1e-5, name
+        assert float((ref["conf"] - outs[name]["conf"]).abs().max()) <= 1e-4, name
+        scale = float(ref["F_Xo_p"].abs().max())
+        assert float((ref["F_Xo_p"] - outs[name]["F_Xo_p"]).abs().max()) <= 1e-4 * max(1.0, scale), name
+
+
 def test_graph_cache_follows_the_weights(dcl):
     """a captured forward must not outlive the weights it was captured with; the model stays deep-copyable"""
     import copy
