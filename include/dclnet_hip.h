@@ -135,7 +135,9 @@ int dcl_sparse_conv_fwd(const float *feat, const int32_t *nbr, int cap, const in
 
 /* Same, with caller scratch: layers whose row count cannot fill the GPU split the 27*Cin contraction over up to 8
  * workgroup groups -- up to 27, one per kernel offset, when cap <= 4096 rows (one-image calls are latency-bound on the
- * contraction loop) -- with partial sums in `scratch`, added in split order by a second kernel, then the epilogue.
+ * contraction loop; with n_out_dev, i.e. in capacity mode, launches of up to 65536 capacity rows count as such too, and
+ * the Cout = 32 layers split as well) -- with partial sums in `scratch`, added in split order by a second kernel, then
+ * the epilogue.
  * scratch_floats >= dcl_sparse_conv_scratch_floats(cap, cout) enables every split; NULL = dcl_sparse_conv_fwd.   */
 int dcl_sparse_conv_fwd_ws(const float *feat, const int32_t *nbr, int cap, const int32_t *n_out_dev,
                            int n_out_host, const float *W, int cin, int cout, int kvol, int subm,
