@@ -139,3 +139,15 @@ def refine_loop(refiner, pred, points_inp, iteration=2, graph=False):
             dst.copy_(src)
         g.replay()
         return out[0].clone(), out[1].clone()
+
+
+def stage2_chain(model, refiner, data, iteration=2, graph=True):
+    """BASELINE configs[4] as one call: the body of the reference's stage-2 eval loop (tools/test_YCBV_stage2.py:204-225):
+    `model(data)` -> canonicalised points (P - t) R -> cat[points, F_Xo_p] -> `iteration` x refiner with pose composition
+    t <- R dt + t, R <- R dR.  -> (rot (b,3,3), trans (b,3), stage-1 prediction dict).  With graph=True the refine loop
+    replays its hipGraph (static shapes); the stage-1 forward keeps its own schedule (eager or forward_graphed)."""
+    with torch.no_grad():
+        pred = model(data)
+        points_inp = data["labels"]["points_inp"]
+        rot, trans = refine_loop(refiner, pred, points_inp, iteration, graph=graph)
+    return rot, trans, pred

@@ -10,7 +10,8 @@ tests/test_oracle_golden.py then checks oracle/graph.py (the restatement that tr
 against these vectors; the GPU parity tests check the HIP path against both.
 
     python tests/golden/make_golden.py        # rewrites tests/golden/dclnet_b2_n256.npz, refiner_b2.npz,
-                                              # dclnet_s0_train.npz, dclnet_nm384_train.npz
+                                              # dclnet_s0_train.npz, dclnet_nm384_train.npz,
+                                              # dclnet_b4_n1024_chain.npz
 """
 import importlib
 import os
@@ -243,7 +244,67 @@ def main():
                 out2["%s_%s" % (side, k)] = in2[side][k].numpy()
         np.savez_compressed(os.path.join(ROOT, "tests", "golden", "dclnet_%s_train.npz" % tag), **out2)
         print("golden written: dclnet_%s_train.npz" % tag, out2.get("losses"), out2.get("loss_refiner"))
+    chain_golden(ref_net_mod, ref_refiner_mod)
+
+
+def chain_golden(ref_net_mod, ref_refiner_mod):
+    """The shape the shipped yaml defines (N = M = 1024, configs/config_YCBV_bs32.yaml:24-25), b = 4, test mode, and
+    BASELINE configs[4]: the reference Network's outputs chained into 2 refiner iterations exactly as
+    tools/test_YCBV_stage2.py:204-225 does it, plus the ADD-S distance of the final pose (:233-235, with the template
+    cloud standing in for the class's CAD points)."""
+    b, n, iteration = 4, 1024, 2
+    cfg = dcl.synth.default_cfg(n, n)
+    net = ref_net_mod.Network(attr(dict(cfg)), mode="test")
+    net.load_state_dict(dcl.synth.synth_state_dict(net, seed=1))
+    net.eval()
+    refiner = ref_refiner_mod.Refiner(None)
+    refiner.load_state_dict(dcl.synth.synth_state_dict(refiner, seed=2))
+    refiner.eval()
+    data = dcl.synth.make_batch(b, n, n, first=50, voxelize_idx=lambda c, bs, mode: tuple(
+        torch.from_numpy(a) for a in K.voxelize_idx(c.numpy(), bs, mode)))
+    inputs = clone_data(data)
+    cls_label = data["obj_idx"]
+    with torch.no_grad():
+        outputs_main = net(data)
+        rot_cur, trans_cur = outputs_main["rot_pred"], outputs_main["trans_pred"]
+        points_inp = data["labels"]["points_inp"]
+        points_inp_cur = torch.bmm(points_inp - trans_cur.unsqueeze(1), rot_cur)
+        F_Xo_p = outputs_main["F_Xo_p"]
+        inp_refiner = torch.cat([points_inp_cur.transpose(1, 2), F_Xo_p], dim=1).detach()
+        conf = outputs_main["conf"]
+        per_iter = []
+        for _ in range(iteration):
+            o = refiner({"input_features": inp_refiner, "conf": conf, "obj_idx": cls_label})
+            trans_cur = (rot_cur @ o["trans_pred"].unsqueeze(2)).squeeze(2) + trans_cur
+            rot_cur = rot_cur @ o["rot_pred"]
+            per_iter.append((rot_cur.clone(), trans_cur.clone()))
+            points_inp_cur = torch.bmm(points_inp - trans_cur.unsqueeze(1), rot_cur)
+            inp_refiner = torch.cat([points_inp_cur.transpose(1, 2), F_Xo_p], dim=1).detach()
+        cld = data["labels"]["points_tmp"]
+        rot_gt, trans_gt = inputs["labels"]["rot_gt"], inputs["labels"]["trans_gt"]
+        adds = []
+        for R, t in ((outputs_main["rot_pred"], outputs_main["trans_pred"]), (rot_cur, trans_cur)):
+            pp = torch.bmm(cld, R.transpose(1, 2)) + t.unsqueeze(1)
+            pg = torch.bmm(cld, rot_gt.transpose(1, 2)) + trans_gt.unsqueeze(1)
+            adds.append(torch.mean(torch.min(torch.norm(pp.unsqueeze(2) - pg.unsqueeze(1), dim=3), 2)[0], dim=1))
+    out = {"trans_pred": outputs_main["trans_pred"].numpy(), "rot_pred": outputs_main["rot_pred"].numpy(),
+           "conf": conf.numpy(), "F_Xo_p_sub": F_Xo_p[:, ::8, ::8].contiguous().numpy(),
+           "F_Xo_p_sum": F_Xo_p.double().sum(dim=2).numpy(),
+           "rot_iter1": per_iter[0][0].numpy(), "trans_iter1": per_iter[0][1].numpy(),
+           "rot_final": rot_cur.numpy(), "trans_final": trans_cur.numpy(),
+           "adds_stage1": adds[0].numpy(), "adds_final": adds[1].numpy(),
+           "rot_gt": rot_gt.numpy(), "trans_gt": trans_gt.numpy(), "obj_idx": cls_label.numpy(),
+           "meta": np.array([b, n, n, 1], np.int64), "refiner_seed": np.array([2]), "first_crop": np.array([50])}
+    for side in ("inp", "tmp"):
+        for k in ("feats", "occupied_voxels", "p2v_maps", "v2p_maps"):
+            out["%s_%s" % (side, k)] = inputs[side][k].numpy()
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "dclnet_b4_n1024_chain.npz"), **out)
+    print("golden written: dclnet_b4_n1024_chain.npz  ADD-S stage1", adds[0].numpy(), "final", adds[1].numpy())
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "chain":           # only the N=M=1024 / stage-2 chain fixture
+        install_stubs()
+        chain_golden(importlib.import_module("models.DCL_Net"), importlib.import_module("models.refiner"))
+    else:
+        main()

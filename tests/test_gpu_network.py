@@ -129,6 +129,103 @@ def test_refiner_matches_reference_golden(dcl, golden_dir):
         assert np.abs(trans.cpu().numpy() - z["trans_final"]).max() <= T_TOL
 
 
+@pytest.mark.parametrize("graphed", [False, True])
+def test_reference_shape_and_stage2_chain_match_reference_golden(dcl, golden_dir, graphed):
+    """N = M = 1024 (the shape config_YCBV_bs32.yaml defines), b = 4, vectors from the REFERENCE's Network + Refiner:
+    stage-1 outputs, then BASELINE configs[4] -- model(data) -> (P - t) R -> cat[points, F_Xo_p] -> 2 x refiner with pose
+    composition (tools/test_YCBV_stage2.py:204-225) -- as ONE pipeline (refiner.stage2_chain), eager and with the
+    whole-forward / refine-loop hipGraphs; ADD-S of both poses through the fused metric kernel"""
+    data, exp, (b, n_inp, n_tmp, wseed) = load_golden_data(os.path.join(golden_dir, "dclnet_b4_n1024_chain.npz"))
+    cfg = dcl.synth.default_cfg(n_inp, n_tmp)
+    net = dcl.DCL_Net.Network(cfg, mode="test", graph_max_batch=8 if graphed else 0)
+    net.load_state_dict(dcl.synth.synth_state_dict(net, wseed))
+    net = net.cuda().eval()
+    ref = dcl.refiner.Refiner()
+    ref.load_state_dict(dcl.synth.synth_state_dict(ref, int(exp["refiner_seed"][0])))
+    ref = ref.cuda().eval()
+    for _ in range(2):                                                       # second round: graph replays
+        d = {k: ({kk: vv.clone() for kk, vv in v.items()} if isinstance(v, dict) else v) for k, v in data.items()}
+        rot, trans, pred = dcl.refiner.stage2_chain(net, ref, d, 2, graph=graphed)
+        _check(pred, exp["rot_pred"], exp["trans_pred"], exp["conf"])
+        sub = pred["F_Xo_p"][:, ::8, ::8].cpu().numpy()
+        assert np.abs(sub - exp["F_Xo_p_sub"]).max() <= 1e-4 * max(1.0, np.abs(exp["F_Xo_p_sub"]).max())
+        assert np.abs(rot.cpu().numpy() - exp["rot_final"]).max() <= R_TOL
+        assert np.abs(trans.cpu().numpy() - exp["trans_final"]).max() <= T_TOL
+        rot1, trans1 = dcl.refiner.refine_loop(ref, pred, d["labels"]["points_inp"], 1, graph=graphed)
+        assert np.abs(rot1.cpu().numpy() - exp["rot_iter1"]).max() <= R_TOL
+        assert np.abs(trans1.cpu().numpy() - exp["trans_iter1"]).max() <= T_TOL
+        cld = d["labels"]["points_tmp"]
+        Rg, tg = torch.from_numpy(exp["rot_gt"]).cuda(), torch.from_numpy(exp["trans_gt"]).cuda()
+        for (R, t), key in (((pred["rot_pred"], pred["trans_pred"]), "adds_stage1"), ((rot, trans), "adds_final")):
+            got = dcl.ops.add_s(cld.contiguous(), R, t, Rg, tg).cpu().numpy()
+            assert np.abs(got - exp[key]).max() <= 2e-5, key
+    if graphed:
+        assert len(net._graphs) == 1 and len(ref._graphs) == 2               # (iteration=2) and (iteration=1) loops
+
+
+def test_bs40_config_forward(dcl, oracle):
+    """BASELINE configs[2]'s per-GPU shape: 40 crops per call (config_YCBV_bs40.yaml: bs 40), N = M = 1024.  Four crops
+    spread over the batch are checked against the CPU oracle graph run on exactly those crops (crops are independent);
+    all 40 get the size-independent checks (valid rotations, confidences in (0,1), determinism, no NaN) and the metric
+    table of the batch reduces to 40 frames"""
+    from oracle import graph as G
+    b, n = 40, 1024
+    net, sd, cfg = _net(dcl, n, n, 1)
+    data = dcl.synth.make_batch(b, n, n, first=100)
+    with torch.no_grad():
+        p1 = net(data)
+        p2 = net(dcl.synth.make_batch(b, n, n, first=100))
+    R = p1["rot_pred"].double()
+    assert tuple(R.shape) == (b, 3, 3) and tuple(p1["conf"].shape) == (b, 2 * n) and tuple(p1["F_Xo_p"].shape) == (b, 256, n)
+    assert float((R @ R.transpose(1, 2) - torch.eye(3, dtype=torch.float64, device="cuda")).abs().max()) <= 1e-5
+    assert float((torch.linalg.det(R) - 1).abs().max()) <= 1e-5
+    assert bool(((p1["conf"] > 0) & (p1["conf"] < 1)).all()) and bool(torch.isfinite(p1["F_Xo_p"]).all())
+    for k in ("rot_pred", "trans_pred", "conf"):
+        assert torch.equal(p1[k], p2[k]), k
+    for i in (0, 13, 27, 39):
+        one = dcl.synth.make_batch(1, n, n, first=100 + i, voxelize_idx=lambda c, bs, mode: tuple(
+            torch.from_numpy(a) for a in oracle.voxelize_idx(c.numpy(), bs, mode)))
+        want = G.forward(sd, dict(cfg), one, mode="test")
+        assert float((p1["rot_pred"][i].cpu() - want["rot_pred"][0]).abs().max()) <= R_TOL, i
+        assert float((p1["trans_pred"][i].cpu() - want["trans_pred"][0]).abs().max()) <= T_TOL, i
+        assert float((p1["conf"][i].cpu() - want["conf"][0]).abs().max()) <= 1e-4, i
+        wF = want["F_Xo_p"][0]
+        assert float((p1["F_Xo_p"][i].cpu() - wF).abs().max()) <= 1e-4 * max(1.0, float(wF.abs().max())), i
+    d = dcl.sharding.add_s(data["labels"]["points_tmp"].contiguous(), p1["rot_pred"], p1["trans_pred"],
+                           data["labels"]["rot_gt"].cuda(), data["labels"]["trans_gt"].cuda()).cpu().tolist()
+    table = dcl.sharding.AddsTable()
+    for c, x in zip(data["obj_idx"].tolist(), d):
+        table.add(int(c), float(x))
+    assert int(table.sums[:, 0].sum()) == b
+
+
+def test_stress_shape_full_batch_properties(dcl):
+    """BASELINE configs[1] at its full size (b = 32, N = 12288, M = 2048; what bench.py times): valid rotations, finite
+    outputs, determinism, and batch invariance -- crops 3 and 30 recomputed alone (4-wave attention kernel, other conv
+    tilings) give the same pose"""
+    n_inp, n_tmp, b = 12288, 2048, 32
+    cfg = dcl.synth.default_cfg(n_inp, n_tmp)
+    net = dcl.DCL_Net.Network(cfg, mode="test")
+    net.load_state_dict(dcl.synth.synth_state_dict(net, 1))
+    net = net.cuda().eval()
+    data = dcl.synth.make_batch(b, n_inp, n_tmp)
+    with torch.no_grad():
+        full = net(data)
+        again = net(data)
+    R = full["rot_pred"].double()
+    assert float((R @ R.transpose(1, 2) - torch.eye(3, dtype=torch.float64, device="cuda")).abs().max()) <= 1e-5
+    assert float((torch.linalg.det(R) - 1).abs().max()) <= 1e-5
+    assert bool(torch.isfinite(full["F_Xo_p"]).all()) and bool(((full["conf"] > 0) & (full["conf"] < 1)).all())
+    for k in ("rot_pred", "trans_pred", "conf"):
+        assert torch.equal(full[k], again[k]), k
+    with torch.no_grad():
+        for i in (3, 30):
+            one = net(dcl.synth.make_batch(1, n_inp, n_tmp, first=i))
+            assert float((one["rot_pred"][0] - full["rot_pred"][i]).abs().max()) <= R_TOL
+            assert float((one["trans_pred"][0] - full["trans_pred"][i]).abs().max()) <= T_TOL
+            assert float((one["conf"][0] - full["conf"][i]).abs().max()) <= 1e-4
+
+
 def test_full_size_properties(dcl):
     """BASELINE-size batch (b=32, N=M=1024): size-independent properties -- valid rotations, softmax-normalised
     confidences, determinism, and batch-composition invariance (crop i's pose does not depend on its batch mates)."""

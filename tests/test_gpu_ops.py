@@ -559,15 +559,18 @@ def test_backbone_runner_edge_cases(dcl, oracle):
 
 
 @pytest.mark.gpu
-def test_point_neighbours_grid_search_is_exact(dcl):
-    """the grid-pruned 3-NN of the point read-out (levels with 32^3 / 16^3 cells) returns bit-for-bit what the per-crop
-    scan returns -- distances, rows and tie order -- for surface points, lattice points (8-way ties), isolated and
-    out-of-grid queries (scan fallback), an empty crop and invalid crop ids; so does the split read-out API"""
+@pytest.mark.parametrize("scales,unit", [((2, 4, 8, 16), 0.006), ((2, 4, 6, 8), 0.006), ((2, 4, 6, 8), 0.005)])
+def test_point_neighbours_grid_search_is_exact(dcl, scales, unit):
+    """the grid-pruned 3-NN of the point read-out returns bit-for-bit what the per-crop scan returns -- distances, rows and
+    tie order -- for surface points, lattice points (8-way ties), isolated and out-of-grid queries (scan fallback), an
+    empty crop and invalid crop ids; so does the split read-out API.  Extents: the true strides (2,4,8,16) and the
+    PRODUCTION quirk (2,4,6,8) of models/DCL_Net.py:54, whose level-3/4 centre lattices (pitch 6u / 8u) do not coincide
+    with the 8^3 / 4^3 occupancy cells (pitch 8u / 16u) -- the case a wrong bound / certification would hide in."""
     rng = np.random.default_rng(23)
     occ, b = _edge_voxels(rng)
-    S, unit = 64, 0.006
+    S = 64
     off = float(np.float32(-0.5 * unit * 64))
-    extents = [float(np.float32(unit * sc)) for sc in (2, 4, 8, 16)]
+    extents = [float(np.float32(unit * sc)) for sc in scales]
     run = dcl.ops.BackboneRun(cuda(occ), b, S)
     run.set_counts(run.counts_dev.cpu().tolist())
     q = []
@@ -578,6 +581,10 @@ def test_point_neighbours_grid_search_is_exact(dcl):
             q.append(np.c_[np.full(300, bi), (pick + rng.uniform(0, 1, pick.shape)) * unit + off])      # points inside occupied voxels
             q.append(np.c_[np.full(100, bi), (pick[:100] * unit + off).astype(np.float32)])             # voxel corners: lattice ties
             q.append(np.c_[np.full(100, bi), ((pick[:100] // 2 * 2 + 1) * unit + off)])                 # level-0 cell centres / corners
+            for lvl, cell in ((2, 8), (3, 16)):                                                         # coarse levels: centres and
+                ci = pick[:60] // cell                                                                  # mid-points of the centre lattice
+                q.append(np.c_[np.full(60, bi), (ci * scales[lvl] + 0.5 * scales[lvl]) * unit + off])   # (pitch = scales[lvl] units)
+                q.append(np.c_[np.full(60, bi), ((ci + 1) * scales[lvl]) * unit + off])
         q.append(np.c_[np.full(60, bi), rng.uniform(-0.192, 0.192, (60, 3))])                           # anywhere in the grid
         q.append(np.c_[np.full(20, bi), rng.uniform(-0.5, 0.5, (20, 3))])                               # partly outside the grid
     q.append(np.c_[np.array([-1.0, b, 0.5, np.nan]), np.zeros((4, 3))])                                 # crop ids that match nothing

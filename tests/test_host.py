@@ -96,6 +96,67 @@ def test_yaml_config_loader(dcl, tmp_path):
     assert net.n_inp == 1024 and cfg.model.backbone.kernel_size == 3
 
 
+def test_yaml_loader_on_the_reference_configs(dcl):
+    """the reference's own yaml files (read here in the build container only; skipped where /root/reference is absent):
+    every model block builds a Network / Refiner with the shapes the configs promise"""
+    import glob
+    import pytest
+    files = sorted(glob.glob("/root/reference/configs/*.yaml"))
+    if not files:
+        pytest.skip("reference configs not present on this box")
+    for f in files:
+        cfg = dcl.synth.load_yaml_cfg(f)
+        m = cfg.model
+        assert m.voxelization_mode == 4 and len(m.unit_voxel_extent) == 3 and m.backbone.kernel_size == 3
+        net = dcl.DCL_Net.Network(m, mode="test")
+        assert (net.n_inp, net.n_tmp) == (m.n_inp, m.n_tmp) == (1024, 1024)
+        assert len(net.state_dict()) == 270
+
+
+def test_load_checkpoint_layouts(dcl, tmp_path):
+    """synth.load_checkpoint against the layouts the reference's tools produce and read: gorilla.solver.save_checkpoint's
+    dict {"model": state_dict, "optimizer": ..., "scheduler": ..., "meta": ...} (tools/train_YCBV_stage1.py:102-104, read
+    back by tools/test_YCBV_stage1.py:233-235), the same saved from an nn.DataParallel wrapper ("module." prefixes,
+    tools/test_YCBV_stage1.py:230-231), a {"state_dict": ...} dict, and a bare state_dict; wrong shapes must raise"""
+    import pytest
+    cfg = dcl.synth.default_cfg(64, 64)
+    src = dcl.DCL_Net.Network(cfg, mode="test")
+    sd = dcl.synth.synth_state_dict(src, 11)
+    layouts = {
+        "gorilla": {"model": sd, "optimizer": {"state": {}, "param_groups": []}, "scheduler": {"last_epoch": 3},
+                    "meta": {"epoch": 30, "iter": 1234}},
+        "dataparallel": {"model": {"module." + k: v for k, v in sd.items()}, "meta": {"epoch": 2}},
+        "state_dict": {"state_dict": sd},
+        "bare": sd,
+    }
+    for name, obj in layouts.items():
+        path = str(tmp_path / (name + ".pth"))
+        torch.save(obj, path)
+        net = dcl.DCL_Net.Network(cfg, mode="test")
+        meta = dcl.synth.load_checkpoint(net, path)
+        got = net.state_dict()
+        assert sorted(got.keys()) == sorted(sd.keys())
+        for k, v in sd.items():
+            assert torch.equal(got[k], v), (name, k)
+        assert meta == (obj.get("meta", {}) if name in ("gorilla", "dataparallel") else {}), name
+    ref = dcl.refiner.Refiner()
+    sdr = dcl.synth.synth_state_dict(ref, 12)
+    path = str(tmp_path / "refiner.pth")
+    torch.save({"model": sdr, "meta": {"epoch": 9}}, path)
+    ref2 = dcl.refiner.Refiner()
+    assert dcl.synth.load_checkpoint(ref2, path) == {"epoch": 9}
+    assert all(torch.equal(ref2.state_dict()[k], v) for k, v in sdr.items())
+    bad = dict(sd)
+    bad["neck_fuser.layers.6.weight"] = torch.zeros(1024, 256, 1)
+    torch.save({"model": bad}, str(tmp_path / "bad.pth"))
+    with pytest.raises(RuntimeError):
+        dcl.synth.load_checkpoint(dcl.DCL_Net.Network(cfg, mode="test"), str(tmp_path / "bad.pth"))
+    missing = {k: v for k, v in sd.items() if not k.startswith("regressor_rot")}
+    torch.save({"model": missing}, str(tmp_path / "missing.pth"))
+    with pytest.raises(RuntimeError):
+        dcl.synth.load_checkpoint(dcl.DCL_Net.Network(cfg, mode="test"), str(tmp_path / "missing.pth"))
+
+
 def test_synth_batch_contract(dcl):
     d = dcl.synth.make_batch(3, 128, 96)
     assert d["inp"]["feats"].shape == (3 * 128, 7) and d["tmp"]["feats"].shape == (3 * 96, 7)

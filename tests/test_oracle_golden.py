@@ -61,6 +61,33 @@ def test_refiner_matches_reference(dcl, golden_dir):
     assert np.abs(trans.numpy() - z["trans_final"]).max() <= 1e-5
 
 
+def test_reference_shape_and_stage2_chain_match_reference(dcl, oracle, golden_dir):
+    """N = M = 1024 (what config_YCBV_bs32.yaml defines), b = 4: the oracle graph against the reference Network's
+    outputs, then BASELINE configs[4] -- stage-1 outputs chained into 2 refiner iterations with pose composition
+    (tools/test_YCBV_stage2.py:204-225) -- and the ADD-S distance of both poses"""
+    data, exp, (b, n_inp, n_tmp, wseed) = load_golden_data(os.path.join(golden_dir, "dclnet_b4_n1024_chain.npz"))
+    cfg = dcl.synth.default_cfg(n_inp, n_tmp)
+    sd = _state(dcl, cfg, wseed, dcl.DCL_Net.Network)
+    pred = G.forward(sd, dict(cfg), data, mode="test")
+    assert np.abs(pred["rot_pred"].numpy() - exp["rot_pred"]).max() <= 1e-4
+    assert np.abs(pred["trans_pred"].numpy() - exp["trans_pred"]).max() <= 1e-5
+    assert np.abs(pred["conf"].numpy() - exp["conf"]).max() <= 1e-5
+    got_sub = pred["F_Xo_p"][:, ::8, ::8].numpy()
+    assert np.abs(got_sub - exp["F_Xo_p_sub"]).max() <= 1e-4 * max(1.0, np.abs(exp["F_Xo_p_sub"]).max())
+    sdr = _state(dcl, None, int(exp["refiner_seed"][0]), dcl.refiner.Refiner)
+    rot1, trans1 = G.refine_loop(sdr, pred, data["labels"]["points_inp"], 1)
+    assert np.abs(rot1.numpy() - exp["rot_iter1"]).max() <= 1e-4
+    assert np.abs(trans1.numpy() - exp["trans_iter1"]).max() <= 1e-5
+    rot, trans = G.refine_loop(sdr, pred, data["labels"]["points_inp"], 2)
+    assert np.abs(rot.numpy() - exp["rot_final"]).max() <= 1e-4
+    assert np.abs(trans.numpy() - exp["trans_final"]).max() <= 1e-5
+    cld = data["labels"]["points_tmp"]
+    Rg, tg = torch.from_numpy(exp["rot_gt"]), torch.from_numpy(exp["trans_gt"])
+    for (R, t), key in (((pred["rot_pred"], pred["trans_pred"]), "adds_stage1"), ((rot, trans), "adds_final")):
+        d = dcl.sharding.add_s(cld, R, t, Rg, tg)
+        assert np.abs(d.numpy() - exp[key]).max() <= 2e-5, key
+
+
 def _train_cases(golden_dir):
     return [os.path.join(golden_dir, f) for f in ("dclnet_s0_train.npz", "dclnet_nm384_train.npz")]
 
