@@ -256,6 +256,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
+        if world == 1:                                         # DCL_FORCE_DIST=1 without a launcher: a one-rank RCCL group
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)         # RCCL over xGMI
     dcl = importlib.import_module("dcl-net_amd")
     b = args.batch
@@ -296,6 +301,7 @@ def main():
         table.add(int(c), float(x))
     table.reduce(device=dev)
     auc, acc2, _, _ = table.finalize()
+    assert int(table.sums[:, 0].sum()) == world * b, "metric reduction lost frames"
 
     line = {"metric": "frames/sec DCL_Net.forward @ YCB-V bs32", "value": round(value, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),

@@ -362,6 +362,48 @@ __global__ void k_pairs_export(const int32_t *__restrict__ nbr, int cap, const i
   }
 }
 
+// reference pair lists -> gather table.  An output row occurs at most once per kernel offset (spconv_ops.h:296-344 relies
+// on the same fact for its non-atomic scatter-add), so the writes of one offset never collide.
+__global__ void k_pairs_import(const int32_t *__restrict__ pairs, int pair_stride, const int32_t *__restrict__ indice_num,
+                               int kvol, int n_in, int n_out, int32_t *__restrict__ nbr, int cap,
+                               int32_t *__restrict__ bad) {
+  const long long total = (long long)kvol * pair_stride;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(t / pair_stride);
+    const int j = (int)(t - (long long)k * pair_stride);
+    if (j >= indice_num[k]) continue;
+    const int i = pairs[((size_t)k * 2 + 0) * pair_stride + j];
+    const int o = pairs[((size_t)k * 2 + 1) * pair_stride + j];
+    if ((unsigned)i >= (unsigned)n_in || (unsigned)o >= (unsigned)n_out) {
+      if (bad) atomicAdd(bad, 1);
+      continue;
+    }
+    nbr[(size_t)k * cap + o] = i;
+  }
+}
+
+// indiceSummaryRF on the pair format (summaryRF.cu:26-41): rf[out] += 1 per pair.  rf must be zeroed by the caller's launch
+// order (k_fill_i32 below).
+__global__ void k_pairs_summary_rf(const int32_t *__restrict__ pairs, int pair_stride, const int32_t *__restrict__ indice_num,
+                                   int kvol, int n_out, int32_t *__restrict__ rf) {
+  const long long total = (long long)kvol * pair_stride;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(t / pair_stride);
+    const int j = (int)(t - (long long)k * pair_stride);
+    if (j >= indice_num[k]) continue;
+    const int o = pairs[((size_t)k * 2 + 1) * pair_stride + j];
+    if ((unsigned)o < (unsigned)n_out) atomicAdd(&rf[o], 1);
+  }
+}
+
+__global__ void k_fill_i32(int32_t *__restrict__ p, long long n, int32_t v, int32_t *__restrict__ zero_word) {
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x)
+    p[t] = v;
+  if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0;
+}
+
 int scan_mask(const uint32_t *mask, int nwords, int32_t *wprefix, int32_t *scratch, hipStream_t s) {
   const int nblocks = dcl_div_up(nwords, kScanWords);
   if (nblocks <= 32 && (reinterpret_cast<uintptr_t>(mask) & 15) == 0) {
@@ -544,6 +586,35 @@ DCL_API int dcl_rulebook_to_pairs(const int32_t *nbr, int cap, const int32_t *n_
                      indice_num, kvol);
   hipLaunchKernelGGL(k_pairs_export, dim3(dcl_grid_1d((long long)cap * kvol, 256)), dim3(256), 0, s, nbr, cap,
                      n_out_dev, n_out_host, kvol, indice_pairs, n_in_cap, indice_num);
+  DCL_LAUNCH_CHECK();
+  return 0;
+}
+
+DCL_API int dcl_rulebook_from_pairs(const int32_t *indice_pairs, int pair_stride, const int32_t *indice_num_dev, int kvol,
+                                    int n_in, int n_out, int32_t *nbr, int cap, int32_t *bad_pairs_dev,
+                                    dclStream_t stream) {
+  DCL_CHECK_ARG(indice_pairs && indice_num_dev && nbr && kvol > 0 && kvol <= 27 && pair_stride >= 0 && n_in >= 0 &&
+                n_out >= 0 && cap > 0 && n_out <= cap);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_fill_i32, dim3(dcl_grid_1d((long long)kvol * cap, 256)), dim3(256), 0, s, nbr, (long long)kvol * cap,
+                     -1, bad_pairs_dev);
+  if (pair_stride > 0 && n_out > 0)
+    hipLaunchKernelGGL(k_pairs_import, dim3(dcl_grid_1d((long long)kvol * pair_stride, 256)), dim3(256), 0, s, indice_pairs,
+                       pair_stride, indice_num_dev, kvol, n_in, n_out, nbr, cap, bad_pairs_dev);
+  DCL_LAUNCH_CHECK();
+  return 0;
+}
+
+DCL_API int dcl_indice_summary_rf(const int32_t *indice_pairs, int pair_stride, const int32_t *indice_num_dev, int kvol,
+                                  int n_out, int32_t *rf, dclStream_t stream) {
+  DCL_CHECK_ARG(indice_pairs && indice_num_dev && kvol > 0 && kvol <= 27 && pair_stride >= 0 && n_out >= 0 &&
+                (rf || n_out == 0));
+  if (n_out == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_fill_i32, dim3(dcl_grid_1d(n_out, 256)), dim3(256), 0, s, rf, (long long)n_out, 0, nullptr);
+  if (pair_stride > 0)
+    hipLaunchKernelGGL(k_pairs_summary_rf, dim3(dcl_grid_1d((long long)kvol * pair_stride, 256)), dim3(256), 0, s,
+                       indice_pairs, pair_stride, indice_num_dev, kvol, n_out, rf);
   DCL_LAUNCH_CHECK();
   return 0;
 }

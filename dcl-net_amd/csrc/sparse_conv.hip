@@ -763,7 +763,8 @@ static void launch_conv_tile(int rows, const float *feat, const DclNbrSrc &nbr, 
 // out = ((0 + f_k0/rf) + f_k1/rf) + ... in ascending offset order (avgpool.cu:130).
 __global__ __launch_bounds__(256) void k_sparse_avgpool(const float *__restrict__ feat, const DclNbrSrc src, int cap,
                                                         const int32_t *__restrict__ n_out_dev, int n_out_host, int c, int kvol,
-                                                        float *__restrict__ out, int32_t *__restrict__ rf_out) {
+                                                        float *__restrict__ out, int32_t *__restrict__ rf_out,
+                                                        const int32_t *__restrict__ rf_in) {
   // the c/4 threads of an output row share its 27 neighbour rows through LDS (one lookup per (row, offset) per block)
   __shared__ int32_t s_v[64 * 27];
   int n = n_out_dev ? *n_out_dev : n_out_host;
@@ -784,6 +785,7 @@ __global__ __launch_bounds__(256) void k_sparse_avgpool(const float *__restrict_
     const int32_t *v = s_v + rr * 27;
     int rf = 0;
     for (int k = 0; k < kvol; ++k) rf += v[k] >= 0;
+    if (rf_in) rf = rf_in[row];                            // caller's summaryrf (indice_avgpool_fp32's 5th argument)
     const float d = (float)rf;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int k = 0; k < kvol; ++k) {
@@ -798,7 +800,8 @@ __global__ __launch_bounds__(256) void k_sparse_avgpool(const float *__restrict_
 
 __global__ void k_sparse_avgpool_scalar(const float *__restrict__ feat, const DclNbrSrc src, int cap,
                                         const int32_t *__restrict__ n_out_dev, int n_out_host, int c, int kvol,
-                                        float *__restrict__ out, int32_t *__restrict__ rf_out) {
+                                        float *__restrict__ out, int32_t *__restrict__ rf_out,
+                                        const int32_t *__restrict__ rf_in) {
   int n = n_out_dev ? *n_out_dev : n_out_host;
   n = n < cap ? n : cap;
   const long long total = (long long)n * c;
@@ -808,6 +811,7 @@ __global__ void k_sparse_avgpool_scalar(const float *__restrict__ feat, const Dc
     const int ch = (int)(t - (long long)row * c);
     int rf = 0;
     for (int k = 0; k < kvol; ++k) rf += dcl_nbr_at(src, cap, k, row) >= 0;
+    if (rf_in) rf = rf_in[row];
     const float d = (float)rf;
     float acc = 0.f;
     for (int k = 0; k < kvol; ++k) {
@@ -952,8 +956,24 @@ DCL_API int dcl_sparse_avgpool_fwd(const float *feat, const int32_t *nbr, int ca
   return dcl_internal_sparse_avgpool_fwd(feat, src, cap, n_out_dev, n_out_host, c, kvol, out, rf, stream);
 }
 
+static int avgpool_launch(const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev, int n_out_host, int c,
+                          int kvol, float *out, int32_t *rf, const int32_t *rf_in, dclStream_t stream);
+
+DCL_API int dcl_sparse_avgpool_fwd_rf(const float *feat, const int32_t *nbr, int cap, const int32_t *n_out_dev,
+                                      int n_out_host, int c, int kvol, const int32_t *summaryrf, float *out,
+                                      dclStream_t stream) {
+  DCL_CHECK_ARG(nbr && summaryrf);
+  const DclNbrSrc src = {nbr, nullptr, nullptr, nullptr, nullptr, 0, 1, 0};
+  return avgpool_launch(feat, src, cap, n_out_dev, n_out_host, c, kvol, out, nullptr, summaryrf, stream);
+}
+
 int dcl_internal_sparse_avgpool_fwd(const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev,
                                     int n_out_host, int c, int kvol, float *out, int32_t *rf, dclStream_t stream) {
+  return avgpool_launch(feat, nbr, cap, n_out_dev, n_out_host, c, kvol, out, rf, nullptr, stream);
+}
+
+static int avgpool_launch(const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev, int n_out_host, int c,
+                          int kvol, float *out, int32_t *rf, const int32_t *rf_in, dclStream_t stream) {
   DCL_CHECK_ARG(feat && (nbr.nbr || (nbr.out_indices && nbr.in_mask && nbr.in_wprefix && kvol == 27)) && out && cap > 0 &&
                 c > 0 && kvol > 0 && kvol <= 27);
   DCL_CHECK_ARG(n_out_dev || (n_out_host >= 0 && n_out_host <= cap));
@@ -963,10 +983,10 @@ int dcl_internal_sparse_avgpool_fwd(const float *feat, const DclNbrSrc &nbr, int
   const int c4 = c / 4;
   if (c % 4 == 0 && c4 >= 4 && c4 <= 64 && 256 % c4 == 0)
     hipLaunchKernelGGL(k_sparse_avgpool, dim3(dcl_grid_1d((long long)rows * c4, 256, 2048)), dim3(256), 0, s, feat,
-                       nbr, cap, n_out_dev, n_out_host, c, kvol, out, rf);
+                       nbr, cap, n_out_dev, n_out_host, c, kvol, out, rf, rf_in);
   else
     hipLaunchKernelGGL(k_sparse_avgpool_scalar, dim3(dcl_grid_1d((long long)rows * c, 256)), dim3(256), 0, s, feat,
-                       nbr, cap, n_out_dev, n_out_host, c, kvol, out, rf);
+                       nbr, cap, n_out_dev, n_out_host, c, kvol, out, rf, rf_in);
   DCL_LAUNCH_CHECK();
   return 0;
 }

@@ -107,6 +107,7 @@ class Network(nn.Module):
         """folded weights and captured graphs (which have the folded tensors' addresses baked in) follow the parameters"""
         self._folded = None
         self.__dict__.pop("_graphs", None)
+        self.__dict__.pop("_vlist", None)
 
     def train(self, mode=True):
         self._invalidate()
@@ -123,7 +124,7 @@ class Network(nn.Module):
     def __getstate__(self):
         """copy.deepcopy / pickling: streams, graphs and folded tensors are per-instance runtime state"""
         state = dict(self.__dict__)
-        for k in ("_side", "_graphs", "_crop_id_cache"):
+        for k in ("_side", "_graphs", "_crop_id_cache", "_vlist"):
             state.pop(k, None)
         state["_folded"] = None
         return state
@@ -134,9 +135,16 @@ class Network(nn.Module):
         return s, bn.bias - bn.running_mean * s
 
     def _fold(self):
-        """BatchNorm(eval) folded into scale/shift or neighbouring weights; cached until weights change."""
+        """BatchNorm(eval) folded into scale/shift or neighbouring weights; cached until weights change -- also in place
+        (the cache and the captured graphs are keyed on the parameters' version counters: optimizer.step() under frozen
+        BatchNorm, an EMA swap through p.data.copy_ or manual surgery all drop them)."""
+        from .refiner import _param_version
+        ver = _param_version(self)
+        if self._folded is not None and self.__dict__.get("_fold_version") != ver:
+            self._invalidate()
         if self._folded is not None:
             return self._folded
+        self.__dict__["_fold_version"] = ver
         f = {}
         with torch.no_grad():
             for bb in ("backbone_inp", "backbone_tmp"):
@@ -502,6 +510,8 @@ class Network(nn.Module):
         return prediction
 
     def forward(self, data):
+        """eval(): the fused inference pipeline -- outputs carry no autograd graph, whether or not the caller wrapped the call
+        in torch.no_grad() (tools/test_LM.py:110 does not).  train() (or fused=False): the module path, differentiable."""
         if self.fused and not self.training:
             if 0 < int(data["batch_offsets"].size(0)) - 1 <= self.graph_max_batch:
                 return self.forward_graphed(data)

@@ -15,7 +15,21 @@ from .losses import losses_refiner  # noqa: F401  (reference: models/refiner.py:
 
 
 def ortho9d2matrix(x_raw, y_raw, z_raw):
-    return ops.ortho9d_to_matrix(torch.cat([x_raw, y_raw, z_raw], dim=1))
+    """models/refiner.py:34-56 == models/DCL_Net.py:15-36; differentiable when a gradient is needed (DCL_Net.ortho9d2matrix)"""
+    from .DCL_Net import ortho9d2matrix as _o
+    return _o(x_raw, y_raw, z_raw)
+
+
+def _param_version(mod):
+    """sum of the in-place version counters of every parameter and buffer: changes whenever a weight is rewritten in
+    place (optimizer.step(), EMA swaps via p.data.copy_, manual surgery), so caches keyed on it cannot go stale"""
+    ts = mod.__dict__.get("_vlist")
+    if ts is None:
+        ts = mod.__dict__["_vlist"] = list(mod.parameters()) + list(mod.buffers())
+    v = 0
+    for t in ts:
+        v += t._version
+    return v
 
 
 class Refiner(nn.Module):
@@ -32,6 +46,7 @@ class Refiner(nn.Module):
         """folded weights and captured refine-loop graphs (folded tensors' addresses baked in) follow the parameters"""
         self._folded = None
         self.__dict__.pop("_graphs", None)
+        self.__dict__.pop("_vlist", None)
 
     def train(self, mode=True):
         self._invalidate()
@@ -48,11 +63,16 @@ class Refiner(nn.Module):
     def __getstate__(self):
         state = dict(self.__dict__)
         state.pop("_graphs", None)
+        state.pop("_vlist", None)
         state["_folded"] = None
         return state
 
     def _fold(self):
+        ver = _param_version(self)
+        if self._folded is not None and self.__dict__.get("_fold_version") != ver:
+            self._invalidate()                       # weights were rewritten in place since the fold / the graph capture
         if self._folded is None:
+            self.__dict__["_fold_version"] = ver
             with torch.no_grad():
                 f = {}
                 for name in ("MLP_share", "regressor_rot2", "regressor_trans2"):
@@ -81,13 +101,26 @@ class Refiner(nn.Module):
         o9 = head(shared, f["regressor_rot2"])
         return head(shared, f["regressor_trans2"]), ops.ortho9d_to_matrix(o9)
 
+    def _forward_modules(self, x, conf):
+        """training path (tools/train_YCBV_stage2.py:169,243-262 calls refiner.train(); outputs = refiner(inp);
+        loss.backward()): the registered modules composed as the reference composes them (models/refiner.py:78-95), every
+        step differentiable, no cached weights."""
+        conf_softmax = torch.softmax(conf.unsqueeze(1), dim=2)[:, :, :1024]
+        shared = (self.MLP_share(x) * conf_softmax).sum(dim=2, keepdim=True)
+        o9 = self.regressor_rot2(shared).squeeze(-1)
+        delta_t = self.regressor_trans2(shared).squeeze(-1)
+        return {"trans_pred": delta_t, "rot_pred": ortho9d2matrix(o9[:, :3], o9[:, 3:6], o9[:, 6:])}
+
     def forward(self, input_dict):
         """reference contract: {"input_features" (b,259,n), "conf" (b,n+m), "obj_idx"} ->
-        {"trans_pred" (b,3), "rot_pred" (b,3,3)}."""
+        {"trans_pred" (b,3), "rot_pred" (b,3,3)}.  train() mode: differentiable module path; eval(): fused inference
+        path (folded weights, no autograd graph)."""
         x = input_dict["input_features"]
         conf = input_dict["conf"]
         if not x.is_cuda:
             raise RuntimeError("dcl-net_amd.Refiner runs on the GPU only (no CPU fallback)")
+        if self.training:
+            return self._forward_modules(x, conf)
         with torch.no_grad():
             f = self._fold()
             b, _, n = x.shape

@@ -166,6 +166,53 @@ def rulebook_to_pairs(nbr, n_out, n_in):
     return pairs[:, :, :n_in], num
 
 
+def rulebook_from_pairs(indice_pairs, indice_num, n_in, n_out, check=False):
+    """Reference-format rulebook (indice_pairs i32 (kvol,2,V) -1 padded, indice_num i32 (kvol)) -> gather table
+    nbr i32 (kvol, max(n_out,1)).  indice_num may live on the host (it does in the reference after spconv_ops.h:264) or
+    on the device; it is used from the device, without a read-back.  check=True reads back the count of pairs that
+    pointed outside the row ranges and raises if there were any."""
+    N.need_cuda(indice_pairs)
+    assert indice_pairs.dtype == torch.int32 and indice_pairs.dim() == 3 and indice_pairs.shape[1] == 2
+    pairs = indice_pairs.contiguous()
+    kvol, _, stride = pairs.shape
+    num = indice_num.to(device=pairs.device, dtype=torch.int32, non_blocking=True).contiguous()
+    assert num.numel() == kvol
+    cap = max(int(n_out), 1)
+    nbr = torch.empty((kvol, cap), dtype=torch.int32, device=pairs.device)
+    bad = torch.empty(1, dtype=torch.int32, device=pairs.device) if check else None
+    N.check(N.lib().dcl_rulebook_from_pairs(N.ptr(pairs), int(stride), N.ptr(num), kvol, int(n_in), int(n_out), N.ptr(nbr),
+                                            cap, N.ptr(bad), N.stream()), "rulebook_from_pairs")
+    if check and int(bad.item()):
+        raise ValueError("rulebook_from_pairs: %d pairs point outside the feature / output rows" % int(bad.item()))
+    return nbr
+
+
+def indice_summary_rf(indice_pairs, indice_num, n_out):
+    """torch.ops.spconv.indiceSummaryRF: receptive-field count i32 (n_out) from the pair format."""
+    N.need_cuda(indice_pairs)
+    pairs = indice_pairs.contiguous()
+    kvol, _, stride = pairs.shape
+    num = indice_num.to(device=pairs.device, dtype=torch.int32, non_blocking=True).contiguous()
+    rf = torch.empty(int(n_out), dtype=torch.int32, device=pairs.device)
+    N.check(N.lib().dcl_indice_summary_rf(N.ptr(pairs), int(stride), N.ptr(num), kvol, int(n_out), N.ptr(rf), N.stream()),
+            "indice_summary_rf")
+    return rf
+
+
+def sparse_avgpool_rf(feat, nbr, n_out, summaryrf):
+    """indice_avgpool_fp32 with the caller's divisor tensor (use_gs=True passes the kernel volume)."""
+    N.need_cuda(feat, nbr, summaryrf)
+    kvol, cap = nbr.shape
+    c = feat.shape[1]
+    out = torch.empty((n_out, c), dtype=torch.float32, device=feat.device)
+    if n_out:
+        rf = N.i32c(summaryrf)
+        assert rf.numel() >= n_out
+        N.check(N.lib().dcl_sparse_avgpool_fwd_rf(N.ptr(feat.contiguous()), N.ptr(nbr), cap, N.vp(0), int(n_out), c, kvol,
+                                                  N.ptr(rf), N.ptr(out), N.stream()), "sparse_avgpool_fwd_rf")
+    return out
+
+
 def sparse_conv(feat, nbr, n_out, W, subm, scale=None, shift=None, relu=False):
     """indice_conv_fp32 (+ folded BatchNorm1d(eval) + ReLU).  feat (V_in,Cin); W (kvol,Cin,Cout)."""
     N.need_cuda(feat, nbr, W)

@@ -51,8 +51,9 @@ class AddsTable(object):
             self.sums[cls, 3] += 1
 
     def reduce(self, device=None, group=None):
-        """all_reduce over the process group (no-op when torch.distributed is not initialised)."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        """all_reduce over the process group (no-op when torch.distributed is not initialised; a one-rank group still
+        goes through the collective, so a single-GPU smoke run exercises the RCCL path)."""
+        if not (dist.is_available() and dist.is_initialized()):
             return self
         s = torch.from_numpy(self.sums).to(device or "cpu")
         m = torch.from_numpy(self.maxd).to(device or "cpu")

@@ -19,7 +19,8 @@ import torch
 from torch import nn
 
 from .. import ops as _ops
-from . import ops  # noqa: F401  (spconv.ops.get_indice_pairs ...)
+from . import ops  # noqa: F401  (spconv.ops.get_indice_pairs, indice_conv, indice_avgpool, get_indice_summaryrf ...)
+from . import functional  # noqa: F401  (spconv.functional.indice_conv / indice_subm_conv / indice_avgpool)
 from .conv import SparseConv3d, SparseConvolution, SubMConv3d  # noqa: F401
 from .modules import SparseModule, SparseSequential, is_spconv_module  # noqa: F401
 from .pool import SparseAvgPool, SparseAvgPool3d  # noqa: F401

@@ -1,4 +1,9 @@
-"""spconv.ops subset (libs/spconv/spconv/ops.py:19-118,168-188)."""
+"""spconv.ops subset (libs/spconv/spconv/ops.py:19-118,168-188): the op-level boundary of the reference's python package --
+what its own conv.py:149-166 / pool.py:237-242 / functional.py:22-174 call, i.e. the Python face of
+torch.ops.spconv.{get_indice_pairs_3d, indice_conv_fp32, indice_conv_backward_fp32, indiceSummaryRF, indice_avgpool_fp32,
+indice_avgpool_backward_fp32} (src/spconv/all.cc:19-42).  Rulebooks cross this boundary in the REFERENCE format
+(indice_pairs (kvol,2,V), indice_pair_num (kvol)); each op converts them to the gather table the kernels walk
+(dcl_rulebook_from_pairs, one extra launch, no host read-back)."""
 import torch
 
 from .. import ops as _ops
@@ -46,3 +51,48 @@ def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padd
     n_out = indices.shape[0] if subm else out.n
     pairs, num = _ops.rulebook_to_pairs(nbr, n_out, indices.shape[0])
     return (indices if subm else out.indices), pairs, num
+
+
+def _w3(filters):
+    """(k,k,k,Cin,Cout) -> (kvol,Cin,Cout) view"""
+    return filters.reshape(-1, filters.shape[-2], filters.shape[-1]).contiguous()
+
+
+def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_out, inverse=False, subm=False):
+    """ops.py:102-118 -> torch.ops.spconv.indice_conv_fp32 (spconv_ops.h:253-349)."""
+    if inverse:
+        raise NotImplementedError("inverse sparse convolution is not on DCL-Net's path")
+    if filters.dtype != torch.float32:
+        raise NotImplementedError("fp32 only (the path computes in fp32)")
+    nbr = _ops.rulebook_from_pairs(indice_pairs, indice_pair_num, features.shape[0], num_activate_out)
+    return _ops.sparse_conv(features.contiguous(), nbr, int(num_activate_out), _w3(filters), bool(subm))
+
+
+def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_num, inverse=False, subm=False):
+    """ops.py:121-135 -> indice_conv_backward_fp32 (spconv_ops.h:351-438): (input_bp, filters_bp)."""
+    if inverse:
+        raise NotImplementedError("inverse sparse convolution is not on DCL-Net's path")
+    n_out = out_bp.shape[0]
+    nbr = _ops.rulebook_from_pairs(indice_pairs, indice_pair_num, features.shape[0], n_out)
+    dx, dW = _ops.sparse_conv_backward(features.contiguous(), _w3(filters), out_bp, nbr, n_out, bool(subm))
+    return dx, dW.view_as(filters)
+
+
+def get_indice_summaryrf(indice_pairs, indice_pair_num, num_activate_out):
+    """ops.py:168-169 -> torch.ops.spconv.indiceSummaryRF (summaryRF.cu:26-68)."""
+    return _ops.indice_summary_rf(indice_pairs, indice_pair_num, num_activate_out)
+
+
+def indice_avgpool(features, indice_pairs, indice_pair_num, num_activate_out, summaryrf):
+    """ops.py:171-179 -> indice_avgpool_fp32 (pool_ops.h:170-208; avgpool.cu:96-176)."""
+    if features.dtype != torch.float32:
+        raise NotImplementedError("fp32 only (the path computes in fp32)")
+    nbr = _ops.rulebook_from_pairs(indice_pairs, indice_pair_num, features.shape[0], num_activate_out)
+    return _ops.sparse_avgpool_rf(features, nbr, int(num_activate_out), summaryrf)
+
+
+def indice_avgpool_backward(features, out_features, out_bp, indice_pairs, indice_pair_num, summaryrf):
+    """ops.py:180-188 -> indice_avgpool_backward_fp32 (avgpool.cu:178-206)."""
+    n_out = out_bp.shape[0]
+    nbr = _ops.rulebook_from_pairs(indice_pairs, indice_pair_num, features.shape[0], n_out)
+    return _ops.sparse_avgpool_backward(out_bp, nbr, n_out, features.shape[0], summaryrf.int().contiguous())

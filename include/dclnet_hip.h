@@ -124,6 +124,20 @@ int dcl_rulebook_to_pairs(const int32_t *nbr, int cap, const int32_t *n_out_dev,
                           int kvol, int32_t *indice_pairs, int n_in_cap, int32_t *indice_num,
                           dclStream_t stream);
 
+/* Importer for callers that hold the REFERENCE's rulebook format (the arguments of torch.ops.spconv.indice_conv_fp32 /
+ * indice_avgpool_fp32 / indiceSummaryRF, libs/spconv/src/spconv/all.cc:19-42, as spconv/conv.py:149-166 and
+ * pool.py:237-242 pass them): indice_pairs i32 (kvol, 2, pair_stride) [k][0][j] = input row, [k][1][j] = output row, -1
+ * padded; indice_num i32 (kvol) ON THE DEVICE (no host read-back -- the reference copies it to the CPU,
+ * spconv_ops.h:264).  Fills the gather table nbr (kvol, cap) (cap >= n_out) that dcl_sparse_conv_fwd* /
+ * dcl_sparse_avgpool_fwd* consume; pairs that point outside [0,n_in) x [0,n_out) are dropped and counted in
+ * *bad_pairs_dev (may be NULL).                                                                                          */
+int dcl_rulebook_from_pairs(const int32_t *indice_pairs, int pair_stride, const int32_t *indice_num_dev, int kvol,
+                            int n_in, int n_out, int32_t *nbr, int cap, int32_t *bad_pairs_dev, dclStream_t stream);
+/* torch.ops.spconv.indiceSummaryRF (all.cc:33; summaryRF.cu:26-68) on the pair format: rf[o] = number of pairs whose
+ * output row is o, i32 (n_out).                                                                                          */
+int dcl_indice_summary_rf(const int32_t *indice_pairs, int pair_stride, const int32_t *indice_num_dev, int kvol,
+                          int n_out, int32_t *rf, dclStream_t stream);
+
 /* indice_conv_fp32 (+ the BatchNorm1d(eval)+ReLU that SparseSequential applies next,
  * models/Modules.py:36-40): out[o] = act( (sum_k feat[nbr[k][o]] * W[k]) * scale + shift ).
  * W (27,Cin,Cout); scale/shift (Cout) or NULL; subm != 0 accumulates the centre offset
@@ -150,6 +164,13 @@ int dcl_sparse_conv_scratch_floats(int rows_cap, int cout, int64_t *floats_host)
 int dcl_sparse_avgpool_fwd(const float *feat, const int32_t *nbr, int cap, const int32_t *n_out_dev,
                            int n_out_host, int c, int kvol, float *out, int32_t *rf,
                            dclStream_t stream);
+
+/* torch.ops.spconv.indice_avgpool_fp32 (all.cc:34; pool_ops.h:170-208) with the caller's `summaryrf` (i32 (n_out): the
+ * receptive-field counts of indiceSummaryRF when use_gs=False, the kernel volume when use_gs=True, functional.py:146-155)
+ * as the divisor: out[o] = sum_k asc feat[nbr[k][o]] / (float)summaryrf[o].                                              */
+int dcl_sparse_avgpool_fwd_rf(const float *feat, const int32_t *nbr, int cap, const int32_t *n_out_dev,
+                              int n_out_host, int c, int kvol, const int32_t *summaryrf, float *out,
+                              dclStream_t stream);
 
 /* ---------------------------------------------------- native backbone runner ---
  * One sparse backbone of DCL-Net (Backbone_SPCONV.forward, models/Modules.py:153-159: 4 x [SparseConv3d k3 s1 p1

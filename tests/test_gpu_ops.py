@@ -154,6 +154,92 @@ def test_sparse_avgpool_bit_exact(dcl, oracle, c):
     assert np.array_equal(got.cpu().numpy(), want)             # same divide-then-add order, k ascending
 
 
+# ------------------------------------------------------------------------------------------- spconv op-level boundary
+def _shuffled_pairs(rng, pairs, num):
+    """the reference fills each offset's pair list by atomicAdd (indice.cu.h:57): any order inside an offset is legal"""
+    out = pairs.copy()
+    for k in range(pairs.shape[0]):
+        perm = rng.permutation(int(num[k]))
+        out[k, :, :num[k]] = pairs[k][:, perm]
+    return out
+
+
+@pytest.mark.parametrize("cin,cout,subm", [(7, 16, False), (32, 64, True), (64, 64, False), (128, 128, True)])
+def test_op_level_indice_conv_takes_reference_pairs(dcl, oracle, cin, cout, subm):
+    """spconv.ops.indice_conv / spconv.functional.indice_conv / indice_subm_conv with the argument lists of the reference
+    (libs/spconv/spconv/ops.py:102-118, functional.py:22-43,69-91), fed with the ORACLE's rulebook in the reference's pair
+    format (pinned to geometry.h): equals oracle.indice_conv; indice_pair_num on the host (as after spconv_ops.h:264) or
+    on the device; backward through the Function == the gather-table backward"""
+    rng = np.random.default_rng(cin * 3 + cout)
+    b, S = 2, 8
+    idx = rand_voxels(rng, b, S, 150)
+    feat = rng.normal(size=(idx.shape[0], cin)).astype(np.float32)
+    W = (rng.normal(size=(3, 3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
+    r_out, r_pairs, r_num, _ = oracle.get_indice_pairs(idx, b, [S] * 3, 3, 1, 1, 1, subm=subm)
+    n_out = r_out.shape[0]
+    want = oracle.indice_conv(feat, W, r_pairs, r_num, n_out, subm=subm)
+    tol = 2e-5 * max(1.0, np.abs(want).max())
+    pairs = cuda(_shuffled_pairs(rng, r_pairs, r_num))
+    sp = dcl.spconv
+    for num in (torch.from_numpy(r_num), cuda(r_num)):
+        got = sp.ops.indice_conv(cuda(feat), cuda(W), pairs, num, n_out, False, subm).cpu().numpy()
+        assert got.shape == want.shape and np.abs(got - want).max() <= tol
+    fn = sp.functional.indice_subm_conv if subm else sp.functional.indice_conv
+    f, w = cuda(feat).requires_grad_(), cuda(W).requires_grad_()
+    out = fn(f, w, pairs, torch.from_numpy(r_num), n_out)
+    assert np.abs(out.detach().cpu().numpy() - want).max() <= tol
+    g = cuda(rng.normal(size=want.shape).astype(np.float32))
+    out.backward(g)
+    nbr = dcl.ops.rulebook_from_pairs(pairs, cuda(r_num), idx.shape[0], n_out, check=True)
+    dx, dW = dcl.ops.sparse_conv_backward(cuda(feat), cuda(W).reshape(27, cin, cout).contiguous(), g, nbr, n_out, subm)
+    assert torch.equal(f.grad, dx) and torch.equal(w.grad, dW.view_as(w))
+    # our own exporter and the importer are inverses
+    aset = dcl.ops.grid_from_indices(cuda(idx), b, S)
+    _, nbr0 = sp.ops.build_rulebook(aset, 3, 1, 1, subm)
+    p2, n2 = dcl.ops.rulebook_to_pairs(nbr0, n_out, idx.shape[0])
+    assert torch.equal(dcl.ops.rulebook_from_pairs(p2, n2, idx.shape[0], n_out)[:, :n_out], nbr0[:, :n_out])
+    with pytest.raises(ValueError):
+        bad = r_pairs.copy()
+        bad[3, 1, 0] = n_out + 5
+        dcl.ops.rulebook_from_pairs(cuda(bad), cuda(r_num), idx.shape[0], n_out, check=True)
+    with pytest.raises(NotImplementedError):
+        sp.ops.indice_conv(cuda(feat), cuda(W), pairs, cuda(r_num), n_out, True, False)
+
+
+@pytest.mark.parametrize("c", [32, 7])
+def test_op_level_avgpool_and_summaryrf_take_reference_pairs(dcl, oracle, c):
+    """spconv.ops.get_indice_summaryrf / indice_avgpool (ops.py:168-179) and spconv.functional.indice_avgpool
+    (functional.py:137-166, use_gs False and True) on the oracle's pair-format rulebook: rf and values bit-exact"""
+    rng = np.random.default_rng(40 + c)
+    b, S = 3, 16
+    idx = rand_voxels(rng, b, S, 400)
+    feat = rng.normal(size=(idx.shape[0], c)).astype(np.float32)
+    r_out, r_pairs, r_num, _ = oracle.get_indice_pairs(idx, b, [S] * 3, 3, 2, 1, 1)
+    n_out = r_out.shape[0]
+    want, want_rf = oracle.indice_avgpool(feat, r_pairs, r_num, n_out)
+    pairs, num = cuda(_shuffled_pairs(rng, r_pairs, r_num)), cuda(r_num)
+    sp = dcl.spconv
+    rf = sp.ops.get_indice_summaryrf(pairs, num, n_out)
+    assert rf.dtype == torch.int32 and np.array_equal(rf.cpu().numpy(), want_rf)
+    got = sp.ops.indice_avgpool(cuda(feat), pairs, num, n_out, rf)
+    assert np.array_equal(got.cpu().numpy(), want)
+    f = cuda(feat).requires_grad_()
+    out = sp.functional.indice_avgpool(f, pairs, num, n_out, False)
+    assert np.array_equal(out.detach().cpu().numpy(), want)
+    g = cuda(rng.normal(size=want.shape).astype(np.float32))
+    out.backward(g)
+    nbr = dcl.ops.rulebook_from_pairs(pairs, num, idx.shape[0], n_out)
+    assert torch.equal(f.grad, dcl.ops.sparse_avgpool_backward(g, nbr, n_out, idx.shape[0], rf))
+    # use_gs=True: every term divided by the kernel volume (functional.py:150-152)
+    gs = sp.functional.indice_avgpool(cuda(feat), pairs, num, n_out, True).cpu().numpy()
+    ref = np.zeros_like(want)
+    for k in range(27):
+        for j in range(int(r_num[k])):
+            i, o = r_pairs[k, 0, j], r_pairs[k, 1, j]
+            ref[o] = ref[o] + feat[i] / np.float32(27)
+    assert np.array_equal(gs, ref)
+
+
 # ------------------------------------------------------------------------------------------- pointnet_sp
 def _sp_case(rng, b, n, m, dup=True):
     unk = np.concatenate([np.repeat(np.arange(b), n)[:, None], rng.uniform(-0.2, 0.2, (b * n, 3))], 1).astype(np.float32)

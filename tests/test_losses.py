@@ -83,3 +83,74 @@ def test_chamfer_term_at_the_shipped_batch_shape(dcl):
     got = dcl.DCL_Net.losses.CD_Dis(a, c)
     want = _cd_literal(a[:2].cpu(), c[:2].cpu())
     assert got.shape == (32, 1024) and float((got[:2].cpu() - want).abs().max()) <= 1e-6
+
+
+def _refiner_case(dcl, b=3, n=1024, seed=4):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.cat([torch.randn(b, 3, n, generator=g) * 0.05, torch.randn(b, 256, n, generator=g)], 1)
+    conf = torch.rand(b, 2 * n, generator=g)
+    R = _rand_rot(g, b)
+    gt = {"rot_gt": _rand_rot(g, b), "trans_gt": torch.randn(b, 3, generator=g) * 0.01}
+    tmp = torch.randn(b, 500, 3, generator=g) * 0.05
+    return x, conf, R, torch.randn(b, 3, generator=g) * 0.01, tmp, torch.tensor([0.0, 1.0, 0.0][:b]), gt
+
+
+def test_refiner_training_path_is_the_reference_graph_and_differentiable(dcl):
+    """Refiner.train(): forward composes the registered modules like models/refiner.py:78-95 (== the oracle restatement that
+    is pinned to the reference's outputs) and losses_refiner(...).backward() reaches all 18 parameters -- the call
+    sequence of tools/train_YCBV_stage2.py:243-262.  (Pure torch modules: this half runs on the CPU.)"""
+    from oracle import graph as G
+    ref = dcl.refiner.Refiner()
+    sd = dcl.synth.synth_state_dict(ref, 2)
+    ref.load_state_dict(sd)
+    ref.train()
+    x, conf, R, t, tmp, sym, gt = _refiner_case(dcl)
+    out = ref._forward_modules(x, conf)
+    want = G.refiner_forward(sd, x, conf)
+    assert float((out["trans_pred"] - want["trans_pred"]).abs().max()) <= 1e-6
+    assert float((out["rot_pred"] - want["rot_pred"]).abs().max()) <= 1e-5
+    loss = dcl.refiner.losses_refiner(None)(out, t, R, tmp, sym, gt)["loss_all"]
+    loss.backward()
+    grads = {k: p.grad for k, p in ref.named_parameters()}
+    assert len(grads) == 18 and all(g is not None and bool(torch.isfinite(g).all()) for g in grads.values())
+    assert all(float(g.abs().max()) > 0 for g in grads.values())
+
+
+@pytest.mark.gpu
+def test_refiner_trains_on_the_gpu(dcl):
+    """train() mode on the GPU: same outputs as the fused eval path, gradients equal to an fp64 CPU evaluation of the same
+    graph, an optimiser step changes the weights and the eval path (folded weights, captured graphs) follows them"""
+    import copy
+    ref = dcl.refiner.Refiner()
+    ref.load_state_dict(dcl.synth.synth_state_dict(ref, 2))
+    ref = ref.cuda()
+    x, conf, R, t, tmp, sym, gt = _refiner_case(dcl)
+    cu = lambda v: v.cuda()                                                     # noqa: E731
+    inp = {"input_features": cu(x), "conf": cu(conf), "obj_idx": None}
+    ev = ref.eval()(inp)
+    assert not ev["rot_pred"].requires_grad
+    out = ref.train()(inp)
+    assert out["rot_pred"].requires_grad and out["trans_pred"].requires_grad
+    assert float((out["rot_pred"] - ev["rot_pred"]).abs().max()) <= 1e-4
+    assert float((out["trans_pred"] - ev["trans_pred"]).abs().max()) <= 1e-5
+    crit = dcl.refiner.losses_refiner(None)
+    gtc = {k: cu(v) for k, v in gt.items()}
+    loss = crit(out, cu(t), cu(R), cu(tmp), cu(sym), gtc)["loss_all"]
+    loss.backward()
+    twin = copy.deepcopy(ref).cpu().double().train()
+    for p in twin.parameters():
+        p.grad = None
+    o64 = twin._forward_modules(x.double(), conf.double())
+    l64 = crit(o64, t.double(), R.double(), tmp.double(), sym.double(), {k: v.double() for k, v in gt.items()})["loss_all"]
+    l64.backward()
+    assert abs(float(loss) - float(l64)) <= 1e-5 * max(1.0, abs(float(l64)))
+    for (k, p), (_, q) in zip(ref.named_parameters(), twin.named_parameters()):
+        scale = max(float(q.grad.abs().max()), 1e-8)
+        assert float((p.grad.cpu().double() - q.grad).abs().max()) <= 2e-3 * scale, k
+    before = ref.eval()(inp)["trans_pred"].clone()
+    opt = torch.optim.SGD(ref.parameters(), lr=1e-2)
+    opt.step()                                                                 # in-place update, no load_state_dict
+    after = ref.eval()(inp)["trans_pred"]
+    assert float((after - before).abs().max()) > 1e-7                          # the fold cache followed the weights
+    want = ref.train()(inp)["trans_pred"].detach()
+    assert float((after - want).abs().max()) <= 1e-5
