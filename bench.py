@@ -30,25 +30,47 @@ PEAK_HBM = 8000.0              # GB/s spec
 SHAPES = {"stress": (12288, 2048), "ref": (1024, 1024)}
 
 
-def pmc_traffic_bytes(kernel_substr):
-    """HBM bytes per launch of a kernel from the committed PMC passes (profiles/r*_pmc_summary.csv, separate
-    rocprofv3 --pmc runs of this same bench at the stress shape): FETCH_SIZE is doubled (gfx950 reports half of a wide
-    coalesced read, MI355X_MICROARCH.md HBM section), both counters are KiB.  None if no summary is committed."""
+def measure_traffic_bytes(kernel_substr, shape, batch, timeout_s=300):
+    """HBM bytes per launch of a kernel, MEASURED IN THIS RUN: two child processes of this same script (one forward pass of
+    the same workload each, `--pmc-child`) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes with
+    --kernel-trace only, as MI355X_MICROARCH.md's rocprofv3 section prescribes (the two counters do not fit one pass) --
+    while this process idles.  Corrections from the guide's HBM section: both counters are KiB; on gfx950 FETCH_SIZE
+    reports half of the bytes of a wide coalesced read, so it is doubled.  -> (bytes or None, source string)."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.csv")))
-    if not files:
-        return None
-    fetch = write = None
-    for r in csv.DictReader(open(files[-1])):
-        if kernel_substr in r["kernel"]:
-            if r["counter"] == "FETCH_SIZE":
-                fetch = float(r["avg_value"])
-            elif r["counter"] == "WRITE_SIZE":
-                write = float(r["avg_value"])
-    if fetch is None or write is None:
-        return None
-    return int((2.0 * fetch + write) * 1024)
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "unmeasured: rocprofv3 not on PATH"
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="dcl_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", tmp, "-o", "pmc", "--output-format", "csv", "--",
+               sys.executable, os.path.abspath(__file__), "--pmc-child", "--shape", shape, "--batch", str(batch)]
+        env = dict(os.environ, TMPDIR="/tmp")
+        for k in ("DCL_FORCE_DIST", "RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                           timeout=timeout_s, check=True)
+            per_launch = []
+            for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                        per_launch.append(float(r["Counter_Value"]))
+            if per_launch:
+                vals[counter] = sum(per_launch) / len(per_launch)
+        except (subprocess.SubprocessError, OSError) as e:
+            shutil.rmtree(tmp, ignore_errors=True)
+            return None, "unmeasured: %s pass failed (%s)" % (counter, type(e).__name__)
+        shutil.rmtree(tmp, ignore_errors=True)
+    if len(vals) != 2:
+        return None, "unmeasured: kernel not found in the counter files"
+    return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), (
+        "measured in this run: child rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over one forward of the same "
+        "workload, average per launch of the kernel; FETCH_SIZE x2 (gfx950), KiB -> B")
 
 
 def to_device(data, dev):
@@ -223,18 +245,105 @@ def refiner_bench(dcl, dev, b, iters=2, reps=20):
     return out
 
 
-def cpu_baseline(dcl, sd, cfg, n_inp, n_tmp, crops=1):
+def stage2_chain_bench(dcl, dev, net, data, b, iters=2, reps=20):
+    """BASELINE configs[4] as ONE workload: stage-1 forward chained into the 2-iteration refiner loop with pose composition
+    (tools/test_YCBV_stage2.py:204-225; refiner.stage2_chain), frames/s including both refine iterations; the refine loop
+    eager and as its hipGraph."""
+    ref = dcl.refiner.Refiner()
+    ref.load_state_dict(dcl.synth.synth_state_dict(ref, 2))
+    ref = ref.to(dev).eval()
+    out = {"workload": "DCL_Net.forward (bs=%d, N=M=1024) -> %d x Refiner with pose composition" % (b, iters)}
+    for name, graph in (("eager_loop", False), ("hipgraph_loop", True)):
+        for _ in range(3):
+            dcl.refiner.stage2_chain(net, ref, data, iters, graph=graph)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            dcl.refiner.stage2_chain(net, ref, data, iters, graph=graph)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        out[name] = {"ms_per_step": round(ms, 3), "frames_per_s": round(b / ms * 1e3, 1)}
+    return out
+
+
+def cpu_baseline(dcl, sd, cfg, n_inp, n_tmp, crops=2):
     """the CPU oracle (kind 'port': the reference has no runnable CPU path) on a bounded sample of
-    the same workload, host cores of this box."""
+    the same workload, on the host cores of this box: the C kernels' row loops run under OpenMP, the dense algebra is
+    torch-CPU fp32, both on every core."""
     from oracle import graph as G
-    torch.set_num_threads(os.cpu_count() or 1)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     data = dcl.synth.make_batch(crops, n_inp, n_tmp)
     t0 = time.perf_counter()
     G.forward(sd, dict(cfg), data, mode="test")
     dt = time.perf_counter() - t0
-    return {"value": round(crops / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d crops of the same workload (N=%d, M=%d), oracle/graph.py: C kernels single-threaded, dense "
-                      "ops torch-CPU fp32 on %d threads; %.1f s" % (crops, n_inp, n_tmp, torch.get_num_threads(), dt)}
+    return {"value": round(crops / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d crops of the same workload (N=%d, M=%d) through oracle/graph.py: C kernels with OpenMP row loops, "
+                      "dense ops torch-CPU fp32, %d threads; %.1f s" % (crops, n_inp, n_tmp, cores, dt)}
+
+
+def conv_pairs_flop(dcl, net, data, dev):
+    """algorithmic sparse-conv work of one forward over `data` = 2 * sum_layers pairs * Cin * Cout with the MEASURED pair
+    counts of this batch: the module mirrors (spconv shim) build every layer's gather table once, its
+    non-negative entries are the rulebook pairs.  Both backbones.  -> (flop, pairs per layer list)"""
+    import numpy as np_
+    vlim = np_.asarray(data["voxel_num_limit"]).astype(np_.int64)
+    b = int(data["batch_offsets"].size(0)) - 1
+    flop, per_layer = 0.0, []
+    with torch.no_grad():
+        for side, bb in (("inp", net.backbone_inp), ("tmp", net.backbone_tmp)):
+            feats = data[side]["feats"].to(dev).float().contiguous()
+            v2p = data[side]["v2p_maps"].to(dev).int().contiguous()
+            occ = data[side]["occupied_voxels"].to(dev).int().contiguous()
+            x = dcl.spconv.SparseConvTensor(dcl.ops.voxelize_fp(feats, v2p, 4), occ, vlim, b)
+            for m in range(1, 5):
+                for blk in getattr(bb, "module%d" % m):
+                    conv = blk.layers[0]
+                    aset = x.active_set()
+                    out_set, nbr = dcl.spconv.ops.build_rulebook(aset, 3, 1, 1, conv.subm)
+                    n_out = x.indices.shape[0] if conv.subm else out_set.n
+                    pairs = int((nbr[:, :n_out] >= 0).sum().item())
+                    per_layer.append((side, conv.in_channels, conv.out_channels, bool(conv.subm), n_out, pairs))
+                    flop += 2.0 * pairs * conv.in_channels * conv.out_channels
+                    x = blk(x)
+                x = bb.pool(x)
+    return flop, per_layer
+
+
+def sparse_conv_roofline(dcl, net, data, dev, steps=3):
+    """roofline entry of the sparse-conv kernel family for one workload: algorithmic flop (measured pairs, above) divided by
+    the summed device time of all 16 conv calls of a forward, measured with HIP events on the launch streams inside the
+    library (dcl_profile_conv_begin/_end) during `steps` ordinary forwards run on ONE stream (DCL_SINGLE_STREAM=1, so that
+    the two backbones' kernels do not overlap each other inside the bracketed intervals)."""
+    import ctypes
+    flop, per_layer = conv_pairs_flop(dcl, net, data, dev)
+    lib = dcl._native.lib()
+    old = os.environ.get("DCL_SINGLE_STREAM")
+    os.environ["DCL_SINGLE_STREAM"] = "1"
+    try:
+        with torch.no_grad():
+            net(data)
+            torch.cuda.synchronize()
+            lib.dcl_profile_conv_begin()
+            for _ in range(steps):
+                net(data)
+            torch.cuda.synchronize()
+            ms, calls = ctypes.c_double(0), ctypes.c_int32(0)
+            lib.dcl_profile_conv_end(ctypes.byref(ms), ctypes.byref(calls))
+    finally:
+        if old is None:
+            os.environ.pop("DCL_SINGLE_STREAM", None)
+        else:
+            os.environ["DCL_SINGLE_STREAM"] = old
+    ms_fwd = ms.value / steps
+    ach = flop / (ms_fwd * 1e-3) / 1e12 if ms_fwd > 0 else float("nan")
+    issued = sum(2.0 * 27 * n_out * ci * co for (_, ci, co, _, n_out, _) in per_layer)
+    return {"kernel": "k_sparse_conv_* (16 layers, both backbones)", "bound": "mfma", "achieved": round(ach, 2),
+            "peak": PEAK_MFMA_F32, "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F32, 4),
+            "flop_per_forward": flop, "conv_ms_per_forward": round(ms_fwd, 4), "conv_calls_timed": int(calls.value),
+            "rulebook_density": round(flop / issued, 4) if issued else None,
+            "pairs_per_forward": int(sum(p[5] for p in per_layer))}
 
 
 def main():
@@ -247,6 +356,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip ref-shape / primitives / cpu baseline legs")
     ap.add_argument("--pipelined-calls", action="store_true",
                     help="let back-to-back forward calls overlap on the GPU (Network(async_inputs=True))")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the in-run PMC passes behind roofline.traffic")
+    ap.add_argument("--pmc-child", action="store_true",
+                    help="(internal) one warm-up + one forward of the workload and exit: the body of the PMC passes")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -275,6 +387,12 @@ def main():
     net = net.to(dev).eval()
     host_data = dcl.synth.make_batch(b, n_inp, n_tmp, first=rank * b)          # disjoint crops per rank
     data = to_device(host_data, dev)
+    if args.pmc_child:
+        with torch.no_grad():
+            net(data)
+            net(data)
+        torch.cuda.synchronize()
+        return
 
     dt, att_ms = run_forward_bench(dcl, net, data, args.steps, args.warmup, distributed)
     frames = world * b * args.steps
@@ -284,9 +402,13 @@ def main():
     flop_dir = [2.0 * (64 + 320) * n_inp * n_tmp * b] * 2     # dir 1: nq=N,nk=M ; dir 2: nq=M,nk=N -- same product
     att_avg_ms = float(np.mean(att_ms)) if att_ms else float("nan")
     achieved = flop_dir[0] / (att_avg_ms * 1e-3) / 1e12 if att_ms else float("nan")
+    traffic, traffic_source = None, "not collected (N > 1, --no-extras or --no-traffic)"
+    if rank == 0 and world == 1 and not args.no_extras and not args.no_traffic:
+        traffic, traffic_source = measure_traffic_bytes("k_cross_attn", args.shape, b)
     roofline = {"kernel": "k_cross_attn", "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_MFMA_F32,
                 "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_F32, 4),
-                "traffic": pmc_traffic_bytes("k_cross_attn") if args.shape == "stress" else None,
+                "traffic": traffic, "traffic_source": traffic_source,
+                "traffic_algorithmic": int(4 * b * (64 * (n_inp + n_tmp) + 320 * (n_inp + n_tmp))),
                 "avg_launch_ms": round(att_avg_ms, 4), "launches_timed": len(att_ms),
                 "flop_per_launch": flop_dir[0]}
 
@@ -315,6 +437,7 @@ def main():
             "adds_auc_synthetic_weights": auc, "metric_frames_reduced": int(table.sums[:, 0].sum())}
     rdata_for_pipe = None
     if rank == 0 and world == 1 and not args.no_extras:
+        line["roofline_sparse_conv"] = {args.shape: sparse_conv_roofline(dcl, net, data, dev)}
         if args.shape != "ref":
             rn, rm = SHAPES["ref"]
             rcfg = dcl.synth.default_cfg(rn, rm)
@@ -329,8 +452,15 @@ def main():
                                  "value": round(b * rsteps / rdt, 2), "unit": "frames/s",
                                  "ms_per_step": round(rdt / rsteps * 1e3, 3),
                                  "attention_TFLOPs": round(rflop / (np.mean(ratt) * 1e-3) / 1e12, 2) if ratt else None}
+            line["roofline_sparse_conv"]["ref"] = sparse_conv_roofline(dcl, rnet, rdata, dev)
+            # BASELINE configs[2]'s per-GPU shape: 40 crops per call (config_YCBV_bs40.yaml)
+            d40 = to_device(dcl.synth.make_batch(40, rn, rm), dev)
+            dt40, _ = run_forward_bench(dcl, rnet, d40, 20, 3, False)
+            line["bs40"] = {"workload": "N=M=1024, bs=40 (config_YCBV_bs40.yaml batch)", "unit": "frames/s",
+                            "value": round(40 * 20 / dt40, 2), "ms_per_step": round(dt40 / 20 * 1e3, 3)}
+            line["stage2_chain"] = stage2_chain_bench(dcl, dev, rnet, rdata, b)
             rdata_for_pipe = (rcfg, rdata)
-            del rnet
+            del rnet, d40
         # the same forward fed from the loader's HOST tensors (pageable memory, H2D inside forward) -- never `value`
         hdt, _ = run_forward_bench(dcl, net, host_data, max(3, args.steps // 2), 1, False)
         hsteps = max(3, args.steps // 2)

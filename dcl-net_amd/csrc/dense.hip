@@ -14,6 +14,7 @@
 // and one final division by the softmax denominator.  Bound: fp32 MFMA (157 TFLOP/s spec);
 // algorithmic flop = 2*(dk+dv)*Nq*Nk per crop per direction.
 #include "common.h"
+#include <atomic>
 #include <math.h>
 
 namespace {
@@ -714,9 +715,9 @@ __global__ void k_ortho9d(int b, const float *__restrict__ o9, float *__restrict
 
 }  // namespace
 
-static int g_attn_variant = 0;   // test hook: 1 = shared-tile 8-wave kernel, 2 = 4-wave register-staged, 3 / 4 = LDS-DMA pipeline with 8 / 4 waves
-static int g_attn_split = 0;            // tuning hook: 0 = automatic key split of small attention launches, n = force n
-static int g_attn_xcd_remap = 1;        // tuning hook: 0 = plain blockIdx order (for traffic comparisons)
+static std::atomic<int> g_attn_variant{0};   // test hook: 1 = shared-tile 8-wave kernel, 2 = 4-wave register-staged, 3 / 4 = LDS-DMA pipeline with 8 / 4 waves
+static std::atomic<int> g_attn_split{0};            // tuning hook: 0 = automatic key split of small attention launches, n = force n
+static std::atomic<int> g_attn_xcd_remap{1};        // tuning hook: 0 = plain blockIdx order (for traffic comparisons)
 DCL_API void dcl_debug_attention_split(int n) { g_attn_split = n; }
 DCL_API void dcl_debug_attention_xcd_remap(int on) { g_attn_xcd_remap = on; }
 DCL_API void dcl_debug_attention_variant(int v) { g_attn_variant = v; }
@@ -801,7 +802,7 @@ DCL_API int dcl_cross_attention_ws(int b, int nq, int nk, const float *Q, int ld
       const long long blocks4 = (long long)b * dcl_div_up(nq, 128);
       int nsplit = 1;
       if (scratch && blocks4 < 192) {
-        nsplit = g_attn_split > 0 ? g_attn_split : (int)dcl_div_up(256, blocks4);
+        nsplit = g_attn_split > 0 ? g_attn_split.load() : (int)dcl_div_up(256, blocks4);
         const int ntiles = dcl_div_up(nk, 32);
         if (nsplit > 8) nsplit = 8;
         if (nsplit > ntiles / 2) nsplit = ntiles / 2;

@@ -11,6 +11,7 @@
 // three_interpolate: lanes run over channels of one point (coalesced row gathers + coalesced
 // stores; the reference maps threads to points and is fully uncoalesced).
 #include "common.h"
+#include <atomic>
 #include <math.h>
 
 namespace {
@@ -373,7 +374,7 @@ int dcl_three_nn_sp_strided(int n, int m, const float *unknown, const float *kno
 }
 
 // internal: the known set is given as voxel rows (b,x,y,z) i32; their centres idx*ve + off + ve/2 are formed in the kernel
-static int g_nn_grid = 1;   // tuning/test hook: 0 = brute-force scan per crop for every level, 2 = grid kernel with the scan forced
+static std::atomic<int> g_nn_grid{1};   // tuning/test hook: 0 = brute-force scan per crop for every level, 2 = grid kernel with the scan forced
 DCL_API void dcl_debug_three_nn_grid(int mode) { g_nn_grid = mode; }
 
 // known_mask / S (optional): the level's occupancy bits and grid size; with them, levels of S = 16 or 32 go through the

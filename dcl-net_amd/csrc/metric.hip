@@ -1,4 +1,7 @@
-// metric.hip -- fused ADD-S distance (the step right after the forward in the eval harness).
+// metric.hip -- fused ADD-S / ADD distances (the step right after the forward in the eval harness).
+//
+// LineMOD variant (tools/test_LM.py:123-135): non-symmetric objects use ADD = mean_i |pred_i - gt_i| (corresponding
+// points), symmetric ones ADD-S; `sym` selects per object inside the same launch (workgroup-uniform branch).
 //
 // tools/test_YCBV_stage1.py:186-189 poses the class cloud (2620 points) by the predicted and by the ground-truth pose and
 // takes mean_i min_j |pred_i - gt_j| through a materialised (b, P, P, 3) difference tensor: 82 MB per object.
@@ -22,7 +25,8 @@ __device__ __forceinline__ void pose_point(const float *R, const float *t, float
 __global__ __launch_bounds__(256) void k_adds_partial(int P, const float *__restrict__ cld, const int32_t *__restrict__ cls,
                                                       const float *__restrict__ Rp, const float *__restrict__ tp,
                                                       const float *__restrict__ Rg, const float *__restrict__ tg,
-                                                      float *__restrict__ partial, int nslices) {
+                                                      float *__restrict__ partial, int nslices,
+                                                      const int32_t *__restrict__ sym, int all_mode) {
   extern __shared__ float gt[];                 // [P][3] posed by the ground truth
   __shared__ float red[4];
   const int obj = blockIdx.y, slice = blockIdx.x, tid = threadIdx.x;
@@ -39,10 +43,16 @@ __global__ __launch_bounds__(256) void k_adds_partial(int P, const float *__rest
   if (i < P) {
     float px, py, pz;
     pose_point(R1, t1, C[i * 3], C[i * 3 + 1], C[i * 3 + 2], px, py, pz);
+    const bool nearest = sym ? sym[obj] != 0 : all_mode != 0;     // ADD-S: nearest gt point; ADD: the corresponding one
     float m = INFINITY;
-    for (int j = 0; j < P; ++j) {
-      const float dx = px - gt[j * 3], dy = py - gt[j * 3 + 1], dz = pz - gt[j * 3 + 2];
-      m = fminf(m, __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, dx * dx)));
+    if (nearest) {
+      for (int j = 0; j < P; ++j) {
+        const float dx = px - gt[j * 3], dy = py - gt[j * 3 + 1], dz = pz - gt[j * 3 + 2];
+        m = fminf(m, __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, dx * dx)));
+      }
+    } else {
+      const float dx = px - gt[i * 3], dy = py - gt[i * 3 + 1], dz = pz - gt[i * 3 + 2];
+      m = __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, dx * dx));
     }
     best = sqrtf(m);
   }
@@ -63,8 +73,30 @@ __global__ void k_adds_finish(int b, int P, int nslices, const float *__restrict
 
 }  // namespace
 
+static int add_launch(int b, int P, const float *cld, const int32_t *cls, const float *R_pred, const float *t_pred,
+                      const float *R_gt, const float *t_gt, float *partial_scratch, float *out, const int32_t *sym,
+                      int all_mode, dclStream_t stream);
+
 DCL_API int dcl_add_s(int b, int P, const float *cld, const int32_t *cls, const float *R_pred, const float *t_pred,
                       const float *R_gt, const float *t_gt, float *partial_scratch, float *out, dclStream_t stream) {
+  return add_launch(b, P, cld, cls, R_pred, t_pred, R_gt, t_gt, partial_scratch, out, nullptr, 1, stream);
+}
+
+DCL_API int dcl_add(int b, int P, const float *cld, const int32_t *cls, const float *R_pred, const float *t_pred,
+                    const float *R_gt, const float *t_gt, float *partial_scratch, float *out, dclStream_t stream) {
+  return add_launch(b, P, cld, cls, R_pred, t_pred, R_gt, t_gt, partial_scratch, out, nullptr, 0, stream);
+}
+
+DCL_API int dcl_add_by_symmetry(int b, int P, const float *cld, const int32_t *cls, const int32_t *sym_flag,
+                                const float *R_pred, const float *t_pred, const float *R_gt, const float *t_gt,
+                                float *partial_scratch, float *out, dclStream_t stream) {
+  DCL_CHECK_ARG(sym_flag || b == 0);
+  return add_launch(b, P, cld, cls, R_pred, t_pred, R_gt, t_gt, partial_scratch, out, sym_flag, 0, stream);
+}
+
+static int add_launch(int b, int P, const float *cld, const int32_t *cls, const float *R_pred, const float *t_pred,
+                      const float *R_gt, const float *t_gt, float *partial_scratch, float *out, const int32_t *sym,
+                      int all_mode, dclStream_t stream) {
   DCL_CHECK_ARG(b >= 0 && P > 0 && (size_t)P * 12 <= 150 * 1024);
   if (b == 0) return 0;
   DCL_CHECK_ARG(cld && R_pred && t_pred && R_gt && t_gt && partial_scratch && out && b <= 65535);
@@ -74,7 +106,7 @@ DCL_API int dcl_add_s(int b, int P, const float *cld, const int32_t *cls, const 
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute((const void *)k_adds_partial, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k_adds_partial, dim3(nslices, b), dim3(256), lds, s, P, cld, cls, R_pred, t_pred, R_gt, t_gt,
-                     partial_scratch, nslices);
+                     partial_scratch, nslices, sym, all_mode);
   hipLaunchKernelGGL(k_adds_finish, dim3(dcl_div_up(b, 64)), dim3(64), 0, s, b, P, nslices, partial_scratch, out);
   DCL_LAUNCH_CHECK();
   return 0;

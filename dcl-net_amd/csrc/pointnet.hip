@@ -13,6 +13,7 @@
 // REGISTERS for the whole run (the reference re-reads dataset[] and temp[] from global memory every iteration), wave
 // argmax by DPP/shuffle, one LDS exchange + two barriers per iteration.
 #include "common.h"
+#include <atomic>
 #include <math.h>
 
 namespace {
@@ -388,7 +389,7 @@ DCL_API int dcl_ball_query(int b, int n, int m, float radius, int nsample, const
   return 0;
 }
 
-static int g_gp_cfg[4] = {0, 0, 0, 0};   // tuning hook: rows per workgroup, x-blocks, threads, stores (2 = plain); 0 = default
+static std::atomic<int> g_gp_cfg[4] = {{0}, {0}, {0}, {0}};   // tuning hook: rows per workgroup, x-blocks, threads, stores (2 = plain); 0 = default
 DCL_API void dcl_debug_group_points_cfg(int cc, int xb, int threads, int nontemporal) {
   g_gp_cfg[0] = cc; g_gp_cfg[1] = xb; g_gp_cfg[2] = threads; g_gp_cfg[3] = nontemporal;
 }
@@ -412,7 +413,7 @@ DCL_API int dcl_group_points_into(int b, int c, int n, int npoints, int nsample,
     int ccu = cc >= 4 ? 4 : cc >= 3 ? 3 : cc >= 2 ? 2 : 1;
     if (g_gp_cfg[0] > 0 && g_gp_cfg[0] <= 4 && (size_t)g_gp_cfg[0] * n * 4 <= 144 * 1024) ccu = g_gp_cfg[0];
     const size_t lds = (size_t)ccu * n * 4;
-    const int threads = g_gp_cfg[2] > 0 ? g_gp_cfg[2] : 1024;
+    const int threads = g_gp_cfg[2] > 0 ? g_gp_cfg[2].load() : 1024;
     const int ychunks = dcl_div_up(c, ccu);
     // enough x-blocks to give every CU work, few enough that the row fill stays a small fraction
     int xb = dcl_div_up(256 * 2, ychunks * b);

@@ -13,6 +13,10 @@
 // The BatchNorm1d(eval)+ReLU that follows every conv in the backbone (models/Modules.py:36-40) is
 // the epilogue.  Bound: MFMA fp32 (2*pairs*Cin*Cout flop); features and weights are L2-resident.
 #include "common.h"
+#include <atomic>
+#include <mutex>
+#include <utility>
+#include <vector>
 
 int dcl_internal_sparse_conv_fwd(const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev,
                                  int n_out_host, const float *W, int cin, int cout, int kvol, int subm, const float *scale,
@@ -697,8 +701,8 @@ static int conv_split_cap(long long rows) { return rows <= kConvFewRows ? 27 : k
 // hipGraph, a handful of crops), a row capacity of at most two crops' worth of cells, whatever the live count turns out to be
 constexpr int kConvFewRowsCap = 65536;
 static bool conv_few_rows(int rows, bool capacity_mode) { return capacity_mode ? rows <= kConvFewRowsCap : rows <= kConvFewRows; }
-static int g_conv_xcd_remap = 1;       // tuning hook: 0 = plain blockIdx order
-static int g_conv_split = 0;           // tuning hook: 0 = automatic, n = force n-way split-K when scratch allows, -1 = never more than kConvMaxSplit
+static std::atomic<int> g_conv_xcd_remap{1};       // tuning hook: 0 = plain blockIdx order
+static std::atomic<int> g_conv_split{0};           // tuning hook: 0 = automatic, n = force n-way split-K when scratch allows, -1 = never more than kConvMaxSplit
 
 template <int CIN, int WR, int WCW, int NT>
 static void launch_conv_dma(int rows, const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev,
@@ -717,7 +721,7 @@ static void launch_conv_dma(int rows, const float *feat, const DclNbrSrc &nbr, i
   int nsplit = 1;
   if (scratch) {
     const bool few_rows = conv_few_rows(rows, n_out_dev != nullptr) && g_conv_split >= 0;
-    nsplit = g_conv_split > 0 ? g_conv_split : (n_out_dev && few_rows ? 27 : dcl_div_up(1024, tiles));
+    nsplit = g_conv_split > 0 ? g_conv_split.load() : (n_out_dev && few_rows ? 27 : dcl_div_up(1024, tiles));
     const int most = few_rows ? conv_split_cap(rows) : kConvMaxSplit;
     if (nsplit > most) nsplit = most;
     if (nsplit > nchunks / (few_rows ? 4 : 8)) nsplit = nchunks / (few_rows ? 4 : 8);
@@ -746,7 +750,7 @@ static void launch_conv_tile(int rows, const float *feat, const DclNbrSrc &nbr, 
   const int nchunks = dcl_div_up(kvol, KC / CIN);
   int nsplit = 1;
   if (scratch && g_conv_split >= 0 && conv_few_rows(rows, n_out_dev != nullptr)) {
-    nsplit = g_conv_split > 0 ? g_conv_split : kConvMaxSplit;
+    nsplit = g_conv_split > 0 ? g_conv_split.load() : kConvMaxSplit;
     if (nsplit > nchunks) nsplit = nchunks;
     while (nsplit > 1 && (long long)nsplit * cap * cout > scratch_floats) --nsplit;
     if (nsplit < 1) nsplit = 1;
@@ -825,7 +829,7 @@ __global__ void k_sparse_avgpool_scalar(const float *__restrict__ feat, const Dc
 
 }  // namespace
 
-static int g_force_valu = 0;   // test hook: 1 = plain VALU kernel for every conv, 2 = MFMA kernel without LDS staging, 3 = LDS-weights kernel, 4 = register-staged tile kernel instead of the LDS-DMA one
+static std::atomic<int> g_force_valu{0};   // test hook: 1 = plain VALU kernel for every conv, 2 = MFMA kernel without LDS staging, 3 = LDS-weights kernel, 4 = register-staged tile kernel instead of the LDS-DMA one
 DCL_API void dcl_debug_force_valu_conv(int on) { g_force_valu = on; }
 
 DCL_API void dcl_debug_conv_split(int n) { g_conv_split = n; }
@@ -858,11 +862,75 @@ DCL_API int dcl_sparse_conv_fwd_ws(const float *feat, const int32_t *nbr, int ca
                                       out, scratch, scratch_floats, stream);
 }
 
+// ---- measurement facility (bench.py's `roofline_sparse_conv`): while enabled, every sparse-conv call is bracketed by
+// HIP events on the stream it is launched on; dcl_profile_conv_end() waits for them and returns the summed device time.
+// Mutex-protected; not for use under stream capture (events would become graph nodes).
+namespace {
+struct ConvProfile {
+  std::mutex mu;
+  bool on = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+};
+ConvProfile g_conv_prof;
+}  // namespace
+
+DCL_API int dcl_profile_conv_begin(void) {
+  std::lock_guard<std::mutex> lock(g_conv_prof.mu);
+  for (auto &e : g_conv_prof.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  g_conv_prof.ev.clear();
+  g_conv_prof.on = true;
+  return 0;
+}
+
+DCL_API int dcl_profile_conv_end(double *ms_total_host, int32_t *calls_host) {
+  std::lock_guard<std::mutex> lock(g_conv_prof.mu);
+  g_conv_prof.on = false;
+  double total = 0.0;
+  for (auto &e : g_conv_prof.ev) {
+    float ms = 0.f;
+    if (hipEventSynchronize(e.second) == hipSuccess && hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) total += ms;
+    (void)hipEventDestroy(e.first);
+    (void)hipEventDestroy(e.second);
+  }
+  if (ms_total_host) *ms_total_host = total;
+  if (calls_host) *calls_host = (int32_t)g_conv_prof.ev.size();
+  g_conv_prof.ev.clear();
+  return 0;
+}
+
+static int conv_dispatch(const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev, int n_out_host,
+                         const float *W, int cin, int cout, int kvol, int subm, const float *scale, const float *shift,
+                         int relu, float *out, float *scratch, int64_t scratch_floats, dclStream_t stream);
+
 // library-internal: `nbr` may be an implicit rulebook (native backbone runner)
 int dcl_internal_sparse_conv_fwd(const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev,
                                  int n_out_host, const float *W, int cin, int cout, int kvol, int subm, const float *scale,
                                  const float *shift, int relu, float *out, float *scratch, int64_t scratch_floats,
                                  dclStream_t stream) {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  bool timed = false;
+  {
+    std::lock_guard<std::mutex> lock(g_conv_prof.mu);
+    timed = g_conv_prof.on;
+  }
+  if (timed) {
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, (hipStream_t)stream);
+  }
+  const int rc = conv_dispatch(feat, nbr, cap, n_out_dev, n_out_host, W, cin, cout, kvol, subm, scale, shift, relu, out,
+                               scratch, scratch_floats, stream);
+  if (timed) {
+    (void)hipEventRecord(e1, (hipStream_t)stream);
+    std::lock_guard<std::mutex> lock(g_conv_prof.mu);
+    g_conv_prof.ev.emplace_back(e0, e1);
+  }
+  return rc;
+}
+
+static int conv_dispatch(const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev, int n_out_host,
+                         const float *W, int cin, int cout, int kvol, int subm, const float *scale, const float *shift,
+                         int relu, float *out, float *scratch, int64_t scratch_floats, dclStream_t stream) {
   DCL_CHECK_ARG(feat && (nbr.nbr || (nbr.out_indices && nbr.in_mask && nbr.in_wprefix && kvol == 27)) && W && out && cap > 0 &&
                 cin > 0 && cout > 0 && kvol > 0 && kvol <= 27);
   DCL_CHECK_ARG((scale == nullptr) == (shift == nullptr));

@@ -612,10 +612,12 @@ def ortho9d_to_matrix(o9):
     return R
 
 
-def add_s(cld, R_pred, t_pred, R_gt, t_gt, cls=None):
+def add_s(cld, R_pred, t_pred, R_gt, t_gt, cls=None, sym_flag=None, mode="adds"):
     """ADD-S per object (tools/test_YCBV_stage1.py:186-189) without the (b,P,P,3) intermediate.
-    cld (n_clouds,P,3) f32; cls (b,) int32 picks each object's cloud (None: cloud o for object o) -> (b,) f32."""
-    N.need_cuda(cld, R_pred, t_pred, R_gt, t_gt, cls)
+    cld (n_clouds,P,3) f32; cls (b,) int32 picks each object's cloud (None: cloud o for object o) -> (b,) f32.
+    mode="add": ADD (corresponding points, tools/test_LM.py:123); sym_flag (b,) given: ADD where it is 0, ADD-S elsewhere
+    (the LineMOD rule, tools/test_LM.py:130-135)."""
+    N.need_cuda(cld, R_pred, t_pred, R_gt, t_gt, cls, sym_flag)
     cld, R_pred, t_pred = N.f32c(cld), N.f32c(R_pred), N.f32c(t_pred)
     R_gt, t_gt = N.f32c(R_gt), N.f32c(t_gt)
     b, P = R_pred.shape[0], cld.shape[1]
@@ -625,9 +627,21 @@ def add_s(cld, R_pred, t_pred, R_gt, t_gt, cls=None):
         assert cld.shape[0] == b
     part = torch.empty((b, (P + 255) // 256), dtype=torch.float32, device=cld.device)
     out = torch.empty(b, dtype=torch.float32, device=cld.device)
-    N.check(N.lib().dcl_add_s(b, P, N.ptr(cld), N.ptr(cls), N.ptr(R_pred), N.ptr(t_pred), N.ptr(R_gt), N.ptr(t_gt),
-                              N.ptr(part), N.ptr(out), N.stream()), "add_s")
+    if sym_flag is not None:
+        sym = N.i32c(sym_flag)
+        assert sym.numel() == b
+        N.check(N.lib().dcl_add_by_symmetry(b, P, N.ptr(cld), N.ptr(cls), N.ptr(sym), N.ptr(R_pred), N.ptr(t_pred),
+                                            N.ptr(R_gt), N.ptr(t_gt), N.ptr(part), N.ptr(out), N.stream()), "add_by_symmetry")
+        return out
+    fn = {"adds": N.lib().dcl_add_s, "add": N.lib().dcl_add}[mode]
+    N.check(fn(b, P, N.ptr(cld), N.ptr(cls), N.ptr(R_pred), N.ptr(t_pred), N.ptr(R_gt), N.ptr(t_gt),
+               N.ptr(part), N.ptr(out), N.stream()), "add_s")
     return out
+
+
+def add(cld, R_pred, t_pred, R_gt, t_gt, cls=None):
+    """ADD per object: mean_i |pred_i - gt_i| (tools/test_LM.py:123 `l2_dis`)."""
+    return add_s(cld, R_pred, t_pred, R_gt, t_gt, cls, mode="add")
 
 
 # ------------------------------------------------------------------------------------ crop builder

@@ -29,8 +29,67 @@ def add_s(cld, R_pred, t_pred, R_gt, t_gt, chunk=512):
     gt = torch.bmm(cld, R_gt.transpose(1, 2)) + t_gt.unsqueeze(1)
     mins = []
     for s in range(0, pred.shape[1], chunk):
-        mins.append(torch.cdist(pred[:, s:s + chunk], gt).min(dim=2)[0])
+        mins.append(torch.cdist(pred[:, s:s + chunk], gt, compute_mode="donot_use_mm_for_euclid_dist").min(dim=2)[0])
     return torch.cat(mins, dim=1).mean(dim=1)
+
+
+def add_lm(cld, R_pred, t_pred, R_gt, t_gt, sym_flag):
+    """LineMOD distance per object (tools/test_LM.py:123-135): ADD (`l2_dis`) where sym_flag == 0, ADD-S (`cd_dis`) where it
+    is 1.  CUDA tensors go to the fused HIP kernel; the torch form is the CPU-side helper of the gloo tests."""
+    if cld.is_cuda:
+        from . import ops
+        return ops.add_s(cld, R_pred, t_pred, R_gt, t_gt, sym_flag=sym_flag)
+    pred = torch.bmm(cld, R_pred.transpose(1, 2)) + t_pred.unsqueeze(1)
+    gt = torch.bmm(cld, R_gt.transpose(1, 2)) + t_gt.unsqueeze(1)
+    l2 = torch.norm(pred - gt, dim=2).mean(dim=1)
+    cd = torch.cdist(pred, gt, compute_mode="donot_use_mm_for_euclid_dist").min(dim=2)[0].mean(dim=1)
+    return torch.where(sym_flag.to(l2.device) != 0, cd, l2)
+
+
+class LmTable(object):
+    """LineMOD ADD(S) < 0.1 d success table (tools/test_LM.py:99-100,126-141,148-153): per object `num_count` and
+    `success_count` with the threshold `dis < diameter[idx]` (diameter[] already holds 0.1 * object diameter in metres,
+    tools/test_LM.py:68-75); lost detections (flag -1) are not counted at all.  Integer counts: the SUM all-reduce over
+    RCCL / gloo is exact."""
+    OBJLIST = (1, 2, 4, 5, 6, 8, 9, 10, 11, 12, 13, 14, 15)          # tools/test_LM.py:71
+
+    def __init__(self, diameter):
+        self.diameter = np.asarray(diameter, np.float64)
+        self.counts = np.zeros((len(self.diameter), 2), np.int64)        # num_count, success_count
+
+    def add(self, idx, dis, flag=0):
+        if flag == -1:
+            return
+        self.counts[idx, 0] += 1
+        if dis < self.diameter[idx]:
+            self.counts[idx, 1] += 1
+
+    def add_batch(self, obj_idx, dis, flags=None):
+        """the per-frame loop of tools/test_LM.py:126-141: `flags` covers every object of the frame (incl. -1 = lost),
+        obj_idx / dis only the detected ones, in order"""
+        flags = [0] * len(dis) if flags is None else [int(f) for f in flags]
+        k = 0
+        for f in flags:
+            if f == -1:
+                continue
+            self.add(int(obj_idx[k]), float(dis[k]))
+            k += 1
+        assert k == len(dis)
+
+    def reduce(self, device=None, group=None):
+        if not (dist.is_available() and dist.is_initialized()):
+            return self
+        c = torch.from_numpy(self.counts).to(device or "cpu")
+        dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
+        self.counts = c.cpu().numpy()
+        return self
+
+    def finalize(self):
+        """-> (ALL success rate, per-object success rates) as tools/test_LM.py:148-153 logs them"""
+        num, suc = self.counts[:, 0], self.counts[:, 1]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            per = np.where(num > 0, suc / np.maximum(num, 1), np.nan)
+        return (float(suc.sum()) / float(num.sum()) if num.sum() else float("nan")), per
 
 
 class AddsTable(object):

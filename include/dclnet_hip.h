@@ -377,6 +377,24 @@ int dcl_crop_sample(int n_inst, int npoint, int cap, const float *xyz, const flo
 int dcl_add_s(int b, int P, const float *cld, const int32_t *cls, const float *R_pred, const float *t_pred,
               const float *R_gt, const float *t_gt, float *partial_scratch, float *out, dclStream_t stream);
 
+/* LineMOD metric (tools/test_LM.py:123-135).  dcl_add: ADD = mean_i |R_pred x_i + t_pred - (R_gt x_i + t_gt)| (the
+ * reference's `l2_dis`, non-symmetric objects).  dcl_add_by_symmetry: per object, sym_flag[o] == 0 -> ADD, != 0 -> ADD-S
+ * (`cd_dis`), one launch.  Same buffers as dcl_add_s.                                                                    */
+int dcl_add(int b, int P, const float *cld, const int32_t *cls, const float *R_pred, const float *t_pred,
+            const float *R_gt, const float *t_gt, float *partial_scratch, float *out, dclStream_t stream);
+int dcl_add_by_symmetry(int b, int P, const float *cld, const int32_t *cls, const int32_t *sym_flag,
+                        const float *R_pred, const float *t_pred, const float *R_gt, const float *t_gt,
+                        float *partial_scratch, float *out, dclStream_t stream);
+
+/* Measurement facility for the sparse-conv roofline (bench.py): between _begin and _end every sparse-conv call (runner or op
+ * API) is bracketed by HIP events on its launch stream; _end waits for them and returns the summed device milliseconds and
+ * the number of calls.  Thread-safe; do not use under stream capture.                                                    */
+int dcl_profile_conv_begin(void);
+int dcl_profile_conv_end(double *ms_total_host, int32_t *calls_host);
+
+/* The dcl_debug_* entry points below are TEST / TUNING hooks, not part of the operator API: each sets one process-wide
+ * atomic switch that later calls from any thread read (A/B kernel variants in tests, tuning sweeps in tools/).  They never
+ * change results beyond the tolerance of the op; production callers leave them alone.                                    */
 /* Test hook, sparse-conv kernel variant: 0 = automatic (LDS-DMA implicit GEMM where Cout % 64 == 0), 1 = plain VALU
  * kernel for every layer (A/B check of the MFMA ones), 2 = MFMA without LDS staging, 3 = MFMA with LDS weights,
  * 4 = register-staged tile kernel instead of the LDS-DMA one. */

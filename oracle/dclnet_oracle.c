@@ -253,9 +253,11 @@ ORC_API void orc_indice_conv(const float *feat, const float *filters, const int3
     memset(out, 0, sizeof(float) * (size_t)n_out * cout);
     int kmax = 0;
     for (int k = 1; k < kv; ++k) if (indice_num[k] > indice_num[kmax]) kmax = k;
-    float *tmp = (float *)malloc(sizeof(float) * cout);
+    /* OpenMP (bench.py's cpu_baseline leg runs this on all host cores): rows of one offset are independent -- an output
+     * row occurs at most once per offset -- so the per-element summation order, hence every bit, is that of the serial loop */
     if (subm) {
         const float *W = filters + (size_t)kmax * cin * cout;
+        #pragma omp parallel for schedule(static)
         for (int r = 0; r < n_out; ++r) {
             const float *f = feat + (size_t)r * cin;
             for (int co = 0; co < cout; ++co) {
@@ -271,18 +273,17 @@ ORC_API void orc_indice_conv(const float *feat, const float *filters, const int3
         const float *W = filters + (size_t)k * cin * cout;
         const int32_t *pin = pairs + ((size_t)k * 2 + 0) * V_in;
         const int32_t *pout = pairs + ((size_t)k * 2 + 1) * V_in;
+        #pragma omp parallel for schedule(static)
         for (int c = 0; c < nHot; ++c) {
             const float *f = feat + (size_t)pin[c] * cin;
             float *o = out + (size_t)pout[c] * cout;
             for (int co = 0; co < cout; ++co) {
                 float acc = 0.0f;
                 for (int ci = 0; ci < cin; ++ci) acc = fmaf(f[ci], W[(size_t)ci * cout + co], acc);
-                tmp[co] = acc;
+                o[co] = o[co] + acc;                                      /* reordering.cu.h:99-157 */
             }
-            for (int co = 0; co < cout; ++co) o[co] = o[co] + tmp[co];  /* reordering.cu.h:99-157 */
         }
     }
-    free(tmp);
 }
 
 /* a6. indiceSummaryRF + indiceAvgPool (pool_ops.h:141-208; summaryRF.cu:26-41;
@@ -299,6 +300,7 @@ ORC_API void orc_indice_avgpool(const float *feat, const int32_t *pairs, const i
     for (int k = 0; k < kv; ++k) {
         const int32_t *pin = pairs + ((size_t)k * 2 + 0) * V_in;
         const int32_t *pout = pairs + ((size_t)k * 2 + 1) * V_in;
+        #pragma omp parallel for schedule(static)
         for (int i = 0; i < indice_num[k]; ++i) {
             const float *f = feat + (size_t)pin[i] * c;
             float *o = out + (size_t)pout[i] * c;
@@ -315,6 +317,7 @@ ORC_API void orc_indice_avgpool(const float *feat, const int32_t *pairs, const i
 /* ------------------------------------------------------------------------- */
 ORC_API void orc_three_nn_sp(int n, int m, const float *unknown, const float *known,
                              float *dist2, int32_t *idx) {
+    #pragma omp parallel for schedule(static)
     for (int p = 0; p < n; ++p) {
         const float *u = unknown + (size_t)p * 4;
         float ub = u[0], ux = u[1], uy = u[2], uz = u[3];
@@ -338,6 +341,7 @@ ORC_API void orc_three_nn_sp(int n, int m, const float *unknown, const float *kn
 ORC_API void orc_three_interpolate_sp(int c, int m, int n, const float *points, const int32_t *idx,
                                       const float *weight, float *out) {
     (void)m;
+    #pragma omp parallel for schedule(static)
     for (int p = 0; p < n; ++p) {
         const int32_t *id = idx + (size_t)p * 3;
         const float *w = weight + (size_t)p * 3;

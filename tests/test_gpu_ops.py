@@ -585,6 +585,28 @@ def test_add_s_matches_reference_expression(dcl):
     assert float(same.abs().max()) == 0.0                      # identical poses: every point matches itself exactly
 
 
+def test_linemod_add_and_adds_kernel_matches_reference_loop_golden(dcl, golden_dir):
+    """fused ADD / ADD-S selection kernel (dcl_add_by_symmetry, dcl_add) vs the distances the reference's own eval-loop body
+    computed (tools/test_LM.py:118-124 via tests/golden/make_lm_metric_golden.py), and the resulting 13-object success
+    table"""
+    import os
+    z = np.load(os.path.join(golden_dir, "lm_metric_ref.npz"))
+    clouds = cuda(z["clouds"])
+    table = dcl.sharding.LmTable(z["diameter"])
+    for f in range(int(z["n_frames"][0])):
+        g = {k: z["f%d_%s" % (f, k)] for k in ("flags", "idx", "Rp", "tp", "Rg", "tg", "l2", "cd")}
+        sym = g["flags"][g["flags"] != -1].astype(np.int32)
+        args = [cuda(g[k]) for k in ("Rp", "tp", "Rg", "tg")]
+        d = dcl.sharding.add_lm(clouds[cuda(g["idx"]).long()].contiguous(), *args, cuda(sym)).cpu().numpy()
+        assert np.abs(d - np.where(sym != 0, g["cd"], g["l2"])).max() <= 1e-6
+        via_cls = dcl.ops.add_s(clouds, *args, cls=cuda(g["idx"]), sym_flag=cuda(sym)).cpu().numpy()
+        assert np.array_equal(via_cls, d)
+        assert np.abs(dcl.ops.add(clouds, *args, cls=cuda(g["idx"])).cpu().numpy() - g["l2"]).max() <= 1e-6
+        assert np.abs(dcl.ops.add_s(clouds, *args, cls=cuda(g["idx"])).cpu().numpy() - g["cd"]).max() <= 1e-6
+        table.add_batch(g["idx"], d.tolist(), g["flags"])
+    assert np.array_equal(table.counts[:, 0], z["num_count"]) and np.array_equal(table.counts[:, 1], z["success_count"])
+
+
 # ------------------------------------------------------------------------------------------- native backbone runner
 def _edge_voxels(rng, S=64):
     """crop 0: random blob touching the 0 and S-1 faces; crop 1: EMPTY; crop 2: one voxel in a corner; crop 3: dense 6^3 block

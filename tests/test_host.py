@@ -185,3 +185,69 @@ def test_metric_matches_reference_functions_golden(dcl, golden_dir):
         assert np.abs(auc - z["auc%d" % case]).max() <= 1e-4          # the reference accumulates its ramp in float32
         assert np.abs(acc - z["acc%d" % case]).max() <= 1e-9
         assert abs(mean_auc - float(z["mean_auc%d" % case][0])) <= 0.0100001     # both rounded to 2 decimals
+
+
+def _lm_frames(golden_dir):
+    z = np.load(os.path.join(golden_dir, "lm_metric_ref.npz"))
+    frames = []
+    for f in range(int(z["n_frames"][0])):
+        frames.append({k: z["f%d_%s" % (f, k)] for k in ("flags", "idx", "Rp", "tp", "Rg", "tg", "l2", "cd")})
+    return z, frames
+
+
+def test_linemod_metric_matches_reference_loop_golden(dcl, golden_dir):
+    """sharding.add_lm + LmTable vs the per-frame body of the reference's LineMOD eval loop (tools/test_LM.py:112-141, run
+    from the reference source by tests/golden/make_lm_metric_golden.py): ADD for non-symmetric, ADD-S for symmetric
+    objects, `dis < diameter[idx]`, lost detections skipped -> the same success_count / num_count"""
+    z, frames = _lm_frames(golden_dir)
+    clouds = torch.from_numpy(z["clouds"])
+    table = dcl.sharding.LmTable(z["diameter"])
+    for fr in frames:
+        flags = fr["flags"]
+        sym = torch.from_numpy(flags[flags != -1].astype(np.int32))
+        cld = clouds[torch.from_numpy(fr["idx"]).long()]
+        args = [torch.from_numpy(fr[k]) for k in ("Rp", "tp", "Rg", "tg")]
+        d = dcl.sharding.add_lm(cld, *args, sym)
+        want = np.where(sym.numpy() != 0, fr["cd"], fr["l2"])
+        assert np.abs(d.numpy() - want).max() <= 1e-6
+        table.add_batch(fr["idx"], d.tolist(), flags)
+    assert np.array_equal(table.counts[:, 0], z["num_count"]) and np.array_equal(table.counts[:, 1], z["success_count"])
+    all_rate, per = table.finalize()
+    assert abs(all_rate - z["success_count"].sum() / z["num_count"].sum()) <= 1e-12
+    assert np.allclose(per, z["success_count"] / z["num_count"])
+    assert len(dcl.sharding.LmTable.OBJLIST) == 13
+
+
+LM_WORKER = textwrap.dedent('''
+    import importlib, os, sys
+    import numpy as np, torch, torch.distributed as dist
+    sys.path.insert(0, %r)
+    dcl = importlib.import_module("dcl-net_amd")
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    z = np.load(%r)
+    n = int(z["n_frames"][0])
+    mine = dcl.sharding.LmTable(z["diameter"])
+    for f in dcl.sharding.shard_indices(n, rank, world):               # frames r, r+W, ... on this rank
+        flags = z["f%%d_flags" %% f]
+        d = np.where(flags[flags != -1] != 0, z["f%%d_cd" %% f], z["f%%d_l2" %% f])
+        mine.add_batch(z["f%%d_idx" %% f], d.tolist(), flags)
+    assert mine.counts[:, 0].sum() < z["num_count"].sum()                # really a shard
+    mine.reduce()
+    assert np.array_equal(mine.counts[:, 0], z["num_count"]) and np.array_equal(mine.counts[:, 1], z["success_count"])
+    dist.destroy_process_group()
+    print("rank", rank, "ok", mine.finalize()[0])
+''')
+
+
+def test_linemod_table_allreduce_two_processes_gloo(tmp_path, golden_dir):
+    """LineMOD variant of the metric reduction (SURVEY 8e): SUM of success_count[13] / num_count[13] over 2 gloo ranks
+    reproduces the reference's single-process counts exactly"""
+    script = tmp_path / "lm_worker.py"
+    script.write_text(LM_WORKER % (ROOT, os.path.join(golden_dir, "lm_metric_ref.npz")))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("ok" in o for o in outs)
