@@ -245,6 +245,19 @@ def refiner_bench(dcl, dev, b, iters=2, reps=20):
     return out
 
 
+def usable_cores():
+    """host cores this process may really use: the affinity mask, capped by the cgroup CPU quota (os.cpu_count() reports
+    the machine's 256 even inside a container that owns a handful)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def stage2_chain_bench(dcl, dev, net, data, b, iters=2, reps=20):
     """BASELINE configs[4] as ONE workload: stage-1 forward chained into the 2-iteration refiner loop with pose composition
     (tools/test_YCBV_stage2.py:204-225; refiner.stage2_chain), frames/s including both refine iterations; the refine loop
@@ -271,9 +284,10 @@ def cpu_baseline(dcl, sd, cfg, n_inp, n_tmp, crops=2):
     the same workload, on the host cores of this box: the C kernels' row loops run under OpenMP, the dense algebra is
     torch-CPU fp32, both on every core."""
     from oracle import graph as G
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    from oracle import native as oracle_native
+    oracle_native.set_num_threads(cores)
     data = dcl.synth.make_batch(crops, n_inp, n_tmp)
     t0 = time.perf_counter()
     G.forward(sd, dict(cfg), data, mode="test")

@@ -10,7 +10,7 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libdclnet_hip.so")
+SO_PATH = os.environ.get("DCL_HIP_LIB") or os.path.join(_HERE, "libdclnet_hip.so")   # DCL_HIP_LIB: diagnostic builds (tools/)
 _LIB = None
 
 vp = C.c_void_p

@@ -21,7 +21,7 @@ int dcl_internal_grid_from_indices(const int32_t *indices, const int32_t *n_rows
 int dcl_internal_sparse_conv_fwd(const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev,
                                  int n_out_host, const float *W, int cin, int cout, int kvol, int subm, const float *scale,
                                  const float *shift, int relu, float *out, float *scratch, int64_t scratch_floats,
-                                 dclStream_t stream);
+                                 dclStream_t stream, int counters_ready = 0);
 int dcl_internal_conv_split_cap(long long rows);
 int dcl_internal_out_mask_k3(const uint32_t *in_mask, int batch, int S_in, int stride, uint32_t *out_mask,
                              dclStream_t stream);
@@ -118,7 +118,8 @@ bool make_feat_layout(const int32_t *counts, const int *chan /*9*/, FeatLayout *
       size_t split = (1024 + tiles - 1) / tiles;
       const size_t most = (size_t)dcl_internal_conv_split_cap((long long)nc);
       if (split > most || nc <= 65536) split = most;      // small passes (and capacity mode) may split all the way
-      if (split > 1 && split * nc * cout > scratch) scratch = split * nc * cout;
+      const size_t nc_pad = (nc + 127) / 128 * 128;       // partial tiles are whole 128-row tiles
+      if (split > 1 && split * nc_pad * cout > scratch) scratch = split * nc_pad * cout;
     }
   }
   size_t off = 0;
@@ -126,6 +127,7 @@ bool make_feat_layout(const int32_t *counts, const int *chan /*9*/, FeatLayout *
   L->nbr = take(sizeof(int32_t) * 27 * max_rows);
   L->x1 = take(x1);
   L->x2 = take(x2);
+  if (scratch) scratch += kConvCounterWords;               // tile tickets of the in-launch split-K combine (common.h)
   L->scratch = take(scratch * sizeof(float));
   L->scratch_floats = scratch;
   L->total = off;
@@ -268,6 +270,8 @@ static int backbone_features(const int32_t *occ, int V0, int batch, int S, void 
   const int32_t *in_wp = at<int32_t>(ws, L.wprefix0);
   const int32_t *in_perm = at<int32_t>(ws, L.perm0);
   int s = S, rc;
+  // split-K tile tickets: zeroed once per pass, every split launch leaves them zero again
+  if (F.scratch_floats) dcl_internal_zero_words(at<float>(ws2, F.scratch), kConvCounterWords, (hipStream_t)stream);
   int steps_left = dbg_steps();
   const bool explicit_nbr = getenv("DCL_EXPLICIT_NBR") != nullptr && atoi(getenv("DCL_EXPLICIT_NBR")) != 0;
 #define DBG_STEP() do { if (--steps_left < 0) return 0; } while (0)
@@ -299,7 +303,7 @@ static int backbone_features(const int32_t *occ, int V0, int batch, int S, void 
       if (rc) return rc;
       DBG_STEP();
       rc = dcl_internal_sparse_conv_fwd(x, src, nc, nc_dev, nc_dev ? 0 : nc, weights[2 * m], c0, c1, 27, 0, scales[2 * m],
-                                        shifts[2 * m], 1, x1, scr, (int64_t)F.scratch_floats, stream);
+                                        shifts[2 * m], 1, x1, scr, (int64_t)F.scratch_floats, stream, 1);
       if (rc) return rc;
       // submanifold conv on the conv set
       DBG_STEP();
@@ -308,7 +312,7 @@ static int backbone_features(const int32_t *occ, int V0, int batch, int S, void 
       if (rc) return rc;
       DBG_STEP();
       rc = dcl_internal_sparse_conv_fwd(x1, src, nc, nc_dev, nc_dev ? 0 : nc, weights[2 * m + 1], c1, c2, 27, 1,
-                                        scales[2 * m + 1], shifts[2 * m + 1], 1, x2, scr, (int64_t)F.scratch_floats, stream);
+                                        scales[2 * m + 1], shifts[2 * m + 1], 1, x2, scr, (int64_t)F.scratch_floats, stream, 1);
       if (rc) return rc;
     }
     if (np > 0) {

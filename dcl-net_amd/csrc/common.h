@@ -40,6 +40,13 @@ __device__ __forceinline__ float dcl_dist2(float ax, float ay, float az, float b
   float dx = ax - bx, dy = ay - by, dz = az - bz;
   return __fmaf_rn(dz, dz, __fmaf_rn(dx, dx, dy * dy));
 }
+// Split-K sparse-conv launches combine their partial sums inside the launch: every (tile, split) workgroup publishes its
+// partial tile, takes a ticket on the tile's counter and the last arriver adds the partials in split order (deterministic)
+// and runs the epilogue.  The counters are the first kConvCounterWords int32 of the caller's split-K scratch; they must be
+// zero before a launch and are left zero by it.
+constexpr int kConvCounterWords = 8192;
+void dcl_internal_zero_words(void *p, long long nwords, hipStream_t s);
+
 // Where a kernel gets nbr[k][o] (the input row feeding output row o under kernel offset k) from: an explicit gather table
 // (dcl_rulebook_gather; the spconv shim and the training path keep it) or, inside the native backbone runner, the input
 // set's occupancy grid directly -- p = o*stride - pad + k looked up by bitmask rank (no table, no k_build_nbr launch).

@@ -21,7 +21,7 @@
 int dcl_internal_sparse_conv_fwd(const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev,
                                  int n_out_host, const float *W, int cin, int cout, int kvol, int subm, const float *scale,
                                  const float *shift, int relu, float *out, float *scratch, int64_t scratch_floats,
-                                 dclStream_t stream);
+                                 dclStream_t stream, int counters_ready = 0);
 int dcl_internal_sparse_avgpool_fwd(const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev,
                                     int n_out_host, int c, int kvol, float *out, int32_t *rf, dclStream_t stream);
 
@@ -486,6 +486,19 @@ __global__ __launch_bounds__(256, 2) void k_sparse_conv_tile(
 // contiguous LDS, bank conflicts are avoided by swizzling instead of padding: the 16-B column c of row r is stored at
 // column c ^ (r & 15) (A), and W rows with bit 2 of their index set swap their 32-column halves (B).
 __device__ float4 g_conv_zero_line = {0.f, 0.f, 0.f, 0.f};
+#ifdef DCL_CONV_STAMPS
+// diagnostic build only (tools/conv_stamps.py): s_memrealtime (100 MHz) of workgroup phases, 8 stamps per workgroup
+constexpr int kStampWgs = 16384;
+__device__ unsigned long long g_conv_stamps[kStampWgs * 8];
+__device__ unsigned long long g_conv_phase[kStampWgs * 8];     // wave 0's shader cycles in: DMA wait, barrier, issue, MFMA block; chunks
+#define CONV_STAMP(i)                                                                                          \
+  do {                                                                                                         \
+    const int wg__ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                           \
+    if (threadIdx.x == 0 && wg__ < kStampWgs) g_conv_stamps[wg__ * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define CONV_STAMP(i) do { } while (0)
+#endif
 typedef __attribute__((address_space(3))) void conv_lds_void_t;
 __device__ __forceinline__ void conv_glds16(const void *gsrc, unsigned lds_byte_addr) {
   unsigned keep;
@@ -493,6 +506,11 @@ __device__ __forceinline__ void conv_glds16(const void *gsrc, unsigned lds_byte_
                : "=&s"(keep)
                : "v"(gsrc), "s"(lds_byte_addr)
                : "memory");
+}
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// 16-B write-through (sc1) store: the payload of an in-launch hand-off (cdna_hip_programming.md Guideline 16, R1)
+__device__ __forceinline__ void conv_store16_wt(f32x4 *p, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ unsigned conv_lds_addr(const float *p) {
   return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(conv_lds_void_t *)p);
@@ -503,18 +521,19 @@ __device__ __forceinline__ unsigned conv_lds_addr(const float *p) {
 // (BM+BN)*KC*4 bytes), not LDS or the MFMA pipe: 64x64 tiles (16 flop/B) saturated at ~45 % of the MFMA peak, hence
 // 128x128 (Cout % 128 == 0, 8 waves, 32 flop/B) and 128x64 (4 waves) here.
 template <int CIN, int WR, int WCW, int NT>
-__global__ __launch_bounds__(64 * WR * WCW, 2) void k_sparse_conv_dma(
+__global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma(   // 2 workgroups per CU (LDS allows 2)
     const float *__restrict__ feat, const DclNbrSrc src, int cap, const int32_t *__restrict__ n_out_dev,
     int n_out_host, const float *__restrict__ W, int cout, int kvol, int subm, const float *__restrict__ scale,
     const float *__restrict__ shift, int relu, float *__restrict__ out, float *__restrict__ partial, int nsplit,
-    int xcd_remap) {
+    int xcd_remap, int32_t *__restrict__ tile_counters) {
   constexpr int NW = WR * WCW, NTHR = 64 * NW;
   constexpr int BM = 32 * WR, BN = 32 * NT * WCW, KC = 32;
   constexpr int AT = BM * KC, BT = KC * BN, ST = AT + BT;      // floats per stage
   constexpr int A_INSTR = BM / 8;                              // 1-KiB DMA instructions per A tile (8 rows of 128 B each)
   constexpr int B_ROWS_PER = 256 / BN;                         // W rows per 1-KiB DMA instruction
   constexpr int B_INSTR = KC / B_ROWS_PER;
-  static_assert(A_INSTR % NW == 0 && B_INSTR % NW == 0 && (BN == 64 || BN == 128), "tile shape");
+  static_assert(A_INSTR % NW == 0 && B_INSTR % NW == 0 && (BN == 32 || BN == 64 || BN == 128), "tile shape");
+  constexpr int BSWZ = BN >= 64 ? 1 : 0;                       // W-row half swap (rows 32 floats wide have no halves to swap)
   extern __shared__ __attribute__((aligned(16))) float conv_lds[];   // [stage 0: A|B][stage 1: A|B][Ns 27*BM][kmask]
   int32_t *Ns = reinterpret_cast<int32_t *>(conv_lds + 2 * ST);
   unsigned *s_kmask = reinterpret_cast<unsigned *>(Ns + 27 * BM);
@@ -548,6 +567,15 @@ __global__ __launch_bounds__(64 * WR * WCW, 2) void k_sparse_conv_dma(
 
   for (int blk = bx; blk < nblk; blk += gridDim.x) {
     const int row0 = blk * BM;
+    CONV_STAMP(0);
+#ifdef DCL_CONV_STAMPS
+    {
+      const int wg__ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+      if (threadIdx.x == 0 && wg__ < kStampWgs)
+        g_conv_stamps[wg__ * 8 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) |
+                                      (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // XCC_ID, HW_ID
+    }
+#endif
     if (tid == 0) *s_kmask = 0;
     __syncthreads();
     // neighbour rows of the offsets this workgroup's chunk range touches (all 27 without split-K)
@@ -578,31 +606,67 @@ __global__ __launch_bounds__(64 * WR * WCW, 2) void k_sparse_conv_dma(
     // A row = 32 floats = 8 blocks of 16 B, block c of row q stored at c ^ ((q >> 1) & 7): 16 consecutive rows read with
     // ds_read_b128 then cover all 64 banks once.  W row kk with bit 2 set swaps its 32-float halves (the two lane
     // halves of an MFMA read rows 4 apart).
+    // The issue of a chunk's operand DMAs sits between the barrier and the MFMA block of every wave, so it is kept
+    // short: what depends only on the lane (tile row, swizzled 16-B piece, W row / column piece) is computed once per
+    // tile; per chunk the neighbour rows of ALL of the wave's A pieces are read from LDS first (independent reads, one
+    // wait) and only then the DMAs go out -- an asm statement with a memory clobber between two LDS reads would serialise
+    // read -> wait -> DMA per piece.
+    constexpr int A_PER = A_INSTR / NW, B_PER = B_INSTR / NW, LPR = BN / 4;
+    int a_row[A_PER], a_chs[A_PER], b_kk[B_PER], b_col[B_PER];
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+      const int g = wave * A_PER + i;
+      a_row[i] = g * 8 + (lane >> 3);
+      a_chs[i] = ((lane & 7) ^ ((a_row[i] >> 1) & 7)) << 2;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      const int g = wave * B_PER + i;
+      b_kk[i] = g * B_ROWS_PER + lane / LPR;
+      const int pcol = lane % LPR;
+      b_col[i] = col0 + ((BSWZ ? pcol ^ (((b_kk[i] >> 2) & 1) << 3) : pcol) << 2);
+    }
     auto issue = [&](int j, int stage) {
       float *As = conv_lds + stage * ST, *Bs = As + AT;
+      const int vc0 = j * KC;
+      const float *asrc[A_PER];
+      if constexpr (CIN >= KC) {                         // the chunk lies inside ONE kernel offset: uniform k and channel base
+        const int sx = vc0 / CIN, chb = vc0 - sx * CIN;
+        const int k = offset_at(sx, kvol, subm);
+        int v[A_PER];
 #pragma unroll
-      for (int i = 0; i < A_INSTR / NW; ++i) {
-        const int g = wave * (A_INSTR / NW) + i;
-        const int row = g * 8 + (lane >> 3), pcol = lane & 7;
-        const int vc = j * KC + ((pcol ^ ((row >> 1) & 7)) << 2);
+        for (int i = 0; i < A_PER; ++i) v[i] = Ns[k * BM + a_row[i]];
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) asrc[i] = v[i] >= 0 ? feat + (size_t)v[i] * CIN + chb + a_chs[i] : zero;
+      } else {                                           // CIN = 16: two offsets per chunk, the piece decides which
+        int v[A_PER], ch[A_PER];
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+          const int vc = vc0 + a_chs[i];
+          const int sx = vc / CIN;
+          ch[i] = vc - sx * CIN;
+          v[i] = sx < kvol ? Ns[offset_at(sx, kvol, subm) * BM + a_row[i]] : -1;
+        }
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) asrc[i] = v[i] >= 0 ? feat + (size_t)v[i] * CIN + ch[i] : zero;
+      }
+      const float *bsrc[B_PER];
+#pragma unroll
+      for (int i = 0; i < B_PER; ++i) {
+        const int vc = vc0 + b_kk[i];
         const int sx = vc / CIN, ch = vc - sx * CIN;
-        int v = -1;
-        if (sx < kvol) v = Ns[offset_at(sx, kvol, subm) * BM + row];
-        const float *src = v >= 0 ? feat + (size_t)v * CIN + ch : zero;
-        conv_glds16(src, conv_lds_addr(As + g * 256));
+        bsrc[i] = sx < kvol ? W + ((size_t)offset_at(sx, kvol, subm) * CIN + ch) * cout + b_col[i] : zero;
       }
 #pragma unroll
-      for (int i = 0; i < B_INSTR / NW; ++i) {
-        const int g = wave * (B_INSTR / NW) + i;
-        constexpr int LPR = BN / 4;                                  // lanes per W row
-        const int kk = g * B_ROWS_PER + lane / LPR, pcol = lane % LPR;
-        const int lcol = pcol ^ (((kk >> 2) & 1) << 3);
-        const int vc = j * KC + kk;
-        const int sx = vc / CIN, ch = vc - sx * CIN;
-        const float *src = sx < kvol ? W + ((size_t)offset_at(sx, kvol, subm) * CIN + ch) * cout + col0 + (lcol << 2) : zero;
-        conv_glds16(src, conv_lds_addr(Bs + g * 256));
-      }
+      for (int i = 0; i < A_PER; ++i) conv_glds16(asrc[i], conv_lds_addr(As + (wave * A_PER + i) * 256));
+#pragma unroll
+      for (int i = 0; i < B_PER; ++i) conv_glds16(bsrc[i], conv_lds_addr(Bs + (wave * B_PER + i) * 256));
     };
+    // offsets under which at least one of THIS WAVE's 32 rows has a neighbour (wave-level skip of a chunk's MFMA block)
+    unsigned wmask = 0;
+    for (int k = 0; k < kvol; ++k)
+      if ((kmask >> k) & 1u) wmask |= (__ballot(Ns[k * BM + wr * 32 + r] >= 0) != 0ull ? 1u : 0u) << k;
+    wmask = __builtin_amdgcn_readfirstlane(wmask);
 
     f32x16 acc[NT];
 #pragma unroll
@@ -610,20 +674,32 @@ __global__ __launch_bounds__(64 * WR * WCW, 2) void k_sparse_conv_dma(
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
     int j = next_used(j_begin), cur = 0;
+    CONV_STAMP(1);
     if (j < nchunks) issue(j, 0);
+    bool first_chunk = true;
+#ifdef DCL_CONV_STAMPS
+    unsigned long long ph_wait = 0, ph_bar = 0, ph_issue = 0, ph_mfma = 0, ph_t = __builtin_amdgcn_s_memtime(), ph_n = 0;
+#define PH(acc) do { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); acc += t__ - ph_t; ph_t = t__; } while (0)
+#else
+#define PH(acc) do { } while (0)
+#endif
     while (j < nchunks) {
       __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this wave's DMA pieces of chunk j have landed
+      PH(ph_wait);
       __syncthreads();                                   // ... everyone's have, and stage cur^1 has no reader left
+      PH(ph_bar);
+      if (first_chunk) { CONV_STAMP(2); first_chunk = false; }
       const int jn = next_used(j + 1);
       if (jn < nchunks) issue(jn, cur ^ 1);
+      PH(ph_issue);
       // wave-level skip: none of this wave's 32 rows has a neighbour under any offset of the chunk
       bool mine = false;
       {
         const int s_lo = (j * KC) / CIN, s_hi = (j * KC + KC - 1) / CIN;
         for (int sx = s_lo; sx <= s_hi; ++sx)
-          if (sx < kvol) mine |= Ns[offset_at(sx, kvol, subm) * BM + wr * 32 + r] >= 0;
+          if (sx < kvol) mine |= ((wmask >> offset_at(sx, kvol, subm)) & 1u) != 0;
       }
-      if (__ballot(mine) != 0ull) {
+      if (mine) {
         const float *arow = conv_lds + cur * ST + (wr * 32 + r) * KC;
         const float *bcol = nullptr;
         const int sw = (r >> 1) & 7;
@@ -637,15 +713,109 @@ __global__ __launch_bounds__(64 * WR * WCW, 2) void k_sparse_conv_dma(
           for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-              const float bv = conv_lds[cur * ST + AT + (8 * i + 4 * h + q) * BN + ((wc * 32 * NT + 32 * t + r) ^ (32 * h))];
+              const float bv = conv_lds[cur * ST + AT + (8 * i + 4 * h + q) * BN + ((wc * 32 * NT + 32 * t + r) ^ (BSWZ * 32 * h))];
               acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv, acc[t], 0, 0, 0);
             }
         }
         (void)bcol;
       }
       asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // MFMA -> VALU hazard pad (see k_sparse_conv_lds)
+      PH(ph_mfma);
+#ifdef DCL_CONV_STAMPS
+      ++ph_n;
+#endif
       j = jn;
       cur ^= 1;
+    }
+#ifdef DCL_CONV_STAMPS
+    {
+      const int wg__ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+      if (threadIdx.x == 0 && wg__ < kStampWgs) {
+        g_conv_phase[wg__ * 8 + 0] = ph_wait; g_conv_phase[wg__ * 8 + 1] = ph_bar; g_conv_phase[wg__ * 8 + 2] = ph_issue;
+        g_conv_phase[wg__ * 8 + 3] = ph_mfma; g_conv_phase[wg__ * 8 + 4] = ph_n;
+      }
+    }
+#endif
+    CONV_STAMP(3);
+    if (nsplit > 1 && tile_counters != nullptr) {
+      // ---- in-launch combine (last arriver).  Publish: write-through (sc1) stores of this split's partial tile, every
+      // storing wave drains them, workgroup barrier, ONE lane takes the tile's ticket.  The workgroup that draws the last
+      // ticket acquires (agent scope), re-reads ALL partials with plain loads and adds them in split order -- the same
+      // order, hence the same bits, as k_conv_split_reduce -- then the epilogue.  The counter is left at zero.
+      // partial tiles live in FRAGMENT order -- [split][tile][wave][t][e/4][lane] float4, i.e. every lane stores and later
+      // re-reads its own accumulator registers as 16-B pieces, 1 KiB contiguous per wave instruction -- whole rows of the
+      // tile, padding rows included (the scratch is sized for row tiles, not rows)
+      const size_t tile_f4 = (size_t)NW * NT * 4 * 64;
+      const size_t ntiles = (size_t)nblk * gridDim.y;
+      f32x4 *mine = reinterpret_cast<f32x4 *>(partial) + ((size_t)blockIdx.z * ntiles + (size_t)blk * gridDim.y + by) * tile_f4 +
+                    (size_t)wave * NT * 4 * 64 + lane;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v;
+          v.x = acc[t][4 * q]; v.y = acc[t][4 * q + 1]; v.z = acc[t][4 * q + 2]; v.w = acc[t][4 * q + 3];
+          conv_store16_wt(mine + (t * 4 + q) * 64, v);
+        }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      CONV_STAMP(4);
+      if (tid == 0) {
+        int32_t *ctr = tile_counters + (size_t)blk * gridDim.y + by;
+        const int old = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned last = old == nsplit - 1 ? 1u : 0u;
+        if (last) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_kmask[1] = last;
+      }
+      __syncthreads();
+      CONV_STAMP(5);
+      if (s_kmask[1]) {
+        // split-major: the NT*4 pieces of one split are independent loads in flight together; per element the sum is
+        // P_0 + P_1 + ... in split order
+        const f32x4 *base = reinterpret_cast<const f32x4 *>(partial) + ((size_t)blk * gridDim.y + by) * tile_f4 +
+                            (size_t)wave * NT * 4 * 64 + lane;
+        for (int z = 0; z < nsplit; ++z) {
+          const f32x4 *pz = base + (size_t)z * ntiles * tile_f4;
+          f32x4 v[NT * 4];
+#pragma unroll
+          for (int i = 0; i < NT * 4; ++i) v[i] = pz[i * 64];
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const f32x4 w = v[t * 4 + q];
+              if (z == 0) {
+                acc[t][4 * q] = w.x; acc[t][4 * q + 1] = w.y; acc[t][4 * q + 2] = w.z; acc[t][4 * q + 3] = w.w;
+              } else {
+                acc[t][4 * q] = acc[t][4 * q] + w.x; acc[t][4 * q + 1] = acc[t][4 * q + 1] + w.y;
+                acc[t][4 * q + 2] = acc[t][4 * q + 2] + w.z; acc[t][4 * q + 3] = acc[t][4 * q + 3] + w.w;
+              }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int co = col0 + wc * 32 * NT + 32 * t + r;
+          const float sc = scale ? scale[co] : 1.0f;
+          const float sh = scale ? shift[co] : 0.0f;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int orow = row0 + wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (orow < n) {
+              float x = acc[t][e];
+              if (scale) x = x * sc + sh;
+              if (relu) x = fmaxf(x, 0.0f);
+              out[(size_t)orow * cout + co] = x;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      CONV_STAMP(6);
+      continue;
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -702,37 +872,80 @@ static int conv_split_cap(long long rows) { return rows <= kConvFewRows ? 27 : k
 constexpr int kConvFewRowsCap = 65536;
 static bool conv_few_rows(int rows, bool capacity_mode) { return capacity_mode ? rows <= kConvFewRowsCap : rows <= kConvFewRows; }
 static std::atomic<int> g_conv_xcd_remap{1};       // tuning hook: 0 = plain blockIdx order
-static std::atomic<int> g_conv_split{0};           // tuning hook: 0 = automatic, n = force n-way split-K when scratch allows, -1 = never more than kConvMaxSplit
+static std::atomic<int> g_conv_split{0};           // tuning hook: 0 = automatic, n = force n-way split-K when scratch allows, -1 = never more than kConvMaxSplit, -2 = never split
 
 template <int CIN, int WR, int WCW, int NT>
 static void launch_conv_dma(int rows, const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev,
                             int n_out_host, const float *W, int cout, int kvol, int subm, const float *scale,
                             const float *shift, int relu, float *out, float *scratch, long long scratch_floats,
-                            hipStream_t s) {
+                            int counters_ready, hipStream_t s) {
   constexpr int BM = 32 * WR, BN = 32 * NT * WCW, KC = 32;
   const size_t lds = (size_t)(2 * (BM * KC + KC * BN) + 27 * BM + 4) * sizeof(float);
   (void)hipFuncSetAttribute((const void *)k_sparse_conv_dma<CIN, WR, WCW, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
   const int nblk = dcl_div_up(rows, BM);
   const int tiles = nblk * (cout / BN);
-  // split-K until ~4 workgroups per CU are in the grid (2 resident + 2 waiting), each split keeping >= 8 chunks; a
-  // handful of crops (one-image calls) is latency-bound on the chunk loop instead: split down to 4 chunks per workgroup
+#ifdef DCL_CONV_STAMPS
+  {
+    int occ = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_sparse_conv_dma<CIN, WR, WCW, NT>, 64 * WR * WCW, lds);
+    fprintf(stderr, "k_sparse_conv_dma<%d,%d,%d,%d>: dynamic LDS %zu B, occupancy API says %d workgroups per CU\n", CIN, WR, WCW, NT, lds, occ);
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, (const void *)k_sparse_conv_dma<CIN, WR, WCW, NT>) == hipSuccess)
+      fprintf(stderr, "  numRegs %d sharedSizeBytes %zu maxThreadsPerBlock %d maxDynamicSharedSizeBytes %d\n", fa.numRegs,
+              fa.sharedSizeBytes, fa.maxThreadsPerBlock, fa.maxDynamicSharedSizeBytes);
+    for (size_t l : {(size_t)16384, (size_t)32768, (size_t)49152, (size_t)65536, (size_t)73728, (size_t)77824, (size_t)79376, (size_t)81920}) {
+      for (int thr : {256, 512}) {
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_sparse_conv_dma<CIN, WR, WCW, NT>, thr, l);
+        fprintf(stderr, "  lds %zu threads %d -> %d;", l, thr, occ);
+      }
+      fprintf(stderr, "\n");
+    }
+  }
+#endif
+  // split-K: layers whose row tiles alone cannot fill the GPU split the 27*Cin contraction over blockIdx.z.  The split
+  // count minimises (rounds of workgroups over the 2 x 256 resident slots) x (chunks per workgroup + a fixed per-workgroup
+  // cost of ~3 chunks: neighbour table, first operand fetch, partial-tile publish): e.g. 204 tiles x 108 chunks take 5
+  // splits (1020 workgroups = 2 full rounds of 22 chunks), not 6 (3 rounds of 18).  A handful of crops (one-image calls)
+  // is latency-bound on the chunk loop instead: split down to 4 chunks per workgroup.
   const int nchunks = dcl_div_up(kvol * CIN, KC);
   int nsplit = 1;
-  if (scratch) {
+  int32_t *counters = nullptr;
+  float *partial = scratch;
+  if (scratch && scratch_floats > kConvCounterWords) {
+    const long long part_floats = scratch_floats - kConvCounterWords;
+    partial = scratch + kConvCounterWords;
     const bool few_rows = conv_few_rows(rows, n_out_dev != nullptr) && g_conv_split >= 0;
-    nsplit = g_conv_split > 0 ? g_conv_split.load() : (n_out_dev && few_rows ? 27 : dcl_div_up(1024, tiles));
-    const int most = few_rows ? conv_split_cap(rows) : kConvMaxSplit;
-    if (nsplit > most) nsplit = most;
-    if (nsplit > nchunks / (few_rows ? 4 : 8)) nsplit = nchunks / (few_rows ? 4 : 8);
-    while (nsplit > 1 && (long long)nsplit * cap * cout > scratch_floats) --nsplit;
-    if (nsplit < 1) nsplit = 1;
+    const bool never = g_conv_split == -2;
+    const int most0 = few_rows ? conv_split_cap(rows) : kConvMaxSplit;
+    int most = most0 < nchunks / (few_rows ? 4 : 8) ? most0 : nchunks / (few_rows ? 4 : 8);
+    const long long rows_pad = (long long)nblk * BM;              // partial tiles are whole row tiles
+    while (most > 1 && (long long)most * (rows_pad > cap ? rows_pad : cap) * cout > part_floats) --most;
+    if (most < 1) most = 1;
+    if (g_conv_split > 0) {
+      nsplit = g_conv_split.load() < most ? g_conv_split.load() : most;
+    } else if (never) {
+      nsplit = 1;
+    } else if (n_out_dev && few_rows) {
+      nsplit = most;
+    } else if (tiles < 1024) {
+      long long best = -1;
+      for (int ns = 1; ns <= most; ++ns) {
+        const long long rounds = dcl_div_up((long long)tiles * ns, 512);
+        const long long cost = rounds * (dcl_div_up(nchunks, ns) + 3) * 16 + ns;      // + ns: prefer fewer splits on ties
+        if (best < 0 || cost < best) { best = cost; nsplit = ns; }
+      }
+    }
+    if (nsplit > 1 && tiles <= kConvCounterWords) {
+      counters = reinterpret_cast<int32_t *>(scratch);
+      if (!counters_ready) dcl_internal_zero_words(counters, kConvCounterWords, s);
+    }
   }
   hipLaunchKernelGGL((k_sparse_conv_dma<CIN, WR, WCW, NT>), dim3(nblk < 65535 ? nblk : 65535, cout / BN, nsplit),
                      dim3(64 * WR * WCW), lds, s, feat, nbr, cap, n_out_dev, n_out_host, W, cout, kvol, subm, scale, shift,
-                     relu, out, scratch, nsplit, g_conv_xcd_remap);
-  if (nsplit > 1)
-    hipLaunchKernelGGL(k_conv_split_reduce, dim3(dcl_grid_1d((long long)rows * (cout / 4), 256)), dim3(256), 0, s, scratch,
+                     relu, out, partial, nsplit, g_conv_xcd_remap, counters);
+  if (nsplit > 1 && counters == nullptr)
+    hipLaunchKernelGGL(k_conv_split_reduce, dim3(dcl_grid_1d((long long)rows * (cout / 4), 256)), dim3(256), 0, s, partial,
                        nsplit, cap, n_out_dev, n_out_host, cout, scale, shift, relu, out);
 }
 
@@ -740,7 +953,10 @@ template <int CIN, int WC, int KC>
 static void launch_conv_tile(int rows, const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev,
                              int n_out_host, const float *W, int cout, int kvol, int subm, const float *scale,
                              const float *shift, int relu, float *out, float *scratch, long long scratch_floats,
-                             hipStream_t s) {
+                             int counters_ready, hipStream_t s) {
+  (void)counters_ready;
+  if (scratch && scratch_floats > kConvCounterWords) { scratch += kConvCounterWords; scratch_floats -= kConvCounterWords; }
+  else scratch = nullptr;
   constexpr int WR = 4 / WC, BM = 32 * WR, BN = 32 * WC;
   const size_t lds = (size_t)(BM * (KC + 4) + KC * BN + 27 * BM) * sizeof(float);
   (void)hipFuncSetAttribute((const void *)k_sparse_conv_tile<CIN, WC, KC>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -833,6 +1049,18 @@ static std::atomic<int> g_force_valu{0};   // test hook: 1 = plain VALU kernel f
 DCL_API void dcl_debug_force_valu_conv(int on) { g_force_valu = on; }
 
 DCL_API void dcl_debug_conv_split(int n) { g_conv_split = n; }
+#ifdef DCL_CONV_STAMPS
+extern "C" __attribute__((visibility("default"))) int dcl_debug_conv_stamps(unsigned long long *host, int n_wg, int clear) {
+  if (clear) {
+    static unsigned long long zeros[kStampWgs * 8];
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_conv_stamps), zeros, sizeof(zeros));
+  }
+  if (n_wg > kStampWgs) n_wg = kStampWgs;
+  if (clear == 0 && n_wg < 0)
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_conv_phase), sizeof(unsigned long long) * 8 * (-n_wg));
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_conv_stamps), sizeof(unsigned long long) * 8 * n_wg);
+}
+#endif
 DCL_API void dcl_debug_conv_xcd_remap(int on) { g_conv_xcd_remap = on; }
 
 // most K-splits a conv launch over `rows` output rows may use (sizes the partial-sum scratch; backbone.hip)
@@ -840,7 +1068,7 @@ int dcl_internal_conv_split_cap(long long rows) { return conv_split_cap(rows); }
 
 DCL_API int dcl_sparse_conv_scratch_floats(int rows_cap, int cout, int64_t *floats_host) {
   DCL_CHECK_ARG(rows_cap >= 0 && cout > 0 && floats_host);
-  *floats_host = (int64_t)conv_split_cap(rows_cap) * rows_cap * cout;
+  *floats_host = (int64_t)conv_split_cap(rows_cap) * (((int64_t)rows_cap + 127) / 128 * 128) * cout + kConvCounterWords;
   return 0;
 }
 
@@ -900,13 +1128,14 @@ DCL_API int dcl_profile_conv_end(double *ms_total_host, int32_t *calls_host) {
 
 static int conv_dispatch(const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev, int n_out_host,
                          const float *W, int cin, int cout, int kvol, int subm, const float *scale, const float *shift,
-                         int relu, float *out, float *scratch, int64_t scratch_floats, dclStream_t stream);
+                         int relu, float *out, float *scratch, int64_t scratch_floats, int counters_ready,
+                         dclStream_t stream);
 
 // library-internal: `nbr` may be an implicit rulebook (native backbone runner)
 int dcl_internal_sparse_conv_fwd(const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev,
                                  int n_out_host, const float *W, int cin, int cout, int kvol, int subm, const float *scale,
                                  const float *shift, int relu, float *out, float *scratch, int64_t scratch_floats,
-                                 dclStream_t stream) {
+                                 dclStream_t stream, int counters_ready) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   bool timed = false;
   {
@@ -919,7 +1148,7 @@ int dcl_internal_sparse_conv_fwd(const float *feat, const DclNbrSrc &nbr, int ca
     (void)hipEventRecord(e0, (hipStream_t)stream);
   }
   const int rc = conv_dispatch(feat, nbr, cap, n_out_dev, n_out_host, W, cin, cout, kvol, subm, scale, shift, relu, out,
-                               scratch, scratch_floats, stream);
+                               scratch, scratch_floats, counters_ready, stream);
   if (timed) {
     (void)hipEventRecord(e1, (hipStream_t)stream);
     std::lock_guard<std::mutex> lock(g_conv_prof.mu);
@@ -930,7 +1159,8 @@ int dcl_internal_sparse_conv_fwd(const float *feat, const DclNbrSrc &nbr, int ca
 
 static int conv_dispatch(const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev, int n_out_host,
                          const float *W, int cin, int cout, int kvol, int subm, const float *scale, const float *shift,
-                         int relu, float *out, float *scratch, int64_t scratch_floats, dclStream_t stream) {
+                         int relu, float *out, float *scratch, int64_t scratch_floats, int counters_ready,
+                         dclStream_t stream) {
   DCL_CHECK_ARG(feat && (nbr.nbr || (nbr.out_indices && nbr.in_mask && nbr.in_wprefix && kvol == 27)) && W && out && cap > 0 &&
                 cin > 0 && cout > 0 && kvol > 0 && kvol <= 27);
   DCL_CHECK_ARG((scale == nullptr) == (shift == nullptr));
@@ -943,10 +1173,24 @@ static int conv_dispatch(const float *feat, const DclNbrSrc &nbr, int cap, const
   if (lds_ok && g_force_valu != 3) {
     // implicit-GEMM tile kernel: 64x64 tiles (KC=128) when Cout allows, else 128x32 tiles (KC=64)
 #define TILE_ARGS rows, feat, nbr, cap, n_out_dev, n_out_host, W, cout, kvol, subm, scale, shift, relu, out, scratch, \
-                  (long long)scratch_floats, s
+                  (long long)scratch_floats, counters_ready, s
 #define DMA_ARGS rows, feat, nbr, cap, n_out_dev, n_out_host, W, cout, kvol, subm, scale, shift, relu, out, scratch, \
-                 (long long)scratch_floats, s
-    if (cout % 128 == 0 && g_force_valu != 4) {
+                 (long long)scratch_floats, counters_ready, s
+    if (g_force_valu == 5 && cout % 128 != 0 && cout % 64 == 0) {          // A/B: 8 waves of 32x32 on 128x64 tiles
+      switch (cin) {
+        case 16: launch_conv_dma<16, 4, 2, 1>(DMA_ARGS); break;
+        case 32: launch_conv_dma<32, 4, 2, 1>(DMA_ARGS); break;
+        case 64: launch_conv_dma<64, 4, 2, 1>(DMA_ARGS); break;
+        default: launch_conv_dma<128, 4, 2, 1>(DMA_ARGS); break;
+      }
+    } else if (g_force_valu == 5 && cout % 64 != 0) {                       // A/B: LDS-DMA kernel on 128x32 tiles
+      switch (cin) {
+        case 16: launch_conv_dma<16, 4, 1, 1>(DMA_ARGS); break;
+        case 32: launch_conv_dma<32, 4, 1, 1>(DMA_ARGS); break;
+        case 64: launch_conv_dma<64, 4, 1, 1>(DMA_ARGS); break;
+        default: launch_conv_dma<128, 4, 1, 1>(DMA_ARGS); break;
+      }
+    } else if (cout % 128 == 0 && g_force_valu != 4) {
       switch (cin) {
         case 16: launch_conv_dma<16, 4, 2, 2>(DMA_ARGS); break;
         case 32: launch_conv_dma<32, 4, 2, 2>(DMA_ARGS); break;

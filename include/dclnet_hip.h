@@ -410,7 +410,8 @@ void dcl_debug_attention_xcd_remap(int on);
 /* Test hook, 3-NN of the point read-out: 1 (default) = grid-pruned search on the 32^3 / 16^3 levels, 0 = per-crop scan on
  * every level, 2 = grid kernel with its scan fallback forced for every query (all three give identical results). */
 void dcl_debug_three_nn_grid(int mode);
-/* Tuning hook: 0 = automatic split-K choice in dcl_sparse_conv_fwd_ws, n = force n splits (when the scratch allows). */
+/* Tuning hook: 0 = automatic split-K choice in dcl_sparse_conv_fwd_ws, n = force n splits (when the scratch allows),
+ * -1 = at most 8 splits even for few-row launches, -2 = never split. */
 void dcl_debug_conv_split(int n);
 /* Tuning hook: 1 (default) = the LDS-DMA conv kernel renumbers its workgroups XCD-aware (column tiles of a row tile and
  * neighbouring row tiles share an L2), 0 = plain blockIdx order. */

@@ -30,6 +30,20 @@
 #include <string.h>
 
 #define ORC_API __attribute__((visibility("default")))
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+/* threads of the row loops marked `omp parallel for` (bench.py's cpu_baseline leg sets the usable host cores; the
+ * results do not depend on it: no reduction crosses threads) */
+ORC_API int orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}
 
 static inline float dist2f(float ax, float ay, float az, float bx, float by, float bz) {
     float dx = ax - bx, dy = ay - by, dz = az - bz;

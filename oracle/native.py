@@ -34,6 +34,11 @@ def lib():
     return _LIB
 
 
+def set_num_threads(n):
+    """threads of the C kernels' OpenMP row loops; returns the count in effect"""
+    return int(lib().orc_set_num_threads(int(n)))
+
+
 def ref_lib():
     """The reference's own geometry.h build (oracle/_ref), or None if absent."""
     global _REF
