@@ -594,14 +594,27 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
     if (lane == 0 && mymask) atomicOr(s_kmask, mymask);
     __syncthreads();
     const unsigned kmask = *s_kmask;
-    auto chunk_used = [&](int j) {
-      const int s_lo = (j * KC) / CIN, s_hi = (j * KC + KC - 1) / CIN;
-      unsigned m = 0;
-      for (int sx = s_lo; sx <= s_hi; ++sx)
-        if (sx < kvol) m |= (kmask >> offset_at(sx, kvol, subm)) & 1u;
-      return m != 0;
+    // ---- chunk control, scalar-light.  Steps (= kernel offsets in visiting order, offset_at) own CPK = CIN/KC chunks
+    // each, or a chunk spans SPC = KC/CIN steps (CIN = 16).  `smask` marks the steps whose offset has a neighbour in this
+    // tile, `wsmask` those with one among this wave's 32 rows; the next used chunk is a find-first-set away.
+    constexpr int CPK = CIN >= KC ? CIN / KC : 1, SPC = CIN >= KC ? 1 : KC / CIN;
+    unsigned smask = 0;
+    for (int sx = 0; sx < kvol; ++sx) smask |= ((kmask >> offset_at(sx, kvol, subm)) & 1u) << sx;
+    auto next_used = [&](int from) -> int {            // smallest used chunk >= from (or nchunks)
+      if (from >= nchunks) return nchunks;
+      if constexpr (SPC == 1) {
+        const int sx = from / CPK;
+        if ((smask >> sx) & 1u) return from;
+        const unsigned rest = sx + 1 < 32 ? (smask >> (sx + 1)) << (sx + 1) : 0u;
+        if (!rest) return nchunks;
+        const int q = __builtin_ctz(rest) * CPK;
+        return q < nchunks ? q : nchunks;
+      } else {
+        for (int q = from; q < nchunks; ++q)
+          if ((smask >> (q * SPC)) & ((1u << SPC) - 1u)) return q;
+        return nchunks;
+      }
     };
-    auto next_used = [&](int from) { int q = from; while (q < nchunks && !chunk_used(q)) ++q; return q; };
 
     // A row = 32 floats = 8 blocks of 16 B, block c of row q stored at c ^ ((q >> 1) & 7): 16 consecutive rows read with
     // ds_read_b128 then cover all 64 banks once.  W row kk with bit 2 set swaps its 32-float halves (the two lane
@@ -612,7 +625,7 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
     // wait) and only then the DMAs go out -- an asm statement with a memory clobber between two LDS reads would serialise
     // read -> wait -> DMA per piece.
     constexpr int A_PER = A_INSTR / NW, B_PER = B_INSTR / NW, LPR = BN / 4;
-    int a_row[A_PER], a_chs[A_PER], b_kk[B_PER], b_col[B_PER];
+    int a_row[A_PER], a_chs[A_PER], b_kk[B_PER], b_off[B_PER];
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
       const int g = wave * A_PER + i;
@@ -624,49 +637,59 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
       const int g = wave * B_PER + i;
       b_kk[i] = g * B_ROWS_PER + lane / LPR;
       const int pcol = lane % LPR;
-      b_col[i] = col0 + ((BSWZ ? pcol ^ (((b_kk[i] >> 2) & 1) << 3) : pcol) << 2);
+      const int bcol = col0 + ((BSWZ ? pcol ^ (((b_kk[i] >> 2) & 1) << 3) : pcol) << 2);
+      b_off[i] = (CIN >= KC ? b_kk[i] : (b_kk[i] % CIN)) * cout + bcol;      // W row inside the chunk's offset, column piece
     }
-    auto issue = [&](int j, int stage) {
-      float *As = conv_lds + stage * ST, *Bs = As + AT;
-      const int vc0 = j * KC;
-      const float *asrc[A_PER];
-      if constexpr (CIN >= KC) {                         // the chunk lies inside ONE kernel offset: uniform k and channel base
-        const int sx = vc0 / CIN, chb = vc0 - sx * CIN;
+    // prep(j): the global source of every DMA piece of chunk j (registers); fire(p, stage): piece p goes out.
+    constexpr int NPIECE = A_PER + B_PER;
+    const float *psrc[NPIECE];
+    auto prep = [&](int j) {
+      const float **asrc = psrc, **bsrc = psrc + A_PER;
+      if constexpr (SPC == 1) {                          // the chunk lies inside ONE kernel offset: uniform k and channel base
+        const int sx = j / CPK, chb = (j - sx * CPK) * KC;
         const int k = offset_at(sx, kvol, subm);
+        const int32_t *nrow = Ns + k * BM;
         int v[A_PER];
 #pragma unroll
-        for (int i = 0; i < A_PER; ++i) v[i] = Ns[k * BM + a_row[i]];
+        for (int i = 0; i < A_PER; ++i) v[i] = nrow[a_row[i]];
+        const float *wbase = W + ((size_t)k * CIN + chb) * cout;
 #pragma unroll
-        for (int i = 0; i < A_PER; ++i) asrc[i] = v[i] >= 0 ? feat + (size_t)v[i] * CIN + chb + a_chs[i] : zero;
-      } else {                                           // CIN = 16: two offsets per chunk, the piece decides which
-        int v[A_PER], ch[A_PER];
+        for (int i = 0; i < B_PER; ++i) bsrc[i] = wbase + b_off[i];
+        const float *fbase = feat + chb;
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) asrc[i] = v[i] >= 0 ? fbase + ((size_t)v[i] * CIN + a_chs[i]) : zero;
+      } else {                                           // CIN = 16: the chunk spans two offsets, the piece decides which
+        const int sx0 = j * SPC;
+        const int k0 = offset_at(sx0, kvol, subm);
+        const bool has1 = sx0 + 1 < kvol;
+        const int k1 = has1 ? offset_at(sx0 + 1, kvol, subm) : k0;
+        int v[A_PER];
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
-          const int vc = vc0 + a_chs[i];
-          const int sx = vc / CIN;
-          ch[i] = vc - sx * CIN;
-          v[i] = sx < kvol ? Ns[offset_at(sx, kvol, subm) * BM + a_row[i]] : -1;
+          const bool second = a_chs[i] >= CIN;
+          v[i] = Ns[(second ? k1 : k0) * BM + a_row[i]];
+          if (second && !has1) v[i] = -1;
         }
 #pragma unroll
-        for (int i = 0; i < A_PER; ++i) asrc[i] = v[i] >= 0 ? feat + (size_t)v[i] * CIN + ch[i] : zero;
+        for (int i = 0; i < B_PER; ++i) {
+          const bool second = b_kk[i] >= CIN;
+          bsrc[i] = (second && !has1) ? zero : W + (size_t)(second ? k1 : k0) * CIN * cout + b_off[i];
+        }
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) asrc[i] = v[i] >= 0 ? feat + ((size_t)v[i] * CIN + (a_chs[i] & (CIN - 1))) : zero;
       }
-      const float *bsrc[B_PER];
-#pragma unroll
-      for (int i = 0; i < B_PER; ++i) {
-        const int vc = vc0 + b_kk[i];
-        const int sx = vc / CIN, ch = vc - sx * CIN;
-        bsrc[i] = sx < kvol ? W + ((size_t)offset_at(sx, kvol, subm) * CIN + ch) * cout + b_col[i] : zero;
-      }
-#pragma unroll
-      for (int i = 0; i < A_PER; ++i) conv_glds16(asrc[i], conv_lds_addr(As + (wave * A_PER + i) * 256));
-#pragma unroll
-      for (int i = 0; i < B_PER; ++i) conv_glds16(bsrc[i], conv_lds_addr(Bs + (wave * B_PER + i) * 256));
     };
-    // offsets under which at least one of THIS WAVE's 32 rows has a neighbour (wave-level skip of a chunk's MFMA block)
-    unsigned wmask = 0;
-    for (int k = 0; k < kvol; ++k)
-      if ((kmask >> k) & 1u) wmask |= (__ballot(Ns[k * BM + wr * 32 + r] >= 0) != 0ull ? 1u : 0u) << k;
-    wmask = __builtin_amdgcn_readfirstlane(wmask);
+    auto fire = [&](int p, int stage) {                  // p is a compile-time constant at every call site
+      float *As = conv_lds + stage * ST, *Bs = As + AT;
+      if (p < A_PER) conv_glds16(psrc[p], conv_lds_addr(As + (wave * A_PER + p) * 256));
+      else conv_glds16(psrc[p], conv_lds_addr(Bs + (wave * B_PER + (p - A_PER)) * 256));
+    };
+    // steps under which at least one of THIS WAVE's 32 rows has a neighbour (wave-level skip of a chunk's MFMA block)
+    unsigned wsmask = 0;
+    for (int sx = 0; sx < kvol; ++sx)
+      if ((smask >> sx) & 1u)
+        wsmask |= (__ballot(Ns[offset_at(sx, kvol, subm) * BM + wr * 32 + r] >= 0) != 0ull ? 1u : 0u) << sx;
+    wsmask = __builtin_amdgcn_readfirstlane(wsmask);
 
     f32x16 acc[NT];
 #pragma unroll
@@ -675,7 +698,11 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
       for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
     int j = next_used(j_begin), cur = 0;
     CONV_STAMP(1);
-    if (j < nchunks) issue(j, 0);
+    if (j < nchunks) {
+      prep(j);
+#pragma unroll
+      for (int p = 0; p < NPIECE; ++p) fire(p, 0);
+    }
     bool first_chunk = true;
 #ifdef DCL_CONV_STAMPS
     unsigned long long ph_wait = 0, ph_bar = 0, ph_issue = 0, ph_mfma = 0, ph_t = __builtin_amdgcn_s_memtime(), ph_n = 0;
@@ -690,15 +717,14 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
       PH(ph_bar);
       if (first_chunk) { CONV_STAMP(2); first_chunk = false; }
       const int jn = next_used(j + 1);
-      if (jn < nchunks) issue(jn, cur ^ 1);
+      if (jn < nchunks) {                                // (spreading the pieces over the MFMA groups was measured: the wave
+        prep(jn);                                        //  pays the same ~350 cycles per piece there, nothing is hidden)
+#pragma unroll
+        for (int p = 0; p < NPIECE; ++p) fire(p, cur ^ 1);
+      }
       PH(ph_issue);
       // wave-level skip: none of this wave's 32 rows has a neighbour under any offset of the chunk
-      bool mine = false;
-      {
-        const int s_lo = (j * KC) / CIN, s_hi = (j * KC + KC - 1) / CIN;
-        for (int sx = s_lo; sx <= s_hi; ++sx)
-          if (sx < kvol) mine |= ((wmask >> offset_at(sx, kvol, subm)) & 1u) != 0;
-      }
+      const bool mine = SPC == 1 ? ((wsmask >> (j / CPK)) & 1u) != 0 : ((wsmask >> (j * SPC)) & ((1u << SPC) - 1u)) != 0;
       if (mine) {
         const float *arow = conv_lds + cur * ST + (wr * 32 + r) * KC;
         const float *bcol = nullptr;
@@ -778,23 +804,34 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
         // P_0 + P_1 + ... in split order
         const f32x4 *base = reinterpret_cast<const f32x4 *>(partial) + ((size_t)blk * gridDim.y + by) * tile_f4 +
                             (size_t)wave * NT * 4 * 64 + lane;
-        for (int z = 0; z < nsplit; ++z) {
-          const f32x4 *pz = base + (size_t)z * ntiles * tile_f4;
-          f32x4 v[NT * 4];
+        // ZU splits' pieces are in flight together (few-row launches split up to 27 ways: one split per load latency
+        // would make the combine the longest phase of the launch); the adds stay in split order
+        constexpr int ZU = NT == 2 ? 2 : 4;
+        for (int z0 = 0; z0 < nsplit; z0 += ZU) {
+          f32x4 v[ZU][NT * 4];
 #pragma unroll
-          for (int i = 0; i < NT * 4; ++i) v[i] = pz[i * 64];
+          for (int u = 0; u < ZU; ++u) {
+            const int zc = z0 + u < nsplit ? z0 + u : nsplit - 1;            // clamped: loaded, not added
+            const f32x4 *pz = base + (size_t)zc * ntiles * tile_f4;
 #pragma unroll
-          for (int t = 0; t < NT; ++t)
+            for (int i = 0; i < NT * 4; ++i) v[u][i] = pz[i * 64];
+          }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const f32x4 w = v[t * 4 + q];
-              if (z == 0) {
-                acc[t][4 * q] = w.x; acc[t][4 * q + 1] = w.y; acc[t][4 * q + 2] = w.z; acc[t][4 * q + 3] = w.w;
-              } else {
-                acc[t][4 * q] = acc[t][4 * q] + w.x; acc[t][4 * q + 1] = acc[t][4 * q + 1] + w.y;
-                acc[t][4 * q + 2] = acc[t][4 * q + 2] + w.z; acc[t][4 * q + 3] = acc[t][4 * q + 3] + w.w;
+          for (int u = 0; u < ZU; ++u) {
+            if (z0 + u >= nsplit) break;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const f32x4 w = v[u][t * 4 + q];
+                if (z0 + u == 0) {
+                  acc[t][4 * q] = w.x; acc[t][4 * q + 1] = w.y; acc[t][4 * q + 2] = w.z; acc[t][4 * q + 3] = w.w;
+                } else {
+                  acc[t][4 * q] = acc[t][4 * q] + w.x; acc[t][4 * q + 1] = acc[t][4 * q + 1] + w.y;
+                  acc[t][4 * q + 2] = acc[t][4 * q + 2] + w.z; acc[t][4 * q + 3] = acc[t][4 * q + 3] + w.w;
+                }
               }
-            }
+          }
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -995,6 +1032,7 @@ __global__ __launch_bounds__(256) void k_sparse_avgpool(const float *__restrict_
   const int rr = tid / c4, q = tid - rr * c4;
   for (int row0 = blockIdx.x * rpb; row0 < n; row0 += gridDim.x * rpb) {
     __syncthreads();
+#pragma unroll 4                                           // the lookups of up to 4 rounds in flight together (2 dependent loads each)
     for (int e = tid; e < rpb * kvol; e += 256) {
       const int r2 = e / kvol, k = e - r2 * kvol;
       s_v[r2 * 27 + k] = row0 + r2 < n ? dcl_nbr_at(src, cap, k, row0 + r2) : -1;
@@ -1183,7 +1221,7 @@ static int conv_dispatch(const float *feat, const DclNbrSrc &nbr, int cap, const
         case 64: launch_conv_dma<64, 4, 2, 1>(DMA_ARGS); break;
         default: launch_conv_dma<128, 4, 2, 1>(DMA_ARGS); break;
       }
-    } else if (g_force_valu == 5 && cout % 64 != 0) {                       // A/B: LDS-DMA kernel on 128x32 tiles
+    } else if (g_force_valu != 4 && cout % 64 != 0) {                       // Cout = 32: LDS-DMA kernel on 128x32 tiles
       switch (cin) {
         case 16: launch_conv_dma<16, 4, 1, 1>(DMA_ARGS); break;
         case 32: launch_conv_dma<32, 4, 1, 1>(DMA_ARGS); break;

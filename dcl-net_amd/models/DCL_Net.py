@@ -32,6 +32,7 @@ from .losses import losses  # noqa: F401  (reference: models/DCL_Net.py::losses)
 from .Modules import (Aligner, Backbone_SPCONV, BasicBlock_3DCONV, Head_MultiLayerPerceptron,
                       Ops_GetPointFeat_spconv)
 
+HOST_TIMES = None                   # tools/host_timeline.py sets this to a list: (label, perf_counter) marks of _forward_fused
 SCALE_LISTS = [2, 4, 6, 8]          # sic -- reference models/DCL_Net.py:54 (true strides are 2,4,8,16)
 VOXEL_NUM_LIMIT = [64, 64, 64]
 
@@ -219,6 +220,9 @@ class Network(nn.Module):
         return max(k, 1)
 
     def _forward_fused(self, data):
+        import time as _t
+        mark = (lambda lbl: HOST_TIMES.append((lbl, _t.perf_counter()))) if HOST_TIMES is not None else (lambda lbl: None)
+        mark("start")
         f = self._fold()
         dev = self.regressor_rot.layers[0].weight.device
         if dev.type != "cuda":
@@ -251,16 +255,24 @@ class Network(nn.Module):
         rstream = self._side_stream(dev, 2)
         npts = {"inp": self.n_inp, "tmp": self.n_tmp}
         side_in, runs, geo, vox, pb4, pf, pts = {}, {}, {}, {}, {}, {}, {}
-        for s in ("inp", "tmp"):
+        # the geometry of BOTH sides goes out first (it needs the occupied voxels only): the host is the slow party here
+        # (16 launches per side), everything else it has to issue before the read-back then runs underneath the geometry
+        occ = {}
+        counts_all = torch.empty(16 * K, dtype=torch.int32, device=dev)       # [chunk][side][8], one read-back
+        for si, s in enumerate(("inp", "tmp")):
+            with torch.cuda.stream(sstream[s]):
+                occ[s] = data[s]["occupied_voxels"].to(dev, non_blocking=True).int().contiguous()
+                for c in range(K):
+                    runs[s, c] = ops.BackboneRun(occ[s], bc, S, batch_lo=c * bc,
+                                                 counts_dev=counts_all[16 * c + 8 * si:16 * c + 8 * si + 8])
+                geo[s] = torch.cuda.Event()
+                geo[s].record(sstream[s])
+        def stage(s):
+            """what a side's feature pass needs besides the level sizes: voxel means, the points' (crop, xyz) rows, buffers"""
             with torch.cuda.stream(sstream[s]):
                 d = data[s]
                 side_in[s] = (d["feats"].to(dev, non_blocking=True).float().contiguous(),
-                              d["v2p_maps"].to(dev, non_blocking=True).int().contiguous(),
-                              d["occupied_voxels"].to(dev, non_blocking=True).int().contiguous())
-                for c in range(K):
-                    runs[s, c] = ops.BackboneRun(side_in[s][2], bc, S, batch_lo=c * bc)
-                geo[s] = torch.cuda.Event()
-                geo[s].record(sstream[s])
+                              d["v2p_maps"].to(dev, non_blocking=True).int().contiguous(), occ[s])
                 pb4[s] = torch.cat([self._crop_ids(dev, b, bc, npts[s]), side_in[s][0][:, 4:7]], 1)   # (crop in its chunk, xyz)
                 vox[s] = ops.voxelize_fp(side_in[s][0], side_in[s][1], self.voxelization_mode)   # all crops at once
                 pf[s] = torch.empty((b * npts[s], 480), dtype=torch.float32, device=dev)   # read on `main`
@@ -268,9 +280,8 @@ class Network(nn.Module):
                 pf[s].record_stream(main)
                 side_in[s][0].record_stream(main)                      # `pts` below is handed to the caller
             pts[s] = side_in[s][0][:, 4:7].reshape(b, npts[s], 3)
-        act = {}
-        for side, key in (("Xc", "inp"), ("Yo", "tmp")):
-            act.update(self._disengage_buffers(side, b * npts[key], dev))
+        stage("inp")                                                   # runs underneath the geometry
+        mark("geometry issued")
         unit = self.unit_voxel_extent
         assert unit[0] == unit[1] == unit[2], "anisotropic voxels: use fused=False"
         off = float(np.float32(-0.5 * unit[0] * VOXEL_NUM_LIMIT[0]))
@@ -278,12 +289,15 @@ class Network(nn.Module):
         with torch.cuda.stream(rstream):                               # the host waits for the two geometry stages only
             for s in ("inp", "tmp"):
                 rstream.wait_event(geo[s])
-            counts = torch.cat([runs[s, c].counts_dev for c in range(K) for s in ("inp", "tmp")]).cpu().tolist()
+            counts = counts_all.cpu().tolist()
+        mark("counts read back")
         for i, key in enumerate((s, c) for c in range(K) for s in ("inp", "tmp")):
             runs[key[0], key[1]].set_counts(counts[8 * i:8 * i + 8])
         done = {}
         for side, bb in (("inp", "backbone_inp"), ("tmp", "backbone_tmp")):
             n = npts[side]
+            if side == "tmp":
+                stage("tmp")                                           # issued after the observed side's convolutions are out
             with torch.cuda.stream(sstream[side]):
                 for c in range(K):
                     rows = slice(c * bc * n, (c + 1) * bc * n)
@@ -291,6 +305,10 @@ class Network(nn.Module):
                     runs[side, c].point_features(pb4[side][rows], extents, off, out=pf[side][rows])
                     done[side, c] = torch.cuda.Event()
                     done[side, c].record(sstream[side])
+        act = {}
+        for side, key in (("Xc", "inp"), ("Yo", "tmp")):
+            act.update(self._disengage_buffers(side, b * npts[key], dev))
+        mark("sparse issued")
         for c in range(K):                                                     # dense stage 1, chunk by chunk on main
             for side, key in (("Xc", "inp"), ("Yo", "tmp")):
                 main.wait_event(done[key, c])
@@ -299,6 +317,7 @@ class Network(nn.Module):
         for st in sstream.values():
             main.wait_stream(st)
         prediction = self._dense_tail(f, act, b, dev)
+        mark("dense issued")
         if self.mode != "test":
             prediction["sym_flag"] = data["flags"].to(dev)
         data["labels"]["points_tmp"] = pts["tmp"]

@@ -20,16 +20,16 @@ def ortho9d2matrix(x_raw, y_raw, z_raw):
     return _o(x_raw, y_raw, z_raw)
 
 
+_VERSION_OF = __import__("operator").attrgetter("_version")
+
+
 def _param_version(mod):
     """sum of the in-place version counters of every parameter and buffer: changes whenever a weight is rewritten in
     place (optimizer.step(), EMA swaps via p.data.copy_, manual surgery), so caches keyed on it cannot go stale"""
     ts = mod.__dict__.get("_vlist")
     if ts is None:
         ts = mod.__dict__["_vlist"] = list(mod.parameters()) + list(mod.buffers())
-    v = 0
-    for t in ts:
-        v += t._version
-    return v
+    return sum(map(_VERSION_OF, ts))
 
 
 class Refiner(nn.Module):

@@ -259,16 +259,17 @@ def _ptr_array(tensors):
 class BackboneRun(object):
     """State of one backbone pass driven by the native runner (csrc/backbone.hip)."""
 
-    def __init__(self, occ, batch, S, batch_lo=0):
+    def __init__(self, occ, batch, S, batch_lo=0, counts_dev=None):
         """occ (V0,4) i32 [b,x,y,z]; batch_lo > 0 (or batch < number of crops in occ): pass over the crop window
-        batch_lo .. batch_lo+batch-1 only (its crops are re-based to 0)."""
+        batch_lo .. batch_lo+batch-1 only (its crops are re-based to 0).  counts_dev: optional i32[8] slice of a caller's
+        tensor that receives the level sizes (several passes can then be read back with one copy)."""
         N.need_cuda(occ)
         assert occ.dtype == torch.int32 and occ.is_contiguous()
         self.occ, self.batch, self.S, self.V0 = occ, int(batch), int(S), occ.shape[0]
         nbytes = C.c_int64(0)
         N.check(N.lib().dcl_backbone_ws_bytes(self.batch, self.S, self.V0, C.byref(nbytes)), "backbone_ws_bytes")
         self.ws = torch.empty(nbytes.value, dtype=torch.uint8, device=occ.device)
-        self.counts_dev = torch.empty(8, dtype=torch.int32, device=occ.device)
+        self.counts_dev = torch.empty(8, dtype=torch.int32, device=occ.device) if counts_dev is None else counts_dev
         self.chan = (C.c_int32 * 9)(*BACKBONE_CHANNELS)
         N.check(N.lib().dcl_backbone_geometry_window(N.ptr(occ), self.V0, int(batch_lo), self.batch, self.S, N.ptr(self.ws),
                                                      nbytes.value, N.ptr(self.counts_dev), N.stream()),
