@@ -110,16 +110,12 @@ bool make_feat_layout(const int32_t *counts, const int *chan /*9*/, FeatLayout *
     if (np > max_rows) max_rows = np;
     if (nc * chan[2 * m + 1] * 4 > x1) x1 = nc * chan[2 * m + 1] * 4;
     if (nc * chan[2 * m + 2] * 4 > x2) x2 = nc * chan[2 * m + 2] * 4;
-    // split-K scratch of the two convs (only layers with few 128-row tiles split; see launch_conv_dma)
+    // stream-K scratch of the two convs: two partial-tile slots per workgroup of the 512-slot grid (see launch_conv_dma)
     for (int q = 1; q <= 2; ++q) {
       const size_t cout = (size_t)chan[2 * m + q];
       if (cout % 32 != 0 || nc == 0) continue;
-      const size_t tiles = ((nc + 127) / 128) * (cout % 128 == 0 ? cout / 128 : (cout % 64 == 0 ? cout / 64 : cout / 32));
-      size_t split = (1024 + tiles - 1) / tiles;
-      const size_t most = (size_t)dcl_internal_conv_split_cap((long long)nc);
-      if (split > most || nc <= 65536) split = most;      // small passes (and capacity mode) may split all the way
-      const size_t nc_pad = (nc + 127) / 128 * 128;       // partial tiles are whole 128-row tiles
-      if (split > 1 && split * nc_pad * cout > scratch) scratch = split * nc_pad * cout;
+      const size_t need = (size_t)2 * 512 * 128 * (cout < 128 ? cout : 128);
+      if (need > scratch) scratch = need;
     }
   }
   size_t off = 0;

@@ -524,8 +524,8 @@ template <int CIN, int WR, int WCW, int NT>
 __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma(   // 2 workgroups per CU (LDS allows 2)
     const float *__restrict__ feat, const DclNbrSrc src, int cap, const int32_t *__restrict__ n_out_dev,
     int n_out_host, const float *__restrict__ W, int cout, int kvol, int subm, const float *__restrict__ scale,
-    const float *__restrict__ shift, int relu, float *__restrict__ out, float *__restrict__ partial, int nsplit,
-    int xcd_remap, int32_t *__restrict__ tile_counters) {
+    const float *__restrict__ shift, int relu, float *__restrict__ out, float *__restrict__ partial, int stream_k,
+    int aligned_ns, int xcd_remap, int32_t *__restrict__ tile_counters) {
   constexpr int NW = WR * WCW, NTHR = 64 * NW;
   constexpr int BM = 32 * WR, BN = 32 * NT * WCW, KC = 32;
   constexpr int AT = BM * KC, BT = KC * BN, ST = AT + BT;      // floats per stage
@@ -543,30 +543,51 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int wr = wave / WCW, wc = wave % WCW;
+  // Work decomposition ("stream-K").  The launch's work is the sequence of chunk units (tile 0: chunks 0..C-1, tile 1:
+  // ..., tiles numbered column-tile-fastest); workgroup w owns the contiguous units [w*U, (w+1)*U) with U = ceil(total / G)
+  // for the G workgroups of the launch, so every workgroup does the same amount of MFMA work whatever the number of
+  // tiles (no partial last round on the 2 x 256 resident slots, no idle CUs when a deep layer has fewer tiles than
+  // slots).  A workgroup's range covers at most two partial tiles (its first and its last segment) and whole tiles in
+  // between; a partial segment is published to the workgroup's slot 0 / 1 and the tile's ticket is drawn -- the last
+  // arriver adds the tile's segments in ascending chunk order (deterministic) and runs the epilogue.  stream_k == 0:
+  // one whole tile per workgroup (grid-stride), no partials -- or, aligned_ns >= 2, classic split-K: workgroup w owns
+  // segment w % ns of tile w / ns (chunks [seg*C/ns, (seg+1)*C/ns)), the choice when tiles * ns just fills the slots.
   // XCD-aware placement (speed only): workgroup ids are dealt round-robin over the 8 XCDs; renumber so that the
-  // workgroups sharing an XCD (= one L2) hold the column tiles of the same row tile and then neighbouring row tiles,
-  // whose gathered input rows overlap
-  // (only when the grid is exactly the live tiles: in capacity mode the grid is sized by the row capacity and a chunked
-  // numbering would put all live tiles on one XCD)
-  int bx = blockIdx.x, by = blockIdx.y;
-  if (xcd_remap && n_out_dev == nullptr && (n + BM - 1) / BM == (int)gridDim.x) {
-    const int nwg = gridDim.x * gridDim.y, id = blockIdx.x + gridDim.x * blockIdx.y;
-    const int xq = nwg >> 3, xr = nwg & 7, xcd = id & 7;
-    const int swz = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (id >> 3);
-    by = swz % (int)gridDim.y;
-    bx = swz / (int)gridDim.y;
+  // workgroups sharing an XCD (= one L2) hold neighbouring unit ranges (column tiles of a row tile, neighbouring row
+  // tiles, whose gathered input rows overlap) -- not in capacity mode, where the live work occupies the low ids only
+  int wid = blockIdx.x;
+  const int G = gridDim.x;
+  if (xcd_remap && n_out_dev == nullptr) {
+    const int xq = G >> 3, xr = G & 7, xcd = wid & 7;
+    wid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (wid >> 3);
   }
-  const int col0 = by * BN;
-  const int nblk = (n + BM - 1) / BM;
-  // split-K: blockIdx.z owns a contiguous range of chunks and writes raw partial sums (k_conv_split_reduce adds them
-  // in split order and applies the epilogue) -- more workgroups for the deep layers whose row count alone cannot fill the GPU
-  const int nchunks_all = (kvol * CIN + KC - 1) / KC;
-  const int j_begin = (int)((long long)blockIdx.z * nchunks_all / nsplit);
-  const int nchunks = (int)((long long)(blockIdx.z + 1) * nchunks_all / nsplit);
+  const int nblk = (n + BM - 1) / BM, ncol = cout / BN;
+  const int C = (kvol * CIN + KC - 1) / KC;                    // chunks per tile
+  // (32-bit unit arithmetic: tiles * C < 2^31 for every launch the host code makes -- 64-bit divisions would cost
+  // dozens of VGPRs in a kernel that sits at the 128-register limit)
+  const int total = nblk * ncol * C;
+  int U = C, u = wid * C, u_end = total;                       // stream_k == 0: tile wid, wid + G, ...
+  if (aligned_ns) {
+    const int tl = wid / aligned_ns, seg = wid - tl * aligned_ns;
+    u = tl * C + seg * C / aligned_ns;
+    u_end = tl < nblk * ncol ? tl * C + (seg + 1) * C / aligned_ns : u;
+  } else if (stream_k) {
+    U = (total + G - 1) / G;
+    if (U < stream_k) U = stream_k;                            // few rows: at least this many chunks per workgroup
+    u = wid * U;
+    u_end = u + U < total ? u + U : total;
+  }
+  if (u > total) u = total;
   const float *zero = reinterpret_cast<const float *>(&g_conv_zero_line);
 
-  for (int blk = bx; blk < nblk; blk += gridDim.x) {
-    const int row0 = blk * BM;
+  while (u < u_end) {
+    const int tile = u / C;
+    const int j_begin = u - tile * C;
+    const int nchunks = (stream_k || aligned_ns) ? (C < j_begin + (u_end - u) ? C : j_begin + (u_end - u)) : C;   // end chunk of the segment
+    const bool whole = j_begin == 0 && nchunks == C;
+    const int blk = tile / ncol, by = tile - blk * ncol;
+    const int row0 = blk * BM, col0 = by * BN;
+    u += (stream_k || aligned_ns) ? nchunks - j_begin : G * C;
     CONV_STAMP(0);
 #ifdef DCL_CONV_STAMPS
     {
@@ -625,26 +646,31 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
     // wait) and only then the DMAs go out -- an asm statement with a memory clobber between two LDS reads would serialise
     // read -> wait -> DMA per piece.
     constexpr int A_PER = A_INSTR / NW, B_PER = B_INSTR / NW, LPR = BN / 4;
-    int a_row[A_PER], a_chs[A_PER], b_kk[B_PER], b_off[B_PER];
+    // (the lane constants are recomputed per chunk -- a handful of VALU ops -- rather than kept in registers across the
+    // MFMA block: the 8-wave 128x128 variant sits at the 128-VGPR limit of two workgroups per CU)
+    auto lane_consts = [&](int (&a_row)[A_PER], int (&a_chs)[A_PER], int (&b_kk)[B_PER], int (&b_off)[B_PER]) {
 #pragma unroll
-    for (int i = 0; i < A_PER; ++i) {
-      const int g = wave * A_PER + i;
-      a_row[i] = g * 8 + (lane >> 3);
-      a_chs[i] = ((lane & 7) ^ ((a_row[i] >> 1) & 7)) << 2;
-    }
+      for (int i = 0; i < A_PER; ++i) {
+        const int g = wave * A_PER + i;
+        a_row[i] = g * 8 + (lane >> 3);
+        a_chs[i] = ((lane & 7) ^ ((a_row[i] >> 1) & 7)) << 2;
+      }
 #pragma unroll
-    for (int i = 0; i < B_PER; ++i) {
-      const int g = wave * B_PER + i;
-      b_kk[i] = g * B_ROWS_PER + lane / LPR;
-      const int pcol = lane % LPR;
-      const int bcol = col0 + ((BSWZ ? pcol ^ (((b_kk[i] >> 2) & 1) << 3) : pcol) << 2);
-      b_off[i] = (CIN >= KC ? b_kk[i] : (b_kk[i] % CIN)) * cout + bcol;      // W row inside the chunk's offset, column piece
-    }
+      for (int i = 0; i < B_PER; ++i) {
+        const int g = wave * B_PER + i;
+        b_kk[i] = g * B_ROWS_PER + lane / LPR;
+        const int pcol = lane % LPR;
+        const int bcol = col0 + ((BSWZ ? pcol ^ (((b_kk[i] >> 2) & 1) << 3) : pcol) << 2);
+        b_off[i] = (CIN >= KC ? b_kk[i] : (b_kk[i] % CIN)) * cout + bcol;      // W row inside the chunk's offset, column piece
+      }
+    };
     // prep(j): the global source of every DMA piece of chunk j (registers); fire(p, stage): piece p goes out.
     constexpr int NPIECE = A_PER + B_PER;
     const float *psrc[NPIECE];
     auto prep = [&](int j) {
       const float **asrc = psrc, **bsrc = psrc + A_PER;
+      int a_row[A_PER], a_chs[A_PER], b_kk[B_PER], b_off[B_PER];
+      lane_consts(a_row, a_chs, b_kk, b_off);
       if constexpr (SPC == 1) {                          // the chunk lies inside ONE kernel offset: uniform k and channel base
         const int sx = j / CPK, chb = (j - sx * CPK) * KC;
         const int k = offset_at(sx, kvol, subm);
@@ -701,7 +727,7 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
     if (j < nchunks) {
       prep(j);
 #pragma unroll
-      for (int p = 0; p < NPIECE; ++p) fire(p, 0);
+      for (int p = 0; p < NPIECE; ++p) fire((p + A_PER) % NPIECE, 0);       // W pieces first: their sources are ready first
     }
     bool first_chunk = true;
 #ifdef DCL_CONV_STAMPS
@@ -720,7 +746,7 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
       if (jn < nchunks) {                                // (spreading the pieces over the MFMA groups was measured: the wave
         prep(jn);                                        //  pays the same ~350 cycles per piece there, nothing is hidden)
 #pragma unroll
-        for (int p = 0; p < NPIECE; ++p) fire(p, cur ^ 1);
+        for (int p = 0; p < NPIECE; ++p) fire((p + A_PER) % NPIECE, cur ^ 1);
       }
       PH(ph_issue);
       // wave-level skip: none of this wave's 32 rows has a neighbour under any offset of the chunk
@@ -763,7 +789,7 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
     }
 #endif
     CONV_STAMP(3);
-    if (nsplit > 1 && tile_counters != nullptr) {
+    if (!whole) {
       // ---- in-launch combine (last arriver).  Publish: write-through (sc1) stores of this split's partial tile, every
       // storing wave drains them, workgroup barrier, ONE lane takes the tile's ticket.  The workgroup that draws the last
       // ticket acquires (agent scope), re-reads ALL partials with plain loads and adds them in split order -- the same
@@ -772,9 +798,10 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
       // re-reads its own accumulator registers as 16-B pieces, 1 KiB contiguous per wave instruction -- whole rows of the
       // tile, padding rows included (the scratch is sized for row tiles, not rows)
       const size_t tile_f4 = (size_t)NW * NT * 4 * 64;
-      const size_t ntiles = (size_t)nblk * gridDim.y;
-      f32x4 *mine = reinterpret_cast<f32x4 *>(partial) + ((size_t)blockIdx.z * ntiles + (size_t)blk * gridDim.y + by) * tile_f4 +
-                    (size_t)wave * NT * 4 * 64 + lane;
+      // slot of a workgroup's segment of `tile`: 2*w if the tile holds w's first unit, else 2*w + 1
+      // (w * U >= tile * C  <=>  the tile holds w's first unit, for the workgroups w that touch the tile at all)
+      auto slot_of = [&](int w) -> size_t { return (size_t)(2 * w + ((aligned_ns || w * U >= tile * C) ? 0 : 1)); };
+      f32x4 *mine = reinterpret_cast<f32x4 *>(partial) + slot_of(wid) * tile_f4 + (size_t)wave * NT * 4 * 64 + lane;
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -786,10 +813,12 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       CONV_STAMP(4);
+      const int w_first = aligned_ns ? tile * aligned_ns : (tile * C) / U;
+      const int w_last = aligned_ns ? w_first + aligned_ns - 1 : ((tile + 1) * C - 1) / U;
       if (tid == 0) {
-        int32_t *ctr = tile_counters + (size_t)blk * gridDim.y + by;
+        int32_t *ctr = tile_counters + tile;
         const int old = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned last = old == nsplit - 1 ? 1u : 0u;
+        const unsigned last = old == w_last - w_first ? 1u : 0u;
         if (last) {
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -802,35 +831,39 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
       if (s_kmask[1]) {
         // split-major: the NT*4 pieces of one split are independent loads in flight together; per element the sum is
         // P_0 + P_1 + ... in split order
-        const f32x4 *base = reinterpret_cast<const f32x4 *>(partial) + ((size_t)blk * gridDim.y + by) * tile_f4 +
-                            (size_t)wave * NT * 4 * 64 + lane;
-        // ZU splits' pieces are in flight together (few-row launches split up to 27 ways: one split per load latency
-        // would make the combine the longest phase of the launch); the adds stay in split order
-        constexpr int ZU = NT == 2 ? 2 : 4;
-        for (int z0 = 0; z0 < nsplit; z0 += ZU) {
-          f32x4 v[ZU][NT * 4];
+        const f32x4 *base = reinterpret_cast<const f32x4 *>(partial) + (size_t)wave * NT * 4 * 64 + lane;
+        const int nseg = w_last - w_first + 1;
+        // ZU segments' pieces of ONE column tile are in flight together (few-row launches have up to 27 segments per tile:
+        // one segment per load latency would make the combine the longest phase of the launch; both column tiles at once
+        // would not fit the 128 registers of two workgroups per CU); the adds stay in segment order
+        constexpr int ZU = NT == 2 ? 3 : 4;
 #pragma unroll
-          for (int u = 0; u < ZU; ++u) {
-            const int zc = z0 + u < nsplit ? z0 + u : nsplit - 1;            // clamped: loaded, not added
-            const f32x4 *pz = base + (size_t)zc * ntiles * tile_f4;
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll 1
+          for (int z0 = 0; z0 < nseg; z0 += ZU) {
+            asm volatile("" ::: "memory");                                   // keep the next block's loads behind this point
+            f32x4 v[ZU][4];
 #pragma unroll
-            for (int i = 0; i < NT * 4; ++i) v[u][i] = pz[i * 64];
-          }
+            for (int uu = 0; uu < ZU; ++uu) {
+              const int zc = z0 + uu < nseg ? z0 + uu : nseg - 1;            // clamped: loaded, not added
+              const f32x4 *pz = base + slot_of(w_first + zc) * tile_f4 + t * 4 * 64;
 #pragma unroll
-          for (int u = 0; u < ZU; ++u) {
-            if (z0 + u >= nsplit) break;
+              for (int q = 0; q < 4; ++q) v[uu][q] = pz[q * 64];
+            }
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+            for (int uu = 0; uu < ZU; ++uu) {
+              if (z0 + uu >= nseg) break;
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
-                const f32x4 w = v[u][t * 4 + q];
-                if (z0 + u == 0) {
+                const f32x4 w = v[uu][q];
+                if (z0 + uu == 0) {
                   acc[t][4 * q] = w.x; acc[t][4 * q + 1] = w.y; acc[t][4 * q + 2] = w.z; acc[t][4 * q + 3] = w.w;
                 } else {
                   acc[t][4 * q] = acc[t][4 * q] + w.x; acc[t][4 * q + 1] = acc[t][4 * q + 1] + w.y;
                   acc[t][4 * q + 2] = acc[t][4 * q + 2] + w.z; acc[t][4 * q + 3] = acc[t][4 * q + 3] + w.w;
                 }
               }
+            }
           }
         }
 #pragma unroll
@@ -859,17 +892,14 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
       const int co = col0 + wc * 32 * NT + 32 * t + r;
       const float sc = scale ? scale[co] : 1.0f;
       const float sh = scale ? shift[co] : 0.0f;
-      float *dst = nsplit > 1 ? partial + (size_t)blockIdx.z * cap * cout : out;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int orow = row0 + wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (orow < n) {
           float x = acc[t][e];
-          if (nsplit == 1) {
-            if (scale) x = x * sc + sh;
-            if (relu) x = fmaxf(x, 0.0f);
-          }
-          dst[(size_t)orow * cout + co] = x;
+          if (scale) x = x * sc + sh;
+          if (relu) x = fmaxf(x, 0.0f);
+          out[(size_t)orow * cout + co] = x;
         }
       }
     }
@@ -940,50 +970,58 @@ static void launch_conv_dma(int rows, const float *feat, const DclNbrSrc &nbr, i
     }
   }
 #endif
-  // split-K: layers whose row tiles alone cannot fill the GPU split the 27*Cin contraction over blockIdx.z.  The split
-  // count minimises (rounds of workgroups over the 2 x 256 resident slots) x (chunks per workgroup + a fixed per-workgroup
-  // cost of ~3 chunks: neighbour table, first operand fetch, partial-tile publish): e.g. 204 tiles x 108 chunks take 5
-  // splits (1020 workgroups = 2 full rounds of 22 chunks), not 6 (3 rounds of 18).  A handful of crops (one-image calls)
-  // is latency-bound on the chunk loop instead: split down to 4 chunks per workgroup.
+  // With scratch (partial-tile slots + tickets) a launch can be decomposed three ways; the cheapest by a small cost model
+  // (chunk units on the critical path of a CU slot, fixed cost f per segment: neighbour table, first operand fetch,
+  // publish) is taken:
+  //   whole tiles      rounds(tiles) * (C + f)                    -- enough tiles, or just under a multiple of the slots
+  //   aligned split-K  rounds(tiles * ns) * (C / ns + f + 1)      -- tiles * ns just fills the 2 x 256 resident slots
+  //   stream-K         ceil(units / 512) + 2 f + 1                -- everything else (no partial rounds, no idle slots)
+  // A handful of crops (one-image calls) is latency-bound on the chunk loop: stream-K with kFewChunks chunks per workgroup.
   const int nchunks = dcl_div_up(kvol * CIN, KC);
-  int nsplit = 1;
+  constexpr int kSlots = 512, kFewChunks = 4, kFix = 4;
+  const long long units = (long long)tiles * nchunks;
+  int stream_k = 0, aligned_ns = 0, G = tiles < 65535 * 16 ? tiles : 65535 * 16;
   int32_t *counters = nullptr;
   float *partial = scratch;
-  if (scratch && scratch_floats > kConvCounterWords) {
-    const long long part_floats = scratch_floats - kConvCounterWords;
-    partial = scratch + kConvCounterWords;
-    const bool few_rows = conv_few_rows(rows, n_out_dev != nullptr) && g_conv_split >= 0;
-    const bool never = g_conv_split == -2;
-    const int most0 = few_rows ? conv_split_cap(rows) : kConvMaxSplit;
-    int most = most0 < nchunks / (few_rows ? 4 : 8) ? most0 : nchunks / (few_rows ? 4 : 8);
-    const long long rows_pad = (long long)nblk * BM;              // partial tiles are whole row tiles
-    while (most > 1 && (long long)most * (rows_pad > cap ? rows_pad : cap) * cout > part_floats) --most;
-    if (most < 1) most = 1;
-    if (g_conv_split > 0) {
-      nsplit = g_conv_split.load() < most ? g_conv_split.load() : most;
-    } else if (never) {
-      nsplit = 1;
-    } else if (n_out_dev && few_rows) {
-      nsplit = most;
-    } else if (tiles < 1024) {
-      long long best = -1;
-      for (int ns = 1; ns <= most; ++ns) {
-        const long long rounds = dcl_div_up((long long)tiles * ns, 512);
-        const long long cost = rounds * (dcl_div_up(nchunks, ns) + 3) * 16 + ns;      // + ns: prefer fewer splits on ties
-        if (best < 0 || cost < best) { best = cost; nsplit = ns; }
+  const bool never = g_conv_split == -2;
+  if (scratch && scratch_floats > kConvCounterWords && tiles <= kConvCounterWords && !never) {
+    const long long slots_fit = (scratch_floats - kConvCounterWords) / ((long long)2 * BM * BN);    // 2 slots per workgroup
+    const bool few = conv_few_rows(rows, n_out_dev != nullptr);
+    long long g_stream = units / kFewChunks < kSlots ? units / kFewChunks : kSlots;
+    if (g_stream > slots_fit) g_stream = slots_fit;
+    long long best = dcl_div_up(tiles, kSlots) * (long long)(nchunks + kFix) * 8;                   // whole tiles
+    int mode = 0, best_ns = 1;
+    if (g_conv_split > 0) {                                        // test / tuning hook: force an aligned split
+      mode = 1;
+      best_ns = g_conv_split.load() < nchunks ? g_conv_split.load() : nchunks;
+    } else if (few || n_out_dev) {
+      mode = 2;                                                    // live sizes unknown or tiny: even shares, >= kFewChunks
+    } else {
+      for (int ns = 2; ns <= kConvMaxSplit && ns * 8 <= nchunks; ++ns) {
+        const long long c = dcl_div_up((long long)tiles * ns, kSlots) * (long long)(dcl_div_up(nchunks, ns) + kFix + 1) * 8 + ns;
+        if ((long long)tiles * ns <= slots_fit && c < best) { best = c; mode = 1; best_ns = ns; }
+      }
+      if (g_stream >= 1) {
+        const long long c = (dcl_div_up(units, g_stream) + 2 * kFix + 1) * 8 + 4;
+        if (c < best) { best = c; mode = 2; }
       }
     }
-    if (nsplit > 1 && tiles <= kConvCounterWords) {
+    if (mode == 1 && best_ns >= 2 && (long long)tiles * best_ns <= slots_fit) {
+      aligned_ns = best_ns;
+      G = tiles * best_ns;
+    } else if (mode == 2 && g_stream >= 1) {
+      stream_k = few ? kFewChunks : 1;
+      G = (int)g_stream;
+    }
+    if (aligned_ns || stream_k) {
+      partial = scratch + kConvCounterWords;
       counters = reinterpret_cast<int32_t *>(scratch);
       if (!counters_ready) dcl_internal_zero_words(counters, kConvCounterWords, s);
     }
   }
-  hipLaunchKernelGGL((k_sparse_conv_dma<CIN, WR, WCW, NT>), dim3(nblk < 65535 ? nblk : 65535, cout / BN, nsplit),
-                     dim3(64 * WR * WCW), lds, s, feat, nbr, cap, n_out_dev, n_out_host, W, cout, kvol, subm, scale, shift,
-                     relu, out, partial, nsplit, g_conv_xcd_remap, counters);
-  if (nsplit > 1 && counters == nullptr)
-    hipLaunchKernelGGL(k_conv_split_reduce, dim3(dcl_grid_1d((long long)rows * (cout / 4), 256)), dim3(256), 0, s, partial,
-                       nsplit, cap, n_out_dev, n_out_host, cout, scale, shift, relu, out);
+  hipLaunchKernelGGL((k_sparse_conv_dma<CIN, WR, WCW, NT>), dim3(G), dim3(64 * WR * WCW), lds, s, feat, nbr, cap, n_out_dev,
+                     n_out_host, W, cout, kvol, subm, scale, shift, relu, out, partial, stream_k, aligned_ns, g_conv_xcd_remap,
+                     counters);
 }
 
 template <int CIN, int WC, int KC>
@@ -1106,7 +1144,11 @@ int dcl_internal_conv_split_cap(long long rows) { return conv_split_cap(rows); }
 
 DCL_API int dcl_sparse_conv_scratch_floats(int rows_cap, int cout, int64_t *floats_host) {
   DCL_CHECK_ARG(rows_cap >= 0 && cout > 0 && floats_host);
-  *floats_host = (int64_t)conv_split_cap(rows_cap) * (((int64_t)rows_cap + 127) / 128 * 128) * cout + kConvCounterWords;
+  // stream-K: two partial-tile slots (128 x min(Cout,128) floats) per workgroup of the 512-slot grid + the tile tickets;
+  // the register-staged tile kernel (A/B variant) keeps split-major row partials
+  const int64_t stream = (int64_t)2 * 512 * 128 * (cout < 128 ? cout : 128);
+  const int64_t rowsplit = (int64_t)conv_split_cap(rows_cap) * (((int64_t)rows_cap + 127) / 128 * 128) * cout;
+  *floats_host = (stream > rowsplit ? stream : rowsplit) + kConvCounterWords;
   return 0;
 }
 

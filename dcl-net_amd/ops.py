@@ -222,9 +222,9 @@ def sparse_conv(feat, nbr, n_out, W, subm, scale=None, shift=None, relu=False):
     out = torch.empty((n_out, cout), dtype=torch.float32, device=feat.device)
     if n_out == 0:
         return out
-    # split-K scratch for layers with few row tiles (csrc/sparse_conv.hip::launch_conv_dma); none needed for big ones
+    # stream-K scratch (partial-tile slots + tile tickets, csrc/sparse_conv.hip::launch_conv_dma)
     scratch = None
-    if cout % 32 == 0 and n_out <= 128 * 1024:
+    if cout % 32 == 0:
         need = C.c_int64(0)
         N.check(N.lib().dcl_sparse_conv_scratch_floats(int(cap), int(cout), C.byref(need)), "sparse_conv_scratch_floats")
         scratch = torch.empty(need.value, dtype=torch.float32, device=feat.device)
