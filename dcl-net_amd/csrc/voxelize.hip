@@ -36,3 +36,46 @@ DCL_API int dcl_voxelize_fp(const float *feats, const int32_t *rules, float *out
   DCL_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- input staging / result hand-over of the whole-forward hipGraph (models/DCL_Net.py::forward_graphed): the loader's
+// tensors go into the graph's static buffers and the graph's outputs into the caller's tensors with ONE launch each,
+// instead of one copy / fill kernel per tensor (a one-crop forward is ~0.8 ms: ten extra launches are 5 % of it).
+// job j: dst (rows_dst x cols_dst, dense) <- src (rows_src x cols_src at src_pitch), zero padded; src == NULL: fill.
+namespace {
+struct PadCopyJobs {
+  DclPadCopyJob job[DCL_PAD_COPY_MAX_JOBS];
+};
+__global__ void k_pad_copy_many(const PadCopyJobs jobs) {
+  const DclPadCopyJob &q = jobs.job[blockIdx.y];
+  const long long total = (long long)q.rows_dst * q.cols_dst;
+  int32_t *dst = reinterpret_cast<int32_t *>(q.dst);
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(t / q.cols_dst), c = (int)(t - (long long)r * q.cols_dst);
+    int32_t v = q.fill_value;
+    if (q.src && r < q.rows_src && c < q.cols_src) {
+      const size_t i = (size_t)r * q.src_pitch + c;
+      v = q.src_is_i64 ? (int32_t) reinterpret_cast<const int64_t *>(q.src)[i] : reinterpret_cast<const int32_t *>(q.src)[i];
+    } else if (q.src) {
+      v = 0;
+    }
+    dst[t] = v;
+  }
+}
+}  // namespace
+
+DCL_API int dcl_pad_copy_many(const DclPadCopyJob *jobs_host, int njobs, dclStream_t stream) {
+  DCL_CHECK_ARG(jobs_host && njobs >= 1 && njobs <= DCL_PAD_COPY_MAX_JOBS);
+  PadCopyJobs pack;
+  long long most = 1;
+  for (int j = 0; j < njobs; ++j) {
+    const DclPadCopyJob &q = jobs_host[j];
+    DCL_CHECK_ARG(q.dst && q.rows_dst >= 0 && q.cols_dst >= 0 && q.rows_src >= 0 && q.cols_src >= 0 &&
+                  q.src_pitch >= q.cols_src);
+    pack.job[j] = q;
+    const long long t = (long long)q.rows_dst * q.cols_dst;
+    if (t > most) most = t;
+  }
+  hipLaunchKernelGGL(k_pad_copy_many, dim3(dcl_grid_1d(most, 256, 1024), njobs), dim3(256), 0, (hipStream_t)stream, pack);
+  DCL_LAUNCH_CHECK();
+  return 0;
+}

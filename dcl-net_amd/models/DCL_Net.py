@@ -358,31 +358,59 @@ class Network(nn.Module):
             self._disengage(f, side, pfs, act)
         return self._dense_tail(f, act, b, dev)
 
-    def _dense_tail(self, f, act, b, dev):
-        """everything behind the disengage stacks (needs the whole batch: the attention launches want >= 256 workgroups)"""
+    def _dense_tail(self, f, act, b, dev, side=None):
+        """everything behind the disengage stacks (needs the whole batch: the attention launches want >= 256 workgroups).
+        side: a second stream (whole-forward graph of a few crops): the two directions of the attention, the two confidence /
+        fuser chains and the two pose heads are independent pairs -- with a handful of crops every kernel leaves the GPU
+        mostly idle, so the halves run as parallel graph branches (fork from / join into the current stream each time)."""
+        main = torch.cuda.current_stream(dev)
+
+        class _Both(object):                           # `with both: ...` runs its body on `side` between a fork and a join
+            def __enter__(self_inner):
+                if side is not None:
+                    side.wait_stream(main)
+                    self_inner.ctx = torch.cuda.stream(side)
+                    self_inner.ctx.__enter__()
+
+            def __exit__(self_inner, *a):
+                if side is not None:
+                    self_inner.ctx.__exit__(*a)
+        second = _Both()
+
+        def join():
+            if side is not None:
+                main.wait_stream(side)
         nN, nM = b * self.n_inp, b * self.n_tmp
         fuse1 = torch.empty((nN, 512), dtype=torch.float32, device=dev)      # cat[F_Xc_p1, F_Xo_p]
         conf_in1 = torch.empty((nN, 128), dtype=torch.float32, device=dev)   # cat[F_Xc_m1, F_Xo_m]
         fuse2 = torch.empty((nM, 512), dtype=torch.float32, device=dev)      # cat[F_Yc_p, F_Yo_p2]
         conf_in2 = torch.empty((nM, 128), dtype=torch.float32, device=dev)   # cat[F_Yc_m, F_Yo_m2]
-        fuse1[:, :256].copy_(act["Xcp1"]); conf_in1[:, :64].copy_(act["Xcm1"])
-        fuse2[:, 256:].copy_(act["Yop2"]); conf_in2[:, 64:].copy_(act["Yom2"])
-        ops.cross_attention(b, act["Xcm1"], act["Yom1"], act["Yop1"], fuse1[:, 256:], act["Yom1"], conf_in1[:, 64:])
-        ops.cross_attention(b, act["Yom2"], act["Xcm2"], act["Xcp2"], fuse2[:, :256], act["Xcm2"], conf_in2[:, :64])
-
-        logit1 = self._mlp(conf_in1, f["regressor_conf"])                    # (b*N, 1)
-        logit2 = self._mlp(conf_in2, f["regressor_conf_bi"])
         (l1, sA, tA), (l2, sB, tB) = f["neck_fuser"], f["neck_fuser_bi"]
-        Fp1, Fp2 = fuse1, fuse2
+        with second:
+            fuse2[:, 256:].copy_(act["Yop2"]); conf_in2[:, 64:].copy_(act["Yom2"])
+            ops.cross_attention(b, act["Yom2"], act["Xcm2"], act["Xcp2"], fuse2[:, :256], act["Xcm2"], conf_in2[:, :64])
+            logit2 = self._mlp(conf_in2, f["regressor_conf_bi"])
+            Fp2 = fuse2
+            for Wt, bias in l2:
+                Fp2 = self._lin_relu(Fp2, Wt, bias)
+            if side is not None:
+                logit2.record_stream(main); Fp2.record_stream(main)          # allocated on `side`, read on `main` below
+        fuse1[:, :256].copy_(act["Xcp1"]); conf_in1[:, :64].copy_(act["Xcm1"])
+        ops.cross_attention(b, act["Xcm1"], act["Yom1"], act["Yop1"], fuse1[:, 256:], act["Yom1"], conf_in1[:, 64:])
+        logit1 = self._mlp(conf_in1, f["regressor_conf"])                    # (b*N, 1)
+        Fp1 = fuse1
         for Wt, bias in l1:
             Fp1 = self._lin_relu(Fp1, Wt, bias)
-        for Wt, bias in l2:
-            Fp2 = self._lin_relu(Fp2, Wt, bias)
+        join()
         # trailing BNs after pooling: F_p_wei = sA*P1 + tA*sum(w1) + sB*P2 + tB*sum(w2), finished inside the pooling op
         conf, F_p_wei = ops.conf_pool(b, logit1.reshape(-1), logit2.reshape(-1), Fp1, Fp2, affine=(sA, tA, sB, tB))
+        with second:
+            trans_pred = self._mlp(F_p_wei, f["regressor_trans"])
+            if side is not None:
+                trans_pred.record_stream(main)
         o9 = self._mlp(F_p_wei, f["regressor_rot"])
         rot_pred = ops.ortho9d_to_matrix(o9)
-        trans_pred = self._mlp(F_p_wei, f["regressor_trans"])
+        join()
         F_Xo_p = fuse1[:, 256:].reshape(b, self.n_inp, 256).transpose(1, 2)  # (b,256,N) view
         prediction = {"trans_pred": trans_pred, "rot_pred": rot_pred, "conf": conf, "F_Xo_p": F_Xo_p}
         if self.mode != "test":
@@ -411,22 +439,47 @@ class Network(nn.Module):
         if ent is None or any(need_ma[s] > ent["ma"][s] for s in ("inp", "tmp")):
             ent = self._capture(f, dev, b, S, {s: max(32, 2 * need_ma[s]) for s in ("inp", "tmp")})
             cache[key] = ent
-        for s, n in (("inp", self.n_inp), ("tmp", self.n_tmp)):
-            st, d = ent[s], data[s]
-            v0 = int(d["occupied_voxels"].shape[0])
-            st["feats"].copy_(d["feats"], non_blocking=True)
-            st["occ"][:v0].copy_(d["occupied_voxels"], non_blocking=True)
-            st["v2p"].zero_()
-            st["v2p"][:v0, :need_ma[s] + 1].copy_(d["v2p_maps"], non_blocking=True)
-            st["v0"].fill_(v0)
+        on_dev = all(data[s][k].is_cuda for s in ("inp", "tmp") for k in ("feats", "v2p_maps", "occupied_voxels")) and \
+            all(data[s]["feats"].dtype == torch.float32 and data[s]["v2p_maps"].dtype == torch.int32 for s in ("inp", "tmp"))
+        if on_dev:                                     # resident inputs: all eight staging copies / fills in one launch
+            jobs = []
+            for s in ("inp", "tmp"):
+                st, d = ent[s], data[s]
+                jobs += [(st["feats"], d["feats"]), (st["occ"], d["occupied_voxels"]), (st["v2p"], d["v2p_maps"]),
+                         (st["v0"], int(d["occupied_voxels"].shape[0]))]
+            ops.pad_copy_many(jobs)
+        else:
+            for s, n in (("inp", self.n_inp), ("tmp", self.n_tmp)):
+                st, d = ent[s], data[s]
+                v0 = int(d["occupied_voxels"].shape[0])
+                st["feats"].copy_(d["feats"], non_blocking=True)
+                st["occ"][:v0].copy_(d["occupied_voxels"], non_blocking=True)
+                st["v2p"].zero_()
+                st["v2p"][:v0, :need_ma[s] + 1].copy_(d["v2p_maps"], non_blocking=True)
+                st["v0"].fill_(v0)
         if ent["graph"] is None:                       # DCL_NO_GRAPH=1: run the capacity-mode body eagerly (debugging aid)
             with torch.no_grad():
                 ent["out"] = ent["body"]()
         else:
             ent["graph"].replay()
-        out = {k: v.clone() for k, v in ent["out"].items()}
-        data["labels"]["points_tmp"] = ent["tmp"]["feats"][:, 4:7].reshape(b, self.n_tmp, 3).clone()
-        data["labels"]["points_inp"] = ent["inp"]["feats"][:, 4:7].reshape(b, self.n_inp, 3).clone()
+        # hand-over: the graph's output buffers are overwritten by the next replay -> copies, one launch for all six
+        o = ent["out"]
+        F = o["F_Xo_p"].transpose(1, 2)                                      # (b, N, 256) rows of the 512-wide fuser input
+        res = {"trans_pred": torch.empty_like(o["trans_pred"]), "rot_pred": torch.empty_like(o["rot_pred"]),
+               "conf": torch.empty_like(o["conf"]), "F": torch.empty((b, self.n_inp, 256), dtype=torch.float32, device=dev),
+               "pts_tmp": torch.empty((b, self.n_tmp, 3), dtype=torch.float32, device=dev),
+               "pts_inp": torch.empty((b, self.n_inp, 3), dtype=torch.float32, device=dev)}
+        ops.pad_copy_many([(res["trans_pred"], o["trans_pred"]), (res["rot_pred"], o["rot_pred"].reshape(b, 9)),
+                           (res["conf"], o["conf"]), (res["F"], F.reshape(b * self.n_inp, 256)),
+                           (res["pts_tmp"].view(b * self.n_tmp, 3), ent["tmp"]["feats"][:, 4:7]),
+                           (res["pts_inp"].view(b * self.n_inp, 3), ent["inp"]["feats"][:, 4:7])])
+        out = {"trans_pred": res["trans_pred"], "rot_pred": res["rot_pred"], "conf": res["conf"],
+               "F_Xo_p": res["F"].transpose(1, 2)}
+        for k in o:                                                          # train-mode extras (Xo_pred, Yc_pred)
+            if k not in out:
+                out[k] = o[k].clone()
+        data["labels"]["points_tmp"] = res["pts_tmp"]
+        data["labels"]["points_inp"] = res["pts_inp"]
         return out
 
     def _capture(self, f, dev, b, S, ma):
@@ -452,6 +505,8 @@ class Network(nn.Module):
             # branches, 1.22 ms with four -- every cross-branch edge costs a barrier packet), and ROCm 7.2 crashes in
             # hipStreamEndCapture when a stream joins the capture through an event of an already forked stream.
             main, side_stream = torch.cuda.current_stream(dev), self._side_stream(dev)
+            act = {}
+            par_dense = b <= 8 and os.environ.get("DCL_GRAPH_SERIAL_DENSE") != "1"
             side_stream.wait_stream(main)
             for s, bb, stream in (("inp", "backbone_inp", main), ("tmp", "backbone_tmp", side_stream)):
                 with torch.cuda.stream(stream):
@@ -462,8 +517,11 @@ class Network(nn.Module):
                     pb4 = torch.cat([st["bid"], st["feats"][:, 4:7]], 1).contiguous()
                     st["run"].point_features(pb4, extents, off, st["pf"], st["tmpbuf"])
                     st["keep"] = (x, pb4)
+                    dside = "Xc" if s == "inp" else "Yo"                   # each side's disengage stacks stay on its branch
+                    act.update(self._disengage_buffers(dside, st["pf"].shape[0], dev))
+                    self._disengage(f, dside, st["pf"], act)
             main.wait_stream(side_stream)                                  # join
-            return self._dense(f, ent["inp"]["pf"], ent["tmp"]["pf"], b, dev)
+            return self._dense_tail(f, act, b, dev, side=side_stream if par_dense else None)
 
         ent["body"] = body
         if os.environ.get("DCL_NO_GRAPH") == "1":

@@ -77,6 +77,37 @@ def voxelize_fp(feats, map_rule, mode=4):
     return out
 
 
+class _PadCopyJob(C.Structure):
+    _fields_ = [("dst", C.c_void_p), ("src", C.c_void_p), ("rows_dst", C.c_int32), ("cols_dst", C.c_int32),
+                ("rows_src", C.c_int32), ("cols_src", C.c_int32), ("src_pitch", C.c_int32), ("src_is_i64", C.c_int32),
+                ("fill_value", C.c_int32), ("reserved", C.c_int32)]
+
+
+def pad_copy_many(jobs):
+    """jobs: list of (dst, src) 2-D CUDA tensor pairs of 4-byte elements (src may be int64 -> narrowed; may be smaller than
+    dst -> zero padded; may be a column block of a wider row-major tensor) or (dst, int) fills -- ONE launch for all."""
+    arr = (_PadCopyJob * len(jobs))()
+    for j, (dst, src) in enumerate(jobs):
+        assert dst.is_cuda and dst.is_contiguous() and dst.element_size() == 4
+        if dst.dim() == 2:
+            d2 = dst
+        elif torch.is_tensor(src):
+            d2 = dst.reshape(-1, src.shape[1])         # same logical rows as the source
+        else:
+            d2 = dst.reshape(1, -1)
+        q = arr[j]
+        q.dst, q.rows_dst, q.cols_dst = dst.data_ptr(), d2.shape[0], d2.shape[1]
+        if torch.is_tensor(src):
+            assert src.is_cuda and src.dim() == 2 and src.stride(1) == 1 and src.element_size() in (4, 8)
+            assert src.element_size() == 4 or src.dtype == torch.int64
+            q.src, q.rows_src, q.cols_src = src.data_ptr(), src.shape[0], src.shape[1]
+            q.src_pitch = src.stride(0) if src.shape[0] > 1 else src.shape[1]
+            q.src_is_i64 = int(src.dtype == torch.int64)
+        else:
+            q.src, q.fill_value = None, int(src)
+    N.check(N.lib().dcl_pad_copy_many(arr, len(jobs), N.stream()), "pad_copy_many")
+
+
 # ------------------------------------------------------------------------------------ rulebooks
 def grid_words(batch, S):
     return (batch * S * S * S + 31) // 32

@@ -172,6 +172,17 @@ int dcl_sparse_avgpool_fwd_rf(const float *feat, const int32_t *nbr, int cap, co
                               int n_out_host, int c, int kvol, const int32_t *summaryrf, float *out,
                               dclStream_t stream);
 
+/* Several zero-padded 2-D copies of 4-byte elements in ONE launch (input staging / result hand-over of the whole-forward
+ * hipGraph): job: dst (rows_dst x cols_dst, dense) <- src (rows_src x cols_src, row pitch src_pitch elements; int64
+ * elements narrowed to int32 when src_is_i64), zero outside src; src == NULL fills dst with fill_value.                 */
+#define DCL_PAD_COPY_MAX_JOBS 12
+typedef struct {
+  void *dst;
+  const void *src;
+  int32_t rows_dst, cols_dst, rows_src, cols_src, src_pitch, src_is_i64, fill_value, reserved;
+} DclPadCopyJob;
+int dcl_pad_copy_many(const DclPadCopyJob *jobs_host, int njobs, dclStream_t stream);
+
 /* ---------------------------------------------------- native backbone runner ---
  * One sparse backbone of DCL-Net (Backbone_SPCONV.forward, models/Modules.py:153-159: 4 x [SparseConv3d k3 s1 p1
  * + BN + ReLU, SubMConv3d k3 + BN + ReLU, SparseAvgPool3d k3 s2 p1]) and its point read-out
