@@ -808,8 +808,13 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
         for (int q = 0; q < 4; ++q) {
           f32x4 v;
           v.x = acc[t][4 * q]; v.y = acc[t][4 * q + 1]; v.z = acc[t][4 * q + 2]; v.w = acc[t][4 * q + 3];
-          conv_store16_wt(mine + (t * 4 + q) * 64, v);
+          if (tile_counters) conv_store16_wt(mine + (t * 4 + q) * 64, v);
+          else mine[(t * 4 + q) * 64] = v;                  // deferred combine (k_conv_frag_reduce, next launch): plain stores
         }
+      if (tile_counters == nullptr) {                      // few-row launches: the combine is a launch of its own
+        __syncthreads();
+        continue;
+      }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       CONV_STAMP(4);
@@ -931,6 +936,54 @@ __global__ void k_conv_split_reduce(const float *__restrict__ partial, int nspli
   }
 }
 
+// Deferred combine of a stream-K launch (few-row launches: a tile has up to 27 segments, which the last arriver would have
+// to add in as many dependent rounds of loads -- here every thread owns one 16-B piece of a tile and has all of its
+// segments' loads in flight at once).  Same unit arithmetic as k_sparse_conv_dma; tiles owned by ONE workgroup were
+// written by it directly and are skipped.  grid = (tiles_cap, NW*NT*4*64/256), 256 threads.
+template <int WR, int WCW, int NT>
+__global__ __launch_bounds__(256) void k_conv_frag_reduce(const float *__restrict__ partial, int cap,
+                                                          const int32_t *__restrict__ n_out_dev, int n_out_host, int cout,
+                                                          int C, int G, int min_u, const float *__restrict__ scale,
+                                                          const float *__restrict__ shift, int relu,
+                                                          float *__restrict__ out) {
+  constexpr int NW = WR * WCW, BM = 32 * WR, BN = 32 * NT * WCW;
+  int n = n_out_dev ? *n_out_dev : n_out_host;
+  n = n < cap ? n : cap;
+  const int nblk = (n + BM - 1) / BM, ncol = cout / BN;
+  const int tile = blockIdx.x;
+  if (tile >= nblk * ncol) return;
+  const int total = nblk * ncol * C;
+  int U = (total + G - 1) / G;
+  if (U < min_u) U = min_u;
+  const int w_first = (tile * C) / U, w_last = ((tile + 1) * C - 1) / U;
+  if (w_first == w_last) return;                                             // one owner: written by the conv kernel
+  const int piece = blockIdx.y * 256 + threadIdx.x;                          // [wave][t][q][lane] inside the tile
+  const int lane = piece & 63, q = (piece >> 6) & 3, t = (piece >> 8) % NT, wave = piece / (256 * NT);
+  const size_t tile_f4 = (size_t)NW * NT * 4 * 64;
+  const f32x4 *base = reinterpret_cast<const f32x4 *>(partial) + piece;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  for (int w = w_first; w <= w_last; ++w) {
+    const f32x4 v = base[(size_t)(2 * w + (w * U >= tile * C ? 0 : 1)) * tile_f4];
+    if (w == w_first) a = v;
+    else { a.x = a.x + v.x; a.y = a.y + v.y; a.z = a.z + v.z; a.w = a.w + v.w; }
+  }
+  const int blk = tile / ncol, by = tile - blk * ncol;
+  const int r = lane & 31, h = lane >> 5, wr = wave / WCW, wc = wave % WCW;
+  const int co = by * BN + wc * 32 * NT + 32 * t + r;
+  const float sc = scale ? scale[co] : 1.0f, sh = scale ? shift[co] : 0.0f;
+  const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int orow = blk * BM + wr * 32 + c + 8 * q + 4 * h;                 // accumulator element e = 4 q + c
+    if (orow < n) {
+      float x = av[c];
+      if (scale) x = x * sc + sh;
+      if (relu) x = fmaxf(x, 0.0f);
+      out[(size_t)orow * cout + co] = x;
+    }
+  }
+}
+
 constexpr int kConvMaxSplit = 8;       // K-splits of a launch with many row tiles
 constexpr int kConvFewRows = 4096;     // at most this many output rows (capacity): up to one split per kernel offset
 static int conv_split_cap(long long rows) { return rows <= kConvFewRows ? 27 : kConvMaxSplit; }
@@ -981,6 +1034,7 @@ static void launch_conv_dma(int rows, const float *feat, const DclNbrSrc &nbr, i
   constexpr int kSlots = 512, kFewChunks = 4, kFix = 4;
   const long long units = (long long)tiles * nchunks;
   int stream_k = 0, aligned_ns = 0, G = tiles < 65535 * 16 ? tiles : 65535 * 16;
+  bool deferred = false;
   int32_t *counters = nullptr;
   float *partial = scratch;
   const bool never = g_conv_split == -2;
@@ -1015,13 +1069,19 @@ static void launch_conv_dma(int rows, const float *feat, const DclNbrSrc &nbr, i
     }
     if (aligned_ns || stream_k) {
       partial = scratch + kConvCounterWords;
-      counters = reinterpret_cast<int32_t *>(scratch);
-      if (!counters_ready) dcl_internal_zero_words(counters, kConvCounterWords, s);
+      deferred = stream_k == kFewChunks;                           // few rows: many segments per tile, combine = own launch
+      if (!deferred) {
+        counters = reinterpret_cast<int32_t *>(scratch);
+        if (!counters_ready) dcl_internal_zero_words(counters, kConvCounterWords, s);
+      }
     }
   }
   hipLaunchKernelGGL((k_sparse_conv_dma<CIN, WR, WCW, NT>), dim3(G), dim3(64 * WR * WCW), lds, s, feat, nbr, cap, n_out_dev,
                      n_out_host, W, cout, kvol, subm, scale, shift, relu, out, partial, stream_k, aligned_ns, g_conv_xcd_remap,
                      counters);
+  if (deferred)
+    hipLaunchKernelGGL((k_conv_frag_reduce<WR, WCW, NT>), dim3(tiles, WR * WCW * NT), dim3(256), 0, s, partial, cap, n_out_dev,
+                       n_out_host, cout, nchunks, G, stream_k, scale, shift, relu, out);
 }
 
 template <int CIN, int WC, int KC>

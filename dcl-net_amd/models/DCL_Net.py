@@ -258,13 +258,14 @@ class Network(nn.Module):
         # the geometry of BOTH sides goes out first (it needs the occupied voxels only): the host is the slow party here
         # (16 launches per side), everything else it has to issue before the read-back then runs underneath the geometry
         occ = {}
-        counts_all = torch.empty(16 * K, dtype=torch.int32, device=dev)       # [chunk][side][8], one read-back
-        for si, s in enumerate(("inp", "tmp")):
+        counts_dev = {}
+        for s in ("inp", "tmp"):
             with torch.cuda.stream(sstream[s]):
                 occ[s] = data[s]["occupied_voxels"].to(dev, non_blocking=True).int().contiguous()
+                # allocated on the stream that writes it (with async_inputs the side streams are not ordered behind `main`)
+                counts_dev[s] = torch.empty(8 * K, dtype=torch.int32, device=dev)
                 for c in range(K):
-                    runs[s, c] = ops.BackboneRun(occ[s], bc, S, batch_lo=c * bc,
-                                                 counts_dev=counts_all[16 * c + 8 * si:16 * c + 8 * si + 8])
+                    runs[s, c] = ops.BackboneRun(occ[s], bc, S, batch_lo=c * bc, counts_dev=counts_dev[s][8 * c:8 * c + 8])
                 geo[s] = torch.cuda.Event()
                 geo[s].record(sstream[s])
         def stage(s):
@@ -289,10 +290,13 @@ class Network(nn.Module):
         with torch.cuda.stream(rstream):                               # the host waits for the two geometry stages only
             for s in ("inp", "tmp"):
                 rstream.wait_event(geo[s])
-            counts = counts_all.cpu().tolist()
+            for s in ("inp", "tmp"):
+                counts_dev[s].record_stream(rstream)
+            counts = torch.cat([counts_dev["inp"], counts_dev["tmp"]]).cpu().tolist()      # [side][chunk][8]
         mark("counts read back")
-        for i, key in enumerate((s, c) for c in range(K) for s in ("inp", "tmp")):
-            runs[key[0], key[1]].set_counts(counts[8 * i:8 * i + 8])
+        for si, s in enumerate(("inp", "tmp")):
+            for c in range(K):
+                runs[s, c].set_counts(counts[8 * (K * si + c):8 * (K * si + c) + 8])
         done = {}
         for side, bb in (("inp", "backbone_inp"), ("tmp", "backbone_tmp")):
             n = npts[side]
@@ -508,18 +512,27 @@ class Network(nn.Module):
             act = {}
             par_dense = b <= 8 and os.environ.get("DCL_GRAPH_SERIAL_DENSE") != "1"
             side_stream.wait_stream(main)
-            for s, bb, stream in (("inp", "backbone_inp", main), ("tmp", "backbone_tmp", side_stream)):
-                with torch.cuda.stream(stream):
-                    st = ent[s]
-                    st["run"].geometry()
-                    x = ops.voxelize_fp(st["feats"], st["v2p"], self.voxelization_mode)
-                    st["run"].features(x, *f[bb + "_ptrs"])
-                    pb4 = torch.cat([st["bid"], st["feats"][:, 4:7]], 1).contiguous()
-                    st["run"].point_features(pb4, extents, off, st["pf"], st["tmpbuf"])
-                    st["keep"] = (x, pb4)
-                    dside = "Xc" if s == "inp" else "Yo"                   # each side's disengage stacks stay on its branch
-                    act.update(self._disengage_buffers(dside, st["pf"].shape[0], dev))
-                    self._disengage(f, dside, st["pf"], act)
+            # The two branches are issued stage by stage, alternating: a graph launch hands its nodes to the queues in
+            # creation order, so a branch captured as a whole after the other one starts ~50 nodes late on replay.
+            sides = (("inp", "backbone_inp", main, "Xc"), ("tmp", "backbone_tmp", side_stream, "Yo"))
+            xs, pb4s = {}, {}
+            for stage in range(5):
+                for s, bb, stream, dside in sides:
+                    with torch.cuda.stream(stream):
+                        st = ent[s]
+                        if stage == 0:
+                            st["run"].geometry()
+                        elif stage == 1:
+                            xs[s] = ops.voxelize_fp(st["feats"], st["v2p"], self.voxelization_mode)
+                            pb4s[s] = torch.cat([st["bid"], st["feats"][:, 4:7]], 1).contiguous()
+                        elif stage == 2:
+                            st["run"].features(xs[s], *f[bb + "_ptrs"])
+                        elif stage == 3:
+                            st["run"].point_features(pb4s[s], extents, off, st["pf"], st["tmpbuf"])
+                            st["keep"] = (xs[s], pb4s[s])
+                        else:                                              # each side's disengage stacks stay on its branch
+                            act.update(self._disengage_buffers(dside, st["pf"].shape[0], dev))
+                            self._disengage(f, dside, st["pf"], act)
             main.wait_stream(side_stream)                                  # join
             return self._dense_tail(f, act, b, dev, side=side_stream if par_dense else None)
 
