@@ -1144,10 +1144,22 @@ __global__ __launch_bounds__(256) void k_sparse_avgpool(const float *__restrict_
     if (rf_in) rf = rf_in[row];                            // caller's summaryrf (indice_avgpool_fp32's 5th argument)
     const float d = (float)rf;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k = 0; k < kvol; ++k) {
-      if (v[k] < 0) continue;
-      const float4 f = reinterpret_cast<const float4 *>(feat + (size_t)v[k] * c)[q];
-      acc.x = acc.x + f.x / d; acc.y = acc.y + f.y / d; acc.z = acc.z + f.z / d; acc.w = acc.w + f.w / d;
+    // nine neighbour rows in flight at a time (a missing neighbour loads row 0 and is not added): the loads of the whole
+    // window used to be 27 dependent steps -- a branch on the LDS value in front of each -- which is what a pool of a few
+    // hundred rows (one-image calls) spent its time on.  The terms are still added in ascending offset order.
+    for (int k0 = 0; k0 < kvol; k0 += 9) {
+      float4 f[9];
+#pragma unroll
+      for (int j = 0; j < 9; ++j) {
+        const int vk = k0 + j < kvol ? v[k0 + j] : -1;
+        f[j] = reinterpret_cast<const float4 *>(feat + (size_t)(vk < 0 ? 0 : vk) * c)[q];
+      }
+#pragma unroll
+      for (int j = 0; j < 9; ++j) {
+        const bool ok = k0 + j < kvol && v[k0 + j] >= 0;
+        acc.x = ok ? acc.x + f[j].x / d : acc.x; acc.y = ok ? acc.y + f[j].y / d : acc.y;
+        acc.z = ok ? acc.z + f[j].z / d : acc.z; acc.w = ok ? acc.w + f[j].w / d : acc.w;
+      }
     }
     reinterpret_cast<float4 *>(out + (size_t)row * c)[q] = acc;
     if (rf_out && q == 0) rf_out[row] = rf;
