@@ -920,3 +920,79 @@ DCL_API int dcl_ortho9d_to_matrix(int b, const float *o9, float *R, dclStream_t 
   DCL_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- pose heads for a handful of crops --------------------------------------------------------------------------
+// regressor_rot / regressor_trans (models/DCL_Net.py:139-151,231-235: Conv1d k1 1024 -> 512 -> 128 -> {9,3}, ReLU after
+// the first two) on the pooled (b,1024) feature.  With a few crops these are row-vector x matrix products: as library
+// GEMMs they are 6 launches + the copy / activation kernels the row-vector path of the library wrapper adds (14-16
+// kernels on the critical path of a one-image forward).  Two launches here, both heads in each:
+//   k_heads_l1: h1[head][crop][512]; workgroup = (64 outputs, crop, head), 4 k-slices of 256 terms, LDS reduce
+//   k_heads_l23: h2 = relu(W2 h1 + b2) (128), out = W3 h2 + b3 (9 | 3); workgroup = (crop, head)
+// Weights are the transposed (in, out) matrices the dense pipeline keeps (row k contiguous over outputs): coalesced.
+namespace {
+struct HeadWeights {
+  const float *w1[2], *b1[2], *w2[2], *b2[2], *w3[2], *b3[2];   // [0] rotation (9 outputs), [1] translation (3)
+};
+
+__global__ __launch_bounds__(256) void k_heads_l1(int b, const float *__restrict__ x, HeadWeights hw, float *__restrict__ h1) {
+  __shared__ float part[4][64];
+  const int head = blockIdx.z, crop = blockIdx.y, o0 = blockIdx.x * 64;
+  const int o = threadIdx.x & 63, ks = threadIdx.x >> 6;
+  const float *w = hw.w1[head] + (size_t)(ks * 256) * 512 + o0 + o;
+  const float *xv = x + (size_t)crop * 1024 + ks * 256;
+  float acc = 0.f;
+#pragma unroll 8
+  for (int i = 0; i < 256; ++i) acc = __fmaf_rn(xv[i], w[(size_t)i * 512], acc);
+  part[ks][o] = acc;
+  __syncthreads();
+  if (ks == 0) {
+    const float v = ((part[0][o] + part[1][o]) + (part[2][o] + part[3][o])) + hw.b1[head][o0 + o];
+    h1[((size_t)head * b + crop) * 512 + o0 + o] = fmaxf(v, 0.f);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_heads_l23(int b, const float *__restrict__ h1, HeadWeights hw,
+                                                   float *__restrict__ o9, float *__restrict__ t3) {
+  __shared__ float xs[512], part[2][128], h2[128];
+  const int head = blockIdx.y, crop = blockIdx.x;
+  const float *xin = h1 + ((size_t)head * b + crop) * 512;
+  for (int i = threadIdx.x; i < 512; i += 256) xs[i] = xin[i];
+  __syncthreads();
+  const int o = threadIdx.x & 127, ks = threadIdx.x >> 7;
+  const float *w = hw.w2[head] + (size_t)(ks * 256) * 128 + o;
+  float acc = 0.f;
+#pragma unroll 8
+  for (int i = 0; i < 256; ++i) acc = __fmaf_rn(xs[ks * 256 + i], w[(size_t)i * 128], acc);
+  part[ks][o] = acc;
+  __syncthreads();
+  if (ks == 0) h2[o] = fmaxf((part[0][o] + part[1][o]) + hw.b2[head][o], 0.f);
+  __syncthreads();
+  const int nout = head == 0 ? 9 : 3;
+  if ((int)threadIdx.x < nout) {
+    const float *w3 = hw.w3[head] + threadIdx.x;
+    float a = 0.f;
+    for (int i = 0; i < 128; ++i) a = __fmaf_rn(h2[i], w3[(size_t)i * nout], a);
+    a += hw.b3[head][threadIdx.x];
+    if (head == 0) o9[(size_t)crop * 9 + threadIdx.x] = a;
+    else t3[(size_t)crop * 3 + threadIdx.x] = a;
+  }
+}
+}  // namespace
+
+DCL_API int dcl_pose_heads(int b, const float *pooled, const float *const *rot_layers, const float *const *trans_layers,
+                           float *h1_scratch, float *o9, float *trans, dclStream_t stream) {
+  DCL_CHECK_ARG(b >= 0 && b <= 65535);
+  if (b == 0) return 0;
+  DCL_CHECK_ARG(pooled && rot_layers && trans_layers && h1_scratch && o9 && trans);
+  HeadWeights hw;
+  for (int h = 0; h < 2; ++h) {
+    const float *const *L = h == 0 ? rot_layers : trans_layers;         // {W1t, b1, W2t, b2, W3t, b3}
+    for (int i = 0; i < 6; ++i) DCL_CHECK_ARG(L[i] != nullptr);
+    hw.w1[h] = L[0]; hw.b1[h] = L[1]; hw.w2[h] = L[2]; hw.b2[h] = L[3]; hw.w3[h] = L[4]; hw.b3[h] = L[5];
+  }
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_heads_l1, dim3(512 / 64, b, 2), dim3(256), 0, s, b, pooled, hw, h1_scratch);
+  hipLaunchKernelGGL(k_heads_l23, dim3(b, 2), dim3(256), 0, s, b, h1_scratch, hw, o9, trans);
+  DCL_LAUNCH_CHECK();
+  return 0;
+}

@@ -408,13 +408,17 @@ class Network(nn.Module):
         join()
         # trailing BNs after pooling: F_p_wei = sA*P1 + tA*sum(w1) + sB*P2 + tB*sum(w2), finished inside the pooling op
         conf, F_p_wei = ops.conf_pool(b, logit1.reshape(-1), logit2.reshape(-1), Fp1, Fp2, affine=(sA, tA, sB, tB))
-        with second:
-            trans_pred = self._mlp(F_p_wei, f["regressor_trans"])
-            if side is not None:
-                trans_pred.record_stream(main)
-        o9 = self._mlp(F_p_wei, f["regressor_rot"])
-        rot_pred = ops.ortho9d_to_matrix(o9)
-        join()
+        if b <= 8:                                     # a handful of crops: both heads in two launches (csrc/dense.hip)
+            o9, trans_pred = ops.pose_heads(F_p_wei, f["regressor_rot"], f["regressor_trans"])
+            rot_pred = ops.ortho9d_to_matrix(o9)
+        else:
+            with second:
+                trans_pred = self._mlp(F_p_wei, f["regressor_trans"])
+                if side is not None:
+                    trans_pred.record_stream(main)
+            o9 = self._mlp(F_p_wei, f["regressor_rot"])
+            rot_pred = ops.ortho9d_to_matrix(o9)
+            join()
         F_Xo_p = fuse1[:, 256:].reshape(b, self.n_inp, 256).transpose(1, 2)  # (b,256,N) view
         prediction = {"trans_pred": trans_pred, "rot_pred": rot_pred, "conf": conf, "F_Xo_p": F_Xo_p}
         if self.mode != "test":

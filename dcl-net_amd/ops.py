@@ -634,6 +634,24 @@ def conf_pool(b, logit1, logit2, F1, F2, affine=None):
     return conf, part1.sum(dim=1), part2.sum(dim=1), ws
 
 
+def pose_heads(pooled, rot_layers, trans_layers):
+    """regressor_rot / regressor_trans on the pooled (b,1024) feature for a handful of crops: both 3-layer heads in two
+    launches.  *_layers: [(W1t, b1), (W2t, b2), (W3t, b3)] with (in, out) matrices -> (o9 (b,9), trans (b,3))."""
+    N.need_cuda(pooled)
+    pooled = pooled.contiguous()
+    b, dev = pooled.shape[0], pooled.device
+    assert pooled.shape[1] == 1024 and tuple(rot_layers[0][0].shape) == (1024, 512) and tuple(rot_layers[2][0].shape) == (128, 9)
+    assert tuple(trans_layers[1][0].shape) == (512, 128) and tuple(trans_layers[2][0].shape) == (128, 3)
+    flat = lambda layers: _ptr_array([t for pair in layers for t in pair])                    # noqa: E731
+    assert all(t.is_contiguous() and t.dtype == torch.float32 for layers in (rot_layers, trans_layers) for p in layers for t in p)
+    h1 = torch.empty((2, b, 512), dtype=torch.float32, device=dev)
+    o9 = torch.empty((b, 9), dtype=torch.float32, device=dev)
+    trans = torch.empty((b, 3), dtype=torch.float32, device=dev)
+    N.check(N.lib().dcl_pose_heads(b, N.ptr(pooled), flat(rot_layers), flat(trans_layers), N.ptr(h1), N.ptr(o9), N.ptr(trans),
+                                   N.stream()), "pose_heads")
+    return o9, trans
+
+
 def ortho9d_to_matrix(o9):
     """ortho9d2matrix (models/DCL_Net.py:15-36): (b,9) -> (b,3,3)."""
     N.need_cuda(o9)

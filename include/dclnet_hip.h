@@ -330,6 +330,13 @@ int dcl_pool_finish(int b, int c, int nslices, const float *part1, const float *
                     const float *scale1, const float *shift1, const float *scale2, const float *shift2, float *out,
                     dclStream_t stream);
 
+/* regressor_rot + regressor_trans (models/DCL_Net.py:139-151,231-235; Head_MultiLayerPerceptron 1024 -> 512 -> 128 -> 9 | 3,
+ * ReLU after the first two layers) on the pooled feature (b,1024), both heads in two launches -- meant for a handful of
+ * crops (one-image calls); large batches use library GEMMs.  rot_layers / trans_layers: {W1t (1024,512), b1, W2t (512,128),
+ * b2, W3t (128,9|3), b3}, matrices stored (in, out) row-major.  h1_scratch: 2*b*512 floats.                              */
+int dcl_pose_heads(int b, const float *pooled, const float *const *rot_layers, const float *const *trans_layers,
+                   float *h1_scratch, float *o9, float *trans, dclStream_t stream);
+
 /* ortho9d2matrix (models/DCL_Net.py:15-36): o9 (b,9) -> R (b,3,3).             */
 int dcl_ortho9d_to_matrix(int b, const float *o9, float *R, dclStream_t stream);
 

@@ -644,6 +644,51 @@ def test_linemod_add_and_adds_kernel_matches_reference_loop_golden(dcl, golden_d
     assert np.array_equal(table.counts[:, 0], z["num_count"]) and np.array_equal(table.counts[:, 1], z["success_count"])
 
 
+def test_pose_heads_match_the_module_heads(dcl):
+    """dcl_pose_heads (both 1024 -> 512 -> 128 -> 9 | 3 heads in two launches, small batches) vs the registered
+    Head_MultiLayerPerceptron modules (reference models/DCL_Net.py:139-151) evaluated in float64"""
+    cfg = dcl.synth.default_cfg(64, 64)
+    net = dcl.DCL_Net.Network(cfg, mode="test")
+    net.load_state_dict(dcl.synth.synth_state_dict(net, 9))
+    net = net.cuda().eval()
+    f = net._fold()
+    g = torch.Generator().manual_seed(1)
+    for b in (1, 5, 8):
+        x = torch.randn(b, 1024, generator=g).cuda()
+        o9, t3 = dcl.ops.pose_heads(x, f["regressor_rot"], f["regressor_trans"])
+        with torch.no_grad():
+            r64 = net.regressor_rot.double()(x.double().unsqueeze(2)).squeeze(2)
+            t64 = net.regressor_trans.double()(x.double().unsqueeze(2)).squeeze(2)
+        net.regressor_rot.float(); net.regressor_trans.float()
+        assert float((o9.double() - r64).abs().max()) <= 2e-5 * max(1.0, float(r64.abs().max()))
+        assert float((t3.double() - t64).abs().max()) <= 2e-6 * max(1.0, float(t64.abs().max()) / 0.02)
+
+
+def test_pad_copy_many_stages_and_hands_over_in_one_launch(dcl):
+    """dcl_pad_copy_many (input staging / result hand-over of the whole-forward hipGraph): zero-padded 2-D copies, int64
+    narrowing, column blocks of wider buffers, scalar fills -- all in one launch, bit for bit what the torch ops did"""
+    g = torch.Generator().manual_seed(3)
+    feats = torch.randn(300, 7, generator=g).cuda()
+    occ = torch.randint(0, 64, (123, 4), generator=g, dtype=torch.int64).cuda()
+    v2p = torch.randint(0, 300, (123, 5), generator=g, dtype=torch.int32).cuda()
+    wide = torch.randn(40, 512, generator=g).cuda()
+    d_feats = torch.full((300, 7), 9.0).cuda()
+    d_occ = torch.full((300, 4), 9, dtype=torch.int32).cuda()
+    d_v2p = torch.full((300, 33), 9, dtype=torch.int32).cuda()
+    d_v0 = torch.full((1,), 9, dtype=torch.int32).cuda()
+    d_cols = torch.full((2, 20, 256), 9.0).cuda()
+    d_r = torch.full((4, 3, 3), 9.0).cuda()
+    src_r = torch.randn(4, 9, generator=g).cuda()
+    dcl.ops.pad_copy_many([(d_feats, feats), (d_occ, occ), (d_v2p, v2p), (d_v0, 123), (d_cols, wide[:, 256:]), (d_r, src_r)])
+    assert torch.equal(d_feats, feats)
+    assert torch.equal(d_occ[:123], occ.int()) and int(d_occ[123:].abs().sum()) == 0
+    assert torch.equal(d_v2p[:123, :5], v2p) and int(d_v2p[:123, 5:].abs().sum()) == 0 and int(d_v2p[123:].abs().sum()) == 0
+    assert int(d_v0[0]) == 123
+    assert torch.equal(d_cols.reshape(40, 256), wide[:, 256:]) and torch.equal(d_r.reshape(4, 9), src_r)
+    with pytest.raises(RuntimeError):
+        dcl.ops.pad_copy_many([(d_feats, feats)] * 13)                     # more jobs than one launch takes
+
+
 # ------------------------------------------------------------------------------------------- native backbone runner
 def _edge_voxels(rng, S=64):
     """crop 0: random blob touching the 0 and S-1 faces; crop 1: EMPTY; crop 2: one voxel in a corner; crop 3: dense 6^3 block

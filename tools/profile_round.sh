@@ -5,7 +5,7 @@
 #                                       gpurun_out/r1_pmcprim_<COUNTER>/        (north-star primitives)
 # then, back in the container: python tools/summarize_profiles.py r1  (copies the summaries into profiles/).
 # PMC passes are separate runs with --kernel-trace only, as the pool requires.
-R=${1:-r1}
+R=${1:-r2}
 export TMPDIR=/tmp
 cd "$(dirname "$0")/.." || exit 1
 O=gpurun_out
