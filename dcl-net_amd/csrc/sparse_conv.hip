@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void k_sparse_conv_mfma(
         }
       }
     }
-    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // MFMA -> VALU read of the accumulator (see k_sparse_conv_lds)
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // MFMA -> VALU read of the accumulator (hipcc 7.2 omitted the wait states when the accumulator is re-read behind a barrier: stale acc[15])
     // C/D layout: col = lane&31 (cout within tile), row = (e&3) + 8*(e>>2) + 4*(lane>>5)
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -179,129 +179,6 @@ __global__ __launch_bounds__(256) void k_sparse_conv_mfma(
         }
       }
     }
-  }
-}
-
-// ---- MFMA kernel, weights through LDS: Cin in {16,32,64,128}, Cout % (32*NT) == 0 -------------------------
-// workgroup = 4 waves = 128 consecutive output rows x (32*NT) output channels.  Per kernel offset k that ANY of
-// the 128 rows uses (27-bit workgroup mask; the rest are skipped), the W[k] tile (Cin x 32NT floats) is staged
-// once in LDS and shared by the 4 waves -- double-buffered: the next used offset's tile is fetched into
-// registers while the current one feeds the MFMAs.  Each lane pulls its own gathered input row (A operand)
-// for the whole offset with Cin/8 independent 16-B loads issued back to back, so their latency overlaps.
-template <int CIN, int NT>
-__global__ __launch_bounds__(256, 2) void k_sparse_conv_lds(
-    const float *__restrict__ feat, const DclNbrSrc src, int cap, const int32_t *__restrict__ n_out_dev,
-    int n_out_host, const float *__restrict__ W, int cout, int kvol, int subm, const float *__restrict__ scale,
-    const float *__restrict__ shift, int relu, float *__restrict__ out) {
-  constexpr int BN = 32 * NT;                    // output channels per workgroup
-  constexpr int TILE = CIN * BN;                 // floats per staged W[k] tile
-  constexpr int LD4 = TILE / 4 / 256 > 0 ? TILE / 4 / 256 : 1;   // float4 per thread per tile
-  __shared__ __attribute__((aligned(16))) float Bs[2][TILE];
-  __shared__ unsigned s_kmask;
-  int n = n_out_dev ? *n_out_dev : n_out_host;
-  n = n < cap ? n : cap;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, h = lane >> 5;
-  const int col0 = blockIdx.y * BN;
-  const int nblk = (n + 127) >> 7;
-  for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-    const int row = blk * 128 + wave * 32 + r;
-    const bool valid = row < n;
-    // which offsets does this workgroup need?
-    unsigned mymask = 0;
-    if (valid)
-      for (int k = 0; k < kvol; ++k) mymask |= (dcl_nbr_at(src, cap, k, row) >= 0 ? 1u : 0u) << k;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) mymask |= __shfl_xor(mymask, d, 64);
-    if (tid == 0) s_kmask = 0;
-    __syncthreads();
-    if (lane == 0 && mymask) atomicOr(&s_kmask, mymask);
-    __syncthreads();
-    const unsigned kmask = s_kmask;
-
-    f32x16 acc[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[j][e] = 0.0f;
-
-    // ordered list of used offsets is walked with a step cursor
-    int s = 0;
-    auto next_used = [&](int from) {
-      int q = from;
-      while (q < kvol && !((kmask >> offset_at(q, kvol, subm)) & 1u)) ++q;
-      return q;
-    };
-    s = next_used(0);
-    float4 breg[LD4];
-    // float4 slot of this thread inside the tile (clamped: when the tile has < 256 slots the surplus threads
-    // re-load / re-store the last slot, which keeps the staging registers branch-free)
-    auto slot = [&](int i) { const int f4 = tid + i * 256; return f4 < TILE / 4 ? f4 : TILE / 4 - 1; };
-    auto fetch_tile = [&](int k) {
-      const float *wp = W + (size_t)k * CIN * cout + col0;
-#pragma unroll
-      for (int i = 0; i < LD4; ++i) {
-        const int f4 = slot(i);
-        const int ci = f4 / (BN / 4), c4 = (f4 - ci * (BN / 4)) * 4;
-        breg[i] = *reinterpret_cast<const float4 *>(wp + (size_t)ci * cout + c4);
-      }
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-      for (int i = 0; i < LD4; ++i) *reinterpret_cast<float4 *>(&Bs[buf][slot(i) * 4]) = breg[i];
-    };
-    int cur = 0;
-    if (s < kvol) { fetch_tile(offset_at(s, kvol, subm)); store_tile(0); }
-    __syncthreads();
-    while (s < kvol) {
-      const int k = offset_at(s, kvol, subm);
-      const int s_next = next_used(s + 1);
-      if (s_next < kvol) fetch_tile(offset_at(s_next, kvol, subm));       // global loads in flight during the MFMAs
-      const int v = valid ? dcl_nbr_at(src, cap, k, row) : -1;
-      if (__ballot(v >= 0) != 0ull) {                                       // this wave's 32 rows use offset k
-        float4 a[CIN / 8];
-        const float *fp = feat + (size_t)(v >= 0 ? v : 0) * CIN + h * 4;
-#pragma unroll
-        for (int i = 0; i < CIN / 8; ++i) {
-          a[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (v >= 0) a[i] = *reinterpret_cast<const float4 *>(fp + 8 * i);
-        }
-        const float *bp = &Bs[cur][(h * 4) * BN + r];
-#pragma unroll
-        for (int i = 0; i < CIN / 8; ++i) {
-          const float av[4] = {a[i].x, a[i].y, a[i].z, a[i].w};
-#pragma unroll
-          for (int t = 0; t < 4; ++t)                 // MFMA step contracts channels {8i+t, 8i+4+t}
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-              acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bp[(8 * i + t) * BN + j * 32], acc[j], 0, 0, 0);
-        }
-        // hipcc (ROCm 7.2) re-reads the accumulator at the loop header right behind the barrier without the
-        // MFMA -> VALU wait states for its last register (seen as stale acc[15] on ~0.5 % of rows): pad here.
-        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
-      }
-      if (s_next < kvol) store_tile(cur ^ 1);
-      __syncthreads();
-      cur ^= 1;
-      s = s_next;
-    }
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int co = col0 + j * 32 + r;
-      const float sc = scale ? scale[co] : 1.0f;
-      const float sh = scale ? shift[co] : 0.0f;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int orow = blk * 128 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (orow < n) {
-          float x = acc[j][e];
-          if (scale) x = x * sc + sh;
-          if (relu) x = fmaxf(x, 0.0f);
-          out[(size_t)orow * cout + co] = x;
-        }
-      }
-    }
-    __syncthreads();                                   // s_kmask / Bs are reused by the next row block
   }
 }
 
@@ -454,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void k_sparse_conv_tile(
           for (int t = 0; t < 4; ++t) b_cur[t] = b_nxt[t];
         }
       }
-      asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // MFMA -> VALU hazard pad (see k_sparse_conv_lds)
+      asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // MFMA -> VALU hazard pad (hipcc 7.2 omitted the wait states when the accumulator is re-read behind a barrier: stale acc[15])
       j = jn;
     }
     const int co = col0 + wc * 32 + r;
@@ -603,6 +480,7 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
     unsigned mymask = 0;
     const int sx_lo = (j_begin * KC) / CIN;
     const int sx_hi = min(kvol - 1, (nchunks * KC - 1) / CIN);
+#pragma unroll 4                                           // several rounds of lookups in flight (2-3 dependent loads each)
     for (int e = tid; e < (sx_hi - sx_lo + 1) * BM; e += NTHR) {
       const int si = e / BM, rr = e - si * BM;
       const int k = offset_at(sx_lo + si, kvol, subm);
@@ -771,7 +649,7 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
         }
         (void)bcol;
       }
-      asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // MFMA -> VALU hazard pad (see k_sparse_conv_lds)
+      asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // MFMA -> VALU hazard pad (hipcc 7.2 omitted the wait states when the accumulator is re-read behind a barrier: stale acc[15])
       PH(ph_mfma);
 #ifdef DCL_CONV_STAMPS
       ++ph_n;
@@ -1193,7 +1071,7 @@ __global__ void k_sparse_avgpool_scalar(const float *__restrict__ feat, const Dc
 
 }  // namespace
 
-static std::atomic<int> g_force_valu{0};   // test hook: 1 = plain VALU kernel for every conv, 2 = MFMA kernel without LDS staging, 3 = LDS-weights kernel, 4 = register-staged tile kernel instead of the LDS-DMA one
+static std::atomic<int> g_force_valu{0};   // test hook: 1 = plain VALU kernel for every conv, 2 = MFMA kernel without LDS staging (the general Cin % 8 fallback), 4 = register-staged tile kernel instead of the LDS-DMA one, 5 = 8-wave 128x64 tiles for Cout = 64
 DCL_API void dcl_debug_force_valu_conv(int on) { g_force_valu = on; }
 
 DCL_API void dcl_debug_conv_split(int n) { g_conv_split = n; }
@@ -1322,7 +1200,7 @@ static int conv_dispatch(const float *feat, const DclNbrSrc &nbr, int cap, const
   hipStream_t s = (hipStream_t)stream;
   const bool mfma_ok = g_force_valu != 1 && (cin % 8 == 0) && (cout % 32 == 0);
   const bool lds_ok = mfma_ok && g_force_valu != 2 && (cin == 16 || cin == 32 || cin == 64 || cin == 128);
-  if (lds_ok && g_force_valu != 3) {
+  if (lds_ok) {
     // implicit-GEMM tile kernel: 64x64 tiles (KC=128) when Cout allows, else 128x32 tiles (KC=64)
 #define TILE_ARGS rows, feat, nbr, cap, n_out_dev, n_out_host, W, cout, kvol, subm, scale, shift, relu, out, scratch, \
                   (long long)scratch_floats, counters_ready, s
@@ -1373,23 +1251,6 @@ static int conv_dispatch(const float *feat, const DclNbrSrc &nbr, int cap, const
     }
 #undef DMA_ARGS
 #undef TILE_ARGS
-  } else if (lds_ok) {
-    const int nblk = dcl_div_up(rows, 128);
-    // 64 output channels per workgroup when that still leaves >= ~3 workgroups per CU, else 32
-    const int nt = (cout % 64 == 0 && (long long)nblk * (cout / 64) >= 768) ? 2 : 1;
-    const dim3 grid(nblk < 65535 ? nblk : 65535, cout / (32 * nt));
-#define CONV_LDS(C, T)                                                                                          \
-  hipLaunchKernelGGL((k_sparse_conv_lds<C, T>), grid, dim3(256), 0, s, feat, nbr, cap, n_out_dev, n_out_host, W, \
-                     cout, kvol, subm, scale, shift, relu, out)
-#define CONV_LDS_C(C) do { if (nt == 2) CONV_LDS(C, 2); else CONV_LDS(C, 1); } while (0)
-    switch (cin) {
-      case 16: CONV_LDS_C(16); break;
-      case 32: CONV_LDS_C(32); break;
-      case 64: CONV_LDS_C(64); break;
-      default: CONV_LDS_C(128); break;
-    }
-#undef CONV_LDS_C
-#undef CONV_LDS
   } else if (mfma_ok) {
     const int ntiles = dcl_div_up(rows, 32);
     const int nt = (cout % 64 == 0 && (long long)ntiles * (cout / 64) >= 4096) ? 2 : 1;

@@ -125,7 +125,7 @@ def test_sparse_conv_matches_oracle(dcl, oracle, cin, cout, subm):
     assert np.abs(got - want).max() <= tol
     # MFMA kernel vs plain VALU kernel on the device (A/B)
     lib = dcl._native.lib()
-    for mode in (1, 2, 3, 4):                                  # 1: VALU, 2: MFMA no LDS, 3: MFMA + LDS weights, 4: reg-staged tiles
+    for mode in (1, 2, 4, 5):                                  # 1: VALU, 2: MFMA no LDS, 4: reg-staged tiles, 5: 8-wave 128x64
         lib.dcl_debug_force_valu_conv(mode)
         try:
             alt = dcl.ops.sparse_conv(cuda(feat), nbr, n_out, Wd, subm).cpu().numpy()
@@ -173,6 +173,35 @@ def test_sparse_conv_split_k_in_launch_combine(dcl, oracle, cin, cout, subm):
                 assert float((e1 - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
     finally:
         lib.dcl_debug_conv_split(0)
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 32), (32, 64), (64, 128)])
+def test_sparse_conv_decompositions_agree_across_sizes(dcl, cin, cout):
+    """row counts from a handful of tiles to tens of thousands of rows drive the launcher through its decompositions
+    (deferred-combine few-row mode, aligned split-K, stream-K, whole tiles); every one must agree with the plain VALU
+    kernel on the same rulebook, with and without the BN+ReLU epilogue"""
+    rng = np.random.default_rng(cin)
+    lib = dcl._native.lib()
+    W = cuda((rng.normal(size=(27, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32))
+    s_, t_ = cuda(rng.uniform(0.5, 1.5, cout).astype(np.float32)), cuda(rng.normal(size=cout).astype(np.float32))
+    for b, S, per in ((1, 8, 130), (2, 16, 900), (6, 16, 1500), (8, 32, 5000)):
+        idx = rand_voxels(rng, b, S, per)
+        aset = dcl.ops.grid_from_indices(cuda(idx), b, S)
+        for subm in (True, False):
+            out, nbr = dcl.spconv.ops.build_rulebook(aset, 3, 1, 1, subm)
+            n_out = idx.shape[0] if subm else out.n
+            feat = cuda(rng.normal(size=(idx.shape[0], cin)).astype(np.float32))
+            got = dcl.ops.sparse_conv(feat, nbr, n_out, W, subm)
+            got2 = dcl.ops.sparse_conv(feat, nbr, n_out, W, subm, s_, t_, True)
+            lib.dcl_debug_force_valu_conv(1)
+            try:
+                ref = dcl.ops.sparse_conv(feat, nbr, n_out, W, subm)
+            finally:
+                lib.dcl_debug_force_valu_conv(0)
+            tol = 2e-5 * max(1.0, float(ref.abs().max()))
+            assert float((got - ref).abs().max()) <= tol, (b, S, per, subm)
+            assert float((got2 - torch.relu(ref * s_ + t_)).abs().max()) <= 2 * tol, (b, S, per, subm)
+            assert torch.equal(got, dcl.ops.sparse_conv(feat, nbr, n_out, W, subm))          # reproducible
 
 
 @pytest.mark.parametrize("c", [32, 7])
