@@ -801,6 +801,24 @@ DCL_API int dcl_cross_attention_ws(int b, int nq, int nk, const float *Q, int ld
       // few workgroups (small batches): split the keys over up to 8 workgroups per query block, >= 2 tiles per split
       const long long blocks4 = (long long)b * dcl_div_up(nq, 128);
       int nsplit = 1;
+      if (scratch && blocks4 >= 192) {
+        // one 4-wave workgroup per CU (LDS): blocks4 workgroups run in ceil(blocks4/256) rounds; a mostly empty last
+        // round (bs 40 at N = 1024: 320 workgroups = 2 rounds for 1.25 rounds of work) is split over the keys like the
+        // 8-wave launches above
+        if (g_attn_split > 0) {
+          nsplit = g_attn_split;
+        } else {
+          double best = (double)dcl_div_up(blocks4, 256);
+          for (int z = 2; z <= 8; z *= 2) {
+            const double cost = (double)dcl_div_up(blocks4 * z, 256) / z;
+            if (cost <= best - 0.2 && (long long)z * b * nq * kAttnPartPitch <= (128ll << 20)) { best = cost; nsplit = z; }
+          }
+        }
+        const int ntiles = dcl_div_up(nk, 32);
+        if (nsplit > ntiles / 2) nsplit = ntiles / 2;
+        while (nsplit > 1 && (long long)nsplit * b * nq * kAttnPartPitch > scratch_floats) --nsplit;
+        if (nsplit < 1) nsplit = 1;
+      }
       if (scratch && blocks4 < 192) {
         nsplit = g_attn_split > 0 ? g_attn_split.load() : (int)dcl_div_up(256, blocks4);
         const int ntiles = dcl_div_up(nk, 32);
