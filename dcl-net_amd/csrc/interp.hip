@@ -121,38 +121,70 @@ __global__ __launch_bounds__(64) void k_three_nn_sp(int n, int m, const float4 *
 // is below that (with a 1e-4 margin for rounding) the answer is the global one, ties included (keys order (d, row)
 // exactly like the sequential scan of interpolate_gpu.cu:36-38).  Otherwise -- isolated queries, queries outside
 // the grid -- the thread scans its crop's rows.
+// mask_lk / pre_lk + wbase: where the window lookups read the occupancy words and rank prefixes from -- the global
+// arrays (wbase = 0) or the LDS copy of the point's crop (wbase = first word of the crop), see k_three_nn_grid_levels
 __device__ __forceinline__ void three_nn_grid_point(int p, const float4 u, const int4 *__restrict__ indices,
                                                     const uint32_t *__restrict__ mask,
                                                     const int32_t *__restrict__ wprefix, int nbatch, int S, int wpc,
                                                     float ve, float off, float *__restrict__ dist2,
-                                                    int32_t *__restrict__ idx, int force_scan) {
+                                                    int32_t *__restrict__ idx, int force_scan,
+                                                    const uint32_t *mask_lk, const int32_t *pre_lk, int wbase) {
   const float half = 0.5f * ve;
   Top3 b; b.init();
   const int bi = (int)u.x;
   if (bi >= 0 && bi < nbatch && (float)bi == u.x) {
     const float pc[3] = {u.y, u.z, u.w};
-    int lo[3], hi[3];
+    int lo[3], hi[3], cc[3];
     float bound = INFINITY;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const float f = floorf((pc[a] - off) / ve);
       const int ci = f >= (float)(S - 1) ? S - 1 : (f > 0.0f ? (int)f : 0);            // NaN -> 0
+      cc[a] = ci;
       lo[a] = max(ci - 2, 0); hi[a] = min(ci + 2, S - 1);
       if (ci - 3 >= 0) bound = fminf(bound, pc[a] - (((float)(ci - 3) * ve + off) + half));
       if (ci + 3 <= S - 1) bound = fminf(bound, (((float)(ci + 3) * ve + off) + half) - pc[a]);
     }
     const uint32_t zmask = (hi[2] - lo[2] == 31) ? 0xffffffffu : ((1u << (hi[2] - lo[2] + 1)) - 1u);
-    if (!force_scan)
-      for (int x = lo[0]; x <= hi[0]; ++x) {
+    // The window is visited from the point's own cell outwards, and a plane / a z-row is skipped once it cannot hold
+    // anything better than the third best key so far: dcl_dist2 = fma(dz,dz, fma(dx,dx, dy*dy)) >= fma(dx,dx, dy*dy)
+    // >= dx*dx in floating point too (dz*dz, dy*dy >= 0 and rounding is monotone), so "row bound > d3" excludes every key
+    // of the row, ties included (an equal distance is not pruned).  Until three candidates exist d3 reads as NaN: no pruning.
+    // The set of the three smallest keys does not depend on the visiting order.
+    if (!force_scan) {
+      const int order[5] = {0, -1, 1, -2, 2};
+#pragma unroll
+      for (int ix = 0; ix < 5; ++ix) {
+        const int x = cc[0] + order[ix];
+        if (x < lo[0] || x > hi[0]) continue;
         const float qx = ((float)x * ve + off) + half;
-        for (int y = lo[1]; y <= hi[1]; ++y) {
+        const float dx = u.y - qx;
+        if (dx * dx > __uint_as_float((unsigned)(b.k3 >> 32))) continue;
+        // the (up to) five z-rows of this x-plane: mask words and rank prefixes are fetched together (independent
+        // loads) before any bit is examined -- one exposed memory latency per plane instead of two per row
+        uint32_t mw[5];
+        int pw[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          const int yy = cc[1] + order[j];
+          const int y = yy < lo[1] ? lo[1] : (yy > hi[1] ? hi[1] : yy);
+          const int w = ((((bi * S + x) * S + y) * S) >> 5) - wbase;
+          mw[j] = mask_lk[w];
+          pw[j] = pre_lk[w];
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          const int y = cc[1] + order[j];
+          if (y < lo[1] || y > hi[1]) continue;
           const int lin0 = ((bi * S + x) * S + y) * S;
-          const int w = lin0 >> 5, sh = lin0 & 31;
-          const uint32_t m = mask[w];
+          const int sh = lin0 & 31;
+          const uint32_t m = mw[j];
           uint32_t bits = (m >> (sh + lo[2])) & zmask;
           if (bits == 0u) continue;
-          const int pre = wprefix[w];
           const float qy = ((float)y * ve + off) + half;
+          const float dy = u.z - qy;
+          if (__fmaf_rn(dx, dx, dy * dy) > __uint_as_float((unsigned)(b.k3 >> 32))) continue;
+          const int pre = pw[j];
           while (bits) {
             const int t = __builtin_ctz(bits);
             bits &= bits - 1u;
@@ -163,6 +195,7 @@ __device__ __forceinline__ void three_nn_grid_point(int p, const float4 u, const
           }
         }
       }
+    }
     const float d3 = __uint_as_float((unsigned)(b.k3 >> 32));
     const bool certified = !force_scan && (bound == INFINITY || d3 < bound * bound * 0.9999f) && !(bound < 0.0f);
     if (!certified) {
@@ -186,49 +219,89 @@ __global__ __launch_bounds__(256) void k_three_nn_grid(int n, const float4 *__re
                                                        float ve, float off, float *__restrict__ dist2,
                                                        int32_t *__restrict__ idx, int force_scan) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < n) three_nn_grid_point(p, unknown[p], indices, mask, wprefix, nbatch, S, wpc, ve, off, dist2, idx, force_scan);
+  if (p < n) three_nn_grid_point(p, unknown[p], indices, mask, wprefix, nbatch, S, wpc, ve, off, dist2, idx, force_scan, mask, wprefix, 0);
 }
 
 // all 4 levels of the read-out in one launch (blockIdx.y = level); dist2 / idx are level-major blocks of n*3
+// Window lookups are per-lane gathers of single words: from global memory every lane of a load hits its own cache line
+// (2 x 25 such loads per point and level: the kernel was bound by the request rate, not by arithmetic).  A crop's
+// occupancy words and rank prefixes of one level are at most 2 x 4 KB (32^3 cells), so a workgroup whose 256 points
+// belong to one crop -- the runner's point rows are crop-contiguous -- stages them in LDS first.
+constexpr int kNnLdsWords = 1024;
 __global__ __launch_bounds__(256) void k_three_nn_grid_levels(int n, const float4 *__restrict__ unknown,
                                                               const DclReadoutLevels L, int nbatch, float off,
                                                               float *__restrict__ dist2, int32_t *__restrict__ idx,
                                                               int force_scan) {
+  __shared__ uint32_t s_mask[kNnLdsWords];
+  __shared__ int32_t s_pre[kNnLdsWords];
   const int p = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+  const int wpc = L.wpc[m];
+  const float4 u = p < n ? unknown[p] : make_float4(-1.f, 0.f, 0.f, 0.f);
+  const float4 u0 = unknown[blockIdx.x * blockDim.x];                       // uniform: the block's first point
+  const int b0 = (int)u0.x;
+  const bool crop_ok = b0 >= 0 && b0 < nbatch && (float)b0 == u0.x && wpc <= kNnLdsWords;
+  const int same = __syncthreads_and((p >= n || u.x == u0.x) ? 1 : 0);
+  const bool staged = crop_ok && same;
+  if (staged) {
+    for (int i = threadIdx.x; i < wpc; i += 256) {
+      s_mask[i] = L.mask[m][(size_t)b0 * wpc + i];
+      s_pre[i] = L.wprefix[m][(size_t)b0 * wpc + i];
+    }
+    __syncthreads();
+  }
   if (p < n)
-    three_nn_grid_point(p, unknown[p], reinterpret_cast<const int4 *>(L.indices[m]), L.mask[m], L.wprefix[m], nbatch,
-                        L.S[m], L.wpc[m], L.ve[m], off, dist2 + (size_t)m * n * 3, idx + (size_t)m * n * 3, force_scan);
+    three_nn_grid_point(p, u, reinterpret_cast<const int4 *>(L.indices[m]), L.mask[m], L.wprefix[m], nbatch, L.S[m], wpc,
+                        L.ve[m], off, dist2 + (size_t)m * n * 3, idx + (size_t)m * n * 3, force_scan,
+                        staged ? s_mask : L.mask[m], staged ? s_pre : L.wprefix[m], staged ? b0 * wpc : 0);
 }
 
-// inverse-distance interpolation of all 4 levels into the (n, ld) row buffer in one launch: thread = 4 channels of a
-// point, levels side by side (same arithmetic as k_three_interpolate_sp<true>)
-__global__ void k_three_interpolate_levels(int n, const DclReadoutLevels L, const int32_t *__restrict__ idx,
-                                           const float *__restrict__ dist2, float *__restrict__ out, int ld) {
+// workgroup = kInterpPts points x all 4 levels: the three weights of a (point, level) pair -- square roots and
+// correctly rounded divisions -- are formed ONCE into LDS (they used to be recomputed by each of the level's C/4
+// threads: most of the kernel's VALU work), then the 480 channels stream out as 16-B nontemporal stores (the rows are
+// read once, much later, by the disengage GEMM: no point in allocating them in L2).  Same arithmetic, same bits.
+constexpr int kInterpPts = 32;
+__global__ __launch_bounds__(256) void k_three_interpolate_levels(int n, const DclReadoutLevels L,
+                                                                  const int32_t *__restrict__ idx,
+                                                                  const float *__restrict__ dist2, float *__restrict__ out,
+                                                                  int ld) {
+  __shared__ float s_w[kInterpPts * 4][3];
+  __shared__ int32_t s_i[kInterpPts * 4][3];
   const int q0 = L.c[0] >> 2, q1 = q0 + (L.c[1] >> 2), q2 = q1 + (L.c[2] >> 2), qn = q2 + (L.c[3] >> 2);
-  const long long total = (long long)n * qn;
-  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
-       t += (long long)gridDim.x * blockDim.x) {
-    const int p = (int)(t / qn);
-    int q = (int)(t - (long long)p * qn);
-    const int m = q < q0 ? 0 : (q < q1 ? 1 : (q < q2 ? 2 : 3));
-    q -= m == 0 ? 0 : (m == 1 ? q0 : (m == 2 ? q1 : q2));
-    const size_t o = ((size_t)m * n + p) * 3;
-    const int i0 = idx[o], i1 = idx[o + 1], i2 = idx[o + 2];
-    const float r0 = 1.0f / (sqrtf(dist2[o]) + 1e-8f), r1 = 1.0f / (sqrtf(dist2[o + 1]) + 1e-8f),
-                r2 = 1.0f / (sqrtf(dist2[o + 2]) + 1e-8f);
-    const float norm = (r0 + r1) + r2;
-    const float w0 = r0 / norm, w1 = r1 / norm, w2 = r2 / norm;
-    const int c = L.c[m];
-    const float *__restrict__ F = L.feats[m];
-    const float4 a = reinterpret_cast<const float4 *>(F + (size_t)i0 * c)[q];
-    const float4 b = reinterpret_cast<const float4 *>(F + (size_t)i1 * c)[q];
-    const float4 d = reinterpret_cast<const float4 *>(F + (size_t)i2 * c)[q];
-    float4 v;
-    v.x = dcl_wsum3(w0, a.x, w1, b.x, w2, d.x);
-    v.y = dcl_wsum3(w0, a.y, w1, b.y, w2, d.y);
-    v.z = dcl_wsum3(w0, a.z, w1, b.z, w2, d.z);
-    v.w = dcl_wsum3(w0, a.w, w1, b.w, w2, d.w);
-    reinterpret_cast<float4 *>(out + (size_t)p * ld + L.col[m])[q] = v;
+  for (int p0 = blockIdx.x * kInterpPts; p0 < n; p0 += gridDim.x * kInterpPts) {
+    __syncthreads();
+    if (threadIdx.x < kInterpPts * 4) {
+      const int pl = threadIdx.x / 4, m = threadIdx.x & 3, p = p0 + pl;
+      if (p < n) {
+        const size_t o = ((size_t)m * n + p) * 3;
+        const float r0 = 1.0f / (sqrtf(dist2[o]) + 1e-8f), r1 = 1.0f / (sqrtf(dist2[o + 1]) + 1e-8f),
+                    r2 = 1.0f / (sqrtf(dist2[o + 2]) + 1e-8f);
+        const float norm = (r0 + r1) + r2;
+        s_w[threadIdx.x][0] = r0 / norm; s_w[threadIdx.x][1] = r1 / norm; s_w[threadIdx.x][2] = r2 / norm;
+        s_i[threadIdx.x][0] = idx[o]; s_i[threadIdx.x][1] = idx[o + 1]; s_i[threadIdx.x][2] = idx[o + 2];
+      }
+    }
+    __syncthreads();
+    const int npts = n - p0 < kInterpPts ? n - p0 : kInterpPts;
+    for (int t = threadIdx.x; t < npts * qn; t += 256) {
+      const int pl = t / qn;
+      int q = t - pl * qn;
+      const int m = q < q0 ? 0 : (q < q1 ? 1 : (q < q2 ? 2 : 3));
+      q -= m == 0 ? 0 : (m == 1 ? q0 : (m == 2 ? q1 : q2));
+      const int e = pl * 4 + m;
+      const float w0 = s_w[e][0], w1 = s_w[e][1], w2 = s_w[e][2];
+      const int c = L.c[m];
+      const float *__restrict__ F = L.feats[m];
+      const float4 a = reinterpret_cast<const float4 *>(F + (size_t)s_i[e][0] * c)[q];
+      const float4 b = reinterpret_cast<const float4 *>(F + (size_t)s_i[e][1] * c)[q];
+      const float4 d = reinterpret_cast<const float4 *>(F + (size_t)s_i[e][2] * c)[q];
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      f4 v;
+      v.x = dcl_wsum3(w0, a.x, w1, b.x, w2, d.x);
+      v.y = dcl_wsum3(w0, a.y, w1, b.y, w2, d.y);
+      v.z = dcl_wsum3(w0, a.z, w1, b.z, w2, d.z);
+      v.w = dcl_wsum3(w0, a.w, w1, b.w, w2, d.w);
+      __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(out + (size_t)(p0 + pl) * ld + L.col[m]) + q);
+    }
   }
 }
 
@@ -430,8 +503,9 @@ int dcl_internal_readout_interpolate(int n, const DclReadoutLevels &L, const int
                                      int ld, dclStream_t stream) {
   DCL_CHECK_ARG(n > 0 && idx && dist2 && out);
   const long long quads = (long long)n * ((L.c[0] + L.c[1] + L.c[2] + L.c[3]) / 4);
-  hipLaunchKernelGGL(k_three_interpolate_levels, dim3(dcl_grid_1d(quads, 256)), dim3(256), 0, (hipStream_t)stream, n, L,
-                     idx, dist2, out, ld);
+  (void)quads;
+  hipLaunchKernelGGL(k_three_interpolate_levels, dim3(dcl_grid_1d(n, kInterpPts, 256 * 32)), dim3(256), 0,
+                     (hipStream_t)stream, n, L, idx, dist2, out, ld);
   DCL_LAUNCH_CHECK();
   return 0;
 }

@@ -147,12 +147,14 @@ int dcl_sparse_conv_fwd(const float *feat, const int32_t *nbr, int cap, const in
                         const float *scale, const float *shift, int relu, float *out,
                         dclStream_t stream);
 
-/* Same, with caller scratch: layers whose row count cannot fill the GPU split the 27*Cin contraction over up to 8
- * workgroup groups -- up to 27, one per kernel offset, when cap <= 4096 rows (one-image calls are latency-bound on the
- * contraction loop; with n_out_dev, i.e. in capacity mode, launches of up to 65536 capacity rows count as such too, and
- * the Cout = 32 layers split as well) -- with partial sums in `scratch`, added in split order by a second kernel, then
- * the epilogue.
- * scratch_floats >= dcl_sparse_conv_scratch_floats(cap, cout) enables every split; NULL = dcl_sparse_conv_fwd.   */
+/* Same, with caller scratch (partial-tile slots + tile tickets): the launch's chunk units -- tile-major, 27*Cin/32 chunks
+ * per 128 x {32,64,128} output tile -- are dealt evenly to the 2 x 256 resident workgroup slots ("stream-K"), or the tiles
+ * are split into aligned K segments, or kept whole, whichever a small cost model prefers; partial tiles are combined
+ * INSIDE the launch by the workgroup that draws a tile's last ticket, in ascending chunk order (deterministic), then the
+ * epilogue.  Launches of a few rows (cap <= 4096, or <= 65536 capacity rows with n_out_dev: one-image calls are
+ * latency-bound on the contraction loop) take 4 chunks per workgroup and combine in a second small launch.
+ * The first 8192 int32 of `scratch` are the tickets: the call zeroes them (they are left zero).
+ * scratch_floats >= dcl_sparse_conv_scratch_floats(cap, cout) enables every decomposition; NULL = whole tiles only.   */
 int dcl_sparse_conv_fwd_ws(const float *feat, const int32_t *nbr, int cap, const int32_t *n_out_dev,
                            int n_out_host, const float *W, int cin, int cout, int kvol, int subm,
                            const float *scale, const float *shift, int relu, float *out, float *scratch,
