@@ -216,6 +216,8 @@ def lm_stream_bench(dcl, dev, reps=30):
             torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / reps * 1e3
         out[name] = {"ms_per_frame": round(ms, 3), "frames_per_s": round(1e3 / ms, 1)}
+    ent = next(iter(getattr(net, "_graphs", {}).values()), None)
+    out["hipgraph"]["kernel_nodes"] = None if ent is None else ent.get("nodes")
     return out
 
 

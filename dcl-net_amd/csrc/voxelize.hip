@@ -45,8 +45,21 @@ namespace {
 struct PadCopyJobs {
   DclPadCopyJob job[DCL_PAD_COPY_MAX_JOBS];
 };
-__global__ void k_pad_copy_many(const PadCopyJobs jobs) {
+__global__ void k_pad_copy_many(const PadCopyJobs jobs, unsigned vec_mask) {
   const DclPadCopyJob &q = jobs.job[blockIdx.y];
+  if ((vec_mask >> blockIdx.y) & 1u) {            // every width / pitch a multiple of 4 elements, 16-B aligned: 16-B moves
+    const int cd = q.cols_dst >> 2, cs = q.cols_src >> 2, sp = q.src_pitch >> 2, dp = q.dst_pitch >> 2;
+    const long long total = (long long)q.rows_dst * cd;
+    int4 *dst = reinterpret_cast<int4 *>(q.dst);
+    const int4 *src = reinterpret_cast<const int4 *>(q.src);
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+      const int r = (int)(t / cd), c = (int)(t - (long long)r * cd);
+      int4 v = make_int4(0, 0, 0, 0);
+      if (r < q.rows_src && c < cs) v = src[(size_t)r * sp + c];
+      dst[dp > 0 ? (size_t)r * dp + c : (size_t)t] = v;
+    }
+    return;
+  }
   const long long total = (long long)q.rows_dst * q.cols_dst;
   int32_t *dst = reinterpret_cast<int32_t *>(q.dst);
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
@@ -58,7 +71,7 @@ __global__ void k_pad_copy_many(const PadCopyJobs jobs) {
     } else if (q.src) {
       v = 0;
     }
-    dst[t] = v;
+    dst[q.dst_pitch > 0 ? (size_t)r * q.dst_pitch + c : (size_t)t] = v;
   }
 }
 }  // namespace
@@ -67,15 +80,20 @@ DCL_API int dcl_pad_copy_many(const DclPadCopyJob *jobs_host, int njobs, dclStre
   DCL_CHECK_ARG(jobs_host && njobs >= 1 && njobs <= DCL_PAD_COPY_MAX_JOBS);
   PadCopyJobs pack;
   long long most = 1;
+  unsigned vec_mask = 0;
   for (int j = 0; j < njobs; ++j) {
     const DclPadCopyJob &q = jobs_host[j];
+    if (q.src && !q.src_is_i64 && ((q.cols_dst | q.cols_src | q.src_pitch | q.dst_pitch) & 3) == 0 &&
+        ((((uintptr_t)q.dst) | ((uintptr_t)q.src)) & 15) == 0)
+      vec_mask |= 1u << j;
     DCL_CHECK_ARG(q.dst && q.rows_dst >= 0 && q.cols_dst >= 0 && q.rows_src >= 0 && q.cols_src >= 0 &&
-                  q.src_pitch >= q.cols_src);
+                  q.src_pitch >= q.cols_src && (q.dst_pitch == 0 || q.dst_pitch >= q.cols_dst));
     pack.job[j] = q;
     const long long t = (long long)q.rows_dst * q.cols_dst;
     if (t > most) most = t;
   }
-  hipLaunchKernelGGL(k_pad_copy_many, dim3(dcl_grid_1d(most, 256, 1024), njobs), dim3(256), 0, (hipStream_t)stream, pack);
+  hipLaunchKernelGGL(k_pad_copy_many, dim3(dcl_grid_1d(most / 4 + 1, 256, 4096), njobs), dim3(256), 0, (hipStream_t)stream,
+                     pack, vec_mask);
   DCL_LAUNCH_CHECK();
   return 0;
 }

@@ -390,8 +390,10 @@ class Network(nn.Module):
         fuse2 = torch.empty((nM, 512), dtype=torch.float32, device=dev)      # cat[F_Yc_p, F_Yo_p2]
         conf_in2 = torch.empty((nM, 128), dtype=torch.float32, device=dev)   # cat[F_Yc_m, F_Yo_m2]
         (l1, sA, tA), (l2, sB, tB) = f["neck_fuser"], f["neck_fuser_bi"]
+        # the four column blocks that the attention does not write, in one launch
+        ops.pad_copy_many([(fuse1[:, :256], act["Xcp1"]), (conf_in1[:, :64], act["Xcm1"]), (fuse2[:, 256:], act["Yop2"]),
+                           (conf_in2[:, 64:], act["Yom2"])])
         with second:
-            fuse2[:, 256:].copy_(act["Yop2"]); conf_in2[:, 64:].copy_(act["Yom2"])
             ops.cross_attention(b, act["Yom2"], act["Xcm2"], act["Xcp2"], fuse2[:, :256], act["Xcm2"], conf_in2[:, :64])
             logit2 = self._mlp(conf_in2, f["regressor_conf_bi"])
             Fp2 = fuse2
@@ -399,7 +401,6 @@ class Network(nn.Module):
                 Fp2 = self._lin_relu(Fp2, Wt, bias)
             if side is not None:
                 logit2.record_stream(main); Fp2.record_stream(main)          # allocated on `side`, read on `main` below
-        fuse1[:, :256].copy_(act["Xcp1"]); conf_in1[:, :64].copy_(act["Xcm1"])
         ops.cross_attention(b, act["Xcm1"], act["Yom1"], act["Yop1"], fuse1[:, 256:], act["Yom1"], conf_in1[:, 64:])
         logit1 = self._mlp(conf_in1, f["regressor_conf"])                    # (b*N, 1)
         Fp1 = fuse1
@@ -551,11 +552,28 @@ class Network(nn.Module):
                 for _ in range(2):                                         # warm-up: lazy inits, allocator, hipBLASLt plans
                     body()
             torch.cuda.current_stream().wait_stream(side)
-            g = torch.cuda.CUDAGraph()
+            try:
+                g = torch.cuda.CUDAGraph(keep_graph=True)                  # keeps the hipGraph_t: its nodes can be counted
+            except TypeError:
+                g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 out = body()
         ent["graph"], ent["out"] = g, out
+        ent["nodes"] = self._graph_nodes(g)
         return ent
+
+    @staticmethod
+    def _graph_nodes(g):
+        """number of nodes of a captured hipGraph (None if the runtime does not let us ask)"""
+        import ctypes
+        try:
+            raw = g.raw_cuda_graph()
+            hip = ctypes.CDLL("libamdhip64.so")
+            n = ctypes.c_size_t(0)
+            rc = hip.hipGraphGetNodes(ctypes.c_void_p(int(raw)), None, ctypes.byref(n))
+            return int(n.value) if rc == 0 else None
+        except Exception:
+            return None
 
     # ------------------------------------------------------------------ compatibility path
     def _forward_compat(self, data):

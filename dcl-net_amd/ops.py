@@ -80,7 +80,7 @@ def voxelize_fp(feats, map_rule, mode=4):
 class _PadCopyJob(C.Structure):
     _fields_ = [("dst", C.c_void_p), ("src", C.c_void_p), ("rows_dst", C.c_int32), ("cols_dst", C.c_int32),
                 ("rows_src", C.c_int32), ("cols_src", C.c_int32), ("src_pitch", C.c_int32), ("src_is_i64", C.c_int32),
-                ("fill_value", C.c_int32), ("reserved", C.c_int32)]
+                ("fill_value", C.c_int32), ("dst_pitch", C.c_int32)]
 
 
 def pad_copy_many(jobs):
@@ -88,15 +88,20 @@ def pad_copy_many(jobs):
     dst -> zero padded; may be a column block of a wider row-major tensor) or (dst, int) fills -- ONE launch for all."""
     arr = (_PadCopyJob * len(jobs))()
     for j, (dst, src) in enumerate(jobs):
-        assert dst.is_cuda and dst.is_contiguous() and dst.element_size() == 4
-        if dst.dim() == 2:
+        assert dst.is_cuda and dst.element_size() == 4
+        pitch = 0
+        if dst.dim() == 2 and not dst.is_contiguous():                 # a column block of a wider row-major buffer
+            assert dst.stride(1) == 1 and dst.stride(0) >= dst.shape[1]
+            d2, pitch = dst, dst.stride(0)
+        elif dst.dim() == 2:
             d2 = dst
         elif torch.is_tensor(src):
             d2 = dst.reshape(-1, src.shape[1])         # same logical rows as the source
         else:
             d2 = dst.reshape(1, -1)
         q = arr[j]
-        q.dst, q.rows_dst, q.cols_dst = dst.data_ptr(), d2.shape[0], d2.shape[1]
+        assert pitch or dst.is_contiguous()
+        q.dst, q.rows_dst, q.cols_dst, q.dst_pitch = dst.data_ptr(), d2.shape[0], d2.shape[1], pitch
         if torch.is_tensor(src):
             assert src.is_cuda and src.dim() == 2 and src.stride(1) == 1 and src.element_size() in (4, 8)
             assert src.element_size() == 4 or src.dtype == torch.int64

@@ -175,13 +175,14 @@ int dcl_sparse_avgpool_fwd_rf(const float *feat, const int32_t *nbr, int cap, co
                               dclStream_t stream);
 
 /* Several zero-padded 2-D copies of 4-byte elements in ONE launch (input staging / result hand-over of the whole-forward
- * hipGraph): job: dst (rows_dst x cols_dst, dense) <- src (rows_src x cols_src, row pitch src_pitch elements; int64
- * elements narrowed to int32 when src_is_i64), zero outside src; src == NULL fills dst with fill_value.                 */
+ * hipGraph): job: dst (rows_dst x cols_dst; dense, or a column block with row pitch dst_pitch elements) <- src (rows_src x
+ * cols_src, row pitch src_pitch elements; int64 elements narrowed to int32 when src_is_i64), zero outside src;
+ * src == NULL fills dst with fill_value.                                                                                */
 #define DCL_PAD_COPY_MAX_JOBS 12
 typedef struct {
   void *dst;
   const void *src;
-  int32_t rows_dst, cols_dst, rows_src, cols_src, src_pitch, src_is_i64, fill_value, reserved;
+  int32_t rows_dst, cols_dst, rows_src, cols_src, src_pitch, src_is_i64, fill_value, dst_pitch /* 0 = dense */;
 } DclPadCopyJob;
 int dcl_pad_copy_many(const DclPadCopyJob *jobs_host, int njobs, dclStream_t stream);
 
