@@ -173,6 +173,24 @@ def test_sparse_conv_split_k_in_launch_combine(dcl, oracle, cin, cout, subm):
                 assert float((e1 - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
     finally:
         lib.dcl_debug_conv_split(0)
+    # uneven load: the same layer racing a different, smaller one on a second stream (their workgroups interleave on the
+    # CUs and finish at unrelated times): every launch must still reproduce its own first result bit for bit
+    idx2 = rand_voxels(rng, 3, S, 300)
+    f2 = cuda(rng.normal(size=(idx2.shape[0], cin)).astype(np.float32))
+    out2, nbr2 = dcl.spconv.ops.build_rulebook(dcl.ops.grid_from_indices(cuda(idx2), 3, S), 3, 1, 1, subm)
+    n2 = idx2.shape[0] if subm else out2.n
+    ref_a, ref_b = dcl.ops.sparse_conv(f, nbr, n_out, Wd, subm), dcl.ops.sparse_conv(f2, nbr2, n2, Wd, subm)
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    got_a, got_b = [], []
+    for _ in range(12):
+        with torch.cuda.stream(sa):
+            got_a.append(dcl.ops.sparse_conv(f, nbr, n_out, Wd, subm))
+        with torch.cuda.stream(sb):
+            got_b.append(dcl.ops.sparse_conv(f2, nbr2, n2, Wd, subm))
+            got_b.append(dcl.ops.sparse_conv(f2, nbr2, n2, Wd, subm))
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, ref_a) for a in got_a) and all(torch.equal(x, ref_b) for x in got_b)
 
 
 @pytest.mark.parametrize("cin,cout", [(16, 32), (32, 64), (64, 128)])
