@@ -26,6 +26,8 @@ int dcl_internal_conv_split_cap(long long rows);
 int dcl_internal_out_mask_k3(const uint32_t *in_mask, int batch, int S_in, int stride, uint32_t *out_mask,
                              dclStream_t stream);
 int dcl_internal_scan_enumerate_sets(const DclGeoSets &g, int nsets, dclStream_t stream);
+bool dcl_internal_mask_chain_ok(int S);
+int dcl_internal_mask_chain(const uint32_t *mask0, int batch, const DclGeoSets &g, dclStream_t stream);
 bool dcl_internal_readout_fused_ok(const DclReadoutLevels &L, int ld, bool need_search);
 int dcl_internal_readout_neighbours(int n, const float *points_b4, const DclReadoutLevels &L, int nbatch, float off,
                                     float *dist2, int32_t *idx, dclStream_t stream);
@@ -40,7 +42,9 @@ int dcl_three_nn_sp_strided(int n, int m, const float *unknown, const float *kno
                             const int32_t *known_seg, int nbatch, int seg_stride, dclStream_t stream);
 
 #include <stdlib.h>
+#include <atomic>
 namespace {
+std::atomic<int> g_geo_chain{1};
 
 // debugging aid: DCL_DBG_FEATURE_STEPS=N enqueues only the first N kernels of dcl_backbone_features*
 inline int dbg_steps() { const char *e = getenv("DCL_DBG_FEATURE_STEPS"); return e ? atoi(e) : 1 << 30; }
@@ -174,18 +178,22 @@ static int backbone_geometry(const int32_t *occ, const int32_t *V0_dev, int V0, 
   int rc = dcl_internal_grid_from_indices(occ, V0_dev, V0, batch_lo, batch, S, at<uint32_t>(ws, L.mask0),
                                           at<int32_t>(ws, L.wprefix0), at<int32_t>(ws, L.perm0), scratch, stream);
   if (rc) return rc;
-  // the 8 masks depend only on each other (bit-parallel dilation / stride-2 reduction of the previous mask): chain them,
-  // then rank and decode all 8 sets in three batched launches (16 launches per pass instead of 30)
+  // the 8 masks depend only on each other (bit-parallel dilation / stride-2 reduction of the previous mask): one
+  // workgroup per crop walks the chain in LDS (64^3 grids; other sizes chain 8 launches), then all 8 sets are ranked and
+  // decoded in three batched launches
   DclGeoSets g{};
   size_t so = (size_t)(words(batch, S) + 1023) / 1024 + 2;
   const uint32_t *in_mask = at<uint32_t>(ws, L.mask0);
   int s = S;
+  const bool fused_chain = dcl_internal_mask_chain_ok(S) && g_geo_chain.load(std::memory_order_relaxed) != 0;
   for (int m = 0; m < kLevels; ++m) {
     const SetLayout *sets[2] = {&L.conv[m], &L.pool[m]};
     for (int q = 0; q < 2; ++q) {
       const SetLayout &t = *sets[q];
-      rc = dcl_internal_out_mask_k3(in_mask, batch, s, q == 0 ? 1 : 2, at<uint32_t>(ws, t.mask), stream);
-      if (rc) return rc;
+      if (!fused_chain) {
+        rc = dcl_internal_out_mask_k3(in_mask, batch, s, q == 0 ? 1 : 2, at<uint32_t>(ws, t.mask), stream);
+        if (rc) return rc;
+      }
       const int i = 2 * m + q, nw = (int)words(batch, t.S);
       g.mask[i] = at<uint32_t>(ws, t.mask);
       g.wprefix[i] = at<int32_t>(ws, t.wprefix);
@@ -198,7 +206,17 @@ static int backbone_geometry(const int32_t *occ, const int32_t *V0_dev, int V0, 
       s = t.S;
     }
   }
+  if (fused_chain) {
+    rc = dcl_internal_mask_chain(at<uint32_t>(ws, L.mask0), batch, g, stream);
+    if (rc) return rc;
+  }
   return dcl_internal_scan_enumerate_sets(g, 2 * kLevels, stream);
+}
+
+// Test hook: 1 (default) = one-launch mask chain on 64^3 grids, 0 = the 8 chained launches (A/B of the two paths).
+DCL_API int dcl_debug_geometry_chain(int mode) {
+  g_geo_chain.store(mode);
+  return 0;
 }
 
 DCL_API int dcl_backbone_ws2_bytes(const int32_t *counts_host, const int32_t *channels_host, int64_t *bytes_host) {

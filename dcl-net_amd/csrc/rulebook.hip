@@ -189,30 +189,62 @@ __device__ __forceinline__ unsigned long long compress_even_bits(unsigned long l
 }
 
 template <int STRIDE>   // 1: conv k3 s1 p1 (S_out = S_in);  2: pool k3 s2 p1 (S_out = S_in / 2)
-__global__ void k_out_mask_k3(const uint32_t *__restrict__ in_mask, int batch, int S_in, int S_out, int nwords_out,
-                              uint32_t *__restrict__ out_mask) {
+__device__ __forceinline__ uint32_t out_word_k3(const uint32_t *__restrict__ in_mask, int batch, int S_in, int S_out, int w) {
   const int rows_per_word = S_out >= 32 ? 1 : 32 / S_out;
   const unsigned long long in_rowmask = S_in == 64 ? ~0ull : ((1ull << S_in) - 1ull);
-  for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < nwords_out; w += gridDim.x * blockDim.x) {
-    uint32_t word = 0;
-    for (int rr = 0; rr < rows_per_word; ++rr) {
-      const long long bit0 = (long long)w * 32 + (long long)rr * S_out;   // first bit of this output row (part)
-      const long long row = bit0 / S_out;                                   // = (b*S_out + ox)*S_out + oy
-      const int oy = (int)(row % S_out);
-      const int ox = (int)((row / S_out) % S_out);
-      const int b = (int)(row / ((long long)S_out * S_out));
-      if (b >= batch) break;
-      unsigned long long u = 0ull;
+  uint32_t word = 0;
+  for (int rr = 0; rr < rows_per_word; ++rr) {
+    const long long bit0 = (long long)w * 32 + (long long)rr * S_out;   // first bit of this output row (part)
+    const long long row = bit0 / S_out;                                   // = (b*S_out + ox)*S_out + oy
+    const int oy = (int)(row % S_out);
+    const int ox = (int)((row / S_out) % S_out);
+    const int b = (int)(row / ((long long)S_out * S_out));
+    if (b >= batch) break;
+    unsigned long long u = 0ull;
 #pragma unroll
-      for (int dx = -1; dx <= 1; ++dx)
+    for (int dx = -1; dx <= 1; ++dx)
 #pragma unroll
-        for (int dy = -1; dy <= 1; ++dy) u |= load_zrow(in_mask, b, ox * STRIDE + dx, oy * STRIDE + dy, S_in);
-      unsigned long long t = (u | (u << 1) | (u >> 1)) & in_rowmask;
-      if (STRIDE == 2) t = compress_even_bits(t);
-      if (S_out == 64) word = (uint32_t)(t >> ((w & 1) * 32));
-      else word |= (uint32_t)t << (rr * S_out);
+      for (int dy = -1; dy <= 1; ++dy) u |= load_zrow(in_mask, b, ox * STRIDE + dx, oy * STRIDE + dy, S_in);
+    unsigned long long t = (u | (u << 1) | (u >> 1)) & in_rowmask;
+    if (STRIDE == 2) t = compress_even_bits(t);
+    if (S_out == 64) word = (uint32_t)(t >> ((w & 1) * 32));
+    else word |= (uint32_t)t << (rr * S_out);
+  }
+  return word;
+}
+
+template <int STRIDE>
+__global__ void k_out_mask_k3(const uint32_t *__restrict__ in_mask, int batch, int S_in, int S_out, int nwords_out,
+                              uint32_t *__restrict__ out_mask) {
+  for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < nwords_out; w += gridDim.x * blockDim.x)
+    out_mask[w] = out_word_k3<STRIDE>(in_mask, batch, S_in, S_out, w);
+}
+
+// The whole mask chain of a backbone pass (conv set, pool set) x 4 levels in ONE launch for 64^3 grids: a crop's occupancy
+// is 32 KiB of bits, so one workgroup per crop keeps the current and the next mask in LDS and walks the 8 stages with a
+// barrier between them (each stage is the same row arithmetic as k_out_mask_k3; words never straddle crops because every
+// level's S^3 is a multiple of 32).  Replaces 8 dependent launches at the head of every pass.
+constexpr int kChainS = 64, kChainWords = kChainS * kChainS * kChainS / 32, kChainThreads = 1024;
+__global__ void __launch_bounds__(kChainThreads) k_mask_chain64(const uint32_t *__restrict__ mask0, const DclGeoSets g) {
+  __shared__ uint32_t buf[2][kChainWords];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < kChainWords; i += kChainThreads) buf[0][i] = mask0[(size_t)b * kChainWords + i];
+  __syncthreads();
+  int S_in = kChainS, cur = 0;
+#pragma unroll 1
+  for (int i = 0; i < 8; ++i) {
+    const int S_out = g.S[i], nw = S_out * S_out * S_out / 32;
+    uint32_t *__restrict__ gout = const_cast<uint32_t *>(g.mask[i]) + (size_t)b * nw;
+    const uint32_t *src = buf[cur];
+    uint32_t *dst = buf[cur ^ 1];
+    for (int w = tid; w < nw; w += kChainThreads) {
+      const uint32_t word = (i & 1) ? out_word_k3<2>(src, 1, S_in, S_out, w) : out_word_k3<1>(src, 1, S_in, S_out, w);
+      dst[w] = word;
+      gout[w] = word;
     }
-    out_mask[w] = word;
+    __syncthreads();
+    cur ^= 1;
+    S_in = S_out;
   }
 }
 
@@ -522,6 +554,16 @@ int dcl_internal_out_mask_k3(const uint32_t *in_mask, int batch, int S_in, int s
 }
 
 // internal (backbone.hip): word prefixes, row counts and (b,x,y,z) rows of `nsets` masks in three launches
+// all 8 masks of a pass from the level-0 mask in one launch (64^3 grids only; the caller falls back to the chained
+// dcl_internal_out_mask_k3 launches otherwise).  g.mask[i] / g.S[i] must be filled for i = 0..7.
+bool dcl_internal_mask_chain_ok(int S) { return S == kChainS; }
+int dcl_internal_mask_chain(const uint32_t *mask0, int batch, const DclGeoSets &g, dclStream_t stream) {
+  if (batch <= 0) return 0;
+  hipLaunchKernelGGL(k_mask_chain64, dim3(batch), dim3(kChainThreads), 0, (hipStream_t)stream, mask0, g);
+  DCL_LAUNCH_CHECK();
+  return 0;
+}
+
 int dcl_internal_scan_enumerate_sets(const DclGeoSets &g, int nsets, dclStream_t stream) {
   DCL_CHECK_ARG(nsets >= 1 && nsets <= 8);
   int max_words = 0;

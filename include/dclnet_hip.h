@@ -428,6 +428,9 @@ void dcl_debug_attention_split(int n);
 /* Tuning hook: 1 (default) = the LDS-DMA attention kernel renumbers its workgroups so that the query blocks of one crop share
  * an XCD (one L2 fetch of the crop's K/V per XCD group), 0 = plain blockIdx order (traffic A/B). */
 void dcl_debug_attention_xcd_remap(int on);
+/* Test hook, geometry stage: 1 (default) = the 8 occupancy masks of a pass come from one launch (one workgroup per crop walks
+ * the conv/pool chain in LDS; 64^3 grids), 0 = 8 chained launches.  Both produce identical masks.  Process-wide atomic. */
+int dcl_debug_geometry_chain(int mode);
 /* Test hook, 3-NN of the point read-out: 1 (default) = grid-pruned search on the 32^3 / 16^3 levels, 0 = per-crop scan on
  * every level, 2 = grid kernel with its scan fallback forced for every query (all three give identical results). */
 void dcl_debug_three_nn_grid(int mode);

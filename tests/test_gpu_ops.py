@@ -796,6 +796,32 @@ def test_backbone_runner_edge_cases(dcl, oracle):
 
 
 @pytest.mark.gpu
+def test_geometry_one_launch_mask_chain_equals_chained_launches(dcl):
+    """the 8 active sets of a pass from the one-workgroup-per-crop LDS chain (default on 64^3 grids) and from the 8 chained
+    mask launches: same counts, same voxel rows at every level -- on the awkward sets and on a 32-crop batch"""
+    lib = dcl._native.lib()
+    rng = np.random.default_rng(23)
+    occ_e, b_e = _edge_voxels(rng)
+    data = dcl.synth.make_batch(32, 1024, 64, first=3)
+    cases = [(cuda(occ_e), b_e), (data["inp"]["occupied_voxels"].int().cuda().contiguous(), 32)]
+    for occ, b in cases:
+        got = {}
+        try:
+            for mode in (0, 1):
+                lib.dcl_debug_geometry_chain(mode)
+                run = dcl.ops.BackboneRun(occ, b, 64)
+                counts = run.counts_dev.cpu().tolist()
+                run.set_counts(counts)
+                got[mode] = (counts, [run.level_indices(m).cpu().numpy() for m in range(4)])
+        finally:
+            lib.dcl_debug_geometry_chain(1)
+        assert got[0][0] == got[1][0]
+        assert all(c >= 0 for c in got[1][0]) and got[1][0][0] > 0
+        for a, c in zip(got[0][1], got[1][1]):
+            assert np.array_equal(a, c)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("scales,unit", [((2, 4, 8, 16), 0.006), ((2, 4, 6, 8), 0.006), ((2, 4, 6, 8), 0.005)])
 def test_point_neighbours_grid_search_is_exact(dcl, scales, unit):
     """the grid-pruned 3-NN of the point read-out returns bit-for-bit what the per-crop scan returns -- distances, rows and
