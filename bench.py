@@ -196,6 +196,17 @@ def pipelined_bench(dcl, dev, sd, cfg, data, b, steps, warmup, ref):
     return out
 
 
+def whole_forward_rate(n_inp, n_tmp, b, step_s):
+    """All MFMA-shaped work of one forward call against the step time (SURVEY.md 8d figures, test mode: the regressor_Xo/Yc
+    heads -- 197 376 FLOP per point -- are not executed and not counted): per-point MLPs 3 473 664 FLOP x (N + M), the two
+    attention directions 1536 N M; the sparse convolutions (~1 % of this) are left out.  One GPU's share."""
+    per_frame = 3473664.0 * (n_inp + n_tmp) + 1536.0 * n_inp * n_tmp
+    ach = per_frame * b / step_s / 1e12
+    return {"dense_flop_per_frame": per_frame, "achieved": round(ach, 2), "unit": "TFLOP/s per GPU", "peak": PEAK_MFMA_F32,
+            "frac": round(ach / PEAK_MFMA_F32, 4),
+            "note": "fp32 MFMA work of the whole step / step time: what is left above the MFMA floor is the sparse prefix"}
+
+
 def lm_stream_bench(dcl, dev, reps=30):
     """BASELINE config 4 (S3): LineMOD eval stream -- one object crop per call (tools/test_LM.py:104-112), N=M=1024,
     5 mm voxels (configs/config_LM.yaml:17-20); forward() vs the whole-forward hipGraph replay, inputs resident in HBM."""
@@ -455,6 +466,7 @@ def main():
                        "weights": "seeded random (no checkpoints offline)",
                        "calls": "pipelined (async_inputs)" if args.pipelined_calls else "serial"},
             "roofline": roofline,
+            "whole_forward": whole_forward_rate(n_inp, n_tmp, b, dt / args.steps),
             "adds_auc_synthetic_weights": auc, "metric_frames_reduced": int(table.sums[:, 0].sum())}
     rdata_for_pipe = None
     if rank == 0 and world == 1 and not args.no_extras:

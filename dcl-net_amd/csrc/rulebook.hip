@@ -222,26 +222,67 @@ __global__ void k_out_mask_k3(const uint32_t *__restrict__ in_mask, int batch, i
 
 // The whole mask chain of a backbone pass (conv set, pool set) x 4 levels in ONE launch for 64^3 grids: a crop's occupancy
 // is 32 KiB of bits, so one workgroup per crop keeps the current and the next mask in LDS and walks the 8 stages with a
-// barrier between them (each stage is the same row arithmetic as k_out_mask_k3; words never straddle crops because every
-// level's S^3 is a multiple of 32).  Replaces 8 dependent launches at the head of every pass.
+// barrier between them (the row arithmetic of k_out_mask_k3 on crop-local rows; words never straddle crops because every
+// level's S^3 is a multiple of 32).  Replaces 8 dependent launches at the head of every pass.  All index arithmetic is
+// 32-bit shifts (S is a power of two): with one workgroup per crop the 64-bit divisions of the general kernel would be the
+// whole run time.
 constexpr int kChainS = 64, kChainWords = kChainS * kChainS * kChainS / 32, kChainThreads = 1024;
+__device__ __forceinline__ unsigned long long local_zrow(const uint32_t *m, int x, int y, int S, int lg) {
+  if ((unsigned)x >= (unsigned)S || (unsigned)y >= (unsigned)S) return 0ull;
+  const int off = ((x << lg) + y) << lg;                                // bit offset of the z-row inside the crop
+  const int w = off >> 5;
+  if (S == 64) return (unsigned long long)m[w] | ((unsigned long long)m[w + 1] << 32);
+  const uint32_t v = m[w] >> (off & 31);
+  return (unsigned long long)(S == 32 ? v : v & ((1u << S) - 1u));
+}
+template <int STRIDE>
+__device__ __forceinline__ unsigned long long local_out_row(const uint32_t *src, int row, int S_in, int lg_in, int lg_out) {
+  const int ox = row >> lg_out, oy = row & ((1 << lg_out) - 1);
+  unsigned long long u = 0ull;
+#pragma unroll
+  for (int dx = -1; dx <= 1; ++dx)
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) u |= local_zrow(src, ox * STRIDE + dx, oy * STRIDE + dy, S_in, lg_in);
+  unsigned long long t = (u | (u << 1) | (u >> 1)) & (S_in == 64 ? ~0ull : ((1ull << S_in) - 1ull));
+  if (STRIDE == 2) t = compress_even_bits(t);
+  return t;
+}
+template <int STRIDE>
+__device__ __forceinline__ void chain_stage(const uint32_t *src, uint32_t *dst, uint32_t *__restrict__ gout, int S_in,
+                                            int S_out, int tid) {
+  const int lg_in = 31 - __clz(S_in), lg_out = 31 - __clz(S_out);
+  const int rows = S_out << lg_out;
+  if (S_out == 64) {                                                    // one thread per row = two words
+    for (int row = tid; row < rows; row += kChainThreads) {
+      const unsigned long long t = local_out_row<STRIDE>(src, row, S_in, lg_in, lg_out);
+      const uint2 v = make_uint2((uint32_t)t, (uint32_t)(t >> 32));
+      reinterpret_cast<uint2 *>(dst)[row] = v;
+      reinterpret_cast<uint2 *>(gout)[row] = v;
+    }
+  } else {                                                              // 32 / S_out rows per word
+    const int lg_rpw = 5 - lg_out, nw = rows >> lg_rpw;
+    for (int w = tid; w < nw; w += kChainThreads) {
+      uint32_t word = 0;
+      for (int rr = 0; rr < (1 << lg_rpw); ++rr)
+        word |= (uint32_t)local_out_row<STRIDE>(src, (w << lg_rpw) + rr, S_in, lg_in, lg_out) << (rr << lg_out);
+      dst[w] = word;
+      gout[w] = word;
+    }
+  }
+}
 __global__ void __launch_bounds__(kChainThreads) k_mask_chain64(const uint32_t *__restrict__ mask0, const DclGeoSets g) {
-  __shared__ uint32_t buf[2][kChainWords];
+  __shared__ __attribute__((aligned(16))) uint32_t buf[2][kChainWords];
   const int b = blockIdx.x, tid = threadIdx.x;
-  for (int i = tid; i < kChainWords; i += kChainThreads) buf[0][i] = mask0[(size_t)b * kChainWords + i];
+  for (int i = tid; i < kChainWords / 4; i += kChainThreads)
+    reinterpret_cast<uint4 *>(buf[0])[i] = reinterpret_cast<const uint4 *>(mask0 + (size_t)b * kChainWords)[i];
   __syncthreads();
   int S_in = kChainS, cur = 0;
 #pragma unroll 1
   for (int i = 0; i < 8; ++i) {
-    const int S_out = g.S[i], nw = S_out * S_out * S_out / 32;
-    uint32_t *__restrict__ gout = const_cast<uint32_t *>(g.mask[i]) + (size_t)b * nw;
-    const uint32_t *src = buf[cur];
-    uint32_t *dst = buf[cur ^ 1];
-    for (int w = tid; w < nw; w += kChainThreads) {
-      const uint32_t word = (i & 1) ? out_word_k3<2>(src, 1, S_in, S_out, w) : out_word_k3<1>(src, 1, S_in, S_out, w);
-      dst[w] = word;
-      gout[w] = word;
-    }
+    const int S_out = g.S[i];
+    uint32_t *gout = const_cast<uint32_t *>(g.mask[i]) + (size_t)b * ((S_out * S_out * S_out) >> 5);
+    if (i & 1) chain_stage<2>(buf[cur], buf[cur ^ 1], gout, S_in, S_out, tid);
+    else chain_stage<1>(buf[cur], buf[cur ^ 1], gout, S_in, S_out, tid);
     __syncthreads();
     cur ^= 1;
     S_in = S_out;

@@ -125,7 +125,7 @@ class Network(nn.Module):
     def __getstate__(self):
         """copy.deepcopy / pickling: streams, graphs and folded tensors are per-instance runtime state"""
         state = dict(self.__dict__)
-        for k in ("_side", "_graphs", "_crop_id_cache", "_vlist"):
+        for k in ("_side", "_graphs", "_crop_id_cache", "_vlist", "_counts_host"):
             state.pop(k, None)
         state["_folded"] = None
         return state
@@ -252,20 +252,23 @@ class Network(nn.Module):
         # stages only (on a helper stream).  Running the 3-NN searches of the read-out beside the convolutions (they need
         # the geometry only) and each level's interpolation as soon as that level is pooled was built and measured: the
         # same step time within 0.1 % -- these kernels fill the GPU, so overlap only re-divides it -- and dropped.
-        rstream = self._side_stream(dev, 2)
         npts = {"inp": self.n_inp, "tmp": self.n_tmp}
         side_in, runs, geo, vox, pb4, pf, pts = {}, {}, {}, {}, {}, {}, {}
-        # the geometry of BOTH sides goes out first (it needs the occupied voxels only): the host is the slow party here
-        # (16 launches per side), everything else it has to issue before the read-back then runs underneath the geometry
+        # The host is the slow party at the head of a call (a geometry stage is a dozen dependent small launches: ~50 us to
+        # issue, done ~40 us later).  One side at a time -- geometry, then what the feature pass needs besides the level
+        # sizes (issued while the geometry runs), then the sizes, then features + read-out -- puts the observed side's
+        # convolutions on the GPU ~150 us after the call starts, and the template side's whole head is issued underneath
+        # them.  The level sizes land in pinned host memory, written by the geometry kernels themselves (device-visible host
+        # allocation): the host waits for that side's geometry event and reads them -- no copy kernel, no D2H enqueue.
+        # DCL_GEOMETRY_FIRST=1: both geometry stages before anything else (the round-1 order; A/B).
         occ = {}
-        counts_dev = {}
-        for s in ("inp", "tmp"):
+        counts_host = self._counts_pinned(K)
+        geometry_first = os.environ.get("DCL_GEOMETRY_FIRST", "0") == "1"
+        def geometry(s):
             with torch.cuda.stream(sstream[s]):
                 occ[s] = data[s]["occupied_voxels"].to(dev, non_blocking=True).int().contiguous()
-                # allocated on the stream that writes it (with async_inputs the side streams are not ordered behind `main`)
-                counts_dev[s] = torch.empty(8 * K, dtype=torch.int32, device=dev)
                 for c in range(K):
-                    runs[s, c] = ops.BackboneRun(occ[s], bc, S, batch_lo=c * bc, counts_dev=counts_dev[s][8 * c:8 * c + 8])
+                    runs[s, c] = ops.BackboneRun(occ[s], bc, S, batch_lo=c * bc, counts_dev=counts_host[s][8 * c:8 * c + 8])
                 geo[s] = torch.cuda.Event()
                 geo[s].record(sstream[s])
         def stage(s):
@@ -281,27 +284,28 @@ class Network(nn.Module):
                 pf[s].record_stream(main)
                 side_in[s][0].record_stream(main)                      # `pts` below is handed to the caller
             pts[s] = side_in[s][0][:, 4:7].reshape(b, npts[s], 3)
-        stage("inp")                                                   # runs underneath the geometry
+        if geometry_first:
+            geometry("inp")
+            geometry("tmp")
+            stage("inp")
         mark("geometry issued")
         unit = self.unit_voxel_extent
         assert unit[0] == unit[1] == unit[2], "anisotropic voxels: use fused=False"
         off = float(np.float32(-0.5 * unit[0] * VOXEL_NUM_LIMIT[0]))
         extents = [float(np.float32(unit[0] * sc)) for sc in SCALE_LISTS]
-        with torch.cuda.stream(rstream):                               # the host waits for the two geometry stages only
-            for s in ("inp", "tmp"):
-                rstream.wait_event(geo[s])
-            for s in ("inp", "tmp"):
-                counts_dev[s].record_stream(rstream)
-            counts = torch.cat([counts_dev["inp"], counts_dev["tmp"]]).cpu().tolist()      # [side][chunk][8]
-        mark("counts read back")
-        for si, s in enumerate(("inp", "tmp")):
-            for c in range(K):
-                runs[s, c].set_counts(counts[8 * (K * si + c):8 * (K * si + c) + 8])
         done = {}
         for side, bb in (("inp", "backbone_inp"), ("tmp", "backbone_tmp")):
             n = npts[side]
-            if side == "tmp":
-                stage("tmp")                                           # issued after the observed side's convolutions are out
+            if not geometry_first:
+                geometry(side)
+                stage(side)                                            # runs underneath the geometry
+            elif side == "tmp":
+                stage("tmp")
+            geo[side].synchronize()                                    # the host waits for THIS side's geometry only
+            counts = counts_host[side].tolist()
+            mark("counts read back " + side)
+            for c in range(K):
+                runs[side, c].set_counts(counts[8 * c:8 * c + 8])
             with torch.cuda.stream(sstream[side]):
                 for c in range(K):
                     rows = slice(c * bc * n, (c + 1) * bc * n)
@@ -327,6 +331,15 @@ class Network(nn.Module):
         data["labels"]["points_tmp"] = pts["tmp"]
         data["labels"]["points_inp"] = pts["inp"]
         return prediction
+
+    def _counts_pinned(self, K):
+        """per side, 8 K int32 of pinned (device-visible) host memory for the level sizes of a call's K passes; reused by
+        every call (the host has consumed a call's sizes before it issues the next call's geometry)"""
+        cache = self.__dict__.setdefault("_counts_host", {})
+        if K not in cache:
+            cache[K] = {s: torch.zeros(8 * K, dtype=torch.int32).pin_memory() for s in ("inp", "tmp")}
+        assert all(t.is_pinned() for t in cache[K].values()), "level-size buffers must be pinned host memory"
+        return cache[K]
 
     def _crop_ids(self, dev, b, bc, n):
         """(b*n, 1) float column: crop id (inside its chunk of bc crops) of every point row; constant per shape, cached"""

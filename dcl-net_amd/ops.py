@@ -305,6 +305,8 @@ class BackboneRun(object):
         nbytes = C.c_int64(0)
         N.check(N.lib().dcl_backbone_ws_bytes(self.batch, self.S, self.V0, C.byref(nbytes)), "backbone_ws_bytes")
         self.ws = torch.empty(nbytes.value, dtype=torch.uint8, device=occ.device)
+        if counts_dev is not None and not counts_dev.is_cuda and not counts_dev.is_pinned():
+            raise RuntimeError("BackboneRun: a host counts buffer must be pinned (the geometry kernels write into it)")
         self.counts_dev = torch.empty(8, dtype=torch.int32, device=occ.device) if counts_dev is None else counts_dev
         self.chan = (C.c_int32 * 9)(*BACKBONE_CHANNELS)
         N.check(N.lib().dcl_backbone_geometry_window(N.ptr(occ), self.V0, int(batch_lo), self.batch, self.S, N.ptr(self.ws),
