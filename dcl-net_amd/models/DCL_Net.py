@@ -33,6 +33,7 @@ from .Modules import (Aligner, Backbone_SPCONV, BasicBlock_3DCONV, Head_MultiLay
                       Ops_GetPointFeat_spconv)
 
 HOST_TIMES = None                   # tools/host_timeline.py sets this to a list: (label, perf_counter) marks of _forward_fused
+_SIDE_STREAMS = {}          # (device index, which) -> torch.cuda.Stream, shared by every Network of the process
 SCALE_LISTS = [2, 4, 6, 8]          # sic -- reference models/DCL_Net.py:54 (true strides are 2,4,8,16)
 VOXEL_NUM_LIMIT = [64, 64, 64]
 
@@ -204,10 +205,14 @@ class Network(nn.Module):
         """per-side streams of the sparse half (DCL_SINGLE_STREAM=1: everything on the current stream)"""
         if os.environ.get("DCL_SINGLE_STREAM") == "1":
             return torch.cuda.current_stream(dev)
-        sts = self.__dict__.setdefault("_side", {})
-        if which not in sts:
-            sts[which] = torch.cuda.Stream(dev)
-        return sts[which]
+        # one set of side streams per device for the whole process: the runtime deals streams round-robin onto a few
+        # hardware queues, so per-instance streams of a second Network can land on a queue its first one (or the other
+        # side) already uses and the two backbones serialise (measured: +0.3 ms per reference-shape step for the
+        # second instance)
+        key = (dev.index if dev.index is not None else torch.cuda.current_device(), which)
+        if key not in _SIDE_STREAMS:
+            _SIDE_STREAMS[key] = torch.cuda.Stream(dev)
+        return _SIDE_STREAMS[key]
 
     def _pipeline_chunks(self, b):
         """number of crop chunks of the sparse/disengage software pipeline.  Measured on MI355X (bs 32): K = 1/2/4 ->
