@@ -590,9 +590,16 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
     };
     // steps under which at least one of THIS WAVE's 32 rows has a neighbour (wave-level skip of a chunk's MFMA block)
     unsigned wsmask = 0;
-    for (int sx = 0; sx < kvol; ++sx)
-      if ((smask >> sx) & 1u)
-        wsmask |= (__ballot(Ns[offset_at(sx, kvol, subm) * BM + wr * 32 + r] >= 0) != 0ull ? 1u : 0u) << sx;
+    {
+      // (the lane's row is made opaque here so that its LDS address is formed per segment: hoisted out of the tile loop
+      // it was the one value the 8-wave variant spilled -- and a kernel with a scratch segment does not get its second
+      // workgroup per CU at dispatch time)
+      int wrow = wr * 32 + r;
+      asm volatile("" : "+v"(wrow));
+      for (int sx = 0; sx < kvol; ++sx)
+        if ((smask >> sx) & 1u)
+          wsmask |= (__ballot(Ns[offset_at(sx, kvol, subm) * BM + wrow] >= 0) != 0ull ? 1u : 0u) << sx;
+    }
     wsmask = __builtin_amdgcn_readfirstlane(wsmask);
 
     f32x16 acc[NT];

@@ -53,16 +53,17 @@ for i, nm in enumerate(names):
     if ok.any():
         print("  %-14s avg %7.2f us  max %7.2f us  (n=%d)" % (nm, d[ok].mean() * tick, d[ok].max() * tick, ok.sum()))
 end = live[:, 1:].max(axis=1)
-print("  workgroup life avg %.2f us; first start -> last end %.2f us; starts spread %.2f us" % (
+print("  (stamps are overwritten per segment: all figures are those of each workgroup's LAST segment)")
+print("  last-segment life avg %.2f us; first start -> last end %.2f us; starts spread %.2f us" % (
     ((end - live[:, 0]).mean()) * tick, (end.max() - t0) * tick, (live[:, 0].max() - t0) * tick))
 st = np.sort(live[:, 0] - t0) * tick
-print("  starts by 20-us bucket:", np.histogram(st, bins=np.arange(0, st.max() + 20, 20))[0].tolist())
+print("  last-segment starts by 20-us bucket:", np.histogram(st, bins=np.arange(0, st.max() + 20, 20))[0].tolist())
 ev = sorted([(x, 1) for x in (live[:, 0] - t0)] + [(x, -1) for x in (end - t0)])
 cur = peak = 0
 for _, d in ev:
     cur += d
     peak = max(peak, cur)
-print("  peak concurrent workgroups: %d" % peak)
+print("  peak concurrent last segments: %d" % peak)
 hw = buf[buf[:, 0] > 0][:, 7]
 xcc, hwid = (hw >> np.uint64(32)).astype(np.int64) & 0xF, hw.astype(np.int64) & 0xFFFFFFFF
 cu_key = xcc * 100000 + ((hwid >> 8) & 0xF) * 1000 + ((hwid >> 13) & 0x7) * 100 + ((hwid >> 12) & 1) * 50   # cu_id, se_id, sh_id
