@@ -39,6 +39,8 @@ def lib():
             L.dcl_debug_conv_xcd_remap(int(os.environ["DCL_CONV_XCD"]))
         if os.environ.get("DCL_CONV_SPLIT"):
             L.dcl_debug_conv_split(int(os.environ["DCL_CONV_SPLIT"]))
+        if os.environ.get("DCL_CONV_SLOTS"):
+            L.dcl_debug_conv_slots(int(os.environ["DCL_CONV_SLOTS"]))
         if os.environ.get("DCL_ATTN_SPLIT"):
             L.dcl_debug_attention_split(int(os.environ["DCL_ATTN_SPLIT"]))
         if os.environ.get("DCL_NN_GRID"):

@@ -877,6 +877,7 @@ static int conv_split_cap(long long rows) { return rows <= kConvFewRows ? 27 : k
 constexpr int kConvFewRowsCap = 65536;
 static bool conv_few_rows(int rows, bool capacity_mode) { return capacity_mode ? rows <= kConvFewRowsCap : rows <= kConvFewRows; }
 static std::atomic<int> g_conv_xcd_remap{1};       // tuning hook: 0 = plain blockIdx order
+static std::atomic<int> g_conv_slots{512};         // tuning hook: workgroups a launch is dealt over (2 x 256 resident slots)
 static std::atomic<int> g_conv_split{0};           // tuning hook: 0 = automatic, n = force n-way split-K when scratch allows, -1 = never more than kConvMaxSplit, -2 = never split
 
 template <int CIN, int WR, int WCW, int NT>
@@ -916,7 +917,8 @@ static void launch_conv_dma(int rows, const float *feat, const DclNbrSrc &nbr, i
   //   stream-K         ceil(units / 512) + 2 f + 1                -- everything else (no partial rounds, no idle slots)
   // A handful of crops (one-image calls) is latency-bound on the chunk loop: stream-K with kFewChunks chunks per workgroup.
   const int nchunks = dcl_div_up(kvol * CIN, KC);
-  constexpr int kSlots = 512, kFewChunks = 4, kFix = 4;
+  constexpr int kFewChunks = 4, kFix = 4;
+  const int kSlots = g_conv_slots.load(std::memory_order_relaxed);
   const long long units = (long long)tiles * nchunks;
   int stream_k = 0, aligned_ns = 0, G = tiles < 65535 * 16 ? tiles : 65535 * 16;
   bool deferred = false;
@@ -1082,6 +1084,7 @@ static std::atomic<int> g_force_valu{0};   // test hook: 1 = plain VALU kernel f
 DCL_API void dcl_debug_force_valu_conv(int on) { g_force_valu = on; }
 
 DCL_API void dcl_debug_conv_split(int n) { g_conv_split = n; }
+DCL_API void dcl_debug_conv_slots(int n) { g_conv_slots = (n >= 64 && n <= 512) ? n : 512; }
 #ifdef DCL_CONV_STAMPS
 extern "C" __attribute__((visibility("default"))) int dcl_debug_conv_stamps(unsigned long long *host, int n_wg, int clear) {
   if (clear) {
