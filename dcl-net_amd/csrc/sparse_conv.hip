@@ -956,7 +956,7 @@ static void launch_conv_dma(int rows, const float *feat, const DclNbrSrc &nbr, i
     }
     if (aligned_ns || stream_k) {
       partial = scratch + kConvCounterWords;
-      deferred = stream_k == kFewChunks;                           // few rows: many segments per tile, combine = own launch
+      deferred = stream_k == kFewChunks && g_conv_split != -3;     // few rows: many segments per tile, combine = own launch (-3: A/B, in the launch)
       if (!deferred) {
         counters = reinterpret_cast<int32_t *>(scratch);
         if (!counters_ready) dcl_internal_zero_words(counters, kConvCounterWords, s);
