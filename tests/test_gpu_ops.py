@@ -795,6 +795,61 @@ def test_backbone_runner_edge_cases(dcl, oracle):
     assert np.abs(got_pf[live] - want_pf[live]).max() <= 5e-5 * max(1.0, np.abs(want_pf[live]).max())
 
 
+def _random_voxels(rng, S=64):
+    """a batch of 1..6 crops of random shape families: gaussian blobs, shells, rods along an axis, sparse noise, near-full
+    small cubes -- some crops hugging a face of the grid, row order shuffled inside each crop"""
+    b = int(rng.integers(1, 7))
+    out = []
+    for c in range(b):
+        kind = int(rng.integers(0, 5))
+        if kind == 0:
+            v = rng.normal(S / 2 + rng.integers(-20, 21, 3), rng.uniform(2, 9), (int(rng.integers(50, 900)), 3))
+        elif kind == 1:
+            d = rng.normal(size=(int(rng.integers(200, 1200)), 3))
+            v = S / 2 + d / np.linalg.norm(d, axis=1, keepdims=True) * rng.uniform(5, 28)
+        elif kind == 2:
+            v = np.zeros((int(rng.integers(20, 200)), 3))
+            ax = int(rng.integers(0, 3))
+            v[:, ax] = rng.uniform(0, S, len(v))
+            v[:, (ax + 1) % 3] = rng.integers(0, S) + rng.normal(0, 0.7, len(v))
+            v[:, (ax + 2) % 3] = rng.integers(0, S) + rng.normal(0, 0.7, len(v))
+        elif kind == 3:
+            v = rng.uniform(0, S, (int(rng.integers(1, 300)), 3))
+        else:
+            e = int(rng.integers(3, 12))
+            o = rng.integers(0, S - e, 3)
+            v = np.stack(np.meshgrid(*[np.arange(e)] * 3, indexing="ij"), -1).reshape(-1, 3) + o
+            v = v[rng.random(len(v)) < 0.9]
+        v = np.unique(np.clip(np.floor(v), 0, S - 1).astype(np.int32), axis=0)
+        v = v[rng.permutation(len(v))]
+        out.append(np.concatenate([np.full((len(v), 1), c, np.int32), v], 1))
+    return np.concatenate(out).astype(np.int32), b
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [101, 102, 103, 104, 105, 106])
+def test_backbone_runner_on_random_active_sets(dcl, oracle, seed):
+    """seeded fuzz of the whole sparse half: random crop counts and shape families through geometry + 8 convs + 4 pools of
+    the native runner against the oracle backbone -- every level's voxel rows bit-exact, features within the GEMM tolerance"""
+    from oracle import graph as G
+    rng = np.random.default_rng(seed)
+    occ, b = _random_voxels(rng)
+    net = dcl.DCL_Net.Network(dcl.synth.default_cfg(64, 64), mode="test")
+    sd = dcl.synth.synth_state_dict(net, seed)
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    vox = rng.normal(size=(occ.shape[0], 7)).astype(np.float32)
+    want = G.backbone(sd, "backbone_tmp", vox, occ, [64] * 3, b)
+    run = dcl.ops.BackboneRun(cuda(occ), b, 64)
+    run.set_counts(run.counts_dev.cpu().tolist())
+    levels = run.features(cuda(vox), *net._fold()["backbone_tmp_ptrs"])
+    for m, (wf, wi) in enumerate(want):
+        assert np.array_equal(run.level_indices(m).cpu().numpy(), wi), (seed, m)
+        got = levels[m].cpu().numpy()
+        assert got.shape == wf.shape
+        assert np.abs(got - wf).max() <= 5e-5 * max(1.0, np.abs(wf).max()), (seed, m)
+
+
 @pytest.mark.gpu
 def test_geometry_one_launch_mask_chain_equals_chained_launches(dcl):
     """the 8 active sets of a pass from the one-workgroup-per-crop LDS chain (default on 64^3 grids) and from the 8 chained
