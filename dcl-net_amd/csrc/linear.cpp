@@ -1,0 +1,114 @@
+// linear.cpp -- the per-point linear layers (Conv1d k=1 / 1x1x1 Conv3d with folded BN, reference models/Modules.py:58-97,
+// 173-201) as plain library GEMMs: y = act(x Wt + bias) through hipBLASLt with the bias / ReLU epilogue, called from the
+// C-ABI so that x, Wt and y may be column blocks of wider row-major buffers (leading dimensions are free).  The point of
+// the free ldy: the disengage layers write straight into the column blocks of the fuser / confidence inputs that the
+// correspondence attention fills from the other side, so no copy kernel sits between them.
+//
+// Row-major y[M x N] = x[M x K] Wt[K x N] is the column-major product Y'[N x M] = W'[N x K] X'[K x M] of the same
+// buffers (ld = row pitch), so no transposes are requested; the bias runs along the rows of Y' (= output channels).
+#include <hipblaslt/hipblaslt.h>
+
+#include <mutex>
+#include <unordered_map>
+
+#include "common.h"
+
+namespace {
+
+struct PlanKey {
+  int64_t M, N, K, ldx, ldw, ldy;
+  int epilogue;
+  int64_t ws;
+  bool operator==(const PlanKey &o) const {
+    return M == o.M && N == o.N && K == o.K && ldx == o.ldx && ldw == o.ldw && ldy == o.ldy && epilogue == o.epilogue && ws == o.ws;
+  }
+};
+struct PlanKeyHash {
+  size_t operator()(const PlanKey &k) const {
+    size_t h = 1469598103934665603ull;
+    for (int64_t v : {k.M, k.N, k.K, k.ldx, k.ldw, k.ldy, (int64_t)k.epilogue, k.ws}) h = (h ^ (size_t)v) * 1099511628211ull;
+    return h;
+  }
+};
+struct Plan {
+  hipblasLtMatmulDesc_t desc = nullptr;
+  hipblasLtMatrixLayout_t w = nullptr, x = nullptr, y = nullptr;
+  hipblasLtMatmulAlgo_t algo;
+  size_t ws = 0;
+};
+
+std::mutex g_mu;
+hipblasLtHandle_t g_handle = nullptr;
+std::unordered_map<PlanKey, Plan, PlanKeyHash> g_plans;
+
+#define LT_CHECK(call)                                                                                   \
+  do {                                                                                                   \
+    hipblasStatus_t st__ = (call);                                                                       \
+    if (st__ != HIPBLAS_STATUS_SUCCESS) {                                                                \
+      dcl_set_error("%s: %s failed with hipblasStatus %d", __func__, #call, (int)st__);                  \
+      return DCL_EINVAL;                                                                                 \
+    }                                                                                                    \
+  } while (0)
+
+int get_plan(const PlanKey &key, Plan **out) {
+  auto it = g_plans.find(key);
+  if (it != g_plans.end()) {
+    *out = &it->second;
+    return 0;
+  }
+  if (!g_handle) LT_CHECK(hipblasLtCreate(&g_handle));
+  Plan p;
+  LT_CHECK(hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F));
+  const int32_t opn = HIPBLAS_OP_N;
+  LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &opn, sizeof(opn)));
+  LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &opn, sizeof(opn)));
+  const uint32_t epi = (uint32_t)key.epilogue;
+  LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof(epi)));
+  if (key.epilogue & HIPBLASLT_EPILOGUE_BIAS) {
+    const int32_t bt = HIP_R_32F;
+    LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bt, sizeof(bt)));
+  }
+  LT_CHECK(hipblasLtMatrixLayoutCreate(&p.w, HIP_R_32F, (uint64_t)key.N, (uint64_t)key.K, key.ldw));
+  LT_CHECK(hipblasLtMatrixLayoutCreate(&p.x, HIP_R_32F, (uint64_t)key.K, (uint64_t)key.M, key.ldx));
+  LT_CHECK(hipblasLtMatrixLayoutCreate(&p.y, HIP_R_32F, (uint64_t)key.N, (uint64_t)key.M, key.ldy));
+  hipblasLtMatmulPreference_t pref = nullptr;
+  LT_CHECK(hipblasLtMatmulPreferenceCreate(&pref));
+  const uint64_t max_ws = (uint64_t)key.ws;
+  LT_CHECK(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &max_ws, sizeof(max_ws)));
+  hipblasLtMatmulHeuristicResult_t res[1];
+  int found = 0;
+  hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(g_handle, p.desc, p.w, p.x, p.y, p.y, pref, 1, res, &found);
+  hipblasLtMatmulPreferenceDestroy(pref);
+  if (st != HIPBLAS_STATUS_SUCCESS || found < 1) {
+    dcl_set_error("dcl_linear_fwd: no hipBLASLt algorithm for M=%lld N=%lld K=%lld (status %d)", (long long)key.M,
+                  (long long)key.N, (long long)key.K, (int)st);
+    return DCL_EINVAL;
+  }
+  p.algo = res[0].algo;
+  p.ws = res[0].workspaceSize;
+  auto ins = g_plans.emplace(key, p);
+  *out = &ins.first->second;
+  return 0;
+}
+
+}  // namespace
+
+DCL_API int dcl_linear_fwd(const float *x, int64_t ldx, const float *Wt, int64_t ldw, const float *bias, float *y, int64_t ldy,
+                           int M, int N, int K, int relu, void *workspace, int64_t workspace_bytes, dclStream_t stream) {
+  DCL_CHECK_ARG(M >= 0 && N > 0 && K > 0 && x && Wt && y && ldx >= K && ldw >= N && ldy >= N && workspace_bytes >= 0);
+  DCL_CHECK_ARG(workspace_bytes == 0 || workspace);
+  if (M == 0) return 0;
+  int epilogue = HIPBLASLT_EPILOGUE_DEFAULT;
+  if (bias && relu) epilogue = HIPBLASLT_EPILOGUE_RELU_BIAS;
+  else if (bias) epilogue = HIPBLASLT_EPILOGUE_BIAS;
+  else if (relu) epilogue = HIPBLASLT_EPILOGUE_RELU;
+  std::lock_guard<std::mutex> lock(g_mu);                  // plans and the descriptor's bias pointer are shared state
+  Plan *p = nullptr;
+  int rc = get_plan(PlanKey{M, N, K, ldx, ldw, ldy, epilogue, workspace_bytes}, &p);
+  if (rc) return rc;
+  if (bias) LT_CHECK(hipblasLtMatmulDescSetAttribute(p->desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)));
+  const float one = 1.0f, zero = 0.0f;
+  LT_CHECK(hipblasLtMatmul(g_handle, p->desc, &one, Wt, p->w, x, p->x, &zero, y, p->y, y, p->y, &p->algo, workspace,
+                           p->ws, (hipStream_t)stream));
+  return 0;
+}

@@ -360,7 +360,17 @@ class Network(nn.Module):
     _DIS_TAGS = (("p1", 256), ("m1", 64), ("p2", 256), ("m2", 64))
 
     def _disengage_buffers(self, side, rows, dev):
-        return {side + tag: torch.empty((rows, c), dtype=torch.float32, device=dev) for tag, c in self._DIS_TAGS}
+        """outputs of a side's four disengage stacks.  Two of them are one half of a later concatenation -- cat[F_Xc_p1,
+        F_Xo_p] / cat[F_Xc_m1, F_Xo_m] feed neck_fuser / regressor_conf (models/DCL_Net.py:207-211), cat[F_Yc_p, F_Yo_p2] /
+        cat[F_Yc_m, F_Yo_m2] the *_bi twins -- so they are column blocks of those wider buffers from the start (the GEMM
+        writes them in place, the attention fills the other block later: no copies)."""
+        new = lambda c: torch.empty((rows, c), dtype=torch.float32, device=dev)               # noqa: E731
+        fuse, conf_in = new(512), new(128)
+        if side == "Xc":
+            return {"fuse1": fuse, "conf_in1": conf_in, "Xcp1": fuse[:, :256], "Xcm1": conf_in[:, :64],
+                    "Xcp2": new(256), "Xcm2": new(64)}
+        return {"fuse2": fuse, "conf_in2": conf_in, "Yop2": fuse[:, 256:], "Yom2": conf_in[:, 64:],
+                "Yop1": new(256), "Yom1": new(64)}
 
     def _disengage(self, f, side, pf_rows, act, rows=slice(None)):
         """the four disengage stacks of one side on a block of points: one shared 480->1024 GEMM (BN folded), then the four
@@ -369,7 +379,7 @@ class Network(nn.Module):
         H = self._lin_relu(pf_rows, W1t, t1)                                # (rows, 1024): 4 stacks at once
         for j, (tag, _) in enumerate(self._DIS_TAGS):
             Wt, bias = second[j]
-            torch._addmm_activation(bias, H[:, 256 * j:256 * (j + 1)], Wt, out=act[side + tag][rows])
+            ops.linear(H[:, 256 * j:256 * (j + 1)], Wt, bias, True, out=act[side + tag][rows])
 
     def _dense(self, f, pf_inp, pf_tmp, b, dev):
         """dense half of the fused pipeline on point-major activations: disengage stacks, correspondence attention,
@@ -402,15 +412,10 @@ class Network(nn.Module):
         def join():
             if side is not None:
                 main.wait_stream(side)
-        nN, nM = b * self.n_inp, b * self.n_tmp
-        fuse1 = torch.empty((nN, 512), dtype=torch.float32, device=dev)      # cat[F_Xc_p1, F_Xo_p]
-        conf_in1 = torch.empty((nN, 128), dtype=torch.float32, device=dev)   # cat[F_Xc_m1, F_Xo_m]
-        fuse2 = torch.empty((nM, 512), dtype=torch.float32, device=dev)      # cat[F_Yc_p, F_Yo_p2]
-        conf_in2 = torch.empty((nM, 128), dtype=torch.float32, device=dev)   # cat[F_Yc_m, F_Yo_m2]
+        # cat[F_Xc_p1, F_Xo_p] / cat[F_Xc_m1, F_Xo_m] / cat[F_Yc_p, F_Yo_p2] / cat[F_Yc_m, F_Yo_m2]: the disengage GEMMs have
+        # already written their column block (_disengage_buffers), the attention fills the other one
+        fuse1, conf_in1, fuse2, conf_in2 = act["fuse1"], act["conf_in1"], act["fuse2"], act["conf_in2"]
         (l1, sA, tA), (l2, sB, tB) = f["neck_fuser"], f["neck_fuser_bi"]
-        # the four column blocks that the attention does not write, in one launch
-        ops.pad_copy_many([(fuse1[:, :256], act["Xcp1"]), (conf_in1[:, :64], act["Xcm1"]), (fuse2[:, 256:], act["Yop2"]),
-                           (conf_in2[:, 64:], act["Yom2"])])
         with second:
             ops.cross_attention(b, act["Yom2"], act["Xcm2"], act["Xcp2"], fuse2[:, :256], act["Xcm2"], conf_in2[:, :64])
             logit2 = self._mlp(conf_in2, f["regressor_conf_bi"])

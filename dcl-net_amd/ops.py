@@ -659,6 +659,43 @@ def pose_heads(pooled, rot_layers, trans_layers):
     return o9, trans
 
 
+_LT_WORKSPACES = {}            # (device index, stream handle) -> uint8 scratch the GEMM library may use on that stream
+_LT_WORKSPACE_BYTES = 32 << 20
+
+
+def _lt_workspace(dev):
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
+    ws = _LT_WORKSPACES.get(key)
+    if ws is None:
+        if torch.cuda.is_current_stream_capturing():       # not from a graph's private pool: run without scratch instead
+            return None
+        ws = _LT_WORKSPACES[key] = torch.empty(_LT_WORKSPACE_BYTES, dtype=torch.uint8, device=dev)
+    return ws
+
+
+def linear(x, Wt, bias=None, relu=False, out=None):
+    """One per-point linear layer (Conv1d k=1 / 1x1x1 Conv3d + folded BN of the reference's MLP stacks): act(x @ Wt + bias)
+    as a library GEMM with bias / ReLU epilogue, called through the C-ABI.  x (M,K), Wt (K,N), out (M,N) are row-major 2-D
+    tensors whose rows may be strided (column blocks of wider buffers): `out=buf[:, 256:512]` is written in place, no copy."""
+    N.need_cuda(x, Wt)
+    assert x.dim() == 2 and Wt.dim() == 2 and x.shape[1] == Wt.shape[0] and x.dtype == Wt.dtype == torch.float32
+    M, K = x.shape
+    n = Wt.shape[1]
+    if out is None:
+        out = torch.empty((M, n), dtype=torch.float32, device=x.device)
+    assert out.shape == (M, n) and out.dtype == torch.float32 and out.is_cuda
+    for t in (x, Wt, out):
+        assert t.stride(1) == 1 or t.shape[1] == 1, "rows must be dense"
+    if bias is not None:
+        assert bias.is_cuda and bias.dtype == torch.float32 and bias.numel() == n and bias.is_contiguous()
+    pitch = lambda t: int(t.stride(0)) if t.shape[0] > 1 else max(int(t.stride(0)), int(t.shape[1]))   # noqa: E731
+    ws = _lt_workspace(x.device)
+    N.check(N.lib().dcl_linear_fwd(N.ptr(x), C.c_int64(pitch(x)), N.ptr(Wt), C.c_int64(pitch(Wt)), N.ptr(bias), N.ptr(out),
+                                   C.c_int64(pitch(out)), int(M), int(n), int(K), int(bool(relu)), N.ptr(ws),
+                                   C.c_int64(0 if ws is None else ws.numel()), N.stream()), "linear_fwd")
+    return out
+
+
 def ortho9d_to_matrix(o9):
     """ortho9d2matrix (models/DCL_Net.py:15-36): (b,9) -> (b,3,3)."""
     N.need_cuda(o9)

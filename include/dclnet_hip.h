@@ -340,6 +340,14 @@ int dcl_pool_finish(int b, int c, int nslices, const float *part1, const float *
 int dcl_pose_heads(int b, const float *pooled, const float *const *rot_layers, const float *const *trans_layers,
                    float *h1_scratch, float *o9, float *trans, dclStream_t stream);
 
+/* One per-point linear layer -- Conv1d(k=1) / 1x1x1 Conv3d with its BatchNorm folded in (models/Modules.py:58-97, 173-201;
+ * the reference runs them as cuDNN pointwise convolutions): y[M x N] = act(x[M x K] Wt[K x N] + bias[N]), row-major, every
+ * matrix with its own row pitch (ldx >= K, ldw >= N, ldy >= N floats) so that x, Wt and y can be column blocks of wider
+ * buffers.  A library GEMM (hipBLASLt, fp32, bias / ReLU epilogue); bias may be NULL, relu 0/1.  workspace: device scratch
+ * the library may use (0 bytes allowed; it then picks an algorithm that needs none) -- not shared between streams.      */
+int dcl_linear_fwd(const float *x, int64_t ldx, const float *Wt, int64_t ldw, const float *bias, float *y, int64_t ldy,
+                   int M, int N, int K, int relu, void *workspace, int64_t workspace_bytes, dclStream_t stream);
+
 /* ortho9d2matrix (models/DCL_Net.py:15-36): o9 (b,9) -> R (b,3,3).             */
 int dcl_ortho9d_to_matrix(int b, const float *o9, float *R, dclStream_t stream);
 

@@ -711,6 +711,29 @@ def test_pose_heads_match_the_module_heads(dcl):
         assert float((t3.double() - t64).abs().max()) <= 2e-6 * max(1.0, float(t64.abs().max()) / 0.02)
 
 
+def test_linear_layer_writes_column_blocks_in_place(dcl):
+    """dcl_linear_fwd (library GEMM + bias / ReLU epilogue behind the C-ABI) against torch on dense and on strided operands:
+    x a column block of a wider buffer, out a column block of another -- the neighbouring columns must stay untouched"""
+    g = torch.Generator().manual_seed(11)
+    for M, K, n in ((1000, 256, 64), (4096, 480, 1024), (37, 128, 1), (2048, 512, 512), (5, 1024, 9)):
+        wide = torch.randn(M, K + 40, generator=g).cuda()
+        x = wide[:, 8:8 + K]
+        Wt = (torch.randn(K, n, generator=g) * 0.05).cuda()
+        bias = torch.randn(n, generator=g).cuda()
+        for relu, with_bias in ((True, True), (False, True), (False, False), (True, False)):
+            want = x @ Wt + (bias if with_bias else 0.0)
+            want = torch.relu(want) if relu else want
+            got = dcl.ops.linear(x, Wt, bias if with_bias else None, relu)
+            tol = 2e-5 * max(1.0, float(want.abs().max()))
+            assert float((got - want).abs().max()) <= tol, (M, K, n, relu, with_bias)
+            buf = torch.full((M, n + 24), 7.0).cuda()
+            dcl.ops.linear(x, Wt, bias if with_bias else None, relu, out=buf[:, 16:16 + n])
+            assert float((buf[:, 16:16 + n] - want).abs().max()) <= tol
+            assert bool((buf[:, :16] == 7.0).all()) and bool((buf[:, 16 + n:] == 7.0).all())
+    with pytest.raises(RuntimeError):
+        dcl.ops.linear(torch.zeros(4, 8), torch.zeros(8, 2))               # host tensors are refused
+
+
 def test_pad_copy_many_stages_and_hands_over_in_one_launch(dcl):
     """dcl_pad_copy_many (input staging / result hand-over of the whole-forward hipGraph): zero-padded 2-D copies, int64
     narrowing, column blocks of wider buffers, scalar fills -- all in one launch, bit for bit what the torch ops did"""
