@@ -123,7 +123,13 @@ __global__ __launch_bounds__(64) void k_three_nn_sp(int n, int m, const float4 *
 // the grid -- the thread scans its crop's rows.
 // mask_lk / pre_lk + wbase: where the window lookups read the occupancy words and rank prefixes from -- the global
 // arrays (wbase = 0) or the LDS copy of the point's crop (wbase = first word of the crop), see k_three_nn_grid_levels
-__device__ __forceinline__ void three_nn_grid_point(int p, const float4 u, const int4 *__restrict__ indices,
+// LPQ lanes per query (1 or 4, consecutive lanes; `sub` = the lane's share): with 4, the 25 (x, y) rows of the window and the
+// rows of a fallback scan are dealt round-robin to the lanes, every lane keeps its own three best keys (and prunes with
+// them), and two shuffle rounds merge the lists -- keys are a total order, so the merged triple is the sequential one.
+// Few queries (the reference's 1024 points per crop at bs 32, one-image calls) leave a one-thread-per-query launch at the
+// latency of its longest thread; many queries (12288 points per crop) fill the GPU either way and skip the merge.
+template <int LPQ>
+__device__ __forceinline__ void three_nn_grid_point(int p, int sub, const float4 u, const int4 *__restrict__ indices,
                                                     const uint32_t *__restrict__ mask,
                                                     const int32_t *__restrict__ wprefix, int nbatch, int S, int wpc,
                                                     float ve, float off, float *__restrict__ dist2,
@@ -151,7 +157,37 @@ __device__ __forceinline__ void three_nn_grid_point(int p, const float4 u, const
     // >= dx*dx in floating point too (dz*dz, dy*dy >= 0 and rounding is monotone), so "row bound > d3" excludes every key
     // of the row, ties included (an equal distance is not pruned).  Until three candidates exist d3 reads as NaN: no pruning.
     // The set of the three smallest keys does not depend on the visiting order.
-    if (!force_scan) {
+    if (!force_scan && LPQ > 1) {
+      const int order[5] = {0, -1, 1, -2, 2};
+#pragma unroll 2
+      for (int t = sub; t < 25; t += LPQ) {              // row t = (x-plane t / 5, y-row t % 5), centre-out in both
+        const int x = cc[0] + order[t / 5], y = cc[1] + order[t % 5];
+        if (x < lo[0] || x > hi[0] || y < lo[1] || y > hi[1]) continue;
+        const float qx = ((float)x * ve + off) + half, qy = ((float)y * ve + off) + half;
+        const float dx = u.y - qx, dy = u.z - qy;
+        if (__fmaf_rn(dx, dx, dy * dy) > __uint_as_float((unsigned)(b.k3 >> 32))) continue;
+        const int lin0 = ((bi * S + x) * S + y) * S;
+        const int w = (lin0 >> 5) - wbase, sh = lin0 & 31;
+        const uint32_t m = mask_lk[w];
+        uint32_t bits = (m >> (sh + lo[2])) & zmask;
+        if (bits == 0u) continue;
+        const int pre = pre_lk[w];
+        while (bits) {
+          const int tz = __builtin_ctz(bits);
+          bits &= bits - 1u;
+          const int z = lo[2] + tz, pos = sh + z;
+          const int row = pre + __popc(m & ((1u << pos) - 1u));
+          const float qz = ((float)z * ve + off) + half;
+          b.push(make_key(dcl_dist2(u.y, u.z, u.w, qx, qy, qz), row));
+        }
+      }
+#pragma unroll
+      for (int d = 1; d < LPQ; d <<= 1) {
+        const u64 o1 = __shfl_xor(b.k1, d, 64), o2 = __shfl_xor(b.k2, d, 64), o3 = __shfl_xor(b.k3, d, 64);
+        b.push(o1); b.push(o2); b.push(o3);
+      }
+    }
+    if (!force_scan && LPQ == 1) {
       const int order[5] = {0, -1, 1, -2, 2};
 #pragma unroll
       for (int ix = 0; ix < 5; ++ix) {
@@ -198,15 +234,22 @@ __device__ __forceinline__ void three_nn_grid_point(int p, const float4 u, const
     }
     const float d3 = __uint_as_float((unsigned)(b.k3 >> 32));
     const bool certified = !force_scan && (bound == INFINITY || d3 < bound * bound * 0.9999f) && !(bound < 0.0f);
-    if (!certified) {
+    if (!certified) {                                    // (uniform over a query's lanes: they hold the same merged keys)
       b.init();
       const int r0 = wprefix[(size_t)bi * wpc], r1 = wprefix[(size_t)(bi + 1) * wpc];
-      for (int j = r0; j < r1; ++j) {
+#pragma unroll 4
+      for (int j = r0 + sub; j < r1; j += LPQ) {
         const float4 q = voxel_centre(indices[j], ve, off, half);
         b.push(q.x == u.x ? make_key(dcl_dist2(u.y, u.z, u.w, q.y, q.z, q.w), j) : ~0ull);
       }
+#pragma unroll
+      for (int d = 1; d < LPQ; d <<= 1) {
+        const u64 o1 = __shfl_xor(b.k1, d, 64), o2 = __shfl_xor(b.k2, d, 64), o3 = __shfl_xor(b.k3, d, 64);
+        b.push(o1); b.push(o2); b.push(o3);
+      }
     }
   }
+  if (sub != 0) return;
   dist2[p * 3 + 0] = __uint_as_float((unsigned)(b.k1 >> 32));
   dist2[p * 3 + 1] = __uint_as_float((unsigned)(b.k2 >> 32));
   dist2[p * 3 + 2] = __uint_as_float((unsigned)(b.k3 >> 32));
@@ -219,7 +262,7 @@ __global__ __launch_bounds__(256) void k_three_nn_grid(int n, const float4 *__re
                                                        float ve, float off, float *__restrict__ dist2,
                                                        int32_t *__restrict__ idx, int force_scan) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < n) three_nn_grid_point(p, unknown[p], indices, mask, wprefix, nbatch, S, wpc, ve, off, dist2, idx, force_scan, mask, wprefix, 0);
+  if (p < n) three_nn_grid_point<1>(p, 0, unknown[p], indices, mask, wprefix, nbatch, S, wpc, ve, off, dist2, idx, force_scan, mask, wprefix, 0);
 }
 
 // all 4 levels of the read-out in one launch (blockIdx.y = level); dist2 / idx are level-major blocks of n*3
@@ -228,16 +271,18 @@ __global__ __launch_bounds__(256) void k_three_nn_grid(int n, const float4 *__re
 // occupancy words and rank prefixes of one level are at most 2 x 4 KB (32^3 cells), so a workgroup whose 256 points
 // belong to one crop -- the runner's point rows are crop-contiguous -- stages them in LDS first.
 constexpr int kNnLdsWords = 1024;
+template <int LPQ>
 __global__ __launch_bounds__(256) void k_three_nn_grid_levels(int n, const float4 *__restrict__ unknown,
                                                               const DclReadoutLevels L, int nbatch, float off,
                                                               float *__restrict__ dist2, int32_t *__restrict__ idx,
                                                               int force_scan) {
   __shared__ uint32_t s_mask[kNnLdsWords];
   __shared__ int32_t s_pre[kNnLdsWords];
-  const int p = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+  constexpr int QPB = 256 / LPQ;                                            // queries per workgroup
+  const int p = blockIdx.x * QPB + threadIdx.x / LPQ, sub = threadIdx.x % LPQ, m = blockIdx.y;
   const int wpc = L.wpc[m];
   const float4 u = p < n ? unknown[p] : make_float4(-1.f, 0.f, 0.f, 0.f);
-  const float4 u0 = unknown[blockIdx.x * blockDim.x];                       // uniform: the block's first point
+  const float4 u0 = unknown[blockIdx.x * QPB];                              // uniform: the block's first point
   const int b0 = (int)u0.x;
   const bool crop_ok = b0 >= 0 && b0 < nbatch && (float)b0 == u0.x && wpc <= kNnLdsWords;
   const int same = __syncthreads_and((p >= n || u.x == u0.x) ? 1 : 0);
@@ -250,7 +295,7 @@ __global__ __launch_bounds__(256) void k_three_nn_grid_levels(int n, const float
     __syncthreads();
   }
   if (p < n)
-    three_nn_grid_point(p, u, reinterpret_cast<const int4 *>(L.indices[m]), L.mask[m], L.wprefix[m], nbatch, L.S[m], wpc,
+    three_nn_grid_point<LPQ>(p, sub, u, reinterpret_cast<const int4 *>(L.indices[m]), L.mask[m], L.wprefix[m], nbatch, L.S[m], wpc,
                         L.ve[m], off, dist2 + (size_t)m * n * 3, idx + (size_t)m * n * 3, force_scan,
                         staged ? s_mask : L.mask[m], staged ? s_pre : L.wprefix[m], staged ? b0 * wpc : 0);
 }
@@ -447,7 +492,9 @@ int dcl_three_nn_sp_strided(int n, int m, const float *unknown, const float *kno
 }
 
 // internal: the known set is given as voxel rows (b,x,y,z) i32; their centres idx*ve + off + ve/2 are formed in the kernel
-static std::atomic<int> g_nn_grid{1};   // tuning/test hook: 0 = brute-force scan per crop for every level, 2 = grid kernel with the scan forced
+static std::atomic<int> g_nn_grid{1};   // tuning/test hook: 0 = brute-force scan per crop for every level, 2 = grid kernel with the scan forced, 3 / 4 / 5 = one / four / eight lanes per query
+constexpr int kNnCoopMaxQueries = 1 << 17;   // read-outs of up to this many points search with four lanes per query,
+constexpr int kNnCoop8MaxQueries = 40960;    // up to this many (bs 40 x 1024 points) with eight
 DCL_API void dcl_debug_three_nn_grid(int mode) { g_nn_grid = mode; }
 
 // known_mask / S (optional): the level's occupancy bits and grid size; with them, levels of S = 16 or 32 go through the
@@ -493,8 +540,20 @@ bool dcl_internal_readout_fused_ok(const DclReadoutLevels &L, int ld, bool need_
 int dcl_internal_readout_neighbours(int n, const float *points_b4, const DclReadoutLevels &L, int nbatch, float off,
                                     float *dist2, int32_t *idx, dclStream_t stream) {
   DCL_CHECK_ARG(n > 0 && points_b4 && dist2 && idx && nbatch > 0);
-  hipLaunchKernelGGL(k_three_nn_grid_levels, dim3(dcl_div_up(n, 256), 4), dim3(256), 0, (hipStream_t)stream, n,
-                     reinterpret_cast<const float4 *>(points_b4), L, nbatch, off, dist2, idx, g_nn_grid == 2 ? 1 : 0);
+  // several lanes per query while the launch would otherwise be latency-bound (see three_nn_grid_point): measured on the
+  // bs-32 sets, us for 1 / 4 / 8 lanes: 32768 points 137 / 44 / 36, 65536 points 141 / 53 / 59, 393216 points 172 / 186 / --.
+  // hook: 3 / 4 / 5 force the one- / four- / eight-lane variant
+  const int mode = g_nn_grid.load();
+  const int lpq = mode == 3 ? 1 : mode == 4 ? 4 : mode == 5 ? 8 : n <= kNnCoop8MaxQueries ? 8 : n <= kNnCoopMaxQueries ? 4 : 1;
+  if (lpq == 8)
+    hipLaunchKernelGGL(k_three_nn_grid_levels<8>, dim3(dcl_div_up(n, 32), 4), dim3(256), 0, (hipStream_t)stream, n,
+                       reinterpret_cast<const float4 *>(points_b4), L, nbatch, off, dist2, idx, mode == 2 ? 1 : 0);
+  else if (lpq == 4)
+    hipLaunchKernelGGL(k_three_nn_grid_levels<4>, dim3(dcl_div_up(n, 64), 4), dim3(256), 0, (hipStream_t)stream, n,
+                       reinterpret_cast<const float4 *>(points_b4), L, nbatch, off, dist2, idx, mode == 2 ? 1 : 0);
+  else
+    hipLaunchKernelGGL(k_three_nn_grid_levels<1>, dim3(dcl_div_up(n, 256), 4), dim3(256), 0, (hipStream_t)stream, n,
+                       reinterpret_cast<const float4 *>(points_b4), L, nbatch, off, dist2, idx, mode == 2 ? 1 : 0);
   DCL_LAUNCH_CHECK();
   return 0;
 }

@@ -440,7 +440,9 @@ void dcl_debug_attention_xcd_remap(int on);
  * the conv/pool chain in LDS; 64^3 grids), 0 = 8 chained launches.  Both produce identical masks.  Process-wide atomic. */
 int dcl_debug_geometry_chain(int mode);
 /* Test hook, 3-NN of the point read-out: 1 (default) = grid-pruned search on the 32^3 / 16^3 levels, 0 = per-crop scan on
- * every level, 2 = grid kernel with its scan fallback forced for every query (all three give identical results). */
+ * every level, 2 = grid kernel with its scan fallback forced for every query, 3 / 4 / 5 = grid kernel with one / four /
+ * eight lanes per query whatever the number of points (automatic: eight up to 40960 points, four up to 131072, else
+ * one).  All give identical results. */
 void dcl_debug_three_nn_grid(int mode);
 /* Tuning hook: 0 = automatic split-K choice in dcl_sparse_conv_fwd_ws, n = force n splits (when the scratch allows),
  * -1 = at most 8 splits even for few-row launches, -2 = never split. */

@@ -933,13 +933,13 @@ def test_point_neighbours_grid_search_is_exact(dcl, scales, unit):
     lib = dcl.ops.N.lib()
     res = {}
     try:
-        for mode in (0, 1, 2):
+        for mode in (0, 1, 2, 3, 4, 5):              # scan / automatic / forced fallback / 1, 4, 8 lanes per query
             lib.dcl_debug_three_nn_grid(mode)
             d, i = run.point_neighbours(pb4, extents, off)
             res[mode] = (d.cpu().numpy(), i.cpu().numpy())
     finally:
         lib.dcl_debug_three_nn_grid(1)
-    for mode in (1, 2):
+    for mode in (1, 2, 3, 4, 5):
         assert np.array_equal(res[mode][1], res[0][1]), mode
         assert np.array_equal(res[mode][0].view(np.uint32), res[0][0].view(np.uint32)), mode
     # the searched levels really had work to do, and the fallback was exercised (isolated queries exist)
