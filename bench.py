@@ -73,6 +73,18 @@ def measure_traffic_bytes(kernel_substr, shape, batch, timeout_s=300):
         "workload, average per launch of the kernel; FETCH_SIZE x2 (gfx950), KiB -> B")
 
 
+def _flush_c_stdio(unbuffer=False):
+    """C-level stdout (libraries that printf, e.g. RCCL's banner): flush it, optionally switch it to unbuffered."""
+    import ctypes
+    try:
+        libc = ctypes.CDLL(None)
+        if unbuffer:
+            libc.setvbuf(ctypes.c_void_p.in_dll(libc, "stdout"), None, 2, 0)          # _IONBF
+        libc.fflush(None)
+    except (OSError, ValueError):
+        pass
+
+
 def to_device(data, dev):
     out = {}
     for k, v in data.items():
@@ -379,6 +391,7 @@ def sparse_conv_roofline(dcl, net, data, dev, steps=3):
 
 
 def main():
+    _flush_c_stdio(unbuffer=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -506,9 +519,16 @@ def main():
         line["primitives"] = primitives_roofline(dcl)
         line["refiner"] = refiner_bench(dcl, dev, b)
         line["cpu_baseline"] = cpu_baseline(dcl, sd, cfg, n_inp, n_tmp)
+    # the JSON line is the LAST thing on stdout: RCCL writes its banner ("RCCL version ...", "Librccl path ...") through C
+    # stdio, which on a pipe is only flushed at exit -- i.e. behind a line printed here.  C stdout was made unbuffered in
+    # main(); every rank flushes once more, and rank 0 prints after a barrier behind those flushes.
+    _flush_c_stdio()
+    if distributed:
+        dist.barrier()
     if rank == 0:
         print(json.dumps(line), flush=True)
     if distributed:
+        dist.barrier()
         dist.destroy_process_group()
 
 
