@@ -298,7 +298,8 @@ class BackboneRun(object):
     def __init__(self, occ, batch, S, batch_lo=0, counts_dev=None):
         """occ (V0,4) i32 [b,x,y,z]; batch_lo > 0 (or batch < number of crops in occ): pass over the crop window
         batch_lo .. batch_lo+batch-1 only (its crops are re-based to 0).  counts_dev: optional i32[8] slice of a caller's
-        tensor that receives the level sizes (several passes can then be read back with one copy)."""
+        tensor that receives the level sizes -- a device tensor (several passes can then be read back with one copy) or
+        PINNED host memory, which the geometry kernels write directly (the caller waits for the stream and reads it)."""
         N.need_cuda(occ)
         assert occ.dtype == torch.int32 and occ.is_contiguous()
         self.occ, self.batch, self.S, self.V0 = occ, int(batch), int(S), occ.shape[0]

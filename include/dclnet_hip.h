@@ -191,7 +191,9 @@ int dcl_pad_copy_many(const DclPadCopyJob *jobs_host, int njobs, dclStream_t str
  * + BN + ReLU, SubMConv3d k3 + BN + ReLU, SparseAvgPool3d k3 s2 p1]) and its point read-out
  * (Ops_GetPointFeat_spconv.forward, :236-251) as three enqueue-only calls with ONE host read-back of the 8 level
  * sizes in between (the reference: ~2.5k launches, 32 blocking copies).  Workspaces are caller-allocated;
- * `channels_host` = the 9 backbone dims [7,16,32,32,64,64,128,128,256]; counts = [n_conv1, n_pool1, ..., n_pool4].   */
+ * `channels_host` = the 9 backbone dims [7,16,32,32,64,64,128,128,256]; counts = [n_conv1, n_pool1, ..., n_pool4].
+ * `counts_dev` of the geometry calls is written by kernels: device memory, or device-visible pinned host memory
+ * (hipHostMalloc) -- the caller then only waits for the stream and reads the 8 sizes, no copy is enqueued.              */
 int dcl_backbone_ws_bytes(int batch, int S, int V0, int64_t *bytes_host);
 int dcl_backbone_geometry(const int32_t *occ, int V0, int batch, int S, void *ws, int64_t ws_bytes,
                           int32_t *counts_dev /* i32[8] */, dclStream_t stream);
