@@ -223,7 +223,7 @@ def lm_stream_bench(dcl, dev, reps=30):
     """BASELINE config 4 (S3): LineMOD eval stream -- one object crop per call (tools/test_LM.py:104-112), N=M=1024,
     5 mm voxels (configs/config_LM.yaml:17-20); forward() vs the whole-forward hipGraph replay, inputs resident in HBM."""
     cfg = dcl.synth.default_cfg(1024, 1024, unit=0.005)
-    net = dcl.DCL_Net.Network(cfg, mode="test")
+    net = dcl.DCL_Net.Network(cfg, mode="test", graph_max_batch=0)      # "eager" below is the plain launch-by-launch call
     net.load_state_dict(dcl.synth.synth_state_dict(net, 1))
     net = net.to(dev).eval()
     out = {"workload": "LineMOD stream: 1 crop per call, N=M=1024, 64^3 x 5 mm voxels"}

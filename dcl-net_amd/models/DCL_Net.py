@@ -66,9 +66,11 @@ def _fuser():
 
 
 class Network(nn.Module):
-    def __init__(self, cfg, mode="train", fused=True, graph_max_batch=0, async_inputs=False):
-        """graph_max_batch > 0: eval-mode calls with at most that many crops go through forward_graphed (one whole-forward
-        hipGraph per batch size) -- the one-image-at-a-time eval loops of the reference are launch-bound otherwise.
+    def __init__(self, cfg, mode="train", fused=True, graph_max_batch=8, async_inputs=False):
+        """graph_max_batch > 0 (default 8): eval-mode calls with at most that many crops go through forward_graphed (one
+        whole-forward hipGraph per batch size, captured on first use) -- the one-image-at-a-time eval loops of the
+        reference (tools/test_LM.py:104-112: one object per call) are launch-bound otherwise: 0.6 instead of 1.2-1.4 ms
+        per one-crop call.  0 switches it off (every call eager).
         async_inputs=True: the caller guarantees that `data`'s CUDA tensors are complete when forward() is called (or hands
         over data["ready_event"]) and are not overwritten until the results have been consumed.  The sparse half of a call
         (side streams) then does not wait for the dense half of the previous call still running on the current stream, so
@@ -510,6 +512,8 @@ class Network(nn.Module):
         for k in o:                                                          # train-mode extras (Xo_pred, Yc_pred)
             if k not in out:
                 out[k] = o[k].clone()
+        if self.mode != "test":
+            out["sym_flag"] = data["flags"].to(dev)                          # as in forward() (models/DCL_Net.py:249)
         data["labels"]["points_tmp"] = res["pts_tmp"]
         data["labels"]["points_inp"] = res["pts_inp"]
         return out

@@ -118,7 +118,7 @@ def test_built_crops_run_through_the_network(dcl):
     builder = dcl.crops.CropBuilder(cfg, sc["cad_pts"], sc["cad_col"])
     np.random.seed(7)
     data = builder.build(sc["img"], sc["depth"], sc["label"], sc["rois"], sc["gt_obj"])
-    net = dcl.DCL_Net.Network(dcl.synth.default_cfg(256, 256), mode="test")
+    net = dcl.DCL_Net.Network(dcl.synth.default_cfg(256, 256), mode="test", graph_max_batch=0)
     net.load_state_dict(dcl.synth.synth_state_dict(net, 1))
     net = net.cuda().eval()
     with torch.no_grad():
@@ -126,7 +126,7 @@ def test_built_crops_run_through_the_network(dcl):
     b = int(data["all_flags"].sum())
     assert out["rot_pred"].shape == (b, 3, 3) and torch.isfinite(out["rot_pred"]).all()
     # the same crops through a pipelining network: its side streams wait on the builder's ready_event only
-    anet = dcl.DCL_Net.Network(dcl.synth.default_cfg(256, 256), mode="test", async_inputs=True)
+    anet = dcl.DCL_Net.Network(dcl.synth.default_cfg(256, 256), mode="test", async_inputs=True, graph_max_batch=0)
     anet.load_state_dict(dcl.synth.synth_state_dict(anet, 1))
     anet = anet.cuda().eval()
     for _ in range(3):

@@ -14,9 +14,10 @@ pytestmark = pytest.mark.gpu
 R_TOL, T_TOL = 1e-4, 1e-5
 
 
-def _net(dcl, n_inp, n_tmp, seed, fused=True):
+def _net(dcl, n_inp, n_tmp, seed, fused=True, graph_max_batch=0):
+    """eager by default: the whole-forward graph path of small batches has its own tests (graphed=True, forward_graphed)"""
     cfg = dcl.synth.default_cfg(n_inp, n_tmp)
-    net = dcl.DCL_Net.Network(cfg, mode="test", fused=fused)
+    net = dcl.DCL_Net.Network(cfg, mode="test", fused=fused, graph_max_batch=graph_max_batch)
     sd = dcl.synth.synth_state_dict(net, seed)
     net.load_state_dict(sd)
     return net.cuda().eval(), sd, cfg
@@ -205,7 +206,7 @@ def test_stress_shape_full_batch_properties(dcl):
     tilings) give the same pose"""
     n_inp, n_tmp, b = 12288, 2048, 32
     cfg = dcl.synth.default_cfg(n_inp, n_tmp)
-    net = dcl.DCL_Net.Network(cfg, mode="test")
+    net = dcl.DCL_Net.Network(cfg, mode="test", graph_max_batch=0)
     net.load_state_dict(dcl.synth.synth_state_dict(net, 1))
     net = net.cuda().eval()
     data = dcl.synth.make_batch(b, n_inp, n_tmp)
@@ -251,7 +252,7 @@ def test_stress_shape_batch_invariance(dcl):
     take the 4-wave one; each crop's pose must not depend on its batch mates or on the kernel variant"""
     n_inp, n_tmp = 12288, 2048
     cfg = dcl.synth.default_cfg(n_inp, n_tmp)
-    net = dcl.DCL_Net.Network(cfg, mode="test")
+    net = dcl.DCL_Net.Network(cfg, mode="test", graph_max_batch=0)      # eager: the kernel variants are the subject
     net.load_state_dict(dcl.synth.synth_state_dict(net, 1))
     net = net.cuda().eval()
     with torch.no_grad():
@@ -317,7 +318,7 @@ def test_pipelined_calls_give_the_same_results(dcl):
     cfg = dcl.synth.default_cfg(n, n)
     nets = {}
     for flag in (False, True):
-        net = dcl.DCL_Net.Network(cfg, mode="test", async_inputs=flag)
+        net = dcl.DCL_Net.Network(cfg, mode="test", async_inputs=flag, graph_max_batch=0)
         net.load_state_dict(dcl.synth.synth_state_dict(net, 1))
         nets[flag] = net.cuda().eval()
     dev = torch.device("cuda")
@@ -342,7 +343,7 @@ def test_chunked_sparse_half_and_stream_switches_give_the_same_results(dcl, monk
     the single-stream mode must return what the default schedule returns"""
     n = 384
     cfg = dcl.synth.default_cfg(n, n)
-    net = dcl.DCL_Net.Network(cfg, mode="test")
+    net = dcl.DCL_Net.Network(cfg, mode="test", graph_max_batch=0)
     net.load_state_dict(dcl.synth.synth_state_dict(net, 1))
     net = net.cuda().eval()
     data = dcl.synth.make_batch(8, n, n)

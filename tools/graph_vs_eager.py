@@ -9,7 +9,7 @@ dcl = importlib.import_module("dcl-net_amd")
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 m = int(sys.argv[3]) if len(sys.argv) > 3 else n
-net = dcl.DCL_Net.Network(dcl.synth.default_cfg(n, m), mode="test")
+net = dcl.DCL_Net.Network(dcl.synth.default_cfg(n, m), mode="test", graph_max_batch=0)
 net.load_state_dict(dcl.synth.synth_state_dict(net, 1))
 net = net.cuda().eval()
 data = bench.to_device(dcl.synth.make_batch(b, n, m), torch.device("cuda"))

@@ -12,7 +12,7 @@ dcl = importlib.import_module("dcl-net_amd")
 shape = sys.argv[1] if len(sys.argv) > 1 else "ref"
 b = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 n_inp, n_tmp = bench.SHAPES[shape]
-net = dcl.DCL_Net.Network(dcl.synth.default_cfg(n_inp, n_tmp), mode="test")
+net = dcl.DCL_Net.Network(dcl.synth.default_cfg(n_inp, n_tmp), mode="test", graph_max_batch=0)
 net.load_state_dict(dcl.synth.synth_state_dict(net, 1))
 net = net.cuda().eval()
 data = bench.to_device(dcl.synth.make_batch(b, n_inp, n_tmp), torch.device("cuda"))

@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 dcl = importlib.import_module("dcl-net_amd")
 n = 1024
 cfg = dcl.synth.default_cfg(n, n)
-net = dcl.DCL_Net.Network(cfg, mode="test")
+net = dcl.DCL_Net.Network(cfg, mode="test", graph_max_batch=0)
 net.load_state_dict(dcl.synth.synth_state_dict(net, 1))
 net = net.cuda().eval()
 for b in (1, 4, 8, 32):

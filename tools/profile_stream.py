@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 import bench
 dcl = importlib.import_module("dcl-net_amd")
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-net = dcl.DCL_Net.Network(dcl.synth.default_cfg(1024, 1024, unit=0.005), mode="test")
+net = dcl.DCL_Net.Network(dcl.synth.default_cfg(1024, 1024, unit=0.005), mode="test", graph_max_batch=0)
 net.load_state_dict(dcl.synth.synth_state_dict(net, 1))
 net = net.cuda().eval()
 data = bench.to_device(dcl.synth.make_batch(b, 1024, 1024, unit=0.005), torch.device("cuda"))

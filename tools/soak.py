@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 import bench
 dcl = importlib.import_module("dcl-net_amd")
 n = 1024
-net = dcl.DCL_Net.Network(dcl.synth.default_cfg(n, n), mode="test", async_inputs=True)
+net = dcl.DCL_Net.Network(dcl.synth.default_cfg(n, n), mode="test", async_inputs=True, graph_max_batch=0)
 net.load_state_dict(dcl.synth.synth_state_dict(net, 1))
 net = net.cuda().eval()
 dev = torch.device("cuda")
