@@ -426,7 +426,8 @@ def main():
     # headline: strictly serial forward calls (the attention roofline is then measured on an otherwise idle GPU);
     # --pipelined-calls lets back-to-back calls overlap (async_inputs: sparse half of call k+1 under the dense half of
     # call k) -- reported as an extra at N=1
-    net = dcl.DCL_Net.Network(cfg, mode="test", async_inputs=args.pipelined_calls)
+    net = dcl.DCL_Net.Network(cfg, mode="test", async_inputs=args.pipelined_calls,
+                              **({"graph_max_batch": 0} if args.pmc_child else {}))   # counter passes: separate launches
     sd = dcl.synth.synth_state_dict(net, 1)
     net.load_state_dict(sd)
     net = net.to(dev).eval()
@@ -440,6 +441,13 @@ def main():
         return
 
     dt, att_ms = run_forward_bench(dcl, net, data, args.steps, args.warmup, distributed)
+    graphed = bool(net.__dict__.get("_graphs"))          # calls this small in points replay a whole-forward hipGraph (default)
+    net_l = net
+    if graphed:                                          # per-kernel timings (attention events, conv hooks) need separate launches
+        net_l = dcl.DCL_Net.Network(cfg, mode="test", async_inputs=args.pipelined_calls, graph_max_batch=0)
+        net_l.load_state_dict(sd)
+        net_l = net_l.to(dev).eval()
+        _, att_ms = run_forward_bench(dcl, net_l, data, max(5, args.steps // 2), 2, False)
     frames = world * b * args.steps
     value = frames / dt
 
@@ -477,36 +485,49 @@ def main():
                                    "64^3 x 6 mm voxels; shape=%s" % (n_inp, n_tmp, args.shape),
                        "global_batch": world * b, "frames_per_step_per_gpu": b, "parallelism": "frames sharded x%d" % world,
                        "weights": "seeded random (no checkpoints offline)",
-                       "calls": "pipelined (async_inputs)" if args.pipelined_calls else "serial"},
+                       "calls": "pipelined (async_inputs)" if args.pipelined_calls else "serial",
+                       "path": "whole-forward hipGraph replay" if graphed else "launch by launch"},
             "roofline": roofline,
             "whole_forward": whole_forward_rate(n_inp, n_tmp, b, dt / args.steps),
             "adds_auc_synthetic_weights": auc, "metric_frames_reduced": int(table.sums[:, 0].sum())}
     rdata_for_pipe = None
     if rank == 0 and world == 1 and not args.no_extras:
-        line["roofline_sparse_conv"] = {args.shape: sparse_conv_roofline(dcl, net, data, dev)}
+        line["roofline_sparse_conv"] = {args.shape: sparse_conv_roofline(dcl, net_l, data, dev)}
         if args.shape != "ref":
             rn, rm = SHAPES["ref"]
             rcfg = dcl.synth.default_cfg(rn, rm)
+            # two instances: `rnet` as a caller constructs it (calls this small in points replay the whole-forward hipGraph,
+            # Network.__init__), `rnet_l` launch by launch -- what the per-kernel timings (attention events, conv hooks)
+            # need, and the number the graph replay is compared with
             rnet = dcl.DCL_Net.Network(rcfg, mode="test", async_inputs=args.pipelined_calls)
-            rnet.load_state_dict(dcl.synth.synth_state_dict(rnet, 1))
-            rnet = rnet.to(dev).eval()
+            rnet_l = dcl.DCL_Net.Network(rcfg, mode="test", async_inputs=args.pipelined_calls, graph_max_batch=0)
+            for m_ in (rnet, rnet_l):
+                m_.load_state_dict(dcl.synth.synth_state_dict(m_, 1))
+            rnet, rnet_l = rnet.to(dev).eval(), rnet_l.to(dev).eval()
             rdata = to_device(dcl.synth.make_batch(b, rn, rm), dev)
-            rdt, ratt = run_forward_bench(dcl, rnet, rdata, max(args.steps, 20), max(args.warmup, 3), False)
             rsteps = max(args.steps, 20)
+            rdt, _ = run_forward_bench(dcl, rnet, rdata, rsteps, max(args.warmup, 3), False)
+            ldt, ratt = run_forward_bench(dcl, rnet_l, rdata, rsteps, max(args.warmup, 3), False)
             rflop = 2.0 * (64 + 320) * rn * rm * b
+            graphed = bool(rnet.__dict__.get("_graphs"))
             line["ref_shape"] = {"workload": "N=M=1024 (what config_YCBV_bs32.yaml defines), bs=32",
                                  "value": round(b * rsteps / rdt, 2), "unit": "frames/s",
                                  "ms_per_step": round(rdt / rsteps * 1e3, 3),
+                                 "path": "whole-forward hipGraph replay (default for calls of <= 98304 points)" if graphed
+                                         else "launch by launch",
+                                 "launch_by_launch": {"value": round(b * rsteps / ldt, 2), "ms_per_step": round(ldt / rsteps * 1e3, 3)},
                                  "attention_TFLOPs": round(rflop / (np.mean(ratt) * 1e-3) / 1e12, 2) if ratt else None}
-            line["roofline_sparse_conv"]["ref"] = sparse_conv_roofline(dcl, rnet, rdata, dev)
+            line["roofline_sparse_conv"]["ref"] = sparse_conv_roofline(dcl, rnet_l, rdata, dev)
             # BASELINE configs[2]'s per-GPU shape: 40 crops per call (config_YCBV_bs40.yaml)
             d40 = to_device(dcl.synth.make_batch(40, rn, rm), dev)
             dt40, _ = run_forward_bench(dcl, rnet, d40, 20, 3, False)
+            lt40, _ = run_forward_bench(dcl, rnet_l, d40, 20, 3, False)
             line["bs40"] = {"workload": "N=M=1024, bs=40 (config_YCBV_bs40.yaml batch)", "unit": "frames/s",
-                            "value": round(40 * 20 / dt40, 2), "ms_per_step": round(dt40 / 20 * 1e3, 3)}
+                            "value": round(40 * 20 / dt40, 2), "ms_per_step": round(dt40 / 20 * 1e3, 3),
+                            "launch_by_launch": {"value": round(40 * 20 / lt40, 2), "ms_per_step": round(lt40 / 20 * 1e3, 3)}}
             line["stage2_chain"] = stage2_chain_bench(dcl, dev, rnet, rdata, b)
             rdata_for_pipe = (rcfg, rdata)
-            del rnet, d40
+            del rnet, rnet_l, d40
         # the same forward fed from the loader's HOST tensors (pageable memory, H2D inside forward) -- never `value`
         hdt, _ = run_forward_bench(dcl, net, host_data, max(3, args.steps // 2), 1, False)
         hsteps = max(3, args.steps // 2)

@@ -66,17 +66,21 @@ def _fuser():
 
 
 class Network(nn.Module):
-    def __init__(self, cfg, mode="train", fused=True, graph_max_batch=8, async_inputs=False):
+    def __init__(self, cfg, mode="train", fused=True, graph_max_batch=8, async_inputs=False, graph_max_points=98304):
         """graph_max_batch > 0 (default 8): eval-mode calls with at most that many crops go through forward_graphed (one
         whole-forward hipGraph per batch size, captured on first use) -- the one-image-at-a-time eval loops of the
         reference (tools/test_LM.py:104-112: one object per call) are launch-bound otherwise: 0.6 instead of 1.2-1.4 ms
-        per one-crop call.  0 switches it off (every call eager).
+        per one-crop call.  Larger batches replay a graph too while the call is small in points, b * (N + M) <=
+        graph_max_points (measured, tools/graph_crossover.py: N = M = 1024 wins 4-6 % up to bs 40, N = 12288 / M = 2048 ties
+        at 4 crops and loses 1-2 % from 8 on) -- not with async_inputs, whose cross-call overlap a replay does not have.
+        graph_max_batch = 0 switches all of it off (every call launch by launch).
         async_inputs=True: the caller guarantees that `data`'s CUDA tensors are complete when forward() is called (or hands
         over data["ready_event"]) and are not overwritten until the results have been consumed.  The sparse half of a call
         (side streams) then does not wait for the dense half of the previous call still running on the current stream, so
         back-to-back calls pipeline: backbones of batch k+1 underneath the GEMMs / attention of batch k."""
         super().__init__()
         self.graph_max_batch = int(graph_max_batch)
+        self.graph_max_points = int(graph_max_points)
         self.async_inputs = bool(async_inputs)
         self.voxelization_mode = cfg.voxelization_mode
         self.unit_voxel_extent = np.array(cfg.unit_voxel_extent)
@@ -652,7 +656,9 @@ class Network(nn.Module):
         """eval(): the fused inference pipeline -- outputs carry no autograd graph, whether or not the caller wrapped the call
         in torch.no_grad() (tools/test_LM.py:110 does not).  train() (or fused=False): the module path, differentiable."""
         if self.fused and not self.training:
-            if 0 < int(data["batch_offsets"].size(0)) - 1 <= self.graph_max_batch:
+            b = int(data["batch_offsets"].size(0)) - 1
+            if self.graph_max_batch > 0 and b > 0 and (b <= self.graph_max_batch or (
+                    not self.async_inputs and b * (self.n_inp + self.n_tmp) <= self.graph_max_points)):
                 return self.forward_graphed(data)
             with torch.no_grad():
                 return self._forward_fused(data)

@@ -164,14 +164,17 @@ def test_reference_shape_and_stage2_chain_match_reference_golden(dcl, golden_dir
         assert len(net._graphs) == 1 and len(ref._graphs) == 2               # (iteration=2) and (iteration=1) loops
 
 
-def test_bs40_config_forward(dcl, oracle):
-    """BASELINE configs[2]'s per-GPU shape: 40 crops per call (config_YCBV_bs40.yaml: bs 40), N = M = 1024.  Four crops
+@pytest.mark.parametrize("path", ["launch by launch", "default"])
+def test_bs40_config_forward(dcl, oracle, path):
+    """BASELINE configs[2]'s per-GPU shape: 40 crops per call (config_YCBV_bs40.yaml: bs 40), N = M = 1024 -- launch by
+    launch and as a default-constructed Network runs it (81920 points per call: whole-forward hipGraph replay).  Four crops
     spread over the batch are checked against the CPU oracle graph run on exactly those crops (crops are independent);
     all 40 get the size-independent checks (valid rotations, confidences in (0,1), determinism, no NaN) and the metric
     table of the batch reduces to 40 frames"""
     from oracle import graph as G
     b, n = 40, 1024
-    net, sd, cfg = _net(dcl, n, n, 1)
+    net, sd, cfg = _net(dcl, n, n, 1, graph_max_batch=8 if path == "default" else 0)
+    assert (len(getattr(net, "_graphs", {})) == 0)
     data = dcl.synth.make_batch(b, n, n, first=100)
     with torch.no_grad():
         p1 = net(data)
@@ -183,6 +186,7 @@ def test_bs40_config_forward(dcl, oracle):
     assert bool(((p1["conf"] > 0) & (p1["conf"] < 1)).all()) and bool(torch.isfinite(p1["F_Xo_p"]).all())
     for k in ("rot_pred", "trans_pred", "conf"):
         assert torch.equal(p1[k], p2[k]), k
+    assert len(net.__dict__.get("_graphs", {})) == (1 if path == "default" else 0)      # the path that was meant ran
     for i in (0, 13, 27, 39):
         one = dcl.synth.make_batch(1, n, n, first=100 + i, voxelize_idx=lambda c, bs, mode: tuple(
             torch.from_numpy(a) for a in oracle.voxelize_idx(c.numpy(), bs, mode)))
@@ -296,7 +300,7 @@ def test_whole_forward_hipgraph_matches_eager(dcl):
 def test_forward_routes_small_batches_through_the_graph(dcl):
     b, n = 2, 256
     cfg = dcl.synth.default_cfg(n, n)
-    net = dcl.DCL_Net.Network(cfg, mode="test", graph_max_batch=4)
+    net = dcl.DCL_Net.Network(cfg, mode="test", graph_max_batch=4, graph_max_points=0)      # the batch rule alone
     net.load_state_dict(dcl.synth.synth_state_dict(net, 1))
     net = net.cuda().eval()
     plain, _, _ = _net(dcl, n, n, 1)
@@ -309,6 +313,17 @@ def test_forward_routes_small_batches_through_the_graph(dcl):
     assert len(net._graphs) == 1
     net(dcl.synth.make_batch(6, n, n))                                       # above the limit: eager path
     assert len(net._graphs) == 1
+    # the points rule: a default-constructed Network replays a graph for 12 crops x 512 points too (more crops than
+    # graph_max_batch = 8), an async_inputs one and a graph_max_batch = 0 one do not
+    for kw, graphs in (({}, 1), ({"async_inputs": True}, 0), ({"graph_max_batch": 0}, 0)):
+        other = dcl.DCL_Net.Network(cfg, mode="test", **kw)
+        other.load_state_dict(dcl.synth.synth_state_dict(other, 1))
+        other = other.cuda().eval()
+        got = other(dcl.synth.make_batch(12, n, n, first=3))
+        with torch.no_grad():
+            want = plain(dcl.synth.make_batch(12, n, n, first=3))
+        assert float((got["rot_pred"] - want["rot_pred"]).abs().max()) <= R_TOL
+        assert len(other.__dict__.get("_graphs", {})) == graphs, kw
 
 
 def test_pipelined_calls_give_the_same_results(dcl):
