@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""Launch-by-launch forward vs whole-forward hipGraph replay per batch size: where the default routing of
+Network.forward (graph_max_batch / graph_max_points) comes from.  usage: graph_crossover.py [N M [b1,b2,...]]"""
 import importlib, sys, time, torch, os
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 dcl = importlib.import_module("dcl-net_amd")
 n, m = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (12288, 2048)

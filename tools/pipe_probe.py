@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""Does a live whole-forward hipGraph (bs 32) slow down the launch-by-launch paths of other Network instances of the
+process?  (No: 4.09 / 4.11 / 4.10 ms for pipelined eager calls before / beside / after it.)  usage: pipe_probe.py [1]"""
 import importlib, sys, time, torch, os
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 dcl = importlib.import_module("dcl-net_amd")
 dev = torch.device("cuda")
