@@ -69,24 +69,30 @@ def test_train_mode_outputs_match_reference_golden(dcl, golden_dir, fixture, fus
 
 
 @pytest.mark.parametrize("b,n_inp,n_tmp,unit", [(3, 1024, 1024, 0.006), (1, 2048, 500, 0.005), (5, 512, 1024, 0.006),
-                                               (8, 1024, 1024, 0.005), (1, 12288, 2048, 0.006)])
+                                               (8, 1024, 1024, 0.005), (1, 12288, 2048, 0.006), (2, 333, 517, 0.006)])
 def test_forward_matches_oracle_graph(dcl, oracle, b, n_inp, n_tmp, unit):
     """fresh crops at the reference shape (N=M=1024), the plumbing shape S0 (N=2048, M=500, 5 mm), a ragged one, the
-    LineMOD config (5 mm voxels, config_LM.yaml) and one crop of the BASELINE stress shape (N=12288, M=2048)"""
+    LineMOD config (5 mm voxels, config_LM.yaml), one crop of the BASELINE stress shape (N=12288, M=2048) and point counts
+    that are multiples of nothing -- each both ways a caller can get it: launch by launch, and as a default-constructed
+    Network runs calls this small (whole-forward hipGraph replay)"""
     from oracle import graph as G
     cfg = dcl.synth.default_cfg(n_inp, n_tmp, unit)
-    net = dcl.DCL_Net.Network(cfg, mode="test")
-    sd = dcl.synth.synth_state_dict(net, 3)
-    net.load_state_dict(sd)
-    net = net.cuda().eval()
     data = dcl.synth.make_batch(b, n_inp, n_tmp, unit=unit, first=40)
     ref_data = {k: ({kk: vv.clone() for kk, vv in v.items()} if isinstance(v, dict) else v) for k, v in data.items()}
-    want = G.forward(sd, dict(cfg), ref_data, mode="test")
-    with torch.no_grad():
-        pred = net(data)
-    _check(pred, want["rot_pred"].numpy(), want["trans_pred"].numpy(), want["conf"].numpy())
-    got_F, want_F = pred["F_Xo_p"].cpu(), want["F_Xo_p"]
-    assert float((got_F - want_F).abs().max()) <= 1e-4 * max(1.0, float(want_F.abs().max()))
+    want = None
+    for kw, graphs in (({"graph_max_batch": 0}, 0), ({}, 1)):
+        net = dcl.DCL_Net.Network(cfg, mode="test", **kw)
+        sd = dcl.synth.synth_state_dict(net, 3)
+        net.load_state_dict(sd)
+        net = net.cuda().eval()
+        if want is None:
+            want = G.forward(sd, dict(cfg), ref_data, mode="test")
+        with torch.no_grad():
+            pred = net(data)
+        assert len(net.__dict__.get("_graphs", {})) == graphs
+        _check(pred, want["rot_pred"].numpy(), want["trans_pred"].numpy(), want["conf"].numpy())
+        got_F, want_F = pred["F_Xo_p"].cpu(), want["F_Xo_p"]
+        assert float((got_F - want_F).abs().max()) <= 1e-4 * max(1.0, float(want_F.abs().max()))
 
 
 def test_backbone_levels_and_indices_bit_exact(dcl, oracle):
