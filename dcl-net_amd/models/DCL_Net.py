@@ -364,6 +364,7 @@ class Network(nn.Module):
         return cache[key]
 
     _DIS_TAGS = (("p1", 256), ("m1", 64), ("p2", 256), ("m2", 64))
+    MAX_GRAPHS = 8            # captured whole-forward graphs kept per instance (one per batch size; least recently used goes)
 
     def _disengage_buffers(self, side, rows, dev):
         """outputs of a side's four disengage stacks.  Two of them are one half of a later concatenation -- cat[F_Xc_p1,
@@ -473,10 +474,13 @@ class Network(nn.Module):
         need_ma = {s: int(data[s]["v2p_maps"].shape[1]) - 1 for s in ("inp", "tmp")}
         key = (b, self.n_inp, self.n_tmp, S)
         cache = self.__dict__.setdefault("_graphs", {})
-        ent = cache.get(key)
+        ent = cache.pop(key, None)                                           # re-inserted below: dict order = recency
         if ent is None or any(need_ma[s] > ent["ma"][s] for s in ("inp", "tmp")):
+            ent = None                                                       # an outgrown capture is released first
+            while len(cache) >= self.MAX_GRAPHS:                             # capacity-sized buffers per batch size: bounded
+                cache.pop(next(iter(cache)))                                 # least recently used
             ent = self._capture(f, dev, b, S, {s: max(32, 2 * need_ma[s]) for s in ("inp", "tmp")})
-            cache[key] = ent
+        cache[key] = ent
         on_dev = all(data[s][k].is_cuda for s in ("inp", "tmp") for k in ("feats", "v2p_maps", "occupied_voxels")) and \
             all(data[s]["feats"].dtype == torch.float32 and data[s]["v2p_maps"].dtype == torch.int32 for s in ("inp", "tmp"))
         if on_dev:                                     # resident inputs: all eight staging copies / fills in one launch

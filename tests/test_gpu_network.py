@@ -390,6 +390,19 @@ def test_chunked_sparse_half_and_stream_switches_give_the_same_results(dcl, monk
         assert float((ref["F_Xo_p"] - outs[name]["F_Xo_p"]).abs().max()) <= 1e-4 * max(1.0, scale), name
 
 
+def test_graph_cache_is_bounded(dcl, monkeypatch):
+    """one captured graph per batch size, capacity-sized buffers each: the cache keeps the most recently used ones only"""
+    n = 128
+    net, _, _ = _net(dcl, n, n, 1, graph_max_batch=8)
+    monkeypatch.setattr(type(net), "MAX_GRAPHS", 3)
+    outs = {}
+    for b in (1, 2, 3, 1, 4, 5):                       # 1 is touched again before 4 and 5 arrive: 2 and 3 go
+        outs[b] = net(dcl.synth.make_batch(b, n, n, first=b))
+    assert [k[0] for k in net._graphs] == [1, 4, 5]
+    again = net(dcl.synth.make_batch(2, n, n, first=2))                       # evicted -> captured anew, same result
+    assert torch.equal(again["rot_pred"], outs[2]["rot_pred"]) and [k[0] for k in net._graphs] == [4, 5, 2]
+
+
 def test_graph_cache_follows_the_weights(dcl):
     """a captured forward must not outlive the weights it was captured with; the model stays deep-copyable"""
     import copy
