@@ -227,13 +227,19 @@ __global__ void k_out_mask_k3(const uint32_t *__restrict__ in_mask, int batch, i
 // 32-bit shifts (S is a power of two): with one workgroup per crop the 64-bit divisions of the general kernel would be the
 // whole run time.
 constexpr int kChainS = 64, kChainWords = kChainS * kChainS * kChainS / 32, kChainThreads = 1024;
+// (branch-free: an out-of-range neighbour row reads row (0, 0) and is masked out, so that the nine rows' LDS reads of an
+// output row are independent loads in flight together instead of nine guarded round trips)
 __device__ __forceinline__ unsigned long long local_zrow(const uint32_t *m, int x, int y, int S, int lg) {
-  if ((unsigned)x >= (unsigned)S || (unsigned)y >= (unsigned)S) return 0ull;
-  const int off = ((x << lg) + y) << lg;                                // bit offset of the z-row inside the crop
+  const bool ok = (unsigned)x < (unsigned)S && (unsigned)y < (unsigned)S;
+  const int off = (((ok ? x : 0) << lg) + (ok ? y : 0)) << lg;          // bit offset of the z-row inside the crop
   const int w = off >> 5;
-  if (S == 64) return (unsigned long long)m[w] | ((unsigned long long)m[w + 1] << 32);
-  const uint32_t v = m[w] >> (off & 31);
-  return (unsigned long long)(S == 32 ? v : v & ((1u << S) - 1u));
+  unsigned long long v;
+  if (S == 64) v = (unsigned long long)m[w] | ((unsigned long long)m[w + 1] << 32);
+  else {
+    const uint32_t r = m[w] >> (off & 31);
+    v = (unsigned long long)(S == 32 ? r : r & ((1u << S) - 1u));
+  }
+  return ok ? v : 0ull;
 }
 template <int STRIDE>
 __device__ __forceinline__ unsigned long long local_out_row(const uint32_t *src, int row, int S_in, int lg_in, int lg_out) {
@@ -259,14 +265,17 @@ __device__ __forceinline__ void chain_stage(const uint32_t *src, uint32_t *dst, 
       reinterpret_cast<uint2 *>(dst)[row] = v;
       reinterpret_cast<uint2 *>(gout)[row] = v;
     }
-  } else {                                                              // 32 / S_out rows per word
-    const int lg_rpw = 5 - lg_out, nw = rows >> lg_rpw;
-    for (int w = tid; w < nw; w += kChainThreads) {
-      uint32_t word = 0;
-      for (int rr = 0; rr < (1 << lg_rpw); ++rr)
-        word |= (uint32_t)local_out_row<STRIDE>(src, (w << lg_rpw) + rr, S_in, lg_in, lg_out) << (rr << lg_out);
-      dst[w] = word;
-      gout[w] = word;
+  } else {
+    // S_out <= 32: at most 1024 rows = one per thread; the 32 / S_out rows of a word sit in consecutive lanes and are
+    // OR-ed together by shuffles (every lane of the workgroup takes part; a thread per WORD would leave the coarse
+    // levels to a handful of threads walking 4-8 rows each -- they were the longest stages of the chain)
+    const int lg_rpw = 5 - lg_out, sub = tid & ((1 << lg_rpw) - 1);
+    uint32_t bits = 0;
+    if (tid < rows) bits = (uint32_t)local_out_row<STRIDE>(src, tid, S_in, lg_in, lg_out) << (sub << lg_out);
+    for (int d = 1; d < (1 << lg_rpw); d <<= 1) bits |= __shfl_xor(bits, d, 64);
+    if (tid < rows && sub == 0) {
+      dst[tid >> lg_rpw] = bits;
+      gout[tid >> lg_rpw] = bits;
     }
   }
 }
