@@ -205,7 +205,9 @@ class Network(nn.Module):
     def _mlp(self, x, layers):
         x = self._lin_relu(x, *layers[0])
         x = self._lin_relu(x, *layers[1])
-        return torch.addmm(layers[2][1], x, layers[2][0])
+        # last layer: bias, no activation -- through dcl_linear_fwd (bias epilogue); torch.addmm would first broadcast the
+        # bias into the output with an elementwise kernel and then accumulate onto it
+        return ops.linear(x, layers[2][0], layers[2][1], False)
 
     def _side_stream(self, dev, which=0):
         """per-side streams of the sparse half (DCL_SINGLE_STREAM=1: everything on the current stream)"""
