@@ -402,7 +402,7 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
     const float *__restrict__ feat, const DclNbrSrc src, int cap, const int32_t *__restrict__ n_out_dev,
     int n_out_host, const float *__restrict__ W, int cout, int kvol, int subm, const float *__restrict__ scale,
     const float *__restrict__ shift, int relu, float *__restrict__ out, float *__restrict__ partial, int stream_k,
-    int aligned_ns, int xcd_remap, int32_t *__restrict__ tile_counters) {
+    int aligned_ns, int xcd_remap, int32_t *__restrict__ tile_counters, const int32_t *__restrict__ bal) {
   constexpr int NW = WR * WCW, NTHR = 64 * NW;
   constexpr int BM = 32 * WR, BN = 32 * NT * WCW, KC = 32;
   constexpr int AT = BM * KC, BT = KC * BN, ST = AT + BT;      // floats per stage
@@ -442,7 +442,11 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
   const int C = (kvol * CIN + KC - 1) / KC;                    // chunks per tile
   // (32-bit unit arithmetic: tiles * C < 2^31 for every launch the host code makes -- 64-bit divisions would cost
   // dozens of VGPRs in a kernel that sits at the 128-register limit)
-  const int total = nblk * ncol * C;
+  // `bal` (experimental, stream-K only, CIN >= 32): units are USED chunks -- bal[0..nblk] is the prefix of the row tiles'
+  // used-step counts, bal[nblk+1 ..] their step masks -- so that row tiles with few used offsets (rows sorted by which
+  // neighbour planes exist) cost their workgroups proportionally less
+  constexpr int CPKH = CIN >= KC ? CIN / KC : 1;
+  const int total = bal ? bal[nblk] * ncol * CPKH : nblk * ncol * C;
   int U = C, u = wid * C, u_end = total;                       // stream_k == 0: tile wid, wid + G, ...
   if (aligned_ns) {
     const int tl = wid / aligned_ns, seg = wid - tl * aligned_ns;
@@ -458,13 +462,43 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
   const float *zero = reinterpret_cast<const float *>(&g_conv_zero_line);
 
   while (u < u_end) {
-    const int tile = u / C;
-    const int j_begin = u - tile * C;
-    const int nchunks = (stream_k || aligned_ns) ? (C < j_begin + (u_end - u) ? C : j_begin + (u_end - u)) : C;   // end chunk of the segment
-    const bool whole = j_begin == 0 && nchunks == C;
-    const int blk = tile / ncol, by = tile - blk * ncol;
+    int tile, j_begin, nchunks, tile_lo, tile_hi, blk, by;
+    bool whole;
+    if (bal) {
+      int lo = 0, hi = nblk;                                   // largest row tile whose first unit is <= u
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (bal[mid] * ncol * CPKH <= u) lo = mid; else hi = mid;
+      }
+      blk = lo;
+      const int cnt = (bal[blk + 1] - bal[blk]) * CPKH, base = bal[blk] * ncol * CPKH;
+      by = (u - base) / cnt;
+      tile_lo = base + by * cnt;
+      tile_hi = tile_lo + cnt;
+      const int v0 = u - tile_lo, v1 = cnt < v0 + (u_end - u) ? cnt : v0 + (u_end - u);
+      const unsigned smk = (unsigned)bal[nblk + 1 + blk];
+      auto nominal = [&](int v) -> int {                       // used chunk v of the tile -> its nominal chunk index
+        unsigned m = smk;
+        for (int q = v / CPKH; q > 0; --q) m &= m - 1u;
+        return __builtin_ctz(m) * CPKH + v % CPKH;
+      };
+      j_begin = nominal(v0);
+      nchunks = nominal(v1 - 1) + 1;
+      whole = v0 == 0 && v1 == cnt;
+      tile = blk * ncol + by;
+      u += v1 - v0;
+    } else {
+      tile = u / C;
+      j_begin = u - tile * C;
+      nchunks = (stream_k || aligned_ns) ? (C < j_begin + (u_end - u) ? C : j_begin + (u_end - u)) : C;   // end chunk of the segment
+      whole = j_begin == 0 && nchunks == C;
+      blk = tile / ncol;
+      by = tile - blk * ncol;
+      tile_lo = tile * C;
+      tile_hi = tile_lo + C;
+      u += (stream_k || aligned_ns) ? nchunks - j_begin : G * C;
+    }
     const int row0 = blk * BM, col0 = by * BN;
-    u += (stream_k || aligned_ns) ? nchunks - j_begin : G * C;
     CONV_STAMP(0);
 #ifdef DCL_CONV_STAMPS
     {
@@ -685,7 +719,7 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
       const size_t tile_f4 = (size_t)NW * NT * 4 * 64;
       // slot of a workgroup's segment of `tile`: 2*w if the tile holds w's first unit, else 2*w + 1
       // (w * U >= tile * C  <=>  the tile holds w's first unit, for the workgroups w that touch the tile at all)
-      auto slot_of = [&](int w) -> size_t { return (size_t)(2 * w + ((aligned_ns || w * U >= tile * C) ? 0 : 1)); };
+      auto slot_of = [&](int w) -> size_t { return (size_t)(2 * w + ((aligned_ns || w * U >= tile_lo) ? 0 : 1)); };
       f32x4 *mine = reinterpret_cast<f32x4 *>(partial) + slot_of(wid) * tile_f4 + (size_t)wave * NT * 4 * 64 + lane;
 #pragma unroll
       for (int t = 0; t < NT; ++t)
@@ -703,8 +737,8 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       CONV_STAMP(4);
-      const int w_first = aligned_ns ? tile * aligned_ns : (tile * C) / U;
-      const int w_last = aligned_ns ? w_first + aligned_ns - 1 : ((tile + 1) * C - 1) / U;
+      const int w_first = aligned_ns ? tile * aligned_ns : tile_lo / U;
+      const int w_last = aligned_ns ? w_first + aligned_ns - 1 : (tile_hi - 1) / U;
       if (tid == 0) {
         int32_t *ctr = tile_counters + tile;
         const int old = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -877,6 +911,7 @@ static int conv_split_cap(long long rows) { return rows <= kConvFewRows ? 27 : k
 constexpr int kConvFewRowsCap = 65536;
 static bool conv_few_rows(int rows, bool capacity_mode) { return capacity_mode ? rows <= kConvFewRowsCap : rows <= kConvFewRows; }
 static std::atomic<int> g_conv_xcd_remap{1};       // tuning hook: 0 = plain blockIdx order
+static std::atomic<const int32_t *> g_conv_bal{nullptr};   // experiment (tools/sort_experiment.py): used-chunk units of the next launches
 static std::atomic<int> g_conv_slots{512};         // tuning hook: workgroups a launch is dealt over (2 x 256 resident slots)
 static std::atomic<int> g_conv_split{0};           // tuning hook: 0 = automatic, n = force n-way split-K when scratch allows, -1 = never more than kConvMaxSplit, -2 = never split
 
@@ -963,9 +998,21 @@ static void launch_conv_dma(int rows, const float *feat, const DclNbrSrc &nbr, i
       }
     }
   }
+  const int32_t *bal = g_conv_bal.load();
+  if (bal && CIN >= 32 && scratch && !n_out_dev) {       // experiment: always stream-K over all slots, in-launch combine
+    stream_k = 1;
+    aligned_ns = 0;
+    G = kSlots;
+    partial = scratch + kConvCounterWords;
+    deferred = false;
+    counters = reinterpret_cast<int32_t *>(scratch);
+    if (!counters_ready) dcl_internal_zero_words(counters, kConvCounterWords, s);
+  } else {
+    bal = nullptr;
+  }
   hipLaunchKernelGGL((k_sparse_conv_dma<CIN, WR, WCW, NT>), dim3(G), dim3(64 * WR * WCW), lds, s, feat, nbr, cap, n_out_dev,
                      n_out_host, W, cout, kvol, subm, scale, shift, relu, out, partial, stream_k, aligned_ns, g_conv_xcd_remap,
-                     counters);
+                     counters, bal);
   if (deferred)
     hipLaunchKernelGGL((k_conv_frag_reduce<WR, WCW, NT>), dim3(tiles, WR * WCW * NT), dim3(256), 0, s, partial, cap, n_out_dev,
                        n_out_host, cout, nchunks, G, stream_k, scale, shift, relu, out);
@@ -1084,6 +1131,7 @@ static std::atomic<int> g_force_valu{0};   // test hook: 1 = plain VALU kernel f
 DCL_API void dcl_debug_force_valu_conv(int on) { g_force_valu = on; }
 
 DCL_API void dcl_debug_conv_split(int n) { g_conv_split = n; }
+DCL_API void dcl_debug_conv_balance(const int32_t *bal_dev) { g_conv_bal = bal_dev; }
 DCL_API void dcl_debug_conv_slots(int n) { g_conv_slots = (n >= 64 && n <= 512) ? n : 512; }
 #ifdef DCL_CONV_STAMPS
 extern "C" __attribute__((visibility("default"))) int dcl_debug_conv_stamps(unsigned long long *host, int n_wg, int clear) {

@@ -452,6 +452,9 @@ void dcl_debug_conv_split(int n);
 /* Tuning hook: number of workgroups the stream-K / split-K decompositions of a sparse-conv launch are dealt over (default
  * 512 = the 2 x 256 resident slots; 256 leaves one slot per CU to a concurrent launch of the other backbone).  64..512. */
 void dcl_debug_conv_slots(int n);
+/* Experiment hook (tools/sort_experiment.py): device array [prefix of used steps per 128-row tile (nblk + 1) | step masks
+ * (nblk)] -- while set, LDS-DMA conv launches with Cin >= 32 deal their work in USED chunks; NULL switches it off. */
+void dcl_debug_conv_balance(const int32_t *bal_dev);
 /* Tuning hook: 1 (default) = the LDS-DMA conv kernel renumbers its workgroups XCD-aware (column tiles of a row tile and
  * neighbouring row tiles share an L2), 0 = plain blockIdx order. */
 void dcl_debug_conv_xcd_remap(int on);

@@ -222,6 +222,50 @@ def test_sparse_conv_decompositions_agree_across_sizes(dcl, cin, cout):
             assert torch.equal(got, dcl.ops.sparse_conv(feat, nbr, n_out, W, subm))          # reproducible
 
 
+@pytest.mark.parametrize("cin,cout", [(64, 64), (128, 128), (32, 64)])
+def test_sparse_conv_used_chunk_dealing_prototype(dcl, cin, cout):
+    """experiment hook dcl_debug_conv_balance: rows of a dilating conv sorted by which neighbour planes exist, stream-K work
+    dealt in USED chunks (per-tile step masks + prefix from the host) -- same result as the VALU kernel on the same table,
+    reproducible, and the hook really is off afterwards"""
+    import ctypes
+    rng = np.random.default_rng(cin + cout)
+    lib = dcl._native.lib()
+    W = cuda((rng.normal(size=(27, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32))
+    idx = rand_voxels(rng, 6, 32, 4000)
+    aset = dcl.ops.grid_from_indices(cuda(idx), 6, 32)
+    out, nbr = dcl.spconv.ops.build_rulebook(aset, 3, 1, 1, False)
+    n = out.n
+    feat = cuda(rng.normal(size=(idx.shape[0], cin)).astype(np.float32))
+    valid = nbr[:, :n] >= 0
+    v3 = valid.view(3, 3, 3, n)
+    key = torch.zeros(n, dtype=torch.int64, device="cuda")
+    for ax in range(3):
+        for q in range(3):
+            key = key * 2 + v3.select(ax, q).reshape(9, n).any(0).long()
+    nbr_s = nbr[:, :n][:, torch.argsort(key, stable=True)].contiguous()
+    nblk = (n + 127) // 128
+    vs = torch.cat([nbr_s >= 0, torch.zeros(27, nblk * 128 - n, dtype=torch.bool, device="cuda")], 1)
+    used = vs.view(27, nblk, 128).any(2)
+    smask = (used.long() << torch.arange(27, device="cuda").view(27, 1)).sum(0)
+    bal = torch.cat([torch.zeros(1, dtype=torch.long, device="cuda"), used.sum(0).cumsum(0), smask]).int().contiguous()
+    assert int(used.sum(0).min()) > 0 and float(used.sum(0).float().mean()) < 26.0          # every tile has work, many skip offsets
+    lib.dcl_debug_force_valu_conv(1)
+    try:
+        ref = dcl.ops.sparse_conv(feat, nbr_s, n, W, False)
+    finally:
+        lib.dcl_debug_force_valu_conv(0)
+    plain = dcl.ops.sparse_conv(feat, nbr_s, n, W, False)
+    lib.dcl_debug_conv_balance(ctypes.c_void_p(bal.data_ptr()))
+    try:
+        got = dcl.ops.sparse_conv(feat, nbr_s, n, W, False)
+        again = dcl.ops.sparse_conv(feat, nbr_s, n, W, False)
+    finally:
+        lib.dcl_debug_conv_balance(None)
+    tol = 2e-5 * max(1.0, float(ref.abs().max()))
+    assert float((got - ref).abs().max()) <= tol and torch.equal(got, again)
+    assert torch.equal(dcl.ops.sparse_conv(feat, nbr_s, n, W, False), plain)
+
+
 @pytest.mark.parametrize("c", [32, 7])
 def test_sparse_avgpool_bit_exact(dcl, oracle, c):
     rng = np.random.default_rng(c)
