@@ -658,13 +658,19 @@ class Network(nn.Module):
         data["labels"]["points_inp"] = points_inp
         return prediction
 
+    def replays_graph(self, b):
+        """routing rule of eval-mode calls (see __init__): True = a call of b crops replays its whole-forward hipGraph"""
+        if self.graph_max_batch <= 0 or b <= 0:
+            return False
+        if b <= self.graph_max_batch:
+            return True
+        return (not self.async_inputs) and b * (self.n_inp + self.n_tmp) <= self.graph_max_points
+
     def forward(self, data):
         """eval(): the fused inference pipeline -- outputs carry no autograd graph, whether or not the caller wrapped the call
         in torch.no_grad() (tools/test_LM.py:110 does not).  train() (or fused=False): the module path, differentiable."""
         if self.fused and not self.training:
-            b = int(data["batch_offsets"].size(0)) - 1
-            if self.graph_max_batch > 0 and b > 0 and (b <= self.graph_max_batch or (
-                    not self.async_inputs and b * (self.n_inp + self.n_tmp) <= self.graph_max_points)):
+            if self.replays_graph(int(data["batch_offsets"].size(0)) - 1):
                 return self.forward_graphed(data)
             with torch.no_grad():
                 return self._forward_fused(data)

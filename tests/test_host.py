@@ -251,3 +251,16 @@ def test_linemod_table_allreduce_two_processes_gloo(tmp_path, golden_dir):
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all("ok" in o for o in outs)
+
+
+def test_graph_routing_rule(dcl):
+    """which eval-mode calls replay a whole-forward hipGraph (host logic only): up to graph_max_batch crops always, larger
+    batches while the call is small in points and the instance is not a pipelining one; graph_max_batch = 0 = never"""
+    mk = lambda n, m, **kw: dcl.DCL_Net.Network(dcl.synth.default_cfg(n, m), mode="test", **kw)    # noqa: E731
+    ref = mk(1024, 1024)
+    assert [ref.replays_graph(b) for b in (0, 1, 8, 32, 40, 48, 49)] == [False, True, True, True, True, True, False]
+    stress = mk(12288, 2048)
+    assert [stress.replays_graph(b) for b in (1, 6, 8, 9, 32)] == [True, True, True, False, False]
+    assert [mk(1024, 1024, async_inputs=True).replays_graph(b) for b in (1, 8, 9, 32)] == [True, True, False, False]
+    assert not any(mk(1024, 1024, graph_max_batch=0).replays_graph(b) for b in (1, 8, 32))
+    assert [mk(1024, 1024, graph_max_batch=4, graph_max_points=0).replays_graph(b) for b in (4, 5)] == [True, False]
