@@ -44,6 +44,8 @@ def measure_traffic_bytes(kernel_substr, shape, batch, timeout_s=300):
     exe = shutil.which("rocprofv3")
     if exe is None:
         return None, "unmeasured: rocprofv3 not on PATH"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "unmeasured: this run is itself under a rocprof tool (no nested counter passes)"
     vals = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         tmp = tempfile.mkdtemp(prefix="dcl_pmc_", dir="/tmp")
