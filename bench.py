@@ -408,6 +408,14 @@ def main():
                     help="(internal) one warm-up + one forward of the workload and exit: the body of the PMC passes")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.pmc_child:
+        # called without a launcher: start one rank per GPU as a CHILD (nothing has touched the GPU yet; never exec) and
+        # hand its output and exit code on
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29517"),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
