@@ -360,13 +360,13 @@ def conv_pairs_flop(dcl, net, data, dev):
 def sparse_conv_roofline(dcl, net, data, dev, steps=3):
     """roofline entry of the sparse-conv kernel family for one workload: algorithmic flop (measured pairs, above) divided by
     the summed device time of all 16 conv calls of a forward, measured with HIP events on the launch streams inside the
-    library (dcl_profile_conv_begin/_end) during `steps` ordinary forwards run on ONE stream (DCL_SINGLE_STREAM=1, so that
+    library (dcl_profile_conv_begin/_end) during `steps` ordinary forwards run on ONE stream (net.single_stream, so that
     the two backbones' kernels do not overlap each other inside the bracketed intervals)."""
     import ctypes
     flop, per_layer = conv_pairs_flop(dcl, net, data, dev)
     lib = dcl._native.lib()
-    old = os.environ.get("DCL_SINGLE_STREAM")
-    os.environ["DCL_SINGLE_STREAM"] = "1"
+    old = net.single_stream
+    net.single_stream = True
     try:
         with torch.no_grad():
             net(data)
@@ -378,10 +378,7 @@ def sparse_conv_roofline(dcl, net, data, dev, steps=3):
             ms, calls = ctypes.c_double(0), ctypes.c_int32(0)
             lib.dcl_profile_conv_end(ctypes.byref(ms), ctypes.byref(calls))
     finally:
-        if old is None:
-            os.environ.pop("DCL_SINGLE_STREAM", None)
-        else:
-            os.environ["DCL_SINGLE_STREAM"] = old
+        net.single_stream = old
     ms_fwd = ms.value / steps
     ach = flop / (ms_fwd * 1e-3) / 1e12 if ms_fwd > 0 else float("nan")
     issued = sum(2.0 * 27 * n_out * ci * co for (_, ci, co, _, n_out, _) in per_layer)

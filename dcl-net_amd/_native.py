@@ -10,47 +10,59 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.environ.get("DCL_HIP_LIB") or os.path.join(_HERE, "libdclnet_hip.so")   # DCL_HIP_LIB: diagnostic builds (tools/)
+SO_PATH = os.path.join(_HERE, "libdclnet_hip.so")
+DIAG_SO_PATH = os.path.join(os.path.dirname(_HERE), "tests", "_diag", "libdclnet_hip_diag.so")
 _LIB = None
 
 vp = C.c_void_p
 
 
-def build(verbose=False):
-    """hipcc --offload-arch=gfx950 build of csrc/ into libdclnet_hip.so (in-tree)."""
+def build(verbose=False, diag=False):
+    """hipcc --offload-arch=gfx950 build of csrc/ into libdclnet_hip.so (in-tree); diag=True also builds the diagnostic
+    library (tests/_diag/libdclnet_hip_diag.so: the same sources with -DDCL_DIAG, see csrc/Makefile)."""
     out = None if verbose else subprocess.DEVNULL
-    subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-j8"], stdout=out)
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-j8"] + (["all", "diag"] if diag else []), stdout=out)
     return SO_PATH
 
 
+def _open(path):
+    L = C.CDLL(path)
+    L.dcl_last_error.restype = C.c_char_p
+    return L
+
+
 def lib():
+    """the product library.  It has no tuning hooks and reads no environment; there is no CPU fallback."""
     global _LIB
     if _LIB is None:
         if not os.path.exists(SO_PATH):
             raise RuntimeError(
                 "libdclnet_hip.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C dcl-net_amd/csrc`.  There is no CPU fallback." % SO_PATH)
-        L = C.CDLL(SO_PATH)
-        L.dcl_last_error.restype = C.c_char_p
-        # A/B switches for profiling runs (kernel-variant hooks of include/dclnet_hip.h)
-        if os.environ.get("DCL_CONV_VARIANT"):
-            L.dcl_debug_force_valu_conv(int(os.environ["DCL_CONV_VARIANT"]))
-        if os.environ.get("DCL_CONV_XCD"):
-            L.dcl_debug_conv_xcd_remap(int(os.environ["DCL_CONV_XCD"]))
-        if os.environ.get("DCL_CONV_SPLIT"):
-            L.dcl_debug_conv_split(int(os.environ["DCL_CONV_SPLIT"]))
-        if os.environ.get("DCL_CONV_SLOTS"):
-            L.dcl_debug_conv_slots(int(os.environ["DCL_CONV_SLOTS"]))
-        if os.environ.get("DCL_ATTN_SPLIT"):
-            L.dcl_debug_attention_split(int(os.environ["DCL_ATTN_SPLIT"]))
-        if os.environ.get("DCL_NN_GRID"):
-            L.dcl_debug_three_nn_grid(int(os.environ["DCL_NN_GRID"]))
-        if os.environ.get("DCL_ATTN_XCD"):
-            L.dcl_debug_attention_xcd_remap(int(os.environ["DCL_ATTN_XCD"]))
-        if os.environ.get("DCL_ATTN_VARIANT"):
-            L.dcl_debug_attention_variant(int(os.environ["DCL_ATTN_VARIANT"]))
-        _LIB = L
+        _LIB = _open(SO_PATH)
     return _LIB
+
+
+class diagnostic_library(object):
+    """`with _native.diagnostic_library() as L:` -- tests/ and tools/ only.  Inside the block every op of this package
+    calls into the DIAGNOSTIC build (tests/_diag/libdclnet_hip_diag.so or `path`: same sources, -DDCL_DIAG) whose
+    dcl_debug_* hooks select kernel variants; the product library is restored on exit."""
+
+    def __init__(self, path=None):
+        self.path = path or DIAG_SO_PATH
+
+    def __enter__(self):
+        global _LIB
+        if not os.path.exists(self.path):
+            raise RuntimeError("diagnostic library missing (%s): make -C dcl-net_amd/csrc diag" % self.path)
+        self.prev = _LIB
+        _LIB = _open(self.path)
+        return _LIB
+
+    def __exit__(self, *exc):
+        global _LIB
+        _LIB = self.prev
+        return False
 
 
 def check(rc, what=""):

@@ -42,12 +42,18 @@ int dcl_three_nn_sp_strided(int n, int m, const float *unknown, const float *kno
                             const int32_t *known_seg, int nbatch, int seg_stride, dclStream_t stream);
 
 #include <stdlib.h>
-#include <atomic>
 namespace {
-std::atomic<int> g_geo_chain{1};
+DCL_HOOK_INT(g_geo_chain, 1);   // (diagnostic library only) 0 = the 8 masks of a pass as 8 chained launches
 
-// debugging aid: DCL_DBG_FEATURE_STEPS=N enqueues only the first N kernels of dcl_backbone_features*
+#ifdef DCL_DIAG
+// debugging aids of the diagnostic library: DCL_DBG_FEATURE_STEPS=N enqueues only the first N kernels of
+// dcl_backbone_features*; DCL_EXPLICIT_NBR=1 feeds the kernels from explicit gather tables (A/B of the implicit rulebooks)
 inline int dbg_steps() { const char *e = getenv("DCL_DBG_FEATURE_STEPS"); return e ? atoi(e) : 1 << 30; }
+inline bool dbg_explicit_nbr() { const char *e = getenv("DCL_EXPLICIT_NBR"); return e != nullptr && atoi(e) != 0; }
+#else
+constexpr int dbg_steps() { return 1 << 30; }                   // the product library reads no environment
+constexpr bool dbg_explicit_nbr() { return false; }
+#endif
 
 constexpr int kLevels = 4;
 constexpr size_t kAlign = 256;
@@ -185,7 +191,7 @@ static int backbone_geometry(const int32_t *occ, const int32_t *V0_dev, int V0, 
   size_t so = (size_t)(words(batch, S) + 1023) / 1024 + 2;
   const uint32_t *in_mask = at<uint32_t>(ws, L.mask0);
   int s = S;
-  const bool fused_chain = dcl_internal_mask_chain_ok(S) && g_geo_chain.load(std::memory_order_relaxed) != 0;
+  const bool fused_chain = dcl_internal_mask_chain_ok(S) && g_geo_chain != 0;
   for (int m = 0; m < kLevels; ++m) {
     const SetLayout *sets[2] = {&L.conv[m], &L.pool[m]};
     for (int q = 0; q < 2; ++q) {
@@ -213,11 +219,13 @@ static int backbone_geometry(const int32_t *occ, const int32_t *V0_dev, int V0, 
   return dcl_internal_scan_enumerate_sets(g, 2 * kLevels, stream);
 }
 
+#ifdef DCL_DIAG
 // Test hook: 1 (default) = one-launch mask chain on 64^3 grids, 0 = the 8 chained launches (A/B of the two paths).
 DCL_API int dcl_debug_geometry_chain(int mode) {
   g_geo_chain.store(mode);
   return 0;
 }
+#endif
 
 DCL_API int dcl_backbone_ws2_bytes(const int32_t *counts_host, const int32_t *channels_host, int64_t *bytes_host) {
   FeatLayout F;
@@ -287,7 +295,7 @@ static int backbone_features(const int32_t *occ, int V0, int batch, int S, void 
   // split-K tile tickets: zeroed once per pass, every split launch leaves them zero again
   if (F.scratch_floats) dcl_internal_zero_words(at<float>(ws2, F.scratch), kConvCounterWords, (hipStream_t)stream);
   int steps_left = dbg_steps();
-  const bool explicit_nbr = getenv("DCL_EXPLICIT_NBR") != nullptr && atoi(getenv("DCL_EXPLICIT_NBR")) != 0;
+  const bool explicit_nbr = dbg_explicit_nbr();
 #define DBG_STEP() do { if (--steps_left < 0) return 0; } while (0)
   for (int m = 0; m < kLevels; ++m) {
     const SetLayout &c = L.conv[m], &p = L.pool[m];

@@ -7,6 +7,17 @@
 
 #define DCL_API extern "C" __attribute__((visibility("default")))
 
+// A/B and tuning switches.  The PRODUCT library (libdclnet_hip.so) is built without DCL_DIAG: every switch is a compile-time
+// constant, no dcl_debug_* symbol is exported, superseded kernel variants are not compiled and nothing reads the environment.
+// The DIAGNOSTIC library (make diag -> tests/_diag/libdclnet_hip_diag.so, -DDCL_DIAG) turns them into process-wide atomics
+// set through the dcl_debug_* entry points of include/dclnet_hip.h; tests and tools/ select kernel variants through it.
+#ifdef DCL_DIAG
+#include <atomic>
+#define DCL_HOOK_INT(name, dflt) static std::atomic<int> name{dflt}
+#else
+#define DCL_HOOK_INT(name, dflt) static constexpr int name = dflt
+#endif
+
 void dcl_set_error(const char *fmt, ...);
 
 #define DCL_CHECK_ARG(cond)                                                          \

@@ -26,6 +26,7 @@ constexpr float kThr = 20.0f;      // lazy-rescale threshold (e^20 ~ 5e8: far in
 
 __device__ __forceinline__ int rowmap(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
 
+#ifdef DCL_DIAG   // general-shape predecessors of k_cross_attn_dma: diagnostic library only (A/B references)
 // All operands POINT-major: X[(b*n + p)*ld + c]  (the layout the 3-NN interpolation produces and the
 // 2-D GEMMs of the MLP stacks consume; the reference's (b,C,n) tensors are transposed views of it).
 //
@@ -311,6 +312,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES >= 8 ? 2 : 1) void k_cross_attn_s
       }
   }
 }
+#endif  // DCL_DIAG
 
 // Variant for LARGE problems with DCL-Net's own channel split (V1 = 256 ch, V2 = 64 ch): the shared-tile kernel above
 // plus an asynchronous tile pipeline.  The V tile (40 of the 48 KiB per 32 keys) is double-buffered in LDS and filled
@@ -715,12 +717,15 @@ __global__ void k_ortho9d(int b, const float *__restrict__ o9, float *__restrict
 
 }  // namespace
 
-static std::atomic<int> g_attn_variant{0};   // test hook: 1 = shared-tile 8-wave kernel, 2 = 4-wave register-staged, 3 / 4 = LDS-DMA pipeline with 8 / 4 waves
-static std::atomic<int> g_attn_split{0};            // tuning hook: 0 = automatic key split of small attention launches, n = force n
-static std::atomic<int> g_attn_xcd_remap{1};        // tuning hook: 0 = plain blockIdx order (for traffic comparisons)
+// (switches: atomics in the diagnostic library, constants in the product -- common.h)
+DCL_HOOK_INT(g_attn_variant, 0);     // 1 = shared-tile 8-wave kernel, 2 = 4-wave register-staged, 3 / 4 = LDS-DMA pipeline with 8 / 4 waves
+DCL_HOOK_INT(g_attn_split, 0);       // 0 = automatic key split of small attention launches, n = force n
+DCL_HOOK_INT(g_attn_xcd_remap, 1);   // 0 = plain blockIdx order (for traffic comparisons)
+#ifdef DCL_DIAG
 DCL_API void dcl_debug_attention_split(int n) { g_attn_split = n; }
 DCL_API void dcl_debug_attention_xcd_remap(int on) { g_attn_xcd_remap = on; }
 DCL_API void dcl_debug_attention_variant(int v) { g_attn_variant = v; }
+#endif
 
 DCL_API int dcl_cross_attention(int b, int nq, int nk, const float *Q, int ldq, const float *K, int ldk,
                                 const float *V1, int dv1, int ldv1, float *O1, int ldo1, const float *V2, int dv2,
@@ -793,7 +798,7 @@ DCL_API int dcl_cross_attention_ws(int b, int nq, int nk, const float *Q, int ld
       }
       (void)hipFuncSetAttribute((const void *)k_cross_attn_dma<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(k_cross_attn_dma<8>, dim3(dcl_div_up(nq, 256), b, nsplit), dim3(512), lds, s, nq, nk, Q, ldq, K, ldk,
-                         V1, ldv1, O1, ldo1, V2, ldv2, O2, ldo2, scratch, g_attn_xcd_remap);
+                         V1, ldv1, O1, ldo1, V2, ldv2, O2, ldo2, scratch, (int)g_attn_xcd_remap);
       if (nsplit > 1)
         hipLaunchKernelGGL(k_cross_attn_combine, dim3(dcl_grid_1d((long long)b * nq * 80, 256)), dim3(256), 0, s, b * nq,
                            nsplit, scratch, O1, ldo1, O2, ldo2);
@@ -820,7 +825,7 @@ DCL_API int dcl_cross_attention_ws(int b, int nq, int nk, const float *Q, int ld
         if (nsplit < 1) nsplit = 1;
       }
       if (scratch && blocks4 < 192) {
-        nsplit = g_attn_split > 0 ? g_attn_split.load() : (int)dcl_div_up(256, blocks4);
+        nsplit = g_attn_split > 0 ? (int)g_attn_split : (int)dcl_div_up(256, blocks4);
         const int ntiles = dcl_div_up(nk, 32);
         if (nsplit > 8) nsplit = 8;
         if (nsplit > ntiles / 2) nsplit = ntiles / 2;
@@ -829,12 +834,14 @@ DCL_API int dcl_cross_attention_ws(int b, int nq, int nk, const float *Q, int ld
       }
       (void)hipFuncSetAttribute((const void *)k_cross_attn_dma<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(k_cross_attn_dma<4>, dim3(dcl_div_up(nq, 128), b, nsplit), dim3(256), lds, s, nq, nk, Q, ldq, K,
-                         ldk, V1, ldv1, O1, ldo1, V2, ldv2, O2, ldo2, scratch, g_attn_xcd_remap);
+                         ldk, V1, ldv1, O1, ldo1, V2, ldv2, O2, ldo2, scratch, (int)g_attn_xcd_remap);
       if (nsplit > 1)
         hipLaunchKernelGGL(k_cross_attn_combine, dim3(dcl_grid_1d((long long)b * nq * 80, 256)), dim3(256), 0, s, b * nq,
                            nsplit, scratch, O1, ldo1, O2, ldo2);
     }
-  } else if ((blocks8 >= 256 && g_attn_variant != 2) || g_attn_variant == 1) {
+  }
+#ifdef DCL_DIAG
+  else if ((blocks8 >= 256 && g_attn_variant != 2) || g_attn_variant == 1) {
     const size_t lds = (size_t)(32 * kKPitch + 32 * nvt * 32 + 8 * 32 * kKPitch) * sizeof(float);
 #define ATT8(N)                                                                                                \
   do {                                                                                                         \
@@ -869,6 +876,14 @@ DCL_API int dcl_cross_attention_ws(int b, int nq, int nk, const float *Q, int ld
     }
 #undef ATT
   }
+#else
+  else {
+    // the product library carries the one kernel the DCL-Net path uses (V = [256 | 64] channels, models/DCL_Net.py:206-215);
+    // its general-shape predecessors live in the diagnostic library only
+    dcl_set_error("dcl_cross_attention: only dv1 = 256, dv2 = 64 is built into the product library (got %d, %d)", dv1, dv2);
+    return DCL_EINVAL;
+  }
+#endif
   DCL_LAUNCH_CHECK();
   return 0;
 }

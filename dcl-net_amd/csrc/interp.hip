@@ -492,10 +492,12 @@ int dcl_three_nn_sp_strided(int n, int m, const float *unknown, const float *kno
 }
 
 // internal: the known set is given as voxel rows (b,x,y,z) i32; their centres idx*ve + off + ve/2 are formed in the kernel
-static std::atomic<int> g_nn_grid{1};   // tuning/test hook: 0 = brute-force scan per crop for every level, 2 = grid kernel with the scan forced, 3 / 4 / 5 = one / four / eight lanes per query
+DCL_HOOK_INT(g_nn_grid, 1);   // (atomic in the diagnostic library, constant in the product) 0 = brute-force scan per crop for every level, 2 = grid kernel with the scan forced, 3 / 4 / 5 = one / four / eight lanes per query
 constexpr int kNnCoopMaxQueries = 1 << 17;   // read-outs of up to this many points search with four lanes per query,
 constexpr int kNnCoop8MaxQueries = 40960;    // up to this many (bs 40 x 1024 points) with eight
+#ifdef DCL_DIAG
 DCL_API void dcl_debug_three_nn_grid(int mode) { g_nn_grid = mode; }
+#endif
 
 // known_mask / S (optional): the level's occupancy bits and grid size; with them, levels of S = 16 or 32 go through the
 // grid-pruned kernel (same results)
@@ -543,7 +545,7 @@ int dcl_internal_readout_neighbours(int n, const float *points_b4, const DclRead
   // several lanes per query while the launch would otherwise be latency-bound (see three_nn_grid_point): measured on the
   // bs-32 sets, us for 1 / 4 / 8 lanes: 32768 points 137 / 44 / 36, 65536 points 141 / 53 / 59, 393216 points 172 / 186 / --.
   // hook: 3 / 4 / 5 force the one- / four- / eight-lane variant
-  const int mode = g_nn_grid.load();
+  const int mode = g_nn_grid;
   const int lpq = mode == 3 ? 1 : mode == 4 ? 4 : mode == 5 ? 8 : n <= kNnCoop8MaxQueries ? 8 : n <= kNnCoopMaxQueries ? 4 : 1;
   if (lpq == 8)
     hipLaunchKernelGGL(k_three_nn_grid_levels<8>, dim3(dcl_div_up(n, 32), 4), dim3(256), 0, (hipStream_t)stream, n,

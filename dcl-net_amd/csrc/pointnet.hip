@@ -389,10 +389,14 @@ DCL_API int dcl_ball_query(int b, int n, int m, float radius, int nsample, const
   return 0;
 }
 
+#ifdef DCL_DIAG
 static std::atomic<int> g_gp_cfg[4] = {{0}, {0}, {0}, {0}};   // tuning hook: rows per workgroup, x-blocks, threads, stores (2 = plain); 0 = default
 DCL_API void dcl_debug_group_points_cfg(int cc, int xb, int threads, int nontemporal) {
   g_gp_cfg[0] = cc; g_gp_cfg[1] = xb; g_gp_cfg[2] = threads; g_gp_cfg[3] = nontemporal;
 }
+#else
+static constexpr int g_gp_cfg[4] = {0, 0, 0, 0};               // product: the built-in choices
+#endif
 
 DCL_API int dcl_group_points(int b, int c, int n, int npoints, int nsample, const float *points, const int32_t *idx,
                              float *out, dclStream_t stream) {
@@ -411,16 +415,16 @@ DCL_API int dcl_group_points_into(int b, int c, int n, int npoints, int nsample,
     // fills its rows while the other streams (measured best at the north-star shape: 1 row of 12288 floats, 5.97 TB/s)
     const int cc = (int)((48 * 1024) / ((size_t)n * 4));
     int ccu = cc >= 4 ? 4 : cc >= 3 ? 3 : cc >= 2 ? 2 : 1;
-    if (g_gp_cfg[0] > 0 && g_gp_cfg[0] <= 4 && (size_t)g_gp_cfg[0] * n * 4 <= 144 * 1024) ccu = g_gp_cfg[0];
+    if (g_gp_cfg[0] > 0 && g_gp_cfg[0] <= 4 && (size_t)g_gp_cfg[0] * n * 4 <= 144 * 1024) ccu = (int)g_gp_cfg[0];
     const size_t lds = (size_t)ccu * n * 4;
-    const int threads = g_gp_cfg[2] > 0 ? g_gp_cfg[2].load() : 1024;
+    const int threads = g_gp_cfg[2] > 0 ? (int)g_gp_cfg[2] : 1024;
     const int ychunks = dcl_div_up(c, ccu);
     // enough x-blocks to give every CU work, few enough that the row fill stays a small fraction
     int xb = dcl_div_up(256 * 2, ychunks * b);
     if (xb < 1) xb = 1;
     const int max_xb = dcl_div_up(nps / 4, 1024 * 8);
     if (xb > max_xb) xb = max_xb > 0 ? max_xb : 1;
-    if (g_gp_cfg[1] > 0) xb = g_gp_cfg[1];
+    if (g_gp_cfg[1] > 0) xb = (int)g_gp_cfg[1];
     const bool nt = g_gp_cfg[3] != 2;                  // nontemporal (streaming) stores unless the hook says 2 = plain
 #define GPL(CCU, NTB)                                                                                               \
   do {                                                                                                         \

@@ -182,6 +182,7 @@ __global__ __launch_bounds__(256) void k_sparse_conv_mfma(
   }
 }
 
+#ifdef DCL_DIAG   // superseded by k_sparse_conv_dma for every shape it takes: kept in the diagnostic library as an A/B reference
 // ---- implicit-GEMM MFMA kernel: gathered A tile AND weight tile through LDS ------------------------------------
 // The 27 offsets x Cin input channels form one long contraction axis of "virtual channels"; it is walked in chunks of
 // KC virtual channels (= G = KC/Cin whole offsets, visited in the reference's order).  Per chunk the workgroup stages
@@ -354,6 +355,8 @@ __global__ __launch_bounds__(256, 2) void k_sparse_conv_tile(
     __syncthreads();
   }
 }
+
+#endif  // DCL_DIAG
 
 // ---- implicit-GEMM MFMA kernel fed by LDS-DMA (Cout % 64 == 0): same 64x64 output tile and virtual-channel walk as
 // k_sparse_conv_tile, but both operand tiles of a 64-channel chunk go global -> LDS with global_load_lds_dwordx4 (no
@@ -831,6 +834,7 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
   }
 }
 
+#ifdef DCL_DIAG
 // out = act(scale * (P_0 + P_1 + ... ) + shift), partial sums added in split order; thread = 4 channels of a row
 __global__ void k_conv_split_reduce(const float *__restrict__ partial, int nsplit, int cap, const int32_t *__restrict__ n_out_dev,
                                     int n_out_host, int cout, const float *__restrict__ scale,
@@ -854,6 +858,8 @@ __global__ void k_conv_split_reduce(const float *__restrict__ partial, int nspli
     reinterpret_cast<float4 *>(out)[t] = a;
   }
 }
+
+#endif  // DCL_DIAG
 
 // Deferred combine of a stream-K launch (few-row launches: a tile has up to 27 segments, which the last arriver would have
 // to add in as many dependent rounds of loads -- here every thread owns one 16-B piece of a tile and has all of its
@@ -910,10 +916,14 @@ static int conv_split_cap(long long rows) { return rows <= kConvFewRows ? 27 : k
 // hipGraph, a handful of crops), a row capacity of at most two crops' worth of cells, whatever the live count turns out to be
 constexpr int kConvFewRowsCap = 65536;
 static bool conv_few_rows(int rows, bool capacity_mode) { return capacity_mode ? rows <= kConvFewRowsCap : rows <= kConvFewRows; }
-static std::atomic<int> g_conv_xcd_remap{1};       // tuning hook: 0 = plain blockIdx order
+// A/B and tuning switches: process-wide atomics set through dcl_debug_* in the DIAGNOSTIC library (-DDCL_DIAG, tests/_diag/),
+// compile-time constants in the product library -- the product has no hooks, no superseded kernels and no getenv
+DCL_HOOK_INT(g_conv_xcd_remap, 1);   // 0 = plain blockIdx order
+DCL_HOOK_INT(g_conv_slots, 512);     // workgroups a launch is dealt over (2 x 256 resident slots)
+DCL_HOOK_INT(g_conv_split, 0);       // 0 = automatic, n = force n-way split-K when scratch allows, -1 = never more than kConvMaxSplit, -2 = never split, -3 = few-row combine inside the launch
+#ifdef DCL_DIAG
 static std::atomic<const int32_t *> g_conv_bal{nullptr};   // experiment (tools/sort_experiment.py): used-chunk units of the next launches
-static std::atomic<int> g_conv_slots{512};         // tuning hook: workgroups a launch is dealt over (2 x 256 resident slots)
-static std::atomic<int> g_conv_split{0};           // tuning hook: 0 = automatic, n = force n-way split-K when scratch allows, -1 = never more than kConvMaxSplit, -2 = never split
+#endif
 
 template <int CIN, int WR, int WCW, int NT>
 static void launch_conv_dma(int rows, const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev,
@@ -953,7 +963,7 @@ static void launch_conv_dma(int rows, const float *feat, const DclNbrSrc &nbr, i
   // A handful of crops (one-image calls) is latency-bound on the chunk loop: stream-K with kFewChunks chunks per workgroup.
   const int nchunks = dcl_div_up(kvol * CIN, KC);
   constexpr int kFewChunks = 4, kFix = 4;
-  const int kSlots = g_conv_slots.load(std::memory_order_relaxed);
+  const int kSlots = g_conv_slots;
   const long long units = (long long)tiles * nchunks;
   int stream_k = 0, aligned_ns = 0, G = tiles < 65535 * 16 ? tiles : 65535 * 16;
   bool deferred = false;
@@ -969,7 +979,7 @@ static void launch_conv_dma(int rows, const float *feat, const DclNbrSrc &nbr, i
     int mode = 0, best_ns = 1;
     if (g_conv_split > 0) {                                        // test / tuning hook: force an aligned split
       mode = 1;
-      best_ns = g_conv_split.load() < nchunks ? g_conv_split.load() : nchunks;
+      best_ns = (int)g_conv_split < nchunks ? (int)g_conv_split : nchunks;
     } else if (few || n_out_dev) {
       mode = 2;                                                    // live sizes unknown or tiny: even shares, >= kFewChunks
     } else {
@@ -998,7 +1008,11 @@ static void launch_conv_dma(int rows, const float *feat, const DclNbrSrc &nbr, i
       }
     }
   }
+#ifdef DCL_DIAG
   const int32_t *bal = g_conv_bal.load();
+#else
+  const int32_t *bal = nullptr;
+#endif
   if (bal && CIN >= 32 && scratch && !n_out_dev) {       // experiment: always stream-K over all slots, in-launch combine
     stream_k = 1;
     aligned_ns = 0;
@@ -1011,13 +1025,14 @@ static void launch_conv_dma(int rows, const float *feat, const DclNbrSrc &nbr, i
     bal = nullptr;
   }
   hipLaunchKernelGGL((k_sparse_conv_dma<CIN, WR, WCW, NT>), dim3(G), dim3(64 * WR * WCW), lds, s, feat, nbr, cap, n_out_dev,
-                     n_out_host, W, cout, kvol, subm, scale, shift, relu, out, partial, stream_k, aligned_ns, g_conv_xcd_remap,
+                     n_out_host, W, cout, kvol, subm, scale, shift, relu, out, partial, stream_k, aligned_ns, (int)g_conv_xcd_remap,
                      counters, bal);
   if (deferred)
     hipLaunchKernelGGL((k_conv_frag_reduce<WR, WCW, NT>), dim3(tiles, WR * WCW * NT), dim3(256), 0, s, partial, cap, n_out_dev,
                        n_out_host, cout, nchunks, G, stream_k, scale, shift, relu, out);
 }
 
+#ifdef DCL_DIAG
 template <int CIN, int WC, int KC>
 static void launch_conv_tile(int rows, const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev,
                              int n_out_host, const float *W, int cout, int kvol, int subm, const float *scale,
@@ -1035,7 +1050,7 @@ static void launch_conv_tile(int rows, const float *feat, const DclNbrSrc &nbr, 
   const int nchunks = dcl_div_up(kvol, KC / CIN);
   int nsplit = 1;
   if (scratch && g_conv_split >= 0 && conv_few_rows(rows, n_out_dev != nullptr)) {
-    nsplit = g_conv_split > 0 ? g_conv_split.load() : kConvMaxSplit;
+    nsplit = g_conv_split > 0 ? (int)g_conv_split : kConvMaxSplit;
     if (nsplit > nchunks) nsplit = nchunks;
     while (nsplit > 1 && (long long)nsplit * cap * cout > scratch_floats) --nsplit;
     if (nsplit < 1) nsplit = 1;
@@ -1046,6 +1061,8 @@ static void launch_conv_tile(int rows, const float *feat, const DclNbrSrc &nbr, 
     hipLaunchKernelGGL(k_conv_split_reduce, dim3(dcl_grid_1d((long long)rows * (cout / 4), 256)), dim3(256), 0, s, scratch,
                        nsplit, cap, n_out_dev, n_out_host, cout, scale, shift, relu, out);
 }
+
+#endif  // DCL_DIAG
 
 // ---- sparse average pool ------------------------------------------------------------------------
 // thread = (output row, 4 channels): rf = #valid offsets (summaryRF.cu:39), then
@@ -1127,12 +1144,14 @@ __global__ void k_sparse_avgpool_scalar(const float *__restrict__ feat, const Dc
 
 }  // namespace
 
-static std::atomic<int> g_force_valu{0};   // test hook: 1 = plain VALU kernel for every conv, 2 = MFMA kernel without LDS staging (the general Cin % 8 fallback), 4 = register-staged tile kernel instead of the LDS-DMA one, 5 = 8-wave 128x64 tiles for Cout = 64
+DCL_HOOK_INT(g_force_valu, 0);   // 1 = plain VALU kernel for every conv, 2 = MFMA kernel without LDS staging (the general Cin % 8 fallback), 4 = register-staged tile kernel instead of the LDS-DMA one, 5 = 8-wave 128x64 tiles for Cout = 64
+#ifdef DCL_DIAG
 DCL_API void dcl_debug_force_valu_conv(int on) { g_force_valu = on; }
-
 DCL_API void dcl_debug_conv_split(int n) { g_conv_split = n; }
 DCL_API void dcl_debug_conv_balance(const int32_t *bal_dev) { g_conv_bal = bal_dev; }
 DCL_API void dcl_debug_conv_slots(int n) { g_conv_slots = (n >= 64 && n <= 512) ? n : 512; }
+DCL_API void dcl_debug_conv_xcd_remap(int on) { g_conv_xcd_remap = on; }
+#endif
 #ifdef DCL_CONV_STAMPS
 extern "C" __attribute__((visibility("default"))) int dcl_debug_conv_stamps(unsigned long long *host, int n_wg, int clear) {
   if (clear) {
@@ -1145,8 +1164,6 @@ extern "C" __attribute__((visibility("default"))) int dcl_debug_conv_stamps(unsi
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_conv_stamps), sizeof(unsigned long long) * 8 * n_wg);
 }
 #endif
-DCL_API void dcl_debug_conv_xcd_remap(int on) { g_conv_xcd_remap = on; }
-
 // most K-splits a conv launch over `rows` output rows may use (sizes the partial-sum scratch; backbone.hip)
 int dcl_internal_conv_split_cap(long long rows) { return conv_split_cap(rows); }
 
@@ -1259,11 +1276,12 @@ static int conv_dispatch(const float *feat, const DclNbrSrc &nbr, int cap, const
   const bool mfma_ok = g_force_valu != 1 && (cin % 8 == 0) && (cout % 32 == 0);
   const bool lds_ok = mfma_ok && g_force_valu != 2 && (cin == 16 || cin == 32 || cin == 64 || cin == 128);
   if (lds_ok) {
-    // implicit-GEMM tile kernel: 64x64 tiles (KC=128) when Cout allows, else 128x32 tiles (KC=64)
+    // LDS-DMA implicit-GEMM kernel; the tile shape follows Cout
 #define TILE_ARGS rows, feat, nbr, cap, n_out_dev, n_out_host, W, cout, kvol, subm, scale, shift, relu, out, scratch, \
                   (long long)scratch_floats, counters_ready, s
 #define DMA_ARGS rows, feat, nbr, cap, n_out_dev, n_out_host, W, cout, kvol, subm, scale, shift, relu, out, scratch, \
                  (long long)scratch_floats, counters_ready, s
+#ifdef DCL_DIAG
     if (g_force_valu == 5 && cout % 128 != 0 && cout % 64 == 0) {          // A/B: 8 waves of 32x32 on 128x64 tiles
       switch (cin) {
         case 16: launch_conv_dma<16, 4, 2, 1>(DMA_ARGS); break;
@@ -1271,40 +1289,42 @@ static int conv_dispatch(const float *feat, const DclNbrSrc &nbr, int cap, const
         case 64: launch_conv_dma<64, 4, 2, 1>(DMA_ARGS); break;
         default: launch_conv_dma<128, 4, 2, 1>(DMA_ARGS); break;
       }
-    } else if (g_force_valu != 4 && cout % 64 != 0) {                       // Cout = 32: LDS-DMA kernel on 128x32 tiles
-      switch (cin) {
-        case 16: launch_conv_dma<16, 4, 1, 1>(DMA_ARGS); break;
-        case 32: launch_conv_dma<32, 4, 1, 1>(DMA_ARGS); break;
-        case 64: launch_conv_dma<64, 4, 1, 1>(DMA_ARGS); break;
-        default: launch_conv_dma<128, 4, 1, 1>(DMA_ARGS); break;
-      }
-    } else if (cout % 128 == 0 && g_force_valu != 4) {
-      switch (cin) {
-        case 16: launch_conv_dma<16, 4, 2, 2>(DMA_ARGS); break;
-        case 32: launch_conv_dma<32, 4, 2, 2>(DMA_ARGS); break;
-        case 64: launch_conv_dma<64, 4, 2, 2>(DMA_ARGS); break;
-        default: launch_conv_dma<128, 4, 2, 2>(DMA_ARGS); break;
-      }
-    } else if (cout % 64 == 0 && g_force_valu != 4) {
-      switch (cin) {
-        case 16: launch_conv_dma<16, 4, 1, 2>(DMA_ARGS); break;
-        case 32: launch_conv_dma<32, 4, 1, 2>(DMA_ARGS); break;
-        case 64: launch_conv_dma<64, 4, 1, 2>(DMA_ARGS); break;
-        default: launch_conv_dma<128, 4, 1, 2>(DMA_ARGS); break;
-      }
-    } else if (cout % 64 == 0) {
+    } else if (g_force_valu == 4 && cout % 64 == 0) {                       // A/B: register-staged tile kernel
       switch (cin) {
         case 16: launch_conv_tile<16, 2, 128>(TILE_ARGS); break;
         case 32: launch_conv_tile<32, 2, 128>(TILE_ARGS); break;
         case 64: launch_conv_tile<64, 2, 128>(TILE_ARGS); break;
         default: launch_conv_tile<128, 2, 128>(TILE_ARGS); break;
       }
-    } else {
+    } else if (g_force_valu == 4) {
       switch (cin) {
         case 16: launch_conv_tile<16, 1, 64>(TILE_ARGS); break;
         case 32: launch_conv_tile<32, 1, 64>(TILE_ARGS); break;
         case 64: launch_conv_tile<64, 1, 64>(TILE_ARGS); break;
         default: launch_conv_tile<128, 1, 128>(TILE_ARGS); break;
+      }
+    } else
+#endif
+    if (cout % 64 != 0) {                                                   // Cout = 32: LDS-DMA kernel on 128x32 tiles
+      switch (cin) {
+        case 16: launch_conv_dma<16, 4, 1, 1>(DMA_ARGS); break;
+        case 32: launch_conv_dma<32, 4, 1, 1>(DMA_ARGS); break;
+        case 64: launch_conv_dma<64, 4, 1, 1>(DMA_ARGS); break;
+        default: launch_conv_dma<128, 4, 1, 1>(DMA_ARGS); break;
+      }
+    } else if (cout % 128 == 0) {                                           // 128x128 tiles, 8 waves
+      switch (cin) {
+        case 16: launch_conv_dma<16, 4, 2, 2>(DMA_ARGS); break;
+        case 32: launch_conv_dma<32, 4, 2, 2>(DMA_ARGS); break;
+        case 64: launch_conv_dma<64, 4, 2, 2>(DMA_ARGS); break;
+        default: launch_conv_dma<128, 4, 2, 2>(DMA_ARGS); break;
+      }
+    } else {                                                                // Cout % 64 == 0: 128x64 tiles, 4 waves
+      switch (cin) {
+        case 16: launch_conv_dma<16, 4, 1, 2>(DMA_ARGS); break;
+        case 32: launch_conv_dma<32, 4, 1, 2>(DMA_ARGS); break;
+        case 64: launch_conv_dma<64, 4, 1, 2>(DMA_ARGS); break;
+        default: launch_conv_dma<128, 4, 1, 2>(DMA_ARGS); break;
       }
     }
 #undef DMA_ARGS

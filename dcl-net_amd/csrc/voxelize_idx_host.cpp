@@ -29,8 +29,8 @@ API int dcl_voxelize_idx_count(const int64_t *coords, int n, int ncol, int batch
                                int32_t *input_map, int32_t *n_active, int32_t *max_active) {
   (void)batch_size;
   if (!coords || !input_map || !n_active || !max_active || n < 0 || (ncol != 3 && ncol != 4) ||
-      (mode != 3 && mode != 4)) {
-    dcl_set_error("dcl_voxelize_idx_count: invalid argument (ncol must be 3|4, mode 3|4)");
+      mode < 0 || mode > 4) {
+    dcl_set_error("dcl_voxelize_idx_count: invalid argument (ncol must be 3|4, mode 0..4)");
     return DCL_EINVAL;
   }
   std::unordered_map<Key, int32_t, KeyHash> grid;
@@ -59,16 +59,44 @@ API int dcl_voxelize_idx_count(const int64_t *coords, int n, int ncol, int batch
   int32_t mx = 1;
   for (int32_t c : count) mx = c > mx ? c : mx;
   *n_active = (int32_t)count.size();
-  *max_active = mx;
+  // modes 0 (guaranteed unique), 1, 2 keep ONE point per voxel: maxActive == 1 (voxelize.cpp:111-138); the reference asserts
+  // uniqueness in mode 0 (:120-124) -- reported as an error here instead of an abort
+  if (mode == 0 && mx > 1) {
+    dcl_set_error("dcl_voxelize_idx_count: mode 0 promises unique coordinates, but a voxel holds %d points", mx);
+    return DCL_EINVAL;
+  }
+  *max_active = mode <= 2 ? 1 : mx;
   return 0;
 }
 
 API int dcl_voxelize_idx_fill(const int64_t *coords, int n, int ncol, const int32_t *input_map,
                               int n_active, int max_active, int64_t *output_coords,
                               int32_t *output_map) {
-  if (!coords || !input_map || !output_coords || !output_map || n < 0 || (ncol != 3 && ncol != 4)) {
+  return dcl_voxelize_idx_fill_mode(coords, n, ncol, input_map, n_active, max_active, 4, output_coords, output_map);
+}
+
+// mode 3 / 4: every point of the voxel, ascending (voxelize.cpp:139-149).  modes 0 / 1: the voxel's FIRST point
+// (outputRows[i][0] / .front(), :120-131), mode 2: its LAST point (.back(), :132-137); rows are [1, point].
+API int dcl_voxelize_idx_fill_mode(const int64_t *coords, int n, int ncol, const int32_t *input_map,
+                                   int n_active, int max_active, int mode, int64_t *output_coords,
+                                   int32_t *output_map) {
+  if (!coords || !input_map || !output_coords || !output_map || n < 0 || (ncol != 3 && ncol != 4) || mode < 0 || mode > 4 ||
+      (mode <= 2 && max_active != 1)) {
     dcl_set_error("dcl_voxelize_idx_fill: invalid argument");
     return DCL_EINVAL;
+  }
+  if (mode <= 2) {
+    for (int i = 0; i < n; ++i) {
+      const int v = input_map[i];
+      if (v < 0 || v >= n_active) {
+        dcl_set_error("dcl_voxelize_idx_fill: input_map[%d]=%d out of range", i, v);
+        return DCL_EINVAL;
+      }
+      int32_t *row = output_map + (size_t)v * 2;
+      if (row[0] == 0) memcpy(output_coords + (size_t)v * ncol, coords + (size_t)i * ncol, sizeof(int64_t) * ncol);
+      if (row[0] == 0 || mode == 2) { row[0] = 1; row[1] = i; }
+    }
+    return 0;
   }
   const size_t stride = (size_t)max_active + 1;
   for (int i = 0; i < n; ++i) {

@@ -18,7 +18,6 @@ Two execution paths over the same parameters:
   fused=False -- composes the mirrored modules exactly like the reference graph (materialised attention
       map, per-layer rulebooks); kept as an executable specification and cross-check.
 """
-import os
 from functools import partial
 
 import numpy as np
@@ -66,7 +65,8 @@ def _fuser():
 
 
 class Network(nn.Module):
-    def __init__(self, cfg, mode="train", fused=True, graph_max_batch=8, async_inputs=False, graph_max_points=98304):
+    def __init__(self, cfg, mode="train", fused=True, graph_max_batch=8, async_inputs=False, graph_max_points=98304,
+                 single_stream=False, pipeline_chunks=1, capture_graph=True):
         """graph_max_batch > 0 (default 8): eval-mode calls with at most that many crops go through forward_graphed (one
         whole-forward hipGraph per batch size, captured on first use) -- the one-image-at-a-time eval loops of the
         reference (tools/test_LM.py:104-112: one object per call) are launch-bound otherwise: 0.6 instead of 1.2-1.4 ms
@@ -77,8 +77,15 @@ class Network(nn.Module):
         async_inputs=True: the caller guarantees that `data`'s CUDA tensors are complete when forward() is called (or hands
         over data["ready_event"]) and are not overwritten until the results have been consumed.  The sparse half of a call
         (side streams) then does not wait for the dense half of the previous call still running on the current stream, so
-        back-to-back calls pipeline: backbones of batch k+1 underneath the GEMMs / attention of batch k."""
+        back-to-back calls pipeline: backbones of batch k+1 underneath the GEMMs / attention of batch k.
+        single_stream=True: the whole call on the caller's stream (no side streams; what bench.py's per-kernel conv timing
+        uses).  pipeline_chunks=K > 1: the sparse half in K passes over b/K crops (measured slower, kept runnable).
+        capture_graph=False: forward_graphed runs its capacity-mode body launch by launch (debugging aid).  These are
+        constructor arguments on purpose: nothing on the call path reads the environment."""
         super().__init__()
+        self.single_stream = bool(single_stream)
+        self.pipeline_chunks = int(pipeline_chunks)
+        self.capture_graph = bool(capture_graph)
         self.graph_max_batch = int(graph_max_batch)
         self.graph_max_points = int(graph_max_points)
         self.async_inputs = bool(async_inputs)
@@ -210,8 +217,8 @@ class Network(nn.Module):
         return ops.linear(x, layers[2][0], layers[2][1], False)
 
     def _side_stream(self, dev, which=0):
-        """per-side streams of the sparse half (DCL_SINGLE_STREAM=1: everything on the current stream)"""
-        if os.environ.get("DCL_SINGLE_STREAM") == "1":
+        """per-side streams of the sparse half (single_stream: everything on the current stream)"""
+        if self.single_stream:
             return torch.cuda.current_stream(dev)
         # one set of side streams per device for the whole process: the runtime deals streams round-robin onto a few
         # hardware queues, so per-instance streams of a second Network can land on a queue its first one (or the other
@@ -226,8 +233,9 @@ class Network(nn.Module):
         """number of crop chunks of the sparse/disengage software pipeline.  Measured on MI355X (bs 32): K = 1/2/4 ->
         25.2/26.0/27.8 ms at N=12288 and 5.3/6.3/8.0 ms at N=1024 -- the sparse passes are latency-bound, so K passes over
         b/K crops cost almost K times one pass over b crops and the overlap cannot pay for that.  Default 1 (the two
-        backbones still overlap each other and the first disengage GEMMs); DCL_CHUNKS=k keeps the experiment runnable."""
-        k = int(os.environ.get("DCL_CHUNKS", "1"))
+        backbones still overlap each other and the first disengage GEMMs); Network(pipeline_chunks=k) keeps the experiment
+        runnable."""
+        k = self.pipeline_chunks
         while k > 1 and (b % k != 0 or b // k < 4):
             k -= 1
         return max(k, 1)
@@ -246,8 +254,8 @@ class Network(nn.Module):
         # stream (input conversion, geometry, features, point read-out); the dense half runs on the caller's stream and
         # starts a side's disengage GEMMs as soon as that side is done.  (2) With async_inputs the side streams do not wait
         # for the caller's stream at all, so the sparse half of this call overlaps the dense half of the previous one.
-        # (3) Optional chunking of the sparse half (DCL_CHUNKS, measured slower).  One host read-back of the level sizes,
-        # made on a side stream.  DCL_SINGLE_STREAM=1 switches all overlap off.
+        # (3) Optional chunking of the sparse half (pipeline_chunks, measured slower).  One host read-back of the level sizes,
+        # made on a side stream.  single_stream=True switches all overlap off.
         main = torch.cuda.current_stream(dev)
         sstream = {"inp": self._side_stream(dev, 0), "tmp": self._side_stream(dev, 1)}
         single = sstream["inp"] is main
@@ -273,10 +281,8 @@ class Network(nn.Module):
         # convolutions on the GPU ~150 us after the call starts, and the template side's whole head is issued underneath
         # them.  The level sizes land in pinned host memory, written by the geometry kernels themselves (device-visible host
         # allocation): the host waits for that side's geometry event and reads them -- no copy kernel, no D2H enqueue.
-        # DCL_GEOMETRY_FIRST=1: both geometry stages before anything else (the round-1 order; A/B).
         occ = {}
         counts_host = self._counts_pinned(K)
-        geometry_first = os.environ.get("DCL_GEOMETRY_FIRST", "0") == "1"
         def geometry(s):
             with torch.cuda.stream(sstream[s]):
                 occ[s] = data[s]["occupied_voxels"].to(dev, non_blocking=True).int().contiguous()
@@ -297,10 +303,6 @@ class Network(nn.Module):
                 pf[s].record_stream(main)
                 side_in[s][0].record_stream(main)                      # `pts` below is handed to the caller
             pts[s] = side_in[s][0][:, 4:7].reshape(b, npts[s], 3)
-        if geometry_first:
-            geometry("inp")
-            geometry("tmp")
-            stage("inp")
         mark("geometry issued")
         unit = self.unit_voxel_extent
         assert unit[0] == unit[1] == unit[2], "anisotropic voxels: use fused=False"
@@ -309,11 +311,8 @@ class Network(nn.Module):
         done = {}
         for side, bb in (("inp", "backbone_inp"), ("tmp", "backbone_tmp")):
             n = npts[side]
-            if not geometry_first:
-                geometry(side)
-                stage(side)                                            # runs underneath the geometry
-            elif side == "tmp":
-                stage("tmp")
+            geometry(side)
+            stage(side)                                                # runs underneath the geometry
             geo[side].synchronize()                                    # the host waits for THIS side's geometry only
             counts = counts_host[side].tolist()
             mark("counts read back " + side)
@@ -501,7 +500,7 @@ class Network(nn.Module):
                 st["v2p"].zero_()
                 st["v2p"][:v0, :need_ma[s] + 1].copy_(d["v2p_maps"], non_blocking=True)
                 st["v0"].fill_(v0)
-        if ent["graph"] is None:                       # DCL_NO_GRAPH=1: run the capacity-mode body eagerly (debugging aid)
+        if ent["graph"] is None:                       # capture_graph=False: the capacity-mode body, launch by launch
             with torch.no_grad():
                 ent["out"] = ent["body"]()
         else:
@@ -552,7 +551,7 @@ class Network(nn.Module):
             # hipStreamEndCapture when a stream joins the capture through an event of an already forked stream.
             main, side_stream = torch.cuda.current_stream(dev), self._side_stream(dev)
             act = {}
-            par_dense = b <= 8 and os.environ.get("DCL_GRAPH_SERIAL_DENSE") != "1"
+            par_dense = b <= 8
             side_stream.wait_stream(main)
             # The two branches are issued stage by stage, alternating: a graph launch hands its nodes to the queues in
             # creation order, so a branch captured as a whole after the other one starts ~50 nodes late on replay.
@@ -579,7 +578,7 @@ class Network(nn.Module):
             return self._dense_tail(f, act, b, dev, side=side_stream if par_dense else None)
 
         ent["body"] = body
-        if os.environ.get("DCL_NO_GRAPH") == "1":
+        if not self.capture_graph:
             ent["graph"], ent["out"] = None, None
             return ent
         with torch.no_grad():

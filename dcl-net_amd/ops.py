@@ -36,8 +36,8 @@ def voxelize_idx(coords, batch_size, mode=4):
                                            C.byref(na), C.byref(ma)), "voxelize_idx_count")
     out_coords = torch.zeros((na.value, ncol), dtype=torch.int64)
     out_map = torch.zeros((na.value, ma.value + 1), dtype=torch.int32)
-    N.check(N.lib().dcl_voxelize_idx_fill(N.ptr(coords), n, ncol, N.ptr(input_map), na.value, ma.value,
-                                          N.ptr(out_coords), N.ptr(out_map)), "voxelize_idx_fill")
+    N.check(N.lib().dcl_voxelize_idx_fill_mode(N.ptr(coords), n, ncol, N.ptr(input_map), na.value, ma.value, int(mode),
+                                               N.ptr(out_coords), N.ptr(out_map)), "voxelize_idx_fill")
     return out_coords, input_map, out_map
 
 

@@ -38,12 +38,18 @@ int dcl_abi_version(void);
  * DataLoader workers, YCBV/dataloader_test_YCBV.py:217,223).  Two calls, like
  * the reference's resize-in-place protocol split in two: _count fills
  * input_map and returns sizes, _fill writes the caller-allocated (zeroed)
- * outputs.  mode 3 (sum) / 4 (mean) only.                                      */
+ * outputs.  All five modes of voxelize.cpp:111-149: 0 = guaranteed unique (an
+ * error here, an assert there, if not), 1 = the voxel's first point, 2 = its last
+ * point (max_active == 1, rows [1, point]), 3 (sum) / 4 (mean) = every point.
+ * dcl_voxelize_idx_fill is _fill_mode with mode 4.                              */
 int dcl_voxelize_idx_count(const int64_t *coords_host, int n, int ncol, int batch_size, int mode,
                            int32_t *input_map_host, int32_t *n_active_host, int32_t *max_active_host);
 int dcl_voxelize_idx_fill(const int64_t *coords_host, int n, int ncol, const int32_t *input_map_host,
                           int n_active, int max_active, int64_t *output_coords_host,
                           int32_t *output_map_host);
+int dcl_voxelize_idx_fill_mode(const int64_t *coords_host, int n, int ncol, const int32_t *input_map_host,
+                               int n_active, int max_active, int mode, int64_t *output_coords_host,
+                               int32_t *output_map_host);
 
 /* DEVICE voxelize_idx (same results as the host one, coords on the GPU inside a batch x S^3 grid).
  * _count: input_map (n) and info_dev = {n_active, max_active, error flag (coordinate out of range)}; the caller reads
@@ -307,7 +313,9 @@ int dcl_three_interpolate(int b, int c, int m, int n, const float *points, const
  *   S[j,i] = <K[j,:], Q[i,:]> over 64 channels, A = softmax over the KEY axis j,
  *   O1[i,:] = sum_j A[j,i] V1[j,:]  (dv1 ch),  O2 likewise from V2 (dv2 ch; may be NULL/0)
  * Q (b*nq rows), K, V1, V2 (b*nk rows), O1, O2 (b*nq rows).  fp32 MFMA, online softmax.
- * dv1, dv2 multiples of 32 with (dv1+dv2)/32 in {1,2,4,8,10}; all ld % 4 == 0, 16-B aligned.   */
+ * The product library is built for DCL-Net's own channel split, dv1 = 256 and dv2 = 64 (DCL_EINVAL otherwise); the
+ * diagnostic library (-DDCL_DIAG) also carries the general-shape predecessors: dv1, dv2 multiples of 32 with
+ * (dv1+dv2)/32 in {1,2,4,8,10}.  All ld % 4 == 0, 16-B aligned.   */
 int dcl_cross_attention(int b, int nq, int nk, const float *Q, int ldq, const float *K, int ldk,
                         const float *V1, int dv1, int ldv1, float *O1, int ldo1, const float *V2,
                         int dv2, int ldv2, float *O2, int ldo2, dclStream_t stream);
@@ -423,9 +431,12 @@ int dcl_add_by_symmetry(int b, int P, const float *cld, const int32_t *cls, cons
 int dcl_profile_conv_begin(void);
 int dcl_profile_conv_end(double *ms_total_host, int32_t *calls_host);
 
-/* The dcl_debug_* entry points below are TEST / TUNING hooks, not part of the operator API: each sets one process-wide
- * atomic switch that later calls from any thread read (A/B kernel variants in tests, tuning sweeps in tools/).  They never
- * change results beyond the tolerance of the op; production callers leave them alone.                                    */
+/* ---- DIAGNOSTIC library only (csrc/Makefile `make diag` -> tests/_diag/libdclnet_hip_diag.so, built with -DDCL_DIAG) ----
+ * The dcl_debug_* entry points are TEST / TUNING hooks, not part of the operator API and NOT exported by the product library
+ * libdclnet_hip.so (where every switch is a compile-time constant and the superseded kernel variants are not compiled):
+ * each sets one process-wide atomic switch that later calls from any thread read (A/B kernel variants in tests, tuning
+ * sweeps in tools/).  They never change results beyond the tolerance of the op.                                          */
+#ifdef DCL_DIAG
 /* Test hook, sparse-conv kernel variant: 0 = automatic (LDS-DMA implicit GEMM where Cout % 64 == 0), 1 = plain VALU
  * kernel for every layer (A/B check of the MFMA ones), 2 = MFMA without LDS staging (the general fallback),
  * 4 = register-staged tile kernel instead of the LDS-DMA one, 5 = 8-wave 128x64 tiles for Cout = 64. */
@@ -461,6 +472,7 @@ void dcl_debug_conv_xcd_remap(int on);
 /* Tuning hook for dcl_group_points' LDS-staged kernel: channel rows per workgroup, x-blocks, threads per workgroup,
  * store kind (2 = plain instead of nontemporal); 0 = built-in choice for each. */
 void dcl_debug_group_points_cfg(int cc, int xb, int threads, int nontemporal);
+#endif /* DCL_DIAG */
 
 #ifdef __cplusplus
 }

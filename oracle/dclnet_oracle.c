@@ -45,14 +45,38 @@ ORC_API int orc_set_num_threads(int n) {
 #endif
 }
 
+/* ORC_FMA_POLICY selects how the two contractible source expressions of the CUDA kernels are associated.  The CUDA
+ * binary cannot be run here, so the policy nvcc really applied is an assumption (policy 0); the alternates exist to
+ * BOUND that assumption: tests/test_fma_policy.py counts the index picks that differ between the three builds and
+ * checks that the pose does not move (oracle/Makefile builds liboracle_p1.so / liboracle_p2.so from this same file).
+ *   0  fmaf(dz,dz, fmaf(dx,dx, dy*dy))   -- LLVM/NVVM scalar contraction of  dx*dx + dy*dy + dz*dz   (the pinned policy)
+ *   1  (dx*dx + dy*dy) + dz*dz            -- no contraction at all (nvcc -fmad=false)
+ *   2  fmaf(dx,dx, fmaf(dy,dy, dz*dz))   -- the other FMA chain a compiler could form                               */
+#ifndef ORC_FMA_POLICY
+#define ORC_FMA_POLICY 0
+#endif
+ORC_API int orc_fma_policy(void) { return ORC_FMA_POLICY; }
+
 static inline float dist2f(float ax, float ay, float az, float bx, float by, float bz) {
     float dx = ax - bx, dy = ay - by, dz = az - bz;
+#if ORC_FMA_POLICY == 0
     return fmaf(dz, dz, fmaf(dx, dx, dy * dy));
+#elif ORC_FMA_POLICY == 1
+    return (dx * dx + dy * dy) + dz * dz;
+#else
+    return fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+#endif
 }
 
 /* a*b + c*d + e*f under the same contraction policy as dist2f. */
 static inline float wsum3(float a, float b, float c, float d, float e, float f) {
+#if ORC_FMA_POLICY == 0
     return fmaf(e, f, fmaf(a, b, c * d));
+#elif ORC_FMA_POLICY == 1
+    return (a * b + c * d) + e * f;
+#else
+    return fmaf(a, b, fmaf(c, d, e * f));
+#endif
 }
 
 /* ------------------------------------------------------------------------- */
@@ -95,6 +119,21 @@ ORC_API int orc_voxelize_idx_pass1(const int64_t *coords, int n, int32_t *input_
     *max_active = mx;
     free(cnt); free(tab);
     return nActive;
+}
+
+/* modes 0 / 1 / 2 (voxelize.cpp:119-138): one point per voxel, rule row = [1, point]; mode 0 = outputRows[i][0] (unique by
+ * contract), mode 1 = outputRows[i].front(), mode 2 = outputRows[i].back().  output_coords = coords of that point
+ * (voxelize.cpp:34-49).  Buffers zeroed by the caller; output_map is (n_active, 2).                                */
+ORC_API void orc_voxelize_idx_pass2_single(const int64_t *coords, int n, const int32_t *input_map, int mode,
+                                           int64_t *output_coords, int32_t *output_map) {
+    for (int i = 0; i < n; ++i) {
+        int v = input_map[i];
+        int32_t *row = output_map + (size_t)v * 2;
+        if (row[0] == 0 || mode == 2) {
+            row[0] = 1; row[1] = i;
+            memcpy(output_coords + (size_t)v * 4, coords + (size_t)i * 4, sizeof(int64_t) * 4);
+        }
+    }
 }
 
 /* pass 2: output_map[v] = [count, p0, p1, ..., 0 pad]; output_coords[v] =

@@ -15,23 +15,55 @@ _LIB = None
 _REF = None
 
 
+def _so_name(policy):
+    return "liboracle.so" if policy == 0 else "liboracle_p%d.so" % policy
+
+
 def build(force=False):
-    """Compile liboracle.so (and oracle/_ref when /root/reference is present)."""
-    so = os.path.join(_HERE, "liboracle.so")
+    """Compile liboracle.so, its two alternate-FMA-policy twins (and oracle/_ref when /root/reference is present)."""
     src = os.path.join(_HERE, "dclnet_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    for policy in (0, 1, 2):
+        so = os.path.join(_HERE, _so_name(policy))
+        if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", _HERE, _so_name(policy)], stdout=subprocess.DEVNULL)
     ref_so = os.path.join(_HERE, "_ref", "libref_geometry.so")
     if os.path.isdir("/root/reference/libs/spconv/include") and (force or not os.path.exists(ref_so)):
         subprocess.call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
 
 
+_POLICY = 0
+_LIBS = {}
+
+
 def lib():
+    """liboracle.so under the FMA-association policy in effect (0 = the pinned one, see fma_policy)."""
     global _LIB
-    if _LIB is None:
+    if _POLICY not in _LIBS:
         build()
-        _LIB = C.CDLL(os.path.join(_HERE, "liboracle.so"))
+        L = C.CDLL(os.path.join(_HERE, _so_name(_POLICY)))
+        assert L.orc_fma_policy() == _POLICY
+        _LIBS[_POLICY] = L
+    _LIB = _LIBS[_POLICY]
     return _LIB
+
+
+class fma_policy:
+    """`with fma_policy(p):` -- every oracle kernel called inside runs the build of dclnet_oracle.c made with
+    -DORC_FMA_POLICY=p (0 pinned; 1 no contraction; 2 the other FMA chain).  tests/test_fma_policy.py only."""
+
+    def __init__(self, policy):
+        assert policy in (0, 1, 2)
+        self.policy = policy
+
+    def __enter__(self):
+        global _POLICY
+        self.prev, _POLICY = _POLICY, self.policy
+        return self
+
+    def __exit__(self, *exc):
+        global _POLICY
+        _POLICY = self.prev
+        return False
 
 
 def set_num_threads(n):
@@ -67,12 +99,19 @@ def _i32(a):
 def voxelize_idx(coords, batch_size, mode=4):
     """PG_OP.voxelize_idx (libs/pointgroup_ops/functions/pointgroup_ops.py:11-39).
     coords int64 (N,4) -> output_coords int64 (M,4), input_map i32 (N), output_map i32 (M,1+maxActive)."""
-    assert mode in (3, 4)
+    assert mode in (0, 1, 2, 3, 4)
     coords = np.ascontiguousarray(coords, dtype=np.int64)
     n = coords.shape[0]
     input_map = np.zeros(n, np.int32)
     mx = C.c_int32(0)
     na = lib().orc_voxelize_idx_pass1(_p(coords, C.c_int64), n, _p(input_map, C.c_int32), C.byref(mx))
+    if mode <= 2:                                          # voxelize.cpp:119-138: one point per voxel, maxActive = 1
+        assert mode != 0 or mx.value == 1, "mode 0 promises unique coordinates (voxelize.cpp:120-124 asserts it)"
+        out_coords = np.zeros((na, 4), np.int64)
+        out_map = np.zeros((na, 2), np.int32)
+        lib().orc_voxelize_idx_pass2_single(_p(coords, C.c_int64), n, _p(input_map, C.c_int32), int(mode),
+                                            _p(out_coords, C.c_int64), _p(out_map, C.c_int32))
+        return out_coords, input_map, out_map
     out_coords = np.zeros((na, 4), np.int64)
     out_map = np.zeros((na, mx.value + 1), np.int32)
     lib().orc_voxelize_idx_pass2(_p(coords, C.c_int64), n, _p(input_map, C.c_int32), na, mx.value,

@@ -1,0 +1,109 @@
+"""Bound on the one oracle assumption that cannot be pinned here: how nvcc associated `dx*dx + dy*dy + dz*dz` in the
+reference's CUDA kernels (libs/pointnet_sp/src/interpolate_gpu.cu:40, libs/pointnet_lib/src/ball_query_gpu.cu:33,
+sampling_gpu.cu:150-152, interpolate_gpu.cu:36,99).  oracle/dclnet_oracle.c is built under three policies
+(ORC_FMA_POLICY 0 = the pinned fma(dz,dz,fma(dx,dx,dy*dy)); 1 = no contraction; 2 = fma(dx,dx,fma(dy,dy,dz*dz))) and
+this file counts the index picks that depend on the choice -- and checks that the POSE does not: under every policy
+the forward of oracle/graph.py stays inside BASELINE's gates (|dR| <= 1e-4, |dt| <= 1e-5 m) of the pinned policy.
+The counts measured in the build container are recorded in DESIGN.md section 3."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import graph as G
+from oracle import native as K
+
+POLICIES = (0, 1, 2)
+
+
+def _forward_all_policies(dcl, b, n, m, first=0):
+    cfg = dcl.synth.default_cfg(n, m)
+    net = dcl.DCL_Net.Network(cfg, mode="test")
+    sd = dcl.synth.synth_state_dict(net, 1)
+    data = dcl.synth.make_batch(b, n, m, first=first, voxelize_idx=lambda c, bs, mode: tuple(
+        torch.from_numpy(a) for a in K.voxelize_idx(c.numpy(), bs, mode)))
+    out = {}
+    for p in POLICIES:
+        with K.fma_policy(p):
+            assert K.lib().orc_fma_policy() == p
+            trace = {}
+            pred = G.forward(sd, dict(cfg), copy.deepcopy(data), mode="test", trace=trace)
+        out[p] = (pred, trace)
+    return out
+
+
+def _nn_flips(out, p):
+    """(#3-NN slots whose index differs from policy 0, #slots) over both sides and the four levels"""
+    diff = total = 0
+    for side in ("inp", "tmp"):
+        for l in range(4):
+            i0 = out[0][1]["%s.nn%d" % (side, l)][1]
+            ip = out[p][1]["%s.nn%d" % (side, l)][1]
+            diff += int((i0 != ip).sum())
+            total += i0.size
+    return diff, total
+
+
+def _check_pose(out, label):
+    r0, t0 = out[0][0]["rot_pred"], out[0][0]["trans_pred"]
+    report = []
+    for p in POLICIES[1:]:
+        dR = float((out[p][0]["rot_pred"] - r0).abs().max())
+        dt = float((out[p][0]["trans_pred"] - t0).abs().max())
+        dc = float((out[p][0]["conf"] - out[0][0]["conf"]).abs().max())
+        flips, total = _nn_flips(out, p)
+        report.append((p, flips, total, dR, dt, dc))
+        print("%s policy %d vs 0: three_nn_sp picks that differ %d / %d (%.4f %%), |dR| %.2e |dt| %.2e |dconf| %.2e"
+              % (label, p, flips, total, 100.0 * flips / total, dR, dt, dc))
+        assert dR <= 1e-4 and dt <= 1e-5, "pose depends on the FMA association beyond BASELINE's gates"
+        assert flips <= 0.005 * total, "an implausible share of 3-NN picks depends on the association"
+    return report
+
+
+def test_pose_is_independent_of_the_fma_association_reference_shape(dcl):
+    """config_YCBV_bs32.yaml's shape (N = M = 1024), 4 crops"""
+    _check_pose(_forward_all_policies(dcl, 4, 1024, 1024), "ref shape b=4")
+
+
+def test_pose_is_independent_of_the_fma_association_stress_crop(dcl):
+    """one crop of BASELINE configs[1] (N = 12288, M = 2048)"""
+    _check_pose(_forward_all_policies(dcl, 1, 12288, 2048), "stress crop b=1")
+
+
+def _cloud(rng, B, n):
+    """points on a 1 mm lattice inside a 12 cm cube: exact ties and near ties are common, as on voxelised scans"""
+    return (rng.integers(-60, 60, size=(B, n, 3)).astype(np.float32) * np.float32(0.001)
+            + rng.normal(0, 2e-4, size=(B, n, 3)).astype(np.float32))
+
+
+def test_index_picks_of_the_pointnet_lib_primitives_across_policies():
+    """ball_query / FPS / knn / batched three_nn: share of picks that depend on the policy"""
+    rng = np.random.default_rng(7)
+    B, n, npoint, ns = 2, 4096, 512, 32
+    xyz = _cloud(rng, B, n)
+    got = {}
+    for p in POLICIES:
+        with K.fma_policy(p):
+            fps = K.furthest_point_sample(xyz, npoint)
+            new_xyz = np.stack([xyz[i][fps[i]] for i in range(B)])
+            got[p] = {"fps": fps, "ball": K.ball_query(0.03, ns, xyz, new_xyz),
+                      "knn1": K.knn(1, new_xyz, xyz)[1], "three_nn": K.three_nn(new_xyz, xyz)[1]}
+    with K.fma_policy(0):                                   # same centres for every policy: isolate ball_query itself
+        centres = np.stack([xyz[i][got[0]["fps"][i]] for i in range(B)])
+    ball_same_centres = {}
+    for p in POLICIES:
+        with K.fma_policy(p):
+            ball_same_centres[p] = K.ball_query(0.03, ns, xyz, centres)
+    for p in POLICIES[1:]:
+        line = []
+        for k in ("fps", "ball", "knn1", "three_nn"):
+            d = int((got[p][k] != got[0][k]).sum())
+            line.append("%s %d/%d" % (k, d, got[0][k].size))
+        d = int((ball_same_centres[p] != ball_same_centres[0]).sum())
+        line.append("ball(same centres) %d/%d" % (d, ball_same_centres[0].size))
+        print("policy %d vs 0: picks that differ: %s" % (p, ", ".join(line)))
+        # the picks are a set-valued function of distances that differ by <= 1 ulp: only (near-)ties can flip
+        assert d <= 0.01 * ball_same_centres[0].size
+        assert int((got[p]["knn1"] != got[0]["knn1"]).sum()) <= 0.01 * got[0]["knn1"].size
+        assert int((got[p]["three_nn"] != got[0]["three_nn"]).sum()) <= 0.01 * got[0]["three_nn"].size

@@ -359,8 +359,8 @@ def test_pipelined_calls_give_the_same_results(dcl):
             assert torch.equal(a[k], c[k]), k
 
 
-def test_chunked_sparse_half_and_stream_switches_give_the_same_results(dcl, monkeypatch):
-    """the batch-window backbone passes (DCL_CHUNKS: crops k*b/K .. of one occupied-voxel array, re-based per pass) and
+def test_chunked_sparse_half_and_stream_switches_give_the_same_results(dcl):
+    """the batch-window backbone passes (pipeline_chunks: crops k*b/K .. of one occupied-voxel array, re-based per pass) and
     the single-stream mode must return what the default schedule returns"""
     n = 384
     cfg = dcl.synth.default_cfg(n, n)
@@ -371,13 +371,12 @@ def test_chunked_sparse_half_and_stream_switches_give_the_same_results(dcl, monk
     with torch.no_grad():
         ref = net(data)
         outs = {}
-        for name, env in (("chunks2", {"DCL_CHUNKS": "2"}), ("chunks4", {"DCL_CHUNKS": "4"}),
-                          ("single", {"DCL_SINGLE_STREAM": "1"})):
-            for k, v in env.items():
-                monkeypatch.setenv(k, v)
+        for name, attr, val in (("chunks2", "pipeline_chunks", 2), ("chunks4", "pipeline_chunks", 4),
+                                ("single", "single_stream", True)):
+            old = getattr(net, attr)                   # the switches are constructor arguments (plain attributes): no environment
+            setattr(net, attr, val)
             outs[name] = net(data)
-            for k in env:
-                monkeypatch.delenv(k)
+            setattr(net, attr, old)
     # one stream: the same kernels in the same order -> identical bits.  Chunked passes have other row counts per launch,
     # hence other split-K / GEMM tilings (other summation orders): equal within the parity tolerance of the path
     for k in ("rot_pred", "trans_pred", "conf", "F_Xo_p"):

@@ -15,6 +15,15 @@ def cuda(a, dtype=None):
     return t.cuda()
 
 
+def enter_diag(dcl, request):
+    """switch the package to the DIAGNOSTIC library (tests/_diag/libdclnet_hip_diag.so, built with -DDCL_DIAG: the product
+    library exports no dcl_debug_* hook and carries no superseded kernel variant) until the test ends; returns its handle"""
+    ctx = dcl._native.diagnostic_library()
+    lib = ctx.__enter__()
+    request.addfinalizer(lambda: ctx.__exit__(None, None, None))
+    return lib
+
+
 def rand_voxels(rng, b, S, n_per):
     """unsorted unique voxel rows per crop, batch-sorted like the loaders produce"""
     rows = []
@@ -108,7 +117,7 @@ def test_rulebook_empty_and_single(dcl, oracle):
 # ------------------------------------------------------------------------------------------- sparse conv / pool
 @pytest.mark.parametrize("cin,cout,subm", [(7, 16, False), (16, 32, True), (32, 32, False), (64, 128, True),
                                            (128, 256, True), (128, 128, False)])
-def test_sparse_conv_matches_oracle(dcl, oracle, cin, cout, subm):
+def test_sparse_conv_matches_oracle(request, dcl, oracle, cin, cout, subm):
     rng = np.random.default_rng(cin + cout)
     b, S = 2, 8
     idx = rand_voxels(rng, b, S, 150)
@@ -124,7 +133,7 @@ def test_sparse_conv_matches_oracle(dcl, oracle, cin, cout, subm):
     tol = 2e-5 * max(1.0, np.abs(want).max())                  # fp32, different summation association
     assert np.abs(got - want).max() <= tol
     # MFMA kernel vs plain VALU kernel on the device (A/B)
-    lib = dcl._native.lib()
+    lib = enter_diag(dcl, request)      # kernel variants live in the diagnostic library only (tests/_diag)
     for mode in (1, 2, 4, 5):                                  # 1: VALU, 2: MFMA no LDS, 4: reg-staged tiles, 5: 8-wave 128x64
         lib.dcl_debug_force_valu_conv(mode)
         try:
@@ -140,7 +149,7 @@ def test_sparse_conv_matches_oracle(dcl, oracle, cin, cout, subm):
 
 
 @pytest.mark.parametrize("cin,cout,subm", [(128, 256, True), (128, 128, False), (64, 128, True), (32, 64, True)])
-def test_sparse_conv_split_k_in_launch_combine(dcl, oracle, cin, cout, subm):
+def test_sparse_conv_split_k_in_launch_combine(request, dcl, oracle, cin, cout, subm):
     """split-K launches combine their partial tiles inside the launch (last-arriver ticket per tile, partials added in split
     order): a mid-size layer (several hundred workgroups, like the backbone's deep levels at bs 32) with forced split counts
     equals the unsplit launch within the fp32 association tolerance, equals the oracle, leaves its ticket counters at zero
@@ -158,7 +167,7 @@ def test_sparse_conv_split_k_in_launch_combine(dcl, oracle, cin, cout, subm):
     tol = 2e-5 * max(1.0, np.abs(want).max())
     f, Wd = cuda(feat), cuda(W).reshape(27, cin, cout).contiguous()
     s_, t_ = cuda(rng.uniform(0.5, 1.5, cout).astype(np.float32)), cuda(rng.normal(size=cout).astype(np.float32))
-    lib = dcl._native.lib()
+    lib = enter_diag(dcl, request)      # kernel variants live in the diagnostic library only (tests/_diag)
     res = {}
     try:
         for ns in (-2, 2, 5, 8, 0):                      # -2: never split ... 0: the automatic choice
@@ -194,12 +203,12 @@ def test_sparse_conv_split_k_in_launch_combine(dcl, oracle, cin, cout, subm):
 
 
 @pytest.mark.parametrize("cin,cout", [(16, 32), (32, 64), (64, 128)])
-def test_sparse_conv_decompositions_agree_across_sizes(dcl, cin, cout):
+def test_sparse_conv_decompositions_agree_across_sizes(request, dcl, cin, cout):
     """row counts from a handful of tiles to tens of thousands of rows drive the launcher through its decompositions
     (deferred-combine few-row mode, aligned split-K, stream-K, whole tiles); every one must agree with the plain VALU
     kernel on the same rulebook, with and without the BN+ReLU epilogue"""
     rng = np.random.default_rng(cin)
-    lib = dcl._native.lib()
+    lib = enter_diag(dcl, request)      # kernel variants live in the diagnostic library only (tests/_diag)
     W = cuda((rng.normal(size=(27, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32))
     s_, t_ = cuda(rng.uniform(0.5, 1.5, cout).astype(np.float32)), cuda(rng.normal(size=cout).astype(np.float32))
     for b, S, per in ((1, 8, 130), (2, 16, 900), (6, 16, 1500), (8, 32, 5000)):
@@ -223,13 +232,13 @@ def test_sparse_conv_decompositions_agree_across_sizes(dcl, cin, cout):
 
 
 @pytest.mark.parametrize("cin,cout", [(64, 64), (128, 128), (32, 64)])
-def test_sparse_conv_used_chunk_dealing_prototype(dcl, cin, cout):
+def test_sparse_conv_used_chunk_dealing_prototype(request, dcl, cin, cout):
     """experiment hook dcl_debug_conv_balance: rows of a dilating conv sorted by which neighbour planes exist, stream-K work
     dealt in USED chunks (per-tile step masks + prefix from the host) -- same result as the VALU kernel on the same table,
     reproducible, and the hook really is off afterwards"""
     import ctypes
     rng = np.random.default_rng(cin + cout)
-    lib = dcl._native.lib()
+    lib = enter_diag(dcl, request)      # kernel variants live in the diagnostic library only (tests/_diag)
     W = cuda((rng.normal(size=(27, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32))
     idx = rand_voxels(rng, 6, 32, 4000)
     aset = dcl.ops.grid_from_indices(cuda(idx), 6, 32)
@@ -541,14 +550,14 @@ def _attn_ref(Q, K, V):
 
 
 @pytest.mark.parametrize("b,nq,nk,scale", [(2, 256, 256, 1.0), (1, 200, 500, 1.0), (3, 64, 96, 6.0), (1, 1000, 132, 0.3)])
-def test_cross_attention_matches_fp64(dcl, b, nq, nk, scale):
+def test_cross_attention_matches_fp64(request, dcl, b, nq, nk, scale):
     g = torch.Generator().manual_seed(nq + nk)
     Q = (torch.randn(b, nq, 64, generator=g) * scale).cuda()
     K = torch.randn(b, nk, 64, generator=g).cuda()
     V1 = torch.randn(b, nk, 256, generator=g).cuda()
     V2 = torch.randn(b, nk, 64, generator=g).cuda()
     want = _attn_ref(Q, K, torch.cat([V1, V2], 2))
-    lib = dcl._native.lib()
+    lib = enter_diag(dcl, request)      # kernel variants live in the diagnostic library only (tests/_diag)
     for variant in (0, 1, 2, 3, 4):            # auto, shared-tile 8-wave, register-staged 4-wave, LDS-DMA 8 / 4 waves
         O1 = torch.empty(b * nq, 256, device="cuda")
         O2 = torch.empty(b * nq, 64, device="cuda")
@@ -562,7 +571,7 @@ def test_cross_attention_matches_fp64(dcl, b, nq, nk, scale):
         assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max())), variant
 
 
-def test_cross_attention_forced_rescale(dcl):
+def test_cross_attention_forced_rescale(request, dcl):
     """spike one key against the queries late in the key axis so the running max jumps past the lazy-rescale
     threshold at a chosen tile (guide rule 26)."""
     b, nq, nk = 1, 96, 320
@@ -573,7 +582,7 @@ def test_cross_attention_forced_rescale(dcl):
     K[0, 300] = Q[0, 40] * 5.0
     V = torch.randn(b, nk, 64, generator=g)
     want = _attn_ref(Q, K, V)[0]
-    lib = dcl._native.lib()
+    lib = enter_diag(dcl, request)      # kernel variants live in the diagnostic library only (tests/_diag)
     for variant in (1, 2):
         O = torch.empty(b * nq, 64, device="cuda")
         lib.dcl_debug_attention_variant(variant)
@@ -584,7 +593,7 @@ def test_cross_attention_forced_rescale(dcl):
         assert float((O.cpu().double() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max())), variant
 
 
-def test_cross_attention_key_split(dcl):
+def test_cross_attention_key_split(request, dcl):
     """small launches split the keys over several workgroups and merge (max, sum, partial output) records: forced split
     counts, ragged key / query counts, a score spike inside one split's range"""
     b, nq, nk = 2, 200, 1000 + 13
@@ -595,7 +604,7 @@ def test_cross_attention_key_split(dcl):
     K[1, 1010] = Q[1, 199] * 6.0
     V1, V2 = torch.randn(b, nk, 256, generator=g), torch.randn(b, nk, 64, generator=g)
     want = _attn_ref(Q, K, torch.cat([V1, V2], 2))
-    lib = dcl._native.lib()
+    lib = enter_diag(dcl, request)      # kernel variants live in the diagnostic library only (tests/_diag)
     Kd, V1d, V2d = K.cuda().reshape(-1, 64), V1.cuda().reshape(-1, 256), V2.cuda().reshape(-1, 64)
     try:
         for variant in (0, 3):                     # 4-wave kernel (small launch) and the 8-wave one (badly quantised grids)
@@ -629,7 +638,7 @@ def test_cross_attention_key_split(dcl):
     assert float((got2 - want2).abs().max()) <= 2e-5 * max(1.0, float(want2.abs().max()))
 
 
-def test_cross_attention_dma_variant_ragged_and_rescale(dcl):
+def test_cross_attention_dma_variant_ragged_and_rescale(request, dcl):
     """the LDS-DMA pipeline (variant 3, DCL-Net's 256+64 channel split): key count not a multiple of 32, query count not
     a multiple of 256, and a forced late rescale"""
     b, nq, nk = 2, 300, 1000 + 13
@@ -640,7 +649,7 @@ def test_cross_attention_dma_variant_ragged_and_rescale(dcl):
     K[1, 1012] = Q[1, 299] * 6.0                      # spike in the very last (partial) tile
     V1, V2 = torch.randn(b, nk, 256, generator=g), torch.randn(b, nk, 64, generator=g)
     want = _attn_ref(Q, K, torch.cat([V1, V2], 2))
-    lib = dcl._native.lib()
+    lib = enter_diag(dcl, request)      # kernel variants live in the diagnostic library only (tests/_diag)
     O1 = torch.empty(b * nq, 256, device="cuda")
     O2 = torch.empty(b * nq, 64, device="cuda")
     lib.dcl_debug_attention_variant(3)
@@ -918,10 +927,10 @@ def test_backbone_runner_on_random_active_sets(dcl, oracle, seed):
 
 
 @pytest.mark.gpu
-def test_geometry_one_launch_mask_chain_equals_chained_launches(dcl):
+def test_geometry_one_launch_mask_chain_equals_chained_launches(request, dcl):
     """the 8 active sets of a pass from the one-workgroup-per-crop LDS chain (default on 64^3 grids) and from the 8 chained
     mask launches: same counts, same voxel rows at every level -- on the awkward sets and on a 32-crop batch"""
-    lib = dcl._native.lib()
+    lib = enter_diag(dcl, request)      # kernel variants live in the diagnostic library only (tests/_diag)
     rng = np.random.default_rng(23)
     occ_e, b_e = _edge_voxels(rng)
     data = dcl.synth.make_batch(32, 1024, 64, first=3)
@@ -945,7 +954,7 @@ def test_geometry_one_launch_mask_chain_equals_chained_launches(dcl):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("scales,unit", [((2, 4, 8, 16), 0.006), ((2, 4, 6, 8), 0.006), ((2, 4, 6, 8), 0.005)])
-def test_point_neighbours_grid_search_is_exact(dcl, scales, unit):
+def test_point_neighbours_grid_search_is_exact(request, dcl, scales, unit):
     """the grid-pruned 3-NN of the point read-out returns bit-for-bit what the per-crop scan returns -- distances, rows and
     tie order -- for surface points, lattice points (8-way ties), isolated and out-of-grid queries (scan fallback), an
     empty crop and invalid crop ids; so does the split read-out API.  Extents: the true strides (2,4,8,16) and the
@@ -974,7 +983,7 @@ def test_point_neighbours_grid_search_is_exact(dcl, scales, unit):
         q.append(np.c_[np.full(20, bi), rng.uniform(-0.5, 0.5, (20, 3))])                               # partly outside the grid
     q.append(np.c_[np.array([-1.0, b, 0.5, np.nan]), np.zeros((4, 3))])                                 # crop ids that match nothing
     pb4 = cuda(np.concatenate(q).astype(np.float32))
-    lib = dcl.ops.N.lib()
+    lib = enter_diag(dcl, request)      # kernel variants live in the diagnostic library only (tests/_diag)
     res = {}
     try:
         for mode in (0, 1, 2, 3, 4, 5):              # scan / automatic / forced fallback / 1, 4, 8 lanes per query

@@ -6,8 +6,10 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 dcl = importlib.import_module("dcl-net_amd")
+from _diag import use_diag
+DIAG = use_diag(dcl)          # kernel-variant hooks exist in the diagnostic library only
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-b = 32
+b = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 cfg = dcl.synth.default_cfg(n, 64)
 net = dcl.DCL_Net.Network(cfg, mode="test")
 net.load_state_dict(dcl.synth.synth_state_dict(net, 1))
@@ -29,6 +31,7 @@ def timeit(fn, reps=30):
     for _ in range(reps): fn()
     e.record(); torch.cuda.synchronize()
     return a.elapsed_time(e) / reps * 1e3
+print("b=%d " % b, end="")
 print("N=%d: features stage %.1f us per pass; geometry + read-back %.1f us" %
       (n, timeit(lambda: run.features(x, *f["backbone_inp_ptrs"])), timeit(geo)))
 lib = dcl._native.lib()

@@ -8,6 +8,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 dcl = importlib.import_module("dcl-net_amd")
+from _diag import use_diag
+DIAG = use_diag(dcl)          # kernel-variant hooks exist in the diagnostic library only
 ops = dcl.ops
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 12288

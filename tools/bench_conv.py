@@ -6,12 +6,14 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 dcl = importlib.import_module("dcl-net_amd")
+from _diag import use_diag
+DIAG = use_diag(dcl)          # kernel-variant hooks exist in the diagnostic library only
 ops, sp = dcl.ops, dcl.spconv.ops
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 modes = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 2, 3]
 if len(sys.argv) > 3:
     ops.N.lib().dcl_debug_conv_split(int(sys.argv[3]))
-b, S = 32, 64
+b, S = int(os.environ.get('DCL_BENCH_B', '32')), 64
 data = dcl.synth.make_batch(b, n, 64)
 occ = data["inp"]["occupied_voxels"].int().cuda().contiguous()
 aset = ops.grid_from_indices(occ, b, S)

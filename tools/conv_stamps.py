@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
 """Where a sparse-conv workgroup spends its time: runs one backbone layer on the real active sets (bs 32) with the
 diagnostic library (make -C dcl-net_amd/csrc stamps; in-kernel s_memrealtime stamps, 100 MHz ticks) and prints the average
-phase durations over the workgroups.  usage: DCL_HIP_LIB=dcl-net_amd/libdclnet_hip_stamps.so tools/conv_stamps.py [level 0-3] [conv|subm] [split]"""
+phase durations over the workgroups.  usage: DCL_HIP_LIB=tests/_diag/libdclnet_hip_stamps.so tools/conv_stamps.py [level 0-3] [conv|subm] [split]"""
 import ctypes, importlib, os, sys
 import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 dcl = importlib.import_module("dcl-net_amd")
+from _diag import use_diag
+DIAG = use_diag(dcl)          # kernel-variant hooks exist in the diagnostic library only
 ops, sp = dcl.ops, dcl.spconv.ops
 level = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 which = sys.argv[2] if len(sys.argv) > 2 else "subm"

@@ -2,6 +2,8 @@ import importlib, os, sys
 import torch
 sys.path.insert(0, "/root/repo" if os.path.isdir("/root/repo/tools") else ".")
 dcl = importlib.import_module("dcl-net_amd")
+from _diag import use_diag
+DIAG = use_diag(dcl)          # kernel-variant hooks exist in the diagnostic library only
 ops, sp = dcl.ops, dcl.spconv.ops
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 b, S = 32, 64

@@ -5,6 +5,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 dcl = importlib.import_module("dcl-net_amd")
+from _diag import use_diag
+DIAG = use_diag(dcl)          # kernel-variant hooks exist in the diagnostic library only
 lib = dcl.ops.N.lib()
 B, N, NP, NS, C = 32, 12288, 2048, 64, 64
 feats = torch.randn(B, C, N, device="cuda")
