@@ -389,6 +389,82 @@ def sparse_conv_roofline(dcl, net, data, dev, steps=3):
             "pairs_per_forward": int(sum(p[5] for p in per_layer))}
 
 
+def collective_report(distributed, rank, world, mine):
+    """what the collective library saw, gathered from every rank (outside the timed region): world size and backend as
+    torch.distributed reports them (not WORLD_SIZE echoed), and per rank its device and the host cores it is pinned to"""
+    if not distributed:
+        return {"world": 1, "backend": None, "initialized": False, "device_per_rank": [mine["device"]],
+                "device_name": mine.get("name"), "cpus_per_rank": [_cpu_ranges(mine["cpus"])]}
+    per = [None] * dist.get_world_size()
+    dist.all_gather_object(per, dict(mine, rank=rank))
+    per.sort(key=lambda d: d["rank"])
+    return {"world": dist.get_world_size(), "backend": dist.get_backend(), "initialized": True,
+            "device_per_rank": [d["device"] for d in per], "device_name": per[0].get("name"),
+            "cpus_per_rank": [_cpu_ranges(d["cpus"]) for d in per]}
+
+
+def _cpu_ranges(cpus):
+    out, cpus = [], sorted(cpus)
+    i = 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        out.append(str(cpus[i]) if i == j else "%d-%d" % (cpus[i], cpus[j]))
+        i = j + 1
+    return ",".join(out)
+
+
+def dry_run(args, rank, local_rank, world, cpus):
+    """`--dry-run`: the N-rank plumbing of this script WITHOUT a GPU (tests/test_host.py runs it under torch.distributed.run
+    with 2 processes): rank / world from the launcher, host-core placement, a gloo group, the barrier-bracketed timing loop
+    with the max over ranks, disjoint crops per rank, the exact metric reduction -- around an EMPTY step (no forward runs:
+    the product path needs the GPU and there is no CPU fallback), so `value` is null and the line says "dry_run": true."""
+    dcl = importlib.import_module("dcl-net_amd")
+    distributed = world > 1
+    if distributed:
+        dist.init_process_group("gloo")
+    b = args.batch
+    n_inp, n_tmp = SHAPES[args.shape] if args.shape in SHAPES else SHAPES["ref"]
+    n_inp, n_tmp = min(n_inp, 64), min(n_tmp, 64)              # tiny crops: only their class ids / poses are used
+    host_data = dcl.synth.make_batch(b, n_inp, n_tmp, first=rank * b, voxelize_idx=lambda c, bs, mode: (
+        torch.zeros((1, 4), dtype=torch.int64), torch.zeros(c.shape[0], dtype=torch.int32), torch.zeros((1, 2), dtype=torch.int32)))
+    if distributed:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass                                                   # the step: nothing (see above)
+    if distributed:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    table = dcl.sharding.AddsTable()
+    for i, c in enumerate(host_data["obj_idx"].tolist()):      # a deterministic stand-in distance per crop
+        table.add(int(c), 0.001 * ((rank * b + i) % 97))
+    table.reduce()
+    auc, _, _, _ = table.finalize()
+    assert int(table.sums[:, 0].sum()) == world * b, "metric reduction lost frames"
+    rccl = collective_report(distributed, rank, world, {"device": "cpu (dry run; cuda:%d on a GPU box)" % local_rank,
+                                                        "name": None, "cpus": cpus})
+    line = {"metric": "frames/sec DCL_Net.forward @ YCB-V bs32", "value": None, "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
+            "config": {"workload": "dry run of the rank plumbing (no forward)", "global_batch": world * b,
+                       "frames_per_step_per_gpu": b, "parallelism": "frames sharded x%d" % world},
+            "loop_seconds_max_over_ranks": dt, "adds_auc_stand_in": auc,
+            "metric_frames_reduced": int(table.sums[:, 0].sum()), "rccl": rccl}
+    if distributed:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     _flush_c_stdio(unbuffer=True)
     ap = argparse.ArgumentParser()
@@ -403,6 +479,9 @@ def main():
     ap.add_argument("--no-traffic", action="store_true", help="skip the in-run PMC passes behind roofline.traffic")
     ap.add_argument("--pmc-child", action="store_true",
                     help="(internal) one warm-up + one forward of the workload and exit: the body of the PMC passes")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: the launcher / rank / affinity / sharding / metric-reduction plumbing over gloo with an "
+                         "empty step; prints the same JSON line with \"dry_run\": true and no rate (CPU test of the N > 1 path)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.pmc_child:
@@ -417,6 +496,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = world > 1 or os.environ.get("DCL_FORCE_DIST") == "1"     # the latter: exercise the RCCL path on 1 GPU
+    # one process per GPU: before anything touches the GPU, every rank moves onto the host cores of its GPU's NUMA node
+    # (KFD topology in sysfs; an even split of the allowed cores if that cannot be read) -- sharding.rank_cpu_set
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    cpus = importlib.import_module("dcl-net_amd").sharding.pin_rank_to_gpu_numa(local_rank, local_world)
+    if args.dry_run:
+        return dry_run(args, rank, local_rank, world, cpus)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
@@ -484,6 +569,8 @@ def main():
     table.reduce(device=dev)
     auc, acc2, _, _ = table.finalize()
     assert int(table.sums[:, 0].sum()) == world * b, "metric reduction lost frames"
+    rccl = collective_report(distributed, rank, world, {"device": "cuda:%d" % local_rank,
+                                                        "name": torch.cuda.get_device_name(dev), "cpus": cpus})
 
     line = {"metric": "frames/sec DCL_Net.forward @ YCB-V bs32", "value": round(value, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -496,7 +583,7 @@ def main():
                        "path": "whole-forward hipGraph replay" if graphed else "launch by launch"},
             "roofline": roofline,
             "whole_forward": whole_forward_rate(n_inp, n_tmp, b, dt / args.steps),
-            "adds_auc_synthetic_weights": auc, "metric_frames_reduced": int(table.sums[:, 0].sum())}
+            "adds_auc_synthetic_weights": auc, "metric_frames_reduced": int(table.sums[:, 0].sum()), "rccl": rccl}
     rdata_for_pipe = None
     if rank == 0 and world == 1 and not args.no_extras:
         line["roofline_sparse_conv"] = {args.shape: sparse_conv_roofline(dcl, net_l, data, dev)}

@@ -128,3 +128,91 @@ class AddsTable(object):
             auc = np.where(n > 0, 100.0 * (10.0 / np.maximum(n, 1)) * (MAX_DIS * m - (sd - self.maxd)), 0.0)
             acc = np.where(n > 0, 100.0 * c2 / np.maximum(n, 1), 0.0)
         return round(float(np.mean(auc)), 2), round(float(np.mean(acc)), 2), auc, acc
+
+
+# ------------------------------------------------------------------------------------------ rank placement on the host
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_numa_nodes(sysfs_root="/sys"):
+    """NUMA node of every GPU in KFD enumeration order (= HIP device order unless *_VISIBLE_DEVICES reorders), read from the
+    KFD topology in sysfs -- no HIP call, so it can run before the process touches a GPU.  A GPU node is a topology node
+    with simd_count > 0; its NUMA node is the CPU node at the other end of its cheapest io_link.  [] if there is no KFD."""
+    import os
+    base = os.path.join(sysfs_root, "class", "kfd", "kfd", "topology", "nodes")
+    if not os.path.isdir(base):
+        return []
+
+    def props(path):
+        out = {}
+        try:
+            for line in open(path):
+                k, _, v = line.strip().partition(" ")
+                out[k] = v
+        except OSError:
+            pass
+        return out
+    nodes = sorted((int(d) for d in os.listdir(base) if d.isdigit()))
+    info = {n: props(os.path.join(base, str(n), "properties")) for n in nodes}
+    cpu_nodes = [n for n in nodes if int(info[n].get("cpu_cores_count", "0") or 0) > 0]
+    numa = []
+    for n in nodes:
+        if int(info[n].get("simd_count", "0") or 0) <= 0:
+            continue
+        best, best_w = (cpu_nodes[0] if cpu_nodes else 0), None
+        links = os.path.join(base, str(n), "io_links")
+        if os.path.isdir(links):
+            for l in sorted(os.listdir(links)):
+                p = props(os.path.join(links, l, "properties"))
+                to, w = int(p.get("node_to", "-1") or -1), int(p.get("weight", "0") or 0)
+                if to in cpu_nodes and (best_w is None or w < best_w):
+                    best, best_w = to, w
+        numa.append(cpu_nodes.index(best) if best in cpu_nodes else 0)
+    return numa
+
+
+def rank_cpu_set(local_rank, local_world, allowed=None, sysfs_root="/sys"):
+    """the host cores rank `local_rank` of `local_world` ranks on this node should run on: the cores of its GPU's NUMA node
+    (inside the process's allowed set), divided evenly among the ranks whose GPUs share that node -- with one process per GPU
+    and a per-call host read-back on the launch-by-launch path, eight ranks hopping over 2 sockets become launch-bound
+    otherwise.  Falls back to an even split of the allowed cores when the topology cannot be read.  Pure function."""
+    import os
+    if allowed is None:
+        allowed = os.sched_getaffinity(0)
+    allowed = sorted(allowed)
+    numa = gpu_numa_nodes(sysfs_root)
+    peers, mine = list(range(local_world)), allowed
+    if len(numa) >= local_world and local_world > 0:
+        node = numa[local_rank]
+        try:
+            cpus = _parse_cpulist(open(os.path.join(sysfs_root, "devices", "system", "node", "node%d" % node, "cpulist")).read())
+        except OSError:
+            cpus = set()
+        on_node = [c for c in allowed if c in cpus]
+        if on_node:
+            mine = on_node
+            peers = [r for r in range(local_world) if numa[r] == node]
+    k, i = len(peers), peers.index(local_rank) if local_rank in peers else 0
+    per = max(1, len(mine) // max(k, 1))
+    chunk = mine[i * per:(i + 1) * per] if i * per < len(mine) else mine
+    return set(chunk or mine)
+
+
+def pin_rank_to_gpu_numa(local_rank, local_world, sysfs_root="/sys"):
+    """call BEFORE the first GPU call of a rank (bench.py does): sets the process's CPU affinity to rank_cpu_set(...).
+    Returns the sorted core list in effect (what the bench line reports per rank)."""
+    import os
+    try:
+        cpus = rank_cpu_set(local_rank, local_world, sysfs_root=sysfs_root)
+        if local_world > 1:
+            os.sched_setaffinity(0, cpus)
+    except OSError:
+        pass
+    return sorted(os.sched_getaffinity(0))

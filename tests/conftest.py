@@ -58,3 +58,20 @@ def load_golden_data(path):
         data["flags"] = torch.from_numpy(exp["flags"])
         data["labels"] = {"rot_gt": torch.from_numpy(exp["rot_gt"]), "trans_gt": torch.from_numpy(exp["trans_gt"])}
     return data, exp, (b, n_inp, n_tmp, wseed)
+
+
+def load_stress_golden(dcl, path, voxelize_idx=None):
+    """tests/golden/dclnet_stress_b1.npz: ONE crop of BASELINE configs[1]'s shape run through the reference's own Network
+    (make_golden.py stress).  The inputs are procedural -- regenerated here and checked against the fixture's checksums."""
+    import torch
+    z = np.load(path)
+    b, n_inp, n_tmp, wseed, first = [int(v) for v in z["meta"]]
+    data = dcl.synth.make_batch(b, n_inp, n_tmp, first=first, voxelize_idx=voxelize_idx)
+    for side in ("inp", "tmp"):
+        chk = z["%s_check" % side]
+        d = data[side]
+        got = [float(d["feats"].double().sum()), float(d["occupied_voxels"].double().sum()), float(d["v2p_maps"].double().sum()),
+               d["occupied_voxels"].shape[0], d["v2p_maps"].shape[1]]
+        assert np.allclose(got, chk, rtol=0, atol=1e-6 * max(1.0, abs(chk[0]))), (side, got, chk)
+    exp = {k: z[k] for k in ("trans_pred", "rot_pred", "conf", "F_Xo_p_sub", "F_Xo_p_sum")}
+    return data, exp, (b, n_inp, n_tmp, wseed)

@@ -11,7 +11,7 @@ against these vectors; the GPU parity tests check the HIP path against both.
 
     python tests/golden/make_golden.py        # rewrites tests/golden/dclnet_b2_n256.npz, refiner_b2.npz,
                                               # dclnet_s0_train.npz, dclnet_nm384_train.npz,
-                                              # dclnet_b4_n1024_chain.npz
+                                              # dclnet_b4_n1024_chain.npz, dclnet_stress_b1.npz
 """
 import importlib
 import os
@@ -245,6 +245,7 @@ def main():
         np.savez_compressed(os.path.join(ROOT, "tests", "golden", "dclnet_%s_train.npz" % tag), **out2)
         print("golden written: dclnet_%s_train.npz" % tag, out2.get("losses"), out2.get("loss_refiner"))
     chain_golden(ref_net_mod, ref_refiner_mod)
+    stress_golden(ref_net_mod)
 
 
 def chain_golden(ref_net_mod, ref_refiner_mod):
@@ -302,8 +303,39 @@ def chain_golden(ref_net_mod, ref_refiner_mod):
     print("golden written: dclnet_b4_n1024_chain.npz  ADD-S stage1", adds[0].numpy(), "final", adds[1].numpy())
 
 
+def stress_golden(ref_net_mod):
+    """ONE crop of BASELINE configs[1]'s shape (N = 12288 observed / M = 2048 template points, 6 mm voxels) through the
+    reference's own test-mode Network (the stress shape was only checked against oracle/graph.py).  The
+    inputs are the procedural crop `synth.make_batch(1, 12288, 2048, first=3)` -- regenerated by the tests, pinned here by
+    a checksum instead of 0.5 MB of points -- so the fixture holds outputs only."""
+    b, n_inp, n_tmp, first = 1, 12288, 2048, 3
+    cfg = dcl.synth.default_cfg(n_inp, n_tmp)
+    ref = ref_net_mod.Network(attr(dict(cfg)), mode="test")
+    ref.load_state_dict(dcl.synth.synth_state_dict(ref, seed=1))
+    ref.eval()
+    data = dcl.synth.make_batch(b, n_inp, n_tmp, first=first, voxelize_idx=lambda c, bs, mode: tuple(
+        torch.from_numpy(a) for a in K.voxelize_idx(c.numpy(), bs, mode)))
+    inputs = clone_data(data)
+    with torch.no_grad():
+        pred = ref(data)
+    out = {"trans_pred": pred["trans_pred"].numpy(), "rot_pred": pred["rot_pred"].numpy(), "conf": pred["conf"].numpy(),
+           "F_Xo_p_sub": pred["F_Xo_p"][:, ::8, ::64].contiguous().numpy(),
+           "F_Xo_p_sum": pred["F_Xo_p"].double().sum(dim=2).numpy(),
+           "meta": np.array([b, n_inp, n_tmp, 1, first], np.int64)}
+    for side in ("inp", "tmp"):                                # input checksums (float64 sums / integer sums) + sizes
+        out["%s_check" % side] = np.array([float(inputs[side]["feats"].double().sum()),
+                                           float(inputs[side]["occupied_voxels"].double().sum()),
+                                           float(inputs[side]["v2p_maps"].double().sum()),
+                                           inputs[side]["occupied_voxels"].shape[0], inputs[side]["v2p_maps"].shape[1]])
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "dclnet_stress_b1.npz"), **out)
+    print("golden written: dclnet_stress_b1.npz", out["trans_pred"], out["inp_check"], out["tmp_check"])
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "chain":           # only the N=M=1024 / stage-2 chain fixture
+    if len(sys.argv) > 1 and sys.argv[1] == "stress":          # only the one-crop stress-shape fixture
+        install_stubs()
+        stress_golden(importlib.import_module("models.DCL_Net"))
+    elif len(sys.argv) > 1 and sys.argv[1] == "chain":           # only the N=M=1024 / stage-2 chain fixture
         install_stubs()
         chain_golden(importlib.import_module("models.DCL_Net"), importlib.import_module("models.refiner"))
     else:

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden_data
+from conftest import load_golden_data, load_stress_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -44,6 +44,23 @@ def test_forward_matches_reference_golden(dcl, golden_dir, fused):
         1.0, np.abs(exp["F_Xo_p_sum"]).max())
     assert tuple(data["labels"]["points_inp"].shape) == (b, n_inp, 3)
     assert tuple(data["labels"]["points_tmp"].shape) == (b, n_tmp, 3)
+
+
+@pytest.mark.parametrize("graph_max_batch", [0, 8])
+def test_forward_matches_reference_golden_at_the_stress_shape(dcl, golden_dir, graph_max_batch):
+    """ONE crop of BASELINE configs[1]'s shape (N = 12288 / M = 2048) against the reference's own Network run on the same
+    procedural crop (tests/golden/dclnet_stress_b1.npz), launch by launch and as the default one-crop graph replay"""
+    data, exp, (b, n_inp, n_tmp, wseed) = load_stress_golden(dcl, os.path.join(golden_dir, "dclnet_stress_b1.npz"))
+    net, _, _ = _net(dcl, n_inp, n_tmp, wseed, graph_max_batch=graph_max_batch)
+    with torch.no_grad():
+        pred = net(data)
+    _check(pred, exp["rot_pred"], exp["trans_pred"], exp["conf"])
+    F = pred["F_Xo_p"]
+    assert tuple(F.shape) == (b, 256, n_inp)
+    sub = F[:, ::8, ::64].cpu().numpy()
+    assert np.abs(sub - exp["F_Xo_p_sub"]).max() <= 1e-4 * max(1.0, np.abs(exp["F_Xo_p_sub"]).max())
+    assert np.abs(F.double().sum(dim=2).cpu().numpy() - exp["F_Xo_p_sum"]).max() <= 1e-3 * max(
+        1.0, np.abs(exp["F_Xo_p_sum"]).max())
 
 
 @pytest.mark.parametrize("fixture", ["dclnet_s0_train.npz", "dclnet_nm384_train.npz"])

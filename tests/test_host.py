@@ -264,3 +264,69 @@ def test_graph_routing_rule(dcl):
     assert [mk(1024, 1024, async_inputs=True).replays_graph(b) for b in (1, 8, 9, 32)] == [True, True, False, False]
     assert not any(mk(1024, 1024, graph_max_batch=0).replays_graph(b) for b in (1, 8, 32))
     assert [mk(1024, 1024, graph_max_batch=4, graph_max_points=0).replays_graph(b) for b in (4, 5)] == [True, False]
+
+
+def test_bench_two_rank_dry_run_line(tmp_path):
+    """bench.py's N > 1 plumbing under the driver's own launcher, on the CPU (gloo, --dry-run: empty step):
+    one JSON line from rank 0, last on stdout, with what torch.distributed saw -- world, backend, one device and one
+    disjoint host-core set per rank -- and a metric reduction that lost no frames."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--dry-run", "--no-extras", "--shape", "ref", "--batch", "4"]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = [l for l in r.stdout.strip().splitlines() if l.strip()][-1]
+    line = json.loads(last)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "rccl", "metric_frames_reduced"):
+        assert k in line, k
+    assert line["dry_run"] is True and line["value"] is None          # no rate is claimed without a GPU
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["metric_frames_reduced"] == 2 * 4
+    rc = line["rccl"]
+    assert rc["world"] == 2 and rc["backend"] == "gloo" and rc["initialized"] is True
+    assert len(rc["device_per_rank"]) == 2 and "cuda:0" in rc["device_per_rank"][0] and "cuda:1" in rc["device_per_rank"][1]
+    sets = [set(dcl_cpus(c)) for c in rc["cpus_per_rank"]]
+    assert all(sets) and not (sets[0] & sets[1]), "ranks must be pinned to disjoint host cores"
+
+
+def dcl_cpus(text):
+    out = []
+    for part in text.split(","):
+        lo, _, hi = part.partition("-")
+        out += list(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def test_rank_cpu_sets_follow_the_gpu_numa_topology(dcl, tmp_path):
+    """sharding.rank_cpu_set on a fake sysfs: 4 GPUs on 2 NUMA nodes -> every rank inside its GPU's node, peers on a node
+    split it evenly, nothing shared"""
+    base = tmp_path / "class" / "kfd" / "kfd" / "topology" / "nodes"
+    def node(i, cpu_cores, simd, links=()):
+        d = base / str(i)
+        (d / "io_links").mkdir(parents=True)
+        (d / "properties").write_text("cpu_cores_count %d\nsimd_count %d\n" % (cpu_cores, simd))
+        for j, (to, w) in enumerate(links):
+            (d / "io_links" / str(j)).mkdir()
+            (d / "io_links" / str(j) / "properties").write_text("node_from %d\nnode_to %d\nweight %d\n" % (i, to, w))
+    node(0, 8, 0); node(1, 8, 0)
+    node(2, 0, 1024, [(0, 20), (1, 40)]); node(3, 0, 1024, [(0, 20)]); node(4, 0, 1024, [(1, 20), (0, 40)]); node(5, 0, 1024, [(1, 20)])
+    for n, cl in ((0, "0-7"), (1, "8-15")):
+        d = tmp_path / "devices" / "system" / "node" / ("node%d" % n)
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(cl + "\n")
+    S = dcl.sharding
+    assert S.gpu_numa_nodes(str(tmp_path)) == [0, 0, 1, 1]
+    sets = [S.rank_cpu_set(r, 4, allowed=set(range(16)), sysfs_root=str(tmp_path)) for r in range(4)]
+    assert sets == [{0, 1, 2, 3}, {4, 5, 6, 7}, {8, 9, 10, 11}, {12, 13, 14, 15}]
+    # a cgroup that grants only part of a node, and a host without KFD: even split of what is allowed
+    assert S.rank_cpu_set(1, 4, allowed={0, 1, 8, 9, 10, 11}, sysfs_root=str(tmp_path)) == {1}
+    assert S.rank_cpu_set(1, 2, allowed=set(range(8)), sysfs_root=str(tmp_path / "nowhere")) == {4, 5, 6, 7}

@@ -5,7 +5,7 @@ import os
 import numpy as np
 import torch
 
-from conftest import load_golden_data
+from conftest import load_golden_data, load_stress_golden
 from oracle import graph as G
 
 
@@ -27,6 +27,20 @@ def test_forward_matches_reference_graph(dcl, oracle, golden_dir):
     got_sub = pred["F_Xo_p"][:, ::8, ::8].numpy()
     assert np.abs(got_sub - ref_sub).max() <= 1e-4 * max(1.0, np.abs(ref_sub).max())
     assert data["labels"]["points_inp"].shape == (b, n_inp, 3) and data["labels"]["points_tmp"].shape == (b, n_tmp, 3)
+
+
+def test_forward_matches_reference_graph_at_the_stress_shape(dcl, oracle, golden_dir):
+    """one crop of BASELINE configs[1] (N = 12288, M = 2048): oracle/graph.py against the reference's own Network"""
+    vox = lambda c, bs, mode: tuple(torch.from_numpy(a) for a in oracle.voxelize_idx(c.numpy(), bs, mode))   # noqa: E731
+    data, exp, (b, n_inp, n_tmp, wseed) = load_stress_golden(dcl, os.path.join(golden_dir, "dclnet_stress_b1.npz"), vox)
+    cfg = dcl.synth.default_cfg(n_inp, n_tmp)
+    sd = _state(dcl, cfg, wseed, dcl.DCL_Net.Network)
+    pred = G.forward(sd, dict(cfg), data, mode="test")
+    assert np.abs(pred["rot_pred"].numpy() - exp["rot_pred"]).max() <= 1e-4
+    assert np.abs(pred["trans_pred"].numpy() - exp["trans_pred"]).max() <= 1e-5
+    assert np.abs(pred["conf"].numpy() - exp["conf"]).max() <= 1e-5
+    sub = pred["F_Xo_p"][:, ::8, ::64].numpy()
+    assert np.abs(sub - exp["F_Xo_p_sub"]).max() <= 1e-4 * max(1.0, np.abs(exp["F_Xo_p_sub"]).max())
 
 
 def test_synth_inputs_are_reproducible(dcl, oracle, golden_dir):
