@@ -7,6 +7,7 @@
 // Row-major y[M x N] = x[M x K] Wt[K x N] is the column-major product Y'[N x M] = W'[N x K] X'[K x M] of the same
 // buffers (ld = row pitch), so no transposes are requested; the bias runs along the rows of Y' (= output channels).
 #include <hipblaslt/hipblaslt.h>
+#include <hipblaslt/hipblaslt-version.h>
 
 #include <mutex>
 #include <unordered_map>
@@ -19,14 +20,16 @@ struct PlanKey {
   int64_t M, N, K, ldx, ldw, ldy;
   int epilogue;
   int64_t ws;
+  int device;                          // plans (heuristics) belong to the device whose handle produced them
   bool operator==(const PlanKey &o) const {
-    return M == o.M && N == o.N && K == o.K && ldx == o.ldx && ldw == o.ldw && ldy == o.ldy && epilogue == o.epilogue && ws == o.ws;
+    return M == o.M && N == o.N && K == o.K && ldx == o.ldx && ldw == o.ldw && ldy == o.ldy && epilogue == o.epilogue &&
+           ws == o.ws && device == o.device;
   }
 };
 struct PlanKeyHash {
   size_t operator()(const PlanKey &k) const {
     size_t h = 1469598103934665603ull;
-    for (int64_t v : {k.M, k.N, k.K, k.ldx, k.ldw, k.ldy, (int64_t)k.epilogue, k.ws}) h = (h ^ (size_t)v) * 1099511628211ull;
+    for (int64_t v : {k.M, k.N, k.K, k.ldx, k.ldw, k.ldy, (int64_t)k.epilogue, k.ws, (int64_t)k.device}) h = (h ^ (size_t)v) * 1099511628211ull;
     return h;
   }
 };
@@ -38,8 +41,9 @@ struct Plan {
 };
 
 std::mutex g_mu;
-hipblasLtHandle_t g_handle = nullptr;
+std::unordered_map<int, hipblasLtHandle_t> g_handles;    // one handle per device (created with that device current)
 std::unordered_map<PlanKey, Plan, PlanKeyHash> g_plans;
+bool g_version_checked = false;
 
 #define LT_CHECK(call)                                                                                   \
   do {                                                                                                   \
@@ -50,13 +54,38 @@ std::unordered_map<PlanKey, Plan, PlanKeyHash> g_plans;
     }                                                                                                    \
   } while (0)
 
-int get_plan(const PlanKey &key, Plan **out) {
+// the handle of the CURRENT device (a process may drive several GPUs; the library binds a handle to the device that was
+// current when it was created)
+int get_handle(int device, hipblasLtHandle_t *out) {
+  auto it = g_handles.find(device);
+  if (it == g_handles.end()) {
+    hipblasLtHandle_t h = nullptr;
+    LT_CHECK(hipblasLtCreate(&h));
+    if (!g_version_checked) {
+      // compiled against the system ROCm's hipBLASLt headers (by-value hipblasLtMatmulAlgo_t, epilogue enums); at run time
+      // the soname binds to the copy the process has already mapped (PyTorch's).  Minor versions have proved layout-
+      // compatible; another MAJOR version is refused loudly (the version word is major * 100000 or * 10000 + ...)
+      int ver = 0;
+      if (hipblasLtGetVersion(h, &ver) == HIPBLAS_STATUS_SUCCESS && ver > 0 && ver / 100000 != HIPBLASLT_VERSION_MAJOR &&
+          ver / 10000 != HIPBLASLT_VERSION_MAJOR) {
+        dcl_set_error("dcl_linear_fwd: hipBLASLt version word %d at run time, headers are %d.%d.%d: rebuild against it", ver,
+                      HIPBLASLT_VERSION_MAJOR, HIPBLASLT_VERSION_MINOR, HIPBLASLT_VERSION_PATCH);
+        return DCL_EINVAL;
+      }
+      g_version_checked = true;
+    }
+    it = g_handles.emplace(device, h).first;
+  }
+  *out = it->second;
+  return 0;
+}
+
+int get_plan(const PlanKey &key, hipblasLtHandle_t g_handle, Plan **out) {
   auto it = g_plans.find(key);
   if (it != g_plans.end()) {
     *out = &it->second;
     return 0;
   }
-  if (!g_handle) LT_CHECK(hipblasLtCreate(&g_handle));
   Plan p;
   LT_CHECK(hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F));
   const int32_t opn = HIPBLAS_OP_N;
@@ -103,8 +132,16 @@ DCL_API int dcl_linear_fwd(const float *x, int64_t ldx, const float *Wt, int64_t
   else if (bias) epilogue = HIPBLASLT_EPILOGUE_BIAS;
   else if (relu) epilogue = HIPBLASLT_EPILOGUE_RELU;
   std::lock_guard<std::mutex> lock(g_mu);                  // plans and the descriptor's bias pointer are shared state
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) {
+    dcl_set_error("dcl_linear_fwd: hipGetDevice failed");
+    return DCL_EINVAL;
+  }
+  hipblasLtHandle_t g_handle = nullptr;
+  int rc = get_handle(device, &g_handle);
+  if (rc) return rc;
   Plan *p = nullptr;
-  int rc = get_plan(PlanKey{M, N, K, ldx, ldw, ldy, epilogue, workspace_bytes}, &p);
+  rc = get_plan(PlanKey{M, N, K, ldx, ldw, ldy, epilogue, workspace_bytes, device}, g_handle, &p);
   if (rc) return rc;
   if (bias) LT_CHECK(hipblasLtMatmulDescSetAttribute(p->desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)));
   const float one = 1.0f, zero = 0.0f;

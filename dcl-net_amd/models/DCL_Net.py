@@ -122,6 +122,7 @@ class Network(nn.Module):
         """folded weights and captured graphs (which have the folded tensors' addresses baked in) follow the parameters"""
         self._folded = None
         self.__dict__.pop("_graphs", None)
+        self.__dict__.pop("_graph_seen", None)
         self.__dict__.pop("_vlist", None)
 
     def train(self, mode=True):
@@ -139,7 +140,7 @@ class Network(nn.Module):
     def __getstate__(self):
         """copy.deepcopy / pickling: streams, graphs and folded tensors are per-instance runtime state"""
         state = dict(self.__dict__)
-        for k in ("_side", "_graphs", "_crop_id_cache", "_vlist", "_counts_host"):
+        for k in ("_side", "_graphs", "_graph_seen", "_crop_id_cache", "_vlist", "_counts_host"):
             state.pop(k, None)
         state["_folded"] = None
         return state
@@ -366,6 +367,7 @@ class Network(nn.Module):
 
     _DIS_TAGS = (("p1", 256), ("m1", 64), ("p2", 256), ("m2", 64))
     MAX_GRAPHS = 8            # captured whole-forward graphs kept per instance (one per batch size; least recently used goes)
+    GRAPH_ADMIT = 3           # with a full cache, a new batch size is captured (evicting the LRU one) on its 3rd call
 
     def _disengage_buffers(self, side, rows, dev):
         """outputs of a side's four disengage stacks.  Two of them are one half of a later concatenation -- cat[F_Xc_p1,
@@ -482,8 +484,12 @@ class Network(nn.Module):
                 cache.pop(next(iter(cache)))                                 # least recently used
             ent = self._capture(f, dev, b, S, {s: max(32, 2 * need_ma[s]) for s in ("inp", "tmp")})
         cache[key] = ent
-        on_dev = all(data[s][k].is_cuda for s in ("inp", "tmp") for k in ("feats", "v2p_maps", "occupied_voxels")) and \
-            all(data[s]["feats"].dtype == torch.float32 and data[s]["v2p_maps"].dtype == torch.int32 for s in ("inp", "tmp"))
+        # resident inputs go through ops.pad_copy_many, which wants dense 2-D rows of 4-byte elements (int64 voxel rows are
+        # narrowed); anything else -- host tensors, column slices, other dtypes -- takes the copy_() staging below
+        def stageable(t, dtypes):
+            return t.is_cuda and t.dim() == 2 and t.stride(1) == 1 and t.dtype in dtypes
+        on_dev = all(stageable(data[s]["feats"], (torch.float32,)) and stageable(data[s]["v2p_maps"], (torch.int32,)) and
+                     stageable(data[s]["occupied_voxels"], (torch.int32, torch.int64)) for s in ("inp", "tmp"))
         if on_dev:                                     # resident inputs: all eight staging copies / fills in one launch
             jobs = []
             for s in ("inp", "tmp"):
@@ -543,8 +549,14 @@ class Network(nn.Module):
             st["tmpbuf"] = torch.empty(st["run"].tmp_bytes(b * n), dtype=torch.uint8, device=dev)
             st["bid"] = torch.arange(b, device=dev, dtype=torch.float32).repeat_interleave(n).unsqueeze(1)
             ent[s] = st
+        # the graph's own GEMM scratch, one per branch, allocated before warm-up and capture (ops.lt_workspace_scope)
+        ent["lt_ws"] = tuple(torch.empty(ops._LT_WORKSPACE_BYTES, dtype=torch.uint8, device=dev) for _ in range(2))
 
         def body():
+            with ops.lt_workspace_scope(ent["lt_ws"][0], ent["lt_ws"][1], self._side_stream(dev)):
+                return body_()
+
+        def body_():
             # Two parallel branches in the graph, one per side.  The eager path also runs each side's 3-NN searches on a
             # helper stream beside its convolutions; in a graph that does not pay (bare replay at b=1: 1.04 ms with two
             # branches, 1.22 ms with four -- every cross-branch edge costs a barrier packet), and ROCm 7.2 crashes in
@@ -657,6 +669,25 @@ class Network(nn.Module):
         data["labels"]["points_inp"] = points_inp
         return prediction
 
+    def _admit_graph(self, b, data):
+        """Eval loops whose crop count varies per image (YCB-V test: 1 to 9+ objects) can cycle through more batch sizes than
+        the cache holds; recapturing on every call (two warm-up forwards + a capture each) would be far slower than launch
+        by launch.  So with a FULL cache a new size is only admitted (evicting the least recently used one) once it has been
+        seen GRAPH_ADMIT times; until then its calls go launch by launch."""
+        S = int(np.asarray(data["voxel_num_limit"]).astype(np.int64)[0])
+        key = (b, self.n_inp, self.n_tmp, S)
+        cache = self.__dict__.setdefault("_graphs", {})
+        if key in cache or len(cache) < self.MAX_GRAPHS:
+            return True
+        seen = self.__dict__.setdefault("_graph_seen", {})
+        if len(seen) > 64:
+            seen.clear()
+        seen[key] = seen.get(key, 0) + 1
+        if seen[key] >= self.GRAPH_ADMIT:
+            del seen[key]
+            return True
+        return False
+
     def replays_graph(self, b):
         """routing rule of eval-mode calls (see __init__): True = a call of b crops replays its whole-forward hipGraph"""
         if self.graph_max_batch <= 0 or b <= 0:
@@ -669,7 +700,8 @@ class Network(nn.Module):
         """eval(): the fused inference pipeline -- outputs carry no autograd graph, whether or not the caller wrapped the call
         in torch.no_grad() (tools/test_LM.py:110 does not).  train() (or fused=False): the module path, differentiable."""
         if self.fused and not self.training:
-            if self.replays_graph(int(data["batch_offsets"].size(0)) - 1):
+            b = int(data["batch_offsets"].size(0)) - 1
+            if self.replays_graph(b) and self._admit_graph(b, data):
                 return self.forward_graphed(data)
             with torch.no_grad():
                 return self._forward_fused(data)

@@ -5,6 +5,7 @@ arguments the way the reference's Python wrappers do (contiguity, dtypes) and ca
 library on torch's current stream.  No function here has a CPU fallback.
 """
 import ctypes as C
+import threading
 
 import torch
 
@@ -662,14 +663,46 @@ def pose_heads(pooled, rot_layers, trans_layers):
 
 _LT_WORKSPACES = {}            # (device index, stream handle) -> uint8 scratch the GEMM library may use on that stream
 _LT_WORKSPACE_BYTES = 32 << 20
+_LT_WORKSPACES_MAX = 8         # eager scratches kept per process (long-lived streams only: captures bring their own, below)
+_LT_SCOPE = threading.local()
+
+
+class lt_workspace_scope(object):
+    """GEMM scratch of a captured forward.  A whole-forward hipGraph owns its scratch: `main_ws` for the branch on the
+    capturing stream, `side_ws` for the branch on `side_stream` -- allocated by the caller BEFORE the warm-up runs and the
+    capture, and named explicitly here, so that (i) warm-up and capture query the library with the same workspace size
+    (same plans, same rounding as the eager path), (ii) no scratch is baked into two graphs (two graphs replayed on
+    different streams would share it unsynchronised) and (iii) nothing is left behind per warm-up stream."""
+
+    def __init__(self, main_ws, side_ws, side_stream):
+        self.main_ws, self.side_ws = main_ws, side_ws
+        self.side_handle = side_stream.cuda_stream if side_stream is not None else None
+
+    def __enter__(self):
+        self.prev = getattr(_LT_SCOPE, "scope", None)
+        _LT_SCOPE.scope = self
+        return self
+
+    def __exit__(self, *exc):
+        _LT_SCOPE.scope = self.prev
+        return False
+
+    def pick(self, dev):
+        on_side = self.side_handle is not None and torch.cuda.current_stream(dev).cuda_stream == self.side_handle
+        return self.side_ws if on_side else self.main_ws
 
 
 def _lt_workspace(dev):
+    scope = getattr(_LT_SCOPE, "scope", None)
+    if scope is not None:
+        return scope.pick(dev)
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
     ws = _LT_WORKSPACES.get(key)
     if ws is None:
-        if torch.cuda.is_current_stream_capturing():       # not from a graph's private pool: run without scratch instead
+        if torch.cuda.is_current_stream_capturing():       # a foreign capture without a scope: run without scratch
             return None
+        while len(_LT_WORKSPACES) >= _LT_WORKSPACES_MAX:   # bounded: the oldest stream's scratch goes back to the allocator
+            _LT_WORKSPACES.pop(next(iter(_LT_WORKSPACES)))
         ws = _LT_WORKSPACES[key] = torch.empty(_LT_WORKSPACE_BYTES, dtype=torch.uint8, device=dev)
     return ws
 

@@ -412,11 +412,32 @@ def test_graph_cache_is_bounded(dcl, monkeypatch):
     net, _, _ = _net(dcl, n, n, 1, graph_max_batch=8)
     monkeypatch.setattr(type(net), "MAX_GRAPHS", 3)
     outs = {}
-    for b in (1, 2, 3, 1, 4, 5):                       # 1 is touched again before 4 and 5 arrive: 2 and 3 go
+    for b in (1, 2, 3, 1):
         outs[b] = net(dcl.synth.make_batch(b, n, n, first=b))
-    assert [k[0] for k in net._graphs] == [1, 4, 5]
-    again = net(dcl.synth.make_batch(2, n, n, first=2))                       # evicted -> captured anew, same result
-    assert torch.equal(again["rot_pred"], outs[2]["rot_pred"]) and [k[0] for k in net._graphs] == [4, 5, 2]
+    assert [k[0] for k in net._graphs] == [2, 3, 1]
+    # the cache is full: a new batch size runs launch by launch until it has been seen GRAPH_ADMIT (3) times -- an eval loop
+    # whose crop count varies per image must not recapture on every call -- then it evicts the least recently used size
+    for rep in range(2):
+        outs[4] = net(dcl.synth.make_batch(4, n, n, first=4))
+        assert [k[0] for k in net._graphs] == [2, 3, 1], rep
+    third = net(dcl.synth.make_batch(4, n, n, first=4))
+    assert [k[0] for k in net._graphs] == [3, 1, 4]
+    assert float((third["rot_pred"] - outs[4]["rot_pred"]).abs().max()) <= 1e-5   # graph replay == launch by launch
+    net(dcl.synth.make_batch(1, n, n, first=1))                                   # 1 touched again: 3 is the LRU now
+    for _ in range(3):
+        again = net(dcl.synth.make_batch(2, n, n, first=2))                       # evicted earlier -> admitted on the 3rd call
+    assert [k[0] for k in net._graphs] == [4, 1, 2]
+    assert float((again["rot_pred"] - outs[2]["rot_pred"]).abs().max()) <= 1e-5
+    # a column-sliced (non-contiguous) resident input takes the copy_() staging instead of tripping pad_copy_many's asserts
+    d = dcl.synth.make_batch(1, n, n, first=1)
+    wide = torch.zeros((d["inp"]["feats"].shape[0], 9), device="cuda")
+    wide[:, :7] = d["inp"]["feats"].cuda()
+    for s_ in ("inp", "tmp"):
+        for k in ("feats", "v2p_maps", "occupied_voxels"):
+            d[s_][k] = d[s_][k].cuda()
+    d["inp"]["feats"] = wide[:, :7]
+    sliced = net(d)
+    assert torch.equal(sliced["rot_pred"], outs[1]["rot_pred"])
 
 
 def test_graph_cache_follows_the_weights(dcl):
