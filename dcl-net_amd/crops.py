@@ -91,11 +91,64 @@ class CropBuilder(object):
                                         int(self.limit[0]))
         self.tmp_feats = feats.view(len(self.cls_ids), self.n_tmp, 7)
         self.tmp_vox = coords.view(len(self.cls_ids), self.n_tmp, 4)[:, :, 1:].contiguous()
+        # The template side of a batch is a function of the crops' CLASSES alone (:179-183,223): voxelise every class once
+        # (device voxelize_idx, crop id 0) and keep the three maps on the host; a frame's maps are those tables put side by
+        # side with the crop ids / row offsets applied (_template_side) -- no kernel and no read-back per frame.
+        S = int(self.limit[0])
+        self._tmp_tab, self._tmp_side_cache = [], {}
+        zero = torch.zeros((self.n_tmp, 1), dtype=torch.int64, device=self.dev)
+        for r in range(len(self.cls_ids)):
+            occ, p2v, v2p = ops.voxelize_idx_gpu(torch.cat([zero, self.tmp_vox[r]], 1).contiguous(), 1, S, self.mode)
+            v2p = v2p.cpu().numpy()
+            ids = (np.arange(v2p.shape[1])[None, :] >= 1) & (np.arange(v2p.shape[1])[None, :] <= v2p[:, :1])
+            self._tmp_tab.append((occ.cpu().numpy(), p2v.cpu().numpy(), v2p, ids))
+
+    def _template_side(self, rows):
+        """occupied_voxels / p2v_maps / v2p_maps of the template clouds of the classes `rows` (one per crop), exactly what
+        voxelize_idx returns for the batch's (b * n_tmp, 4) coordinate rows (first-encounter voxel ids crop by crop, point
+        ids offset by the crop's first point, maxActive = the batch's maximum).  Assembled on the host from the per-class
+        tables and cached per class tuple (the objects of a video sequence repeat frame after frame)."""
+        key = tuple(int(r) for r in rows)
+        hit = self._tmp_side_cache.get(key)
+        if hit is not None:
+            return hit
+        tabs = [self._tmp_tab[r] for r in key]
+        ma = max(t[2].shape[1] for t in tabs) - 1
+        occ, p2v, v2p, voff = [], [], [], 0
+        for j, (o, p, v, ids) in enumerate(tabs):
+            oj = o.copy()
+            oj[:, 0] = j
+            occ.append(oj)
+            p2v.append(p + voff)
+            vj = np.zeros((v.shape[0], ma + 1), np.int32)
+            vj[:, :v.shape[1]] = v + (j * self.n_tmp) * ids
+            v2p.append(vj)
+            voff += o.shape[0]
+        out = tuple(torch.from_numpy(np.ascontiguousarray(np.concatenate(a, 0))).to(self.dev) for a in (occ, p2v, v2p))
+        b = len(key)
+        ids = torch.arange(b, device=self.dev).view(b, 1, 1).expand(b, self.n_tmp, 1)
+        rows_t = torch.tensor(key, device=self.dev)
+        out = out + (torch.cat([ids, self.tmp_vox[rows_t]], 2).reshape(b * self.n_tmp, 4).contiguous(),)   # voxelize_idx's input rows
+        if len(self._tmp_side_cache) >= 64:
+            self._tmp_side_cache.pop(next(iter(self._tmp_side_cache)))
+        self._tmp_side_cache[key] = out
+        return out
+
+    @staticmethod
+    def resident(img, depth, label, device="cuda"):
+        """upload one frame's arrays in the layout build() wants (u8 colour, depth as 16-bit storage, i32 labels): a caller
+        that decodes frames ahead of the network keeps them in HBM and passes these tensors instead of numpy arrays"""
+        dev = torch.device(device)
+        return (torch.from_numpy(np.ascontiguousarray(img)).to(dev),
+                torch.from_numpy(np.ascontiguousarray(depth).astype(np.uint16).view(np.int16)).to(dev),
+                torch.from_numpy(np.ascontiguousarray(label).astype(np.int32)).to(dev))
 
     def build(self, img, depth, label, rois, gt_obj, poses=None):
         """img (H,W,3|4) u8, depth (H,W) u16, label (H,W) integer, rois (k,>=6), gt_obj (n) class ids, poses (3,4,n) or
-        None -- numpy arrays as the loader reads them.  Returns the loader's dict with CUDA tensors (instances without a
-        detection or with an empty mask are dropped and flagged 0 in `all_flags`, :116,134)."""
+        None -- numpy arrays as the loader reads them, or the CUDA tensors of CropBuilder.resident().  Returns the loader's
+        dict with CUDA tensors (instances without a detection or with an empty mask are dropped and flagged 0 in
+        `all_flags`, :116,134).  Host synchronisations per frame: the per-instance point counts (the sampling draws are the
+        loader's own np.random.choice calls) and {V, maxActive} of the observed side's voxelisation; nothing else."""
         H, W = depth.shape
         gt_obj = np.asarray(gt_obj).astype(np.int32)
         rois = np.asarray(rois)
@@ -110,13 +163,16 @@ class CropBuilder(object):
         flags = np.zeros(len(gt_obj), np.int8)
         if not cand:
             raise ValueError("no object instance of this image has a detection")
-        d_t = torch.from_numpy(np.ascontiguousarray(depth).astype(np.uint16).view(np.int16)).to(dev)
-        l_t = torch.from_numpy(np.ascontiguousarray(label).astype(np.int32)).to(dev)
-        i_t = torch.from_numpy(np.ascontiguousarray(img)).to(dev)
-        b_t = torch.tensor(boxes, dtype=torch.int32, device=dev)
-        o_t = torch.from_numpy(gt_obj[cand]).to(dev)
+        if torch.is_tensor(depth):
+            i_t, d_t, l_t = img, depth, label                                       # resident frame (CropBuilder.resident)
+        else:
+            i_t, d_t, l_t = self.resident(img, depth, label, dev)
+        bo = np.concatenate([np.asarray(boxes, np.int32), gt_obj[cand][:, None]], 1)   # boxes + class ids: one upload
+        bo_t = torch.from_numpy(bo).to(dev)
+        b_t, o_t = bo_t[:, :4].contiguous(), bo_t[:, 4].contiguous()
+        cap = max(1, max(max(r1 - r0, 0) * max(c1 - c0, 0) for r0, r1, c0, c1 in boxes))
         xyz, col, centroid, counts = ops.crop_points(d_t, l_t, i_t, b_t, o_t, self.camera, RGB_MEAN, self.extent * 0.5,
-                                                     MIN_VALID)
+                                                     MIN_VALID, cap=cap)
         cnt = counts.cpu().numpy()                                                  # the builder's host read-back
         keep = [k for k in range(len(cand)) if cnt[k, 0] > 0]
         if not keep:
@@ -127,17 +183,16 @@ class CropBuilder(object):
             picks.append(np.random.choice(m, self.n_inp, replace=False) if m > self.n_inp
                          else np.random.choice(m, self.n_inp))
             flags[cand[k]] = 1
-        kt = torch.tensor(keep, device=dev)
         if len(keep) != len(cand):
+            kt = torch.tensor(keep, device=dev)
             xyz, col, centroid, counts = xyz[kt].contiguous(), col[kt].contiguous(), centroid[kt], counts[kt].contiguous()
         pick_t = torch.from_numpy(np.stack(picks).astype(np.int64)).to(dev)
         feats_inp, coords_inp = ops.crop_sample(xyz, col, pick_t, counts, self.extent[0] * 0.5, self.unit,
                                                 int(self.limit[0]), min_valid=MIN_VALID)
         b = len(keep)
-        cls_rows = torch.tensor([self.cls_row[int(gt_obj[cand[k]])] for k in keep], device=dev)
+        rows = [self.cls_row[int(gt_obj[cand[k]])] for k in keep]
+        cls_rows = torch.tensor(rows, device=dev)
         feats_tmp = self.tmp_feats[cls_rows].reshape(b * self.n_tmp, 7)
-        ids = torch.arange(b, device=dev).view(b, 1, 1).expand(b, self.n_tmp, 1)
-        coords_tmp = torch.cat([ids, self.tmp_vox[cls_rows]], 2).reshape(b * self.n_tmp, 4).contiguous()
         data = {"batch_offsets": (torch.arange(b + 1) * 1024).int(), "voxel_num_limit": torch.tensor(self.limit),
                 "obj_idx": torch.IntTensor(gt_obj - 1), "all_flags": torch.IntTensor(flags),
                 "flags": torch.IntTensor([-1]), "all_centroids": centroid, "labels": {}, "counts": cnt[keep]}
@@ -148,9 +203,10 @@ class CropBuilder(object):
                      for j, k in enumerate(keep)]
             data["labels"] = {"rot_gt": torch.stack(rot), "trans_gt": torch.stack(trans)}
         S = int(self.limit[0])
-        for side, feats, coords in (("inp", feats_inp, coords_inp), ("tmp", feats_tmp, coords_tmp)):
-            occ, p2v, v2p = ops.voxelize_idx_gpu(coords, b, S, self.mode)
-            data[side] = {"feats": feats, "coords": coords, "occupied_voxels": occ, "p2v_maps": p2v, "v2p_maps": v2p}
+        occ, p2v, v2p = ops.voxelize_idx_gpu(coords_inp, b, S, self.mode)
+        data["inp"] = {"feats": feats_inp, "coords": coords_inp, "occupied_voxels": occ, "p2v_maps": p2v, "v2p_maps": v2p}
+        occ, p2v, v2p, coords_tmp = self._template_side(rows)                       # tables: no kernel, no read-back
+        data["tmp"] = {"feats": feats_tmp, "coords": coords_tmp, "occupied_voxels": occ, "p2v_maps": p2v, "v2p_maps": v2p}
         # a Network(async_inputs=True) lets its side streams wait for exactly this point instead of the whole stream
         data["ready_event"] = torch.cuda.Event()
         data["ready_event"].record(torch.cuda.current_stream(dev))

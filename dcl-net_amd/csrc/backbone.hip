@@ -21,8 +21,9 @@ int dcl_internal_grid_from_indices(const int32_t *indices, const int32_t *n_rows
 int dcl_internal_sparse_conv_fwd(const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev,
                                  int n_out_host, const float *W, int cin, int cout, int kvol, int subm, const float *scale,
                                  const float *shift, int relu, float *out, float *scratch, int64_t scratch_floats,
-                                 dclStream_t stream, int counters_ready = 0);
+                                 dclStream_t stream, int counters_ready = 0, const DclRowOrder *ord = nullptr);
 int dcl_internal_conv_split_cap(long long rows);
+int dcl_internal_order_rows(const DclOrderJobs &jobs, int njobs, dclStream_t stream);
 int dcl_internal_out_mask_k3(const uint32_t *in_mask, int batch, int S_in, int stride, uint32_t *out_mask,
                              dclStream_t stream);
 int dcl_internal_scan_enumerate_sets(const DclGeoSets &g, int nsets, dclStream_t stream);
@@ -66,11 +67,24 @@ struct SetLayout {
   size_t mask, wprefix, indices;      // byte offsets in the geometry workspace
 };
 
+// row order of one conv layer (row_order.hip): outputs order / bal / smask + the pass's scratch
+struct OrderLayout {
+  bool on;
+  size_t order, bal, smask, rowmask, hist, tile_cnt;
+  int nblk_cap;
+};
+
 struct GeoLayout {
   size_t mask0, wprefix0, perm0;
   SetLayout conv[kLevels], pool[kLevels];
+  OrderLayout ord[kLevels][2];          // [level][0 = the dilating conv, 1 = the submanifold conv] on the level's conv set
   size_t scratch, total;
 };
+
+// Row ordering pays where launches are MFMA-bound on their tiles: from a dozen crops on (one-image calls are latency-bound
+// few-row launches, which take no order), for the layers the LDS-DMA kernel deals in used chunks (Cin >= 32)
+constexpr int kOrderMinBatch = 12;
+inline bool order_layer(int batch, int m, int which) { return batch >= kOrderMinBatch && m >= 1 && (which == 0 || which == 1); }
 
 bool make_geo_layout(int batch, int S, int V0, GeoLayout *L) {
   if (batch <= 0 || S < 16 || (S & (S - 1)) || S > 64 || V0 < 0) return false;
@@ -99,6 +113,20 @@ bool make_geo_layout(int batch, int S, int V0, GeoLayout *L) {
     cap_prev = cap_p;
     s = sp;
   }
+  for (int m = 0; m < kLevels; ++m)
+    for (int q = 0; q < 2; ++q) {
+      OrderLayout &o = L->ord[m][q];
+      o.on = order_layer(batch, m, q);
+      if (!o.on) continue;
+      const size_t cap = (size_t)L->conv[m].cap, tiles = (cap + 127) / 128;
+      o.nblk_cap = (int)((cap + 1023) / 1024);
+      o.order = take(sizeof(int32_t) * cap);
+      o.bal = take(sizeof(int32_t) * (tiles + 2));
+      o.smask = take(sizeof(uint32_t) * (tiles + 1));
+      o.rowmask = take(sizeof(uint32_t) * cap);
+      o.hist = take(sizeof(int32_t) * 512 * (size_t)o.nblk_cap);
+      o.tile_cnt = take(sizeof(int32_t) * (tiles + 1));
+    }
   // scan scratch: block sums of the input grid, then of the 8 generated sets (batched scan, one slice per set)
   size_t blocks = (size_t)(nw0 + 1023) / 1024 + 2;
   for (int m = 0; m < kLevels; ++m)
@@ -216,7 +244,32 @@ static int backbone_geometry(const int32_t *occ, const int32_t *V0_dev, int V0, 
     rc = dcl_internal_mask_chain(at<uint32_t>(ws, L.mask0), batch, g, stream);
     if (rc) return rc;
   }
-  return dcl_internal_scan_enumerate_sets(g, 2 * kLevels, stream);
+  rc = dcl_internal_scan_enumerate_sets(g, 2 * kLevels, stream);
+  if (rc) return rc;
+  // row orders of the MFMA-bound conv layers (depends on the geometry only): all jobs of the pass in five launches
+  DclOrderJobs jobs{};
+  int njobs = 0;
+  for (int m = 0; m < kLevels; ++m)
+    for (int q = 0; q < 2; ++q) {
+      const OrderLayout &o = L.ord[m][q];
+      if (!o.on) continue;
+      DclOrderJob &j = jobs.job[njobs++];
+      j.out_indices = at<int32_t>(ws, L.conv[m].indices);
+      j.n_dev = counts_dev + 2 * m;
+      j.n_host = 0;
+      j.cap = L.conv[m].cap;
+      j.S_in = L.conv[m].S;
+      j.subm = q;
+      j.in_mask = q ? at<uint32_t>(ws, L.conv[m].mask) : at<uint32_t>(ws, L.pool[m - 1].mask);   // order_layer: m >= 1
+      j.rowmask = at<uint32_t>(ws, o.rowmask);
+      j.hist = at<int32_t>(ws, o.hist);
+      j.order = at<int32_t>(ws, o.order);
+      j.tile_cnt = at<int32_t>(ws, o.tile_cnt);
+      j.bal = at<int32_t>(ws, o.bal);
+      j.smask = at<uint32_t>(ws, o.smask);
+      j.nblk_cap = o.nblk_cap;
+    }
+  return njobs ? dcl_internal_order_rows(jobs, njobs, stream) : 0;
 }
 
 #ifdef DCL_DIAG
@@ -324,8 +377,15 @@ static int backbone_features(const int32_t *occ, int V0, int batch, int S, void 
       rc = source(at<int32_t>(ws, c.indices), nc_dev, nc, in_mask, in_wp, in_perm, 1, &src);
       if (rc) return rc;
       DBG_STEP();
+      const DclRowOrder ord_c{L.ord[m][0].on ? at<int32_t>(ws, L.ord[m][0].order) : nullptr,
+                              L.ord[m][0].on ? at<int32_t>(ws, L.ord[m][0].bal) : nullptr,
+                              L.ord[m][0].on ? at<uint32_t>(ws, L.ord[m][0].smask) : nullptr};
+      const DclRowOrder ord_s{L.ord[m][1].on ? at<int32_t>(ws, L.ord[m][1].order) : nullptr,
+                              L.ord[m][1].on ? at<int32_t>(ws, L.ord[m][1].bal) : nullptr,
+                              L.ord[m][1].on ? at<uint32_t>(ws, L.ord[m][1].smask) : nullptr};
       rc = dcl_internal_sparse_conv_fwd(x, src, nc, nc_dev, nc_dev ? 0 : nc, weights[2 * m], c0, c1, 27, 0, scales[2 * m],
-                                        shifts[2 * m], 1, x1, scr, (int64_t)F.scratch_floats, stream, 1);
+                                        shifts[2 * m], 1, x1, scr, (int64_t)F.scratch_floats, stream, 1,
+                                        explicit_nbr ? nullptr : &ord_c);
       if (rc) return rc;
       // submanifold conv on the conv set
       DBG_STEP();
@@ -334,7 +394,8 @@ static int backbone_features(const int32_t *occ, int V0, int batch, int S, void 
       if (rc) return rc;
       DBG_STEP();
       rc = dcl_internal_sparse_conv_fwd(x1, src, nc, nc_dev, nc_dev ? 0 : nc, weights[2 * m + 1], c1, c2, 27, 1,
-                                        scales[2 * m + 1], shifts[2 * m + 1], 1, x2, scr, (int64_t)F.scratch_floats, stream, 1);
+                                        scales[2 * m + 1], shifts[2 * m + 1], 1, x2, scr, (int64_t)F.scratch_floats, stream, 1,
+                                        explicit_nbr ? nullptr : &ord_s);
       if (rc) return rc;
     }
     if (np > 0) {

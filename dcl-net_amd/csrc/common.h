@@ -79,6 +79,29 @@ struct DclGeoSets {
   int32_t *block_sums[8];   // scratch: one entry per 1024-word scan block
   int nwords[8], S[8], cap[8];
 };
+// Row ordering of one conv layer (row_order.hip): tile slot i of the launch computes output row order[i]; bal[t] = number of
+// used kernel-offset steps of the 128-row tiles in front of tile t (bal[ntiles] = all of them), smask[t] = tile t's step mask.
+struct DclRowOrder {
+  const int32_t *order;
+  const int32_t *bal;
+  const uint32_t *smask;
+};
+struct DclOrderJob {
+  const int32_t *out_indices;   // (rows, 4) [b,x,y,z] of the layer's output set
+  const int32_t *n_dev;         // live row count (device-visible) or nullptr -> n_host
+  const uint32_t *in_mask;      // occupancy bits of the layer's INPUT set (k3, s1, p1: same grid side as the output set)
+  uint32_t *rowmask;            // scratch [cap]: 27-bit neighbour mask per row
+  int32_t *hist;                // scratch [512][nblk_cap]: key histogram per 1024-row block, then its exclusive scan
+  int32_t *order;               // out [cap]
+  int32_t *tile_cnt;            // scratch [ceil(cap/128)]
+  int32_t *bal;                 // out [ceil(cap/128) + 1]
+  uint32_t *smask;              // out [ceil(cap/128)]
+  int n_host, cap, S_in, subm, nblk_cap;
+};
+constexpr int DCL_ORDER_MAX_JOBS = 8;
+struct DclOrderJobs {
+  DclOrderJob job[DCL_ORDER_MAX_JOBS];
+};
 // The 4 pooled levels of a backbone pass as seen by the point read-out (interp.hip: dcl_internal_readout_*): occupancy
 // bits + ranks + rows for the 3-NN searches, features for the interpolation; out columns col[m] .. col[m]+c[m].
 struct DclReadoutLevels {

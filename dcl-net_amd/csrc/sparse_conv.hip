@@ -21,7 +21,7 @@
 int dcl_internal_sparse_conv_fwd(const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev,
                                  int n_out_host, const float *W, int cin, int cout, int kvol, int subm, const float *scale,
                                  const float *shift, int relu, float *out, float *scratch, int64_t scratch_floats,
-                                 dclStream_t stream, int counters_ready = 0);
+                                 dclStream_t stream, int counters_ready = 0, const DclRowOrder *ord = nullptr);
 int dcl_internal_sparse_avgpool_fwd(const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev,
                                     int n_out_host, int c, int kvol, float *out, int32_t *rf, dclStream_t stream);
 
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
     const float *__restrict__ feat, const DclNbrSrc src, int cap, const int32_t *__restrict__ n_out_dev,
     int n_out_host, const float *__restrict__ W, int cout, int kvol, int subm, const float *__restrict__ scale,
     const float *__restrict__ shift, int relu, float *__restrict__ out, float *__restrict__ partial, int stream_k,
-    int aligned_ns, int xcd_remap, int32_t *__restrict__ tile_counters, const int32_t *__restrict__ bal) {
+    int aligned_ns, int xcd_remap, int32_t *__restrict__ tile_counters, const DclRowOrder ord, int use_bal) {
   constexpr int NW = WR * WCW, NTHR = 64 * NW;
   constexpr int BM = 32 * WR, BN = 32 * NT * WCW, KC = 32;
   constexpr int AT = BM * KC, BT = KC * BN, ST = AT + BT;      // floats per stage
@@ -414,9 +414,10 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
   constexpr int B_INSTR = KC / B_ROWS_PER;
   static_assert(A_INSTR % NW == 0 && B_INSTR % NW == 0 && (BN == 32 || BN == 64 || BN == 128), "tile shape");
   constexpr int BSWZ = BN >= 64 ? 1 : 0;                       // W-row half swap (rows 32 floats wide have no halves to swap)
-  extern __shared__ __attribute__((aligned(16))) float conv_lds[];   // [stage 0: A|B][stage 1: A|B][Ns 27*BM][kmask]
+  extern __shared__ __attribute__((aligned(16))) float conv_lds[];   // [stage 0: A|B][stage 1: A|B][Ns 27*BM][kmask (4)][rows BM]
   int32_t *Ns = reinterpret_cast<int32_t *>(conv_lds + 2 * ST);
   unsigned *s_kmask = reinterpret_cast<unsigned *>(Ns + 27 * BM);
+  int32_t *s_rows = reinterpret_cast<int32_t *>(s_kmask + 4);         // output row of every tile slot (-1 = none): the row order
 
   int n = n_out_dev ? *n_out_dev : n_out_host;
   n = n < cap ? n : cap;
@@ -445,9 +446,11 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
   const int C = (kvol * CIN + KC - 1) / KC;                    // chunks per tile
   // (32-bit unit arithmetic: tiles * C < 2^31 for every launch the host code makes -- 64-bit divisions would cost
   // dozens of VGPRs in a kernel that sits at the 128-register limit)
-  // `bal` (experimental, stream-K only, CIN >= 32): units are USED chunks -- bal[0..nblk] is the prefix of the row tiles'
-  // used-step counts, bal[nblk+1 ..] their step masks -- so that row tiles with few used offsets (rows sorted by which
-  // neighbour planes exist) cost their workgroups proportionally less
+  // Row order (row_order.hip): tile slot i computes output row ord.order[i] -- rows sorted by the shape of their
+  // neighbourhood, so that a tile's rows use the same few kernel offsets.  use_bal (stream-K only, CIN >= 32): the units are
+  // USED chunks -- ord.bal[0..nblk] is the prefix of the row tiles' used-step counts, ord.smask[] their step masks -- so a
+  // row tile with few used offsets costs its workgroups proportionally less
+  const int32_t *__restrict__ bal = use_bal ? ord.bal : nullptr;
   constexpr int CPKH = CIN >= KC ? CIN / KC : 1;
   const int total = bal ? bal[nblk] * ncol * CPKH : nblk * ncol * C;
   int U = C, u = wid * C, u_end = total;                       // stream_k == 0: tile wid, wid + G, ...
@@ -479,7 +482,7 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
       tile_lo = base + by * cnt;
       tile_hi = tile_lo + cnt;
       const int v0 = u - tile_lo, v1 = cnt < v0 + (u_end - u) ? cnt : v0 + (u_end - u);
-      const unsigned smk = (unsigned)bal[nblk + 1 + blk];
+      const unsigned smk = ord.smask[blk];
       auto nominal = [&](int v) -> int {                       // used chunk v of the tile -> its nominal chunk index
         unsigned m = smk;
         for (int q = v / CPKH; q > 0; --q) m &= m - 1u;
@@ -512,6 +515,7 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
     }
 #endif
     if (tid == 0) *s_kmask = 0;
+    for (int rr = tid; rr < BM; rr += NTHR) s_rows[rr] = row0 + rr < n ? (ord.order ? ord.order[row0 + rr] : row0 + rr) : -1;
     __syncthreads();
     // neighbour rows of the offsets this workgroup's chunk range touches (all 27 without split-K)
     unsigned mymask = 0;
@@ -521,7 +525,8 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
     for (int e = tid; e < (sx_hi - sx_lo + 1) * BM; e += NTHR) {
       const int si = e / BM, rr = e - si * BM;
       const int k = offset_at(sx_lo + si, kvol, subm);
-      const int v = (row0 + rr < n) ? dcl_nbr_at(src, cap, k, row0 + rr) : -1;
+      const int orow = s_rows[rr];
+      const int v = orow >= 0 ? dcl_nbr_at(src, cap, k, orow) : -1;
       Ns[k * BM + rr] = v;
       mymask |= (v >= 0 ? 1u : 0u) << k;
     }
@@ -800,8 +805,8 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
           const float sh = scale ? shift[co] : 0.0f;
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
-            const int orow = row0 + wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (orow < n) {
+            const int orow = s_rows[wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * h];
+            if (orow >= 0) {
               float x = acc[t][e];
               if (scale) x = x * sc + sh;
               if (relu) x = fmaxf(x, 0.0f);
@@ -821,8 +826,8 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
       const float sh = scale ? shift[co] : 0.0f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int orow = row0 + wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (orow < n) {
+        const int orow = s_rows[wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * h];
+        if (orow >= 0) {
           float x = acc[t][e];
           if (scale) x = x * sc + sh;
           if (relu) x = fmaxf(x, 0.0f);
@@ -922,16 +927,16 @@ DCL_HOOK_INT(g_conv_xcd_remap, 1);   // 0 = plain blockIdx order
 DCL_HOOK_INT(g_conv_slots, 512);     // workgroups a launch is dealt over (2 x 256 resident slots)
 DCL_HOOK_INT(g_conv_split, 0);       // 0 = automatic, n = force n-way split-K when scratch allows, -1 = never more than kConvMaxSplit, -2 = never split, -3 = few-row combine inside the launch
 #ifdef DCL_DIAG
-static std::atomic<const int32_t *> g_conv_bal{nullptr};   // experiment (tools/sort_experiment.py): used-chunk units of the next launches
+static std::atomic<int> g_conv_order_mode{0};   // A/B: 0 = as given, 1 = ignore the row order (natural rows), 2 = order but nominal chunk units
 #endif
 
 template <int CIN, int WR, int WCW, int NT>
 static void launch_conv_dma(int rows, const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev,
                             int n_out_host, const float *W, int cout, int kvol, int subm, const float *scale,
                             const float *shift, int relu, float *out, float *scratch, long long scratch_floats,
-                            int counters_ready, hipStream_t s) {
+                            int counters_ready, const DclRowOrder *ord_in, hipStream_t s) {
   constexpr int BM = 32 * WR, BN = 32 * NT * WCW, KC = 32;
-  const size_t lds = (size_t)(2 * (BM * KC + KC * BN) + 27 * BM + 4) * sizeof(float);
+  const size_t lds = (size_t)(2 * (BM * KC + KC * BN) + 27 * BM + 4 + BM) * sizeof(float);
   (void)hipFuncSetAttribute((const void *)k_sparse_conv_dma<CIN, WR, WCW, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
   const int nblk = dcl_div_up(rows, BM);
@@ -1008,25 +1013,31 @@ static void launch_conv_dma(int rows, const float *feat, const DclNbrSrc &nbr, i
       }
     }
   }
-#ifdef DCL_DIAG
-  const int32_t *bal = g_conv_bal.load();
-#else
-  const int32_t *bal = nullptr;
-#endif
-  if (bal && CIN >= 32 && scratch && !n_out_dev) {       // experiment: always stream-K over all slots, in-launch combine
-    stream_k = 1;
-    aligned_ns = 0;
-    G = kSlots;
-    partial = scratch + kConvCounterWords;
-    deferred = false;
-    counters = reinterpret_cast<int32_t *>(scratch);
-    if (!counters_ready) dcl_internal_zero_words(counters, kConvCounterWords, s);
-  } else {
-    bal = nullptr;
+  // Row order (row_order.hip).  The order itself works with every decomposition whose combine runs inside the launch (the
+  // deferred combine of few-row launches maps tile slots to rows on its own: such launches take no order).  Used-chunk
+  // dealing replaces the nominal units whenever the launch would split tiles anyway (aligned split-K / stream-K);
+  // launches whose tiles fit one round of whole tiles keep them (measured: forced stream-K only adds the combine there).
+  DclRowOrder ord{nullptr, nullptr, nullptr};
+  int use_bal = 0;
+  if (ord_in && ord_in->order && !deferred && BM == 128) {
+    ord = *ord_in;
+    if (ord.bal && ord.smask && CIN >= 32 && (aligned_ns || stream_k) && scratch && scratch_floats > kConvCounterWords) {
+      use_bal = 1;
+      stream_k = 1;
+      aligned_ns = 0;
+      const long long slots_fit = (scratch_floats - kConvCounterWords) / ((long long)2 * BM * BN);
+      G = (int)(kSlots < slots_fit ? kSlots : slots_fit);
+      partial = scratch + kConvCounterWords;
+      counters = reinterpret_cast<int32_t *>(scratch);            // (already zeroed above: aligned / stream-K launches own them)
+    }
   }
+#ifdef DCL_DIAG
+  if (g_conv_order_mode == 1) { ord = DclRowOrder{nullptr, nullptr, nullptr}; use_bal = 0; }   // A/B: natural row order
+  if (g_conv_order_mode == 2) use_bal = 0;                                                     // A/B: order, nominal units
+#endif
   hipLaunchKernelGGL((k_sparse_conv_dma<CIN, WR, WCW, NT>), dim3(G), dim3(64 * WR * WCW), lds, s, feat, nbr, cap, n_out_dev,
                      n_out_host, W, cout, kvol, subm, scale, shift, relu, out, partial, stream_k, aligned_ns, (int)g_conv_xcd_remap,
-                     counters, bal);
+                     counters, ord, use_bal);
   if (deferred)
     hipLaunchKernelGGL((k_conv_frag_reduce<WR, WCW, NT>), dim3(tiles, WR * WCW * NT), dim3(256), 0, s, partial, cap, n_out_dev,
                        n_out_host, cout, nchunks, G, stream_k, scale, shift, relu, out);
@@ -1148,7 +1159,7 @@ DCL_HOOK_INT(g_force_valu, 0);   // 1 = plain VALU kernel for every conv, 2 = MF
 #ifdef DCL_DIAG
 DCL_API void dcl_debug_force_valu_conv(int on) { g_force_valu = on; }
 DCL_API void dcl_debug_conv_split(int n) { g_conv_split = n; }
-DCL_API void dcl_debug_conv_balance(const int32_t *bal_dev) { g_conv_bal = bal_dev; }
+DCL_API void dcl_debug_conv_order_mode(int mode) { g_conv_order_mode = mode; }
 DCL_API void dcl_debug_conv_slots(int n) { g_conv_slots = (n >= 64 && n <= 512) ? n : 512; }
 DCL_API void dcl_debug_conv_xcd_remap(int on) { g_conv_xcd_remap = on; }
 #endif
@@ -1195,6 +1206,20 @@ DCL_API int dcl_sparse_conv_fwd_ws(const float *feat, const int32_t *nbr, int ca
                                       out, scratch, scratch_floats, stream);
 }
 
+// Same with a row order from dcl_order_rows (row_order.hip): tile slots compute rows in that order, work is dealt in used
+// chunks where the launch splits tiles.  Results equal dcl_sparse_conv_fwd_ws up to the fp32 summation split points.
+DCL_API int dcl_sparse_conv_fwd_ordered(const float *feat, const int32_t *nbr, int cap, const int32_t *n_out_dev,
+                                        int n_out_host, const float *W, int cin, int cout, int kvol, int subm,
+                                        const float *scale, const float *shift, int relu, float *out, float *scratch,
+                                        int64_t scratch_floats, const int32_t *order, const int32_t *bal,
+                                        const uint32_t *smask, dclStream_t stream) {
+  DCL_CHECK_ARG(nbr && order && (bal == nullptr) == (smask == nullptr));
+  const DclNbrSrc src = {nbr, nullptr, nullptr, nullptr, nullptr, 0, 1, 0};
+  const DclRowOrder ord{order, bal, smask};
+  return dcl_internal_sparse_conv_fwd(feat, src, cap, n_out_dev, n_out_host, W, cin, cout, kvol, subm, scale, shift, relu,
+                                      out, scratch, scratch_floats, stream, 0, &ord);
+}
+
 // ---- measurement facility (bench.py's `roofline_sparse_conv`): while enabled, every sparse-conv call is bracketed by
 // HIP events on the stream it is launched on; dcl_profile_conv_end() waits for them and returns the summed device time.
 // Mutex-protected; not for use under stream capture (events would become graph nodes).
@@ -1234,13 +1259,13 @@ DCL_API int dcl_profile_conv_end(double *ms_total_host, int32_t *calls_host) {
 static int conv_dispatch(const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev, int n_out_host,
                          const float *W, int cin, int cout, int kvol, int subm, const float *scale, const float *shift,
                          int relu, float *out, float *scratch, int64_t scratch_floats, int counters_ready,
-                         dclStream_t stream);
+                         const DclRowOrder *ord, dclStream_t stream);
 
 // library-internal: `nbr` may be an implicit rulebook (native backbone runner)
 int dcl_internal_sparse_conv_fwd(const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev,
                                  int n_out_host, const float *W, int cin, int cout, int kvol, int subm, const float *scale,
                                  const float *shift, int relu, float *out, float *scratch, int64_t scratch_floats,
-                                 dclStream_t stream, int counters_ready) {
+                                 dclStream_t stream, int counters_ready, const DclRowOrder *ord) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   bool timed = false;
   {
@@ -1253,7 +1278,7 @@ int dcl_internal_sparse_conv_fwd(const float *feat, const DclNbrSrc &nbr, int ca
     (void)hipEventRecord(e0, (hipStream_t)stream);
   }
   const int rc = conv_dispatch(feat, nbr, cap, n_out_dev, n_out_host, W, cin, cout, kvol, subm, scale, shift, relu, out,
-                               scratch, scratch_floats, counters_ready, stream);
+                               scratch, scratch_floats, counters_ready, ord, stream);
   if (timed) {
     (void)hipEventRecord(e1, (hipStream_t)stream);
     std::lock_guard<std::mutex> lock(g_conv_prof.mu);
@@ -1265,7 +1290,7 @@ int dcl_internal_sparse_conv_fwd(const float *feat, const DclNbrSrc &nbr, int ca
 static int conv_dispatch(const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev, int n_out_host,
                          const float *W, int cin, int cout, int kvol, int subm, const float *scale, const float *shift,
                          int relu, float *out, float *scratch, int64_t scratch_floats, int counters_ready,
-                         dclStream_t stream) {
+                         const DclRowOrder *ord, dclStream_t stream) {
   DCL_CHECK_ARG(feat && (nbr.nbr || (nbr.out_indices && nbr.in_mask && nbr.in_wprefix && kvol == 27)) && W && out && cap > 0 &&
                 cin > 0 && cout > 0 && kvol > 0 && kvol <= 27);
   DCL_CHECK_ARG((scale == nullptr) == (shift == nullptr));
@@ -1280,7 +1305,7 @@ static int conv_dispatch(const float *feat, const DclNbrSrc &nbr, int cap, const
 #define TILE_ARGS rows, feat, nbr, cap, n_out_dev, n_out_host, W, cout, kvol, subm, scale, shift, relu, out, scratch, \
                   (long long)scratch_floats, counters_ready, s
 #define DMA_ARGS rows, feat, nbr, cap, n_out_dev, n_out_host, W, cout, kvol, subm, scale, shift, relu, out, scratch, \
-                 (long long)scratch_floats, counters_ready, s
+                 (long long)scratch_floats, counters_ready, ord, s
 #ifdef DCL_DIAG
     if (g_force_valu == 5 && cout % 128 != 0 && cout % 64 == 0) {          // A/B: 8 waves of 32x32 on 128x64 tiles
       switch (cin) {

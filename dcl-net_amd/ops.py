@@ -250,8 +250,29 @@ def sparse_avgpool_rf(feat, nbr, n_out, summaryrf):
     return out
 
 
-def sparse_conv(feat, nbr, n_out, W, subm, scale=None, shift=None, relu=False):
-    """indice_conv_fp32 (+ folded BatchNorm1d(eval) + ReLU).  feat (V_in,Cin); W (kvol,Cin,Cout)."""
+def order_rows(out_set, in_mask, subm):
+    """Row order of a k3 / s1 / p1 conv layer with output set `out_set` (ActiveSet) and the INPUT set's occupancy bits
+    `in_mask` on the same batch x S^3 grid (csrc/row_order.hip) -> (order (n,) i32, bal (ntiles+1,) i32, smask (ntiles,) i32)
+    for sparse_conv(..., order=...): tile slot i of the launch computes output row order[i]."""
+    N.need_cuda(out_set.indices, in_mask)
+    n, dev = int(out_set.n), out_set.indices.device
+    cap = max(n, 1)
+    tiles = (cap + 127) // 128
+    nbytes = C.c_int64(0)
+    N.check(N.lib().dcl_order_rows_ws_bytes(cap, C.byref(nbytes)), "order_rows_ws_bytes")
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+    order = torch.empty(cap, dtype=torch.int32, device=dev)
+    bal = torch.zeros(tiles + 2, dtype=torch.int32, device=dev)
+    smask = torch.zeros(tiles + 1, dtype=torch.int32, device=dev)
+    N.check(N.lib().dcl_order_rows(N.ptr(out_set.indices), N.vp(0), n, cap, N.ptr(in_mask), int(out_set.S), int(bool(subm)),
+                                   N.ptr(ws), nbytes.value, N.ptr(order), N.ptr(bal), N.ptr(smask), N.stream()), "order_rows")
+    nt = (n + 127) // 128
+    return order[:n], bal[:nt + 1], smask[:nt]
+
+
+def sparse_conv(feat, nbr, n_out, W, subm, scale=None, shift=None, relu=False, order=None):
+    """indice_conv_fp32 (+ folded BatchNorm1d(eval) + ReLU).  feat (V_in,Cin); W (kvol,Cin,Cout).  order: the triple of
+    order_rows -- the launch then computes its rows in that order and deals its work in used chunks (same output)."""
     N.need_cuda(feat, nbr, W)
     kvol, cap = nbr.shape
     cin, cout = W.shape[-2], W.shape[-1]
@@ -265,6 +286,14 @@ def sparse_conv(feat, nbr, n_out, W, subm, scale=None, shift=None, relu=False):
         need = C.c_int64(0)
         N.check(N.lib().dcl_sparse_conv_scratch_floats(int(cap), int(cout), C.byref(need)), "sparse_conv_scratch_floats")
         scratch = torch.empty(need.value, dtype=torch.float32, device=feat.device)
+    if order is not None:
+        o, bal, smask = order
+        assert o.numel() >= n_out and o.dtype == torch.int32 and o.is_cuda
+        N.check(N.lib().dcl_sparse_conv_fwd_ordered(N.ptr(feat), N.ptr(nbr), cap, N.vp(0), int(n_out), N.ptr(W), cin, cout, kvol,
+                                                    int(bool(subm)), N.ptr(scale), N.ptr(shift), int(bool(relu)), N.ptr(out),
+                                                    N.ptr(scratch), C.c_int64(0 if scratch is None else scratch.numel()),
+                                                    N.ptr(o), N.ptr(bal), N.ptr(smask), N.stream()), "sparse_conv_fwd_ordered")
+        return out
     N.check(N.lib().dcl_sparse_conv_fwd_ws(N.ptr(feat), N.ptr(nbr), cap, N.vp(0), int(n_out), N.ptr(W), cin, cout, kvol,
                                            int(bool(subm)), N.ptr(scale), N.ptr(shift), int(bool(relu)), N.ptr(out),
                                            N.ptr(scratch), C.c_int64(0 if scratch is None else scratch.numel()),
@@ -773,7 +802,7 @@ def add(cld, R_pred, t_pred, R_gt, t_gt, cls=None):
 
 
 # ------------------------------------------------------------------------------------ crop builder
-def crop_points(depth, label, rgb, boxes, obj_ids, cam, rgb_mean, half_extent, min_valid=32, always_filter=False):
+def crop_points(depth, label, rgb, boxes, obj_ids, cam, rgb_mean, half_extent, min_valid=32, always_filter=False, cap=None):
     """Masked back-projection + centring + grid filter of every object instance of one image
     (YCBV/dataloader_test_YCBV.py:124-165).  depth (H,W) u16 viewed as int16 storage, label (H,W) i32, rgb (H,W,C) u8,
     boxes (n,4) i32 [rmin,rmax,cmin,cmax], obj_ids (n) i32 -- all CUDA.  cam = (cx,cy,fx,fy,scale[,post_div]).
@@ -785,8 +814,9 @@ def crop_points(depth, label, rgb, boxes, obj_ids, cam, rgb_mean, half_extent, m
     H, W = depth.shape
     n = boxes.shape[0]
     dev = depth.device
-    bx = boxes.cpu()
-    cap = int(max(1, ((bx[:, 1] - bx[:, 0]).clamp(min=0) * (bx[:, 3] - bx[:, 2]).clamp(min=0)).max().item())) if n else 1
+    if cap is None:                                            # (a caller that made the boxes on the host passes the largest area)
+        bx = boxes.cpu()
+        cap = int(max(1, ((bx[:, 1] - bx[:, 0]).clamp(min=0) * (bx[:, 3] - bx[:, 2]).clamp(min=0)).max().item())) if n else 1
     raw_xyz = torch.empty((n, cap, 3), dtype=torch.float32, device=dev)
     raw_rgb = torch.empty((n, cap, 3), dtype=torch.float32, device=dev)
     xyz = torch.empty((n, cap, 3), dtype=torch.float32, device=dev)

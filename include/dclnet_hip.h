@@ -165,6 +165,26 @@ int dcl_sparse_conv_fwd_ws(const float *feat, const int32_t *nbr, int cap, const
                            int n_out_host, const float *W, int cin, int cout, int kvol, int subm,
                            const float *scale, const float *shift, int relu, float *out, float *scratch,
                            int64_t scratch_floats, dclStream_t stream);
+
+/* Row ordering of a conv layer's output rows + the launch that uses it (csrc/row_order.hip; replaces nothing in the
+ * reference -- it re-orders the work of indiceConv, spconv_ops.h:284-344, not its results).  dcl_order_rows: for the output
+ * set `out_indices` (rows, 4) [b,x,y,z] of a k3 / s1 / p1 layer whose INPUT set has the occupancy bits `in_mask` on a
+ * batch x S_in^3 grid (S_in in {8,16,32,64}), writes
+ *   order[i]  = the output row tile slot i computes (rows sorted, stably, by a 9-bit key of their neighbourhood shape),
+ *   bal[t]    = number of used kernel-offset steps of the 128-row tiles in front of tile t (bal[ntiles] = their total),
+ *   smask[t]  = tile t's step mask (bit s = step s of the visiting order has a neighbour among the tile's rows).
+ * order: cap ints; bal: cap/128 + 2 ints; smask: cap/128 + 1 words; ws: dcl_order_rows_ws_bytes(cap).  Live row count from
+ * n_out_dev (device-visible) or n_out_host.  dcl_sparse_conv_fwd_ordered = dcl_sparse_conv_fwd_ws with that order: same
+ * output rows, same values up to the fp32 summation split points of the decomposition (bal / smask may be NULL: the order
+ * alone).                                                                                                             */
+int dcl_order_rows_ws_bytes(int cap, int64_t *bytes_host);
+int dcl_order_rows(const int32_t *out_indices, const int32_t *n_out_dev, int n_out_host, int cap, const uint32_t *in_mask,
+                   int S_in, int subm, void *ws, int64_t ws_bytes, int32_t *order, int32_t *bal, uint32_t *smask,
+                   dclStream_t stream);
+int dcl_sparse_conv_fwd_ordered(const float *feat, const int32_t *nbr, int cap, const int32_t *n_out_dev, int n_out_host,
+                                const float *W, int cin, int cout, int kvol, int subm, const float *scale,
+                                const float *shift, int relu, float *out, float *scratch, int64_t scratch_floats,
+                                const int32_t *order, const int32_t *bal, const uint32_t *smask, dclStream_t stream);
 int dcl_sparse_conv_scratch_floats(int rows_cap, int cout, int64_t *floats_host);
 
 /* indiceSummaryRF + indice_avgpool_fp32 (use_gs=False): rf[o] = #valid offsets,
@@ -463,9 +483,9 @@ void dcl_debug_conv_split(int n);
 /* Tuning hook: number of workgroups the stream-K / split-K decompositions of a sparse-conv launch are dealt over (default
  * 512 = the 2 x 256 resident slots; 256 leaves one slot per CU to a concurrent launch of the other backbone).  64..512. */
 void dcl_debug_conv_slots(int n);
-/* Experiment hook (tools/sort_experiment.py): device array [prefix of used steps per 128-row tile (nblk + 1) | step masks
- * (nblk)] -- while set, LDS-DMA conv launches with Cin >= 32 deal their work in USED chunks; NULL switches it off. */
-void dcl_debug_conv_balance(const int32_t *bal_dev);
+/* Test hook, row order of the LDS-DMA conv launches (dcl_sparse_conv_fwd_ordered, the backbone runner): 0 = as given,
+ * 1 = ignore the order (natural rows, nominal units), 2 = keep the order but deal nominal chunk units. */
+void dcl_debug_conv_order_mode(int mode);
 /* Tuning hook: 1 (default) = the LDS-DMA conv kernel renumbers its workgroups XCD-aware (column tiles of a row tile and
  * neighbouring row tiles share an L2), 0 = plain blockIdx order. */
 void dcl_debug_conv_xcd_remap(int on);

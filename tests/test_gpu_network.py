@@ -422,12 +422,12 @@ def test_graph_cache_is_bounded(dcl, monkeypatch):
         assert [k[0] for k in net._graphs] == [2, 3, 1], rep
     third = net(dcl.synth.make_batch(4, n, n, first=4))
     assert [k[0] for k in net._graphs] == [3, 1, 4]
-    assert float((third["rot_pred"] - outs[4]["rot_pred"]).abs().max()) <= 1e-5   # graph replay == launch by launch
+    assert float((third["rot_pred"] - outs[4]["rot_pred"]).abs().max()) <= R_TOL  # graph replay vs launch by launch: other GEMM tilings
     net(dcl.synth.make_batch(1, n, n, first=1))                                   # 1 touched again: 3 is the LRU now
     for _ in range(3):
         again = net(dcl.synth.make_batch(2, n, n, first=2))                       # evicted earlier -> admitted on the 3rd call
     assert [k[0] for k in net._graphs] == [4, 1, 2]
-    assert float((again["rot_pred"] - outs[2]["rot_pred"]).abs().max()) <= 1e-5
+    assert float((again["rot_pred"] - outs[2]["rot_pred"]).abs().max()) <= R_TOL
     # a column-sliced (non-contiguous) resident input takes the copy_() staging instead of tripping pad_copy_many's asserts
     d = dcl.synth.make_batch(1, n, n, first=1)
     wide = torch.zeros((d["inp"]["feats"].shape[0], 9), device="cuda")

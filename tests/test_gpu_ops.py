@@ -231,48 +231,82 @@ def test_sparse_conv_decompositions_agree_across_sizes(request, dcl, cin, cout):
             assert torch.equal(got, dcl.ops.sparse_conv(feat, nbr, n_out, W, subm))          # reproducible
 
 
-@pytest.mark.parametrize("cin,cout", [(64, 64), (128, 128), (32, 64)])
-def test_sparse_conv_used_chunk_dealing_prototype(request, dcl, cin, cout):
-    """experiment hook dcl_debug_conv_balance: rows of a dilating conv sorted by which neighbour planes exist, stream-K work
-    dealt in USED chunks (per-tile step masks + prefix from the host) -- same result as the VALU kernel on the same table,
-    reproducible, and the hook really is off afterwards"""
-    import ctypes
+def _plane_key(valid27):
+    """9-bit key of csrc/row_order.hip::plane_key from a (27, n) bool table of present neighbours (k = kz + 3 ky + 9 kx)"""
+    v3 = valid27.view(3, 3, 3, -1)                                             # [kx][ky][kz]
+    key = torch.zeros(valid27.shape[1], dtype=torch.int64, device=valid27.device)
+    bit = 0
+    for ax in range(3):                                                        # x planes: bits 0-2, y: 3-5, z: 6-8
+        for q in range(3):
+            key |= v3.select(ax, q).reshape(9, -1).any(0).long() << bit
+            bit += 1
+    return key
+
+
+@pytest.mark.parametrize("S,per,subm", [(32, 3000, False), (16, 700, True), (8, 90, False), (64, 1500, True)])
+def test_row_order_is_the_stable_sort_by_neighbourhood_shape(dcl, S, per, subm):
+    """dcl_order_rows: order == the STABLE argsort of the 9-bit plane key computed from the layer's own gather table, the
+    tiles' step masks / used-step prefix follow from it, and two runs give the same bits"""
+    rng = np.random.default_rng(S + per)
+    b = 5
+    idx = rand_voxels(rng, b, S, per)
+    aset = dcl.ops.grid_from_indices(cuda(idx), b, S)
+    out, nbr = dcl.spconv.ops.build_rulebook(aset, 3, 1, 1, subm)
+    n = out.n
+    order, bal, smask = dcl.ops.order_rows(out, aset.mask, subm)
+    valid = nbr[:, :n] >= 0
+    want = torch.argsort(_plane_key(valid), stable=True).int()
+    assert torch.equal(order, want)
+    nt = (n + 127) // 128
+    vs = torch.cat([valid[:, want.long()], torch.zeros(27, nt * 128 - n, dtype=torch.bool, device="cuda")], 1)
+    used = vs.view(27, nt, 128).any(2)                                          # [offset k][tile]
+    steps = list(range(27)) if not subm else [13] + list(range(13)) + list(range(14, 27))    # visiting order (centre first)
+    want_mask = sum(used[k].long() << s for s, k in enumerate(steps))
+    assert torch.equal(smask.long() & 0xFFFFFFFF, want_mask)
+    cnt = used.sum(0)
+    assert torch.equal(bal.long(), torch.cat([torch.zeros(1, dtype=torch.long, device="cuda"), cnt.cumsum(0)]))
+    again = dcl.ops.order_rows(out, aset.mask, subm)
+    assert all(torch.equal(x, y) for x, y in zip((order, bal, smask), again))
+
+
+@pytest.mark.parametrize("cin,cout,subm", [(64, 64, False), (128, 128, False), (32, 64, True), (128, 256, True), (32, 32, False),
+                                           (16, 32, True)])
+def test_sparse_conv_in_row_order_matches_the_plain_launch(request, dcl, oracle, cin, cout, subm):
+    """the product path of the big launches: rows ordered on the device (dcl_order_rows), work dealt in USED chunks -- same
+    values as the oracle / the natural-order launch within the fp32 summation tolerance, every output row written exactly
+    once, reproducible bits; A/B modes of the diagnostic library (order ignored / order with nominal units) agree too"""
     rng = np.random.default_rng(cin + cout)
-    lib = enter_diag(dcl, request)      # kernel variants live in the diagnostic library only (tests/_diag)
-    W = cuda((rng.normal(size=(27, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32))
-    idx = rand_voxels(rng, 6, 32, 4000)
-    aset = dcl.ops.grid_from_indices(cuda(idx), 6, 32)
-    out, nbr = dcl.spconv.ops.build_rulebook(aset, 3, 1, 1, False)
+    b, S = 6, 32
+    idx = rand_voxels(rng, b, S, 4000 if not subm else 6000)
+    aset = dcl.ops.grid_from_indices(cuda(idx), b, S)
+    out, nbr = dcl.spconv.ops.build_rulebook(aset, 3, 1, 1, subm)
     n = out.n
     feat = cuda(rng.normal(size=(idx.shape[0], cin)).astype(np.float32))
-    valid = nbr[:, :n] >= 0
-    v3 = valid.view(3, 3, 3, n)
-    key = torch.zeros(n, dtype=torch.int64, device="cuda")
-    for ax in range(3):
-        for q in range(3):
-            key = key * 2 + v3.select(ax, q).reshape(9, n).any(0).long()
-    nbr_s = nbr[:, :n][:, torch.argsort(key, stable=True)].contiguous()
-    nblk = (n + 127) // 128
-    vs = torch.cat([nbr_s >= 0, torch.zeros(27, nblk * 128 - n, dtype=torch.bool, device="cuda")], 1)
-    used = vs.view(27, nblk, 128).any(2)
-    smask = (used.long() << torch.arange(27, device="cuda").view(27, 1)).sum(0)
-    bal = torch.cat([torch.zeros(1, dtype=torch.long, device="cuda"), used.sum(0).cumsum(0), smask]).int().contiguous()
-    assert int(used.sum(0).min()) > 0 and float(used.sum(0).float().mean()) < 26.0          # every tile has work, many skip offsets
-    lib.dcl_debug_force_valu_conv(1)
-    try:
-        ref = dcl.ops.sparse_conv(feat, nbr_s, n, W, False)
-    finally:
-        lib.dcl_debug_force_valu_conv(0)
-    plain = dcl.ops.sparse_conv(feat, nbr_s, n, W, False)
-    lib.dcl_debug_conv_balance(ctypes.c_void_p(bal.data_ptr()))
-    try:
-        got = dcl.ops.sparse_conv(feat, nbr_s, n, W, False)
-        again = dcl.ops.sparse_conv(feat, nbr_s, n, W, False)
-    finally:
-        lib.dcl_debug_conv_balance(None)
-    tol = 2e-5 * max(1.0, float(ref.abs().max()))
-    assert float((got - ref).abs().max()) <= tol and torch.equal(got, again)
-    assert torch.equal(dcl.ops.sparse_conv(feat, nbr_s, n, W, False), plain)
+    W = cuda((rng.normal(size=(27, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32))
+    order = dcl.ops.order_rows(out, aset.mask, subm)
+    plain = dcl.ops.sparse_conv(feat, nbr, n, W, subm)
+    got = dcl.ops.sparse_conv(feat, nbr, n, W, subm, order=order)
+    tol = 2e-5 * max(1.0, float(plain.abs().max()))
+    assert float((got - plain).abs().max()) <= tol
+    assert torch.equal(got, dcl.ops.sparse_conv(feat, nbr, n, W, subm, order=order))
+    s_ = cuda(rng.uniform(0.5, 1.5, cout).astype(np.float32))
+    t_ = cuda(rng.normal(size=cout).astype(np.float32))
+    got2 = dcl.ops.sparse_conv(feat, nbr, n, W, subm, s_, t_, True, order=order)
+    assert float((got2 - torch.relu(plain * s_ + t_)).abs().max()) <= 2 * tol
+    # a poisoned output buffer: every row must be written (the order is a permutation of the rows)
+    assert bool(torch.isfinite(got).all())
+    r_out, r_pairs, r_num, _ = oracle.get_indice_pairs(idx, b, [S] * 3, 3, 1, 1, 1, subm=subm)
+    sub = slice(0, 20000)
+    want = oracle.indice_conv(feat.cpu().numpy(), W.cpu().numpy().reshape(3, 3, 3, cin, cout), r_pairs, r_num, n, subm=subm)
+    assert np.abs(got.cpu().numpy()[sub] - want[sub]).max() <= 2e-5 * max(1.0, np.abs(want).max())
+    lib = enter_diag(dcl, request)
+    for mode in (1, 2):
+        lib.dcl_debug_conv_order_mode(mode)
+        try:
+            alt = dcl.ops.sparse_conv(feat, nbr, n, W, subm, order=order)
+        finally:
+            lib.dcl_debug_conv_order_mode(0)
+        assert float((alt - plain).abs().max()) <= tol, mode
 
 
 @pytest.mark.parametrize("c", [32, 7])
