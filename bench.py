@@ -246,6 +246,121 @@ def lm_stream_bench(dcl, dev, reps=30):
     return out
 
 
+def eval_stream_bench(dcl, dev, images=40, n_obj=6):
+    """The reference's eval loop as ONE pipeline (tools/test_YCBV_stage1.py:173-199; SURVEY 8f-1 + path + 8f-2): per 480x640
+    frame with `n_obj` objects  CropBuilder.build -> Network.forward -> ADD-S -> per-class table,  frames resident in HBM
+    (decoded ahead, like the forward's own inputs), N = M = 1024, 6 mm voxels.  Two schedules: `serial` = the reference's
+    order, one frame after the other on one stream; `pipelined` = frame k+1 is built on a second stream (its two host
+    synchronisations and the loader's np.random.choice draws then run underneath frame k's forward; the network waits for the
+    builder's ready_event).  Same crops, same results.  The ADD-S values stay on the device until the stream ends (one
+    read-back for the table).  Also reported: each stage alone (device-synchronised), and the LineMOD-regime variant
+    (tools/test_LM.py:104-141: one object per frame, 5 mm voxels, ADD / ADD-S by symmetry flag, success counts)."""
+    out = {}
+    bstream = torch.cuda.Stream(dev)
+    for tag, unit, n_o in (("ycbv", 0.006, n_obj), ("linemod", 0.005, 1)):
+        cfg_b = dict(input_size=1024, tmp_size=1024, unit_voxel_extent=[unit] * 3, voxel_num_limit=[64] * 3, voxelization_mode=4)
+        frames = [dcl.synth.make_frame(500 + i, n_obj=n_o, tmp_size=1024) for i in range(4)]
+        builder = dcl.crops.CropBuilder(cfg_b, frames[0]["cad_pts"], frames[0]["cad_col"], device=dev)
+        res = [dcl.crops.CropBuilder.resident(f["img"], f["depth"], f["label"], dev) for f in frames]
+        net = dcl.DCL_Net.Network(dcl.synth.default_cfg(1024, 1024, unit=unit), mode="test")     # default routing: graph replay
+        net.load_state_dict(dcl.synth.synth_state_dict(net, 1))
+        net = net.to(dev).eval()
+        sym = torch.tensor([0, 1] * 16, dtype=torch.int32, device=dev)
+        main = torch.cuda.current_stream(dev)
+
+        def build(i):
+            f, (im, de, la) = frames[i % 4], res[i % 4]
+            return builder.build(im, de, la, f["rois"], f["gt_obj"], poses=f["poses"])
+
+        def build_ahead(i):                                      # on the builder stream; what main will read is marked
+            with torch.cuda.stream(bstream):
+                d = build(i)
+            for side in ("inp", "tmp"):
+                for k in ("feats", "occupied_voxels", "v2p_maps"):
+                    d[side][k].record_stream(main)
+            for k in ("rot_gt", "trans_gt"):
+                d["labels"][k].record_stream(main)
+            return d
+
+        def metric(data, pred):
+            b = pred["rot_pred"].shape[0]
+            cld = data["tmp"]["feats"][:, 4:7].reshape(b, 1024, 3)
+            if tag == "linemod":
+                return dcl.sharding.add_lm(cld, pred["rot_pred"], pred["trans_pred"], data["labels"]["rot_gt"],
+                                           data["labels"]["trans_gt"], sym[:b])
+            return dcl.sharding.add_s(cld, pred["rot_pred"], pred["trans_pred"], data["labels"]["rot_gt"],
+                                      data["labels"]["trans_gt"])
+
+        def tabulate(dist_dev):                                  # the per-class lists of :190-199, from one read-back each
+            table = dcl.sharding.AddsTable() if tag == "ycbv" else dcl.sharding.LmTable([0.01] * 22)
+            for obj_idx, flags, dd in dist_dev:
+                cls = [int(c) for c, f in zip(obj_idx.tolist(), flags.tolist()) if f]
+                for c, x in zip(cls, dd.cpu().tolist()):
+                    table.add(c, float(x))
+            return table
+        res_tag = {"workload": "%d object(s) per 480x640 frame, N=M=1024, %g mm voxels" % (n_o, unit * 1e3)}
+        with torch.no_grad():
+            np.random.seed(1)
+            for i in range(6):                                   # warm-up: graph capture, builder caches
+                d = build(i)
+                metric(d, net(d))
+            torch.cuda.synchronize()
+            ref_d = None
+            for sched in ("serial", "pipelined"):
+                np.random.seed(2)
+                dist_dev, crops = [], 0
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                if sched == "serial":
+                    for i in range(images):
+                        d = build(i)
+                        p = net(d)
+                        dist_dev.append((d["obj_idx"], d["all_flags"], metric(d, p)))
+                        crops += int(p["rot_pred"].shape[0])
+                else:
+                    d = build_ahead(0)
+                    for i in range(images):
+                        main.wait_event(d["ready_event"])
+                        p = net(d)                                # queued; the host goes on to build the next frame
+                        dist_dev.append((d["obj_idx"], d["all_flags"], metric(d, p)))
+                        crops += int(p["rot_pred"].shape[0])
+                        if i + 1 < images:
+                            d = build_ahead(i + 1)
+                torch.cuda.synchronize()
+                table = tabulate(dist_dev)
+                dt = time.perf_counter() - t0
+                dd = torch.cat([x[2] for x in dist_dev]).cpu()
+                if ref_d is None:
+                    ref_d = dd
+                res_tag[sched] = {"images_per_s": round(images / dt, 1), "crops_per_s": round(crops / dt, 1),
+                                  "ms_per_image": round(dt / images * 1e3, 3)}
+                if sched == "pipelined":
+                    res_tag[sched]["same_distances_as_serial"] = bool(torch.equal(dd, ref_d))
+            # stages alone, device-synchronised
+            stage = {}
+            builder.draw_seconds = 0.0
+            t = time.perf_counter()
+            for i in range(20):
+                d = build(i)
+            torch.cuda.synchronize()
+            stage["builder_ms"] = (time.perf_counter() - t) / 20 * 1e3
+            stage["builder_ms_of_which_loader_rng_draws_on_the_host"] = builder.draw_seconds / 20 * 1e3
+            t = time.perf_counter()
+            for _ in range(20):
+                p = net(d)
+            torch.cuda.synchronize()
+            stage["forward_ms"] = (time.perf_counter() - t) / 20 * 1e3
+            t = time.perf_counter()
+            for _ in range(20):
+                metric(d, p)
+            torch.cuda.synchronize()
+            stage["metric_ms"] = (time.perf_counter() - t) / 20 * 1e3
+        res_tag["stages_alone_ms"] = {k: round(v, 3) for k, v in stage.items()}
+        res_tag["builder_host_syncs_per_frame"] = 2
+        out[tag] = res_tag
+    return out
+
+
 def refiner_bench(dcl, dev, b, iters=2, reps=20):
     """BASELINE config 5 (S4): the stage-2 refine loop (2 iterations, tools/test_YCBV_stage2.py:214-225) on b crops of
     1024 points, eager vs hipGraph-captured; ms per loop and crops/s."""
@@ -631,6 +746,7 @@ def main():
         if not args.pipelined_calls:
             line["pipelined_calls"] = pipelined_bench(dcl, dev, sd, cfg, data, b, args.steps, args.warmup, rdata_for_pipe)
         line["lm_stream"] = lm_stream_bench(dcl, dev)
+        line["eval_stream"] = eval_stream_bench(dcl, dev)
         line["primitives"] = primitives_roofline(dcl)
         line["refiner"] = refiner_bench(dcl, dev, b)
         line["cpu_baseline"] = cpu_baseline(dcl, sd, cfg, n_inp, n_tmp)

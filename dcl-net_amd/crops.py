@@ -9,6 +9,8 @@ a seeded run consumes the global numpy RNG stream exactly like the original load
 needs the per-instance point counts on the host: the one read-back of the builder (plus the {V, maxActive} read-back of
 each voxelize_idx).  No CPU fallback: the arrays are uploaded and everything else happens on the device.
 """
+import time
+
 import numpy as np
 import torch
 
@@ -91,6 +93,7 @@ class CropBuilder(object):
                                         int(self.limit[0]))
         self.tmp_feats = feats.view(len(self.cls_ids), self.n_tmp, 7)
         self.tmp_vox = coords.view(len(self.cls_ids), self.n_tmp, 4)[:, :, 1:].contiguous()
+        self.draw_seconds = 0.0                  # host time spent in the loader's np.random.choice draws (accumulated)
         # The template side of a batch is a function of the crops' CLASSES alone (:179-183,223): voxelise every class once
         # (device voxelize_idx, crop id 0) and keep the three maps on the host; a frame's maps are those tables put side by
         # side with the crop ids / row offsets applied (_template_side) -- no kernel and no read-back per frame.
@@ -178,11 +181,15 @@ class CropBuilder(object):
         if not keep:
             raise ValueError("every object mask of this image is empty")
         picks = []
+        t_draw = time.perf_counter()
         for k in keep:                                                              # :166-169, the loader's RNG calls
             m = int(cnt[k, 2])
             picks.append(np.random.choice(m, self.n_inp, replace=False) if m > self.n_inp
                          else np.random.choice(m, self.n_inp))
             flags[cand[k]] = 1
+        # (the legacy np.random.choice(m, n, replace=False) shuffles all m masked points: 0.1-0.4 ms per object -- the
+        # reference loader's own cost, kept because a seeded run must consume the global RNG stream like the original)
+        self.draw_seconds += time.perf_counter() - t_draw
         if len(keep) != len(cand):
             kt = torch.tensor(keep, device=dev)
             xyz, col, centroid, counts = xyz[kt].contiguous(), col[kt].contiguous(), centroid[kt], counts[kt].contiguous()
@@ -197,11 +204,11 @@ class CropBuilder(object):
                 "obj_idx": torch.IntTensor(gt_obj - 1), "all_flags": torch.IntTensor(flags),
                 "flags": torch.IntTensor([-1]), "all_centroids": centroid, "labels": {}, "counts": cnt[keep]}
         if poses is not None:
-            cen = centroid.cpu().numpy()
-            rot = [torch.FloatTensor(np.array(poses[:, :, cand[k]][:, 0:3])) for k in keep]
-            trans = [torch.FloatTensor(np.array([poses[:, :, cand[k]][:, 3:4].flatten()]).reshape(3) - cen[j])
-                     for j, k in enumerate(keep)]
-            data["labels"] = {"rot_gt": torch.stack(rot), "trans_gt": torch.stack(trans)}
+            # rot_gt = poses[:, 0:3], trans_gt = poses[:, 3] - centroid (:226-240: float64 difference, rounded to float32
+            # once) -- formed on the device from one small upload, so the centroids never come back to the host
+            P = torch.from_numpy(np.ascontiguousarray(np.asarray(poses, np.float64)[:, :, [cand[k] for k in keep]])).to(dev)
+            data["labels"] = {"rot_gt": P[:, 0:3, :].permute(2, 0, 1).float().contiguous(),
+                              "trans_gt": (P[:, 3, :].t() - centroid.double()).float().contiguous()}
         S = int(self.limit[0])
         occ, p2v, v2p = ops.voxelize_idx_gpu(coords_inp, b, S, self.mode)
         data["inp"] = {"feats": feats_inp, "coords": coords_inp, "occupied_voxels": occ, "p2v_maps": p2v, "v2p_maps": v2p}

@@ -70,14 +70,14 @@ struct SetLayout {
 // row order of one conv layer (row_order.hip): outputs order / bal / smask + the pass's scratch
 struct OrderLayout {
   bool on;
-  size_t order, bal, smask, rowmask, hist, tile_cnt;
-  int nblk_cap;
+  size_t order, bal, smask, tile_cnt, rowmask;
 };
 
 struct GeoLayout {
   size_t mask0, wprefix0, perm0;
   SetLayout conv[kLevels], pool[kLevels];
   OrderLayout ord[kLevels][2];          // [level][0 = the dilating conv, 1 = the submanifold conv] on the level's conv set
+  size_t tickets;                       // 16 int32: in-launch hand-off tickets of the row-order launch (zeroed every pass)
   size_t scratch, total;
 };
 
@@ -119,14 +119,13 @@ bool make_geo_layout(int batch, int S, int V0, GeoLayout *L) {
       o.on = order_layer(batch, m, q);
       if (!o.on) continue;
       const size_t cap = (size_t)L->conv[m].cap, tiles = (cap + 127) / 128;
-      o.nblk_cap = (int)((cap + 1023) / 1024);
       o.order = take(sizeof(int32_t) * cap);
       o.bal = take(sizeof(int32_t) * (tiles + 2));
       o.smask = take(sizeof(uint32_t) * (tiles + 1));
-      o.rowmask = take(sizeof(uint32_t) * cap);
-      o.hist = take(sizeof(int32_t) * 512 * (size_t)o.nblk_cap);
       o.tile_cnt = take(sizeof(int32_t) * (tiles + 1));
+      o.rowmask = take(sizeof(uint32_t) * cap);
     }
+  L->tickets = take(sizeof(int32_t) * 16);
   // scan scratch: block sums of the input grid, then of the 8 generated sets (batched scan, one slice per set)
   size_t blocks = (size_t)(nw0 + 1023) / 1024 + 2;
   for (int m = 0; m < kLevels; ++m)
@@ -216,6 +215,7 @@ static int backbone_geometry(const int32_t *occ, const int32_t *V0_dev, int V0, 
   // workgroup per crop walks the chain in LDS (64^3 grids; other sizes chain 8 launches), then all 8 sets are ranked and
   // decoded in three batched launches
   DclGeoSets g{};
+  g.zero_words = at<int32_t>(ws, L.tickets);
   size_t so = (size_t)(words(batch, S) + 1023) / 1024 + 2;
   const uint32_t *in_mask = at<uint32_t>(ws, L.mask0);
   int s = S;
@@ -262,12 +262,11 @@ static int backbone_geometry(const int32_t *occ, const int32_t *V0_dev, int V0, 
       j.subm = q;
       j.in_mask = q ? at<uint32_t>(ws, L.conv[m].mask) : at<uint32_t>(ws, L.pool[m - 1].mask);   // order_layer: m >= 1
       j.rowmask = at<uint32_t>(ws, o.rowmask);
-      j.hist = at<int32_t>(ws, o.hist);
       j.order = at<int32_t>(ws, o.order);
       j.tile_cnt = at<int32_t>(ws, o.tile_cnt);
       j.bal = at<int32_t>(ws, o.bal);
       j.smask = at<uint32_t>(ws, o.smask);
-      j.nblk_cap = o.nblk_cap;
+      j.ticket = at<int32_t>(ws, L.tickets) + njobs - 1;
     }
   return njobs ? dcl_internal_order_rows(jobs, njobs, stream) : 0;
 }

@@ -78,6 +78,7 @@ struct DclGeoSets {
   int32_t *n_out[8];        // live row count (device)
   int32_t *block_sums[8];   // scratch: one entry per 1024-word scan block
   int nwords[8], S[8], cap[8];
+  int32_t *zero_words;      // optional: 16 int32 the first batched launch zeroes (tickets of the row-order launch of the pass)
 };
 // Row ordering of one conv layer (row_order.hip): tile slot i of the launch computes output row order[i]; bal[t] = number of
 // used kernel-offset steps of the 128-row tiles in front of tile t (bal[ntiles] = all of them), smask[t] = tile t's step mask.
@@ -91,12 +92,12 @@ struct DclOrderJob {
   const int32_t *n_dev;         // live row count (device-visible) or nullptr -> n_host
   const uint32_t *in_mask;      // occupancy bits of the layer's INPUT set (k3, s1, p1: same grid side as the output set)
   uint32_t *rowmask;            // scratch [cap]: 27-bit neighbour mask per row
-  int32_t *hist;                // scratch [512][nblk_cap]: key histogram per 1024-row block, then its exclusive scan
   int32_t *order;               // out [cap]
   int32_t *tile_cnt;            // scratch [ceil(cap/128)]
   int32_t *bal;                 // out [ceil(cap/128) + 1]
   uint32_t *smask;              // out [ceil(cap/128)]
-  int n_host, cap, S_in, subm, nblk_cap;
+  int32_t *ticket;              // one int32, zero before the launch (left zero)
+  int n_host, cap, S_in, subm;
 };
 constexpr int DCL_ORDER_MAX_JOBS = 8;
 struct DclOrderJobs {

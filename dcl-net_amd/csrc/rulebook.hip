@@ -325,6 +325,7 @@ __global__ void k_enumerate(const uint32_t *__restrict__ mask, const int32_t *__
 // depend only on each other, so the geometry stage first chains the 8 mask kernels and then ranks / decodes all sets at once
 __global__ void k_block_popc_sets(const DclGeoSets g) {
   const int set = blockIdx.y, nwords = g.nwords[set];
+  if (g.zero_words && blockIdx.x == 0 && set == 0 && threadIdx.x < 16) g.zero_words[threadIdx.x] = 0;   // tickets of later launches of the pass
   if ((int)blockIdx.x * kScanWords >= nwords) return;
   const uint32_t *__restrict__ mask = g.mask[set];
   const int w0 = blockIdx.x * kScanWords + threadIdx.x * 4;

@@ -486,6 +486,8 @@ void dcl_debug_conv_slots(int n);
 /* Test hook, row order of the LDS-DMA conv launches (dcl_sparse_conv_fwd_ordered, the backbone runner): 0 = as given,
  * 1 = ignore the order (natural rows, nominal units), 2 = keep the order but deal nominal chunk units. */
 void dcl_debug_conv_order_mode(int mode);
+/* Diagnostic: s_memrealtime stamps (100 MHz) of the phases of the last row-order launch's first workgroup. */
+int dcl_debug_order_stamps(unsigned long long *host16);
 /* Tuning hook: 1 (default) = the LDS-DMA conv kernel renumbers its workgroups XCD-aware (column tiles of a row tile and
  * neighbouring row tiles share an L2), 0 = plain blockIdx order. */
 void dcl_debug_conv_xcd_remap(int on);

@@ -243,10 +243,11 @@ def _plane_key(valid27):
     return key
 
 
-@pytest.mark.parametrize("S,per,subm", [(32, 3000, False), (16, 700, True), (8, 90, False), (64, 1500, True)])
+@pytest.mark.parametrize("S,per,subm", [(32, 3000, False), (16, 700, True), (8, 90, False), (64, 1500, True), (32, 9000, True)])
 def test_row_order_is_the_stable_sort_by_neighbourhood_shape(dcl, S, per, subm):
-    """dcl_order_rows: order == the STABLE argsort of the 9-bit plane key computed from the layer's own gather table, the
-    tiles' step masks / used-step prefix follow from it, and two runs give the same bits"""
+    """dcl_order_rows: inside every window of 8192 consecutive rows, order == the STABLE argsort of the 9-bit plane key
+    computed from the layer's own gather table; the tiles' step masks / used-step prefix follow from it, and two runs give
+    the same bits"""
     rng = np.random.default_rng(S + per)
     b = 5
     idx = rand_voxels(rng, b, S, per)
@@ -255,8 +256,10 @@ def test_row_order_is_the_stable_sort_by_neighbourhood_shape(dcl, S, per, subm):
     n = out.n
     order, bal, smask = dcl.ops.order_rows(out, aset.mask, subm)
     valid = nbr[:, :n] >= 0
-    want = torch.argsort(_plane_key(valid), stable=True).int()
+    key = _plane_key(valid)
+    want = torch.cat([w0 + torch.argsort(key[w0:w0 + 8192], stable=True) for w0 in range(0, n, 8192)]).int()
     assert torch.equal(order, want)
+    assert torch.equal(torch.sort(order.long())[0], torch.arange(n, device="cuda"))       # a permutation of the rows
     nt = (n + 127) // 128
     vs = torch.cat([valid[:, want.long()], torch.zeros(27, nt * 128 - n, dtype=torch.bool, device="cuda")], 1)
     used = vs.view(27, nt, 128).any(2)                                          # [offset k][tile]
