@@ -22,6 +22,10 @@ int dcl_internal_sparse_conv_fwd(const float *feat, const DclNbrSrc &nbr, int ca
                                  int n_out_host, const float *W, int cin, int cout, int kvol, int subm, const float *scale,
                                  const float *shift, int relu, float *out, float *scratch, int64_t scratch_floats,
                                  dclStream_t stream, int counters_ready = 0, const DclRowOrder *ord = nullptr);
+int dcl_internal_sparse_conv_fwd_sides(const DclConvSides &sides, int nsides, int cin, int cout, int kvol, int subm, int relu,
+                                       float *scratch, int64_t scratch_floats, dclStream_t stream, int counters_ready = 0);
+int dcl_internal_sparse_avgpool_fwd_sides(const DclConvSides &sides, int nsides, int c, int kvol, int32_t *rf,
+                                          const int32_t *rf_in, dclStream_t stream);
 int dcl_internal_conv_split_cap(long long rows);
 int dcl_internal_order_rows(const DclOrderJobs &jobs, int njobs, dclStream_t stream);
 int dcl_internal_out_mask_k3(const uint32_t *in_mask, int batch, int S_in, int stride, uint32_t *out_mask,
@@ -287,20 +291,138 @@ DCL_API int dcl_backbone_ws2_bytes(const int32_t *counts_host, const int32_t *ch
 }
 
 // weights[2m], weights[2m+1]: (27,Cin,Cout) of module m's conv / subm conv; scale/shift: folded BatchNorm1d.
-// level_out[m]: caller-allocated (counts[2m+1], channels[2m+2]).  level_idx_out[m] (optional): receives a pointer
-// into `ws` (the level's (b,x,y,z) rows).
-static int backbone_features(const int32_t *occ, int V0, int batch, int S, void *ws, const int32_t *counts_host,
-                             const int32_t *counts_dev, const int32_t *channels_host, const float *vox_feats,
-                             const float *const *weights, const float *const *scales, const float *const *shifts,
-                             void *ws2, int64_t ws2_bytes, float *const *level_out, dclStream_t stream);
+// level_out[m]: caller-allocated (counts[2m+1], channels[2m+2]).
+// One backbone of the feature stage: its geometry, inputs, parameters and outputs.  DCL-Net runs TWO backbones of the same
+// shape (observed crops / template clouds, separate weights) per forward: backbone_features takes one or both and issues
+// every layer as ONE launch over both sides' tiles (DclConvSides), so a forward has 8 conv + 4 pool launches, not 16 + 8.
+namespace {
+struct SideArgs {
+  int V0;
+  void *ws;
+  const int32_t *counts_host, *counts_dev;
+  const float *vox_feats;
+  const float *const *weights, *const *scales, *const *shifts;
+  void *ws2;
+  int64_t ws2_bytes;
+  float *const *level_out;
+};
+}  // namespace
+
+static int backbone_features(const SideArgs *sd, int nsides, int batch, int S, const int32_t *channels_host, dclStream_t stream) {
+  DCL_CHECK_ARG(sd && nsides >= 1 && nsides <= 2 && channels_host);
+  GeoLayout L[2];
+  FeatLayout F[2];
+  for (int i = 0; i < nsides; ++i) {
+    const SideArgs &a = sd[i];
+    DCL_CHECK_ARG(a.ws && a.ws2 && a.counts_host && a.weights && a.scales && a.shifts && a.level_out);
+    DCL_CHECK_ARG(make_geo_layout(batch, S, a.V0, &L[i]) && make_feat_layout(a.counts_host, channels_host, &F[i]) &&
+                  a.ws2_bytes >= (int64_t)F[i].total);
+    DCL_CHECK_ARG((a.counts_dev != nullptr) == (sd[0].counts_dev != nullptr));
+    for (int m = 0; m < kLevels; ++m)
+      DCL_CHECK_ARG(a.counts_host[2 * m] <= L[i].conv[m].cap && a.counts_host[2 * m + 1] <= L[i].pool[m].cap);
+  }
+  // split-K scratch (partial-tile slots + tile tickets) of the launches: side 0's; the tickets are zeroed once per pass,
+  // every split launch leaves them zero again
+  float *scr = F[0].scratch_floats ? at<float>(sd[0].ws2, F[0].scratch) : nullptr;
+  const int64_t scr_floats = (int64_t)F[0].scratch_floats;
+  if (scr) dcl_internal_zero_words(scr, kConvCounterWords, (hipStream_t)stream);
+  int steps_left = dbg_steps();
+  const bool explicit_nbr = dbg_explicit_nbr() && nsides == 1;
+#define DBG_STEP() do { if (--steps_left < 0) return 0; } while (0)
+  const float *x[2];
+  const uint32_t *in_mask[2];
+  const int32_t *in_wp[2], *in_perm[2];
+  for (int i = 0; i < nsides; ++i) {
+    x[i] = sd[i].vox_feats;
+    in_mask[i] = at<uint32_t>(sd[i].ws, L[i].mask0);
+    in_wp[i] = at<int32_t>(sd[i].ws, L[i].wprefix0);
+    in_perm[i] = at<int32_t>(sd[i].ws, L[i].perm0);
+  }
+  int s = S, rc;
+  for (int m = 0; m < kLevels; ++m) {
+    const int c0 = channels_host[2 * m], c1 = channels_host[2 * m + 1], c2 = channels_host[2 * m + 2];
+    // The kernels derive their neighbour rows from the input set's occupancy grid themselves (DclNbrSrc, no gather
+    // table and no k_build_nbr launch); the diagnostic library's DCL_EXPLICIT_NBR=1 keeps the table path for A/B runs.
+    auto source = [&](int i, const int32_t *out_idx, const int32_t *n_dev, int n_host, const uint32_t *mask, const int32_t *wp,
+                      const int32_t *perm, int stride, DclNbrSrc *src) -> int {
+      if (explicit_nbr) {
+        int32_t *nbr = at<int32_t>(sd[i].ws2, F[i].nbr);
+        const int rc2 = dcl_rulebook_gather(out_idx, n_dev, n_dev ? 0 : n_host, mask, wp, perm, batch, s, 3, stride, 1, nbr,
+                                            n_host, stream);
+        *src = DclNbrSrc{nbr, nullptr, nullptr, nullptr, nullptr, 0, 1, 0};
+        return rc2;
+      }
+      *src = DclNbrSrc{nullptr, out_idx, mask, wp, perm, s, stride, 1};
+      return 0;
+    };
+    auto order_of = [&](int i, int which) -> DclRowOrder {
+      const OrderLayout &o = L[i].ord[m][which];
+      if (!o.on || explicit_nbr) return DclRowOrder{nullptr, nullptr, nullptr};
+      return DclRowOrder{at<int32_t>(sd[i].ws, o.order), at<int32_t>(sd[i].ws, o.bal), at<uint32_t>(sd[i].ws, o.smask)};
+    };
+    // conv (k3,s1,p1): out rows = conv set, inputs looked up in the previous level's set; then the submanifold conv on the
+    // conv set; then the pool onto the pool set -- each ONE launch over the sides that have rows at this level
+    for (int stage = 0; stage < 3; ++stage) {
+      DclConvSides cs{};
+      int ns = 0;
+      for (int i = 0; i < nsides; ++i) {
+        const SideArgs &a = sd[i];
+        const SetLayout &c = L[i].conv[m], &p = L[i].pool[m];
+        const int nc = a.counts_host[2 * m], np = a.counts_host[2 * m + 1];     // live counts, or capacities in capacity mode
+        const int32_t *nc_dev = a.counts_dev ? a.counts_dev + 2 * m : nullptr;
+        const int32_t *np_dev = a.counts_dev ? a.counts_dev + 2 * m + 1 : nullptr;
+        float *x1 = at<float>(a.ws2, F[i].x1), *x2 = at<float>(a.ws2, F[i].x2);
+        if (stage < 2 ? nc <= 0 : np <= 0) continue;
+        DclConvSide &Sd = cs.s[ns];
+        if (stage == 0) {
+          rc = source(i, at<int32_t>(a.ws, c.indices), nc_dev, nc, in_mask[i], in_wp[i], in_perm[i], 1, &Sd.src);
+          if (rc) return rc;
+          Sd.feat = x[i]; Sd.out = x1; Sd.cap = nc; Sd.n_dev = nc_dev; Sd.n_host = nc_dev ? 0 : nc;
+          Sd.W = a.weights[2 * m]; Sd.scale = a.scales[2 * m]; Sd.shift = a.shifts[2 * m];
+          Sd.ord = order_of(i, 0);
+        } else if (stage == 1) {
+          rc = source(i, at<int32_t>(a.ws, c.indices), nc_dev, nc, at<uint32_t>(a.ws, c.mask), at<int32_t>(a.ws, c.wprefix),
+                      nullptr, 1, &Sd.src);
+          if (rc) return rc;
+          Sd.feat = x1; Sd.out = x2; Sd.cap = nc; Sd.n_dev = nc_dev; Sd.n_host = nc_dev ? 0 : nc;
+          Sd.W = a.weights[2 * m + 1]; Sd.scale = a.scales[2 * m + 1]; Sd.shift = a.shifts[2 * m + 1];
+          Sd.ord = order_of(i, 1);
+        } else {
+          rc = source(i, at<int32_t>(a.ws, p.indices), np_dev, np, at<uint32_t>(a.ws, c.mask), at<int32_t>(a.ws, c.wprefix),
+                      nullptr, 2, &Sd.src);
+          if (rc) return rc;
+          Sd.feat = x2; Sd.out = a.level_out[m]; Sd.cap = np; Sd.n_dev = np_dev; Sd.n_host = np_dev ? 0 : np;
+          Sd.ord = DclRowOrder{nullptr, nullptr, nullptr};
+        }
+        ++ns;
+      }
+      if (ns == 0) continue;
+      DBG_STEP();
+      if (stage == 0) rc = dcl_internal_sparse_conv_fwd_sides(cs, ns, c0, c1, 27, 0, 1, scr, scr_floats, stream, 1);
+      else if (stage == 1) rc = dcl_internal_sparse_conv_fwd_sides(cs, ns, c1, c2, 27, 1, 1, scr, scr_floats, stream, 1);
+      else rc = dcl_internal_sparse_avgpool_fwd_sides(cs, ns, c2, 27, nullptr, nullptr, stream);
+      if (rc) return rc;
+    }
+    for (int i = 0; i < nsides; ++i) {
+      x[i] = sd[i].level_out[m];
+      in_mask[i] = at<uint32_t>(sd[i].ws, L[i].pool[m].mask);
+      in_wp[i] = at<int32_t>(sd[i].ws, L[i].pool[m].wprefix);
+      in_perm[i] = nullptr;
+    }
+    s = L[0].pool[m].S;
+  }
+#undef DBG_STEP
+  return 0;
+}
 
 DCL_API int dcl_backbone_features(const int32_t *occ, int V0, int batch, int S, void *ws, const int32_t *counts_host,
                                   const int32_t *channels_host, const float *vox_feats, const float *const *weights,
                                   const float *const *scales, const float *const *shifts, void *ws2, int64_t ws2_bytes,
                                   float *const *level_out, dclStream_t stream) {
+  (void)occ;
   DCL_CHECK_ARG(counts_host);
-  return backbone_features(occ, V0, batch, S, ws, counts_host, nullptr, channels_host, vox_feats, weights, scales, shifts,
-                           ws2, ws2_bytes, level_out, stream);
+  const SideArgs a{V0, ws, counts_host, nullptr, vox_feats, weights, scales, shifts, ws2, ws2_bytes, level_out};
+  return backbone_features(&a, 1, batch, S, channels_host, stream);
 }
 
 // capacity mode: every buffer is sized by the layout's capacities (dcl_backbone_caps), the live row counts are read
@@ -317,102 +439,38 @@ DCL_API int dcl_backbone_features_cap(const int32_t *occ, int V0_cap, int batch,
                                       const float *const *weights, const float *const *scales,
                                       const float *const *shifts, void *ws2, int64_t ws2_bytes,
                                       float *const *level_out, dclStream_t stream) {
+  (void)occ;
   int32_t caps[8];
   DCL_CHECK_ARG(counts_dev);
   int rc = dcl_backbone_caps(batch, S, V0_cap, caps);
   if (rc) return rc;
-  return backbone_features(occ, V0_cap, batch, S, ws, caps, counts_dev, channels_host, vox_feats, weights, scales, shifts,
-                           ws2, ws2_bytes, level_out, stream);
+  const SideArgs a{V0_cap, ws, caps, counts_dev, vox_feats, weights, scales, shifts, ws2, ws2_bytes, level_out};
+  return backbone_features(&a, 1, batch, S, channels_host, stream);
 }
 
-static int backbone_features(const int32_t *occ, int V0, int batch, int S, void *ws, const int32_t *counts_host,
-                             const int32_t *counts_dev, const int32_t *channels_host, const float *vox_feats,
-                             const float *const *weights, const float *const *scales, const float *const *shifts,
-                             void *ws2, int64_t ws2_bytes, float *const *level_out, dclStream_t stream) {
-  GeoLayout L;
-  FeatLayout F;
-  DCL_CHECK_ARG(ws && ws2 && counts_host && channels_host && weights && scales && shifts && level_out);
-  DCL_CHECK_ARG(make_geo_layout(batch, S, V0, &L) && make_feat_layout(counts_host, channels_host, &F) &&
-                ws2_bytes >= (int64_t)F.total);
-  for (int m = 0; m < kLevels; ++m)
-    DCL_CHECK_ARG(counts_host[2 * m] <= L.conv[m].cap && counts_host[2 * m + 1] <= L.pool[m].cap);
-  (void)occ;
-  int32_t *nbr = at<int32_t>(ws2, F.nbr);
-  float *x1 = at<float>(ws2, F.x1), *x2 = at<float>(ws2, F.x2);
-  const float *x = vox_feats;
-  const uint32_t *in_mask = at<uint32_t>(ws, L.mask0);
-  const int32_t *in_wp = at<int32_t>(ws, L.wprefix0);
-  const int32_t *in_perm = at<int32_t>(ws, L.perm0);
-  int s = S, rc;
-  // split-K tile tickets: zeroed once per pass, every split launch leaves them zero again
-  if (F.scratch_floats) dcl_internal_zero_words(at<float>(ws2, F.scratch), kConvCounterWords, (hipStream_t)stream);
-  int steps_left = dbg_steps();
-  const bool explicit_nbr = dbg_explicit_nbr();
-#define DBG_STEP() do { if (--steps_left < 0) return 0; } while (0)
-  for (int m = 0; m < kLevels; ++m) {
-    const SetLayout &c = L.conv[m], &p = L.pool[m];
-    const int nc = counts_host[2 * m], np = counts_host[2 * m + 1];     // live counts, or capacities in capacity mode
-    const int32_t *nc_dev = counts_dev ? counts_dev + 2 * m : nullptr;
-    const int32_t *np_dev = counts_dev ? counts_dev + 2 * m + 1 : nullptr;
-    const int c0 = channels_host[2 * m], c1 = channels_host[2 * m + 1], c2 = channels_host[2 * m + 2];
-    float *scr = F.scratch_floats ? at<float>(ws2, F.scratch) : nullptr;
-    // The kernels derive their neighbour rows from the input set's occupancy grid themselves (DclNbrSrc, no gather
-    // table and no k_build_nbr launch); DCL_EXPLICIT_NBR=1 keeps the table path for A/B runs.
-    auto source = [&](const int32_t *out_idx, const int32_t *n_dev, int n_host, const uint32_t *mask,
-                      const int32_t *wp, const int32_t *perm, int stride, DclNbrSrc *src) -> int {
-      if (explicit_nbr) {
-        const int rc2 = dcl_rulebook_gather(out_idx, n_dev, n_dev ? 0 : n_host, mask, wp, perm, batch, s, 3, stride, 1, nbr,
-                                            n_host, stream);
-        *src = DclNbrSrc{nbr, nullptr, nullptr, nullptr, nullptr, 0, 1, 0};
-        return rc2;
-      }
-      *src = DclNbrSrc{nullptr, out_idx, mask, wp, perm, s, stride, 1};
-      return 0;
-    };
-    DclNbrSrc src;
-    if (nc > 0) {
-      // conv (k3,s1,p1): out rows = conv set, inputs looked up in the previous level's set
-      DBG_STEP();
-      rc = source(at<int32_t>(ws, c.indices), nc_dev, nc, in_mask, in_wp, in_perm, 1, &src);
+// Both backbones of a forward in one feature stage: per-side arrays of 2 (index 0 / 1 = the two sides, e.g. observed /
+// template).  counts_dev != NULL selects capacity mode for both sides (V0 are then capacities, counts_host is ignored).
+DCL_API int dcl_backbone_features_pair(int batch, int S, const int32_t *channels_host, const int32_t *V0, void *const *ws,
+                                       const int32_t *const *counts_host, const int32_t *const *counts_dev,
+                                       const float *const *vox_feats, const float *const *const *weights,
+                                       const float *const *const *scales, const float *const *const *shifts, void *const *ws2,
+                                       const int64_t *ws2_bytes, float *const *const *level_out, dclStream_t stream) {
+  DCL_CHECK_ARG(V0 && ws && vox_feats && weights && scales && shifts && ws2 && ws2_bytes && level_out &&
+                (counts_dev || counts_host));
+  int32_t caps[2][8];
+  SideArgs a[2];
+  for (int i = 0; i < 2; ++i) {
+    const int32_t *ch = counts_host ? counts_host[i] : nullptr;
+    const int32_t *cd = counts_dev ? counts_dev[i] : nullptr;
+    if (cd) {
+      const int rc = dcl_backbone_caps(batch, S, V0[i], caps[i]);
       if (rc) return rc;
-      DBG_STEP();
-      const DclRowOrder ord_c{L.ord[m][0].on ? at<int32_t>(ws, L.ord[m][0].order) : nullptr,
-                              L.ord[m][0].on ? at<int32_t>(ws, L.ord[m][0].bal) : nullptr,
-                              L.ord[m][0].on ? at<uint32_t>(ws, L.ord[m][0].smask) : nullptr};
-      const DclRowOrder ord_s{L.ord[m][1].on ? at<int32_t>(ws, L.ord[m][1].order) : nullptr,
-                              L.ord[m][1].on ? at<int32_t>(ws, L.ord[m][1].bal) : nullptr,
-                              L.ord[m][1].on ? at<uint32_t>(ws, L.ord[m][1].smask) : nullptr};
-      rc = dcl_internal_sparse_conv_fwd(x, src, nc, nc_dev, nc_dev ? 0 : nc, weights[2 * m], c0, c1, 27, 0, scales[2 * m],
-                                        shifts[2 * m], 1, x1, scr, (int64_t)F.scratch_floats, stream, 1,
-                                        explicit_nbr ? nullptr : &ord_c);
-      if (rc) return rc;
-      // submanifold conv on the conv set
-      DBG_STEP();
-      rc = source(at<int32_t>(ws, c.indices), nc_dev, nc, at<uint32_t>(ws, c.mask), at<int32_t>(ws, c.wprefix), nullptr, 1,
-                  &src);
-      if (rc) return rc;
-      DBG_STEP();
-      rc = dcl_internal_sparse_conv_fwd(x1, src, nc, nc_dev, nc_dev ? 0 : nc, weights[2 * m + 1], c1, c2, 27, 1,
-                                        scales[2 * m + 1], shifts[2 * m + 1], 1, x2, scr, (int64_t)F.scratch_floats, stream, 1,
-                                        explicit_nbr ? nullptr : &ord_s);
-      if (rc) return rc;
+      ch = caps[i];
     }
-    if (np > 0) {
-      DBG_STEP();
-      rc = source(at<int32_t>(ws, p.indices), np_dev, np, at<uint32_t>(ws, c.mask), at<int32_t>(ws, c.wprefix), nullptr, 2,
-                  &src);
-      if (rc) return rc;
-      DBG_STEP();
-      rc = dcl_internal_sparse_avgpool_fwd(x2, src, np, np_dev, np_dev ? 0 : np, c2, 27, level_out[m], nullptr, stream);
-      if (rc) return rc;
-    }
-    x = level_out[m];
-    in_mask = at<uint32_t>(ws, p.mask);
-    in_wp = at<int32_t>(ws, p.wprefix);
-    in_perm = nullptr;
-    s = p.S;
+    DCL_CHECK_ARG(ch);
+    a[i] = SideArgs{V0[i], ws[i], ch, cd, vox_feats[i], weights[i], scales[i], shifts[i], ws2[i], ws2_bytes[i], level_out[i]};
   }
-  return 0;
+  return backbone_features(a, 2, batch, S, channels_host, stream);
 }
 
 // Byte offsets of level m's rows / prefix inside the geometry workspace (for callers that want the voxel ids).

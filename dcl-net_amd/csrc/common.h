@@ -87,6 +87,22 @@ struct DclRowOrder {
   const int32_t *bal;
   const uint32_t *smask;
 };
+// One problem of a (possibly grouped) sparse-conv / avg-pool launch.  DCL-Net's two backbones (observed crops / template
+// clouds) run the same layer shapes on different active sets with different weights: a grouped launch deals the tiles of
+// both over the same resident workgroup slots, so the fixed part of a launch (ramp, tail, combine) is paid once per layer
+// instead of once per layer and side.
+struct DclConvSide {
+  const float *feat;
+  DclNbrSrc src;
+  const int32_t *n_dev;         // live output rows (device-visible) or nullptr -> n_host
+  const float *W, *scale, *shift;
+  float *out;
+  DclRowOrder ord;
+  int cap, n_host;
+};
+struct DclConvSides {
+  DclConvSide s[2];
+};
 struct DclOrderJob {
   const int32_t *out_indices;   // (rows, 4) [b,x,y,z] of the layer's output set
   const int32_t *n_dev;         // live row count (device-visible) or nullptr -> n_host

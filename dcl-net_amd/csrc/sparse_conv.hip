@@ -24,6 +24,10 @@ int dcl_internal_sparse_conv_fwd(const float *feat, const DclNbrSrc &nbr, int ca
                                  dclStream_t stream, int counters_ready = 0, const DclRowOrder *ord = nullptr);
 int dcl_internal_sparse_avgpool_fwd(const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev,
                                     int n_out_host, int c, int kvol, float *out, int32_t *rf, dclStream_t stream);
+int dcl_internal_sparse_conv_fwd_sides(const DclConvSides &sides, int nsides, int cin, int cout, int kvol, int subm, int relu,
+                                       float *scratch, int64_t scratch_floats, dclStream_t stream, int counters_ready = 0);
+int dcl_internal_sparse_avgpool_fwd_sides(const DclConvSides &sides, int nsides, int c, int kvol, int32_t *rf,
+                                          const int32_t *rf_in, dclStream_t stream);
 
 namespace {
 
@@ -71,28 +75,35 @@ __global__ void k_sparse_conv_valu(const float *__restrict__ feat, const DclNbrS
 // one thread per output row, all COUT channels in registers; W (kvol x CIN x COUT) lives in LDS and is read as
 // wave-uniform broadcasts.  Same summation order as the generic kernel (per offset an ascending-ci fmaf chain, then one add).
 template <int CIN, int COUT>
-__global__ __launch_bounds__(256) void k_sparse_conv_stem(const float *__restrict__ feat, const DclNbrSrc src,
-                                                          int cap, const int32_t *__restrict__ n_out_dev, int n_out_host,
-                                                          const float *__restrict__ W, int kvol, int subm,
-                                                          const float *__restrict__ scale, const float *__restrict__ shift,
-                                                          int relu, float *__restrict__ out) {
-  __shared__ __attribute__((aligned(16))) float Ws[27 * CIN * COUT];
-  int n = n_out_dev ? *n_out_dev : n_out_host;
-  n = n < cap ? n : cap;
-  for (int i = threadIdx.x; i < kvol * CIN * COUT; i += 256) Ws[i] = W[i];
+__global__ __launch_bounds__(256) void k_sparse_conv_stem(const DclConvSides sides, int nsides, int kvol, int subm, int relu) {
+  __shared__ __attribute__((aligned(16))) float Ws[2 * 27 * CIN * COUT];         // both sides' filters
+  int n0 = sides.s[0].n_dev ? *sides.s[0].n_dev : sides.s[0].n_host;
+  n0 = n0 < sides.s[0].cap ? n0 : sides.s[0].cap;
+  int n1 = 0;
+  if (nsides > 1) {
+    n1 = sides.s[1].n_dev ? *sides.s[1].n_dev : sides.s[1].n_host;
+    n1 = n1 < sides.s[1].cap ? n1 : sides.s[1].cap;
+  }
+  for (int i = threadIdx.x; i < kvol * CIN * COUT; i += 256) {
+    Ws[i] = sides.s[0].W[i];
+    if (nsides > 1) Ws[27 * CIN * COUT + i] = sides.s[1].W[i];
+  }
   __syncthreads();
-  for (int row = blockIdx.x * 256 + threadIdx.x; row < n; row += gridDim.x * 256) {
+  for (int g = blockIdx.x * 256 + threadIdx.x; g < n0 + n1; g += gridDim.x * 256) {
+    const int second = g >= n0 ? 1 : 0;
+    const DclConvSide &S = sides.s[second];
+    const int row = g - (second ? n0 : 0);
     float acc[COUT];
 #pragma unroll
     for (int co = 0; co < COUT; ++co) acc[co] = 0.0f;
     for (int s = 0; s < kvol; ++s) {
       const int k = offset_at(s, kvol, subm);
-      const int v = dcl_nbr_at(src, cap, k, row);
+      const int v = dcl_nbr_at(S.src, S.cap, k, row);
       if (v < 0) continue;
       float f[CIN];
 #pragma unroll
-      for (int ci = 0; ci < CIN; ++ci) f[ci] = feat[(size_t)v * CIN + ci];
-      const float *w = Ws + k * CIN * COUT;
+      for (int ci = 0; ci < CIN; ++ci) f[ci] = S.feat[(size_t)v * CIN + ci];
+      const float *w = Ws + second * 27 * CIN * COUT + k * CIN * COUT;
       float part[COUT];
 #pragma unroll
       for (int co = 0; co < COUT; ++co) part[co] = 0.0f;
@@ -106,11 +117,11 @@ __global__ __launch_bounds__(256) void k_sparse_conv_stem(const float *__restric
 #pragma unroll
     for (int co = 0; co < COUT; ++co) {
       float x = acc[co];
-      if (scale) x = x * scale[co] + shift[co];
+      if (S.scale) x = x * S.scale[co] + S.shift[co];
       if (relu) x = fmaxf(x, 0.0f);
       acc[co] = x;
     }
-    float4 *o = reinterpret_cast<float4 *>(out + (size_t)row * COUT);
+    float4 *o = reinterpret_cast<float4 *>(S.out + (size_t)row * COUT);
 #pragma unroll
     for (int q = 0; q < COUT / 4; ++q) o[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
   }
@@ -402,10 +413,8 @@ __device__ __forceinline__ unsigned conv_lds_addr(const float *p) {
 // 128x128 (Cout % 128 == 0, 8 waves, 32 flop/B) and 128x64 (4 waves) here.
 template <int CIN, int WR, int WCW, int NT>
 __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma(   // 2 workgroups per CU (LDS allows 2)
-    const float *__restrict__ feat, const DclNbrSrc src, int cap, const int32_t *__restrict__ n_out_dev,
-    int n_out_host, const float *__restrict__ W, int cout, int kvol, int subm, const float *__restrict__ scale,
-    const float *__restrict__ shift, int relu, float *__restrict__ out, float *__restrict__ partial, int stream_k,
-    int aligned_ns, int xcd_remap, int32_t *__restrict__ tile_counters, const DclRowOrder ord, int use_bal) {
+    const DclConvSides sides, int nsides, int cout, int kvol, int subm, int relu, float *__restrict__ partial, int stream_k,
+    int aligned_ns, int xcd_remap, int32_t *__restrict__ tile_counters, int use_bal) {
   constexpr int NW = WR * WCW, NTHR = 64 * NW;
   constexpr int BM = 32 * WR, BN = 32 * NT * WCW, KC = 32;
   constexpr int AT = BM * KC, BT = KC * BN, ST = AT + BT;      // floats per stage
@@ -419,8 +428,15 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
   unsigned *s_kmask = reinterpret_cast<unsigned *>(Ns + 27 * BM);
   int32_t *s_rows = reinterpret_cast<int32_t *>(s_kmask + 4);         // output row of every tile slot (-1 = none): the row order
 
-  int n = n_out_dev ? *n_out_dev : n_out_host;
-  n = n < cap ? n : cap;
+  // the launch's problems ("sides": the observed / template backbone of the same layer; one for a plain call): their
+  // live row counts and tile counts -- every workgroup needs both to find its place in the common unit sequence
+  int n0 = sides.s[0].n_dev ? *sides.s[0].n_dev : sides.s[0].n_host;
+  n0 = n0 < sides.s[0].cap ? n0 : sides.s[0].cap;
+  int n1 = 0;
+  if (nsides > 1) {
+    n1 = sides.s[1].n_dev ? *sides.s[1].n_dev : sides.s[1].n_host;
+    n1 = n1 < sides.s[1].cap ? n1 : sides.s[1].cap;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int wr = wave / WCW, wc = wave % WCW;
@@ -438,21 +454,24 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
   // tiles, whose gathered input rows overlap) -- not in capacity mode, where the live work occupies the low ids only
   int wid = blockIdx.x;
   const int G = gridDim.x;
-  if (xcd_remap && n_out_dev == nullptr) {
+  if (xcd_remap && sides.s[0].n_dev == nullptr) {
     const int xq = G >> 3, xr = G & 7, xcd = wid & 7;
     wid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (wid >> 3);
   }
-  const int nblk = (n + BM - 1) / BM, ncol = cout / BN;
+  const int nblk0 = (n0 + BM - 1) / BM, nblk1 = (n1 + BM - 1) / BM, ncol = cout / BN;
   const int C = (kvol * CIN + KC - 1) / KC;                    // chunks per tile
   // (32-bit unit arithmetic: tiles * C < 2^31 for every launch the host code makes -- 64-bit divisions would cost
   // dozens of VGPRs in a kernel that sits at the 128-register limit)
   // Row order (row_order.hip): tile slot i computes output row ord.order[i] -- rows sorted by the shape of their
   // neighbourhood, so that a tile's rows use the same few kernel offsets.  use_bal (stream-K only, CIN >= 32): the units are
   // USED chunks -- ord.bal[0..nblk] is the prefix of the row tiles' used-step counts, ord.smask[] their step masks -- so a
-  // row tile with few used offsets costs its workgroups proportionally less
-  const int32_t *__restrict__ bal = use_bal ? ord.bal : nullptr;
+  // row tile with few used offsets costs its workgroups proportionally less.  The unit sequence of a grouped launch is side
+  // 0's units followed by side 1's (tiles never straddle the sides).
   constexpr int CPKH = CIN >= KC ? CIN / KC : 1;
-  const int total = bal ? bal[nblk] * ncol * CPKH : nblk * ncol * C;
+  const int units0 = use_bal ? sides.s[0].ord.bal[nblk0] * ncol * CPKH : nblk0 * ncol * C;
+  const int units1 = nsides > 1 ? (use_bal ? sides.s[1].ord.bal[nblk1] * ncol * CPKH : nblk1 * ncol * C) : 0;
+  const int total = units0 + units1;
+  const int nblk = nblk0 + nblk1;                              // row tiles of the launch (aligned split-K numbers them through)
   int U = C, u = wid * C, u_end = total;                       // stream_k == 0: tile wid, wid + G, ...
   if (aligned_ns) {
     const int tl = wid / aligned_ns, seg = wid - tl * aligned_ns;
@@ -470,18 +489,35 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
   while (u < u_end) {
     int tile, j_begin, nchunks, tile_lo, tile_hi, blk, by;
     bool whole;
+    // which side this segment belongs to, and that side's problem (uniform: scalar loads of ONE side's descriptor)
+    const int second = u >= units0 ? 1 : 0;
+    const DclConvSide &S = sides.s[second];
+    const float *__restrict__ feat = S.feat;
+    const DclNbrSrc src = S.src;
+    const int cap = S.cap;
+    const float *__restrict__ W = S.W;
+    const float *__restrict__ scale = S.scale;
+    const float *__restrict__ shift = S.shift;
+    float *__restrict__ out = S.out;
+    const DclRowOrder ord = S.ord;
+    const int32_t *__restrict__ bal = use_bal ? ord.bal : nullptr;
+    const int n = second ? n1 : n0;
+    const int ubase = second ? units0 : 0, tbase = second ? nblk0 * ncol : 0;       // first unit / tile of the side
+    const int ul = u - ubase;                                                        // the side's own unit index
+    const int ul_end = (u_end < ubase + (second ? units1 : units0) ? u_end : ubase + (second ? units1 : units0)) - ubase;
     if (bal) {
-      int lo = 0, hi = nblk;                                   // largest row tile whose first unit is <= u
+      const int nblk_s = second ? nblk1 : nblk0;
+      int lo = 0, hi = nblk_s;                                 // largest row tile whose first unit is <= ul
       while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
-        if (bal[mid] * ncol * CPKH <= u) lo = mid; else hi = mid;
+        if (bal[mid] * ncol * CPKH <= ul) lo = mid; else hi = mid;
       }
       blk = lo;
       const int cnt = (bal[blk + 1] - bal[blk]) * CPKH, base = bal[blk] * ncol * CPKH;
-      by = (u - base) / cnt;
+      by = (ul - base) / cnt;
       tile_lo = base + by * cnt;
       tile_hi = tile_lo + cnt;
-      const int v0 = u - tile_lo, v1 = cnt < v0 + (u_end - u) ? cnt : v0 + (u_end - u);
+      const int v0 = ul - tile_lo, v1 = cnt < v0 + (ul_end - ul) ? cnt : v0 + (ul_end - ul);
       const unsigned smk = ord.smask[blk];
       auto nominal = [&](int v) -> int {                       // used chunk v of the tile -> its nominal chunk index
         unsigned m = smk;
@@ -494,9 +530,9 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
       tile = blk * ncol + by;
       u += v1 - v0;
     } else {
-      tile = u / C;
-      j_begin = u - tile * C;
-      nchunks = (stream_k || aligned_ns) ? (C < j_begin + (u_end - u) ? C : j_begin + (u_end - u)) : C;   // end chunk of the segment
+      tile = ul / C;
+      j_begin = ul - tile * C;
+      nchunks = (stream_k || aligned_ns) ? (C < j_begin + (ul_end - ul) ? C : j_begin + (ul_end - ul)) : C;   // end chunk of the segment
       whole = j_begin == 0 && nchunks == C;
       blk = tile / ncol;
       by = tile - blk * ncol;
@@ -504,6 +540,9 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
       tile_hi = tile_lo + C;
       u += (stream_k || aligned_ns) ? nchunks - j_begin : G * C;
     }
+    tile_lo += ubase;                                          // slots / tickets are numbered over the whole launch
+    tile_hi += ubase;
+    tile += tbase;
     const int row0 = blk * BM, col0 = by * BN;
     CONV_STAMP(0);
 #ifdef DCL_CONV_STAMPS
@@ -871,18 +910,21 @@ __global__ void k_conv_split_reduce(const float *__restrict__ partial, int nspli
 // segments' loads in flight at once).  Same unit arithmetic as k_sparse_conv_dma; tiles owned by ONE workgroup were
 // written by it directly and are skipped.  grid = (tiles_cap, NW*NT*4*64/256), 256 threads.
 template <int WR, int WCW, int NT>
-__global__ __launch_bounds__(256) void k_conv_frag_reduce(const float *__restrict__ partial, int cap,
-                                                          const int32_t *__restrict__ n_out_dev, int n_out_host, int cout,
-                                                          int C, int G, int min_u, const float *__restrict__ scale,
-                                                          const float *__restrict__ shift, int relu,
-                                                          float *__restrict__ out) {
+__global__ __launch_bounds__(256) void k_conv_frag_reduce(const float *__restrict__ partial, const DclConvSides sides, int nsides,
+                                                          int cout, int C, int G, int min_u, int relu) {
   constexpr int NW = WR * WCW, BM = 32 * WR, BN = 32 * NT * WCW;
-  int n = n_out_dev ? *n_out_dev : n_out_host;
-  n = n < cap ? n : cap;
-  const int nblk = (n + BM - 1) / BM, ncol = cout / BN;
-  const int tile = blockIdx.x;
-  if (tile >= nblk * ncol) return;
-  const int total = nblk * ncol * C;
+  int n0 = sides.s[0].n_dev ? *sides.s[0].n_dev : sides.s[0].n_host;
+  n0 = n0 < sides.s[0].cap ? n0 : sides.s[0].cap;
+  int n1 = 0;
+  if (nsides > 1) {
+    n1 = sides.s[1].n_dev ? *sides.s[1].n_dev : sides.s[1].n_host;
+    n1 = n1 < sides.s[1].cap ? n1 : sides.s[1].cap;
+  }
+  const int ncol = cout / BN;
+  const int tiles0 = (n0 + BM - 1) / BM * ncol, tiles1 = (n1 + BM - 1) / BM * ncol;
+  const int tile = blockIdx.x;                                               // numbered over the whole launch: side 0's, then side 1's
+  if (tile >= tiles0 + tiles1) return;
+  const int total = (tiles0 + tiles1) * C;
   int U = (total + G - 1) / G;
   if (U < min_u) U = min_u;
   const int w_first = (tile * C) / U, w_last = ((tile + 1) * C - 1) / U;
@@ -897,19 +939,22 @@ __global__ __launch_bounds__(256) void k_conv_frag_reduce(const float *__restric
     if (w == w_first) a = v;
     else { a.x = a.x + v.x; a.y = a.y + v.y; a.z = a.z + v.z; a.w = a.w + v.w; }
   }
-  const int blk = tile / ncol, by = tile - blk * ncol;
+  const int second = tile >= tiles0 ? 1 : 0;
+  const DclConvSide &S = sides.s[second];
+  const int n = second ? n1 : n0, lt = tile - (second ? tiles0 : 0);
+  const int blk = lt / ncol, by = lt - blk * ncol;
   const int r = lane & 31, h = lane >> 5, wr = wave / WCW, wc = wave % WCW;
   const int co = by * BN + wc * 32 * NT + 32 * t + r;
-  const float sc = scale ? scale[co] : 1.0f, sh = scale ? shift[co] : 0.0f;
+  const float sc = S.scale ? S.scale[co] : 1.0f, sh = S.scale ? S.shift[co] : 0.0f;
   const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const int orow = blk * BM + wr * 32 + c + 8 * q + 4 * h;                 // accumulator element e = 4 q + c
     if (orow < n) {
       float x = av[c];
-      if (scale) x = x * sc + sh;
+      if (S.scale) x = x * sc + sh;
       if (relu) x = fmaxf(x, 0.0f);
-      out[(size_t)orow * cout + co] = x;
+      S.out[(size_t)orow * cout + co] = x;
     }
   }
 }
@@ -931,16 +976,19 @@ static std::atomic<int> g_conv_order_mode{0};   // A/B: 0 = as given, 1 = ignore
 #endif
 
 template <int CIN, int WR, int WCW, int NT>
-static void launch_conv_dma(int rows, const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev,
-                            int n_out_host, const float *W, int cout, int kvol, int subm, const float *scale,
-                            const float *shift, int relu, float *out, float *scratch, long long scratch_floats,
-                            int counters_ready, const DclRowOrder *ord_in, hipStream_t s) {
+static void launch_conv_dma(const DclConvSides &sides, int nsides, int cout, int kvol, int subm, int relu, float *scratch,
+                            long long scratch_floats, int counters_ready, hipStream_t s) {
   constexpr int BM = 32 * WR, BN = 32 * NT * WCW, KC = 32;
   const size_t lds = (size_t)(2 * (BM * KC + KC * BN) + 27 * BM + 4 + BM) * sizeof(float);
   (void)hipFuncSetAttribute((const void *)k_sparse_conv_dma<CIN, WR, WCW, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
-  const int nblk = dcl_div_up(rows, BM);
-  const int tiles = nblk * (cout / BN);
+  const bool capacity_mode = sides.s[0].n_dev != nullptr;
+  int rows = 0, tiles = 0;                                  // rows: of the larger side (what makes a launch "few rows")
+  for (int i = 0; i < nsides; ++i) {
+    const int r_i = sides.s[i].n_dev ? sides.s[i].cap : sides.s[i].n_host;
+    rows = r_i > rows ? r_i : rows;
+    tiles += dcl_div_up(r_i, BM) * (cout / BN);
+  }
 #ifdef DCL_CONV_STAMPS
   {
     int occ = -1;
@@ -977,7 +1025,7 @@ static void launch_conv_dma(int rows, const float *feat, const DclNbrSrc &nbr, i
   const bool never = g_conv_split == -2;
   if (scratch && scratch_floats > kConvCounterWords && tiles <= kConvCounterWords && !never) {
     const long long slots_fit = (scratch_floats - kConvCounterWords) / ((long long)2 * BM * BN);    // 2 slots per workgroup
-    const bool few = conv_few_rows(rows, n_out_dev != nullptr);
+    const bool few = conv_few_rows(rows, capacity_mode);
     long long g_stream = units / kFewChunks < kSlots ? units / kFewChunks : kSlots;
     if (g_stream > slots_fit) g_stream = slots_fit;
     long long best = dcl_div_up(tiles, kSlots) * (long long)(nchunks + kFix) * 8;                   // whole tiles
@@ -985,7 +1033,7 @@ static void launch_conv_dma(int rows, const float *feat, const DclNbrSrc &nbr, i
     if (g_conv_split > 0) {                                        // test / tuning hook: force an aligned split
       mode = 1;
       best_ns = (int)g_conv_split < nchunks ? (int)g_conv_split : nchunks;
-    } else if (few || n_out_dev) {
+    } else if (few || capacity_mode) {
       mode = 2;                                                    // live sizes unknown or tiny: even shares, >= kFewChunks
     } else {
       for (int ns = 2; ns <= kConvMaxSplit && ns * 8 <= nchunks; ++ns) {
@@ -1017,11 +1065,15 @@ static void launch_conv_dma(int rows, const float *feat, const DclNbrSrc &nbr, i
   // deferred combine of few-row launches maps tile slots to rows on its own: such launches take no order).  Used-chunk
   // dealing replaces the nominal units whenever the launch would split tiles anyway (aligned split-K / stream-K);
   // launches whose tiles fit one round of whole tiles keep them (measured: forced stream-K only adds the combine there).
-  DclRowOrder ord{nullptr, nullptr, nullptr};
+  DclConvSides sd = sides;
+  bool have_order = true, have_bal = true;
+  for (int i = 0; i < nsides; ++i) {
+    have_order = have_order && sd.s[i].ord.order != nullptr;
+    have_bal = have_bal && sd.s[i].ord.bal != nullptr && sd.s[i].ord.smask != nullptr;
+  }
   int use_bal = 0;
-  if (ord_in && ord_in->order && !deferred && BM == 128) {
-    ord = *ord_in;
-    if (ord.bal && ord.smask && CIN >= 32 && (aligned_ns || stream_k) && scratch && scratch_floats > kConvCounterWords) {
+  if (have_order && !deferred && BM == 128) {
+    if (have_bal && CIN >= 32 && (aligned_ns || stream_k) && scratch && scratch_floats > kConvCounterWords) {
       use_bal = 1;
       stream_k = 1;
       aligned_ns = 0;
@@ -1030,17 +1082,21 @@ static void launch_conv_dma(int rows, const float *feat, const DclNbrSrc &nbr, i
       partial = scratch + kConvCounterWords;
       counters = reinterpret_cast<int32_t *>(scratch);            // (already zeroed above: aligned / stream-K launches own them)
     }
+  } else {
+    for (int i = 0; i < nsides; ++i) sd.s[i].ord = DclRowOrder{nullptr, nullptr, nullptr};
   }
 #ifdef DCL_DIAG
-  if (g_conv_order_mode == 1) { ord = DclRowOrder{nullptr, nullptr, nullptr}; use_bal = 0; }   // A/B: natural row order
+  if (g_conv_order_mode == 1) {                                                                // A/B: natural row order
+    for (int i = 0; i < nsides; ++i) sd.s[i].ord = DclRowOrder{nullptr, nullptr, nullptr};
+    use_bal = 0;
+  }
   if (g_conv_order_mode == 2) use_bal = 0;                                                     // A/B: order, nominal units
 #endif
-  hipLaunchKernelGGL((k_sparse_conv_dma<CIN, WR, WCW, NT>), dim3(G), dim3(64 * WR * WCW), lds, s, feat, nbr, cap, n_out_dev,
-                     n_out_host, W, cout, kvol, subm, scale, shift, relu, out, partial, stream_k, aligned_ns, (int)g_conv_xcd_remap,
-                     counters, ord, use_bal);
+  hipLaunchKernelGGL((k_sparse_conv_dma<CIN, WR, WCW, NT>), dim3(G), dim3(64 * WR * WCW), lds, s, sd, nsides, cout, kvol, subm,
+                     relu, partial, stream_k, aligned_ns, (int)g_conv_xcd_remap, counters, use_bal);
   if (deferred)
-    hipLaunchKernelGGL((k_conv_frag_reduce<WR, WCW, NT>), dim3(tiles, WR * WCW * NT), dim3(256), 0, s, partial, cap, n_out_dev,
-                       n_out_host, cout, nchunks, G, stream_k, scale, shift, relu, out);
+    hipLaunchKernelGGL((k_conv_frag_reduce<WR, WCW, NT>), dim3(tiles, WR * WCW * NT), dim3(256), 0, s, partial, sd, nsides, cout,
+                       nchunks, G, stream_k, relu);
 }
 
 #ifdef DCL_DIAG
@@ -1078,24 +1134,36 @@ static void launch_conv_tile(int rows, const float *feat, const DclNbrSrc &nbr, 
 // ---- sparse average pool ------------------------------------------------------------------------
 // thread = (output row, 4 channels): rf = #valid offsets (summaryRF.cu:39), then
 // out = ((0 + f_k0/rf) + f_k1/rf) + ... in ascending offset order (avgpool.cu:130).
-__global__ __launch_bounds__(256) void k_sparse_avgpool(const float *__restrict__ feat, const DclNbrSrc src, int cap,
-                                                        const int32_t *__restrict__ n_out_dev, int n_out_host, int c, int kvol,
-                                                        float *__restrict__ out, int32_t *__restrict__ rf_out,
-                                                        const int32_t *__restrict__ rf_in) {
-  // the c/4 threads of an output row share its 27 neighbour rows through LDS (one lookup per (row, offset) per block)
+__global__ __launch_bounds__(256) void k_sparse_avgpool(const DclConvSides sides, int nsides, int c, int kvol,
+                                                        int32_t *__restrict__ rf_out, const int32_t *__restrict__ rf_in) {
+  // the c/4 threads of an output row share its 27 neighbour rows through LDS (one lookup per (row, offset) per block).
+  // Up to two problems per launch (the two backbones' pools of a level): the row blocks of side 0, then those of side 1;
+  // rf_out / rf_in (the op-level API) belong to side 0 of a one-sided launch.
   __shared__ int32_t s_v[64 * 27];
-  int n = n_out_dev ? *n_out_dev : n_out_host;
-  n = n < cap ? n : cap;
+  int n0 = sides.s[0].n_dev ? *sides.s[0].n_dev : sides.s[0].n_host;
+  n0 = n0 < sides.s[0].cap ? n0 : sides.s[0].cap;
+  int n1 = 0;
+  if (nsides > 1) {
+    n1 = sides.s[1].n_dev ? *sides.s[1].n_dev : sides.s[1].n_host;
+    n1 = n1 < sides.s[1].cap ? n1 : sides.s[1].cap;
+  }
   const int c4 = c >> 2;                                   // 4..64 and a divisor of 256 (checked by the launcher)
   const int rpb = 256 / c4;                                // output rows per block step
   const int tid = threadIdx.x;
   const int rr = tid / c4, q = tid - rr * c4;
-  for (int row0 = blockIdx.x * rpb; row0 < n; row0 += gridDim.x * rpb) {
+  const int nb0 = (n0 + rpb - 1) / rpb, nb1 = (n1 + rpb - 1) / rpb;
+  for (int bi = blockIdx.x; bi < nb0 + nb1; bi += gridDim.x) {
+    const int second = bi >= nb0 ? 1 : 0;
+    const DclConvSide &S = sides.s[second];
+    const float *__restrict__ feat = S.feat;
+    float *__restrict__ out = S.out;
+    const int n = second ? n1 : n0, cap = S.cap;
+    const int row0 = (bi - (second ? nb0 : 0)) * rpb;
     __syncthreads();
 #pragma unroll 4                                           // the lookups of up to 4 rounds in flight together (2 dependent loads each)
     for (int e = tid; e < rpb * kvol; e += 256) {
       const int r2 = e / kvol, k = e - r2 * kvol;
-      s_v[r2 * 27 + k] = row0 + r2 < n ? dcl_nbr_at(src, cap, k, row0 + r2) : -1;
+      s_v[r2 * 27 + k] = row0 + r2 < n ? dcl_nbr_at(S.src, cap, k, row0 + r2) : -1;
     }
     __syncthreads();
     const int row = row0 + rr;
@@ -1256,16 +1324,13 @@ DCL_API int dcl_profile_conv_end(double *ms_total_host, int32_t *calls_host) {
   return 0;
 }
 
-static int conv_dispatch(const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev, int n_out_host,
-                         const float *W, int cin, int cout, int kvol, int subm, const float *scale, const float *shift,
-                         int relu, float *out, float *scratch, int64_t scratch_floats, int counters_ready,
-                         const DclRowOrder *ord, dclStream_t stream);
+static int conv_dispatch(const DclConvSides &sides, int nsides, int cin, int cout, int kvol, int subm, int relu, float *scratch,
+                         int64_t scratch_floats, int counters_ready, dclStream_t stream);
 
-// library-internal: `nbr` may be an implicit rulebook (native backbone runner)
-int dcl_internal_sparse_conv_fwd(const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev,
-                                 int n_out_host, const float *W, int cin, int cout, int kvol, int subm, const float *scale,
-                                 const float *shift, int relu, float *out, float *scratch, int64_t scratch_floats,
-                                 dclStream_t stream, int counters_ready, const DclRowOrder *ord) {
+// library-internal: one layer of up to two problems ("sides") in one launch; `src` may be an implicit rulebook (native
+// backbone runner).  Timed as ONE conv call by the measurement facility above.
+int dcl_internal_sparse_conv_fwd_sides(const DclConvSides &sides, int nsides, int cin, int cout, int kvol, int subm, int relu,
+                                       float *scratch, int64_t scratch_floats, dclStream_t stream, int counters_ready) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   bool timed = false;
   {
@@ -1277,8 +1342,7 @@ int dcl_internal_sparse_conv_fwd(const float *feat, const DclNbrSrc &nbr, int ca
     (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, (hipStream_t)stream);
   }
-  const int rc = conv_dispatch(feat, nbr, cap, n_out_dev, n_out_host, W, cin, cout, kvol, subm, scale, shift, relu, out,
-                               scratch, scratch_floats, counters_ready, ord, stream);
+  const int rc = conv_dispatch(sides, nsides, cin, cout, kvol, subm, relu, scratch, scratch_floats, counters_ready, stream);
   if (timed) {
     (void)hipEventRecord(e1, (hipStream_t)stream);
     std::lock_guard<std::mutex> lock(g_conv_prof.mu);
@@ -1287,25 +1351,46 @@ int dcl_internal_sparse_conv_fwd(const float *feat, const DclNbrSrc &nbr, int ca
   return rc;
 }
 
-static int conv_dispatch(const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev, int n_out_host,
-                         const float *W, int cin, int cout, int kvol, int subm, const float *scale, const float *shift,
-                         int relu, float *out, float *scratch, int64_t scratch_floats, int counters_ready,
-                         const DclRowOrder *ord, dclStream_t stream) {
-  DCL_CHECK_ARG(feat && (nbr.nbr || (nbr.out_indices && nbr.in_mask && nbr.in_wprefix && kvol == 27)) && W && out && cap > 0 &&
-                cin > 0 && cout > 0 && kvol > 0 && kvol <= 27);
-  DCL_CHECK_ARG((scale == nullptr) == (shift == nullptr));
-  DCL_CHECK_ARG(n_out_dev || (n_out_host >= 0 && n_out_host <= cap));
-  const int rows = n_out_dev ? cap : n_out_host;
-  if (rows == 0) return 0;
+int dcl_internal_sparse_conv_fwd(const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev,
+                                 int n_out_host, const float *W, int cin, int cout, int kvol, int subm, const float *scale,
+                                 const float *shift, int relu, float *out, float *scratch, int64_t scratch_floats,
+                                 dclStream_t stream, int counters_ready, const DclRowOrder *ord) {
+  DclConvSides sides{};
+  DclConvSide &S = sides.s[0];
+  S.feat = feat; S.src = nbr; S.n_dev = n_out_dev; S.n_host = n_out_dev ? 0 : n_out_host; S.cap = cap;
+  S.W = W; S.scale = scale; S.shift = shift; S.out = out;
+  S.ord = ord ? *ord : DclRowOrder{nullptr, nullptr, nullptr};
+  return dcl_internal_sparse_conv_fwd_sides(sides, 1, cin, cout, kvol, subm, relu, scratch, scratch_floats, stream,
+                                            counters_ready);
+}
+
+static int conv_dispatch(const DclConvSides &sides_in, int nsides_in, int cin, int cout, int kvol, int subm, int relu,
+                         float *scratch, int64_t scratch_floats, int counters_ready, dclStream_t stream) {
+  DCL_CHECK_ARG(nsides_in >= 1 && nsides_in <= 2 && cin > 0 && cout > 0 && kvol > 0 && kvol <= 27);
+  // sides without rows drop out (an empty level of one backbone)
+  DclConvSides sides{};
+  int nsides = 0;
+  for (int i = 0; i < nsides_in; ++i) {
+    const DclConvSide &S = sides_in.s[i];
+    DCL_CHECK_ARG(S.feat && (S.src.nbr || (S.src.out_indices && S.src.in_mask && S.src.in_wprefix && kvol == 27)) && S.W && S.out &&
+                  S.cap > 0);
+    DCL_CHECK_ARG((S.scale == nullptr) == (S.shift == nullptr));
+    DCL_CHECK_ARG(S.n_dev || (S.n_host >= 0 && S.n_host <= S.cap));
+    DCL_CHECK_ARG((S.n_dev != nullptr) == (sides_in.s[0].n_dev != nullptr));           // capacity mode: all sides or none
+    if (S.n_dev || S.n_host > 0) sides.s[nsides++] = S;
+  }
+  if (nsides == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const bool mfma_ok = g_force_valu != 1 && (cin % 8 == 0) && (cout % 32 == 0);
   const bool lds_ok = mfma_ok && g_force_valu != 2 && (cin == 16 || cin == 32 || cin == 64 || cin == 128);
-  if (lds_ok) {
+#ifdef DCL_DIAG
+  const bool diag_tile = lds_ok && g_force_valu == 4;
+#else
+  const bool diag_tile = false;
+#endif
+  if (lds_ok && !diag_tile) {
     // LDS-DMA implicit-GEMM kernel; the tile shape follows Cout
-#define TILE_ARGS rows, feat, nbr, cap, n_out_dev, n_out_host, W, cout, kvol, subm, scale, shift, relu, out, scratch, \
-                  (long long)scratch_floats, counters_ready, s
-#define DMA_ARGS rows, feat, nbr, cap, n_out_dev, n_out_host, W, cout, kvol, subm, scale, shift, relu, out, scratch, \
-                 (long long)scratch_floats, counters_ready, ord, s
+#define DMA_ARGS sides, nsides, cout, kvol, subm, relu, scratch, (long long)scratch_floats, counters_ready, s
 #ifdef DCL_DIAG
     if (g_force_valu == 5 && cout % 128 != 0 && cout % 64 == 0) {          // A/B: 8 waves of 32x32 on 128x64 tiles
       switch (cin) {
@@ -1313,20 +1398,6 @@ static int conv_dispatch(const float *feat, const DclNbrSrc &nbr, int cap, const
         case 32: launch_conv_dma<32, 4, 2, 1>(DMA_ARGS); break;
         case 64: launch_conv_dma<64, 4, 2, 1>(DMA_ARGS); break;
         default: launch_conv_dma<128, 4, 2, 1>(DMA_ARGS); break;
-      }
-    } else if (g_force_valu == 4 && cout % 64 == 0) {                       // A/B: register-staged tile kernel
-      switch (cin) {
-        case 16: launch_conv_tile<16, 2, 128>(TILE_ARGS); break;
-        case 32: launch_conv_tile<32, 2, 128>(TILE_ARGS); break;
-        case 64: launch_conv_tile<64, 2, 128>(TILE_ARGS); break;
-        default: launch_conv_tile<128, 2, 128>(TILE_ARGS); break;
-      }
-    } else if (g_force_valu == 4) {
-      switch (cin) {
-        case 16: launch_conv_tile<16, 1, 64>(TILE_ARGS); break;
-        case 32: launch_conv_tile<32, 1, 64>(TILE_ARGS); break;
-        case 64: launch_conv_tile<64, 1, 64>(TILE_ARGS); break;
-        default: launch_conv_tile<128, 1, 128>(TILE_ARGS); break;
       }
     } else
 #endif
@@ -1353,24 +1424,56 @@ static int conv_dispatch(const float *feat, const DclNbrSrc &nbr, int cap, const
       }
     }
 #undef DMA_ARGS
-#undef TILE_ARGS
-  } else if (mfma_ok) {
-    const int ntiles = dcl_div_up(rows, 32);
-    const int nt = (cout % 64 == 0 && (long long)ntiles * (cout / 64) >= 4096) ? 2 : 1;
-    const int ytiles = cout / (32 * nt);
-    const int blocks = dcl_grid_1d(ntiles, 4, 256 * 8);
-    if (nt == 2)
-      hipLaunchKernelGGL((k_sparse_conv_mfma<2>), dim3(blocks, ytiles), dim3(256), 0, s, feat, nbr, cap, n_out_dev,
-                         n_out_host, W, cin, cout, kvol, subm, scale, shift, relu, out);
-    else
-      hipLaunchKernelGGL((k_sparse_conv_mfma<1>), dim3(blocks, ytiles), dim3(256), 0, s, feat, nbr, cap, n_out_dev,
-                         n_out_host, W, cin, cout, kvol, subm, scale, shift, relu, out);
-  } else if (cin == 7 && cout == 16 && kvol <= 27 && g_force_valu != 1) {
-    hipLaunchKernelGGL((k_sparse_conv_stem<7, 16>), dim3(dcl_grid_1d(rows, 256)), dim3(256), 0, s, feat, nbr, cap,
-                       n_out_dev, n_out_host, W, kvol, subm, scale, shift, relu, out);
+  } else if (cin == 7 && cout == 16 && kvol <= 27 && g_force_valu != 1 && !mfma_ok) {
+    int rows = 0;
+    for (int i = 0; i < nsides; ++i) rows += sides.s[i].n_dev ? sides.s[i].cap : sides.s[i].n_host;
+    hipLaunchKernelGGL((k_sparse_conv_stem<7, 16>), dim3(dcl_grid_1d(rows, 256)), dim3(256), 0, s, sides, nsides, kvol, subm,
+                       relu);
   } else {
-    hipLaunchKernelGGL(k_sparse_conv_valu, dim3(dcl_grid_1d((long long)rows * cout, 256)), dim3(256), 0, s, feat,
-                       nbr, cap, n_out_dev, n_out_host, W, cin, cout, kvol, subm, scale, shift, relu, out);
+    // the general kernels take one problem per launch
+    for (int i = 0; i < nsides; ++i) {
+      const DclConvSide &S = sides.s[i];
+      const int rows = S.n_dev ? S.cap : S.n_host;
+#ifdef DCL_DIAG
+      if (diag_tile) {                                                       // A/B: register-staged tile kernel
+        float *scr = i == 0 ? scratch : nullptr;                             // (one scratch: the second side goes unsplit)
+#define TILE_ARGS rows, S.feat, S.src, S.cap, S.n_dev, S.n_host, S.W, cout, kvol, subm, S.scale, S.shift, relu, S.out, scr, \
+                  (long long)scratch_floats, counters_ready, s
+        if (cout % 64 == 0) {
+          switch (cin) {
+            case 16: launch_conv_tile<16, 2, 128>(TILE_ARGS); break;
+            case 32: launch_conv_tile<32, 2, 128>(TILE_ARGS); break;
+            case 64: launch_conv_tile<64, 2, 128>(TILE_ARGS); break;
+            default: launch_conv_tile<128, 2, 128>(TILE_ARGS); break;
+          }
+        } else {
+          switch (cin) {
+            case 16: launch_conv_tile<16, 1, 64>(TILE_ARGS); break;
+            case 32: launch_conv_tile<32, 1, 64>(TILE_ARGS); break;
+            case 64: launch_conv_tile<64, 1, 64>(TILE_ARGS); break;
+            default: launch_conv_tile<128, 1, 128>(TILE_ARGS); break;
+          }
+        }
+#undef TILE_ARGS
+        continue;
+      }
+#endif
+      if (mfma_ok) {
+        const int ntiles = dcl_div_up(rows, 32);
+        const int nt = (cout % 64 == 0 && (long long)ntiles * (cout / 64) >= 4096) ? 2 : 1;
+        const int ytiles = cout / (32 * nt);
+        const int blocks = dcl_grid_1d(ntiles, 4, 256 * 8);
+        if (nt == 2)
+          hipLaunchKernelGGL((k_sparse_conv_mfma<2>), dim3(blocks, ytiles), dim3(256), 0, s, S.feat, S.src, S.cap, S.n_dev,
+                             S.n_host, S.W, cin, cout, kvol, subm, S.scale, S.shift, relu, S.out);
+        else
+          hipLaunchKernelGGL((k_sparse_conv_mfma<1>), dim3(blocks, ytiles), dim3(256), 0, s, S.feat, S.src, S.cap, S.n_dev,
+                             S.n_host, S.W, cin, cout, kvol, subm, S.scale, S.shift, relu, S.out);
+      } else {
+        hipLaunchKernelGGL(k_sparse_conv_valu, dim3(dcl_grid_1d((long long)rows * cout, 256)), dim3(256), 0, s, S.feat, S.src,
+                           S.cap, S.n_dev, S.n_host, S.W, cin, cout, kvol, subm, S.scale, S.shift, relu, S.out);
+      }
+    }
   }
   DCL_LAUNCH_CHECK();
   return 0;
@@ -1402,19 +1505,40 @@ int dcl_internal_sparse_avgpool_fwd(const float *feat, const DclNbrSrc &nbr, int
 
 static int avgpool_launch(const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev, int n_out_host, int c,
                           int kvol, float *out, int32_t *rf, const int32_t *rf_in, dclStream_t stream) {
-  DCL_CHECK_ARG(feat && (nbr.nbr || (nbr.out_indices && nbr.in_mask && nbr.in_wprefix && kvol == 27)) && out && cap > 0 &&
-                c > 0 && kvol > 0 && kvol <= 27);
-  DCL_CHECK_ARG(n_out_dev || (n_out_host >= 0 && n_out_host <= cap));
-  const int rows = n_out_dev ? cap : n_out_host;
-  if (rows == 0) return 0;
+  DclConvSides sides{};
+  DclConvSide &S = sides.s[0];
+  S.feat = feat; S.src = nbr; S.cap = cap; S.n_dev = n_out_dev; S.n_host = n_out_dev ? 0 : n_out_host; S.out = out;
+  return dcl_internal_sparse_avgpool_fwd_sides(sides, 1, c, kvol, rf, rf_in, stream);
+}
+
+// up to two pools (the two backbones' pools of a level) in one launch; rf / rf_in only with one side
+int dcl_internal_sparse_avgpool_fwd_sides(const DclConvSides &sides_in, int nsides_in, int c, int kvol, int32_t *rf,
+                                          const int32_t *rf_in, dclStream_t stream) {
+  DCL_CHECK_ARG(nsides_in >= 1 && nsides_in <= 2 && c > 0 && kvol > 0 && kvol <= 27 && (nsides_in == 1 || (!rf && !rf_in)));
+  DclConvSides sides{};
+  int nsides = 0;
+  long long rows = 0;
+  for (int i = 0; i < nsides_in; ++i) {
+    const DclConvSide &S = sides_in.s[i];
+    DCL_CHECK_ARG(S.feat && (S.src.nbr || (S.src.out_indices && S.src.in_mask && S.src.in_wprefix && kvol == 27)) && S.out && S.cap > 0);
+    DCL_CHECK_ARG(S.n_dev || (S.n_host >= 0 && S.n_host <= S.cap));
+    if (S.n_dev || S.n_host > 0) {
+      sides.s[nsides++] = S;
+      rows += S.n_dev ? S.cap : S.n_host;
+    }
+  }
+  if (nsides == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const int c4 = c / 4;
-  if (c % 4 == 0 && c4 >= 4 && c4 <= 64 && 256 % c4 == 0)
-    hipLaunchKernelGGL(k_sparse_avgpool, dim3(dcl_grid_1d((long long)rows * c4, 256, 2048)), dim3(256), 0, s, feat,
-                       nbr, cap, n_out_dev, n_out_host, c, kvol, out, rf, rf_in);
-  else
-    hipLaunchKernelGGL(k_sparse_avgpool_scalar, dim3(dcl_grid_1d((long long)rows * c, 256)), dim3(256), 0, s, feat,
-                       nbr, cap, n_out_dev, n_out_host, c, kvol, out, rf, rf_in);
+  if (c % 4 == 0 && c4 >= 4 && c4 <= 64 && 256 % c4 == 0) {
+    hipLaunchKernelGGL(k_sparse_avgpool, dim3(dcl_grid_1d(rows * c4, 256, 2048)), dim3(256), 0, s, sides, nsides, c, kvol, rf, rf_in);
+  } else {
+    for (int i = 0; i < nsides; ++i) {
+      const DclConvSide &S = sides.s[i];
+      hipLaunchKernelGGL(k_sparse_avgpool_scalar, dim3(dcl_grid_1d((long long)(S.n_dev ? S.cap : S.n_host) * c, 256)), dim3(256), 0,
+                         s, S.feat, S.src, S.cap, S.n_dev, S.n_host, c, kvol, S.out, rf, rf_in);
+    }
+  }
   DCL_LAUNCH_CHECK();
   return 0;
 }

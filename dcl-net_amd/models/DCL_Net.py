@@ -66,7 +66,7 @@ def _fuser():
 
 class Network(nn.Module):
     def __init__(self, cfg, mode="train", fused=True, graph_max_batch=8, async_inputs=False, graph_max_points=98304,
-                 single_stream=False, pipeline_chunks=1, capture_graph=True):
+                 single_stream=False, pipeline_chunks=1, capture_graph=True, pair_features=True):
         """graph_max_batch > 0 (default 8): eval-mode calls with at most that many crops go through forward_graphed (one
         whole-forward hipGraph per batch size, captured on first use) -- the one-image-at-a-time eval loops of the
         reference (tools/test_LM.py:104-112: one object per call) are launch-bound otherwise: 0.6 instead of 1.2-1.4 ms
@@ -81,9 +81,12 @@ class Network(nn.Module):
         single_stream=True: the whole call on the caller's stream (no side streams; what bench.py's per-kernel conv timing
         uses).  pipeline_chunks=K > 1: the sparse half in K passes over b/K crops (measured slower, kept runnable).
         capture_graph=False: forward_graphed runs its capacity-mode body launch by launch (debugging aid).  These are
-        constructor arguments on purpose: nothing on the call path reads the environment."""
+        pair_features=False: the two backbones' feature stages as separate launch sequences on their own streams (the A/B
+        of the grouped launches).  These are constructor arguments on purpose: nothing on the call path reads the
+        environment."""
         super().__init__()
         self.single_stream = bool(single_stream)
+        self.pair_features = bool(pair_features)         # both backbones' layers as ONE launch each (ops.backbone_features_pair)
         self.pipeline_chunks = int(pipeline_chunks)
         self.capture_graph = bool(capture_graph)
         self.graph_max_batch = int(graph_max_batch)
@@ -118,10 +121,22 @@ class Network(nn.Module):
         self._folded = None
 
     # ------------------------------------------------------------------ parameter folding (eval mode)
+    @staticmethod
+    def _drop_graph(ent):
+        """release a captured forward NOW: the entry's `body` closure refers back to the entry, and a cycle is only freed by
+        the cyclic collector at a moment of its choosing -- possibly in the middle of another capture, where destroying a
+        hipGraph (and freeing its pool) aborts the process.  Breaking the cycle here frees it by reference count."""
+        if ent is not None:
+            if ent.get("graph") is not None and torch.cuda.is_available():
+                torch.cuda.synchronize()                   # (evictions are rare: a replay of the graph may still be in flight)
+            ent["body"] = None
+            ent.clear()
+
     def _invalidate(self):
         """folded weights and captured graphs (which have the folded tensors' addresses baked in) follow the parameters"""
         self._folded = None
-        self.__dict__.pop("_graphs", None)
+        for ent in (self.__dict__.pop("_graphs", None) or {}).values():
+            self._drop_graph(ent)
         self.__dict__.pop("_graph_seen", None)
         self.__dict__.pop("_vlist", None)
 
@@ -310,7 +325,44 @@ class Network(nn.Module):
         off = float(np.float32(-0.5 * unit[0] * VOXEL_NUM_LIMIT[0]))
         extents = [float(np.float32(unit[0] * sc)) for sc in SCALE_LISTS]
         done = {}
-        for side, bb in (("inp", "backbone_inp"), ("tmp", "backbone_tmp")):
+        if self.pair_features and K == 1:
+            # Both sides' geometry first (each on its stream, staging underneath), ONE wait for the 16 level sizes, then the
+            # feature stage of BOTH backbones as one launch sequence -- every layer one launch over both sides' tiles -- on the
+            # observed side's stream; the two read-outs run side by side again.
+            staged = {}
+            for side in ("inp", "tmp"):
+                geometry(side)
+                stage(side)
+                staged[side] = torch.cuda.Event()
+                staged[side].record(sstream[side])
+            for side in ("inp", "tmp"):
+                geo[side].synchronize()
+                runs[side, 0].set_counts(counts_host[side].tolist()[:8])
+            mark("counts read back")
+            s_inp, s_tmp = sstream["inp"], sstream["tmp"]
+            with torch.cuda.stream(s_inp):
+                if not single:
+                    s_inp.wait_event(staged["tmp"])
+                    for t in (vox["tmp"], runs["tmp", 0].ws):
+                        t.record_stream(s_inp)
+                ops.backbone_features_pair(runs["inp", 0], vox["inp"], f["backbone_inp_ptrs"],
+                                           runs["tmp", 0], vox["tmp"], f["backbone_tmp_ptrs"])
+                feat_done = torch.cuda.Event()
+                feat_done.record(s_inp)
+                if not single:
+                    for t in runs["tmp", 0].levels:
+                        t.record_stream(s_tmp)
+                runs["inp", 0].point_features(pb4["inp"], extents, off, out=pf["inp"])
+                done["inp", 0] = torch.cuda.Event()
+                done["inp", 0].record(s_inp)
+            with torch.cuda.stream(s_tmp):
+                if not single:
+                    s_tmp.wait_event(feat_done)
+                runs["tmp", 0].point_features(pb4["tmp"], extents, off, out=pf["tmp"])
+                done["tmp", 0] = torch.cuda.Event()
+                done["tmp", 0].record(s_tmp)
+        paired = bool(done)
+        for side, bb in (() if paired else (("inp", "backbone_inp"), ("tmp", "backbone_tmp"))):
             n = npts[side]
             geometry(side)
             stage(side)                                                # runs underneath the geometry
@@ -479,9 +531,10 @@ class Network(nn.Module):
         cache = self.__dict__.setdefault("_graphs", {})
         ent = cache.pop(key, None)                                           # re-inserted below: dict order = recency
         if ent is None or any(need_ma[s] > ent["ma"][s] for s in ("inp", "tmp")):
-            ent = None                                                       # an outgrown capture is released first
+            self._drop_graph(ent)                                            # an outgrown capture is released first
+            ent = None
             while len(cache) >= self.MAX_GRAPHS:                             # capacity-sized buffers per batch size: bounded
-                cache.pop(next(iter(cache)))                                 # least recently used
+                self._drop_graph(cache.pop(next(iter(cache))))               # least recently used
             ent = self._capture(f, dev, b, S, {s: max(32, 2 * need_ma[s]) for s in ("inp", "tmp")})
         cache[key] = ent
         # resident inputs go through ops.pad_copy_many, which wants dense 2-D rows of 4-byte elements (int64 voxel rows are
@@ -570,6 +623,13 @@ class Network(nn.Module):
             sides = (("inp", "backbone_inp", main, "Xc"), ("tmp", "backbone_tmp", side_stream, "Yo"))
             xs, pb4s = {}, {}
             for stage in range(5):
+                if stage == 2 and self.pair_features:
+                    # the feature stage of both backbones as ONE launch sequence on the main branch (join, run, fork again)
+                    main.wait_stream(side_stream)
+                    ops.backbone_features_pair(ent["inp"]["run"], xs["inp"], f["backbone_inp_ptrs"],
+                                               ent["tmp"]["run"], xs["tmp"], f["backbone_tmp_ptrs"])
+                    side_stream.wait_stream(main)
+                    continue
                 for s, bb, stream, dside in sides:
                     with torch.cuda.stream(stream):
                         st = ent[s]

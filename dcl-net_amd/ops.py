@@ -409,6 +409,44 @@ class BackboneRun(object):
         return out
 
 
+def backbone_features_pair(run_a, vox_a, ptrs_a, run_b, vox_b, ptrs_b):
+    """The feature stage of BOTH backbones of a forward (observed / template side; two BackboneRun or two BackboneRunCap of
+    the same batch and grid): every layer is one launch over both sides' tiles (dcl_backbone_features_pair), so the fixed
+    part of a launch is paid once per layer, not once per layer and side.  ptrs_*: (weights, scales, shifts) pointer
+    arrays of a side.  Fills run_*.levels like run.features()."""
+    cap_mode = isinstance(run_a, BackboneRunCap)
+    assert isinstance(run_b, type(run_a)) and run_a.batch == run_b.batch and run_a.S == run_b.S
+    dev = vox_a.device
+    runs, voxs, ptrs = (run_a, run_b), (vox_a, vox_b), (ptrs_a, ptrs_b)
+    if cap_mode:
+        ws2 = [r.ws2 for r in runs]
+        ws2_bytes = [r.ws2_bytes for r in runs]
+        counts_host, counts_dev = None, (C.c_void_p * 2)(*[r.counts_dev.data_ptr() for r in runs])
+    else:
+        ws2, ws2_bytes = [], []
+        for r in runs:
+            nbytes = C.c_int64(0)
+            N.check(N.lib().dcl_backbone_ws2_bytes(r.ccounts, r.chan, C.byref(nbytes)), "backbone_ws2_bytes")
+            ws2.append(torch.empty(nbytes.value, dtype=torch.uint8, device=dev))
+            ws2_bytes.append(nbytes.value)
+            r.levels = [torch.empty((r.counts[2 * m + 1], BACKBONE_CHANNELS[2 * m + 2]), dtype=torch.float32, device=dev)
+                        for m in range(4)]
+        counts_host = (C.POINTER(C.c_int32) * 2)(*[C.cast(r.ccounts, C.POINTER(C.c_int32)) for r in runs])
+        counts_dev = None
+    level_ptrs = [r.level_ptrs if cap_mode else _ptr_array(r.levels) for r in runs]
+    pp = lambda arrs: (C.c_void_p * 2)(*[C.cast(a, C.c_void_p) for a in arrs])                # noqa: E731
+    N.check(N.lib().dcl_backbone_features_pair(
+        run_a.batch, run_a.S, run_a.chan, (C.c_int32 * 2)(run_a.V0, run_b.V0),
+        (C.c_void_p * 2)(*[r.ws.data_ptr() for r in runs]), counts_host, counts_dev,
+        (C.c_void_p * 2)(*[v.data_ptr() for v in voxs]), pp([p[0] for p in ptrs]), pp([p[1] for p in ptrs]),
+        pp([p[2] for p in ptrs]), (C.c_void_p * 2)(*[w.data_ptr() for w in ws2]), (C.c_int64 * 2)(*ws2_bytes),
+        pp(level_ptrs), N.stream()), "backbone_features_pair")
+    if not cap_mode:
+        for r, w in zip(runs, ws2):
+            r._ws2_keep = w                                # the levels are separate tensors; the scratch may go when the run goes
+    return run_a.levels, run_b.levels
+
+
 class BackboneRunCap(object):
     """Capacity-mode backbone pass (whole-forward hipGraph capture): every buffer is sized from (batch, S, V0_cap) alone,
     live row counts stay on the device, no host read-back.  `occ` is a STATIC (V0_cap,4) buffer whose first *v0_dev rows

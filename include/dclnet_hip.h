@@ -246,6 +246,17 @@ int dcl_backbone_features_cap(const int32_t *occ, int V0_cap, int batch, int S, 
                               const int32_t *channels_host, const float *vox_feats, const float *const *weights_host,
                               const float *const *scales_host, const float *const *shifts_host, void *ws2,
                               int64_t ws2_bytes, float *const *level_out_host, dclStream_t stream);
+/* BOTH backbones of a forward in one feature stage (DCL-Net runs two of the same shape: observed crops and template clouds,
+ * models/DCL_Net.py:93-94,173-186): per-side arrays of 2.  Every layer becomes ONE launch over both sides' tiles -- 8 conv
+ * + 4 pool launches per forward instead of 16 + 8 -- with results identical to two dcl_backbone_features calls up to the
+ * fp32 summation split points of the stream-K decomposition.  counts_dev != NULL selects capacity mode for both sides
+ * (V0 are then capacities and counts_host is ignored); otherwise counts_host[i] are the sides' 8 level sizes.  The sides
+ * share batch, S and the channel list; each has its own geometry workspace, parameters, ws2 and level outputs.         */
+int dcl_backbone_features_pair(int batch, int S, const int32_t *channels_host, const int32_t *V0, void *const *ws,
+                               const int32_t *const *counts_host, const int32_t *const *counts_dev,
+                               const float *const *vox_feats, const float *const *const *weights,
+                               const float *const *const *scales, const float *const *const *shifts, void *const *ws2,
+                               const int64_t *ws2_bytes, float *const *const *level_out, dclStream_t stream);
 int dcl_point_features_cap(int n, const float *points_b4, int batch, int S, int V0_cap, void *ws,
                            const int32_t *counts_dev, const int32_t *channels_host,
                            const float *const *level_feats_host, const float *voxel_extent_host, float offset,

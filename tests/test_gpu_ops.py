@@ -964,6 +964,57 @@ def test_backbone_runner_on_random_active_sets(dcl, oracle, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("b,per", [(2, 300), (16, 900), (5, 40)])
+def test_backbone_feature_stage_of_both_sides_in_one_launch_sequence(dcl, oracle, b, per):
+    """dcl_backbone_features_pair: the observed and the template backbone (different active sets, different weights) with
+    every layer as ONE launch over both sides' tiles -- each side's levels equal its own single-side pass within the GEMM
+    tolerance and the oracle backbone; exact and capacity mode; a side that runs out of voxels at a deep level drops out"""
+    from oracle import graph as G
+    rng = np.random.default_rng(b * 1000 + per)
+    net = dcl.DCL_Net.Network(dcl.synth.default_cfg(64, 64), mode="test")
+    sd = dcl.synth.synth_state_dict(net, 7)
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    f = net._fold()
+    occ = {"inp": rand_voxels(rng, b, 64, per), "tmp": rand_voxels(rng, b, 64, max(3, per // 3))}
+    vox = {k: rng.normal(size=(v.shape[0], 7)).astype(np.float32) for k, v in occ.items()}
+    runs, single = {}, {}
+    for side in ("inp", "tmp"):
+        runs[side] = dcl.ops.BackboneRun(cuda(occ[side]), b, 64)
+        runs[side].set_counts(runs[side].counts_dev.cpu().tolist())
+        solo = dcl.ops.BackboneRun(cuda(occ[side]), b, 64)
+        solo.set_counts(solo.counts_dev.cpu().tolist())
+        single[side] = [t.clone() for t in solo.features(cuda(vox[side]), *f["backbone_%s_ptrs" % side])]
+    la, lb = dcl.ops.backbone_features_pair(runs["inp"], cuda(vox["inp"]), f["backbone_inp_ptrs"],
+                                            runs["tmp"], cuda(vox["tmp"]), f["backbone_tmp_ptrs"])
+    for side, levels in (("inp", la), ("tmp", lb)):
+        want = G.backbone(sd, "backbone_" + side, vox[side], occ[side], [64] * 3, b)
+        for m in range(4):
+            tol = 5e-5 * max(1.0, float(single[side][m].abs().max())) if single[side][m].numel() else 0.0
+            assert levels[m].shape == single[side][m].shape
+            assert float((levels[m] - single[side][m]).abs().max()) <= tol if levels[m].numel() else True, (side, m)
+            assert np.abs(levels[m].cpu().numpy() - want[m][0]).max() <= 5e-5 * max(1.0, np.abs(want[m][0]).max()), (side, m)
+    # capacity mode (what a captured forward runs): same values in the live rows
+    caps = {}
+    for side in ("inp", "tmp"):
+        V0 = occ[side].shape[0]
+        pad = torch.zeros((V0 + 17, 4), dtype=torch.int32, device="cuda")
+        pad[:V0] = cuda(occ[side])
+        caps[side] = dcl.ops.BackboneRunCap(pad, torch.tensor([V0], dtype=torch.int32, device="cuda"), b, 64)
+        caps[side].geometry()
+        caps[side].vox = torch.zeros((V0 + 17, 7), device="cuda")
+        caps[side].vox[:V0] = cuda(vox[side])
+    ca, cb = dcl.ops.backbone_features_pair(caps["inp"], caps["inp"].vox, f["backbone_inp_ptrs"],
+                                            caps["tmp"], caps["tmp"].vox, f["backbone_tmp_ptrs"])
+    for side, levels in (("inp", ca), ("tmp", cb)):
+        for m in range(4):
+            n = single[side][m].shape[0]
+            tol = 5e-5 * max(1.0, float(single[side][m].abs().max())) if n else 0.0
+            if n:
+                assert float((levels[m][:n] - single[side][m]).abs().max()) <= tol, (side, m)
+
+
+@pytest.mark.gpu
 def test_geometry_one_launch_mask_chain_equals_chained_launches(request, dcl):
     """the 8 active sets of a pass from the one-workgroup-per-crop LDS chain (default on 64^3 grids) and from the 8 chained
     mask launches: same counts, same voxel rows at every level -- on the awkward sets and on a 32-crop batch"""
