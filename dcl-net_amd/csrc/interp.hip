@@ -428,6 +428,171 @@ __global__ __launch_bounds__(256) void k_three_nn(int n, int m, const float *__r
   }
 }
 
+// ---- pruned exact search for k = 1 and k = 3 (knn with k = 1 is what DCL-Net's get_cano_label calls; three_nn is k = 3):
+// the batch's known points are bucketed along the axis of their largest extent (256 buckets, counting sort in LDS, exact
+// per-bucket minimum / maximum coordinate), every query scans its own bucket and then walks outwards in both directions
+// until the squared coordinate gap to the next bucket already exceeds its current worst distance.  Exact: candidates are
+// 64-bit (d2, index) keys -- the reference's strict-'<' cascade over ascending k is the lexicographic order of those keys,
+// so the scan order is free -- and d2 = fma(dz,dz, fma(dx,dx, dy*dy)) >= fl(gap*gap) for the gap along ANY one axis
+// (rounding is monotonic), so a bucket whose nearest coordinate is further than the worst kept distance cannot contribute,
+// ties included (the walk stops on a strictly greater bound only).
+constexpr int kNNBuckets = 256;
+constexpr int kNNThreads = 512;           // queries per workgroup: the bucket build (per workgroup) is shared by more of them
+template <int KB>
+__global__ __launch_bounds__(kNNThreads) void k_nn_bucketed(int n, int m, const float *__restrict__ unknown,
+                                                     const float *__restrict__ known, float *__restrict__ dist2,
+                                                     int32_t *__restrict__ idx) {
+  extern __shared__ __attribute__((aligned(16))) float nn_lds[];
+  float4 *pts = reinterpret_cast<float4 *>(nn_lds);                        // [m] (x, y, z, index bits), bucket by bucket
+  int *start = reinterpret_cast<int *>(nn_lds + 4 * (size_t)m);            // [kNNBuckets + 1]
+  int *fill = start + kNNBuckets + 1;                                      // [kNNBuckets] counts, then fill cursors
+  unsigned *bmin = reinterpret_cast<unsigned *>(fill + kNNBuckets);        // [kNNBuckets] monotone-uint minimum coordinate
+  unsigned *bmax = bmin + kNNBuckets;                                      // [kNNBuckets]
+  float *red = reinterpret_cast<float *>(bmax + kNNBuckets);               // [6][NWV] wave partials of the extent
+  constexpr int NWV = kNNThreads / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bs = blockIdx.y;
+  const float *K = known + (size_t)bs * m * 3;
+  // 1. extent of the known points along the three axes
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = tid; i < m; i += kNNThreads)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float c = K[i * 3 + a];
+      lo[a] = fminf(lo[a], c);
+      hi[a] = fmaxf(hi[a], c);
+    }
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      lo[a] = fminf(lo[a], __shfl_xor(lo[a], d, 64));
+      hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], d, 64));
+    }
+  if (lane == 0)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { red[a * NWV + wave] = lo[a]; red[3 * NWV + a * NWV + wave] = hi[a]; }
+  if (tid < kNNBuckets) {
+    fill[tid] = 0;
+    bmin[tid] = 0xffffffffu;
+    bmax[tid] = 0u;
+  }
+  __syncthreads();
+  int axis = 0;
+  float cmin = 0.f, inv_w = 0.f;
+  {
+    float best = -1.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      float l = INFINITY, h = -INFINITY;
+#pragma unroll
+      for (int w = 0; w < NWV; ++w) {
+        l = fminf(l, red[a * NWV + w]);
+        h = fmaxf(h, red[3 * NWV + a * NWV + w]);
+      }
+      if (h - l > best) { best = h - l; axis = a; cmin = l; }
+    }
+    inv_w = best > 0.f ? (float)kNNBuckets / best : 0.f;
+  }
+  auto bucket_of = [&](float c) -> int {                                   // monotone non-decreasing in c
+    const float f = (c - cmin) * inv_w;
+    int q = f > 0.f ? (int)fminf(f, (float)(kNNBuckets - 1)) : 0;
+    return q;
+  };
+  auto mono = [](float c) -> unsigned {                                    // float order -> unsigned order
+    const unsigned u = __float_as_uint(c);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  };
+  auto unmono = [](unsigned u) -> float { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); };
+  // 2. counting sort into the buckets (the order inside a bucket is free: keys are a total order)
+  for (int i = tid; i < m; i += kNNThreads) {
+    const float c = K[i * 3 + axis];
+    const int q = bucket_of(c);
+    atomicAdd(&fill[q], 1);
+    atomicMin(&bmin[q], mono(c));
+    atomicMax(&bmax[q], mono(c));
+  }
+  __syncthreads();
+  {                                                                        // exclusive scan of the 256 counts (waves 0-3)
+    const int cnt = tid < kNNBuckets ? fill[tid] : 0;
+    int inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += t;
+    }
+    __syncthreads();                                                       // (everyone has read its count, and the extent partials)
+    if (lane == 63 && wave < kNNBuckets / 64) red[wave] = __int_as_float(inc);
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int w = 0; w < kNNBuckets / 64; ++w) base += w < wave ? __float_as_int(red[w]) : 0;
+    if (tid < kNNBuckets) {
+      start[tid] = base + inc - cnt;
+      fill[tid] = base + inc - cnt;                                        // fill cursor
+      if (tid == kNNBuckets - 1) start[kNNBuckets] = base + inc;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < m; i += kNNThreads) {
+    const float x = K[i * 3], y = K[i * 3 + 1], z = K[i * 3 + 2];
+    const float c = axis == 0 ? x : (axis == 1 ? y : z);
+    const int pos = atomicAdd(&fill[bucket_of(c)], 1);
+    pts[pos] = make_float4(x, y, z, __int_as_float(i));
+  }
+  __syncthreads();
+  // 3. the queries of this block
+  const int p = blockIdx.x * kNNThreads + tid;
+  if (p >= n) return;
+  const float *u = unknown + ((size_t)bs * n + p) * 3;
+  const float ux = u[0], uy = u[1], uz = u[2];
+  const float uc = axis == 0 ? ux : (axis == 1 ? uy : uz);
+  u64 key[KB];
+#pragma unroll
+  for (int j = 0; j < KB; ++j) key[j] = kEmptyKey;
+  auto push = [&](u64 c) {
+#pragma unroll
+    for (int j = 0; j < KB; ++j) {
+      const u64 t = c < key[j] ? c : key[j];
+      c = c < key[j] ? key[j] : c;
+      key[j] = t;
+    }
+  };
+  float worst = INFINITY;                                                  // distance of the last kept key
+  auto scan = [&](int q) {
+    const int e = start[q + 1];
+    for (int i = start[q]; i < e; ++i) {
+      const float4 v = pts[i];
+      const float d = dcl_dist2(ux, uy, uz, v.x, v.y, v.z);
+      if (d > worst) continue;                                             // cannot enter (an equal distance may: lower index)
+      push(make_key(d, __float_as_int(v.w)));
+      worst = __uint_as_float((unsigned)(key[KB - 1] >> 32));
+    }
+  };
+  const int q0 = bucket_of(uc);
+  scan(q0);
+  for (int q = q0 + 1; q < kNNBuckets; ++q) {
+    if (start[q + 1] == start[q]) continue;
+    const float gap = unmono(bmin[q]) - uc;                                // every point from here on is at least this far along the axis
+    if (gap > 0.f && gap * gap > worst) break;
+    scan(q);
+  }
+  for (int q = q0 - 1; q >= 0; --q) {
+    if (start[q + 1] == start[q]) continue;
+    const float gap = uc - unmono(bmax[q]);
+    if (gap > 0.f && gap * gap > worst) break;
+    scan(q);
+  }
+  const size_t o = ((size_t)bs * n + p) * KB;
+#pragma unroll
+  for (int j = 0; j < KB; ++j) {
+    dist2[o + j] = __uint_as_float((unsigned)(key[j] >> 32));
+    idx[o + j] = (int)(unsigned)key[j];
+  }
+}
+constexpr int kNNBucketedMaxKnown = 8192;       // 128 KiB of staged points
+static size_t nn_bucketed_lds(int m) { return (size_t)m * 16 + (size_t)(4 * kNNBuckets + 1 + 6 * (kNNThreads / 64) + 4) * 4; }
+
 // knn, k <= 200 (interpolate_gpu.cu:9-57): sorted list with strict-'<' insertion, one query per
 // thread, list kept in a per-thread LDS column (conflict-free: slot j of thread t at j*T + t).
 constexpr int kKnnThreads = 64;
@@ -495,8 +660,10 @@ int dcl_three_nn_sp_strided(int n, int m, const float *unknown, const float *kno
 DCL_HOOK_INT(g_nn_grid, 1);   // (atomic in the diagnostic library, constant in the product) 0 = brute-force scan per crop for every level, 2 = grid kernel with the scan forced, 3 / 4 / 5 = one / four / eight lanes per query
 constexpr int kNnCoopMaxQueries = 1 << 17;   // read-outs of up to this many points search with four lanes per query,
 constexpr int kNnCoop8MaxQueries = 40960;    // up to this many (bs 40 x 1024 points) with eight
+DCL_HOOK_INT(g_nn_batched_mode, 0);   // (diagnostic library) 1 = the batched three_nn / knn as plain scans (A/B of the bucketed search)
 #ifdef DCL_DIAG
 DCL_API void dcl_debug_three_nn_grid(int mode) { g_nn_grid = mode; }
+DCL_API void dcl_debug_nn_batched_mode(int mode) { g_nn_batched_mode = mode; }
 #endif
 
 // known_mask / S (optional): the level's occupancy bits and grid size; with them, levels of S = 16 or 32 go through the
@@ -624,6 +791,14 @@ DCL_API int dcl_three_nn(int b, int n, int m, const float *unknown, const float 
   DCL_CHECK_ARG(b >= 0 && n >= 0 && m >= 0);
   if (b == 0 || n == 0) return 0;
   DCL_CHECK_ARG(unknown && dist2 && idx && (m == 0 || known) && b <= 65535);
+  if (m >= 64 && m <= kNNBucketedMaxKnown && g_nn_batched_mode == 0) {        // bucketed exact search (same results as the scan)
+    const size_t lds = nn_bucketed_lds(m);
+    (void)hipFuncSetAttribute((const void *)k_nn_bucketed<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_nn_bucketed<3>, dim3(dcl_div_up(n, kNNThreads), b), dim3(kNNThreads), lds, (hipStream_t)stream, n, m, unknown, known,
+                       dist2, idx);
+    DCL_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(k_three_nn, dim3(dcl_div_up(n, 256), b), dim3(256), 0, (hipStream_t)stream, n, m, unknown, known,
                      dist2, idx);
   DCL_LAUNCH_CHECK();
@@ -635,6 +810,14 @@ DCL_API int dcl_knn(int b, int n, int m, int k, const float *unknown, const floa
   DCL_CHECK_ARG(b >= 0 && n >= 0 && m >= 0 && k >= 1 && k <= 200);
   if (b == 0 || n == 0) return 0;
   DCL_CHECK_ARG(unknown && dist2 && idx && (m == 0 || known) && b <= 65535);
+  if (k == 1 && m >= 64 && m <= kNNBucketedMaxKnown && g_nn_batched_mode == 0) {
+    const size_t lds1 = nn_bucketed_lds(m);
+    (void)hipFuncSetAttribute((const void *)k_nn_bucketed<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    hipLaunchKernelGGL(k_nn_bucketed<1>, dim3(dcl_div_up(n, kNNThreads), b), dim3(kNNThreads), lds1, (hipStream_t)stream, n, m, unknown, known,
+                       dist2, idx);
+    DCL_LAUNCH_CHECK();
+    return 0;
+  }
   const size_t lds = (size_t)k * kKnnThreads * 8;
   hipLaunchKernelGGL(k_knn, dim3(dcl_div_up(n, kKnnThreads), b), dim3(kKnnThreads), lds, (hipStream_t)stream, n, m, k,
                      unknown, known, dist2, idx);

@@ -295,12 +295,7 @@ __global__ __launch_bounds__(1024) void k_fps(int n, int m, int TR, int log2TR, 
     v = row_max_u64(v);
     unsigned long long *buf = xch + (j & 1) * 64;
     if ((lane & 15) == 0) buf[wave * 4 + (lane >> 4)] = v;
-    // raw barrier behind an LDS-only wait: __syncthreads() would also drain vmcnt, i.e. make every iteration wait for the
-    // winner-index store of the previous one (a global store round trip per iteration, on a loop that is pure latency)
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): this wave's row winners are in LDS
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
+    __syncthreads();
     unsigned long long w = row_max_u64(buf[lane]);
     w = wave_max_of_rows_u64(w);
     const int wi = (int)((unsigned)w & 0x3fffffu);

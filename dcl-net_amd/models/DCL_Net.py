@@ -66,7 +66,7 @@ def _fuser():
 
 class Network(nn.Module):
     def __init__(self, cfg, mode="train", fused=True, graph_max_batch=8, async_inputs=False, graph_max_points=98304,
-                 single_stream=False, pipeline_chunks=1, capture_graph=True, pair_features=True):
+                 single_stream=False, pipeline_chunks=1, capture_graph=True, pair_features=None):
         """graph_max_batch > 0 (default 8): eval-mode calls with at most that many crops go through forward_graphed (one
         whole-forward hipGraph per batch size, captured on first use) -- the one-image-at-a-time eval loops of the
         reference (tools/test_LM.py:104-112: one object per call) are launch-bound otherwise: 0.6 instead of 1.2-1.4 ms
@@ -81,12 +81,16 @@ class Network(nn.Module):
         single_stream=True: the whole call on the caller's stream (no side streams; what bench.py's per-kernel conv timing
         uses).  pipeline_chunks=K > 1: the sparse half in K passes over b/K crops (measured slower, kept runnable).
         capture_graph=False: forward_graphed runs its capacity-mode body launch by launch (debugging aid).  These are
-        pair_features=False: the two backbones' feature stages as separate launch sequences on their own streams (the A/B
-        of the grouped launches).  These are constructor arguments on purpose: nothing on the call path reads the
-        environment."""
+        pair_features: True = the feature stage of both backbones as ONE launch sequence (every layer one launch over both
+        sides' tiles, ops.backbone_features_pair: 8 conv + 4 pool launches per forward instead of 16 + 8), False = each side's
+        own launches on its own stream, None (default) = automatic: paired when everything runs on one stream anyway
+        (single_stream: measured 1.63 -> 1.53 ms of conv time per bs-32 forward), separate otherwise -- with two side streams
+        the sides' stages overlap each other and the first dense GEMMs, which a common feature stage would serialise (measured
+        at N = M = 1024: bs 32 4.28 vs 4.40 ms per step, one crop 0.61 vs 0.65 ms).  These are constructor arguments on
+        purpose: nothing on the call path reads the environment."""
         super().__init__()
         self.single_stream = bool(single_stream)
-        self.pair_features = bool(pair_features)         # both backbones' layers as ONE launch each (ops.backbone_features_pair)
+        self._pair_features = pair_features              # both backbones' layers as ONE launch each; None = automatic (see property)
         self.pipeline_chunks = int(pipeline_chunks)
         self.capture_graph = bool(capture_graph)
         self.graph_max_batch = int(graph_max_batch)
@@ -119,6 +123,10 @@ class Network(nn.Module):
         self.regressor_rot = _mlp3([1024, 512, 128, 9])
         self.regressor_trans = _mlp3([1024, 512, 128, 3])
         self._folded = None
+
+    @property
+    def pair_features(self):
+        return self.single_stream if self._pair_features is None else bool(self._pair_features)
 
     # ------------------------------------------------------------------ parameter folding (eval mode)
     @staticmethod

@@ -488,6 +488,8 @@ int dcl_debug_geometry_chain(int mode);
  * eight lanes per query whatever the number of points (automatic: eight up to 40960 points, four up to 131072, else
  * one).  All give identical results. */
 void dcl_debug_three_nn_grid(int mode);
+/* Test hook, batched three_nn / knn (k = 1): 0 (default) = bucketed exact search, 1 = the plain scan (A/B). */
+void dcl_debug_nn_batched_mode(int mode);
 /* Tuning hook: 0 = automatic split-K choice in dcl_sparse_conv_fwd_ws, n = force n splits (when the scratch allows),
  * -1 = at most 8 splits even for few-row launches, -2 = never split. */
 void dcl_debug_conv_split(int n);

@@ -389,16 +389,19 @@ def test_chunked_sparse_half_and_stream_switches_give_the_same_results(dcl):
         ref = net(data)
         outs = {}
         for name, attr, val in (("chunks2", "pipeline_chunks", 2), ("chunks4", "pipeline_chunks", 4),
-                                ("single", "single_stream", True)):
+                                ("single", "single_stream", True), ("single_paired", "single_stream", True)):
             old = getattr(net, attr)                   # the switches are constructor arguments (plain attributes): no environment
             setattr(net, attr, val)
+            net._pair_features = False if name == "single" else None     # None: one stream -> grouped launches of both sides
             outs[name] = net(data)
             setattr(net, attr, old)
+            net._pair_features = None
     # one stream: the same kernels in the same order -> identical bits.  Chunked passes have other row counts per launch,
     # hence other split-K / GEMM tilings (other summation orders): equal within the parity tolerance of the path
     for k in ("rot_pred", "trans_pred", "conf", "F_Xo_p"):
         assert torch.equal(ref[k], outs["single"][k]), k
-    for name in ("chunks2", "chunks4"):
+    # (on one stream the default groups both backbones' layers into common launches: other tile decompositions, like chunks)
+    for name in ("chunks2", "chunks4", "single_paired"):
         assert float((ref["rot_pred"] - outs[name]["rot_pred"]).abs().max()) <= 1e-4, name          # the path's parity bar
         assert float((ref["trans_pred"] - outs[name]["trans_pred"]).abs().max()) <= 1e-5, name
         assert float((ref["conf"] - outs[name]["conf"]).abs().max()) <= 1e-4, name

@@ -578,6 +578,44 @@ def test_knn_three_nn_three_interpolate_batched(dcl, oracle):
                           oracle.three_interpolate(feats, wi, w))
 
 
+@pytest.mark.parametrize("case", ["surface", "lattice", "flat", "identical", "outliers", "big"])
+def test_batched_three_nn_and_knn1_bucketed_search_is_exact(request, dcl, oracle, case):
+    """the pruned search of dcl_three_nn / dcl_knn(k=1) -- known points bucketed along their widest axis, walk outwards
+    until the axis gap exceeds the worst kept distance -- returns the scan's (dist2, idx) bit for bit: random clouds, an
+    integer lattice (exact ties: the lowest index must win), a flat cloud (axis choice), all points identical (one
+    bucket), far outlier queries (clamped start bucket) and BASELINE's primitive shape"""
+    rng = np.random.default_rng(len(case))
+    B, n, m = 2, 700, 900
+    if case == "surface":
+        kn = _cloud(rng, B, m); unk = _cloud(rng, B, n)
+    elif case == "lattice":
+        kn = rng.integers(-6, 7, size=(B, m, 3)).astype(np.float32) * np.float32(0.01)
+        unk = rng.integers(-6, 7, size=(B, n, 3)).astype(np.float32) * np.float32(0.01)
+    elif case == "flat":
+        kn = _cloud(rng, B, m); kn[:, :, 0] *= 1e-4; kn[:, :, 2] *= 1e-3
+        unk = _cloud(rng, B, n); unk[:, :, 0] *= 1e-4
+    elif case == "identical":
+        kn = np.tile(np.float32([[0.01, -0.02, 0.03]]), (B, m, 1)); unk = _cloud(rng, B, n)
+    elif case == "outliers":
+        kn = _cloud(rng, B, m); unk = _cloud(rng, B, n) * np.float32(40.0)
+    else:
+        B, n, m = 2, 12288, 2048
+        kn = _cloud(rng, B, m); unk = _cloud(rng, B, n)
+    wd, wi = oracle.three_nn(unk, kn)
+    d2, idx = dcl.ops.three_nn(cuda(unk), cuda(kn))
+    assert np.array_equal(idx.cpu().numpy(), wi) and np.array_equal(d2.cpu().numpy(), wd)
+    wd1, wi1 = oracle.knn(1, unk, kn)
+    d1, i1 = dcl.ops.knn(1, cuda(unk), cuda(kn))
+    assert np.array_equal(i1.cpu().numpy(), wi1) and np.array_equal(d1.cpu().numpy(), wd1)
+    lib = enter_diag(dcl, request)                              # A/B: the plain scans of the diagnostic library
+    lib.dcl_debug_nn_batched_mode(1)
+    try:
+        d2s, idxs = dcl.ops.three_nn(cuda(unk), cuda(kn))
+    finally:
+        lib.dcl_debug_nn_batched_mode(0)
+    assert torch.equal(idxs, idx) and torch.equal(d2s, d2)
+
+
 # ------------------------------------------------------------------------------------------- dense kernels
 def _attn_ref(Q, K, V):
     """torch fp64 reference of Aligner (models/Modules.py:166-169) on point-major operands"""
