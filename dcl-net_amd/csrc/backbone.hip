@@ -86,9 +86,12 @@ struct GeoLayout {
 };
 
 // Row ordering pays where launches are MFMA-bound on their tiles: from a dozen crops on (one-image calls are latency-bound
-// few-row launches, which take no order), for the layers the LDS-DMA kernel deals in used chunks (Cin >= 32)
-constexpr int kOrderMinBatch = 12;
-inline bool order_layer(int batch, int m, int which) { return batch >= kOrderMinBatch && m >= 1 && (which == 0 || which == 1); }
+// few-row launches, which take no order), for the layers of the two deep levels (64- and 128-channel inputs: the dilating
+// convs skip 35-45 % of their issued chunks there, the submanifold ones 10-15 %).  Level 1 (32 channels) was measured both
+// ways: its launches are bound by the per-tile fixed cost, not by MFMA work -- ordered 55.9 / 89.6 us, natural 53 / 83 --
+// and its two sets are the largest ones to sort; level 0 runs the stem and a 16-channel layer (no used-chunk dealing).
+DCL_HOOK_INT(kOrderMinBatch, 12);   // (diagnostic library: dcl_debug_order_min_batch; a huge value switches the ordering off for A/B runs)
+inline bool order_layer(int batch, int m, int which) { return batch >= kOrderMinBatch && m >= 2 && (which == 0 || which == 1); }
 
 bool make_geo_layout(int batch, int S, int V0, GeoLayout *L) {
   if (batch <= 0 || S < 16 || (S & (S - 1)) || S > 64 || V0 < 0) return false;
@@ -276,6 +279,7 @@ static int backbone_geometry(const int32_t *occ, const int32_t *V0_dev, int V0, 
 }
 
 #ifdef DCL_DIAG
+DCL_API void dcl_debug_order_min_batch(int n) { kOrderMinBatch = n; }
 // Test hook: 1 (default) = one-launch mask chain on 64^3 grids, 0 = the 8 chained launches (A/B of the two paths).
 DCL_API int dcl_debug_geometry_chain(int mode) {
   g_geo_chain.store(mode);

@@ -76,7 +76,12 @@ __global__ void k_sparse_conv_valu(const float *__restrict__ feat, const DclNbrS
 // wave-uniform broadcasts.  Same summation order as the generic kernel (per offset an ascending-ci fmaf chain, then one add).
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void k_sparse_conv_stem(const DclConvSides sides, int nsides, int kvol, int subm, int relu) {
+  // FOUR lanes per output row: lane g of a row's quad walks the kernel offsets s = g, g + 4, ... (each offset: neighbour
+  // look-up, CIN loads, a CIN x COUT fmaf block -> one partial row added to the lane's sum in ascending s), then the four
+  // lane sums are added as (l0 + l1) + (l2 + l3) by two butterfly rounds.  One thread per row made every row a serial chain
+  // of 27 dependent look-ups -- 28 us for the 3 200 rows of a one-crop call, 23 us at 108 000 rows.
   __shared__ __attribute__((aligned(16))) float Ws[2 * 27 * CIN * COUT];         // both sides' filters
+  static_assert(COUT % 16 == 0, "four lanes write COUT / 4 channels each as float4s");
   int n0 = sides.s[0].n_dev ? *sides.s[0].n_dev : sides.s[0].n_host;
   n0 = n0 < sides.s[0].cap ? n0 : sides.s[0].cap;
   int n1 = 0;
@@ -89,16 +94,18 @@ __global__ __launch_bounds__(256) void k_sparse_conv_stem(const DclConvSides sid
     if (nsides > 1) Ws[27 * CIN * COUT + i] = sides.s[1].W[i];
   }
   __syncthreads();
-  for (int g = blockIdx.x * 256 + threadIdx.x; g < n0 + n1; g += gridDim.x * 256) {
-    const int second = g >= n0 ? 1 : 0;
+  const int g = threadIdx.x & 3;
+  for (int q = blockIdx.x * 64 + (threadIdx.x >> 2); q < ((n0 + n1 + 63) & ~63); q += gridDim.x * 64) {   // whole quads stay together
+    const bool live = q < n0 + n1;
+    const int second = (live && q >= n0) ? 1 : 0;
     const DclConvSide &S = sides.s[second];
-    const int row = g - (second ? n0 : 0);
+    const int row = live ? q - (second ? n0 : 0) : 0;
     float acc[COUT];
 #pragma unroll
     for (int co = 0; co < COUT; ++co) acc[co] = 0.0f;
-    for (int s = 0; s < kvol; ++s) {
+    for (int s = g; s < kvol; s += 4) {
       const int k = offset_at(s, kvol, subm);
-      const int v = dcl_nbr_at(S.src, S.cap, k, row);
+      const int v = live ? dcl_nbr_at(S.src, S.cap, k, row) : -1;
       if (v < 0) continue;
       float f[CIN];
 #pragma unroll
@@ -115,15 +122,26 @@ __global__ __launch_bounds__(256) void k_sparse_conv_stem(const DclConvSides sid
       for (int co = 0; co < COUT; ++co) acc[co] = acc[co] + part[co];
     }
 #pragma unroll
-    for (int co = 0; co < COUT; ++co) {
-      float x = acc[co];
+    for (int co = 0; co < COUT; ++co) {                  // (l0 + l1) + (l2 + l3): commutative adds, the same bits in all four lanes
+      acc[co] = acc[co] + __shfl_xor(acc[co], 1, 64);
+      acc[co] = acc[co] + __shfl_xor(acc[co], 2, 64);
+    }
+    if (!live) continue;
+    constexpr int PER = COUT / 4;                        // channels written by each of the four lanes
+    float o[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      float x = 0.f;
+#pragma unroll
+      for (int gg = 0; gg < 4; ++gg) x = g == gg ? acc[gg * PER + j] : x;       // static register indices
+      const int co = g * PER + j;
       if (S.scale) x = x * S.scale[co] + S.shift[co];
       if (relu) x = fmaxf(x, 0.0f);
-      acc[co] = x;
+      o[j] = x;
     }
-    float4 *o = reinterpret_cast<float4 *>(S.out + (size_t)row * COUT);
+    float4 *dst = reinterpret_cast<float4 *>(S.out + (size_t)row * COUT + g * PER);
 #pragma unroll
-    for (int q = 0; q < COUT / 4; ++q) o[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    for (int j = 0; j < PER / 4; ++j) dst[j] = make_float4(o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]);
   }
 }
 
@@ -411,10 +429,14 @@ __device__ __forceinline__ unsigned conv_lds_addr(const float *p) {
 // KC = 32 virtual channels per chunk.  What bounds this kernel is the L2 -> LDS operand traffic (2*BM*BN*KC flop per
 // (BM+BN)*KC*4 bytes), not LDS or the MFMA pipe: 64x64 tiles (16 flop/B) saturated at ~45 % of the MFMA peak, hence
 // 128x128 (Cout % 128 == 0, 8 waves, 32 flop/B) and 128x64 (4 waves) here.
-template <int CIN, int WR, int WCW, int NT>
+// ORD: the launch carries a row order (sides.s[].ord; the two deep levels of a batch of a dozen crops or more) -- a
+// compile-time switch, because the natural-order instantiation must not pay registers for the order's bookkeeping (the
+// 8-wave variants sit at the 128-VGPR limit of two workgroups per CU)
+template <int CIN, int WR, int WCW, int NT, bool ORD>
 __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma(   // 2 workgroups per CU (LDS allows 2)
     const DclConvSides sides, int nsides, int cout, int kvol, int subm, int relu, float *__restrict__ partial, int stream_k,
-    int aligned_ns, int xcd_remap, int32_t *__restrict__ tile_counters, int use_bal) {
+    int aligned_ns, int xcd_remap, int32_t *__restrict__ tile_counters, int use_bal_arg) {
+  const int use_bal = ORD ? use_bal_arg : 0;
   constexpr int NW = WR * WCW, NTHR = 64 * NW;
   constexpr int BM = 32 * WR, BN = 32 * NT * WCW, KC = 32;
   constexpr int AT = BM * KC, BT = KC * BN, ST = AT + BT;      // floats per stage
@@ -496,10 +518,7 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
     const DclNbrSrc src = S.src;
     const int cap = S.cap;
     const float *__restrict__ W = S.W;
-    const float *__restrict__ scale = S.scale;
-    const float *__restrict__ shift = S.shift;
-    float *__restrict__ out = S.out;
-    const DclRowOrder ord = S.ord;
+    const DclRowOrder ord = ORD ? S.ord : DclRowOrder{nullptr, nullptr, nullptr};
     const int32_t *__restrict__ bal = use_bal ? ord.bal : nullptr;
     const int n = second ? n1 : n0;
     const int ubase = second ? units0 : 0, tbase = second ? nblk0 * ncol : 0;       // first unit / tile of the side
@@ -554,7 +573,9 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
     }
 #endif
     if (tid == 0) *s_kmask = 0;
-    for (int rr = tid; rr < BM; rr += NTHR) s_rows[rr] = row0 + rr < n ? (ord.order ? ord.order[row0 + rr] : row0 + rr) : -1;
+    constexpr bool ordered = ORD;                          // (natural order: the slot -> row map is arithmetic, no LDS round trip)
+    if (ordered)
+      for (int rr = tid; rr < BM; rr += NTHR) s_rows[rr] = row0 + rr < n ? ord.order[row0 + rr] : -1;
     __syncthreads();
     // neighbour rows of the offsets this workgroup's chunk range touches (all 27 without split-K)
     unsigned mymask = 0;
@@ -564,7 +585,7 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
     for (int e = tid; e < (sx_hi - sx_lo + 1) * BM; e += NTHR) {
       const int si = e / BM, rr = e - si * BM;
       const int k = offset_at(sx_lo + si, kvol, subm);
-      const int orow = s_rows[rr];
+      const int orow = ordered ? s_rows[rr] : (row0 + rr < n ? row0 + rr : -1);
       const int v = orow >= 0 ? dcl_nbr_at(src, cap, k, orow) : -1;
       Ns[k * BM + rr] = v;
       mymask |= (v >= 0 ? 1u : 0u) << k;
@@ -837,6 +858,12 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
             }
           }
         }
+        // (the epilogue's pointers are fetched from the side's descriptor HERE, through an opaque index, so that they are
+        // not kept in scalar registers across the chunk loop: the kernel runs at the SGPR limit)
+        const int sec_e = __builtin_amdgcn_readfirstlane(second);
+        const float *__restrict__ scale = sides.s[sec_e].scale;
+        const float *__restrict__ shift = sides.s[sec_e].shift;
+        float *__restrict__ out = sides.s[sec_e].out;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const int co = col0 + wc * 32 * NT + 32 * t + r;
@@ -844,7 +871,8 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
           const float sh = scale ? shift[co] : 0.0f;
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
-            const int orow = s_rows[wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * h];
+            const int slot = wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const int orow = ordered ? s_rows[slot] : (row0 + slot < n ? row0 + slot : -1);
             if (orow >= 0) {
               float x = acc[t][e];
               if (scale) x = x * sc + sh;
@@ -858,6 +886,10 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
       CONV_STAMP(6);
       continue;
     }
+    const int sec_e = __builtin_amdgcn_readfirstlane(second);
+    const float *__restrict__ scale = sides.s[sec_e].scale;
+    const float *__restrict__ shift = sides.s[sec_e].shift;
+    float *__restrict__ out = sides.s[sec_e].out;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int co = col0 + wc * 32 * NT + 32 * t + r;
@@ -865,7 +897,8 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
       const float sh = scale ? shift[co] : 0.0f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int orow = s_rows[wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * h];
+        const int slot = wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int orow = ordered ? s_rows[slot] : (row0 + slot < n ? row0 + slot : -1);
         if (orow >= 0) {
           float x = acc[t][e];
           if (scale) x = x * sc + sh;
@@ -980,7 +1013,9 @@ static void launch_conv_dma(const DclConvSides &sides, int nsides, int cout, int
                             long long scratch_floats, int counters_ready, hipStream_t s) {
   constexpr int BM = 32 * WR, BN = 32 * NT * WCW, KC = 32;
   const size_t lds = (size_t)(2 * (BM * KC + KC * BN) + 27 * BM + 4 + BM) * sizeof(float);
-  (void)hipFuncSetAttribute((const void *)k_sparse_conv_dma<CIN, WR, WCW, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+  (void)hipFuncSetAttribute((const void *)k_sparse_conv_dma<CIN, WR, WCW, NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+  (void)hipFuncSetAttribute((const void *)k_sparse_conv_dma<CIN, WR, WCW, NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
   const bool capacity_mode = sides.s[0].n_dev != nullptr;
   int rows = 0, tiles = 0;                                  // rows: of the larger side (what makes a launch "few rows")
@@ -992,15 +1027,15 @@ static void launch_conv_dma(const DclConvSides &sides, int nsides, int cout, int
 #ifdef DCL_CONV_STAMPS
   {
     int occ = -1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_sparse_conv_dma<CIN, WR, WCW, NT>, 64 * WR * WCW, lds);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_sparse_conv_dma<CIN, WR, WCW, NT, true>, 64 * WR * WCW, lds);
     fprintf(stderr, "k_sparse_conv_dma<%d,%d,%d,%d>: dynamic LDS %zu B, occupancy API says %d workgroups per CU\n", CIN, WR, WCW, NT, lds, occ);
     hipFuncAttributes fa;
-    if (hipFuncGetAttributes(&fa, (const void *)k_sparse_conv_dma<CIN, WR, WCW, NT>) == hipSuccess)
+    if (hipFuncGetAttributes(&fa, (const void *)k_sparse_conv_dma<CIN, WR, WCW, NT, true>) == hipSuccess)
       fprintf(stderr, "  numRegs %d sharedSizeBytes %zu maxThreadsPerBlock %d maxDynamicSharedSizeBytes %d\n", fa.numRegs,
               fa.sharedSizeBytes, fa.maxThreadsPerBlock, fa.maxDynamicSharedSizeBytes);
     for (size_t l : {(size_t)16384, (size_t)32768, (size_t)49152, (size_t)65536, (size_t)73728, (size_t)77824, (size_t)79376, (size_t)81920}) {
       for (int thr : {256, 512}) {
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_sparse_conv_dma<CIN, WR, WCW, NT>, thr, l);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_sparse_conv_dma<CIN, WR, WCW, NT, true>, thr, l);
         fprintf(stderr, "  lds %zu threads %d -> %d;", l, thr, occ);
       }
       fprintf(stderr, "\n");
@@ -1092,8 +1127,14 @@ static void launch_conv_dma(const DclConvSides &sides, int nsides, int cout, int
   }
   if (g_conv_order_mode == 2) use_bal = 0;                                                     // A/B: order, nominal units
 #endif
-  hipLaunchKernelGGL((k_sparse_conv_dma<CIN, WR, WCW, NT>), dim3(G), dim3(64 * WR * WCW), lds, s, sd, nsides, cout, kvol, subm,
-                     relu, partial, stream_k, aligned_ns, (int)g_conv_xcd_remap, counters, use_bal);
+  bool any_order = false;
+  for (int i = 0; i < nsides; ++i) any_order = any_order || sd.s[i].ord.order != nullptr;
+  if (any_order)
+    hipLaunchKernelGGL((k_sparse_conv_dma<CIN, WR, WCW, NT, true>), dim3(G), dim3(64 * WR * WCW), lds, s, sd, nsides, cout, kvol,
+                       subm, relu, partial, stream_k, aligned_ns, (int)g_conv_xcd_remap, counters, use_bal);
+  else
+    hipLaunchKernelGGL((k_sparse_conv_dma<CIN, WR, WCW, NT, false>), dim3(G), dim3(64 * WR * WCW), lds, s, sd, nsides, cout, kvol,
+                       subm, relu, partial, stream_k, aligned_ns, (int)g_conv_xcd_remap, counters, 0);
   if (deferred)
     hipLaunchKernelGGL((k_conv_frag_reduce<WR, WCW, NT>), dim3(tiles, WR * WCW * NT), dim3(256), 0, s, partial, sd, nsides, cout,
                        nchunks, G, stream_k, relu);
@@ -1427,7 +1468,7 @@ static int conv_dispatch(const DclConvSides &sides_in, int nsides_in, int cin, i
   } else if (cin == 7 && cout == 16 && kvol <= 27 && g_force_valu != 1 && !mfma_ok) {
     int rows = 0;
     for (int i = 0; i < nsides; ++i) rows += sides.s[i].n_dev ? sides.s[i].cap : sides.s[i].n_host;
-    hipLaunchKernelGGL((k_sparse_conv_stem<7, 16>), dim3(dcl_grid_1d(rows, 256)), dim3(256), 0, s, sides, nsides, kvol, subm,
+    hipLaunchKernelGGL((k_sparse_conv_stem<7, 16>), dim3(dcl_grid_1d(rows, 64)), dim3(256), 0, s, sides, nsides, kvol, subm,
                        relu);
   } else {
     // the general kernels take one problem per launch

@@ -483,6 +483,8 @@ void dcl_debug_attention_xcd_remap(int on);
 /* Test hook, geometry stage: 1 (default) = the 8 occupancy masks of a pass come from one launch (one workgroup per crop walks
  * the conv/pool chain in LDS; 64^3 grids), 0 = 8 chained launches.  Both produce identical masks.  Process-wide atomic. */
 int dcl_debug_geometry_chain(int mode);
+/* Tuning hook: smallest batch whose deep conv layers get a row order (default 12); a huge value switches the ordering off. */
+void dcl_debug_order_min_batch(int n);
 /* Test hook, 3-NN of the point read-out: 1 (default) = grid-pruned search on the 32^3 / 16^3 levels, 0 = per-crop scan on
  * every level, 2 = grid kernel with its scan fallback forced for every query, 3 / 4 / 5 = grid kernel with one / four /
  * eight lanes per query whatever the number of points (automatic: eight up to 40960 points, four up to 131072, else

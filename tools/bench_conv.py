@@ -6,11 +6,13 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 dcl = importlib.import_module("dcl-net_amd")
-from _diag import use_diag
-DIAG = use_diag(dcl)          # kernel-variant hooks exist in the diagnostic library only
 ops, sp = dcl.ops, dcl.spconv.ops
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-modes = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 2, 3]
+modes = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
+DIAG = None
+if modes != [0] or len(sys.argv) > 3:             # kernel-variant hooks exist in the diagnostic library only; mode 0 alone runs the PRODUCT library
+    from _diag import use_diag
+    DIAG = use_diag(dcl)
 if len(sys.argv) > 3:
     ops.N.lib().dcl_debug_conv_split(int(sys.argv[3]))
 b, S = int(os.environ.get('DCL_BENCH_B', '32')), 64
@@ -37,15 +39,19 @@ for lvl in range(4):
     x1 = None
     for name, f_in, nbr, W, subm in (("conv", feat, nbr1, W1, False), ("subm", None, nbr2, W2, True)):
         if f_in is None: f_in = x1
+        # the runner's row order (csrc/row_order.hip) for the layers it orders (levels >= 2), as the product path uses it
+        order = ops.order_rows(out, (out if subm else aset).mask, subm) if lvl >= 2 and os.environ.get("DCL_BENCH_NO_ORDER") != "1" else None
         pairs = int((nbr[:, :out.n] >= 0).sum())
         flop = 2.0 * pairs * W.shape[1] * W.shape[2]
         line = "L%d %s %3d->%3d rows %6d pairs %8d density %.2f :" % (lvl, name, W.shape[1], W.shape[2], out.n, pairs, pairs / (27.0 * out.n))
         for m in modes:
-            ops.N.lib().dcl_debug_force_valu_conv(m)
-            us = timeit(lambda: ops.sparse_conv(f_in, nbr, out.n, W, subm))
+            if DIAG is not None:
+                ops.N.lib().dcl_debug_force_valu_conv(m)
+            us = timeit(lambda: ops.sparse_conv(f_in, nbr, out.n, W, subm, order=order))
             tot[m] += us
             line += "  mode%d %7.1f us (%5.1f TF useful)" % (m, us, flop / us / 1e6)
-        ops.N.lib().dcl_debug_force_valu_conv(0)
+        if DIAG is not None:
+            ops.N.lib().dcl_debug_force_valu_conv(0)
         print(line, flush=True)
         if x1 is None: x1 = ops.sparse_conv(f_in, nbr, out.n, W, subm)
     x2 = ops.sparse_conv(x1, nbr2, out.n, W2, True)

@@ -5,7 +5,7 @@
 #                                       gpurun_out/r1_pmcprim_<COUNTER>/        (north-star primitives)
 # then, back in the container: python tools/summarize_profiles.py r1  (copies the summaries into profiles/).
 # PMC passes are separate runs with --kernel-trace only, as the pool requires.
-R=${1:-r2}
+R=${1:-r3}
 export TMPDIR=/tmp
 cd "$(dirname "$0")/.." || exit 1
 O=gpurun_out
@@ -16,10 +16,18 @@ stats stress python3 bench.py --steps 20 --warmup 3 --no-extras
 stats ref    python3 bench.py --shape ref --steps 40 --warmup 3 --no-extras
 stats prim   python3 tools/bench_primitives.py
 stats stream python3 tools/profile_stream.py 1
+stats crops  python3 tools/bench_crops.py
+stats conv   python3 tools/bench_conv.py 1024 0
 for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
   pmc pmc $c python3 bench.py --steps 4 --warmup 2 --no-extras
 done
 for c in FETCH_SIZE WRITE_SIZE; do
   pmc pmcprim $c python3 tools/bench_primitives.py
+done
+for c in SQ_VALU_MFMA_BUSY_CYCLES; do
+  pmc pmcconv $c python3 tools/bench_conv.py 1024 0
+done
+for c in FETCH_SIZE WRITE_SIZE; do
+  pmc pmccrops $c python3 tools/bench_crops.py
 done
 ls $O | grep "^${R}_" | tr '\n' ' '

@@ -14,7 +14,8 @@ rnd = sys.argv[1] if len(sys.argv) > 1 else "r1"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
-for shape, tag in (("stress", "stress"), ("ref", "ref"), ("prim", "primitives"), ("stream", "stream_b1_graph")):
+for shape, tag in (("stress", "stress"), ("ref", "ref"), ("prim", "primitives"), ("stream", "stream_b1_graph"),
+                   ("crops", "crop_builder"), ("conv", "conv_layers")):
     found = sorted(glob.glob(os.path.join(root, "gpurun_out", "%s_%s" % (rnd, shape), "**", "*kernel_stats.csv"),
                              recursive=True), key=os.path.getmtime)
     if found:                                                   # the newest run of that shape
