@@ -15,8 +15,8 @@
 
 namespace {
 
-constexpr int kCropThreads = 256;
-constexpr int kCropChunk = 1024;               // pixels / rows per block step (4 consecutive per thread)
+constexpr int kCropThreads = 1024;              // one workgroup per instance: its loops over the box / the points are chains of
+constexpr int kCropChunk = 4096;                // dependent steps (load, scan, store), so the steps are made wide: 4 consecutive pixels / rows per thread
 
 // exclusive prefix of one small count per thread over the workgroup (order = thread id); returns the block total
 __device__ __forceinline__ int block_excl_scan(int v, int *s_wave /* [4] */, int &total) {
@@ -113,8 +113,19 @@ __global__ __launch_bounds__(kCropThreads) void k_crop_points(
     __syncthreads();
     for (int j = t; j < rows * 3; j += kCropThreads) s_stage[j] = rx[(size_t)base * 3 + j];
     __syncthreads();
-    if (t < 3)
-      for (int i = 0; i < rows; ++i) acc = acc + s_stage[i * 3 + t];
+    if (t < 3) {
+      // the sum is sequential by contract (row order, one rounding per row), i.e. a chain of `rows` dependent adds; what
+      // can be taken off the chain is everything else: 64 LDS reads in flight per 64 adds (4 cycles each once fed)
+      int i = 0;
+      for (; i + 64 <= rows; i += 64) {
+        float v[64];
+#pragma unroll
+        for (int q = 0; q < 64; ++q) v[q] = s_stage[(i + q) * 3 + t];
+#pragma unroll
+        for (int q = 0; q < 64; ++q) acc = acc + v[q];
+      }
+      for (; i < rows; ++i) acc = acc + s_stage[i * 3 + t];
+    }
   }
   if (t < 3) { const float cen = acc / (float)n; s_cen[t] = cen; centroid[inst * 3 + t] = cen; }
   __syncthreads();
