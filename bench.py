@@ -221,15 +221,15 @@ def whole_forward_rate(n_inp, n_tmp, b, step_s):
             "note": "fp32 MFMA work of the whole step / step time: what is left above the MFMA floor is the sparse prefix"}
 
 
-def lm_stream_bench(dcl, dev, reps=30):
+def lm_stream_bench(dcl, dev, reps=30, b=1):
     """BASELINE config 4 (S3): LineMOD eval stream -- one object crop per call (tools/test_LM.py:104-112), N=M=1024,
     5 mm voxels (configs/config_LM.yaml:17-20); forward() vs the whole-forward hipGraph replay, inputs resident in HBM."""
     cfg = dcl.synth.default_cfg(1024, 1024, unit=0.005)
     net = dcl.DCL_Net.Network(cfg, mode="test", graph_max_batch=0)      # "eager" below is the plain launch-by-launch call
     net.load_state_dict(dcl.synth.synth_state_dict(net, 1))
     net = net.to(dev).eval()
-    out = {"workload": "LineMOD stream: 1 crop per call, N=M=1024, 64^3 x 5 mm voxels"}
-    data = to_device(dcl.synth.make_batch(1, 1024, 1024, unit=0.005), dev)
+    out = {"workload": "LineMOD stream: %d crop%s per call, N=M=1024, 64^3 x 5 mm voxels" % (b, "" if b == 1 else "s")}
+    data = to_device(dcl.synth.make_batch(b, 1024, 1024, unit=0.005), dev)
     for name, fn in (("eager", lambda: net(data)), ("hipgraph", lambda: net.forward_graphed(data))):
         with torch.no_grad():
             for _ in range(3):
@@ -249,10 +249,11 @@ def lm_stream_bench(dcl, dev, reps=30):
 def eval_stream_bench(dcl, dev, images=40, n_obj=6):
     """The reference's eval loop as ONE pipeline (tools/test_YCBV_stage1.py:173-199; SURVEY 8f-1 + path + 8f-2): per 480x640
     frame with `n_obj` objects  CropBuilder.build -> Network.forward -> ADD-S -> per-class table,  frames resident in HBM
-    (decoded ahead, like the forward's own inputs), N = M = 1024, 6 mm voxels.  Two schedules: `serial` = the reference's
+    (decoded ahead, like the forward's own inputs), N = M = 1024, 6 mm voxels.  Three schedules: `serial` = the reference's
     order, one frame after the other on one stream; `pipelined` = frame k+1 is built on a second stream (its two host
     synchronisations and the loader's np.random.choice draws then run underneath frame k's forward; the network waits for the
-    builder's ready_event).  Same crops, same results.  The ADD-S values stay on the device until the stream ends (one
+    builder's ready_event); `prefetch_thread` = crops.CropPrefetcher, the role of the reference's DataLoader workers (:133-137):
+    a builder thread keeps two frames ahead of the network's thread.  Same crops, same results.  The ADD-S values stay on the device until the stream ends (one
     read-back for the table).  Also reported: each stage alone (device-synchronised), and the LineMOD-regime variant
     (tools/test_LM.py:104-141: one object per frame, 5 mm voxels, ADD / ADD-S by symmetry flag, success counts)."""
     out = {}
@@ -306,7 +307,7 @@ def eval_stream_bench(dcl, dev, images=40, n_obj=6):
                 metric(d, net(d))
             torch.cuda.synchronize()
             ref_d = None
-            for sched in ("serial", "pipelined"):
+            for sched in ("serial", "pipelined", "prefetch_thread"):
                 np.random.seed(2)
                 dist_dev, crops = [], 0
                 torch.cuda.synchronize()
@@ -317,7 +318,7 @@ def eval_stream_bench(dcl, dev, images=40, n_obj=6):
                         p = net(d)
                         dist_dev.append((d["obj_idx"], d["all_flags"], metric(d, p)))
                         crops += int(p["rot_pred"].shape[0])
-                else:
+                elif sched == "pipelined":
                     d = build_ahead(0)
                     for i in range(images):
                         main.wait_event(d["ready_event"])
@@ -326,6 +327,14 @@ def eval_stream_bench(dcl, dev, images=40, n_obj=6):
                         crops += int(p["rot_pred"].shape[0])
                         if i + 1 < images:
                             d = build_ahead(i + 1)
+                else:                                             # the loader-worker role: a builder thread, two frames ahead
+                    args = ((res[i % 4][0], res[i % 4][1], res[i % 4][2], frames[i % 4]["rois"], frames[i % 4]["gt_obj"],
+                             {"poses": frames[i % 4]["poses"]}) for i in range(images))
+                    with dcl.crops.CropPrefetcher(builder, args, depth=2, priority=int(os.environ.get("DCL_PREFETCH_PRIO", "-1"))) as feed:
+                        for d in feed:
+                            p = net(d)
+                            dist_dev.append((d["obj_idx"], d["all_flags"], metric(d, p)))
+                            crops += int(p["rot_pred"].shape[0])
                 torch.cuda.synchronize()
                 table = tabulate(dist_dev)
                 dt = time.perf_counter() - t0
@@ -334,7 +343,7 @@ def eval_stream_bench(dcl, dev, images=40, n_obj=6):
                     ref_d = dd
                 res_tag[sched] = {"images_per_s": round(images / dt, 1), "crops_per_s": round(crops / dt, 1),
                                   "ms_per_image": round(dt / images * 1e3, 3)}
-                if sched == "pipelined":
+                if sched != "serial":
                     res_tag[sched]["same_distances_as_serial"] = bool(torch.equal(dd, ref_d))
             # stages alone, device-synchronised
             stage = {}

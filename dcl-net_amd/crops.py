@@ -243,3 +243,93 @@ class CropBuilder(object):
         feats, coords = ops.crop_sample(xyz, col, pick_t, None, self.extent[0] * 0.5, self.unit, int(self.limit[0]))
         row = self.cls_row[int(obj)]
         return feats, coords[:, 1:].contiguous(), self.tmp_feats[row], self.tmp_vox[row], centroid[0]
+
+
+class CropPrefetcher(object):
+    """The role of the reference's loader workers (torch.utils.data.DataLoader(num_workers=...), tools/test_YCBV_stage1.py:133-
+    137, tools/test_LM.py:88-92: frames are prepared ahead of the network): ONE host thread builds the crops of up to `depth`
+    frames ahead on its own stream while the caller's thread runs the network.  `frames` yields the argument tuples of
+    CropBuilder.build (a trailing dict = keyword arguments).  The frames are built strictly in order by that one thread, so
+    a seeded run consumes the global np.random stream exactly like a serial loop; the caller must not draw from np.random
+    while iterating.  Iterating yields build()'s dicts: the caller's current stream already waits for the builder's
+    ready_event, and every tensor is marked as used on that stream (allocator hand-over between streams)."""
+    _END = object()
+
+    def __init__(self, builder, frames, depth=2, priority=-1):
+        import queue
+        import threading
+        self.builder, self.dev = builder, builder.dev
+        self._q = queue.Queue(maxsize=max(1, int(depth)))
+        self._stop = threading.Event()
+        self._priority = int(priority)
+        self._thread = threading.Thread(target=self._work, args=(iter(frames),), name="dcl-crop-prefetch", daemon=True)
+        self._thread.start()
+
+    def _put(self, item):
+        import queue
+        while not self._stop.is_set():
+            try:
+                self._q.put(item, timeout=0.05)
+                return True
+            except queue.Full:
+                continue
+        return False
+
+    def _work(self, frames):
+        try:
+            with torch.cuda.device(self.dev):
+                stream = torch.cuda.Stream(self.dev, priority=self._priority)
+                with torch.cuda.stream(stream):
+                    for args in frames:
+                        if self._stop.is_set():
+                            return
+                        args = tuple(args)
+                        kw = args[-1] if args and isinstance(args[-1], dict) else {}
+                        if kw:
+                            args = args[:-1]
+                        if not self._put(self.builder.build(*args, **kw)):
+                            return
+            self._put(self._END)
+        except BaseException as e:                      # handed to the consumer, raised from its next()
+            self._put(e)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        item = self._q.get()
+        if item is self._END:
+            self._q.put(item)                           # a second next() ends as well
+            raise StopIteration
+        if isinstance(item, BaseException):
+            self._q.put(self._END)
+            raise item
+        cur = torch.cuda.current_stream(self.dev)
+        cur.wait_event(item["ready_event"])
+
+        def mark(v):
+            if torch.is_tensor(v):
+                if v.is_cuda:
+                    v.record_stream(cur)
+            elif isinstance(v, dict):
+                for x in v.values():
+                    mark(x)
+        mark(item)
+        return item
+
+    def close(self):
+        """stop the builder thread (frames already built are dropped)"""
+        import queue
+        self._stop.set()
+        try:
+            while True:
+                self._q.get_nowait()
+        except queue.Empty:
+            pass
+        self._thread.join(timeout=5.0)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

@@ -416,6 +416,27 @@ __device__ __forceinline__ void conv_glds16(const void *gsrc, unsigned lds_byte_
                : "v"(gsrc), "s"(lds_byte_addr)
                : "memory");
 }
+// N pieces whose LDS destinations are 1 KiB apart, ONE M0 value: the destination of piece i is the instruction's offset
+// field (i * 1024), which the hardware adds to the GLOBAL address as well -- the caller's source pointer of piece i is
+// pre-decremented by i * 1024 bytes.  One wave pays ~45 cycles per piece for this form against ~58 for an M0 write per
+// piece (tools/ubench_glds.hip; four waves issuing at once: 83 against 119).
+template <int N>
+__device__ __forceinline__ void conv_glds16_group(const float *const *gsrc, unsigned lds_byte_addr) {
+  static_assert(N == 1 || N == 2 || N == 4, "pieces per group");
+  unsigned keep;
+  if constexpr (N == 1)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc[0]), "s"(lds_byte_addr) : "memory");
+  else if constexpr (N == 2)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                 "global_load_lds_dwordx4 %2, off offset:1024\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc[0]), "v"(gsrc[1]), "s"(lds_byte_addr) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                 "global_load_lds_dwordx4 %2, off offset:1024\n\tglobal_load_lds_dwordx4 %3, off offset:2048\n\t"
+                 "global_load_lds_dwordx4 %4, off offset:3072\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc[0]), "v"(gsrc[1]), "v"(gsrc[2]), "v"(gsrc[3]), "s"(lds_byte_addr) : "memory");
+}
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 // 16-B write-through (sc1) store: the payload of an in-launch hand-off (cdna_hip_programming.md Guideline 16, R1)
 __device__ __forceinline__ void conv_store16_wt(f32x4 *p, f32x4 v) {
@@ -581,7 +602,7 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
     unsigned mymask = 0;
     const int sx_lo = (j_begin * KC) / CIN;
     const int sx_hi = min(kvol - 1, (nchunks * KC - 1) / CIN);
-#pragma unroll 4                                           // several rounds of lookups in flight (2-3 dependent loads each)
+#pragma unroll NW == 4 ? 8 : 4                             // several rounds of lookups in flight (2-3 dependent loads each)
     for (int e = tid; e < (sx_hi - sx_lo + 1) * BM; e += NTHR) {
       const int si = e / BM, rr = e - si * BM;
       const int k = offset_at(sx_lo + si, kvol, subm);
@@ -644,8 +665,11 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
         b_off[i] = (CIN >= KC ? b_kk[i] : (b_kk[i] % CIN)) * cout + bcol;      // W row inside the chunk's offset, column piece
       }
     };
-    // prep(j): the global source of every DMA piece of chunk j (registers); fire(p, stage): piece p goes out.
+    // prep(j): the global source of every DMA piece of chunk j (registers), piece i of a group of GRP pieces pre-decremented
+    // by i KiB (conv_glds16_group); fire_all(stage): the chunk's pieces go out, W first (their sources are ready first).
     constexpr int NPIECE = A_PER + B_PER;
+    constexpr int AGRP = A_PER >= 4 ? 4 : A_PER, BGRP = B_PER >= 4 ? 4 : B_PER;
+    static_assert(A_PER % AGRP == 0 && B_PER % BGRP == 0 && (AGRP == 1 || AGRP == 2 || AGRP == 4) && (BGRP == 1 || BGRP == 2 || BGRP == 4), "DMA groups");
     const float *psrc[NPIECE];
     auto prep = [&](int j) {
       const float **asrc = psrc, **bsrc = psrc + A_PER;
@@ -660,10 +684,10 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
         for (int i = 0; i < A_PER; ++i) v[i] = nrow[a_row[i]];
         const float *wbase = W + ((size_t)k * CIN + chb) * cout;
 #pragma unroll
-        for (int i = 0; i < B_PER; ++i) bsrc[i] = wbase + b_off[i];
+        for (int i = 0; i < B_PER; ++i) bsrc[i] = wbase + b_off[i] - (i % BGRP) * 256;
         const float *fbase = feat + chb;
 #pragma unroll
-        for (int i = 0; i < A_PER; ++i) asrc[i] = v[i] >= 0 ? fbase + ((size_t)v[i] * CIN + a_chs[i]) : zero;
+        for (int i = 0; i < A_PER; ++i) asrc[i] = (v[i] >= 0 ? fbase + ((size_t)v[i] * CIN + a_chs[i]) : zero) - (i % AGRP) * 256;
       } else {                                           // CIN = 16: the chunk spans two offsets, the piece decides which
         const int sx0 = j * SPC;
         const int k0 = offset_at(sx0, kvol, subm);
@@ -679,16 +703,19 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
           const bool second = b_kk[i] >= CIN;
-          bsrc[i] = (second && !has1) ? zero : W + (size_t)(second ? k1 : k0) * CIN * cout + b_off[i];
+          bsrc[i] = ((second && !has1) ? zero : W + (size_t)(second ? k1 : k0) * CIN * cout + b_off[i]) - (i % BGRP) * 256;
         }
 #pragma unroll
-        for (int i = 0; i < A_PER; ++i) asrc[i] = v[i] >= 0 ? feat + ((size_t)v[i] * CIN + (a_chs[i] & (CIN - 1))) : zero;
+        for (int i = 0; i < A_PER; ++i)
+          asrc[i] = (v[i] >= 0 ? feat + ((size_t)v[i] * CIN + (a_chs[i] & (CIN - 1))) : zero) - (i % AGRP) * 256;
       }
     };
-    auto fire = [&](int p, int stage) {                  // p is a compile-time constant at every call site
+    auto fire_all = [&](int stage) {
       float *As = conv_lds + stage * ST, *Bs = As + AT;
-      if (p < A_PER) conv_glds16(psrc[p], conv_lds_addr(As + (wave * A_PER + p) * 256));
-      else conv_glds16(psrc[p], conv_lds_addr(Bs + (wave * B_PER + (p - A_PER)) * 256));
+#pragma unroll
+      for (int g = 0; g < B_PER; g += BGRP) conv_glds16_group<BGRP>(psrc + A_PER + g, conv_lds_addr(Bs + (wave * B_PER + g) * 256));
+#pragma unroll
+      for (int g = 0; g < A_PER; g += AGRP) conv_glds16_group<AGRP>(psrc + g, conv_lds_addr(As + (wave * A_PER + g) * 256));
     };
     // steps under which at least one of THIS WAVE's 32 rows has a neighbour (wave-level skip of a chunk's MFMA block)
     unsigned wsmask = 0;
@@ -711,11 +738,17 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
       for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
     int j = next_used(j_begin), cur = 0;
     CONV_STAMP(1);
+    // Four-wave tiles have registers to spare (2 workgroups x 4 waves per CU = 2 waves per SIMD): the sources of the chunk
+    // AFTER the next are prepared under the MFMA block (LDS reads of the neighbour table + address arithmetic), so that only
+    // the DMA instructions themselves stand between the barrier and the MFMAs.  Eight-wave tiles sit at their 128 registers
+    // and prepare right before they fire.
+    constexpr bool PIPE = NW == 4;
     if (j < nchunks) {
       prep(j);
-#pragma unroll
-      for (int p = 0; p < NPIECE; ++p) fire((p + A_PER) % NPIECE, 0);       // W pieces first: their sources are ready first
+      fire_all(0);
     }
+    int jn = next_used(j + 1);
+    if (PIPE && jn < nchunks) prep(jn);
     bool first_chunk = true;
 #ifdef DCL_CONV_STAMPS
     unsigned long long ph_wait = 0, ph_bar = 0, ph_issue = 0, ph_mfma = 0, ph_t = __builtin_amdgcn_s_memtime(), ph_n = 0;
@@ -729,12 +762,12 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
       __syncthreads();                                   // ... everyone's have, and stage cur^1 has no reader left
       PH(ph_bar);
       if (first_chunk) { CONV_STAMP(2); first_chunk = false; }
-      const int jn = next_used(j + 1);
       if (jn < nchunks) {                                // (spreading the pieces over the MFMA groups was measured: the wave
-        prep(jn);                                        //  pays the same ~350 cycles per piece there, nothing is hidden)
-#pragma unroll
-        for (int p = 0; p < NPIECE; ++p) fire((p + A_PER) % NPIECE, cur ^ 1);
+        if (!PIPE) prep(jn);                             //  pays the same per piece there, nothing is hidden)
+        fire_all(cur ^ 1);
       }
+      const int jn2 = next_used(jn + 1);
+      if (PIPE && jn2 < nchunks) prep(jn2);
       PH(ph_issue);
       // wave-level skip: none of this wave's 32 rows has a neighbour under any offset of the chunk
       const bool mine = SPC == 1 ? ((wsmask >> (j / CPK)) & 1u) != 0 : ((wsmask >> (j * SPC)) & ((1u << SPC) - 1u)) != 0;
@@ -764,6 +797,7 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
       ++ph_n;
 #endif
       j = jn;
+      jn = jn2;
       cur ^= 1;
     }
 #ifdef DCL_CONV_STAMPS
@@ -967,10 +1001,21 @@ __global__ __launch_bounds__(256) void k_conv_frag_reduce(const float *__restric
   const size_t tile_f4 = (size_t)NW * NT * 4 * 64;
   const f32x4 *base = reinterpret_cast<const f32x4 *>(partial) + piece;
   f32x4 a = {0.f, 0.f, 0.f, 0.f};
-  for (int w = w_first; w <= w_last; ++w) {
-    const f32x4 v = base[(size_t)(2 * w + (w * U >= tile * C ? 0 : 1)) * tile_f4];
-    if (w == w_first) a = v;
-    else { a.x = a.x + v.x; a.y = a.y + v.y; a.z = a.z + v.z; a.w = a.w + v.w; }
+  constexpr int ZR = 9;                                                      // segments in flight per round (27 = 3 rounds)
+#pragma unroll 1
+  for (int w0 = w_first; w0 <= w_last; w0 += ZR) {
+    f32x4 v[ZR];
+#pragma unroll
+    for (int i = 0; i < ZR; ++i) {
+      const int w = w0 + i <= w_last ? w0 + i : w_last;                      // clamped: loaded, not added
+      v[i] = base[(size_t)(2 * w + (w * U >= tile * C ? 0 : 1)) * tile_f4];
+    }
+#pragma unroll
+    for (int i = 0; i < ZR; ++i) {
+      const bool first = w0 + i == w_first, live = w0 + i <= w_last;
+      const f32x4 sum = {a.x + v[i].x, a.y + v[i].y, a.z + v[i].z, a.w + v[i].w};
+      a = first ? v[i] : (live ? sum : a);
+    }
   }
   const int second = tile >= tiles0 ? 1 : 0;
   const DclConvSide &S = sides.s[second];
@@ -1003,6 +1048,7 @@ static bool conv_few_rows(int rows, bool capacity_mode) { return capacity_mode ?
 // compile-time constants in the product library -- the product has no hooks, no superseded kernels and no getenv
 DCL_HOOK_INT(g_conv_xcd_remap, 1);   // 0 = plain blockIdx order
 DCL_HOOK_INT(g_conv_slots, 512);     // workgroups a launch is dealt over (2 x 256 resident slots)
+DCL_HOOK_INT(g_conv_few_chunks, 4);  // chunks per workgroup (at least) of a few-row launch
 DCL_HOOK_INT(g_conv_split, 0);       // 0 = automatic, n = force n-way split-K when scratch allows, -1 = never more than kConvMaxSplit, -2 = never split, -3 = few-row combine inside the launch
 #ifdef DCL_DIAG
 static std::atomic<int> g_conv_order_mode{0};   // A/B: 0 = as given, 1 = ignore the row order (natural rows), 2 = order but nominal chunk units
@@ -1050,7 +1096,8 @@ static void launch_conv_dma(const DclConvSides &sides, int nsides, int cout, int
   //   stream-K         ceil(units / 512) + 2 f + 1                -- everything else (no partial rounds, no idle slots)
   // A handful of crops (one-image calls) is latency-bound on the chunk loop: stream-K with kFewChunks chunks per workgroup.
   const int nchunks = dcl_div_up(kvol * CIN, KC);
-  constexpr int kFewChunks = 4, kFix = 4;
+  constexpr int kFix = 4;
+  const int kFewChunks = g_conv_few_chunks;
   const int kSlots = g_conv_slots;
   const long long units = (long long)tiles * nchunks;
   int stream_k = 0, aligned_ns = 0, G = tiles < 65535 * 16 ? tiles : 65535 * 16;
@@ -1089,7 +1136,7 @@ static void launch_conv_dma(const DclConvSides &sides, int nsides, int cout, int
     }
     if (aligned_ns || stream_k) {
       partial = scratch + kConvCounterWords;
-      deferred = stream_k == kFewChunks && g_conv_split != -3;     // few rows: many segments per tile, combine = own launch (-3: A/B, in the launch)
+      deferred = few && stream_k == kFewChunks && g_conv_split != -3;     // few rows: many segments per tile, combine = own launch (-3: A/B, in the launch)
       if (!deferred) {
         counters = reinterpret_cast<int32_t *>(scratch);
         if (!counters_ready) dcl_internal_zero_words(counters, kConvCounterWords, s);
@@ -1215,18 +1262,19 @@ __global__ __launch_bounds__(256) void k_sparse_avgpool(const DclConvSides sides
     if (rf_in) rf = rf_in[row];                            // caller's summaryrf (indice_avgpool_fp32's 5th argument)
     const float d = (float)rf;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    // nine neighbour rows in flight at a time (a missing neighbour loads row 0 and is not added): the loads of the whole
+    // all 27 neighbour rows in flight (a missing neighbour loads row 0 and is not added): the loads of the whole
     // window used to be 27 dependent steps -- a branch on the LDS value in front of each -- which is what a pool of a few
     // hundred rows (one-image calls) spent its time on.  The terms are still added in ascending offset order.
-    for (int k0 = 0; k0 < kvol; k0 += 9) {
-      float4 f[9];
+    constexpr int PF = 27;                                   // the whole window in flight
+    for (int k0 = 0; k0 < kvol; k0 += PF) {
+      float4 f[PF];
 #pragma unroll
-      for (int j = 0; j < 9; ++j) {
+      for (int j = 0; j < PF; ++j) {
         const int vk = k0 + j < kvol ? v[k0 + j] : -1;
         f[j] = reinterpret_cast<const float4 *>(feat + (size_t)(vk < 0 ? 0 : vk) * c)[q];
       }
 #pragma unroll
-      for (int j = 0; j < 9; ++j) {
+      for (int j = 0; j < PF; ++j) {
         const bool ok = k0 + j < kvol && v[k0 + j] >= 0;
         acc.x = ok ? acc.x + f[j].x / d : acc.x; acc.y = ok ? acc.y + f[j].y / d : acc.y;
         acc.z = ok ? acc.z + f[j].z / d : acc.z; acc.w = ok ? acc.w + f[j].w / d : acc.w;
@@ -1268,6 +1316,7 @@ DCL_HOOK_INT(g_force_valu, 0);   // 1 = plain VALU kernel for every conv, 2 = MF
 #ifdef DCL_DIAG
 DCL_API void dcl_debug_force_valu_conv(int on) { g_force_valu = on; }
 DCL_API void dcl_debug_conv_split(int n) { g_conv_split = n; }
+DCL_API void dcl_debug_conv_few_chunks(int n) { g_conv_few_chunks = n >= 1 ? n : 4; }
 DCL_API void dcl_debug_conv_order_mode(int mode) { g_conv_order_mode = mode; }
 DCL_API void dcl_debug_conv_slots(int n) { g_conv_slots = (n >= 64 && n <= 512) ? n : 512; }
 DCL_API void dcl_debug_conv_xcd_remap(int on) { g_conv_xcd_remap = on; }

@@ -495,6 +495,8 @@ void dcl_debug_nn_batched_mode(int mode);
 /* Tuning hook: 0 = automatic split-K choice in dcl_sparse_conv_fwd_ws, n = force n splits (when the scratch allows),
  * -1 = at most 8 splits even for few-row launches, -2 = never split. */
 void dcl_debug_conv_split(int n);
+/* Tuning hook: least number of chunks a workgroup of a few-row conv launch walks (default 4). */
+void dcl_debug_conv_few_chunks(int n);
 /* Tuning hook: number of workgroups the stream-K / split-K decompositions of a sparse-conv launch are dealt over (default
  * 512 = the 2 x 256 resident slots; 256 leaves one slot per CU to a concurrent launch of the other backbone).  64..512. */
 void dcl_debug_conv_slots(int n);

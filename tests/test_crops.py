@@ -144,6 +144,36 @@ def test_built_crops_run_through_the_network(dcl):
 
 
 @pytest.mark.gpu
+def test_prefetcher_yields_the_serial_loops_crops(dcl):
+    """crops.CropPrefetcher (the loader workers' role, tools/test_YCBV_stage1.py:133-137): a builder thread two frames ahead of
+    the caller yields, frame by frame, exactly what a serial loop over CropBuilder.build yields under the same seed; an error
+    in the builder thread surfaces in the caller"""
+    cfg = dict(CFG, input_size=256, tmp_size=256)
+    scenes = [make_scene(30 + i, n_obj=3, tmp_size=256) for i in range(3)]
+    builder = dcl.crops.CropBuilder(cfg, scenes[0]["cad_pts"], scenes[0]["cad_col"])
+    order = [0, 1, 2, 1, 0, 2, 2]
+    args = lambda i: (scenes[i]["img"], scenes[i]["depth"], scenes[i]["label"], scenes[i]["rois"], scenes[i]["gt_obj"])  # noqa: E731
+    np.random.seed(11)
+    want = [builder.build(*args(i)) for i in order]
+    torch.cuda.synchronize()
+    np.random.seed(11)
+    n = 0
+    with dcl.crops.CropPrefetcher(builder, (args(i) for i in order), depth=2) as feed:
+        for got, ref in zip(feed, want):
+            for side in ("inp", "tmp"):
+                for k in ("feats", "occupied_voxels", "p2v_maps", "v2p_maps"):
+                    assert torch.equal(got[side][k], ref[side][k]), (n, side, k)
+            assert torch.equal(got["all_flags"], ref["all_flags"])
+            n += 1
+    assert n == len(order)
+    bad = (args(0), (None,) * 5)
+    with dcl.crops.CropPrefetcher(builder, bad, depth=2) as feed:
+        next(feed)
+        with pytest.raises(Exception):
+            next(feed)
+
+
+@pytest.mark.gpu
 def test_device_crop_builder_timing(dcl, capsys):
     """reported number: device builder vs the CPU restatement of the loader on one 6-object frame"""
     import time
