@@ -100,6 +100,11 @@ struct DclConvSide {
   DclRowOrder ord;
   int cap, n_host;
 };
+// the problems of one dcl_linear_group_fwd launch (kernel argument)
+struct DclLinearJobs {
+  DclLinearJob job[DCL_LINEAR_MAX_JOBS];
+};
+
 struct DclConvSides {
   DclConvSide s[2];
 };

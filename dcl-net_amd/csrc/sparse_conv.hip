@@ -1048,6 +1048,7 @@ static bool conv_few_rows(int rows, bool capacity_mode) { return capacity_mode ?
 // compile-time constants in the product library -- the product has no hooks, no superseded kernels and no getenv
 DCL_HOOK_INT(g_conv_xcd_remap, 1);   // 0 = plain blockIdx order
 DCL_HOOK_INT(g_conv_slots, 512);     // workgroups a launch is dealt over (2 x 256 resident slots)
+DCL_HOOK_INT(g_conv_few_tiles, 1);   // 1 = few-row launches on 64-row tiles, 0 = 128-row tiles for every launch
 DCL_HOOK_INT(g_conv_few_chunks, 4);  // chunks per workgroup (at least) of a few-row launch
 DCL_HOOK_INT(g_conv_split, 0);       // 0 = automatic, n = force n-way split-K when scratch allows, -1 = never more than kConvMaxSplit, -2 = never split, -3 = few-row combine inside the launch
 #ifdef DCL_DIAG
@@ -1317,6 +1318,7 @@ DCL_HOOK_INT(g_force_valu, 0);   // 1 = plain VALU kernel for every conv, 2 = MF
 DCL_API void dcl_debug_force_valu_conv(int on) { g_force_valu = on; }
 DCL_API void dcl_debug_conv_split(int n) { g_conv_split = n; }
 DCL_API void dcl_debug_conv_few_chunks(int n) { g_conv_few_chunks = n >= 1 ? n : 4; }
+DCL_API void dcl_debug_conv_few_tiles(int on) { g_conv_few_tiles = on; }
 DCL_API void dcl_debug_conv_order_mode(int mode) { g_conv_order_mode = mode; }
 DCL_API void dcl_debug_conv_slots(int n) { g_conv_slots = (n >= 64 && n <= 512) ? n : 512; }
 DCL_API void dcl_debug_conv_xcd_remap(int on) { g_conv_xcd_remap = on; }
@@ -1479,7 +1481,14 @@ static int conv_dispatch(const DclConvSides &sides_in, int nsides_in, int cin, i
   const bool diag_tile = false;
 #endif
   if (lds_ok && !diag_tile) {
-    // LDS-DMA implicit-GEMM kernel; the tile shape follows Cout
+    // LDS-DMA implicit-GEMM kernel; the tile shape follows Cout.  Few-row launches (a handful of crops; latency-bound) take
+    // 64-row tiles: twice the workgroups, half the MFMA time per chunk and half the neighbour table per workgroup.
+    int rows_max = 0;
+    for (int i = 0; i < nsides; ++i) {
+      const int r_i = sides.s[i].n_dev ? sides.s[i].cap : sides.s[i].n_host;
+      rows_max = r_i > rows_max ? r_i : rows_max;
+    }
+    const bool few_tiles = g_conv_few_tiles != 0 && scratch && cout % 64 == 0 && conv_few_rows(rows_max, sides.s[0].n_dev != nullptr);
 #define DMA_ARGS sides, nsides, cout, kvol, subm, relu, scratch, (long long)scratch_floats, counters_ready, s
 #ifdef DCL_DIAG
     if (g_force_valu == 5 && cout % 128 != 0 && cout % 64 == 0) {          // A/B: 8 waves of 32x32 on 128x64 tiles
@@ -1491,7 +1500,23 @@ static int conv_dispatch(const DclConvSides &sides_in, int nsides_in, int cin, i
       }
     } else
 #endif
-    if (cout % 64 != 0) {                                                   // Cout = 32: LDS-DMA kernel on 128x32 tiles
+    if (few_tiles) {                                                        // few rows: 64-row tiles (see above)
+      if (cout % 128 == 0) {
+        switch (cin) {
+          case 16: launch_conv_dma<16, 2, 2, 2>(DMA_ARGS); break;
+          case 32: launch_conv_dma<32, 2, 2, 2>(DMA_ARGS); break;
+          case 64: launch_conv_dma<64, 2, 2, 2>(DMA_ARGS); break;
+          default: launch_conv_dma<128, 2, 2, 2>(DMA_ARGS); break;
+        }
+      } else {                                                              // 64x64 tiles, 4 waves of 32x32
+        switch (cin) {
+          case 16: launch_conv_dma<16, 2, 2, 1>(DMA_ARGS); break;
+          case 32: launch_conv_dma<32, 2, 2, 1>(DMA_ARGS); break;
+          case 64: launch_conv_dma<64, 2, 2, 1>(DMA_ARGS); break;
+          default: launch_conv_dma<128, 2, 2, 1>(DMA_ARGS); break;
+        }
+      }
+    } else if (cout % 64 != 0) {                                            // Cout = 32: LDS-DMA kernel on 128x32 tiles
       switch (cin) {
         case 16: launch_conv_dma<16, 4, 1, 1>(DMA_ARGS); break;
         case 32: launch_conv_dma<32, 4, 1, 1>(DMA_ARGS); break;

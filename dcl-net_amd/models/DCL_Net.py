@@ -213,7 +213,10 @@ class Network(nn.Module):
             for name in ("regressor_conf", "regressor_conf_bi", "regressor_rot", "regressor_trans", "regressor_Xo",
                          "regressor_Yc"):
                 L = getattr(self, name).layers
-                f[name] = [(L[i].weight[:, :, 0].t().contiguous(), L[i].bias.contiguous()) for i in (0, 2, 4)]
+                # (the confidence heads' last layer, one output column, sits in rows padded to 4 floats: what
+                # ops.linear_group's 16-byte pieces want; the library GEMM takes the row pitch as its leading dimension)
+                pad = ops.pad_linear_weight if name.startswith("regressor_conf") else (lambda w: w.contiguous())
+                f[name] = [(pad(L[i].weight[:, :, 0].t()), L[i].bias.contiguous()) for i in (0, 2, 4)]
             for name in ("neck_fuser", "neck_fuser_bi"):
                 L = getattr(self, name).layers      # Conv,ReLU,BN, Conv,ReLU,BN, Conv,ReLU,BN
                 out, s_prev, t_prev = [], None, None
@@ -426,6 +429,8 @@ class Network(nn.Module):
         return cache[key]
 
     _DIS_TAGS = (("p1", 256), ("m1", 64), ("p2", 256), ("m2", 64))
+    GROUP_ROWS = 8 * 1024     # calls of at most this many points per side issue independent MLP layers as ONE launch each
+                              # (ops.linear_group); larger ones keep one library GEMM per layer
     MAX_GRAPHS = 8            # captured whole-forward graphs kept per instance (one per batch size; least recently used goes)
     GRAPH_ADMIT = 3           # with a full cache, a new batch size is captured (evicting the LRU one) on its 3rd call
 
@@ -447,6 +452,10 @@ class Network(nn.Module):
         second layers, written into rows `rows` of the activation buffers in `act`"""
         W1t, t1, second = f["dis_" + side]
         H = self._lin_relu(pf_rows, W1t, t1)                                # (rows, 1024): 4 stacks at once
+        if pf_rows.shape[0] <= self.GROUP_ROWS:                             # a handful of crops: the four layers in ONE launch
+            ops.linear_group([(H[:, 256 * j:256 * (j + 1)], second[j][0], second[j][1], True, act[side + tag][rows])
+                              for j, (tag, _) in enumerate(self._DIS_TAGS)])
+            return
         for j, (tag, _) in enumerate(self._DIS_TAGS):
             Wt, bias = second[j]
             ops.linear(H[:, 256 * j:256 * (j + 1)], Wt, bias, True, out=act[side + tag][rows])
@@ -486,19 +495,22 @@ class Network(nn.Module):
         # already written their column block (_disengage_buffers), the attention fills the other one
         fuse1, conf_in1, fuse2, conf_in2 = act["fuse1"], act["conf_in1"], act["fuse2"], act["conf_in2"]
         (l1, sA, tA), (l2, sB, tB) = f["neck_fuser"], f["neck_fuser_bi"]
+        def conf_and_fuser(conf_in, fuse, conf_layers, fuser_layers):
+            """regressor_conf* (128 -> 128 -> 128 -> 1) and neck_fuser* (512 -> 512 -> 512 -> 1024) of one direction.  (Layer d
+            of both stacks as one ops.linear_group launch was measured for a handful of crops: 56 against 54 us at one crop,
+            156 against 142 at six -- the library's small-tile kernels are faster per layer than the grouped kernel's 64 x 64
+            tiles at K = 512, and the chain is three layers deep either way.)"""
+            F = fuse
+            for Wt, bias in fuser_layers:
+                F = self._lin_relu(F, Wt, bias)
+            return self._mlp(conf_in, conf_layers), F
         with second:
             ops.cross_attention(b, act["Yom2"], act["Xcm2"], act["Xcp2"], fuse2[:, :256], act["Xcm2"], conf_in2[:, :64])
-            logit2 = self._mlp(conf_in2, f["regressor_conf_bi"])
-            Fp2 = fuse2
-            for Wt, bias in l2:
-                Fp2 = self._lin_relu(Fp2, Wt, bias)
+            logit2, Fp2 = conf_and_fuser(conf_in2, fuse2, f["regressor_conf_bi"], l2)
             if side is not None:
                 logit2.record_stream(main); Fp2.record_stream(main)          # allocated on `side`, read on `main` below
         ops.cross_attention(b, act["Xcm1"], act["Yom1"], act["Yop1"], fuse1[:, 256:], act["Yom1"], conf_in1[:, 64:])
-        logit1 = self._mlp(conf_in1, f["regressor_conf"])                    # (b*N, 1)
-        Fp1 = fuse1
-        for Wt, bias in l1:
-            Fp1 = self._lin_relu(Fp1, Wt, bias)
+        logit1, Fp1 = conf_and_fuser(conf_in1, fuse1, f["regressor_conf"], l1)   # (b*N, 1), (b*N, 1024)
         join()
         # trailing BNs after pooling: F_p_wei = sA*P1 + tA*sum(w1) + sB*P2 + tB*sum(w2), finished inside the pooling op
         conf, F_p_wei = ops.conf_pool(b, logit1.reshape(-1), logit2.reshape(-1), Fp1, Fp2, affine=(sA, tA, sB, tB))

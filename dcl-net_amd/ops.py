@@ -797,6 +797,53 @@ def linear(x, Wt, bias=None, relu=False, out=None):
     return out
 
 
+class _LinearJob(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("ldx", C.c_int64), ("Wt", C.c_void_p), ("ldw", C.c_int64), ("bias", C.c_void_p),
+                ("y", C.c_void_p), ("ldy", C.c_int64), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("relu", C.c_int32)]
+
+
+LINEAR_GROUP_MAX = 8
+
+
+def linear_group(jobs):
+    """Independent per-point linear layers in ONE launch (csrc/linear_group.hip; calls of a handful of crops, where a forward
+    costs its number of dependent launches).  jobs: list of (x, Wt, bias, relu, out) with linear()'s conventions -- x (M,K),
+    Wt (K,N), out (M,N) row-major with free row pitches, out=None allocates; K % 32 == 0; a Wt whose N is not a multiple of 4
+    must be a column block of a buffer with rows padded to 4 floats (pad_linear_weight).  Returns the outputs."""
+    assert 1 <= len(jobs) <= LINEAR_GROUP_MAX
+    arr = (_LinearJob * len(jobs))()
+    outs, keep = [], []
+    pitch = lambda t: int(t.stride(0)) if t.shape[0] > 1 else max(int(t.stride(0)), int(t.shape[1]))   # noqa: E731
+    for q, (x, Wt, bias, relu, out) in zip(arr, jobs):
+        N.need_cuda(x, Wt)
+        assert x.dim() == 2 and Wt.dim() == 2 and x.shape[1] == Wt.shape[0] and x.dtype == Wt.dtype == torch.float32
+        M, K = x.shape
+        n = Wt.shape[1]
+        if out is None:
+            out = torch.empty((M, n), dtype=torch.float32, device=x.device)
+        assert out.shape == (M, n) and out.dtype == torch.float32 and out.is_cuda
+        for t in (x, Wt, out):
+            assert t.stride(1) == 1 or t.shape[1] == 1, "rows must be dense"
+        if bias is not None:
+            assert bias.is_cuda and bias.dtype == torch.float32 and bias.numel() == n and bias.is_contiguous()
+        q.x, q.ldx, q.Wt, q.ldw, q.bias = x.data_ptr(), pitch(x), Wt.data_ptr(), pitch(Wt), (None if bias is None else bias.data_ptr())
+        q.y, q.ldy, q.M, q.N, q.K, q.relu = out.data_ptr(), pitch(out), int(M), int(n), int(K), int(bool(relu))
+        outs.append(out)
+        keep.append((x, Wt, bias))
+    N.check(N.lib().dcl_linear_group_fwd(arr, len(jobs), N.stream()), "linear_group_fwd")
+    return outs
+
+
+def pad_linear_weight(Wt):
+    """(K,N) weight as a column block of a (K, N rounded up to 4) zero-padded buffer: what linear_group wants for N % 4 != 0"""
+    K, n = Wt.shape
+    if n % 4 == 0:
+        return Wt.contiguous()
+    buf = torch.zeros((K, (n + 3) // 4 * 4), dtype=Wt.dtype, device=Wt.device)
+    buf[:, :n] = Wt
+    return buf[:, :n]
+
+
 def ortho9d_to_matrix(o9):
     """ortho9d2matrix (models/DCL_Net.py:15-36): (b,9) -> (b,3,3)."""
     N.need_cuda(o9)

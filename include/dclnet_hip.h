@@ -389,6 +389,23 @@ int dcl_pose_heads(int b, const float *pooled, const float *const *rot_layers, c
 int dcl_linear_fwd(const float *x, int64_t ldx, const float *Wt, int64_t ldw, const float *bias, float *y, int64_t ldy,
                    int M, int N, int K, int relu, void *workspace, int64_t workspace_bytes, dclStream_t stream);
 
+/* Several INDEPENDENT per-point linear layers in one launch (csrc/linear_group.hip), for calls of a handful of crops: the
+ * reference issues every Conv1d(k=1) / 1x1x1 Conv3d of its MLP stacks as its own launch (models/Modules.py:58-97,173-201; the
+ * four disengage second layers of a side, models/DCL_Net.py:188-200, and a regressor_conf layer beside the neck_fuser layer
+ * of the same depth, :207-216, do not depend on each other).  Each job is dcl_linear_fwd's problem: y[M x N] = act(x[M x K]
+ * Wt[K x N] + bias[N]), row-major with free row pitches; K % 32 == 0, ldx % 4 == 0, ldw % 4 == 0 and ldw >= N rounded up to 4
+ * (a layer with N % 4 != 0 passes a zero-padded Wt), x and Wt 16-byte aligned.  Own fp32 MFMA kernel (64 x 64 tiles), the sum
+ * of an element runs over k ascending.  jobs: HOST array of njobs <= DCL_LINEAR_MAX_JOBS descriptors holding DEVICE pointers. */
+#define DCL_LINEAR_MAX_JOBS 8
+typedef struct DclLinearJob {
+  const float *x; int64_t ldx;
+  const float *Wt; int64_t ldw;
+  const float *bias;          /* may be NULL */
+  float *y; int64_t ldy;
+  int M, N, K, relu;
+} DclLinearJob;
+int dcl_linear_group_fwd(const DclLinearJob *jobs, int njobs, dclStream_t stream);
+
 /* ortho9d2matrix (models/DCL_Net.py:15-36): o9 (b,9) -> R (b,3,3).             */
 int dcl_ortho9d_to_matrix(int b, const float *o9, float *R, dclStream_t stream);
 
@@ -497,6 +514,8 @@ void dcl_debug_nn_batched_mode(int mode);
 void dcl_debug_conv_split(int n);
 /* Tuning hook: least number of chunks a workgroup of a few-row conv launch walks (default 4). */
 void dcl_debug_conv_few_chunks(int n);
+/* Tuning hook: 1 (default) = few-row conv launches use 64-row tiles, 0 = 128-row tiles for every launch. */
+void dcl_debug_conv_few_tiles(int on);
 /* Tuning hook: number of workgroups the stream-K / split-K decompositions of a sparse-conv launch are dealt over (default
  * 512 = the 2 x 256 resident slots; 256 leaves one slot per CU to a concurrent launch of the other backbone).  64..512. */
 void dcl_debug_conv_slots(int n);

@@ -862,6 +862,41 @@ def test_linear_layer_writes_column_blocks_in_place(dcl):
         dcl.ops.linear(torch.zeros(4, 8), torch.zeros(8, 2))               # host tensors are refused
 
 
+def test_linear_group_equals_separate_layers(dcl):
+    """dcl_linear_group_fwd (own fp32 MFMA kernel, several independent layers per launch) against float64 products: the
+    model's small-batch shapes -- the four disengage second layers of a side (column blocks in, column blocks out), a
+    confidence layer beside a fuser layer, a lone output column (zero-padded weight), ragged row counts"""
+    g = torch.Generator().manual_seed(5)
+    for M in (1024, 1000, 37, 2048):
+        H = torch.randn(M, 1024 + 8, generator=g).cuda()[:, 8:]                      # a column block: pitch 1032, 32-byte offset
+        fuse, conf_in = torch.full((M, 512), 7.0).cuda(), torch.full((M, 128), 7.0).cuda()
+        jobs, want = [], []
+        for j, n in enumerate((256, 64, 256, 64)):
+            Wt = (torch.randn(256, n, generator=g) * 0.05).cuda()
+            bias = torch.randn(n, generator=g).cuda()
+            out = (fuse[:, :256], conf_in[:, :64], None, None)[j]
+            jobs.append((H[:, 256 * j:256 * (j + 1)], Wt, bias, True, out))
+            want.append(torch.relu(H[:, 256 * j:256 * (j + 1)].double() @ Wt.double() + bias.double()))
+        got = dcl.ops.linear_group(jobs)
+        for a, w in zip(got, want):
+            assert float((a.double() - w).abs().max()) <= 2e-5 * max(1.0, float(w.abs().max())), M
+        assert bool((fuse[:, 256:] == 7.0).all()) and bool((conf_in[:, 64:] == 7.0).all())   # neighbours untouched
+        # mixed depths and a lone column; no bias / no ReLU
+        x1, x2 = torch.randn(M, 128, generator=g).cuda(), torch.randn(M, 512, generator=g).cuda()
+        W1 = dcl.ops.pad_linear_weight((torch.randn(128, 1, generator=g) * 0.1).cuda())
+        W2 = (torch.randn(512, 1024, generator=g) * 0.03).cuda()
+        W3 = (torch.randn(480, 96, generator=g) * 0.03).cuda()
+        x3 = torch.randn(M, 480, generator=g).cuda()
+        b2 = torch.randn(1024, generator=g).cuda()
+        o1, o2, o3 = dcl.ops.linear_group([(x1, W1, None, False, None), (x2, W2, b2, True, None), (x3, W3, None, True, None)])
+        for a, w in ((o1, x1.double() @ W1.double()), (o2, torch.relu(x2.double() @ W2.double() + b2.double())),
+                     (o3, torch.relu(x3.double() @ W3.double()))):
+            assert a.shape == w.shape
+            assert float((a.double() - w).abs().max()) <= 2e-5 * max(1.0, float(w.abs().max())), M
+    with pytest.raises(RuntimeError):
+        dcl.ops.linear_group([(torch.zeros(64, 48).cuda(), torch.zeros(48, 64).cuda(), None, False, None)])   # K % 32 != 0
+
+
 def test_pad_copy_many_stages_and_hands_over_in_one_launch(dcl):
     """dcl_pad_copy_many (input staging / result hand-over of the whole-forward hipGraph): zero-padded 2-D copies, int64
     narrowing, column blocks of wider buffers, scalar fills -- all in one launch, bit for bit what the torch ops did"""
