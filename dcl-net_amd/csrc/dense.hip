@@ -609,11 +609,16 @@ __global__ __launch_bounds__(256) void k_conf_softmax(int n1, int n2, const floa
 }
 
 // part[b][slice][c] = sum over this slice's points of w[j] * F[j][c]
-__global__ __launch_bounds__(256) void k_weighted_colsum(int c, int n, int nslices, const float *__restrict__ w,
-                                                         int w_stride, int w_off, const float *__restrict__ F, int ld,
-                                                         float *__restrict__ part) {
+// (both directions in one launch: blockIdx.y = direction * nslices + slice)
+__global__ __launch_bounds__(256) void k_weighted_colsum(int c, int n1, int n2, int nslices, const float *__restrict__ w,
+                                                         const float *__restrict__ F1, int ld1, float *__restrict__ part1,
+                                                         const float *__restrict__ F2, int ld2, float *__restrict__ part2) {
   __shared__ float4 red[4][64];
-  const int b = blockIdx.z, slice = blockIdx.y;
+  const int second = (int)blockIdx.y >= nslices ? 1 : 0;
+  const int b = blockIdx.z, slice = blockIdx.y - second * nslices;
+  const int n = second ? n2 : n1, ld = second ? ld2 : ld1, w_stride = n1 + n2, w_off = second ? n1 : 0;
+  const float *__restrict__ F = second ? F2 : F1;
+  float *__restrict__ part = second ? part2 : part1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ch = blockIdx.x * 256 + lane * 4;
   const int per = (n + nslices - 1) / nslices;
@@ -645,9 +650,7 @@ __global__ __launch_bounds__(256) void k_weighted_colsum(int c, int n, int nslic
 // R = U diag(1,1,det(U V^T)) V^T of the column-stacked, normalised raw vectors: one thread per crop,
 // one-sided Jacobi SVD in fp64 (the reference calls a batched LAPACK/MAGMA gesdd, ms-scale latency).
 // With A V = U Sigma:  R = u1 v1^T + u2 v2^T + det(V) (u1 x u2) v3^T   (sign-ambiguity free).
-__global__ void k_ortho9d(int b, const float *__restrict__ o9, float *__restrict__ R) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= b) return;
+__device__ void ortho9d_one(const float *__restrict__ o9, float *__restrict__ R, int i) {
   double A[3][3], V[3][3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -713,6 +716,10 @@ __global__ void k_ortho9d(int b, const float *__restrict__ o9, float *__restrict
 #pragma unroll
     for (int c = 0; c < 3; ++c)
       R[i * 9 + r * 3 + c] = (float)(u1[r] * v0[c] + u2[r] * v1[c] + detV * u3[r] * v2[c]);
+}
+__global__ void k_ortho9d(int b, const float *__restrict__ o9, float *__restrict__ R) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < b) ortho9d_one(o9, R, i);
 }
 
 }  // namespace
@@ -895,13 +902,11 @@ DCL_API int dcl_conf_pool(int b, int c, int n1, int n2, const float *logit1, con
                 ld2 % 4 == 0 && nslices >= 1);
   if (b == 0) return 0;
   DCL_CHECK_ARG(conf && w_scratch && part1 && part2 && wsum && logit1 && F1 && logit2 && F2 && b <= 65535 &&
-                nslices <= 65535);
+                nslices <= 32767);
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_conf_softmax, dim3(b), dim3(256), 0, s, n1, n2, logit1, logit2, conf, w_scratch, wsum);
-  hipLaunchKernelGGL(k_weighted_colsum, dim3(dcl_div_up(c, 256), nslices, b), dim3(256), 0, s, c, n1, nslices,
-                     w_scratch, n1 + n2, 0, F1, ld1, part1);
-  hipLaunchKernelGGL(k_weighted_colsum, dim3(dcl_div_up(c, 256), nslices, b), dim3(256), 0, s, c, n2, nslices,
-                     w_scratch, n1 + n2, n1, F2, ld2, part2);
+  hipLaunchKernelGGL(k_weighted_colsum, dim3(dcl_div_up(c, 256), 2 * nslices, b), dim3(256), 0, s, c, n1, n2, nslices,
+                     w_scratch, F1, ld1, part1, F2, ld2, part2);
   DCL_LAUNCH_CHECK();
   return 0;
 }
@@ -959,7 +964,7 @@ DCL_API int dcl_ortho9d_to_matrix(int b, const float *o9, float *R, dclStream_t 
 // the first two) on the pooled (b,1024) feature.  With a few crops these are row-vector x matrix products: as library
 // GEMMs they are 6 launches + the copy / activation kernels the row-vector path of the library wrapper adds (14-16
 // kernels on the critical path of a one-image forward).  Two launches here, both heads in each:
-//   k_heads_l1: h1[head][crop][512]; workgroup = (64 outputs, crop, head), 4 k-slices of 256 terms, LDS reduce
+//   k_heads_l1: h1[head][crop][512]; workgroup = (64 outputs, crop, head), 16 k-slices of 64 terms, LDS reduce
 //   k_heads_l23: h2 = relu(W2 h1 + b2) (128), out = W3 h2 + b3 (9 | 3); workgroup = (crop, head)
 // Weights are the transposed (in, out) matrices the dense pipeline keeps (row k contiguous over outputs): coalesced.
 namespace {
@@ -967,53 +972,87 @@ struct HeadWeights {
   const float *w1[2], *b1[2], *w2[2], *b2[2], *w3[2], *b3[2];   // [0] rotation (9 outputs), [1] translation (3)
 };
 
-__global__ __launch_bounds__(256) void k_heads_l1(int b, const float *__restrict__ x, HeadWeights hw, float *__restrict__ h1) {
-  __shared__ float part[4][64];
+// (k-slices: a thread's dot product is a chain of dependent FMAs fed by strided weight loads; with 4 slices of 256 terms a
+// launch spent 15 us waiting on 32 rounds of loads -- 16 slices of 64 terms need 4-8 rounds.  The slice sums are added in a
+// fixed tree order.)
+constexpr int kHeadSlices = 16;
+__device__ __forceinline__ float heads_tree16(const float (*part)[64], int o) {
+  float v[kHeadSlices];
+#pragma unroll
+  for (int i = 0; i < kHeadSlices; ++i) v[i] = part[i][o];
+#pragma unroll
+  for (int d = 1; d < kHeadSlices; d <<= 1)
+#pragma unroll
+    for (int i = 0; i < kHeadSlices; i += 2 * d) v[i] = v[i] + v[i + d];
+  return v[0];
+}
+
+__global__ __launch_bounds__(1024) void k_heads_l1(int b, const float *__restrict__ x, HeadWeights hw, float *__restrict__ h1) {
+  __shared__ float part[kHeadSlices][64];
   const int head = blockIdx.z, crop = blockIdx.y, o0 = blockIdx.x * 64;
-  const int o = threadIdx.x & 63, ks = threadIdx.x >> 6;
-  const float *w = hw.w1[head] + (size_t)(ks * 256) * 512 + o0 + o;
-  const float *xv = x + (size_t)crop * 1024 + ks * 256;
+  const int o = threadIdx.x & 63, ks = threadIdx.x >> 6;                   // 16 slices of 64 terms
+  const float *w = hw.w1[head] + (size_t)(ks * 64) * 512 + o0 + o;
+  const float *xv = x + (size_t)crop * 1024 + ks * 64;
   float acc = 0.f;
-#pragma unroll 8
-  for (int i = 0; i < 256; ++i) acc = __fmaf_rn(xv[i], w[(size_t)i * 512], acc);
+#pragma unroll 16
+  for (int i = 0; i < 64; ++i) acc = __fmaf_rn(xv[i], w[(size_t)i * 512], acc);
   part[ks][o] = acc;
   __syncthreads();
   if (ks == 0) {
-    const float v = ((part[0][o] + part[1][o]) + (part[2][o] + part[3][o])) + hw.b1[head][o0 + o];
+    const float v = heads_tree16(part, o) + hw.b1[head][o0 + o];
     h1[((size_t)head * b + crop) * 512 + o0 + o] = fmaxf(v, 0.f);
   }
 }
 
-__global__ __launch_bounds__(256) void k_heads_l23(int b, const float *__restrict__ h1, HeadWeights hw,
-                                                   float *__restrict__ o9, float *__restrict__ t3) {
-  __shared__ float xs[512], part[2][128], h2[128];
+__global__ __launch_bounds__(1024) void k_heads_l23(int b, const float *__restrict__ h1, HeadWeights hw,
+                                                    float *__restrict__ o9, float *__restrict__ t3, float *__restrict__ R) {
+  __shared__ float xs[512], part[8][128], h2[128], part3[16][12], o9s[12];
   const int head = blockIdx.y, crop = blockIdx.x;
   const float *xin = h1 + ((size_t)head * b + crop) * 512;
-  for (int i = threadIdx.x; i < 512; i += 256) xs[i] = xin[i];
+  for (int i = threadIdx.x; i < 512; i += 1024) xs[i] = xin[i];
   __syncthreads();
-  const int o = threadIdx.x & 127, ks = threadIdx.x >> 7;
-  const float *w = hw.w2[head] + (size_t)(ks * 256) * 128 + o;
+  const int o = threadIdx.x & 127, ks = threadIdx.x >> 7;                  // 8 slices of 64 terms
+  const float *w = hw.w2[head] + (size_t)(ks * 64) * 128 + o;
   float acc = 0.f;
-#pragma unroll 8
-  for (int i = 0; i < 256; ++i) acc = __fmaf_rn(xs[ks * 256 + i], w[(size_t)i * 128], acc);
+#pragma unroll 16
+  for (int i = 0; i < 64; ++i) acc = __fmaf_rn(xs[ks * 64 + i], w[(size_t)i * 128], acc);
   part[ks][o] = acc;
   __syncthreads();
-  if (ks == 0) h2[o] = fmaxf((part[0][o] + part[1][o]) + hw.b2[head][o], 0.f);
+  if (ks == 0)
+    h2[o] = fmaxf((((part[0][o] + part[1][o]) + (part[2][o] + part[3][o])) + ((part[4][o] + part[5][o]) + (part[6][o] + part[7][o]))) +
+                      hw.b2[head][o], 0.f);
   __syncthreads();
   const int nout = head == 0 ? 9 : 3;
-  if ((int)threadIdx.x < nout) {
-    const float *w3 = hw.w3[head] + threadIdx.x;
+  const int o3 = threadIdx.x & 15, k3 = threadIdx.x >> 4;                  // layer 3: 16 slices of 8 terms per output
+  if (k3 < 16 && o3 < nout) {
+    const float *w3 = hw.w3[head] + (size_t)(k3 * 8) * nout + o3;
     float a = 0.f;
-    for (int i = 0; i < 128; ++i) a = __fmaf_rn(h2[i], w3[(size_t)i * nout], a);
-    a += hw.b3[head][threadIdx.x];
-    if (head == 0) o9[(size_t)crop * 9 + threadIdx.x] = a;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a = __fmaf_rn(h2[k3 * 8 + i], w3[(size_t)i * nout], a);
+    part3[k3][o3] = a;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < nout) {
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = part3[i][threadIdx.x];
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1)
+#pragma unroll
+      for (int i = 0; i < 16; i += 2 * d) v[i] = v[i] + v[i + d];
+    const float a = v[0] + hw.b3[head][threadIdx.x];
+    if (head == 0) { o9[(size_t)crop * 9 + threadIdx.x] = a; o9s[threadIdx.x] = a; }
     else t3[(size_t)crop * 3 + threadIdx.x] = a;
+  }
+  if (head == 0 && R != nullptr) {                     // ortho9d2matrix of this crop right here: one launch less on the path
+    __syncthreads();
+    if (threadIdx.x == 0) ortho9d_one(o9s, R + (size_t)crop * 9, 0);
   }
 }
 }  // namespace
 
 DCL_API int dcl_pose_heads(int b, const float *pooled, const float *const *rot_layers, const float *const *trans_layers,
-                           float *h1_scratch, float *o9, float *trans, dclStream_t stream) {
+                           float *h1_scratch, float *o9, float *trans, float *R, dclStream_t stream) {
   DCL_CHECK_ARG(b >= 0 && b <= 65535);
   if (b == 0) return 0;
   DCL_CHECK_ARG(pooled && rot_layers && trans_layers && h1_scratch && o9 && trans);
@@ -1024,8 +1063,8 @@ DCL_API int dcl_pose_heads(int b, const float *pooled, const float *const *rot_l
     hw.w1[h] = L[0]; hw.b1[h] = L[1]; hw.w2[h] = L[2]; hw.b2[h] = L[3]; hw.w3[h] = L[4]; hw.b3[h] = L[5];
   }
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_heads_l1, dim3(512 / 64, b, 2), dim3(256), 0, s, b, pooled, hw, h1_scratch);
-  hipLaunchKernelGGL(k_heads_l23, dim3(b, 2), dim3(256), 0, s, b, h1_scratch, hw, o9, trans);
+  hipLaunchKernelGGL(k_heads_l1, dim3(512 / 64, b, 2), dim3(1024), 0, s, b, pooled, hw, h1_scratch);
+  hipLaunchKernelGGL(k_heads_l23, dim3(b, 2), dim3(1024), 0, s, b, h1_scratch, hw, o9, trans, R);
   DCL_LAUNCH_CHECK();
   return 0;
 }

@@ -515,8 +515,7 @@ class Network(nn.Module):
         # trailing BNs after pooling: F_p_wei = sA*P1 + tA*sum(w1) + sB*P2 + tB*sum(w2), finished inside the pooling op
         conf, F_p_wei = ops.conf_pool(b, logit1.reshape(-1), logit2.reshape(-1), Fp1, Fp2, affine=(sA, tA, sB, tB))
         if b <= 8:                                     # a handful of crops: both heads in two launches (csrc/dense.hip)
-            o9, trans_pred = ops.pose_heads(F_p_wei, f["regressor_rot"], f["regressor_trans"])
-            rot_pred = ops.ortho9d_to_matrix(o9)
+            o9, trans_pred, rot_pred = ops.pose_heads(F_p_wei, f["regressor_rot"], f["regressor_trans"], with_rotation=True)
         else:
             with second:
                 trans_pred = self._mlp(F_p_wei, f["regressor_trans"])

@@ -710,9 +710,10 @@ def conf_pool(b, logit1, logit2, F1, F2, affine=None):
     return conf, part1.sum(dim=1), part2.sum(dim=1), ws
 
 
-def pose_heads(pooled, rot_layers, trans_layers):
+def pose_heads(pooled, rot_layers, trans_layers, with_rotation=False):
     """regressor_rot / regressor_trans on the pooled (b,1024) feature for a handful of crops: both 3-layer heads in two
-    launches.  *_layers: [(W1t, b1), (W2t, b2), (W3t, b3)] with (in, out) matrices -> (o9 (b,9), trans (b,3))."""
+    launches.  *_layers: [(W1t, b1), (W2t, b2), (W3t, b3)] with (in, out) matrices -> (o9 (b,9), trans (b,3)); with_rotation:
+    also R (b,3,3) = ortho9d_to_matrix(o9), formed by the second launch."""
     N.need_cuda(pooled)
     pooled = pooled.contiguous()
     b, dev = pooled.shape[0], pooled.device
@@ -723,9 +724,10 @@ def pose_heads(pooled, rot_layers, trans_layers):
     h1 = torch.empty((2, b, 512), dtype=torch.float32, device=dev)
     o9 = torch.empty((b, 9), dtype=torch.float32, device=dev)
     trans = torch.empty((b, 3), dtype=torch.float32, device=dev)
+    R = torch.empty((b, 3, 3), dtype=torch.float32, device=dev) if with_rotation else None
     N.check(N.lib().dcl_pose_heads(b, N.ptr(pooled), flat(rot_layers), flat(trans_layers), N.ptr(h1), N.ptr(o9), N.ptr(trans),
-                                   N.stream()), "pose_heads")
-    return o9, trans
+                                   N.ptr(R), N.stream()), "pose_heads")
+    return (o9, trans, R) if with_rotation else (o9, trans)
 
 
 _LT_WORKSPACES = {}            # (device index, stream handle) -> uint8 scratch the GEMM library may use on that stream

@@ -377,9 +377,10 @@ int dcl_pool_finish(int b, int c, int nslices, const float *part1, const float *
 /* regressor_rot + regressor_trans (models/DCL_Net.py:139-151,231-235; Head_MultiLayerPerceptron 1024 -> 512 -> 128 -> 9 | 3,
  * ReLU after the first two layers) on the pooled feature (b,1024), both heads in two launches -- meant for a handful of
  * crops (one-image calls); large batches use library GEMMs.  rot_layers / trans_layers: {W1t (1024,512), b1, W2t (512,128),
- * b2, W3t (128,9|3), b3}, matrices stored (in, out) row-major.  h1_scratch: 2*b*512 floats.                              */
+ * b2, W3t (128,9|3), b3}, matrices stored (in, out) row-major.  h1_scratch: 2*b*512 floats.  R (b,3,3), may be NULL: the
+ * rotation matrices ortho9d2matrix (dcl_ortho9d_to_matrix) makes of o9, formed by the second launch itself.              */
 int dcl_pose_heads(int b, const float *pooled, const float *const *rot_layers, const float *const *trans_layers,
-                   float *h1_scratch, float *o9, float *trans, dclStream_t stream);
+                   float *h1_scratch, float *o9, float *trans, float *R, dclStream_t stream);
 
 /* One per-point linear layer -- Conv1d(k=1) / 1x1x1 Conv3d with its BatchNorm folded in (models/Modules.py:58-97, 173-201;
  * the reference runs them as cuDNN pointwise convolutions): y[M x N] = act(x[M x K] Wt[K x N] + bias[N]), row-major, every

@@ -837,6 +837,10 @@ def test_pose_heads_match_the_module_heads(dcl):
         net.regressor_rot.float(); net.regressor_trans.float()
         assert float((o9.double() - r64).abs().max()) <= 2e-5 * max(1.0, float(r64.abs().max()))
         assert float((t3.double() - t64).abs().max()) <= 2e-6 * max(1.0, float(t64.abs().max()) / 0.02)
+        # the rotation formed by the second launch itself == ortho9d2matrix of the o9 it wrote (the stand-alone kernel)
+        o9b, t3b, R = dcl.ops.pose_heads(x, f["regressor_rot"], f["regressor_trans"], with_rotation=True)
+        assert torch.equal(o9b, o9) and torch.equal(t3b, t3)
+        assert torch.equal(R, dcl.ops.ortho9d_to_matrix(o9))
 
 
 def test_linear_layer_writes_column_blocks_in_place(dcl):
