@@ -33,6 +33,9 @@ int dcl_internal_out_mask_k3(const uint32_t *in_mask, int batch, int S_in, int s
 int dcl_internal_scan_enumerate_sets(const DclGeoSets &g, int nsets, dclStream_t stream);
 bool dcl_internal_mask_chain_ok(int S);
 int dcl_internal_mask_chain(const uint32_t *mask0, int batch, const DclGeoSets &g, dclStream_t stream);
+bool dcl_internal_geometry_small_ok(int batch, int S);
+int dcl_internal_geometry_small(const int32_t *occ, const int32_t *n_dev, int n_host, int batch_lo, int batch, uint32_t *mask0,
+                                int32_t *wprefix0, int32_t *perm0, int32_t *comm, const DclGeoSets &g, dclStream_t stream);
 bool dcl_internal_readout_fused_ok(const DclReadoutLevels &L, int ld, bool need_search);
 int dcl_internal_readout_neighbours(int n, const float *points_b4, const DclReadoutLevels &L, int nbatch, float off,
                                     float *dist2, int32_t *idx, dclStream_t stream);
@@ -48,7 +51,7 @@ int dcl_three_nn_sp_strided(int n, int m, const float *unknown, const float *kno
 
 #include <stdlib.h>
 namespace {
-DCL_HOOK_INT(g_geo_chain, 1);   // (diagnostic library only) 0 = the 8 masks of a pass as 8 chained launches
+DCL_HOOK_INT(g_geo_chain, 1);   // (diagnostic library only) 0 = the 8 masks of a pass as 8 chained launches, 2 = one-launch mask chain but never the one-launch geometry stage
 
 #ifdef DCL_DIAG
 // debugging aids of the diagnostic library: DCL_DBG_FEATURE_STEPS=N enqueues only the first N kernels of
@@ -81,6 +84,7 @@ struct GeoLayout {
   size_t mask0, wprefix0, perm0;
   SetLayout conv[kLevels], pool[kLevels];
   OrderLayout ord[kLevels][2];          // [level][0 = the dilating conv, 1 = the submanifold conv] on the level's conv set
+  size_t comm;                          // exchange words of the one-launch geometry stage (k_geometry_small)
   size_t tickets;                       // 16 int32: in-launch hand-off tickets of the row-order launch (zeroed every pass)
   size_t scratch, total;
 };
@@ -133,6 +137,7 @@ bool make_geo_layout(int batch, int S, int V0, GeoLayout *L) {
       o.rowmask = take(sizeof(uint32_t) * cap);
     }
   L->tickets = take(sizeof(int32_t) * 16);
+  L->comm = take(sizeof(int32_t) * 16 * 16);                   // exchange words of the one-launch geometry (small batches)
   // scan scratch: block sums of the input grid, then of the 8 generated sets (batched scan, one slice per set)
   size_t blocks = (size_t)(nw0 + 1023) / 1024 + 2;
   for (int m = 0; m < kLevels; ++m)
@@ -215,9 +220,14 @@ static int backbone_geometry(const int32_t *occ, const int32_t *V0_dev, int V0, 
   DCL_CHECK_ARG(ws && counts_dev && make_geo_layout(batch, S, V0, &L) && ws_bytes >= (int64_t)L.total);
   DCL_CHECK_ARG(V0 == 0 || occ);
   int32_t *scratch = at<int32_t>(ws, L.scratch);
-  int rc = dcl_internal_grid_from_indices(occ, V0_dev, V0, batch_lo, batch, S, at<uint32_t>(ws, L.mask0),
-                                          at<int32_t>(ws, L.wprefix0), at<int32_t>(ws, L.perm0), scratch, stream);
-  if (rc) return rc;
+  // a handful of crops on 64^3 grids: the whole stage is ONE launch (rulebook.hip: k_geometry_small)
+  const bool one_launch = dcl_internal_geometry_small_ok(batch, S) && g_geo_chain == 1;
+  int rc = 0;
+  if (!one_launch) {
+    rc = dcl_internal_grid_from_indices(occ, V0_dev, V0, batch_lo, batch, S, at<uint32_t>(ws, L.mask0),
+                                        at<int32_t>(ws, L.wprefix0), at<int32_t>(ws, L.perm0), scratch, stream);
+    if (rc) return rc;
+  }
   // the 8 masks depend only on each other (bit-parallel dilation / stride-2 reduction of the previous mask): one
   // workgroup per crop walks the chain in LDS (64^3 grids; other sizes chain 8 launches), then all 8 sets are ranked and
   // decoded in three batched launches
@@ -231,7 +241,7 @@ static int backbone_geometry(const int32_t *occ, const int32_t *V0_dev, int V0, 
     const SetLayout *sets[2] = {&L.conv[m], &L.pool[m]};
     for (int q = 0; q < 2; ++q) {
       const SetLayout &t = *sets[q];
-      if (!fused_chain) {
+      if (!fused_chain && !one_launch) {
         rc = dcl_internal_out_mask_k3(in_mask, batch, s, q == 0 ? 1 : 2, at<uint32_t>(ws, t.mask), stream);
         if (rc) return rc;
       }
@@ -247,12 +257,18 @@ static int backbone_geometry(const int32_t *occ, const int32_t *V0_dev, int V0, 
       s = t.S;
     }
   }
-  if (fused_chain) {
-    rc = dcl_internal_mask_chain(at<uint32_t>(ws, L.mask0), batch, g, stream);
+  if (one_launch) {
+    rc = dcl_internal_geometry_small(occ, V0_dev, V0, batch_lo, batch, at<uint32_t>(ws, L.mask0), at<int32_t>(ws, L.wprefix0),
+                                     at<int32_t>(ws, L.perm0), at<int32_t>(ws, L.comm), g, stream);
+    if (rc) return rc;
+  } else {
+    if (fused_chain) {
+      rc = dcl_internal_mask_chain(at<uint32_t>(ws, L.mask0), batch, g, stream);
+      if (rc) return rc;
+    }
+    rc = dcl_internal_scan_enumerate_sets(g, 2 * kLevels, stream);
     if (rc) return rc;
   }
-  rc = dcl_internal_scan_enumerate_sets(g, 2 * kLevels, stream);
-  if (rc) return rc;
   // row orders of the MFMA-bound conv layers (depends on the geometry only): all jobs of the pass in five launches
   DclOrderJobs jobs{};
   int njobs = 0;

@@ -298,6 +298,179 @@ __global__ void __launch_bounds__(kChainThreads) k_mask_chain64(const uint32_t *
   }
 }
 
+// ---- the WHOLE geometry stage of a pass of a handful of crops in one launch ------------------------------------------------
+// (64^3 grids, at most kGeoSmallBatch crops: one-image calls, where the stage's 8 launches -- zero, mark, scan, fill_perm,
+// mask chain, block counts, word prefixes, enumerate -- are a third of the sparse half's critical path.)  One workgroup
+// per crop: marks the crop's voxels in an LDS bitmask, walks the 8-stage mask chain in LDS (as k_mask_chain64), counts
+// every set, exchanges the nine counts with the other crops' workgroups (a flag per crop in `comm`, zeroed by the caller
+// before the launch; crop c waits for crops < c only, and workgroups are dispatched in index order, so the wait cannot
+// deadlock), then writes word prefixes, decoded rows and the level-0 permutation of its own crop at the ranks
+// base(crops before it) + local rank -- the same ascending linear-index numbering as the separate launches, bit for bit.
+constexpr int kGeoSmallBatch = 8, kGeoCommStride = 16;
+struct GeoSmallArgs {
+  const int32_t *occ, *n_dev;
+  int n_host, batch_lo, batch;
+  uint32_t *mask0;
+  int32_t *wprefix0, *perm0, *comm;
+};
+// nine independent exclusive scans over the 1024 threads of the workgroup at once (one barrier pair for all of them);
+// the per-thread values sit in LDS (s_ex[s][thread]: count in, exclusive prefix out) so that the set loop stays rolled --
+// unrolled, the nine sets' pointers and prefixes spilled the kernel's 128 registers
+__device__ __forceinline__ void block_excl_scan9_1024(int (*s_ex)[kChainThreads], int *s_tot, int (*s_w)[16]) {
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+#pragma unroll 1
+  for (int s = 0; s < 9; ++s) {
+    const int v = s_ex[s][tid];
+    const int inc = wave_incl_scan(v);
+    if (lane == 63) s_w[s][wid] = inc;
+    s_ex[s][tid] = inc - v;                              // exclusive inside the wave
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int s = 0; s < 9; ++s) {
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int t = s_w[s][i];
+      base += i < wid ? t : 0;
+      tot += t;
+    }
+    s_ex[s][tid] += base;
+    if (tid == 0) s_tot[s] = tot;
+  }
+  __syncthreads();
+}
+__global__ void __launch_bounds__(kChainThreads) k_geometry_small(const GeoSmallArgs a, const DclGeoSets g) {
+  __shared__ __attribute__((aligned(16))) uint32_t buf[2][kChainWords];
+  __shared__ int s_w[9][16], s_base[9], s_tot[9];
+  __shared__ int s_ex[9][kChainThreads];               // per set: the thread's bit count, then its exclusive prefix
+  __shared__ uint32_t s_mw[7][kChainThreads];          // sets 2..8: the thread's word (the loops over sets stay rolled)
+  const int c = blockIdx.x, tid = threadIdx.x;
+  if (c == 0 && tid < 16 && g.zero_words) g.zero_words[tid] = 0;            // tickets of later launches of the pass
+  // 1. this crop's occupancy (rows of other crops are skipped; rows are re-based by batch_lo)
+  for (int i = tid; i < kChainWords / 4; i += kChainThreads) reinterpret_cast<uint4 *>(buf[0])[i] = make_uint4(0u, 0u, 0u, 0u);
+  __syncthreads();
+  const int n = a.n_dev ? min(*a.n_dev, a.n_host) : a.n_host;
+  for (int i = tid; i < n; i += kChainThreads) {
+    const int4 p = reinterpret_cast<const int4 *>(a.occ)[i];
+    if (p.x - a.batch_lo != c) continue;
+    const int lin = ((((p.y << 6) + p.z) << 6)) + p.w;
+    atomicOr(&buf[0][lin >> 5], 1u << (lin & 31));
+  }
+  __syncthreads();
+  // (thread t owns words 8t .. 8t+7 of the two 64^3 sets, word t of the 32^3 sets, ... in step 3: same split here)
+  {
+    const uint4 lo = reinterpret_cast<const uint4 *>(buf[0])[2 * tid], hi = reinterpret_cast<const uint4 *>(buf[0])[2 * tid + 1];
+    uint4 *m0 = reinterpret_cast<uint4 *>(a.mask0 + (size_t)c * kChainWords);
+    m0[2 * tid] = lo;
+    m0[2 * tid + 1] = hi;
+    s_ex[0][tid] = ((__popc(lo.x) + __popc(lo.y)) + (__popc(lo.z) + __popc(lo.w))) + ((__popc(hi.x) + __popc(hi.y)) + (__popc(hi.z) + __popc(hi.w)));
+  }
+  // 2. the mask chain (as k_mask_chain64): every stage's result goes to global memory and stays in LDS for the next stage
+  int S_in = kChainS, cur = 0;
+#pragma unroll 1
+  for (int i = 0; i < 8; ++i) {
+    const int S_out = g.S[i], nw = (S_out * S_out * S_out) >> 5;
+    uint32_t *gout = const_cast<uint32_t *>(g.mask[i]) + (size_t)c * nw;
+    if (i & 1) chain_stage<2>(buf[cur], buf[cur ^ 1], gout, S_in, S_out, tid);
+    else chain_stage<1>(buf[cur], buf[cur ^ 1], gout, S_in, S_out, tid);
+    __syncthreads();
+    cur ^= 1;
+    S_in = S_out;
+  }
+  // 3. this thread's words of the nine sets (the workgroup's own writes, barriers since), all loads in flight; the 2 x 8
+  // words of the 64^3 sets are parked in LDS (the chain's buffers are free now; every thread touches its own words only)
+  uint32_t mw[7];                                      // sets 2..8: at most one word per thread
+  {
+    const uint4 *m0 = reinterpret_cast<const uint4 *>(a.mask0 + (size_t)c * kChainWords);
+    const uint4 *m1 = reinterpret_cast<const uint4 *>(g.mask[0] + (size_t)c * kChainWords);
+    const uint4 lo0 = m0[2 * tid], hi0 = m0[2 * tid + 1], lo = m1[2 * tid], hi = m1[2 * tid + 1];
+#pragma unroll
+    for (int s = 2; s < 9; ++s) {
+      const int S = g.S[s - 1], nw = (S * S * S) >> 5;
+      mw[s - 2] = tid < nw ? g.mask[s - 1][(size_t)c * nw + tid] : 0u;
+    }
+    reinterpret_cast<uint4 *>(buf[0])[2 * tid] = lo0;
+    reinterpret_cast<uint4 *>(buf[0])[2 * tid + 1] = hi0;
+    reinterpret_cast<uint4 *>(buf[1])[2 * tid] = lo;
+    reinterpret_cast<uint4 *>(buf[1])[2 * tid + 1] = hi;
+    s_ex[1][tid] = ((__popc(lo.x) + __popc(lo.y)) + (__popc(lo.z) + __popc(lo.w))) + ((__popc(hi.x) + __popc(hi.y)) + (__popc(hi.z) + __popc(hi.w)));
+  }
+#pragma unroll
+  for (int s = 2; s < 9; ++s) {
+    s_ex[s][tid] = __popc(mw[s - 2]);
+    s_mw[s - 2][tid] = mw[s - 2];
+  }
+  block_excl_scan9_1024(s_ex, s_tot, s_w);
+  // 4. counts out, bases in
+  int32_t *mine = a.comm + c * kGeoCommStride;
+  if (tid == 0) {
+    for (int s = 0; s < 9; ++s) __hip_atomic_store(mine + s, s_tot[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(mine + 15, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (tid < 9) {
+    int base = 0;
+    for (int c2 = 0; c2 < c; ++c2) {
+      const int32_t *theirs = a.comm + c2 * kGeoCommStride;
+      while (__hip_atomic_load(theirs + 15, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(2);
+      base += __hip_atomic_load(theirs + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s_base[tid] = base;
+  }
+  __syncthreads();
+  // 5. word prefixes and decoded rows at base(crops before this one) + local rank (set 0 = the input grid: no rows)
+  const bool last = c == a.batch - 1;
+  auto emit = [&](int s, int S, int w, uint32_t m, int &r) __attribute__((always_inline)) {
+    const int lg = 31 - __clz(S), nw = (S * S * S) >> 5;
+    (s == 0 ? a.wprefix0 : g.wprefix[s - 1])[(size_t)c * nw + w] = r;
+    if (s == 0) { r += __popc(m); return; }
+    int4 *rows = reinterpret_cast<int4 *>(g.indices[s - 1]);
+    const int cap = g.cap[s - 1];
+    while (m) {
+      const int bit = __ffs(m) - 1;
+      m &= m - 1;
+      const int lin = (w << 5) + bit;
+      if (r < cap) rows[r] = make_int4(c, lin >> (2 * lg), (lin >> lg) & (S - 1), lin & (S - 1));
+      ++r;
+    }
+  };
+  {
+    int r0 = s_ex[0][tid] + s_base[0], r1 = s_ex[1][tid] + s_base[1];
+#pragma unroll 1
+    for (int j = 0; j < 8; ++j) {
+      emit(0, kChainS, 8 * tid + j, buf[0][8 * tid + j], r0);
+      emit(1, kChainS, 8 * tid + j, buf[1][8 * tid + j], r1);
+    }
+#pragma unroll 1
+    for (int s = 2; s < 9; ++s) {
+      const int S = g.S[s - 1], nw = (S * S * S) >> 5;
+      int r = s_ex[s][tid] + s_base[s];
+      if (tid < nw) emit(s, S, tid, s_mw[s - 2][tid], r);
+    }
+  }
+  if (last && tid == 0) {
+    for (int s = 0; s < 9; ++s) {
+      const int S = s == 0 ? kChainS : g.S[s - 1], nw = (S * S * S) >> 5;
+      const int total = s_base[s] + s_tot[s];
+      (s == 0 ? a.wprefix0 : g.wprefix[s - 1])[(size_t)a.batch * nw] = total;
+      if (s > 0 && g.n_out[s - 1]) *g.n_out[s - 1] = total;
+    }
+  }
+  __syncthreads();
+  // 6. level-0 permutation: rank -> row of the caller's voxel list
+  if (a.perm0) {
+    const uint32_t *m0 = a.mask0 + (size_t)c * kChainWords;
+    const int32_t *wp0 = a.wprefix0 + (size_t)c * kChainWords;
+    for (int i = tid; i < n; i += kChainThreads) {
+      const int4 p = reinterpret_cast<const int4 *>(a.occ)[i];
+      if (p.x - a.batch_lo != c) continue;
+      const int lin = ((((p.y << 6) + p.z) << 6)) + p.w;
+      const uint32_t mword = m0[lin >> 5];
+      a.perm0[wp0[lin >> 5] + __popc(mword & ((1u << (lin & 31)) - 1u))] = i;
+    }
+  }
+}
+
 // decode every set bit into its (b,x,y,z) row at its rank (assignGridAndIndiceOutKernel,
 // indice.cu.h:112-128, without the sort that precedes it).
 __global__ void k_enumerate(const uint32_t *__restrict__ mask, const int32_t *__restrict__ wprefix, int nwords,
@@ -611,6 +784,21 @@ bool dcl_internal_mask_chain_ok(int S) { return S == kChainS; }
 int dcl_internal_mask_chain(const uint32_t *mask0, int batch, const DclGeoSets &g, dclStream_t stream) {
   if (batch <= 0) return 0;
   hipLaunchKernelGGL(k_mask_chain64, dim3(batch), dim3(kChainThreads), 0, (hipStream_t)stream, mask0, g);
+  DCL_LAUNCH_CHECK();
+  return 0;
+}
+
+// the geometry stage of a pass of a handful of crops in one launch (+ the zeroing of its exchange words); see
+// k_geometry_small.  comm: kGeoSmallBatch * 16 ints of scratch.
+bool dcl_internal_geometry_small_ok(int batch, int S) { return S == kChainS && batch >= 1 && batch <= kGeoSmallBatch; }
+int dcl_internal_geometry_small(const int32_t *occ, const int32_t *n_dev, int n_host, int batch_lo, int batch, uint32_t *mask0,
+                                int32_t *wprefix0, int32_t *perm0, int32_t *comm, const DclGeoSets &g, dclStream_t stream) {
+  DCL_CHECK_ARG(dcl_internal_geometry_small_ok(batch, kChainS) && mask0 && wprefix0 && comm && (n_host == 0 || occ));
+  for (int i = 0; i < 8; ++i) DCL_CHECK_ARG(g.mask[i] && g.wprefix[i] && g.indices[i] && g.S[i] > 0);
+  hipStream_t s = (hipStream_t)stream;
+  dcl_internal_zero_words(comm, (long long)kGeoSmallBatch * kGeoCommStride, s);
+  GeoSmallArgs a{occ, n_dev, n_host, batch_lo, batch, mask0, wprefix0, perm0, comm};
+  hipLaunchKernelGGL(k_geometry_small, dim3(batch), dim3(kChainThreads), 0, s, a, g);
   DCL_LAUNCH_CHECK();
   return 0;
 }

@@ -1118,6 +1118,43 @@ def test_geometry_one_launch_mask_chain_equals_chained_launches(request, dcl):
 
 
 @pytest.mark.gpu
+def test_geometry_stage_in_one_launch_equals_the_separate_launches(request, dcl):
+    """a pass of at most 8 crops runs its whole geometry stage as ONE launch (k_geometry_small: mark, mask chain, counts
+    exchanged between the crops' workgroups, prefixes, rows, permutation); against the separate launches: same counts, same
+    voxel rows, and -- through masks, prefixes, conv-set rows and the level-0 permutation -- bit-identical features"""
+    lib = enter_diag(dcl, request)
+    rng = np.random.default_rng(5)
+    occ_e, b_e = _edge_voxels(rng)
+    cases = [(cuda(occ_e), b_e)]
+    for b in (1, 2, 8):
+        d = dcl.synth.make_batch(b, 1024, 64, first=7 + b)
+        occ = d["inp"]["occupied_voxels"].int()
+        perm = torch.cat([torch.randperm(int((occ[:, 0] == i).sum())) + int((occ[:, 0] < i).sum()) for i in range(b)])
+        cases.append((occ[perm].cuda().contiguous(), b))                     # unsorted inside a crop
+    net = dcl.DCL_Net.Network(dcl.synth.default_cfg(64, 64), mode="test")
+    net.load_state_dict(dcl.synth.synth_state_dict(net, 5))
+    f = net.cuda().eval()._fold()
+    for occ, b in cases:
+        vox = torch.randn(occ.shape[0], 7, generator=torch.Generator().manual_seed(b)).cuda()
+        got = {}
+        try:
+            for mode in (2, 1):                                              # 2 = separate launches, 1 = default
+                lib.dcl_debug_geometry_chain(mode)
+                run = dcl.ops.BackboneRun(occ, b, 64)
+                counts = run.counts_dev.cpu().tolist()
+                run.set_counts(counts)
+                levels = [t.clone() for t in run.features(vox, *f["backbone_inp_ptrs"])]
+                got[mode] = (counts, [run.level_indices(m).cpu() for m in range(4)], levels)
+        finally:
+            lib.dcl_debug_geometry_chain(1)
+        assert got[1][0] == got[2][0] and got[1][0][0] > 0, b
+        for a, c in zip(got[1][1], got[2][1]):
+            assert torch.equal(a, c), b
+        for a, c in zip(got[1][2], got[2][2]):
+            assert torch.equal(a, c), b
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("scales,unit", [((2, 4, 8, 16), 0.006), ((2, 4, 6, 8), 0.006), ((2, 4, 6, 8), 0.005)])
 def test_point_neighbours_grid_search_is_exact(request, dcl, scales, unit):
     """the grid-pruned 3-NN of the point read-out returns bit-for-bit what the per-crop scan returns -- distances, rows and
