@@ -252,10 +252,12 @@ class CropPrefetcher(object):
     CropBuilder.build (a trailing dict = keyword arguments).  The frames are built strictly in order by that one thread, so
     a seeded run consumes the global np.random stream exactly like a serial loop; the caller must not draw from np.random
     while iterating.  Iterating yields build()'s dicts: the caller's current stream already waits for the builder's
-    ready_event, and every tensor is marked as used on that stream (allocator hand-over between streams)."""
+    ready_event, and every tensor is marked as used on that stream (allocator hand-over between streams).  priority: of the
+    builder's stream (0 = default; a high-priority builder stream (-1) was measured slower on 6-object frames: its kernels then
+    cut into the network's)."""
     _END = object()
 
-    def __init__(self, builder, frames, depth=2, priority=-1):
+    def __init__(self, builder, frames, depth=2, priority=0):
         import queue
         import threading
         self.builder, self.dev = builder, builder.dev
