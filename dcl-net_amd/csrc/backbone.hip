@@ -328,6 +328,15 @@ struct SideArgs {
 };
 }  // namespace
 
+// Capacity mode (whole-forward graph): how many rows the conv launches of level m will really see, roughly -- the measured
+// per-crop means of the dilated sets on 64^3 grids (3217 / 1537 / 729 / 382 voxels) with a margin.  A hint for
+// the few-row decisions of the conv launcher (a capacity says little about the fill), never a bound.
+static int expect_rows(int batch, int level, int cap) {
+  static const int per_crop[kLevels] = {3600, 1800, 900, 450};
+  const long long e = (long long)batch * per_crop[level];
+  return (int)(e < cap ? e : cap);
+}
+
 static int backbone_features(const SideArgs *sd, int nsides, int batch, int S, const int32_t *channels_host, dclStream_t stream) {
   DCL_CHECK_ARG(sd && nsides >= 1 && nsides <= 2 && channels_host);
   GeoLayout L[2];
@@ -397,14 +406,14 @@ static int backbone_features(const SideArgs *sd, int nsides, int batch, int S, c
         if (stage == 0) {
           rc = source(i, at<int32_t>(a.ws, c.indices), nc_dev, nc, in_mask[i], in_wp[i], in_perm[i], 1, &Sd.src);
           if (rc) return rc;
-          Sd.feat = x[i]; Sd.out = x1; Sd.cap = nc; Sd.n_dev = nc_dev; Sd.n_host = nc_dev ? 0 : nc;
+          Sd.feat = x[i]; Sd.out = x1; Sd.cap = nc; Sd.n_dev = nc_dev; Sd.n_host = nc_dev ? expect_rows(batch, m, nc) : nc;
           Sd.W = a.weights[2 * m]; Sd.scale = a.scales[2 * m]; Sd.shift = a.shifts[2 * m];
           Sd.ord = order_of(i, 0);
         } else if (stage == 1) {
           rc = source(i, at<int32_t>(a.ws, c.indices), nc_dev, nc, at<uint32_t>(a.ws, c.mask), at<int32_t>(a.ws, c.wprefix),
                       nullptr, 1, &Sd.src);
           if (rc) return rc;
-          Sd.feat = x1; Sd.out = x2; Sd.cap = nc; Sd.n_dev = nc_dev; Sd.n_host = nc_dev ? 0 : nc;
+          Sd.feat = x1; Sd.out = x2; Sd.cap = nc; Sd.n_dev = nc_dev; Sd.n_host = nc_dev ? expect_rows(batch, m, nc) : nc;
           Sd.W = a.weights[2 * m + 1]; Sd.scale = a.scales[2 * m + 1]; Sd.shift = a.shifts[2 * m + 1];
           Sd.ord = order_of(i, 1);
         } else {

@@ -1042,8 +1042,24 @@ constexpr int kConvFewRows = 4096;     // at most this many output rows (capacit
 static int conv_split_cap(long long rows) { return rows <= kConvFewRows ? 27 : kConvMaxSplit; }
 // launches that are latency-bound on the contraction walk: few output rows -- or, in capacity mode (whole-forward
 // hipGraph, a handful of crops), a row capacity of at most two crops' worth of cells, whatever the live count turns out to be
-constexpr int kConvFewRowsCap = 65536;
+DCL_HOOK_INT(kConvFewRowsCap, 65536);
 static bool conv_few_rows(int rows, bool capacity_mode) { return capacity_mode ? rows <= kConvFewRowsCap : rows <= kConvFewRows; }
+// ... unless the caller says how many rows it EXPECTS (DclConvSide::n_host beside n_dev: the backbone runner knows the batch
+// size and the level): a capacity says little -- level 4 of 32 crops has a capacity of 16384 rows and fills 3/4 of it, level 3
+// of 6 crops has one of 24576 and fills a fifth
+DCL_HOOK_INT(kConvFewRowsHint, 6144);
+static bool conv_launch_is_few(const DclConvSides &sides, int nsides) {
+  const bool capacity_mode = sides.s[0].n_dev != nullptr;
+  int rows = 0;
+  bool hinted = capacity_mode;
+  for (int i = 0; i < nsides; ++i) {
+    const DclConvSide &S = sides.s[i];
+    const int r_i = S.n_dev ? (S.n_host > 0 ? S.n_host : S.cap) : S.n_host;
+    hinted = hinted && S.n_host > 0;
+    rows = r_i > rows ? r_i : rows;
+  }
+  return hinted ? rows <= kConvFewRowsHint : conv_few_rows(rows, capacity_mode);
+}
 // A/B and tuning switches: process-wide atomics set through dcl_debug_* in the DIAGNOSTIC library (-DDCL_DIAG, tests/_diag/),
 // compile-time constants in the product library -- the product has no hooks, no superseded kernels and no getenv
 DCL_HOOK_INT(g_conv_xcd_remap, 1);   // 0 = plain blockIdx order
@@ -1065,10 +1081,9 @@ static void launch_conv_dma(const DclConvSides &sides, int nsides, int cout, int
   (void)hipFuncSetAttribute((const void *)k_sparse_conv_dma<CIN, WR, WCW, NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
   const bool capacity_mode = sides.s[0].n_dev != nullptr;
-  int rows = 0, tiles = 0;                                  // rows: of the larger side (what makes a launch "few rows")
+  int tiles = 0;
   for (int i = 0; i < nsides; ++i) {
     const int r_i = sides.s[i].n_dev ? sides.s[i].cap : sides.s[i].n_host;
-    rows = r_i > rows ? r_i : rows;
     tiles += dcl_div_up(r_i, BM) * (cout / BN);
   }
 #ifdef DCL_CONV_STAMPS
@@ -1108,7 +1123,7 @@ static void launch_conv_dma(const DclConvSides &sides, int nsides, int cout, int
   const bool never = g_conv_split == -2;
   if (scratch && scratch_floats > kConvCounterWords && tiles <= kConvCounterWords && !never) {
     const long long slots_fit = (scratch_floats - kConvCounterWords) / ((long long)2 * BM * BN);    // 2 slots per workgroup
-    const bool few = conv_few_rows(rows, capacity_mode);
+    const bool few = conv_launch_is_few(sides, nsides);
     long long g_stream = units / kFewChunks < kSlots ? units / kFewChunks : kSlots;
     if (g_stream > slots_fit) g_stream = slots_fit;
     long long best = dcl_div_up(tiles, kSlots) * (long long)(nchunks + kFix) * 8;                   // whole tiles
@@ -1319,6 +1334,8 @@ DCL_API void dcl_debug_force_valu_conv(int on) { g_force_valu = on; }
 DCL_API void dcl_debug_conv_split(int n) { g_conv_split = n; }
 DCL_API void dcl_debug_conv_few_chunks(int n) { g_conv_few_chunks = n >= 1 ? n : 4; }
 DCL_API void dcl_debug_conv_few_tiles(int on) { g_conv_few_tiles = on; }
+DCL_API void dcl_debug_conv_few_cap(int rows) { kConvFewRowsCap = rows; }
+DCL_API void dcl_debug_conv_few_hint(int rows) { kConvFewRowsHint = rows; }
 DCL_API void dcl_debug_conv_order_mode(int mode) { g_conv_order_mode = mode; }
 DCL_API void dcl_debug_conv_slots(int n) { g_conv_slots = (n >= 64 && n <= 512) ? n : 512; }
 DCL_API void dcl_debug_conv_xcd_remap(int on) { g_conv_xcd_remap = on; }
@@ -1483,12 +1500,7 @@ static int conv_dispatch(const DclConvSides &sides_in, int nsides_in, int cin, i
   if (lds_ok && !diag_tile) {
     // LDS-DMA implicit-GEMM kernel; the tile shape follows Cout.  Few-row launches (a handful of crops; latency-bound) take
     // 64-row tiles: twice the workgroups, half the MFMA time per chunk and half the neighbour table per workgroup.
-    int rows_max = 0;
-    for (int i = 0; i < nsides; ++i) {
-      const int r_i = sides.s[i].n_dev ? sides.s[i].cap : sides.s[i].n_host;
-      rows_max = r_i > rows_max ? r_i : rows_max;
-    }
-    const bool few_tiles = g_conv_few_tiles != 0 && scratch && cout % 64 == 0 && conv_few_rows(rows_max, sides.s[0].n_dev != nullptr);
+    const bool few_tiles = g_conv_few_tiles != 0 && scratch && cout % 64 == 0 && conv_launch_is_few(sides, nsides);
 #define DMA_ARGS sides, nsides, cout, kvol, subm, relu, scratch, (long long)scratch_floats, counters_ready, s
 #ifdef DCL_DIAG
     if (g_force_valu == 5 && cout % 128 != 0 && cout % 64 == 0) {          // A/B: 8 waves of 32x32 on 128x64 tiles

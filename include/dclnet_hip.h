@@ -517,6 +517,10 @@ void dcl_debug_conv_split(int n);
 void dcl_debug_conv_few_chunks(int n);
 /* Tuning hook: 1 (default) = few-row conv launches use 64-row tiles, 0 = 128-row tiles for every launch. */
 void dcl_debug_conv_few_tiles(int on);
+/* Tuning hook: row CAPACITY up to which a capacity-mode conv launch (whole-forward graph) counts as a few-row launch. */
+void dcl_debug_conv_few_cap(int rows);
+/* Tuning hook: EXPECTED rows (the backbone runner's hint) up to which a capacity-mode conv launch counts as few-row. */
+void dcl_debug_conv_few_hint(int rows);
 /* Tuning hook: number of workgroups the stream-K / split-K decompositions of a sparse-conv launch are dealt over (default
  * 512 = the 2 x 256 resident slots; 256 leaves one slot per CU to a concurrent launch of the other backbone).  64..512. */
 void dcl_debug_conv_slots(int n);

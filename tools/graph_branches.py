@@ -8,9 +8,13 @@ sys.path.insert(0, ROOT)
 import bench
 dcl = importlib.import_module("dcl-net_amd")
 dev = torch.device("cuda:0")
+if os.environ.get("DCL_DIAG"):                     # A/B of kernel switches (DCL_CONV_* etc., tools/_diag.py): diagnostic library
+    from _diag import use_diag
+    use_diag(dcl)
+CONFIGS = ({},) if os.environ.get("DCL_DIAG") else ({}, {"single_stream": True}, {"single_stream": True, "pair_features": False})
 for b in [int(x) for x in sys.argv[1:]] or [1, 6]:
     data = bench.to_device(dcl.synth.make_batch(b, 1024, 1024, unit=0.005), dev)
-    for kw in ({}, {"single_stream": True}, {"single_stream": True, "pair_features": False}):
+    for kw in CONFIGS:
         net = dcl.DCL_Net.Network(dcl.synth.default_cfg(1024, 1024, unit=0.005), mode="test", **kw)
         net.load_state_dict(dcl.synth.synth_state_dict(net, 1))
         net = net.to(dev).eval()
