@@ -211,6 +211,110 @@ __global__ __launch_bounds__(256) void k_sparse_conv_mfma(
   }
 }
 
+// ---- MFMA kernel with the WHOLE filter resident in LDS: the wide, shallow layers (Cin 16 / 32 -> Cout 32) -----------------
+// The first two MFMA layers of a backbone have the most rows (10^5 at 32 crops) and the fewest channels: 27 * Cin * 32 floats
+// of weights are 54 / 108 KiB -- they fit the CU's LDS whole.  In the LDS-DMA implicit GEMM these layers were bound by the
+// per-chunk hand-shake (a 128 x 32 tile is 16 MFMAs per wave between two barriers: MFMA busy 0.27-0.35); here there is no
+// staging of the gathered rows and NO barrier after the filter load: a wave owns 32 output rows, looks up their 27
+// neighbour rows once, and per kernel offset every lane loads ITS row's channels straight into the registers that are the
+// MFMA's A operand (lane (r, h) holds channels 8h .. 8h+7 of every 16-channel group, so MFMA step i contracts the channel
+// pair {i, 8 + i}; the B operand W[k][8h + i][col r] comes from LDS), the loads of the next offset in flight under the
+// MFMAs of this one.  16 waves per CU hide the rest.  Offsets none of the wave's rows has are skipped.  Summation: per
+// output the offsets in the reference's visiting order, inside an offset the MFMA's pair order -- a different fp32
+// association than the DMA kernel's (both within the tolerance of the parity tests).
+// Up to two problems per launch: the workgroups are split between the sides in proportion to their row tiles.
+// (Cin = 16: 16 waves per workgroup at 128 registers; Cin = 32 has half the row tiles and twice the registers per offset in
+// flight: 8 waves at 256 registers, five offsets ahead)
+// Cout = 64 (the 32 -> 64 layer): blockIdx.y picks one of the two 32-column halves of the filter (108 KiB each); both halves
+// gather the same rows (L2 traffic, not HBM).
+template <int CIN, int COUT_T, bool SUBM>
+__global__ __launch_bounds__(CIN == 16 ? 1024 : 512) void k_sparse_conv_wlds(const DclConvSides sides, int nsides, int relu) {
+  constexpr int COUT = 32, KV = 27, GRP = CIN / 16;                          // 32 columns per workgroup; 16-channel groups per row
+  constexpr int NTHR = CIN == 16 ? 1024 : 512, NWAVE = NTHR / 64;
+  extern __shared__ __attribute__((aligned(16))) float wl_lds[];             // [27][CIN][32]
+  const int col0 = blockIdx.y * COUT;
+  int n0 = sides.s[0].n_dev ? *sides.s[0].n_dev : sides.s[0].n_host;
+  n0 = n0 < sides.s[0].cap ? n0 : sides.s[0].cap;
+  int n1 = 0;
+  if (nsides > 1) {
+    n1 = sides.s[1].n_dev ? *sides.s[1].n_dev : sides.s[1].n_host;
+    n1 = n1 < sides.s[1].cap ? n1 : sides.s[1].cap;
+  }
+  const int t0 = (n0 + 31) >> 5, t1 = (n1 + 31) >> 5;
+  const int G = gridDim.x;
+  int g0 = G;                                                                // workgroups of side 0
+  if (t1 > 0) {
+    g0 = (int)(((long long)G * t0 + (t0 + t1) / 2) / (t0 + t1));
+    g0 = g0 < 1 ? 1 : (g0 > G - 1 ? G - 1 : g0);
+    if (t0 == 0) g0 = 0;
+  }
+  const int second = (int)blockIdx.x >= g0 ? 1 : 0;
+  const DclConvSide &S = sides.s[second];
+  const int n = second ? n1 : n0, ntiles = second ? t1 : t0;
+  const int wg = blockIdx.x - (second ? g0 : 0), nwg = second ? G - g0 : g0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const float *__restrict__ feat = S.feat;
+  {
+    const float4 *Wg = reinterpret_cast<const float4 *>(S.W + col0);
+    float4 *Wl = reinterpret_cast<float4 *>(wl_lds);
+    for (int i = threadIdx.x; i < KV * CIN * COUT / 4; i += NTHR) Wl[i] = Wg[(i >> 3) * (COUT_T / 4) + (i & 7)];
+  }
+  __syncthreads();
+  // (running the first tile's look-ups under the filter load was measured: the 27 live row numbers across the load push
+  // the 16-wave variant over its 128 registers -- 43 -> 52 us)
+  for (int tile = wg * NWAVE + wave; tile < ntiles; tile += nwg * NWAVE) {
+    const int row = tile * 32 + r;
+    const bool valid = row < n;
+    int v[KV];                                                               // the 27 neighbour rows of this lane's output row
+#pragma unroll
+    for (int st = 0; st < KV; ++st) v[st] = valid ? dcl_nbr_at(S.src, S.cap, offset_at(st, KV, SUBM ? 1 : 0), row) : -1;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    constexpr int PF = CIN == 16 ? 4 : 5;              // offsets whose rows are in flight ahead of the MFMAs (register ring)
+    float4 ring[PF + 1][2 * GRP];
+    auto fetch = [&](int vv, float4 (&a)[2 * GRP]) {                          // a missing neighbour reads row 0 and is zeroed below
+      const float4 *fp = reinterpret_cast<const float4 *>(feat + (size_t)(vv >= 0 ? vv : 0) * CIN + 8 * h);
+#pragma unroll
+      for (int g = 0; g < GRP; ++g) { a[2 * g] = fp[4 * g]; a[2 * g + 1] = fp[4 * g + 1]; }
+    };
+#pragma unroll
+    for (int st = 0; st < PF; ++st) fetch(v[st], ring[st]);
+#pragma unroll
+    for (int st = 0; st < KV; ++st) {
+      if (st + PF < KV) fetch(v[st + PF], ring[(st + PF) % (PF + 1)]);
+      if (__ballot(v[st] >= 0) != 0ull) {
+        const int k = offset_at(st, KV, SUBM ? 1 : 0);
+        const bool have = v[st] >= 0;
+        const float *wk = wl_lds + (k * CIN + 8 * h) * COUT + r;
+        const float4 (&cur)[2 * GRP] = ring[st % (PF + 1)];
+#pragma unroll
+        for (int g = 0; g < GRP; ++g) {
+          const float av[8] = {cur[2 * g].x, cur[2 * g].y, cur[2 * g].z, cur[2 * g].w,
+                               cur[2 * g + 1].x, cur[2 * g + 1].y, cur[2 * g + 1].z, cur[2 * g + 1].w};
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(have ? av[i] : 0.0f, wk[(16 * g + i) * COUT], acc, 0, 0, 0);
+        }
+      }
+    }
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // MFMA -> VALU read of the accumulator
+    const float sc = S.scale ? S.scale[col0 + r] : 1.0f, sh = S.scale ? S.shift[col0 + r] : 0.0f;
+    float *__restrict__ out = S.out;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int orow = tile * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (orow < n) {
+        float x = acc[e];
+        if (S.scale) x = x * sc + sh;
+        if (relu) x = fmaxf(x, 0.0f);
+        out[(size_t)orow * COUT_T + col0 + r] = x;
+      }
+    }
+  }
+}
+
 #ifdef DCL_DIAG   // superseded by k_sparse_conv_dma for every shape it takes: kept in the diagnostic library as an A/B reference
 // ---- implicit-GEMM MFMA kernel: gathered A tile AND weight tile through LDS ------------------------------------
 // The 27 offsets x Cin input channels form one long contraction axis of "virtual channels"; it is walked in chunks of
@@ -1064,6 +1168,7 @@ static bool conv_launch_is_few(const DclConvSides &sides, int nsides) {
 // compile-time constants in the product library -- the product has no hooks, no superseded kernels and no getenv
 DCL_HOOK_INT(g_conv_xcd_remap, 1);   // 0 = plain blockIdx order
 DCL_HOOK_INT(g_conv_slots, 512);     // workgroups a launch is dealt over (2 x 256 resident slots)
+DCL_HOOK_INT(g_conv_wlds, 1);        // 1 = Cin 16 / 32 -> 32 layers with many rows on the filter-resident kernel, 0 = LDS-DMA kernel
 DCL_HOOK_INT(g_conv_few_tiles, 1);   // 1 = few-row launches on 64-row tiles, 0 = 128-row tiles for every launch
 DCL_HOOK_INT(g_conv_few_chunks, 4);  // chunks per workgroup (at least) of a few-row launch
 DCL_HOOK_INT(g_conv_split, 0);       // 0 = automatic, n = force n-way split-K when scratch allows, -1 = never more than kConvMaxSplit, -2 = never split, -3 = few-row combine inside the launch
@@ -1334,6 +1439,7 @@ DCL_API void dcl_debug_force_valu_conv(int on) { g_force_valu = on; }
 DCL_API void dcl_debug_conv_split(int n) { g_conv_split = n; }
 DCL_API void dcl_debug_conv_few_chunks(int n) { g_conv_few_chunks = n >= 1 ? n : 4; }
 DCL_API void dcl_debug_conv_few_tiles(int on) { g_conv_few_tiles = on; }
+DCL_API void dcl_debug_conv_wlds(int on) { g_conv_wlds = on; }
 DCL_API void dcl_debug_conv_few_cap(int rows) { kConvFewRowsCap = rows; }
 DCL_API void dcl_debug_conv_few_hint(int rows) { kConvFewRowsHint = rows; }
 DCL_API void dcl_debug_conv_order_mode(int mode) { g_conv_order_mode = mode; }
@@ -1500,7 +1606,26 @@ static int conv_dispatch(const DclConvSides &sides_in, int nsides_in, int cin, i
   if (lds_ok && !diag_tile) {
     // LDS-DMA implicit-GEMM kernel; the tile shape follows Cout.  Few-row launches (a handful of crops; latency-bound) take
     // 64-row tiles: twice the workgroups, half the MFMA time per chunk and half the neighbour table per workgroup.
-    const bool few_tiles = g_conv_few_tiles != 0 && scratch && cout % 64 == 0 && conv_launch_is_few(sides, nsides);
+    const bool is_few = conv_launch_is_few(sides, nsides);
+    const bool few_tiles = g_conv_few_tiles != 0 && scratch && cout % 64 == 0 && is_few;
+    // wide, shallow layers (Cin 16 / 32 -> 32 channels, many rows): the filter-resident kernel, no staging, no barriers
+    // (the 32 -> 64 layer as two 32-column halves -- instantiated, measured, not used: 99 us against the DMA kernel's 86)
+    if (g_conv_wlds != 0 && ((cout == 32 && (cin == 16 || cin == 32)) || (g_conv_wlds == 2 && cout == 64 && cin == 32)) && kvol == 27 && !is_few) {
+      const size_t lds = (size_t)27 * cin * 32 * sizeof(float);
+      const dim3 grid(256 / (cout / 32), cout / 32), block(cin == 16 ? 1024 : 512);
+#define WLDS_LAUNCH(CI, CO, SB)                                                                                              \
+      do {                                                                                                                   \
+        (void)hipFuncSetAttribute((const void *)k_sparse_conv_wlds<CI, CO, SB>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                  (int)lds);                                                                                 \
+        hipLaunchKernelGGL((k_sparse_conv_wlds<CI, CO, SB>), grid, block, lds, s, sides, nsides, relu);                      \
+      } while (0)
+      if (cin == 16) { if (subm) WLDS_LAUNCH(16, 32, true); else WLDS_LAUNCH(16, 32, false); }
+      else if (cout == 32) { if (subm) WLDS_LAUNCH(32, 32, true); else WLDS_LAUNCH(32, 32, false); }
+      else { if (subm) WLDS_LAUNCH(32, 64, true); else WLDS_LAUNCH(32, 64, false); }
+#undef WLDS_LAUNCH
+      DCL_LAUNCH_CHECK();
+      return 0;
+    }
 #define DMA_ARGS sides, nsides, cout, kvol, subm, relu, scratch, (long long)scratch_floats, counters_ready, s
 #ifdef DCL_DIAG
     if (g_force_valu == 5 && cout % 128 != 0 && cout % 64 == 0) {          // A/B: 8 waves of 32x32 on 128x64 tiles

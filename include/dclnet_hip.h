@@ -517,6 +517,8 @@ void dcl_debug_conv_split(int n);
 void dcl_debug_conv_few_chunks(int n);
 /* Tuning hook: 1 (default) = few-row conv launches use 64-row tiles, 0 = 128-row tiles for every launch. */
 void dcl_debug_conv_few_tiles(int on);
+/* Tuning hook: 1 (default) = the Cin 16 / 32 -> 32 conv layers of many rows run the filter-resident kernel, 0 = LDS-DMA kernel. */
+void dcl_debug_conv_wlds(int on);
 /* Tuning hook: row CAPACITY up to which a capacity-mode conv launch (whole-forward graph) counts as a few-row launch. */
 void dcl_debug_conv_few_cap(int rows);
 /* Tuning hook: EXPECTED rows (the backbone runner's hint) up to which a capacity-mode conv launch counts as few-row. */
