@@ -1609,6 +1609,10 @@ static int conv_dispatch(const DclConvSides &sides_in, int nsides_in, int cin, i
     const bool is_few = conv_launch_is_few(sides, nsides);
     const bool few_tiles = g_conv_few_tiles != 0 && scratch && cout % 64 == 0 && is_few;
     // wide, shallow layers (Cin 16 / 32 -> 32 channels, many rows): the filter-resident kernel, no staging, no barriers
+    // (Measured and dropped: the middle layers (Cin 32 / 64, filter too big for LDS) with the rows in registers and one
+    // offset's filter slice staged per step, workgroups of 2 / 4 waves in lock step over the 27 offsets, no split-K -- 99 /
+    // 105 / 161 us for the 32->64 / 64->64 / 64->128 layers against 87 / 79 / 142 of the LDS-DMA kernel: a barrier and a
+    // drained vmcnt per offset cost more than the row staging they replace.)
     // (the 32 -> 64 layer as two 32-column halves -- instantiated, measured, not used: 99 us against the DMA kernel's 86)
     if (g_conv_wlds != 0 && ((cout == 32 && (cin == 16 || cin == 32)) || (g_conv_wlds == 2 && cout == 64 && cin == 32)) && kvol == 27 && !is_few) {
       const size_t lds = (size_t)27 * cin * 32 * sizeof(float);
