@@ -1614,7 +1614,10 @@ static int conv_dispatch(const DclConvSides &sides_in, int nsides_in, int cin, i
     // 105 / 161 us for the 32->64 / 64->64 / 64->128 layers against 87 / 79 / 142 of the LDS-DMA kernel: a barrier and a
     // drained vmcnt per offset cost more than the row staging they replace.)
     // (the 32 -> 64 layer as two 32-column halves -- instantiated, measured, not used: 99 us against the DMA kernel's 86)
-    if (g_conv_wlds != 0 && ((cout == 32 && (cin == 16 || cin == 32)) || (g_conv_wlds == 2 && cout == 64 && cin == 32)) && kvol == 27 && !is_few) {
+    // Two sides in one call (one-stream schedule): the 16-channel layer goes out as a launch per side (44 us each against 105
+    // for the grouped LDS-DMA launch), the 32-channel one keeps the grouped LDS-DMA launch (72 us against 2 x 48).
+    if (g_conv_wlds != 0 && ((cout == 32 && (cin == 16 || (cin == 32 && nsides == 1))) || (g_conv_wlds == 2 && cout == 64 && cin == 32)) &&
+        kvol == 27 && !is_few) {
       const size_t lds = (size_t)27 * cin * 32 * sizeof(float);
       const dim3 grid(256 / (cout / 32), cout / 32), block(cin == 16 ? 1024 : 512);
 #define WLDS_LAUNCH(CI, CO, SB)                                                                                              \
@@ -1623,9 +1626,18 @@ static int conv_dispatch(const DclConvSides &sides_in, int nsides_in, int cin, i
                                   (int)lds);                                                                                 \
         hipLaunchKernelGGL((k_sparse_conv_wlds<CI, CO, SB>), grid, block, lds, s, sides, nsides, relu);                      \
       } while (0)
-      if (cin == 16) { if (subm) WLDS_LAUNCH(16, 32, true); else WLDS_LAUNCH(16, 32, false); }
-      else if (cout == 32) { if (subm) WLDS_LAUNCH(32, 32, true); else WLDS_LAUNCH(32, 32, false); }
-      else { if (subm) WLDS_LAUNCH(32, 64, true); else WLDS_LAUNCH(32, 64, false); }
+      // (a launch per side: one workgroup per CU is all the filter leaves room for, so two sides in one launch only halve
+      // each side's CUs -- measured 101 us for both against 2 x 44)
+      const DclConvSides both = sides;
+      const int nboth = nsides;
+      for (int side_i = 0; side_i < nboth; ++side_i) {
+        DclConvSides sides{};
+        sides.s[0] = both.s[side_i];
+        const int nsides = 1;
+        if (cin == 16) { if (subm) WLDS_LAUNCH(16, 32, true); else WLDS_LAUNCH(16, 32, false); }
+        else if (cout == 32) { if (subm) WLDS_LAUNCH(32, 32, true); else WLDS_LAUNCH(32, 32, false); }
+        else { if (subm) WLDS_LAUNCH(32, 64, true); else WLDS_LAUNCH(32, 64, false); }
+      }
 #undef WLDS_LAUNCH
       DCL_LAUNCH_CHECK();
       return 0;
