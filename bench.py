@@ -330,7 +330,7 @@ def eval_stream_bench(dcl, dev, images=40, n_obj=6):
                 else:                                             # the loader-worker role: a builder thread, two frames ahead
                     args = ((res[i % 4][0], res[i % 4][1], res[i % 4][2], frames[i % 4]["rois"], frames[i % 4]["gt_obj"],
                              {"poses": frames[i % 4]["poses"]}) for i in range(images))
-                    with dcl.crops.CropPrefetcher(builder, args, depth=2, priority=int(os.environ.get("DCL_PREFETCH_PRIO", "0"))) as feed:
+                    with dcl.crops.CropPrefetcher(builder, args, depth=2, stream=bstream) as feed:
                         for d in feed:
                             p = net(d)
                             dist_dev.append((d["obj_idx"], d["all_flags"], metric(d, p)))

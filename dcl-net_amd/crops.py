@@ -254,16 +254,18 @@ class CropPrefetcher(object):
     while iterating.  Iterating yields build()'s dicts: the caller's current stream already waits for the builder's
     ready_event, and every tensor is marked as used on that stream (allocator hand-over between streams).  priority: of the
     builder's stream (0 = default; a high-priority builder stream (-1) was measured slower on 6-object frames: its kernels then
-    cut into the network's)."""
+    cut into the network's); stream: an existing stream to build on (a long-lived process that has made many streams may
+    want to reuse one it knows not to share a hardware queue with the network's)."""
     _END = object()
 
-    def __init__(self, builder, frames, depth=2, priority=0):
+    def __init__(self, builder, frames, depth=2, priority=0, stream=None):
         import queue
         import threading
         self.builder, self.dev = builder, builder.dev
         self._q = queue.Queue(maxsize=max(1, int(depth)))
         self._stop = threading.Event()
         self._priority = int(priority)
+        self._stream = stream                         # the builder's stream (None: a new one of the given priority)
         self._thread = threading.Thread(target=self._work, args=(iter(frames),), name="dcl-crop-prefetch", daemon=True)
         self._thread.start()
 
@@ -280,7 +282,7 @@ class CropPrefetcher(object):
     def _work(self, frames):
         try:
             with torch.cuda.device(self.dev):
-                stream = torch.cuda.Stream(self.dev, priority=self._priority)
+                stream = self._stream if self._stream is not None else torch.cuda.Stream(self.dev, priority=self._priority)
                 with torch.cuda.stream(stream):
                     for args in frames:
                         if self._stop.is_set():
