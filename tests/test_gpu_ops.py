@@ -202,11 +202,12 @@ def test_sparse_conv_split_k_in_launch_combine(request, dcl, oracle, cin, cout, 
     assert all(torch.equal(a, ref_a) for a in got_a) and all(torch.equal(x, ref_b) for x in got_b)
 
 
-@pytest.mark.parametrize("cin,cout", [(16, 32), (32, 64), (64, 128)])
+@pytest.mark.parametrize("cin,cout", [(16, 32), (32, 32), (32, 64), (64, 128)])
 def test_sparse_conv_decompositions_agree_across_sizes(request, dcl, cin, cout):
     """row counts from a handful of tiles to tens of thousands of rows drive the launcher through its decompositions
-    (deferred-combine few-row mode, aligned split-K, stream-K, whole tiles); every one must agree with the plain VALU
-    kernel on the same rulebook, with and without the BN+ReLU epilogue"""
+    (deferred-combine few-row mode on 64-row tiles, aligned split-K, stream-K, whole tiles; the filter-resident kernel for
+    Cin 16 / 32 -> 32 channels once a launch is not a few-row one); every one must agree with the plain VALU kernel on the
+    same rulebook, with and without the BN+ReLU epilogue -- and the filter-resident kernel with the LDS-DMA kernel it replaces"""
     rng = np.random.default_rng(cin)
     lib = enter_diag(dcl, request)      # kernel variants live in the diagnostic library only (tests/_diag)
     W = cuda((rng.normal(size=(27, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32))
@@ -229,6 +230,14 @@ def test_sparse_conv_decompositions_agree_across_sizes(request, dcl, cin, cout):
             assert float((got - ref).abs().max()) <= tol, (b, S, per, subm)
             assert float((got2 - torch.relu(ref * s_ + t_)).abs().max()) <= 2 * tol, (b, S, per, subm)
             assert torch.equal(got, dcl.ops.sparse_conv(feat, nbr, n_out, W, subm))          # reproducible
+            if cout == 32:                                                                   # A/B: LDS-DMA kernel for the same launch
+                lib.dcl_debug_conv_wlds(0)
+                try:
+                    dma = dcl.ops.sparse_conv(feat, nbr, n_out, W, subm)
+                finally:
+                    lib.dcl_debug_conv_wlds(1)
+                assert float((dma - ref).abs().max()) <= tol, (b, S, per, subm)
+                assert torch.equal(got, dma) == (n_out <= 4096), (b, S, per, subm)            # few-row launches never take it
 
 
 def _plane_key(valid27):
