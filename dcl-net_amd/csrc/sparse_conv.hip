@@ -1383,10 +1383,13 @@ __global__ __launch_bounds__(256) void k_sparse_avgpool(const DclConvSides sides
     if (rf_in) rf = rf_in[row];                            // caller's summaryrf (indice_avgpool_fp32's 5th argument)
     const float d = (float)rf;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    // all 27 neighbour rows in flight (a missing neighbour loads row 0 and is not added): the loads of the whole
+    // 14 neighbour rows in flight per round (a missing neighbour loads row 0 and is not added): the loads of the whole
     // window used to be 27 dependent steps -- a branch on the LDS value in front of each -- which is what a pool of a few
-    // hundred rows (one-image calls) spent its time on.  The terms are still added in ascending offset order.
-    constexpr int PF = 27;                                   // the whole window in flight
+    // hundred rows (one-image calls) spent its time on.  The terms are still added in ascending offset order.  (Rounds of 9
+    // and of 27 were measured too: 24 / 21 / 20 / 12 us for the four pools of 32 crops either way -- 27 in flight cost the
+    // occupancy that 9 lacked in depth -- against 19 / 17 / 16 / 12 with two rounds of 14.  The kernel is bound by its chain of
+    // dependent loads, not by the 108 divisions per thread: a three-instruction exact division changed nothing.)
+    constexpr int PF = 14;
     for (int k0 = 0; k0 < kvol; k0 += PF) {
       float4 f[PF];
 #pragma unroll
