@@ -137,7 +137,7 @@ bool make_geo_layout(int batch, int S, int V0, GeoLayout *L) {
       o.rowmask = take(sizeof(uint32_t) * cap);
     }
   L->tickets = take(sizeof(int32_t) * 16);
-  L->comm = take(sizeof(int32_t) * 16 * 16);                   // exchange words of the one-launch geometry (small batches)
+  L->comm = take(sizeof(int32_t) * 64 * 16);                   // exchange words of the one-launch geometry (small batches)
   // scan scratch: block sums of the input grid, then of the 8 generated sets (batched scan, one slice per set)
   size_t blocks = (size_t)(nw0 + 1023) / 1024 + 2;
   for (int m = 0; m < kLevels; ++m)

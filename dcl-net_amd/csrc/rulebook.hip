@@ -306,7 +306,8 @@ __global__ void __launch_bounds__(kChainThreads) k_mask_chain64(const uint32_t *
 // before the launch; crop c waits for crops < c only, and workgroups are dispatched in index order, so the wait cannot
 // deadlock), then writes word prefixes, decoded rows and the level-0 permutation of its own crop at the ranks
 // base(crops before it) + local rank -- the same ascending linear-index numbering as the separate launches, bit for bit.
-constexpr int kGeoSmallBatch = 8, kGeoCommStride = 16;
+DCL_HOOK_INT(kGeoSmallBatch, 8);      // most crops of a pass that takes the one-launch geometry stage (comm holds 64 crops)
+constexpr int kGeoSmallMax = 64, kGeoCommStride = 16;
 struct GeoSmallArgs {
   const int32_t *occ, *n_dev;
   int n_host, batch_lo, batch;
@@ -789,14 +790,17 @@ int dcl_internal_mask_chain(const uint32_t *mask0, int batch, const DclGeoSets &
 }
 
 // the geometry stage of a pass of a handful of crops in one launch (+ the zeroing of its exchange words); see
-// k_geometry_small.  comm: kGeoSmallBatch * 16 ints of scratch.
-bool dcl_internal_geometry_small_ok(int batch, int S) { return S == kChainS && batch >= 1 && batch <= kGeoSmallBatch; }
+// k_geometry_small.  comm: kGeoSmallMax * 16 ints of scratch.
+bool dcl_internal_geometry_small_ok(int batch, int S) { return S == kChainS && batch >= 1 && batch <= kGeoSmallBatch && batch <= kGeoSmallMax; }
+#ifdef DCL_DIAG
+DCL_API void dcl_debug_geometry_small_batch(int n) { kGeoSmallBatch = n; }
+#endif
 int dcl_internal_geometry_small(const int32_t *occ, const int32_t *n_dev, int n_host, int batch_lo, int batch, uint32_t *mask0,
                                 int32_t *wprefix0, int32_t *perm0, int32_t *comm, const DclGeoSets &g, dclStream_t stream) {
   DCL_CHECK_ARG(dcl_internal_geometry_small_ok(batch, kChainS) && mask0 && wprefix0 && comm && (n_host == 0 || occ));
   for (int i = 0; i < 8; ++i) DCL_CHECK_ARG(g.mask[i] && g.wprefix[i] && g.indices[i] && g.S[i] > 0);
   hipStream_t s = (hipStream_t)stream;
-  dcl_internal_zero_words(comm, (long long)kGeoSmallBatch * kGeoCommStride, s);
+  dcl_internal_zero_words(comm, (long long)kGeoSmallMax * kGeoCommStride, s);
   GeoSmallArgs a{occ, n_dev, n_host, batch_lo, batch, mask0, wprefix0, perm0, comm};
   hipLaunchKernelGGL(k_geometry_small, dim3(batch), dim3(kChainThreads), 0, s, a, g);
   DCL_LAUNCH_CHECK();

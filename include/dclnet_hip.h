@@ -519,6 +519,8 @@ void dcl_debug_conv_few_chunks(int n);
 void dcl_debug_conv_few_tiles(int on);
 /* Tuning hook: 1 (default) = the Cin 16 / 32 -> 32 conv layers of many rows run the filter-resident kernel, 0 = LDS-DMA kernel. */
 void dcl_debug_conv_wlds(int on);
+/* Tuning hook: most crops of a pass whose geometry stage runs as one launch (k_geometry_small; default 8, at most 64). */
+void dcl_debug_geometry_small_batch(int n);
 /* Tuning hook: row CAPACITY up to which a capacity-mode conv launch (whole-forward graph) counts as a few-row launch. */
 void dcl_debug_conv_few_cap(int rows);
 /* Tuning hook: EXPECTED rows (the backbone runner's hint) up to which a capacity-mode conv launch counts as few-row. */
