@@ -686,6 +686,17 @@ __global__ void k_zero_words(uint32_t *__restrict__ p, long long nwords) {
   for (long long j = i; j < n4; j += stride) p4[j] = make_uint4(0u, 0u, 0u, 0u);
   for (long long j = 4 * n4 + i; j < nwords; j += stride) p[j] = 0u;
 }
+#ifdef DCL_DIAG
+// diagnostic: one lane writes the 100 MHz wall clock into *slot -- a time stamp INSIDE a stream / a captured graph, to see
+// what really overlaps in an unprofiled replay (tools/graph_timeline.py)
+__global__ void k_debug_stamp(unsigned long long *slot) { *slot = __builtin_amdgcn_s_memrealtime(); }
+DCL_API int dcl_debug_stamp(unsigned long long *slot_dev, dclStream_t stream) {
+  DCL_CHECK_ARG(slot_dev);
+  hipLaunchKernelGGL(k_debug_stamp, dim3(1), dim3(1), 0, (hipStream_t)stream, slot_dev);
+  DCL_LAUNCH_CHECK();
+  return 0;
+}
+#endif
 void dcl_internal_zero_words(void *p, long long nwords, hipStream_t s) {
   if (nwords <= 0) return;
   hipLaunchKernelGGL(k_zero_words, dim3(dcl_grid_1d((nwords + 3) / 4, 256, 2048)), dim3(256), 0, s, (uint32_t *)p, nwords);

@@ -636,6 +636,17 @@ class Network(nn.Module):
             main, side_stream = torch.cuda.current_stream(dev), self._side_stream(dev)
             act = {}
             par_dense = b <= 8
+            stamps = self.__dict__.get("_debug_stamps")            # tools/graph_timeline.py (diagnostic library): (buf, names)
+
+            def stamp(name, stream):
+                if stamps is not None:
+                    buf, names = stamps
+                    if name not in names:
+                        names.append(name)
+                    slot = names.index(name)
+                    with torch.cuda.stream(stream):
+                        ops.N.check(ops.N.lib().dcl_debug_stamp(ops.C.c_void_p(buf[slot:].data_ptr()), ops.N.stream()), "stamp")
+            stamp("start", main)
             side_stream.wait_stream(main)
             # The two branches are issued stage by stage, alternating: a graph launch hands its nodes to the queues in
             # creation order, so a branch captured as a whole after the other one starts ~50 nodes late on replay.
@@ -665,8 +676,11 @@ class Network(nn.Module):
                         else:                                              # each side's disengage stacks stay on its branch
                             act.update(self._disengage_buffers(dside, st["pf"].shape[0], dev))
                             self._disengage(f, dside, st["pf"], act)
+                    stamp("%s stage %d done" % (s, stage), stream)
             main.wait_stream(side_stream)                                  # join
-            return self._dense_tail(f, act, b, dev, side=side_stream if par_dense else None)
+            out_ = self._dense_tail(f, act, b, dev, side=side_stream if par_dense else None)
+            stamp("end", main)
+            return out_
 
         ent["body"] = body
         if not self.capture_graph:

@@ -521,6 +521,9 @@ void dcl_debug_conv_few_tiles(int on);
 void dcl_debug_conv_wlds(int on);
 /* Tuning hook: most crops of a pass whose geometry stage runs as one launch (k_geometry_small; default 8, at most 64). */
 void dcl_debug_geometry_small_batch(int n);
+/* Diagnostic: a one-thread launch that writes the 100 MHz wall clock into *slot_dev (a time stamp inside a stream or a
+ * captured graph: tools/graph_timeline.py). */
+int dcl_debug_stamp(unsigned long long *slot_dev, dclStream_t stream);
 /* Tuning hook: row CAPACITY up to which a capacity-mode conv launch (whole-forward graph) counts as a few-row launch. */
 void dcl_debug_conv_few_cap(int rows);
 /* Tuning hook: EXPECTED rows (the backbone runner's hint) up to which a capacity-mode conv launch counts as few-row. */
