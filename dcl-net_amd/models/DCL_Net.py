@@ -533,6 +533,10 @@ class Network(nn.Module):
         return prediction
 
 
+    def _stage_done(self, name, stream):
+        """called behind every stage of the two branches while the whole-forward graph is laid out (name, the stage's stream);
+        does nothing -- a measuring tool may replace it on an instance to enqueue a marker there"""
+
     # ------------------------------------------------------------------ whole-forward hipGraph (small-batch latency)
     def forward_graphed(self, data):
         """Same results as forward() (eval mode), but the whole forward -- sparse backbones in capacity mode (device-side
@@ -636,16 +640,7 @@ class Network(nn.Module):
             main, side_stream = torch.cuda.current_stream(dev), self._side_stream(dev)
             act = {}
             par_dense = b <= 8
-            stamps = self.__dict__.get("_debug_stamps")            # tools/graph_timeline.py (diagnostic library): (buf, names)
-
-            def stamp(name, stream):
-                if stamps is not None:
-                    buf, names = stamps
-                    if name not in names:
-                        names.append(name)
-                    slot = names.index(name)
-                    with torch.cuda.stream(stream):
-                        ops.N.check(ops.N.lib().dcl_debug_stamp(ops.C.c_void_p(buf[slot:].data_ptr()), ops.N.stream()), "stamp")
+            stamp = self._stage_done                               # a no-op; tools/graph_timeline.py hangs time stamps on it
             stamp("start", main)
             side_stream.wait_stream(main)
             # The two branches are issued stage by stage, alternating: a graph launch hands its nodes to the queues in

@@ -17,7 +17,13 @@ for b in [int(x) for x in sys.argv[1:]] or [32]:
     net = net.to(dev).eval()
     buf = torch.zeros(64, dtype=torch.int64, device=dev)
     names = []
-    net.__dict__["_debug_stamps"] = (buf, names)
+
+    def stage_done(name, stream, buf=buf, names=names):          # replaces Network._stage_done on this instance
+        if name not in names:
+            names.append(name)
+        with torch.cuda.stream(stream):
+            dcl.ops.N.check(dcl.ops.N.lib().dcl_debug_stamp(dcl.ops.C.c_void_p(buf[names.index(name):].data_ptr()), dcl.ops.N.stream()), "stamp")
+    net._stage_done = stage_done
     with torch.no_grad():
         for _ in range(4):
             net.forward_graphed(data)
