@@ -15,7 +15,7 @@ level = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 which = sys.argv[2] if len(sys.argv) > 2 else "subm"
 if len(sys.argv) > 3:
     ops.N.lib().dcl_debug_conv_split(int(sys.argv[3]))
-b, S = 32, 64
+b, S = int(os.environ.get("DCL_BENCH_B", "32")), 64
 data = dcl.synth.make_batch(b, 1024, 64)
 aset = ops.grid_from_indices(data["inp"]["occupied_voxels"].int().cuda().contiguous(), b, S)
 chans = [7, 16, 32, 32, 64, 64, 128, 128, 256]
