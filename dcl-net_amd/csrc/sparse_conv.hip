@@ -844,8 +844,8 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
     CONV_STAMP(1);
     // Four-wave tiles have registers to spare (2 workgroups x 4 waves per CU = 2 waves per SIMD): the sources of the chunk
     // AFTER the next are prepared under the MFMA block (LDS reads of the neighbour table + address arithmetic), so that only
-    // the DMA instructions themselves stand between the barrier and the MFMAs.  Eight-wave tiles sit at their 128 registers
-    // and prepare right before they fire.
+    // the DMA instructions themselves stand between the barrier and the MFMAs.  Eight-wave tiles prepare right before they
+    // fire (128 x 128: at their 128 registers; 128 x 64: measured both ways, 80 / 70 us against 82 / 71 with the early prep).
     constexpr bool PIPE = NW == 4;
     if (j < nchunks) {
       prep(j);
@@ -1436,7 +1436,7 @@ __global__ void k_sparse_avgpool_scalar(const float *__restrict__ feat, const Dc
 
 }  // namespace
 
-DCL_HOOK_INT(g_force_valu, 0);   // 1 = plain VALU kernel for every conv, 2 = MFMA kernel without LDS staging (the general Cin % 8 fallback), 4 = register-staged tile kernel instead of the LDS-DMA one, 5 = 8-wave 128x64 tiles for Cout = 64
+DCL_HOOK_INT(g_force_valu, 0);   // 1 = plain VALU kernel for every conv, 2 = MFMA kernel without LDS staging (the general Cin % 8 fallback), 4 = register-staged tile kernel instead of the LDS-DMA one, 5 = 4-wave 128x64 tiles for Cout = 64 (the former default)
 #ifdef DCL_DIAG
 DCL_API void dcl_debug_force_valu_conv(int on) { g_force_valu = on; }
 DCL_API void dcl_debug_conv_split(int n) { g_conv_split = n; }
@@ -1647,12 +1647,12 @@ static int conv_dispatch(const DclConvSides &sides_in, int nsides_in, int cin, i
     }
 #define DMA_ARGS sides, nsides, cout, kvol, subm, relu, scratch, (long long)scratch_floats, counters_ready, s
 #ifdef DCL_DIAG
-    if (g_force_valu == 5 && cout % 128 != 0 && cout % 64 == 0) {          // A/B: 8 waves of 32x32 on 128x64 tiles
+    if (g_force_valu == 5 && cout % 128 != 0 && cout % 64 == 0) {          // A/B: the former 4 waves of 32x64 on 128x64 tiles
       switch (cin) {
-        case 16: launch_conv_dma<16, 4, 2, 1>(DMA_ARGS); break;
-        case 32: launch_conv_dma<32, 4, 2, 1>(DMA_ARGS); break;
-        case 64: launch_conv_dma<64, 4, 2, 1>(DMA_ARGS); break;
-        default: launch_conv_dma<128, 4, 2, 1>(DMA_ARGS); break;
+        case 16: launch_conv_dma<16, 4, 1, 2>(DMA_ARGS); break;
+        case 32: launch_conv_dma<32, 4, 1, 2>(DMA_ARGS); break;
+        case 64: launch_conv_dma<64, 4, 1, 2>(DMA_ARGS); break;
+        default: launch_conv_dma<128, 4, 1, 2>(DMA_ARGS); break;
       }
     } else
 #endif
@@ -1686,12 +1686,15 @@ static int conv_dispatch(const DclConvSides &sides_in, int nsides_in, int cin, i
         case 64: launch_conv_dma<64, 4, 2, 2>(DMA_ARGS); break;
         default: launch_conv_dma<128, 4, 2, 2>(DMA_ARGS); break;
       }
-    } else {                                                                // Cout % 64 == 0: 128x64 tiles, 4 waves
+    } else {
+      // Cout % 64 == 0: 128x64 tiles, EIGHT waves of 32x32 (each wave issues 3 DMA pieces per chunk instead of 6 and has 16
+      // MFMAs instead of 32 behind them: 84 -> 80 us on the 32->64 layer, 80 -> 70 on the 64->64 one; four waves of 32x64
+      // were the form until the DMA pieces of a wave went out as grouped statements)
       switch (cin) {
-        case 16: launch_conv_dma<16, 4, 1, 2>(DMA_ARGS); break;
-        case 32: launch_conv_dma<32, 4, 1, 2>(DMA_ARGS); break;
-        case 64: launch_conv_dma<64, 4, 1, 2>(DMA_ARGS); break;
-        default: launch_conv_dma<128, 4, 1, 2>(DMA_ARGS); break;
+        case 16: launch_conv_dma<16, 4, 2, 1>(DMA_ARGS); break;
+        case 32: launch_conv_dma<32, 4, 2, 1>(DMA_ARGS); break;
+        case 64: launch_conv_dma<64, 4, 2, 1>(DMA_ARGS); break;
+        default: launch_conv_dma<128, 4, 2, 1>(DMA_ARGS); break;
       }
     }
 #undef DMA_ARGS

@@ -488,7 +488,7 @@ int dcl_profile_conv_end(double *ms_total_host, int32_t *calls_host);
 #ifdef DCL_DIAG
 /* Test hook, sparse-conv kernel variant: 0 = automatic (LDS-DMA implicit GEMM where Cout % 64 == 0), 1 = plain VALU
  * kernel for every layer (A/B check of the MFMA ones), 2 = MFMA without LDS staging (the general fallback),
- * 4 = register-staged tile kernel instead of the LDS-DMA one, 5 = 8-wave 128x64 tiles for Cout = 64. */
+ * 4 = register-staged tile kernel instead of the LDS-DMA one, 5 = 4-wave 128x64 tiles for Cout = 64 (the default has 8 waves). */
 void dcl_debug_force_valu_conv(int on);
 /* Test hook, attention kernel: 0 = automatic, 1 = shared-tile 8-wave variant, 2 = double-buffered 4-wave register
  * staging, 3 / 4 = LDS-DMA pipeline with 8 / 4 waves. */

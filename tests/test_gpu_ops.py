@@ -134,7 +134,7 @@ def test_sparse_conv_matches_oracle(request, dcl, oracle, cin, cout, subm):
     assert np.abs(got - want).max() <= tol
     # MFMA kernel vs plain VALU kernel on the device (A/B)
     lib = enter_diag(dcl, request)      # kernel variants live in the diagnostic library only (tests/_diag)
-    for mode in (1, 2, 4, 5):                                  # 1: VALU, 2: MFMA no LDS, 4: reg-staged tiles, 5: 8-wave 128x64
+    for mode in (1, 2, 4, 5):                                  # 1: VALU, 2: MFMA no LDS, 4: reg-staged tiles, 5: 4-wave 128x64
         lib.dcl_debug_force_valu_conv(mode)
         try:
             alt = dcl.ops.sparse_conv(cuda(feat), nbr, n_out, Wd, subm).cpu().numpy()
