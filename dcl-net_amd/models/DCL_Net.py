@@ -429,8 +429,9 @@ class Network(nn.Module):
         return cache[key]
 
     _DIS_TAGS = (("p1", 256), ("m1", 64), ("p2", 256), ("m2", 64))
-    GROUP_ROWS = 8 * 1024     # calls of at most this many points per side issue independent MLP layers as ONE launch each
-                              # (ops.linear_group); larger ones keep one library GEMM per layer
+    GROUP_ROWS = 2 * 1024     # calls of at most this many points per side issue independent MLP layers as ONE launch each
+                              # (ops.linear_group; same-job A/B: -2 % at one crop, +1.3 % at four, 0 at eight); larger ones
+                              # keep one library GEMM per layer
     MAX_GRAPHS = 8            # captured whole-forward graphs kept per instance (one per batch size; least recently used goes)
     GRAPH_ADMIT = 3           # with a full cache, a new batch size is captured (evicting the LRU one) on its 3rd call
 
