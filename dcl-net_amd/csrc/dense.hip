@@ -834,11 +834,12 @@ DCL_API int dcl_cross_attention_ws(int b, int nq, int nk, const float *Q, int ld
       if (scratch && blocks4 < 192) {
         // a POWER OF TWO of key splits (the 32 key tiles of a 1024-key crop divide evenly; 3 or 6 splits measured 2-4 %
         // slower than 2 or 4) that brings the launch to >= 128 workgroups -- calls of up to 8 crops run their two directions
-        // side by side, so half the chip per launch is what there is to fill -- or >= 192 above that.  Same-job A/B on the
+        // side by side, so half the chip per launch is what there is to fill -- or >= 144 above that (16 crops = 128 workgroups
+        // want 2 splits, 20 crops = 160 want none: 320 workgroups would be 1.25 rounds).  Same-job A/B on the
         // whole forward (tools/ab_hook.py dcl_debug_attention_split): 4 crops 0.893 -> 0.860 ms, 6: 1.17 -> 1.13, 8: 1.338 ->
         // 1.322, 12: 2.058 -> 1.973; 1, 2 and 16 crops keep their 8 / 8 / 2 splits.
         int pow2 = 1;
-        while (pow2 < 8 && blocks4 * pow2 < (blocks4 <= 64 ? 128 : 192)) pow2 *= 2;
+        while (pow2 < 8 && blocks4 * pow2 < (blocks4 <= 64 ? 128 : 144)) pow2 *= 2;
         nsplit = g_attn_split > 0 ? (int)g_attn_split : pow2;
         const int ntiles = dcl_div_up(nk, 32);
         if (nsplit > 8) nsplit = 8;
