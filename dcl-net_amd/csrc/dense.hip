@@ -813,34 +813,27 @@ DCL_API int dcl_cross_attention_ws(int b, int nq, int nk, const float *Q, int ld
       // few workgroups (small batches): split the keys over up to 8 workgroups per query block, >= 2 tiles per split
       const long long blocks4 = (long long)b * dcl_div_up(nq, 128);
       int nsplit = 1;
-      if (scratch && blocks4 >= 192) {
-        // one 4-wave workgroup per CU (LDS): blocks4 workgroups run in ceil(blocks4/256) rounds; a mostly empty last
-        // round (bs 40 at N = 1024: 320 workgroups = 2 rounds for 1.25 rounds of work) is split over the keys like the
-        // 8-wave launches above
+      if (scratch) {
+        // Key split of a 4-wave launch (one workgroup per CU): a power of two z (the 32 key tiles of a 1024-key crop divide
+        // evenly; 3 or 6 splits measured 2-4 % slower than 2 or 4) by a small time model in microseconds,
+        //     rounds(z) * (tiles * 1.1 / z + 4)  +  (z > 1 ? 4 + 0.15 * z * b * nq / 1024 : 0),
+        // rounds(z) = ceil(T z / 256) with T = 2 x blocks -- the two directions of a call run side by side (parallel branches
+        // of the whole-forward graph, the path every call this small takes); the second term is the combine launch.  Fitted
+        // to same-job A/B runs on the whole forward (tools/ab_hook.py dcl_debug_attention_split), best z at 1 / 2 / 4 / 6 / 8 /
+        // 12 / 16 / 20 / 32 crops of 1024 x 1024: 8 / 8 / 4 / 2 / 2 / 1 / 1 / 2 / 1 -- what this picks; against the former rule
+        // (fill 256 workgroups per launch) 4 crops -3 %, 6: -1.8 %, 8: -1.3 %, 12: -5.4 %, 16: -1.6 %, 20: -2.5 %.
         if (g_attn_split > 0) {
           nsplit = g_attn_split;
         } else {
-          double best = (double)dcl_div_up(blocks4, 256);
-          for (int z = 2; z <= 8; z *= 2) {
-            const double cost = (double)dcl_div_up(blocks4 * z, 256) / z;
-            if (cost <= best - 0.2 && (long long)z * b * nq * kAttnPartPitch <= (128ll << 20)) { best = cost; nsplit = z; }
+          const long long T = 2 * blocks4;
+          const double tiles_us = 1.1 * dcl_div_up(nk, 32);
+          double best = 1e30;
+          for (int z = 1; z <= 8; z *= 2) {
+            const double cost = (double)dcl_div_up(T * z, 256) * (tiles_us / z + 4.0) +
+                                (z > 1 ? 4.0 + 0.15 * z * (double)b * nq / 1024.0 : 0.0);
+            if (cost < best - 1e-9) { best = cost; nsplit = z; }
           }
         }
-        const int ntiles = dcl_div_up(nk, 32);
-        if (nsplit > ntiles / 2) nsplit = ntiles / 2;
-        while (nsplit > 1 && (long long)nsplit * b * nq * kAttnPartPitch > scratch_floats) --nsplit;
-        if (nsplit < 1) nsplit = 1;
-      }
-      if (scratch && blocks4 < 192) {
-        // a POWER OF TWO of key splits (the 32 key tiles of a 1024-key crop divide evenly; 3 or 6 splits measured 2-4 %
-        // slower than 2 or 4) that brings the launch to >= 128 workgroups -- calls of up to 8 crops run their two directions
-        // side by side, so half the chip per launch is what there is to fill -- or >= 144 above that (16 crops = 128 workgroups
-        // want 2 splits, 20 crops = 160 want none: 320 workgroups would be 1.25 rounds).  Same-job A/B on the
-        // whole forward (tools/ab_hook.py dcl_debug_attention_split): 4 crops 0.893 -> 0.860 ms, 6: 1.17 -> 1.13, 8: 1.338 ->
-        // 1.322, 12: 2.058 -> 1.973; 1, 2 and 16 crops keep their 8 / 8 / 2 splits.
-        int pow2 = 1;
-        while (pow2 < 8 && blocks4 * pow2 < (blocks4 <= 64 ? 128 : 144)) pow2 *= 2;
-        nsplit = g_attn_split > 0 ? (int)g_attn_split : pow2;
         const int ntiles = dcl_div_up(nk, 32);
         if (nsplit > 8) nsplit = 8;
         if (nsplit > ntiles / 2) nsplit = ntiles / 2;
