@@ -400,7 +400,11 @@ class Network(nn.Module):
                 self._disengage(f, side, pf[key][rows], act, rows)
         for st in sstream.values():
             main.wait_stream(st)
-        prediction = self._dense_tail(f, act, b, dev)
+        # (launch by launch too, the tail's two directions run side by side -- on the observed side's stream, idle by now --
+        # unless the instance is single-stream: a partial last round of one direction's attention / GEMM workgroups then
+        # overlaps the other direction instead of idling the chip)
+        tail_side = sstream["inp"] if (not self.single_stream and self._tail_parallel(b)) else None
+        prediction = self._dense_tail(f, act, b, dev, side=tail_side)
         mark("dense issued")
         if self.mode != "test":
             prediction["sym_flag"] = data["flags"].to(dev)
@@ -429,8 +433,8 @@ class Network(nn.Module):
         return cache[key]
 
     _DIS_TAGS = (("p1", 256), ("m1", 64), ("p2", 256), ("m2", 64))
-    PAR_DENSE_MAX = 1 << 20   # up to this many crops the two directions of the dense tail run as parallel graph branches
-                              # (same-job A/B against one branch: 6 crops -5.6 %, 8: -11 %, 12: -4.1 %, 16: -2.2 %, 32: -1.3 %)
+    PAR_TAIL = None           # None = by shape (_tail_parallel); True / False force the dense tail's two directions onto two
+                              # streams / one (A/B runs)
     GROUP_ROWS = 2 * 1024     # calls of at most this many points per side issue independent MLP layers as ONE launch each
                               # (ops.linear_group; same-job A/B: -2 % at one crop, +1.3 % at four, 0 at eight); larger ones
                               # keep one library GEMM per layer
@@ -535,6 +539,21 @@ class Network(nn.Module):
             prediction["Yc_pred"] = self._mlp(F_Yc_p, f["regressor_Yc"]).reshape(b, self.n_tmp, 3)
         return prediction
 
+
+    def _tail_parallel(self, b):
+        """Do the dense tail's two directions (attention + conf / fuser chains each) run side by side -- as parallel graph
+        branches, or on two streams launch by launch?  Every kernel of the tail fills the GPU, so side by side only pays
+        where a launch leaves CUs idle: while both attention launches are small (4-wave path: fewer than 256 eight-wave
+        workgroups per direction -- every N = M = 1024 call: same-job A/B 6 crops -5.6 %, 12: -4.1 %, 32: -1.3 %, 40: -4 %), or
+        when the larger direction's last round of 256 workgroups is mostly empty (N = 12288: 8 crops = 1.5 rounds -17 %,
+        24 crops = 4.5 rounds -9 %; 16 and 32 crops = whole rounds: +2.8 % / +0.5 % side by side, so those stay serial)."""
+        if self.PAR_TAIL is not None:
+            return bool(self.PAR_TAIL)
+        blocks = max(b * -(-self.n_inp // 256), b * -(-self.n_tmp // 256))        # 8-wave workgroups of the larger direction
+        if blocks < 256:
+            return True
+        rounds = -(-blocks // 256)
+        return (rounds - blocks / 256.0) / rounds >= 0.1
 
     def _stage_done(self, name, stream):
         """called behind every stage of the two branches while the whole-forward graph is laid out (name, the stage's stream);
@@ -642,7 +661,7 @@ class Network(nn.Module):
             # hipStreamEndCapture when a stream joins the capture through an event of an already forked stream.
             main, side_stream = torch.cuda.current_stream(dev), self._side_stream(dev)
             act = {}
-            par_dense = b <= self.PAR_DENSE_MAX
+            par_dense = self._tail_parallel(b)
             stamp = self._stage_done                               # a no-op; tools/graph_timeline.py hangs time stamps on it
             stamp("start", main)
             side_stream.wait_stream(main)
