@@ -69,10 +69,10 @@ class Network(nn.Module):
                  single_stream=False, pipeline_chunks=1, capture_graph=True, pair_features=None):
         """graph_max_batch > 0 (default 8): eval-mode calls with at most that many crops go through forward_graphed (one
         whole-forward hipGraph per batch size, captured on first use) -- the one-image-at-a-time eval loops of the
-        reference (tools/test_LM.py:104-112: one object per call) are launch-bound otherwise: 0.6 instead of 1.2-1.4 ms
+        reference (tools/test_LM.py:104-112: one object per call) are launch-bound otherwise: 0.53 instead of 1.1 ms
         per one-crop call.  Larger batches replay a graph too while the call is small in points, b * (N + M) <=
-        graph_max_points (measured, tools/graph_crossover.py: N = M = 1024 wins 4-6 % up to bs 40, N = 12288 / M = 2048 ties
-        at 4 crops and loses 1-2 % from 8 on) -- not with async_inputs, whose cross-call overlap a replay does not have.
+        graph_max_points (measured, tools/graph_crossover.py: N = M = 1024 wins 3-9 % at every batch size tried, up to 96
+        crops; N = 12288 / M = 2048 loses 1-2 % from 8 crops on) -- not with async_inputs, whose cross-call overlap a replay does not have.
         graph_max_batch = 0 switches all of it off (every call launch by launch).
         async_inputs=True: the caller guarantees that `data`'s CUDA tensors are complete when forward() is called (or hands
         over data["ready_event"]) and are not overwritten until the results have been consumed.  The sparse half of a call
