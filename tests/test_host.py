@@ -266,6 +266,20 @@ def test_graph_routing_rule(dcl):
     assert [mk(1024, 1024, graph_max_batch=4, graph_max_points=0).replays_graph(b) for b in (4, 5)] == [True, False]
 
 
+def test_tail_parallel_rule(dcl):
+    """do the dense tail's two directions run side by side?  (host logic only) -- always while both attention launches are
+    small (every N = M = 1024 call), at N = 12288 only for the batch sizes whose grid of 256-query workgroups ends in a
+    mostly empty round (8 crops = 1.5 rounds, 24 = 4.5), not for whole rounds (16, 32); PAR_TAIL forces either way"""
+    mk = lambda n, m: dcl.DCL_Net.Network(dcl.synth.default_cfg(n, m), mode="test")    # noqa: E731
+    ref, stress = mk(1024, 1024), mk(12288, 2048)
+    assert all(ref._tail_parallel(b) for b in (1, 6, 32, 40, 63))
+    assert [stress._tail_parallel(b) for b in (1, 4, 8, 16, 24, 32)] == [True, True, True, False, True, False]
+    stress.PAR_TAIL = True
+    assert stress._tail_parallel(32)
+    ref.PAR_TAIL = False
+    assert not ref._tail_parallel(1)
+
+
 def test_bench_two_rank_dry_run_line(tmp_path):
     """bench.py's N > 1 plumbing under the driver's own launcher, on the CPU (gloo, --dry-run: empty step):
     one JSON line from rank 0, last on stdout, with what torch.distributed saw -- world, backend, one device and one
