@@ -469,3 +469,28 @@ def test_ops_refuse_cpu_tensors(dcl):
     net = dcl.DCL_Net.Network(cfg, mode="test").eval()        # not moved to the GPU
     with pytest.raises(RuntimeError):
         net(dcl.synth.make_batch(1, 64, 64))
+
+
+@pytest.mark.gpu
+def test_tail_side_by_side_equals_serial_tail(dcl):
+    """the dense tail's two directions on two streams (launch by launch) / as two graph branches give the bits of the
+    serial tail: the same kernels on the same operands, only placed differently (Network._tail_parallel chooses by shape)"""
+    n, b = 256, 10
+    cfg = dcl.synth.default_cfg(n, n)
+    res = {}
+    for par in (False, True):
+        for path in ("eager", "graph"):
+            net = dcl.DCL_Net.Network(cfg, mode="test", graph_max_batch=0)
+            net.load_state_dict(dcl.synth.synth_state_dict(net, 1))
+            net = net.cuda().eval()
+            net.PAR_TAIL = par
+            with torch.no_grad():
+                for _ in range(2):                                          # the second call: warm caches, captured graph
+                    out = net(dcl.synth.make_batch(b, n, n, first=5)) if path == "eager" else \
+                        net.forward_graphed(dcl.synth.make_batch(b, n, n, first=5))
+            res[par, path] = {k: out[k].clone() for k in ("rot_pred", "trans_pred", "conf")}
+    torch.cuda.synchronize()
+    for path in ("eager", "graph"):
+        for k in ("rot_pred", "trans_pred", "conf"):
+            assert torch.equal(res[False, path][k], res[True, path][k]), (path, k)
+
