@@ -89,12 +89,12 @@ struct GeoLayout {
   size_t scratch, total;
 };
 
-// Row ordering pays where launches are MFMA-bound on their tiles: from a dozen crops on (one-image calls are latency-bound
+// Row ordering pays where launches are MFMA-bound on their tiles: from 14 crops on (one-image calls are latency-bound
 // few-row launches, which take no order), for the layers of the two deep levels (64- and 128-channel inputs: the dilating
 // convs skip 35-45 % of their issued chunks there, the submanifold ones 10-15 %).  Level 1 (32 channels) was measured both
 // ways: its launches are bound by the per-tile fixed cost, not by MFMA work -- ordered 55.9 / 89.6 us, natural 53 / 83 --
 // and its two sets are the largest ones to sort; level 0 runs the stem and a 16-channel layer (no used-chunk dealing).
-DCL_HOOK_INT(kOrderMinBatch, 12);   // (diagnostic library: dcl_debug_order_min_batch; a huge value switches the ordering off for A/B runs)
+DCL_HOOK_INT(kOrderMinBatch, 14);   // same-job A/B, order on vs off: 10 crops +0.9 %, 12: +1.5 %, 13: +0.7 %, 14: -1.2 %, 16: -1.5 %, 32: -3.2 % (diagnostic library: dcl_debug_order_min_batch; a huge value = off)
 inline bool order_layer(int batch, int m, int which) { return batch >= kOrderMinBatch && m >= 2 && (which == 0 || which == 1); }
 
 bool make_geo_layout(int batch, int S, int V0, GeoLayout *L) {

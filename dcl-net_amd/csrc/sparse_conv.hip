@@ -554,7 +554,7 @@ __device__ __forceinline__ unsigned conv_lds_addr(const float *p) {
 // KC = 32 virtual channels per chunk.  What bounds this kernel is the L2 -> LDS operand traffic (2*BM*BN*KC flop per
 // (BM+BN)*KC*4 bytes), not LDS or the MFMA pipe: 64x64 tiles (16 flop/B) saturated at ~45 % of the MFMA peak, hence
 // 128x128 (Cout % 128 == 0, 8 waves, 32 flop/B) and 128x64 (4 waves) here.
-// ORD: the launch carries a row order (sides.s[].ord; the two deep levels of a batch of a dozen crops or more) -- a
+// ORD: the launch carries a row order (sides.s[].ord; the two deep levels of a batch of 14 crops or more) -- a
 // compile-time switch, because the natural-order instantiation must not pay registers for the order's bookkeeping (the
 // 8-wave variants sit at the 128-VGPR limit of two workgroups per CU)
 template <int CIN, int WR, int WCW, int NT, bool ORD>
