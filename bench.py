@@ -740,7 +740,12 @@ def main():
             rdata = to_device(dcl.synth.make_batch(b, rn, rm), dev)
             rsteps = max(args.steps, 20)
             rdt, _ = run_forward_bench(dcl, rnet, rdata, rsteps, max(args.warmup, 3), False)
-            ldt, ratt = run_forward_bench(dcl, rnet_l, rdata, rsteps, max(args.warmup, 3), False)
+            ldt, _ = run_forward_bench(dcl, rnet_l, rdata, rsteps, max(args.warmup, 3), False)
+            # (the attention launches are timed by events around each of them: with the tail's two directions side by side --
+            # what a launch-by-launch call of this shape does too -- two launches would share one interval; timed serially)
+            rnet_l.PAR_TAIL = False
+            _, ratt = run_forward_bench(dcl, rnet_l, rdata, rsteps, max(args.warmup, 3), False)
+            rnet_l.PAR_TAIL = None
             rflop = 2.0 * (64 + 320) * rn * rm * b
             graphed = bool(rnet.__dict__.get("_graphs"))
             line["ref_shape"] = {"workload": "N=M=1024 (what config_YCBV_bs32.yaml defines), bs=32",

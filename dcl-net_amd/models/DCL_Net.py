@@ -404,7 +404,7 @@ class Network(nn.Module):
         # (launch by launch too, the tail's two directions run side by side -- on the observed side's stream, idle by now --
         # unless the instance is single-stream: a partial last round of one direction's attention / GEMM workgroups then
         # overlaps the other direction instead of idling the chip)
-        tail_side = sstream["inp"] if (not self.single_stream and self._tail_parallel(b)) else None
+        tail_side = sstream["inp"] if (not self.single_stream and self._tail_parallel(b, launch_by_launch=True)) else None
         prediction = self._dense_tail(f, act, b, dev, side=tail_side)
         mark("dense issued")
         if self.mode != "test":
@@ -543,7 +543,7 @@ class Network(nn.Module):
         return prediction
 
 
-    def _tail_parallel(self, b):
+    def _tail_parallel(self, b, launch_by_launch=False):
         """Do the dense tail's two directions (attention + conf / fuser chains each) run side by side -- as parallel graph
         branches, or on two streams launch by launch?  Every kernel of the tail fills the GPU, so side by side only pays
         where a launch leaves CUs idle: while both attention launches are small (4-wave path: fewer than 256 eight-wave
@@ -552,6 +552,8 @@ class Network(nn.Module):
         24 crops = 4.5 rounds -9 %; 16 and 32 crops = whole rounds: +2.8 % / +0.5 % side by side, so those stay serial)."""
         if self.PAR_TAIL is not None:
             return bool(self.PAR_TAIL)
+        if launch_by_launch and b < 3:                 # host-bound calls: the extra stream hand-overs cost more (one crop +5 %)
+            return False
         blocks = max(b * -(-self.n_inp // 256), b * -(-self.n_tmp // 256))        # 8-wave workgroups of the larger direction
         if blocks < 256:
             return True

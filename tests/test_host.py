@@ -273,6 +273,7 @@ def test_tail_parallel_rule(dcl):
     mk = lambda n, m: dcl.DCL_Net.Network(dcl.synth.default_cfg(n, m), mode="test")    # noqa: E731
     ref, stress = mk(1024, 1024), mk(12288, 2048)
     assert all(ref._tail_parallel(b) for b in (1, 6, 32, 40, 63))
+    assert [ref._tail_parallel(b, launch_by_launch=True) for b in (1, 2, 3, 32)] == [False, False, True, True]
     assert [stress._tail_parallel(b) for b in (1, 4, 8, 16, 24, 32)] == [True, True, True, False, True, False]
     stress.PAR_TAIL = True
     assert stress._tail_parallel(32)
