@@ -402,9 +402,12 @@ class Network(nn.Module):
         for st in sstream.values():
             main.wait_stream(st)
         # (launch by launch too, the tail's two directions run side by side -- on the observed side's stream, idle by now --
-        # unless the instance is single-stream: a partial last round of one direction's attention / GEMM workgroups then
+        # unless the instance is single-stream or a pipelining one: a partial last round of one direction's attention / GEMM workgroups then
         # overlaps the other direction instead of idling the chip)
-        tail_side = sstream["inp"] if (not self.single_stream and self._tail_parallel(b, launch_by_launch=True)) else None
+        # (not for a pipelining instance: its side streams already belong to the next call's sparse half -- measured 3.92 ->
+        # 4.36 ms per back-to-back reference-shape call with the tail on one of them)
+        tail_side = sstream["inp"] if (not self.single_stream and not self.async_inputs and
+                                       self._tail_parallel(b, launch_by_launch=True)) else None
         prediction = self._dense_tail(f, act, b, dev, side=tail_side)
         mark("dense issued")
         if self.mode != "test":
