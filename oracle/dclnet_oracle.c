@@ -47,11 +47,13 @@ ORC_API int orc_set_num_threads(int n) {
 
 /* ORC_FMA_POLICY selects how the two contractible source expressions of the CUDA kernels are associated.  The CUDA
  * binary cannot be run here, so the policy nvcc really applied is an assumption (policy 0); the alternates exist to
- * BOUND that assumption: tests/test_fma_policy.py counts the index picks that differ between the three builds and
- * checks that the pose does not move (oracle/Makefile builds liboracle_p1.so / liboracle_p2.so from this same file).
+ * BOUND that assumption: tests/test_fma_policy.py counts the index picks that differ between the four builds and
+ * checks that the pose does not move (oracle/Makefile builds liboracle_p1.so .. liboracle_p3.so from this same file).
  *   0  fmaf(dz,dz, fmaf(dx,dx, dy*dy))   -- LLVM/NVVM scalar contraction of  dx*dx + dy*dy + dz*dz   (the pinned policy)
  *   1  (dx*dx + dy*dy) + dz*dz            -- no contraction at all (nvcc -fmad=false)
- *   2  fmaf(dx,dx, fmaf(dy,dy, dz*dz))   -- the other FMA chain a compiler could form                               */
+ *   2  fmaf(dx,dx, fmaf(dy,dy, dz*dz))   -- the chain a compiler forms when it contracts from the right
+ *   3  fmaf(dz,dz, fmaf(dy,dy, dx*dx))   -- left-to-right contraction with the FIRST product kept as the multiply:
+ *                                           with 0 the two ways to contract (dx*dx + dy*dy) + dz*dz                    */
 #ifndef ORC_FMA_POLICY
 #define ORC_FMA_POLICY 0
 #endif
@@ -63,8 +65,10 @@ static inline float dist2f(float ax, float ay, float az, float bx, float by, flo
     return fmaf(dz, dz, fmaf(dx, dx, dy * dy));
 #elif ORC_FMA_POLICY == 1
     return (dx * dx + dy * dy) + dz * dz;
-#else
+#elif ORC_FMA_POLICY == 2
     return fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+#else
+    return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
 #endif
 }
 
@@ -74,8 +78,10 @@ static inline float wsum3(float a, float b, float c, float d, float e, float f) 
     return fmaf(e, f, fmaf(a, b, c * d));
 #elif ORC_FMA_POLICY == 1
     return (a * b + c * d) + e * f;
-#else
+#elif ORC_FMA_POLICY == 2
     return fmaf(a, b, fmaf(c, d, e * f));
+#else
+    return fmaf(e, f, fmaf(c, d, a * b));
 #endif
 }
 

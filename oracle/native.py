@@ -20,9 +20,9 @@ def _so_name(policy):
 
 
 def build(force=False):
-    """Compile liboracle.so, its two alternate-FMA-policy twins (and oracle/_ref when /root/reference is present)."""
+    """Compile liboracle.so, its three alternate-FMA-policy twins (and oracle/_ref when /root/reference is present)."""
     src = os.path.join(_HERE, "dclnet_oracle.c")
-    for policy in (0, 1, 2):
+    for policy in (0, 1, 2, 3):
         so = os.path.join(_HERE, _so_name(policy))
         if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
             subprocess.check_call(["make", "-C", _HERE, _so_name(policy)], stdout=subprocess.DEVNULL)
@@ -49,10 +49,10 @@ def lib():
 
 class fma_policy:
     """`with fma_policy(p):` -- every oracle kernel called inside runs the build of dclnet_oracle.c made with
-    -DORC_FMA_POLICY=p (0 pinned; 1 no contraction; 2 the other FMA chain).  tests/test_fma_policy.py only."""
+    -DORC_FMA_POLICY=p (0 pinned; 1 no contraction; 2 / 3 the other two FMA chains).  tests/test_fma_policy.py only."""
 
     def __init__(self, policy):
-        assert policy in (0, 1, 2)
+        assert policy in (0, 1, 2, 3)
         self.policy = policy
 
     def __enter__(self):
