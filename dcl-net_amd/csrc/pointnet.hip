@@ -214,36 +214,31 @@ __device__ __forceinline__ Cand better(const Cand &a, const Cand &b) {
   return (b.d > a.d || (b.d == a.d && b.key < a.key)) ? b : a;
 }
 
-// Register-resident kernel.  The (larger d, then smaller brev(t)) order is one unsigned 64-bit maximum over
-//   key64 = bits(d) << 32 | (TR-1 - brev(t)) << 22 | k        (d >= 0, so its bit pattern is monotonic; k < 2^22)
-// reduced with DPP inside the 16-lane rows, one LDS exchange of the 4 row winners of every wave, ONE barrier per
-// iteration (the exchange buffer alternates), then every wave reduces the <= 64 row winners itself, so nobody waits for
-// a broadcast.  The winner's coordinates come from an LDS copy of the cloud (n*12 B, up to ~13k points; beyond that from
-// global memory) instead of a dependent global load on the critical path.
-__device__ __forceinline__ unsigned long long dpp_max_u64(unsigned long long v, const int ctrl_sel) {
-  unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32), olo, ohi;
-  switch (ctrl_sel) {                                              // dpp_ctrl must be an immediate
-    case 0: olo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, false); ohi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, false); break;   // quad_perm [1,0,3,2]
-    case 1: olo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xF, 0xF, false); ohi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xF, 0xF, false); break;   // quad_perm [2,3,0,1]
-    case 2: olo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xF, 0xF, false); ohi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xF, 0xF, false); break; // row_half_mirror
-    default: olo = __builtin_amdgcn_update_dpp(lo, lo, 0x140, 0xF, 0xF, false); ohi = __builtin_amdgcn_update_dpp(hi, hi, 0x140, 0xF, 0xF, false); break; // row_mirror
-  }
-  const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
-  return o > v ? o : v;
-}
-__device__ __forceinline__ unsigned long long row_max_u64(unsigned long long v) {   // all 16 lanes of a row get the row maximum
-  v = dpp_max_u64(v, 0); v = dpp_max_u64(v, 1); v = dpp_max_u64(v, 2); v = dpp_max_u64(v, 3);
+// Register-resident kernel.  The (larger d, then smaller brev(t)) order is the order of the pair
+//   (bits(d), (TR-1 - brev(t)) << 22 | k)        (d >= 0, so its bit pattern is monotonic; k < 2^22)
+// reduced with DPP inside the waves, one LDS exchange of the waves' winners, ONE barrier per iteration (the exchange buffer
+// alternates), then every wave reduces the <= 16 wave winners itself, so nobody waits for a broadcast.  The winner's
+// coordinates come from an LDS copy of the cloud (n*12 B, up to ~13k points; beyond that from global memory) instead of a
+// dependent global load on the critical path.
+// 32-bit maxima by DPP: every lane of a 16-lane row gets the row's maximum (the compiler folds the DPP move into v_max_u32),
+// then the four rows' values meet in scalar registers.  The (d, key) order of the reduction is taken in two 32-bit passes --
+// first the largest distance bits, then, among the lanes that hold it, the largest low word -- which is the same total order
+// as one unsigned 64-bit maximum at under half the vector instructions (a 64-bit step is two DPP moves, a 64-bit compare and
+// two selects).
+__device__ __forceinline__ unsigned row_max_u32(unsigned v) {
+  unsigned o;
+  o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); v = o > v ? o : v;    // quad_perm [1,0,3,2]
+  o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true); v = o > v ? o : v;    // quad_perm [2,3,0,1]
+  o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true); v = o > v ? o : v;   // row_half_mirror
+  o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true); v = o > v ? o : v;   // row_mirror
   return v;
 }
-__device__ __forceinline__ unsigned long long wave_max_of_rows_u64(unsigned long long v) {   // v uniform per row -> wave maximum (uniform)
-  unsigned long long m = 0ull;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, 16 * r), hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), 16 * r);
-    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-    m = o > m ? o : m;
-  }
-  return m;
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {      // -> the wave's maximum, uniform (scalar)
+  v = row_max_u32(v);
+  const unsigned a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+  const unsigned c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+  const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
+  return ab > cd ? ab : cd;
 }
 
 template <int R, bool PTS_IN_LDS>   // R = points per thread (registers), block = TR threads (TR >= 64)
@@ -268,7 +263,7 @@ __global__ __launch_bounds__(1024) void k_fps(int n, int m, int TR, int log2TR, 
   }
   if (PTS_IN_LDS)
     for (int j = t; j < 3 * n; j += TR) pts[j] = X[j];
-  for (int q = t; q < 128; q += TR) xch[q] = 0ull;    // rows of waves that do not exist never win
+  for (int q = t; q < 128; q += TR) xch[q] = 0ull;    // waves that do not exist never win
   const unsigned key = __brev((unsigned)t) >> (32 - log2TR);
   const unsigned low_base = ((unsigned)(TR - 1) - key) << 22;
   if (t == 0) out[0] = 0;
@@ -276,7 +271,7 @@ __global__ __launch_bounds__(1024) void k_fps(int n, int m, int TR, int log2TR, 
   float x1 = X[0], y1 = X[1], z1 = X[2];
   for (int j = 1; j < m; ++j) {
     float bd = -1.0f;
-    int bi = 0;
+    int br = 0;                                          // the thread's best slot r (its point index is t + r * TR)
     {
       // two points per packed instruction, dcl_dist2's association per component
       const f32x2 x2 = {x1, x1}, y2 = {y1, y1}, z2 = {z1, z1};
@@ -284,21 +279,33 @@ __global__ __launch_bounds__(1024) void k_fps(int n, int m, int TR, int log2TR, 
       for (int q = 0; q < R2; ++q) {
         const f32x2 dx = px[q] - x2, dy = py[q] - y2, dz = pz[q] - z2;
         const f32x2 d = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));
-        const float da = fminf(d.x, td[q].x), db = fminf(d.y, td[q].y);
-        const int ka = t + 2 * q * TR, kb = ka + TR;     // branch-free: padded slots carry -1 and never win
-        td[q].x = da; td[q].y = db;
-        if (da > bd) { bd = da; bi = ka; }
-        if (db > bd) { bd = db; bi = kb; }
+        // (v_min_f32 directly: fminf() would first canonicalise both operands -- one more instruction per point in a loop
+        // that is bound by vector-instruction issue; distances and the running minima are never NaN)
+        float da, db;
+        asm("v_min_f32 %0, %1, %2" : "=v"(da) : "v"(d.x), "v"(td[q].x));
+        asm("v_min_f32 %0, %1, %2" : "=v"(db) : "v"(d.y), "v"(td[q].y));
+        td[q].x = da; td[q].y = db;                      // branch-free: padded slots carry -1 and never win
+        if (da > bd) { bd = da; br = 2 * q; }            // (slot numbers are inline constants: no index arithmetic per point)
+        if (db > bd) { bd = db; br = 2 * q + 1; }
       }
     }
-    unsigned long long v = bd >= 0.0f ? (((unsigned long long)__float_as_uint(bd) << 32) | (low_base | (unsigned)bi)) : 0ull;
-    v = row_max_u64(v);
+    // reduction in the reference's order -- larger d, then smaller brev(t) -- in two 32-bit passes (see row_max_u32): inside
+    // the wave, ONE exchange of the 16 waves' (d, low) pairs through LDS and ONE barrier (the buffer alternates), then every
+    // wave finishes on the 16 pairs itself, so nobody waits for a broadcast.  d >= 0: its bit pattern is monotonic; a thread
+    // without a live point (bd = -1) enters as (0, 0) and cannot win: every live low word is > 0.
+    const bool has = bd >= 0.0f;
+    const unsigned hi = has ? __float_as_uint(bd) : 0u;
+    const unsigned lo = has ? (low_base | (unsigned)(t + br * TR)) : 0u;
+    const unsigned whi = wave_max_u32(hi);
+    const unsigned wlo = wave_max_u32(hi == whi ? lo : 0u);
     unsigned long long *buf = xch + (j & 1) * 64;
-    if ((lane & 15) == 0) buf[wave * 4 + (lane >> 4)] = v;
+    if (lane == 0) buf[wave] = ((unsigned long long)whi << 32) | wlo;
     __syncthreads();
-    unsigned long long w = row_max_u64(buf[lane]);
-    w = wave_max_of_rows_u64(w);
-    const int wi = (int)((unsigned)w & 0x3fffffu);
+    const unsigned long long e = buf[lane & 15];         // the 16 waves' pairs in every row
+    const unsigned ehi = (unsigned)(e >> 32), elo = (unsigned)e;
+    const unsigned ghi = row_max_u32(ehi);
+    const unsigned glo = row_max_u32(ehi == ghi ? elo : 0u);
+    const int wi = (int)(glo & 0x3fffffu);
     if (PTS_IN_LDS) { x1 = pts[wi * 3]; y1 = pts[wi * 3 + 1]; z1 = pts[wi * 3 + 2]; }
     else { x1 = X[wi * 3]; y1 = X[wi * 3 + 1]; z1 = X[wi * 3 + 2]; }
     if (t == 0) out[j] = wi;
