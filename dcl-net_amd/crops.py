@@ -114,7 +114,11 @@ class CropBuilder(object):
         key = tuple(int(r) for r in rows)
         hit = self._tmp_side_cache.get(key)
         if hit is not None:
-            return hit
+            # the entry was made on whatever stream built it first (pageable uploads + a cat kernel); a hit from another
+            # stream or thread orders itself behind that work.  The tensors are shared by every frame with this class tuple:
+            # READ-ONLY for consumers.
+            torch.cuda.current_stream(self.dev).wait_event(hit[1])
+            return hit[0]
         tabs = [self._tmp_tab[r] for r in key]
         ma = max(t[2].shape[1] for t in tabs) - 1
         occ, p2v, v2p, voff = [], [], [], 0
@@ -134,7 +138,9 @@ class CropBuilder(object):
         out = out + (torch.cat([ids, self.tmp_vox[rows_t]], 2).reshape(b * self.n_tmp, 4).contiguous(),)   # voxelize_idx's input rows
         if len(self._tmp_side_cache) >= 64:
             self._tmp_side_cache.pop(next(iter(self._tmp_side_cache)))
-        self._tmp_side_cache[key] = out
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.dev))
+        self._tmp_side_cache[key] = (out, ready)
         return out
 
     @staticmethod

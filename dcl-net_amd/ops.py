@@ -713,7 +713,9 @@ def _ld(t):
 def cross_attention(b, Q, K, V1, O1, V2=None, O2=None):
     """One direction of the correspondence attention on POINT-major 2-D operands (row = point):
     Q (b*nq, 64), K (b*nk, 64), V1 (b*nk, dv1) -> O1 (b*nq, dv1) [, V2 -> O2].  Operands may be
-    column blocks of wider buffers (row stride honoured)."""
+    column blocks of wider buffers (row stride honoured).  The PRODUCT library carries DCL-Net's own channel split only,
+    dv1 = 256 with dv2 = 64 (anything else: DCL_EINVAL at run time -- include/dclnet_hip.h says so at dcl_cross_attention);
+    the general-shape kernels (dv1, dv2 multiples of 32) live in the diagnostic library."""
     N.need_cuda(Q, K, V1, O1, V2, O2)
     nq, nk = Q.shape[0] // b, K.shape[0] // b
     assert Q.shape[1] == 64 and K.shape[1] == 64 and V1.shape[0] == K.shape[0] and O1.shape[0] == Q.shape[0]
@@ -826,11 +828,13 @@ def _lt_workspace(dev):
     scope = getattr(_LT_SCOPE, "scope", None)
     if scope is not None:
         return scope.pick(dev)
+    if torch.cuda.is_current_stream_capturing():
+        # a foreign capture without a scope: run without scratch -- never hand out an eager scratch here: its address would be
+        # baked into the graph, and a later eviction below would give the memory back while the graph's GEMMs still write there
+        return None
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
     ws = _LT_WORKSPACES.get(key)
     if ws is None:
-        if torch.cuda.is_current_stream_capturing():       # a foreign capture without a scope: run without scratch
-            return None
         while len(_LT_WORKSPACES) >= _LT_WORKSPACES_MAX:   # bounded: the oldest stream's scratch goes back to the allocator
             _LT_WORKSPACES.pop(next(iter(_LT_WORKSPACES)))
         ws = _LT_WORKSPACES[key] = torch.empty(_LT_WORKSPACE_BYTES, dtype=torch.uint8, device=dev)

@@ -178,7 +178,28 @@ def gpu_numa_nodes(sysfs_root="/sys"):
     return numa
 
 
-def rank_cpu_set(local_rank, local_world, allowed=None, sysfs_root="/sys"):
+def visible_device_map(env, n_gpus):
+    """KFD GPU index of every HIP ordinal under ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES (ROCR first:
+    it filters what HIP then numbers): list of ints, all of 0..n_gpus-1 when nothing is set; None when a variable cannot be
+    resolved to plain ordinals (then the topology is not used)."""
+    ids = list(range(n_gpus))
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        val = env.get(var)
+        if val is None or val.strip() == "":
+            continue
+        picked = []
+        for tok in val.split(","):
+            tok = tok.strip()
+            if not tok.isdigit() or int(tok) >= len(ids):
+                return None
+            picked.append(ids[int(tok)])
+        ids = picked
+        if var == "HIP_VISIBLE_DEVICES":
+            break                                              # (CUDA_VISIBLE_DEVICES is an alias of it: not applied twice)
+    return ids
+
+
+def rank_cpu_set(local_rank, local_world, allowed=None, sysfs_root="/sys", env=None):
     """the host cores rank `local_rank` of `local_world` ranks on this node should run on: the cores of its GPU's NUMA node
     (inside the process's allowed set), divided evenly among the ranks whose GPUs share that node -- with one process per GPU
     and a per-call host read-back on the launch-by-launch path, eight ranks hopping over 2 sockets become launch-bound
@@ -189,6 +210,13 @@ def rank_cpu_set(local_rank, local_world, allowed=None, sysfs_root="/sys"):
     allowed = sorted(allowed)
     numa = gpu_numa_nodes(sysfs_root)
     peers, mine = list(range(local_world)), allowed
+    # HIP ordinal i is KFD GPU i only while no *_VISIBLE_DEVICES selects or reorders a subset (a leased N-of-8 box): an
+    # explicit plain list "a,b,c" of ordinals is followed; anything else (uuids, ...) takes the even split below
+    vis = visible_device_map(env if env is not None else os.environ, len(numa))
+    if vis is None:
+        numa = []
+    else:
+        numa = [numa[g] for g in vis]
     if len(numa) >= local_world and local_world > 0:
         node = numa[local_rank]
         try:

@@ -6,6 +6,7 @@ import sys
 import textwrap
 
 import numpy as np
+import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -281,10 +282,12 @@ def test_tail_parallel_rule(dcl):
     assert not ref._tail_parallel(1)
 
 
-def test_bench_two_rank_dry_run_line(tmp_path):
-    """bench.py's N > 1 plumbing under the driver's own launcher, on the CPU (gloo, --dry-run: empty step):
-    one JSON line from rank 0, last on stdout, with what torch.distributed saw -- world, backend, one device and one
-    disjoint host-core set per rank -- and a metric reduction that lost no frames."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_two_rank_dry_run_line(tmp_path, world):
+    """bench.py's N > 1 plumbing under the driver's own launcher, on the CPU (gloo, --dry-run: empty
+    step), for 2 ranks and for the 8 ranks of a full node: one JSON line from rank 0, last on stdout, with what
+    torch.distributed saw -- world, backend, one device and one DISJOINT host-core set per rank -- and a metric reduction
+    that lost no frames (metric_frames_reduced == world * b)."""
     import json
     import socket
     import subprocess
@@ -293,11 +296,13 @@ def test_bench_two_rank_dry_run_line(tmp_path):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1",
            "--dry-run", "--no-extras", "--shape", "ref", "--batch", "4"]
     env = dict(os.environ, OMP_NUM_THREADS="1")
-    r = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=300)
+    if len(os.sched_getaffinity(0)) < world:
+        pytest.skip("fewer host cores than ranks: the sets cannot be disjoint")
+    r = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     last = [l for l in r.stdout.strip().splitlines() if l.strip()][-1]
     line = json.loads(last)
@@ -305,12 +310,16 @@ def test_bench_two_rank_dry_run_line(tmp_path):
               "vs_baseline", "dtype", "data", "config", "rccl", "metric_frames_reduced"):
         assert k in line, k
     assert line["dry_run"] is True and line["value"] is None          # no rate is claimed without a GPU
-    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["metric_frames_reduced"] == 2 * 4
+    assert line["n_gpus"] == world and line["scaling"] == "weak" and line["metric_frames_reduced"] == world * 4
     rc = line["rccl"]
-    assert rc["world"] == 2 and rc["backend"] == "gloo" and rc["initialized"] is True
-    assert len(rc["device_per_rank"]) == 2 and "cuda:0" in rc["device_per_rank"][0] and "cuda:1" in rc["device_per_rank"][1]
+    assert rc["world"] == world and rc["backend"] == "gloo" and rc["initialized"] is True
+    assert len(rc["device_per_rank"]) == world
+    assert all("cuda:%d" % i in rc["device_per_rank"][i] for i in range(world))
     sets = [set(dcl_cpus(c)) for c in rc["cpus_per_rank"]]
-    assert all(sets) and not (sets[0] & sets[1]), "ranks must be pinned to disjoint host cores"
+    assert all(sets), "every rank reports its cores"
+    for i in range(world):
+        for j in range(i + 1, world):
+            assert not (sets[i] & sets[j]), "ranks must be pinned to disjoint host cores"
 
 
 def dcl_cpus(text):
@@ -345,3 +354,14 @@ def test_rank_cpu_sets_follow_the_gpu_numa_topology(dcl, tmp_path):
     # a cgroup that grants only part of a node, and a host without KFD: even split of what is allowed
     assert S.rank_cpu_set(1, 4, allowed={0, 1, 8, 9, 10, 11}, sysfs_root=str(tmp_path)) == {1}
     assert S.rank_cpu_set(1, 2, allowed=set(range(8)), sysfs_root=str(tmp_path / "nowhere")) == {4, 5, 6, 7}
+    # a leased subset -- HIP ordinal i is not KFD GPU i.  A plain ordinal list is followed (HIP 0 = GPU 2 on node 1,
+    # HIP 1 = GPU 0 on node 0); a list that cannot be resolved (uuids) falls back to the even split of the allowed cores
+    env = {"HIP_VISIBLE_DEVICES": "2,0"}
+    assert S.visible_device_map(env, 4) == [2, 0]
+    assert S.rank_cpu_set(0, 2, allowed=set(range(16)), sysfs_root=str(tmp_path), env=env) == set(range(8, 16))
+    assert S.rank_cpu_set(1, 2, allowed=set(range(16)), sysfs_root=str(tmp_path), env=env) == set(range(0, 8))
+    assert S.visible_device_map({"ROCR_VISIBLE_DEVICES": "1,2,3", "HIP_VISIBLE_DEVICES": "2,0"}, 4) == [3, 1]
+    env = {"ROCR_VISIBLE_DEVICES": "GPU-deadbeef,GPU-cafe"}
+    assert S.visible_device_map(env, 4) is None
+    assert S.rank_cpu_set(1, 2, allowed=set(range(16)), sysfs_root=str(tmp_path), env=env) == set(range(8, 16))
+    assert S.visible_device_map({}, 4) == [0, 1, 2, 3]
