@@ -75,6 +75,57 @@ def measure_traffic_bytes(kernel_substr, shape, batch, timeout_s=300):
         "workload, average per launch of the kernel; FETCH_SIZE x2 (gfx950), KiB -> B")
 
 
+def measure_kernel_shares(shape, batch, timeout_s=300):
+    """Whose kernels the step's GPU time goes to, MEASURED IN THIS RUN: one more child process of this script (`--pmc-child`:
+    two launch-by-launch forwards of the same workload) under `rocprofv3 --kernel-trace` alone (no counters: kernels keep
+    their concurrency and their durations), this process idle meanwhile.  -> (dict or None, source string): per kernel family
+    the summed kernel time and its share of the sum over ALL kernels of the child."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "unmeasured: rocprofv3 not on PATH"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "unmeasured: this run is itself under a rocprof tool"
+    tmp = tempfile.mkdtemp(prefix="dcl_kt_", dir="/tmp")
+    cmd = [exe, "--kernel-trace", "-d", tmp, "-o", "kt", "--output-format", "csv", "--",
+           sys.executable, os.path.abspath(__file__), "--pmc-child", "--shape", shape, "--batch", str(batch)]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("DCL_FORCE_DIST", "RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    fam = {"attention (k_cross_attn*)": 0.0, "vendor_gemm (hipBLASLt Cijk_*)": 0.0, "sparse conv (k_sparse_conv*, k_conv_frag*)": 0.0,
+           "other": 0.0}
+    launches = {k: 0 for k in fam}
+    try:
+        subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s,
+                       check=True)
+        rows = 0
+        for f in glob.glob(os.path.join(tmp, "**", "*kernel_trace.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                name = r["Kernel_Name"]
+                dur = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+                key = ("attention (k_cross_attn*)" if "k_cross_attn" in name else
+                       "vendor_gemm (hipBLASLt Cijk_*)" if name.startswith("Cijk_") else
+                       "sparse conv (k_sparse_conv*, k_conv_frag*)" if ("k_sparse_conv" in name or "k_conv_frag" in name) else "other")
+                fam[key] += dur
+                launches[key] += 1
+                rows += 1
+    except (subprocess.SubprocessError, OSError, KeyError, ValueError) as e:
+        shutil.rmtree(tmp, ignore_errors=True)
+        return None, "unmeasured: kernel-trace pass failed (%s)" % type(e).__name__
+    shutil.rmtree(tmp, ignore_errors=True)
+    total = sum(fam.values())
+    if rows == 0 or total <= 0:
+        return None, "unmeasured: empty kernel trace"
+    out = {k: {"ns": v, "share": v / total, "launches": launches[k]} for k, v in fam.items()}
+    out["_forwards"] = 2
+    return out, ("measured in this run: child rocprofv3 --kernel-trace pass over two launch-by-launch forwards of the same "
+                 "workload; share = the family's summed kernel time / the summed kernel time of all kernels")
+
+
 def _flush_c_stdio(unbuffer=False):
     """C-level stdout (libraries that printf, e.g. RCCL's banner): flush it, optionally switch it to unbuffered."""
     import ctypes
@@ -695,6 +746,23 @@ def main():
                 "traffic_algorithmic": int(4 * b * (64 * (n_inp + n_tmp) + 320 * (n_inp + n_tmp))),
                 "avg_launch_ms": round(att_avg_ms, 4), "launches_timed": len(att_ms),
                 "flop_per_launch": flop_dir[0]}
+    # whose kernels the step's GPU time goes to: the named kernel is the dominant HAND-WRITTEN one; the
+    # largest single share belongs to the vendor library's GEMMs, like-for-like with the reference's cuBLAS / cuDNN calls
+    roofline["share_of_gpu_time"], roofline["vendor_gemm"] = None, None
+    roofline["share_source"] = "not collected (N > 1, --no-extras or --no-traffic)"
+    if rank == 0 and world == 1 and not args.no_extras and not args.no_traffic:
+        shares, roofline["share_source"] = measure_kernel_shares(args.shape, b)
+        if shares is not None:
+            att, gem = shares["attention (k_cross_attn*)"], shares["vendor_gemm (hipBLASLt Cijk_*)"]
+            gemm_flop = 3473664.0 * b * (n_inp + n_tmp) * shares["_forwards"]       # test-mode dense flop per point
+            roofline["share_of_gpu_time"] = round(att["share"], 4)
+            roofline["vendor_gemm"] = {"share_of_gpu_time": round(gem["share"], 4),
+                                       "TFLOPs": round(gemm_flop / (gem["ns"] * 1e-9) / 1e12, 1) if gem["ns"] > 0 else None,
+                                       "launches_per_forward": gem["launches"] // shares["_forwards"],
+                                       "note": "hipBLASLt Tensile kernels (Cijk_*): every 1x1x1-conv / head layer of the dense half"}
+            roofline["sparse_conv_share_of_gpu_time"] = round(shares["sparse conv (k_sparse_conv*, k_conv_frag*)"]["share"], 4)
+            roofline["note"] = ("k_cross_attn is the dominant hand-written kernel, not the dominant kernel family: the "
+                                "vendor GEMMs hold the largest share")
 
     # metric reduction over RCCL (outside the timed region): ADD-S table of this rank's crops
     with torch.no_grad():
@@ -769,9 +837,16 @@ def main():
         # the same forward fed from the loader's HOST tensors (pageable memory, H2D inside forward) -- never `value`
         hdt, _ = run_forward_bench(dcl, net, host_data, max(3, args.steps // 2), 1, False)
         hsteps = max(3, args.steps // 2)
-        line["h2d_inclusive"] = {"value": round(b * hsteps / hdt, 2), "unit": "frames/s",
-                                 "ms_per_step": round(hdt / hsteps * 1e3, 3),
-                                 "what": "data dict on the host (pageable), uploaded inside forward()"}
+        # ... and from PINNED host tensors (what DataLoader(pin_memory=True) hands over; the copies inside forward() are then
+        # real asynchronous DMAs instead of staged pageable copies)
+        pinned = {k: ({kk: (vv.pin_memory() if torch.is_tensor(vv) else vv) for kk, vv in v.items()} if isinstance(v, dict)
+                      else (v.pin_memory() if torch.is_tensor(v) else v)) for k, v in host_data.items()}
+        pdt, _ = run_forward_bench(dcl, net, pinned, max(3, args.steps // 2), 1, False)
+        line["h2d_inclusive"] = {"value": round(b * hsteps / pdt, 2), "unit": "frames/s",
+                                 "ms_per_step": round(pdt / hsteps * 1e3, 3),
+                                 "what": "data dict in PINNED host memory (a pinning loader), uploaded inside forward()",
+                                 "pageable": {"value": round(b * hsteps / hdt, 2), "ms_per_step": round(hdt / hsteps * 1e3, 3),
+                                              "what": "the same from pageable host tensors (pin_memory: False in config_YCBV_bs32.yaml:47,62 -- what the shipped configs hand over)"}}
         if not args.pipelined_calls:
             line["pipelined_calls"] = pipelined_bench(dcl, dev, sd, cfg, data, b, args.steps, args.warmup, rdata_for_pipe)
         line["lm_stream"] = lm_stream_bench(dcl, dev)
