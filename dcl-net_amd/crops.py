@@ -69,11 +69,34 @@ def lm_box(obj_bb, img_h=480, img_w=640):
     return r0, r1, c0, c1
 
 
+def _upload(a, dev):
+    """small host array -> device WITHOUT stalling the host: through pinned memory (torch's caching host allocator hands the
+    block out again only after the copy has run) and a non-blocking copy.  A pageable .to(dev) is stream-ordered AND blocks
+    the host: in the middle of build() it waited for the crop kernel, at its start for the previous frame's forward."""
+    t = torch.from_numpy(np.ascontiguousarray(a)) if not torch.is_tensor(a) else a
+    return t.pin_memory().to(dev, non_blocking=True)
+
+
+MARKS = None          # tools/builder_trace.py sets a list: (label, perf_counter) host marks of build()
+
+
+def _mark(label):
+    if MARKS is not None:
+        MARKS.append((label, time.perf_counter()))
+
+
 class CropBuilder(object):
-    def __init__(self, cfg, cad_points_mm, cad_colors, camera=YCBV_CAMERA, device="cuda"):
+    def __init__(self, cfg, cad_points_mm, cad_colors, camera=YCBV_CAMERA, device="cuda", capacity=False, v2p_pitch=33):
         """cfg: mapping with input_size, tmp_size, unit_voxel_extent, voxel_num_limit, voxelization_mode (the `test`
         block of configs/config_YCBV_bs32.yaml).  cad_points_mm / cad_colors: {class id: (tmp_size,3) float64}, the
-        loader's list_pc_CAD / list_rgb_CAD (millimetres; colours already mean-subtracted, :57-58)."""
+        loader's list_pc_CAD / list_rgb_CAD (millimetres; colours already mean-subtracted, :57-58).
+        capacity=True: the observed side's voxelisation stays in CAPACITY form -- occupied_voxels (b*n, 4) and v2p_maps
+        (b*n, v2p_pitch) with the live row count on the device (data["inp"]["v0_dev"]) -- so build() makes ONE host
+        read-back per frame (the per-instance point counts the loader's random draws need) instead of two; Network.forward
+        takes that form on its graph path (exact_form(data) converts, with the read-back).  v2p_pitch: 1 + the most points of
+        a crop one voxel may hold.  Exact mode repeats an image whose crops exceed it with the general op; in capacity mode
+        the device-side flag data["inp"]["vi_info"][2] says so (the caller reads it with its results; exact_form raises)."""
+        self.capacity, self.v2p_pitch = bool(capacity), int(v2p_pitch)
         self.n_inp, self.n_tmp = int(cfg["input_size"]), int(cfg["tmp_size"])
         self.unit = np.array(cfg["unit_voxel_extent"]).astype(float)
         self.limit = np.array(cfg["voxel_num_limit"]).astype(float)
@@ -158,6 +181,7 @@ class CropBuilder(object):
         dict with CUDA tensors (instances without a detection or with an empty mask are dropped and flagged 0 in
         `all_flags`, :116,134).  Host synchronisations per frame: the per-instance point counts (the sampling draws are the
         loader's own np.random.choice calls) and {V, maxActive} of the observed side's voxelisation; nothing else."""
+        _mark("start")
         H, W = depth.shape
         gt_obj = np.asarray(gt_obj).astype(np.int32)
         rois = np.asarray(rois)
@@ -177,52 +201,101 @@ class CropBuilder(object):
         else:
             i_t, d_t, l_t = self.resident(img, depth, label, dev)
         bo = np.concatenate([np.asarray(boxes, np.int32), gt_obj[cand][:, None]], 1)   # boxes + class ids: one upload
-        bo_t = torch.from_numpy(bo).to(dev)
+        bo_t = _upload(bo, dev)
         b_t, o_t = bo_t[:, :4].contiguous(), bo_t[:, 4].contiguous()
         cap = max(1, max(max(r1 - r0, 0) * max(c1 - c0, 0) for r0, r1, c0, c1 in boxes))
         xyz, col, centroid, counts = ops.crop_points(d_t, l_t, i_t, b_t, o_t, self.camera, RGB_MEAN, self.extent * 0.5,
                                                      MIN_VALID, cap=cap)
+        _mark("crop_points issued")
+        # What does not depend on the instances' point counts is issued NOW, while the GPU runs k_crop_points (~0.17 ms) and
+        # before the host waits for the counts: the template side (class rows, feats, voxel tables), the gt labels (the
+        # centroids are read on the device, in stream order) and the dict's host tensors -- for ALL candidates; the rare image
+        # that then drops an instance (an empty mask) redoes this part for the kept ones.
+        def count_free_part(keep):
+            rows = [self.cls_row[int(gt_obj[cand[k]])] for k in keep]
+            cls_rows = _upload(np.asarray(rows, np.int64), dev)
+            part = {"rows": rows, "feats_tmp": self.tmp_feats[cls_rows].reshape(len(keep) * self.n_tmp, 7),
+                    "tmp_side": self._template_side(rows), "labels": {}}
+            cen = centroid if len(keep) == len(cand) else centroid[_upload(np.asarray(keep, np.int64), dev)]
+            if poses is not None:
+                # rot_gt = poses[:, 0:3], trans_gt = poses[:, 3] - centroid (:226-240: float64 difference, rounded to float32
+                # once) -- formed on the device from one small upload, so the centroids never come back to the host
+                P = _upload(np.asarray(poses, np.float64)[:, :, [cand[k] for k in keep]], dev)
+                part["labels"] = {"rot_gt": P[:, 0:3, :].permute(2, 0, 1).float().contiguous(),
+                                  "trans_gt": (P[:, 3, :].t() - cen.double()).float().contiguous()}
+            part["centroid"] = cen
+            part["host"] = {"batch_offsets": (torch.arange(len(keep) + 1) * 1024).int(), "voxel_num_limit": torch.tensor(self.limit),
+                            "obj_idx": torch.IntTensor(gt_obj - 1), "flags": torch.IntTensor([-1])}
+            return part
+        part = count_free_part(list(range(len(cand))))
+        _mark("count-free part issued")
         cnt = counts.cpu().numpy()                                                  # the builder's host read-back
+        _mark("counts read back")
         keep = [k for k in range(len(cand)) if cnt[k, 0] > 0]
         if not keep:
             raise ValueError("every object mask of this image is empty")
         picks = []
         t_draw = time.perf_counter()
-        for k in keep:                                                              # :166-169, the loader's RNG calls
+        # :166-169, the loader's RNG calls, in the loader's order on the global legacy generator: choice(m, n, replace=False) --
+        # numpy shuffles all m masked points for it, 14.5 ns each -- runs of such objects go through ops.legacy_choice_heads (the
+        # same walk on the same generator state, bit for bit, ~3x faster: 0.44 -> 0.14 ms per 6-object frame); the rare
+        # choice(m, n) WITH replacement (m <= n points) stays numpy's.  A seeded run consumes the stream like the original.
+        run = []
+        def flush():
+            if run:
+                picks.extend(ops.legacy_choice_heads([int(cnt[k, 2]) for k in run], self.n_inp))
+                del run[:]
+        for k in keep:
             m = int(cnt[k, 2])
-            picks.append(np.random.choice(m, self.n_inp, replace=False) if m > self.n_inp
-                         else np.random.choice(m, self.n_inp))
+            if m > self.n_inp:
+                run.append(k)
+            else:
+                flush()
+                picks.append(np.random.choice(m, self.n_inp))
             flags[cand[k]] = 1
-        # (the legacy np.random.choice(m, n, replace=False) shuffles all m masked points: 0.1-0.4 ms per object -- the
-        # reference loader's own cost, kept because a seeded run must consume the global RNG stream like the original)
+        flush()
         self.draw_seconds += time.perf_counter() - t_draw
+        _mark("draws done")
         if len(keep) != len(cand):
-            kt = torch.tensor(keep, device=dev)
-            xyz, col, centroid, counts = xyz[kt].contiguous(), col[kt].contiguous(), centroid[kt], counts[kt].contiguous()
-        pick_t = torch.from_numpy(np.stack(picks).astype(np.int64)).to(dev)
+            kt = _upload(np.asarray(keep, np.int64), dev)
+            xyz, col, counts = xyz[kt].contiguous(), col[kt].contiguous(), counts[kt].contiguous()
+            part = count_free_part(keep)
+        pick_t = _upload(np.stack(picks).astype(np.int64), dev)
         feats_inp, coords_inp = ops.crop_sample(xyz, col, pick_t, counts, self.extent[0] * 0.5, self.unit,
                                                 int(self.limit[0]), min_valid=MIN_VALID)
         b = len(keep)
-        rows = [self.cls_row[int(gt_obj[cand[k]])] for k in keep]
-        cls_rows = torch.tensor(rows, device=dev)
-        feats_tmp = self.tmp_feats[cls_rows].reshape(b * self.n_tmp, 7)
-        data = {"batch_offsets": (torch.arange(b + 1) * 1024).int(), "voxel_num_limit": torch.tensor(self.limit),
-                "obj_idx": torch.IntTensor(gt_obj - 1), "all_flags": torch.IntTensor(flags),
-                "flags": torch.IntTensor([-1]), "all_centroids": centroid, "labels": {}, "counts": cnt[keep]}
-        if poses is not None:
-            # rot_gt = poses[:, 0:3], trans_gt = poses[:, 3] - centroid (:226-240: float64 difference, rounded to float32
-            # once) -- formed on the device from one small upload, so the centroids never come back to the host
-            P = torch.from_numpy(np.ascontiguousarray(np.asarray(poses, np.float64)[:, :, [cand[k] for k in keep]])).to(dev)
-            data["labels"] = {"rot_gt": P[:, 0:3, :].permute(2, 0, 1).float().contiguous(),
-                              "trans_gt": (P[:, 3, :].t() - centroid.double()).float().contiguous()}
+        rows, feats_tmp = part["rows"], part["feats_tmp"]
+        data = dict(part["host"], all_flags=torch.IntTensor(flags), all_centroids=part["centroid"], labels=part["labels"],
+                    counts=cnt[keep])
+        _mark("sample + labels issued")
         S = int(self.limit[0])
-        occ, p2v, v2p = ops.voxelize_idx_gpu(coords_inp, b, S, self.mode)
-        data["inp"] = {"feats": feats_inp, "coords": coords_inp, "occupied_voxels": occ, "p2v_maps": p2v, "v2p_maps": v2p}
-        occ, p2v, v2p, coords_tmp = self._template_side(rows)                       # tables: no kernel, no read-back
+        if (b <= ops.VI_CROPS_MAX_BATCH and self.n_inp <= ops.VI_CROPS_MAX_POINTS and S == ops.VI_CROPS_S and
+                self.mode in (3, 4)):
+            # the image's crops are voxelised in ONE launch (one workgroup per crop) into capacity-shaped tensors
+            occ, p2v, v2p, info = ops.voxelize_idx_crops(coords_inp, b, self.n_inp, S, self.mode, pitch=self.v2p_pitch)
+            if self.capacity:
+                # capacity form: nothing comes back to the host -- occupied_voxels / v2p_maps keep their b*n rows and `pitch`
+                # columns, the live row count stays on the device (v0_dev; Network.forward's graph path takes it as it is)
+                data["inp"] = {"feats": feats_inp, "coords": coords_inp, "occupied_voxels": occ, "p2v_maps": p2v, "v2p_maps": v2p,
+                               "v0_dev": info[0:1], "vi_info": info}
+            else:
+                V, ma, err = info.cpu().tolist()                                    # the builder's second host read-back
+                if err:      # a voxel with more points than the pitch holds (a tiny object sampled with replacement): general op
+                    occ, p2v, v2p = ops.voxelize_idx_gpu(coords_inp, b, S, self.mode)
+                    data["inp"] = {"feats": feats_inp, "coords": coords_inp, "occupied_voxels": occ, "p2v_maps": p2v, "v2p_maps": v2p}
+                else:
+                    data["inp"] = {"feats": feats_inp, "coords": coords_inp, "occupied_voxels": occ[:V], "p2v_maps": p2v,
+                                   "v2p_maps": v2p[:V, :max(ma, 1) + 1].contiguous()}
+        else:
+            occ, p2v, v2p = ops.voxelize_idx_gpu(coords_inp, b, S, self.mode)
+            data["inp"] = {"feats": feats_inp, "coords": coords_inp, "occupied_voxels": occ, "p2v_maps": p2v, "v2p_maps": v2p}
+        _mark("voxelisation issued")
+        occ, p2v, v2p, coords_tmp = part["tmp_side"]                                # tables: no kernel, no read-back
         data["tmp"] = {"feats": feats_tmp, "coords": coords_tmp, "occupied_voxels": occ, "p2v_maps": p2v, "v2p_maps": v2p}
         # a Network(async_inputs=True) lets its side streams wait for exactly this point instead of the whole stream
         data["ready_event"] = torch.cuda.Event()
         data["ready_event"].record(torch.cuda.current_stream(dev))
+        _mark("end")
         return data
 
     def build_lm(self, img, depth, mask_label, obj_bb, obj, eval_mode=False):
@@ -244,7 +317,7 @@ class CropBuilder(object):
         n_mask, n_valid, m = counts.cpu().numpy()[0]
         if n_mask == 0 or not (n_valid > LM_MIN_VALID or eval_mode):
             return None
-        pick = np.random.choice(m, self.n_inp, replace=False) if m > self.n_inp else np.random.choice(m, self.n_inp)
+        pick = ops.legacy_choice_heads([int(m)], self.n_inp)[0] if m > self.n_inp else np.random.choice(m, self.n_inp)
         pick_t = torch.from_numpy(pick.astype(np.int64)).view(1, -1).to(dev)
         feats, coords = ops.crop_sample(xyz, col, pick_t, None, self.extent[0] * 0.5, self.unit, int(self.limit[0]))
         row = self.cls_row[int(obj)]
@@ -343,3 +416,19 @@ class CropPrefetcher(object):
 
     def __exit__(self, *a):
         self.close()
+
+
+def exact_form(data):
+    """a capacity-form data dict of CropBuilder(capacity=True) -> the loader's exact form (occupied_voxels (V,4), v2p_maps
+    (V, 1+maxActive)): ONE host read-back of {V, maxActive, error}.  A dict that is exact already is returned as it is."""
+    side = data["inp"]
+    if "v0_dev" not in side:
+        return data
+    V, ma, err = side["vi_info"].cpu().tolist()
+    if err:
+        raise RuntimeError("CropBuilder: a voxel holds more points than v2p_pitch - 1, or a point lies outside its grid")
+    out = dict(data)
+    out["inp"] = {k: v for k, v in side.items() if k not in ("v0_dev", "vi_info")}
+    out["inp"]["occupied_voxels"] = side["occupied_voxels"][:V]
+    out["inp"]["v2p_maps"] = side["v2p_maps"][:V, :max(ma, 1) + 1].contiguous()
+    return out

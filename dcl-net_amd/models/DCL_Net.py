@@ -639,10 +639,13 @@ class Network(nn.Module):
             jobs = []
             for s in ("inp", "tmp"):
                 st, d = ent[s], data[s]
+                # (capacity-form crops carry their live row count on the device: copied, not read)
+                v0 = d["v0_dev"].view(1, 1) if "v0_dev" in d else int(d["occupied_voxels"].shape[0])
                 jobs += [(st["feats"], d["feats"]), (st["occ"], d["occupied_voxels"]), (st["v2p"], d["v2p_maps"]),
-                         (st["v0"], int(d["occupied_voxels"].shape[0]))]
+                         (st["v0"].view(1, 1) if torch.is_tensor(v0) else st["v0"], v0)]
             ops.pad_copy_many(jobs)
         else:
+            assert "v0_dev" not in data["inp"], "capacity-form crops must be resident, dense CUDA tensors"
             for s, n in (("inp", self.n_inp), ("tmp", self.n_tmp)):
                 st, d = ent[s], data[s]
                 v0 = int(d["occupied_voxels"].shape[0])
@@ -863,6 +866,13 @@ class Network(nn.Module):
             b = int(data["batch_offsets"].size(0)) - 1
             if self.replays_graph(b) and self._admit_graph(b, data):
                 return self.forward_graphed(data)
+            if "v0_dev" in data["inp"]:                 # capacity-form crops (CropBuilder(capacity=True)) off the graph path:
+                from ..crops import exact_form          # the launch-by-launch path sizes its buffers on the host
+                exact = exact_form(data)
+                with torch.no_grad():
+                    pred = self._forward_fused(exact)
+                data["labels"] = exact["labels"]
+                return pred
             with torch.no_grad():
                 return self._forward_fused(data)
         return self._forward_compat(data)

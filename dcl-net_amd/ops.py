@@ -66,6 +66,38 @@ def voxelize_idx_gpu(coords, batch_size, S=64, mode=4):
     return out_coords, input_map, out_map
 
 
+VI_CROPS_MAX_BATCH, VI_CROPS_MAX_POINTS, VI_CROPS_S = 64, 1024, 64
+_VI_COMM = {}
+
+
+def voxelize_idx_crops(coords, batch_size, n_per, S=64, mode=4, pitch=33, occ_dtype=torch.int64):
+    """voxelize_idx for the crop builder's layout -- batch_size crops of exactly n_per <= 1024 points each (rows c*n_per .. of
+    `coords` (b*n_per, 4) int64 belong to crop c), 64^3 grids, at most 64 crops -- in ONE launch and WITHOUT a host read-back
+    (csrc/voxelize_idx.hip: k_vi_crops).  Returns CAPACITY-shaped tensors: occ (b*n_per, 4) of occ_dtype, input_map (b*n_per),
+    v2p (b*n_per, pitch) and info = device int32 {V, maxActive, error}: the first V rows of occ / v2p are live and equal
+    voxelize_idx_gpu's rows bit for bit (v2p[:V, :maxActive+1]); error = a point outside its grid or a voxel with more than
+    pitch-1 points."""
+    N.need_cuda(coords)
+    b, n_per = int(batch_size), int(n_per)
+    assert coords.is_contiguous() and coords.dtype == torch.int64 and tuple(coords.shape) == (b * n_per, 4)
+    assert 1 <= b <= VI_CROPS_MAX_BATCH and 1 <= n_per <= VI_CROPS_MAX_POINTS and int(S) == VI_CROPS_S
+    dev = coords.device
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    ent = _VI_COMM.get(key)
+    if ent is None:                                            # 2 ints per crop that persist between calls + the call counter
+        ent = _VI_COMM[key] = [torch.zeros(2 * VI_CROPS_MAX_BATCH, dtype=torch.int32, device=dev), 0]
+    ent[1] = ent[1] % 0x3fffffff + 1
+    occ = torch.empty((b * n_per, 4), dtype=occ_dtype, device=dev)
+    input_map = torch.empty(b * n_per, dtype=torch.int32, device=dev)
+    v2p = torch.empty((b * n_per, int(pitch)), dtype=torch.int32, device=dev)
+    info = torch.empty(3, dtype=torch.int32, device=dev)
+    assert occ_dtype in (torch.int64, torch.int32)
+    N.check(N.lib().dcl_voxelize_idx_crops(N.ptr(coords), b, n_per, int(S), int(mode), int(pitch), N.ptr(ent[0]), ent[1],
+                                           N.ptr(input_map), N.ptr(occ), int(occ_dtype == torch.int32), N.ptr(v2p), N.ptr(info),
+                                           N.stream()), "voxelize_idx_crops")
+    return occ, input_map, v2p, info
+
+
 def voxelize_fp(feats, map_rule, mode=4):
     """PG_OP.voxelize_fp (pointgroup_ops.py:42-62): feats (N,C) f32, map_rule (M,1+maxActive) i32 -> (M,C)."""
     N.need_cuda(feats, map_rule)
@@ -954,6 +986,28 @@ def add(cld, R_pred, t_pred, R_gt, t_gt, cls=None):
 
 
 # ------------------------------------------------------------------------------------ crop builder
+def legacy_choice_heads(ms, n):
+    """[np.random.choice(m, n, replace=False) for m in ms] on the GLOBAL legacy generator, bit for bit and with the same
+    advance of its state, ~3x faster (csrc/legacy_rng.cpp: numpy's Fisher-Yates walk as a tight branch-free loop).  Host
+    code; every m must be >= n.  -> int64 array (len(ms), n).  (The loaders' sampling draws: YCBV/dataloader_test_YCBV.py:166-169.)"""
+    import numpy as np
+    k = len(ms)
+    out = np.empty((k, int(n)), np.int64)
+    if k == 0:
+        return out
+    st = np.random.get_state()
+    assert st[0] == "MT19937"
+    key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
+    pos = C.c_int32(int(st[2]))
+    m = np.ascontiguousarray(np.asarray(ms, np.int32))
+    scratch = np.empty(int(m.max()), np.int32)
+    N.check(N.lib().dcl_legacy_permutation_heads(key.ctypes.data_as(C.c_void_p), C.byref(pos), m.ctypes.data_as(C.c_void_p), k, int(n),
+                                                 out.ctypes.data_as(C.c_void_p), scratch.ctypes.data_as(C.c_void_p)),
+            "legacy_permutation_heads")
+    np.random.set_state((st[0], key, int(pos.value), st[3], st[4]))
+    return out
+
+
 def crop_points(depth, label, rgb, boxes, obj_ids, cam, rgb_mean, half_extent, min_valid=32, always_filter=False, cap=None):
     """Masked back-projection + centring + grid filter of every object instance of one image
     (YCBV/dataloader_test_YCBV.py:124-165).  depth (H,W) u16 viewed as int16 storage, label (H,W) i32, rgb (H,W,C) u8,

@@ -61,6 +61,16 @@ int dcl_voxelize_idx_gpu_count(const int64_t *coords, int n, int batch, int S, i
 int dcl_voxelize_idx_gpu_fill(const int64_t *coords, int n, int batch, int S, void *ws, const int32_t *input_map,
                               int n_active, int max_active, int64_t *output_coords, int32_t *output_map,
                               dclStream_t stream);
+/* The crop builder's case of the above in ONE launch and without a host read-back (the loader voxelises the
+ * b x n sampled points of an image's crops, YCBV/dataloader_test_YCBV.py:213-223): b <= 64 crops of n_per <= 1024 points each
+ * (rows c*n_per .. belong to crop c) on 64^3 grids, one workgroup per crop.  Outputs are CAPACITY-pitched: output_map rows of
+ * `pitch` ints (1 + the most points a voxel can hold), output_coords (rows,4) int64 (occ32 = 0) or int32 (occ32 = 1), both
+ * b*n_per rows of which the ones behind the V live rows are zeroed; info_dev = {V, maxActive, error}, error = a point outside its crop's grid or a voxel with more than
+ * pitch-1 points.  Ids in first-encounter order, rows ascending, zero padded -- bit for bit voxelize.cpp:58-152 on the live
+ * part.  comm: 2*b ints that persist between calls (zero before the first); gen != 0 must differ from the previous call's. */
+int dcl_voxelize_idx_crops(const int64_t *coords, int batch, int n_per, int S, int mode, int pitch, int32_t *comm, int gen,
+                           int32_t *input_map, void *output_coords, int occ32, int32_t *output_map, int32_t *info_dev,
+                           dclStream_t stream);
 
 /* voxelize_fp: pointgroup_ops_api.cpp:8 -> src/voxelize/voxelize.cu:9-31.
  * feats (N,C), rules (V,1+maxActive) -> out (V,C); out need not be zeroed.     */
@@ -498,6 +508,15 @@ int dcl_add(int b, int P, const float *cld, const int32_t *cls, const float *R_p
 int dcl_add_by_symmetry(int b, int P, const float *cld, const int32_t *cls, const int32_t *sym_flag,
                         const float *R_pred, const float *t_pred, const float *R_gt, const float *t_gt,
                         float *partial_scratch, float *out, dclStream_t stream);
+
+/* The loaders' point-sampling draws, bit for bit (host code, no GPU call): for each of k objects out[o*n .. o*n+n) =
+ * np.random.permutation(m[o])[:n] = what np.random.choice(m[o], n, replace=False) returns (YCBV/dataloader_test_YCBV.py:166-169,
+ * LM/dataloader_test_LM.py:176-181) -- numpy's legacy Fisher-Yates walk (mtrand.pyx: _shuffle_raw, random_interval: MT19937
+ * words masked and rejected) on the CALLER's generator state: key624 = np.random.get_state()[1] (updated in place), *pos_io =
+ * [2] (in / out); put them back with np.random.set_state() and the global stream has advanced exactly as under numpy.
+ * Requires n <= m[o] < 2^31; scratch = max(m) int32.  ~3x numpy's speed (a tight 32-bit loop instead of 3 memcpy per swap). */
+int dcl_legacy_permutation_heads(uint32_t *key624, int32_t *pos_io, const int32_t *m, int k, int n, int64_t *out,
+                                 int32_t *scratch);
 
 /* The ONE measurement facility of the product library (it selects nothing and changes no result; every tuning / A-B switch
  * lives in the diagnostic library below): between _begin and _end every sparse-conv call (runner or op API) is bracketed by

@@ -144,6 +144,67 @@ def test_built_crops_run_through_the_network(dcl):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("b,n_per,span", [(1, 1024, 64), (3, 1024, 20), (6, 1024, 40), (17, 500, 12), (64, 257, 64), (5, 1, 64)])
+def test_one_launch_crop_voxelisation_equals_the_general_device_op(dcl, b, n_per, span):
+    """ops.voxelize_idx_crops (one workgroup per crop, capacity-pitched outputs, no read-back) == ops.voxelize_idx_gpu on
+    the builder's layout: V, maxActive, voxel rows, point -> voxel map and the ascending, zero-padded point lists bit for
+    bit; the capacity rows behind the V live ones are zero; a voxel beyond the pitch is flagged, not silently dropped"""
+    ops = dcl.ops
+    rng = np.random.default_rng(b * 1000 + n_per)
+    xyz = rng.integers(0, span, size=(b, n_per, 3))                      # small spans: many points per voxel, long rows
+    coords = torch.from_numpy(np.concatenate([np.repeat(np.arange(b), n_per)[:, None], xyz.reshape(-1, 3)], 1).astype(np.int64)).cuda()
+    occ_w, p2v_w, v2p_w = ops.voxelize_idx_gpu(coords, b, 64, 4)
+    V, ma = occ_w.shape[0], v2p_w.shape[1] - 1
+    pitch = ma + 3
+    for dtype in (torch.int64, torch.int32):
+        occ, p2v, v2p, info = ops.voxelize_idx_crops(coords, b, n_per, 64, 4, pitch=pitch, occ_dtype=dtype)
+        assert info.cpu().tolist() == [V, ma, 0]
+        assert torch.equal(occ[:V].long(), occ_w) and torch.equal(p2v, p2v_w)
+        assert torch.equal(v2p[:V, :ma + 1], v2p_w) and int(v2p[:V, ma + 1:].abs().sum()) == 0
+        assert int(v2p[V:].abs().sum()) == 0 and int(occ[V:].abs().sum()) == 0
+        occ2, p2v2, v2p2, info2 = ops.voxelize_idx_crops(coords, b, n_per, 64, 4, pitch=pitch, occ_dtype=dtype)   # next generation
+        assert torch.equal(v2p2[:V], v2p[:V]) and torch.equal(p2v2, p2v) and info2.cpu().tolist() == [V, ma, 0]
+    if ma >= 2:
+        _, _, _, info = ops.voxelize_idx_crops(coords, b, n_per, 64, 4, pitch=ma)           # one column short
+        assert info.cpu().tolist()[2] == 1
+    bad = coords.clone()
+    bad[0, 1] = 64                                                                         # outside the grid
+    _, _, _, info = ops.voxelize_idx_crops(bad, b, n_per, 64, 4, pitch=pitch)
+    assert info.cpu().tolist()[2] == 1
+
+
+@pytest.mark.gpu
+def test_capacity_form_crops_give_the_same_poses(dcl):
+    """CropBuilder(capacity=True): one host read-back per frame instead of two -- the observed side's voxel rows stay
+    capacity-shaped with their count on the device.  Through the network's graph path (which takes that form as it is) and
+    through the launch-by-launch path (which converts: exact_form) the poses equal those of the exact-form crops."""
+    cfg = dict(CFG, input_size=256, tmp_size=256)
+    sc = make_scene(23, n_obj=4, tmp_size=256)
+    for c in sc["cad_pts"]:
+        sc["cad_pts"][c] = sc["cad_pts"][c] * 0.8
+    exact_b = dcl.crops.CropBuilder(cfg, sc["cad_pts"], sc["cad_col"])
+    cap_b = dcl.crops.CropBuilder(cfg, sc["cad_pts"], sc["cad_col"], capacity=True)
+    np.random.seed(3)
+    want_d = exact_b.build(sc["img"], sc["depth"], sc["label"], sc["rois"], sc["gt_obj"])
+    np.random.seed(3)
+    cap_d = cap_b.build(sc["img"], sc["depth"], sc["label"], sc["rois"], sc["gt_obj"])
+    assert "v0_dev" in cap_d["inp"] and cap_d["inp"]["occupied_voxels"].shape[0] == cap_d["inp"]["feats"].shape[0]
+    back = dcl.crops.exact_form(cap_d)
+    for k in ("feats", "occupied_voxels", "p2v_maps", "v2p_maps"):
+        assert torch.equal(back["inp"][k], want_d["inp"][k]), k
+    for graph in (8, 0):
+        net = dcl.DCL_Net.Network(dcl.synth.default_cfg(256, 256), mode="test", graph_max_batch=graph)
+        net.load_state_dict(dcl.synth.synth_state_dict(net, 1))
+        net = net.cuda().eval()
+        with torch.no_grad():
+            want = net(dict(want_d, labels={}))
+            got = net(dict(cap_d, labels={}))
+            again = net(dict(cap_d, labels={}))
+        for k in ("rot_pred", "trans_pred", "conf"):
+            assert torch.equal(want[k], got[k]) and torch.equal(want[k], again[k]), (graph, k)
+
+
+@pytest.mark.gpu
 def test_prefetcher_yields_the_serial_loops_crops(dcl):
     """crops.CropPrefetcher (the loader workers' role, tools/test_YCBV_stage1.py:133-137): a builder thread two frames ahead of
     the caller yields, frame by frame, exactly what a serial loop over CropBuilder.build yields under the same seed; an error

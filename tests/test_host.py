@@ -365,3 +365,28 @@ def test_rank_cpu_sets_follow_the_gpu_numa_topology(dcl, tmp_path):
     assert S.visible_device_map(env, 4) is None
     assert S.rank_cpu_set(1, 2, allowed=set(range(16)), sysfs_root=str(tmp_path), env=env) == set(range(8, 16))
     assert S.visible_device_map({}, 4) == [0, 1, 2, 3]
+
+
+def test_legacy_choice_heads_equal_numpy_and_advance_the_global_stream_alike(dcl):
+    """ops.legacy_choice_heads (csrc/legacy_rng.cpp, host code) == [np.random.choice(m, n, replace=False) ...] on the global
+    legacy generator, for sizes around the powers of two (where the mask of random_interval changes), after an arbitrary
+    number of earlier draws (generator position mid-block), and the draws that FOLLOW are the same too"""
+    rng = np.random.RandomState(5)
+    for trial in range(40):
+        seed = int(rng.randint(0, 2 ** 31))
+        ms = [int(rng.randint(1025, 40000)) for _ in range(int(rng.randint(1, 7)))]
+        if trial % 5 == 0:
+            ms[0] = 1024
+        if trial % 3 == 0:
+            ms[-1] = (1 << int(rng.randint(11, 16))) + int(rng.randint(-1, 2))
+        pre = int(rng.randint(0, 1500))
+        np.random.seed(seed)
+        np.random.rand(pre)
+        want = [np.random.choice(m, 1024, replace=False) for m in ms]
+        tail_w = np.random.randint(0, 1 << 30, 5)
+        np.random.seed(seed)
+        np.random.rand(pre)
+        got = dcl.ops.legacy_choice_heads(ms, 1024)
+        tail_g = np.random.randint(0, 1 << 30, 5)
+        assert all((got[i] == want[i]).all() for i in range(len(ms))), (trial, ms)
+        assert (tail_w == tail_g).all(), trial
