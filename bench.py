@@ -582,11 +582,59 @@ def sparse_conv_roofline(dcl, net, data, dev, steps=3):
             "schedule": "one stream; every layer of the two backbones as ONE grouped launch (what Network(single_stream=True) "
                         "runs); rows of the two deep levels ordered on the device (the ordering launches run in the geometry "
                         "stage, outside the timed conv calls: 2 launches per backbone, see profiles/)",
+            "feature_stage": dict(feature_stage_times(dcl, net, data, dev),
+                                  what="convs + pools of both backbones stand-alone: a launch per layer and side / one grouped "
+                                       "launch per layer / everything as ONE launch (Network(feature_stage=True); not the default: "
+                                       "inside the whole forward it ties with the two-stream schedule, DESIGN section 10)"),
             "separate_launches": {"conv_ms_per_forward": round(timed["separate"][0], 4), "conv_calls_timed": timed["separate"][1],
                                   "frac": round(flop / (timed["separate"][0] * 1e-3) / 1e12 / PEAK_MFMA_F32, 4)
                                   if timed["separate"][0] > 0 else None,
                                   "what": "the same forwards with each backbone's own launches (the default two-stream "
                                           "schedule issues these, on two streams)"}}
+
+
+def feature_stage_times(dcl, net, data, dev, reps=10):
+    """The sparse feature stage of BOTH backbones (8 convs + 4 pools each) on this batch, stand-alone, three ways: one launch
+    per layer and side, one grouped launch per layer (dcl_backbone_features_pair), and ONE launch for everything
+    (dcl_backbone_features_stage, csrc/feature_stage.hip).  HIP events around the calls; the stage's status word is checked."""
+    ops = dcl.ops
+    f = net._fold()
+    b = int(data["batch_offsets"].size(0)) - 1
+    runs, xs, ptrs = [], [], []
+    with torch.no_grad():
+        for s in ("inp", "tmp"):
+            occ = data[s]["occupied_voxels"].to(dev).int().contiguous()
+            xs.append(ops.voxelize_fp(data[s]["feats"].to(dev).float().contiguous(), data[s]["v2p_maps"].to(dev).int().contiguous(), 4))
+            run = ops.BackboneRun(occ, b, 64)
+            run.set_counts(run.counts_dev.cpu().tolist())
+            runs.append(run)
+            ptrs.append(f["backbone_%s_ptrs" % s])
+        status = ops.stage_status_buffer()
+
+        def per_layer():
+            for r, x, p in zip(runs, xs, ptrs):
+                r.features(x, *p)
+
+        def pair():
+            ops.backbone_features_pair(runs[0], xs[0], ptrs[0], runs[1], xs[1], ptrs[1])
+
+        def stage():
+            assert ops.backbone_features_stage(runs, xs, ptrs, status, slots=512)
+
+        out = {}
+        for name, fn in (("per_layer_side_after_side", per_layer), ("per_layer_grouped", pair), ("one_launch_stage", stage)):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            out[name + "_ms"] = round(e0.elapsed_time(e1) / reps, 4)
+        out["stage_status"] = int(status[0])
+    return out
 
 
 def collective_report(distributed, rank, world, mine):
@@ -849,8 +897,10 @@ def main():
         hsteps = max(3, args.steps // 2)
         # ... and from PINNED host tensors (what DataLoader(pin_memory=True) hands over; the copies inside forward() are then
         # real asynchronous DMAs instead of staged pageable copies)
-        pinned = {k: ({kk: (vv.pin_memory() if torch.is_tensor(vv) else vv) for kk, vv in v.items()} if isinstance(v, dict)
-                      else (v.pin_memory() if torch.is_tensor(v) else v)) for k, v in host_data.items()}
+        def pin(v):
+            return v.pin_memory() if torch.is_tensor(v) and not v.is_cuda else v
+        pinned = {k: ({kk: pin(vv) for kk, vv in v.items()} if isinstance(v, dict) else pin(v)) for k, v in host_data.items()}
+        pinned["labels"] = {}
         pdt, _ = run_forward_bench(dcl, net, pinned, max(3, args.steps // 2), 1, False)
         line["h2d_inclusive"] = {"value": round(b * hsteps / pdt, 2), "unit": "frames/s",
                                  "ms_per_step": round(pdt / hsteps * 1e3, 3),

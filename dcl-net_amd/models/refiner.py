@@ -33,6 +33,8 @@ def _param_version(mod):
 
 
 class Refiner(nn.Module):
+    POSE_HEADS_MAX = 128      # crops up to which the two heads run as dcl_pose_heads (two launches; Network.POSE_HEADS_MAX)
+
     def __init__(self, cfg=None):
         super().__init__()
         self.MLP_share = Head_MultiLayerPerceptron([256 + 3, 512, 512, 1024], ["relu"] * 3, [False] * 3, [0.0] * 3)
@@ -89,10 +91,17 @@ class Refiner(nn.Module):
         (constant over refinement iterations), conf_w (b,n) softmax slice.  -> (delta_t (b,3), delta_R (b,3,3))."""
         f = self._fold()
         b, n = conf_w.shape
-        h = torch.relu(torch.addmm(feat_term, xyz_pm, f["share0_xyz"]))
+        # first shared layer: the K = 3 product + the constant term + ReLU in one pass (ops.affine3_relu; a library GEMM and a
+        # ReLU sweep before: 49 -> ~27 us per iteration at 32 768 rows)
+        h = ops.affine3_relu(xyz_pm.contiguous(), f["share0_xyz"], feat_term)
         h = torch._addmm_activation(f["MLP_share"][1][1], h, f["MLP_share"][1][0])
         h = torch._addmm_activation(f["MLP_share"][2][1], h, f["MLP_share"][2][0])          # (b*n, 1024)
         shared = torch.bmm(conf_w.unsqueeze(1), h.view(b, n, -1)).squeeze(1)                 # (b, 1024)
+        # both pose heads (1024 -> 512 -> 128 -> 9 | 3) and the rotation in two launches (ops.pose_heads, as in stage 1) instead of
+        # six library GEMMs of 5-14 us each on 32 rows + the ortho kernel; larger batches keep the library
+        if b <= self.POSE_HEADS_MAX:
+            _, dt, dR = ops.pose_heads(shared, f["regressor_rot2"], f["regressor_trans2"], with_rotation=True)
+            return dt, dR
 
         def head(x, layers):
             x = torch._addmm_activation(layers[0][1], x, layers[0][0])

@@ -805,6 +805,19 @@ def conf_pool(b, logit1, logit2, F1, F2, affine=None):
     return conf, part1.sum(dim=1), part2.sum(dim=1), ws
 
 
+def affine3_relu(xyz, W3, term):
+    """relu(term + xyz @ W3): xyz (rows,3), W3 (3,c), term (rows,c) -> (rows,c), one pass (csrc/dense.hip: k_affine3_relu) -- the
+    xyz part of the refiner's first shared layer (models/refiner.py:78-80)."""
+    N.need_cuda(xyz, W3, term)
+    assert xyz.is_contiguous() and W3.is_contiguous() and term.is_contiguous() and xyz.shape[1] == 3
+    rows, c = term.shape
+    assert tuple(W3.shape) == (3, c) and xyz.shape[0] == rows
+    out = torch.empty_like(term)
+    N.check(N.lib().dcl_affine3_relu(C.c_int64(rows), int(c), N.ptr(xyz), N.ptr(W3), N.ptr(term), N.ptr(out), N.stream()),
+            "affine3_relu")
+    return out
+
+
 def pose_heads(pooled, rot_layers, trans_layers, with_rotation=False):
     """regressor_rot / regressor_trans on the pooled (b,1024) feature for a handful of crops: both 3-layer heads in two
     launches.  *_layers: [(W1t, b1), (W2t, b2), (W3t, b3)] with (in, out) matrices -> (o9 (b,9), trans (b,3)); with_rotation:

@@ -409,6 +409,11 @@ int dcl_pool_finish(int b, int c, int nslices, const float *part1, const float *
                     const float *scale1, const float *shift1, const float *scale2, const float *shift2, float *out,
                     dclStream_t stream);
 
+/* out (rows, c) = relu(term + xyz (rows,3) @ W3 (3,c)): the xyz part of the first MLP_share layer of the stage-2 refiner
+ * (models/refiner.py:78-80: Conv1d(259 -> 512) over cat[xyz, F_Xo_p]; `term` = F_Xo_p's part + bias, constant over the
+ * refine iterations) in ONE pass over the tensor.  c % 4 == 0, 16-B aligned rows.                                       */
+int dcl_affine3_relu(int64_t rows, int c, const float *xyz, const float *W3, const float *term, float *out,
+                     dclStream_t stream);
 /* regressor_rot + regressor_trans (models/DCL_Net.py:139-151,231-235; Head_MultiLayerPerceptron 1024 -> 512 -> 128 -> 9 | 3,
  * ReLU after the first two layers) on the pooled feature (b,1024), both heads in two launches -- meant for a handful of
  * crops (one-image calls); large batches use library GEMMs.  rot_layers / trans_layers: {W1t (1024,512), b1, W2t (512,128),
