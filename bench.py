@@ -204,6 +204,18 @@ def primitives_roofline(dcl, reps=5):
         torch.cuda.synchronize()
         ms = a.elapsed_time(b) / reps
         out[name] = {"ms": round(ms, 4), "GBps": round(nbytes / ms / 1e6, 1), "bytes": nbytes}
+    # ball_query is an exact brute-force search: its bound is the vector-instruction issue rate, not HBM.  Per
+    # candidate test the kernel issues 4.5 vector instructions (two tests per 3 packed subtractions + packed mul + 2 packed fma +
+    # packed compare-subtract + 2 v_alignbit); the chip issues 256 CUs x 64 lanes x 2.4 GHz lane-instructions per second.
+    tests = float(B) * NP * N
+    bq_s = out["ball_query"]["ms"] * 1e-3
+    valu_bound = 256 * 64 * 2.4e9 / 4.5
+    out["ball_query"].update({"bound": "valu (packed f32 issue)", "candidate_tests": tests,
+                              "tests_per_s": round(tests / bq_s, 1), "valu_bound_tests_per_s": round(valu_bound, 1),
+                              "frac_of_valu_bound": round(tests / bq_s / valu_bound, 3),
+                              "note": "brute-force-equivalent rate; above 1.0 because a workgroup stops scanning once its 16 "
+                                      "centres hold nsample hits (r = 0.03, nsample = 64 on these clouds: about half of the "
+                                      "candidates are never tested)"})
     tot_b = out["ball_query"]["bytes"] + out["group_points"]["bytes"]
     tot_ms = out["ball_query"]["ms"] + out["group_points"]["ms"]
     out["ball_query+group_points"] = {"bound": "hbm", "achieved": round(tot_b / tot_ms / 1e6, 1), "peak": PEAK_HBM,

@@ -195,7 +195,7 @@ __device__ __forceinline__ int offset_at(int step, int kvol, int subm) {
 // wave-uniform broadcasts.  Per offset an ascending-ci fmaf chain like the generic kernel; the OFFSETS of a row are summed as four
 // interleaved chains (lane g of the row's quad: offsets g, g + 4, ... in visiting order) added pairwise at the end,
 // (l0 + l1) + (l2 + l3) -- not the generic kernel's / the reference's one offset-sequential chain; the parity tests hold it
-// to 2e-5 against the oracle, no test expects its bits.
+// to 2e-5 against the CPU restatement, no test expects its bits.
 // NTB = threads of the workgroup (NTB / 4 output rows per step).  Per-layer launch: item = blockIdx.x of nitems = gridDim.x,
 // row blocks dealt round-robin.  STAGED (one side per phase): an item owns a contiguous run of row blocks and reports the rows
 // it has written to the output tensor's group counters.

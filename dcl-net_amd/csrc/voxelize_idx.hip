@@ -192,7 +192,11 @@ __global__ __launch_bounds__(kViCropThreads) void k_vi_crops(const int64_t *__re
   }
   int base = 0;
   if (t < c) {
-    while (__hip_atomic_load(comm + 2 * t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != gen) __builtin_amdgcn_s_sleep(2);
+    int spins = 0;                                                       // bounded all the same: ~2 s, then the error flag
+    while (__hip_atomic_load(comm + 2 * t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != gen) {
+      if (++spins > (1 << 22)) { s_red[2] = 1; break; }
+      __builtin_amdgcn_s_sleep(8);
+    }
     base = __hip_atomic_load(comm + 2 * t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (t < 64) {                                                          // batch <= 64: one wave sums the bases

@@ -68,6 +68,7 @@ def voxelize_idx_gpu(coords, batch_size, S=64, mode=4):
 
 VI_CROPS_MAX_BATCH, VI_CROPS_MAX_POINTS, VI_CROPS_S = 64, 1024, 64
 _VI_COMM = {}
+_VI_LOCK = threading.Lock()
 
 
 def voxelize_idx_crops(coords, batch_size, n_per, S=64, mode=4, pitch=33, occ_dtype=torch.int64):
@@ -84,15 +85,18 @@ def voxelize_idx_crops(coords, batch_size, n_per, S=64, mode=4, pitch=33, occ_dt
     dev = coords.device
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     ent = _VI_COMM.get(key)
-    if ent is None:                                            # 2 ints per crop that persist between calls + the call counter
-        ent = _VI_COMM[key] = [torch.zeros(2 * VI_CROPS_MAX_BATCH, dtype=torch.int32, device=dev), 0]
-    ent[1] = ent[1] % 0x3fffffff + 1
+    if ent is None:        # a ring of 64 regions of 2 ints per crop that persist between calls + the call counter: consecutive calls
+        ent = _VI_COMM[key] = [torch.zeros(64 * 2 * VI_CROPS_MAX_BATCH, dtype=torch.int32, device=dev), 0]   # (also on other streams / threads) use different words
+    with _VI_LOCK:
+        ent[1] = ent[1] % 0x3fffffff + 1
+        gen = ent[1]
+    comm = ent[0][(gen % 64) * 2 * VI_CROPS_MAX_BATCH:]
     occ = torch.empty((b * n_per, 4), dtype=occ_dtype, device=dev)
     input_map = torch.empty(b * n_per, dtype=torch.int32, device=dev)
     v2p = torch.empty((b * n_per, int(pitch)), dtype=torch.int32, device=dev)
     info = torch.empty(3, dtype=torch.int32, device=dev)
     assert occ_dtype in (torch.int64, torch.int32)
-    N.check(N.lib().dcl_voxelize_idx_crops(N.ptr(coords), b, n_per, int(S), int(mode), int(pitch), N.ptr(ent[0]), ent[1],
+    N.check(N.lib().dcl_voxelize_idx_crops(N.ptr(coords), b, n_per, int(S), int(mode), int(pitch), N.ptr(comm), gen,
                                            N.ptr(input_map), N.ptr(occ), int(occ_dtype == torch.int32), N.ptr(v2p), N.ptr(info),
                                            N.stream()), "voxelize_idx_crops")
     return occ, input_map, v2p, info
