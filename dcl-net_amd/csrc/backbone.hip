@@ -644,7 +644,17 @@ static int backbone_features_stage(const SideArgs *sd, int nsides, int batch, in
             P.ord = Sd.ord.order != nullptr ? 1 : 0;
             P.stream_k = pl.stream_k; P.aligned_ns = pl.aligned_ns; P.use_bal = pl.use_bal;
             P.items = pl.G;
-            P.nchunks = pl.nchunks; P.conv_items = pl.G;
+            // capacity mode: the planner sizes a stream-K phase by the row CAPACITY; the items beyond the live work would only
+            // draw a ticket and leave (hundreds of empty workgroups per phase in front of the next phase's real ones), so the
+            // phase gets as many items as the EXPECTED rows need (x 1.5).  Any count is correct: U = max(ceil(live units / items),
+            // stream_k) is formed from the live rows in the kernel, more rows than expected only make the items longer.
+            if (rows_dev && pl.stream_k && !pl.aligned_ns) {
+              const long long ncol = P.cout / BN;
+              const long long units = (((long long)expect + BM - 1) / BM) * ncol * pl.nchunks;
+              const long long want = (units * 3 / 2 + pl.stream_k - 1) / pl.stream_k;
+              P.items = clampi(want, 1, pl.G);
+            }
+            P.nchunks = pl.nchunks; P.conv_items = P.items;
             P.partial = scr;
             P.tile_counters = pl.counters ? sync + sl.tickets[m][q] : nullptr;
             if (pl.counters) DCL_CHECK_ARG((long long)pl.tiles <= ((long long)nc + 63) / 64 * 4 + 1);
@@ -654,12 +664,12 @@ static int backbone_features_stage(const SideArgs *sd, int nsides, int batch, in
               DCL_CHECK_ARG((long long)pl.tiles <= ((long long)nc + 63) / 64 * 4 + 1);
               P.arrive_off = (int32_t)sl.arrive[m][q];
             }
-            (void)BM;
             ph[nph++] = P;
             if (pl.deferred) {                             // the combine of the split tiles: a phase of its own
               DclStagePhase R = P;
               R.kind = DCL_PH_REDUCE;
-              R.items = clampi(pl.tiles, 1, 2 * slots);
+              R.items = clampi(rows_dev ? (((long long)expect + BM - 1) / BM) * (P.cout / BN) * 3 / 2 + 1 : (long long)pl.tiles, 1,
+                               2 * slots);                 // (a combine item walks tiles item, item + items, ...: any count is correct)
               R.dep_off = -1;                              // (it waits for its tile's arrivals, not for rows)
               ph[nph++] = R;
             }
