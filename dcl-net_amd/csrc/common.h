@@ -54,8 +54,9 @@ __device__ __forceinline__ float dcl_dist2(float ax, float ay, float az, float b
 // Split-K sparse-conv launches combine their partial sums inside the launch: every (tile, split) workgroup publishes its
 // partial tile, takes a ticket on the tile's counter and the last arriver adds the partials in split order (deterministic)
 // and runs the epilogue.  The counters are the first kConvCounterWords int32 of the caller's split-K scratch; they must be
-// zero before a launch and are left zero by it.
-constexpr int kConvCounterWords = 8192;
+// zero before a launch and are left zero by it.  (32768: a capacity-mode launch is planned by its CAPACITY in tiles -- 40 crops'
+// level 1 are 10240 -- and one with more tiles than counters is never split: one workgroup per capacity tile, mostly empty.)
+constexpr int kConvCounterWords = 32768;
 void dcl_internal_zero_words(void *p, long long nwords, hipStream_t s);
 
 // Where a kernel gets nbr[k][o] (the input row feeding output row o under kernel offset k) from: an explicit gather table

@@ -26,7 +26,16 @@ sides = ("inp", "tmp")
 occ = {s: data[s]["occupied_voxels"].int().cuda().contiguous() for s in sides}
 x = {s: ops.voxelize_fp(data[s]["feats"].cuda(), data[s]["v2p_maps"].cuda(), 4) for s in sides}
 ptrs = {s: f["backbone_%s_ptrs" % s] for s in sides}
+CAP = bool(os.environ.get("STAGE_CAP"))      # capacity mode (what a captured whole-forward graph runs): device-side counts only
 def geo(s):
+    if CAP:
+        v0 = occ[s].shape[0]
+        pad = torch.zeros((b * n, 4), dtype=torch.int32, device="cuda"); pad[:v0] = occ[s]
+        xs = torch.zeros((b * n, x[s].shape[1]), dtype=torch.float32, device="cuda"); xs[:v0] = x[s]; x[s] = xs
+        run = ops.BackboneRunCap(pad, torch.tensor([v0], dtype=torch.int32, device="cuda"), b, 64)
+        run.geometry()
+        run.counts = run.counts_dev.cpu().tolist()
+        return run
     run = ops.BackboneRun(occ[s], b, 64)
     run.set_counts(run.counts_dev.cpu().tolist())
     return run
@@ -38,6 +47,8 @@ def per_layer():
     for s in sides:
         runs[s].features(x[s], *ptrs[s])
 def pair():
+    if CAP:
+        return per_layer()
     ops.backbone_features_pair(runs["inp"], x["inp"], ptrs["inp"], runs["tmp"], x["tmp"], ptrs["tmp"])
 def stage():
     assert ops.backbone_features_stage([runs[s] for s in sides], [x[s] for s in sides], [ptrs[s] for s in sides], status, slots=slots, flags=flags)
@@ -46,7 +57,7 @@ def stage1():
         assert ops.backbone_features_stage([runs[s]], [x[s]], [ptrs[s]], status, slots=slots, flags=flags)
 def levels():
     torch.cuda.synchronize()
-    return {s: [t.clone() for t in runs[s].levels] for s in sides}
+    return {s: [t[:runs[s].counts[2 * m + 1]].clone() for m, t in enumerate(runs[s].levels)] for s in sides}
 per_layer(); want = levels()
 for name, fn in (("pair", pair), ("stage (both sides, one launch)", stage), ("stage (a launch per side)", stage1)):
     for rep in range(3):
@@ -81,11 +92,15 @@ if os.environ.get("STAGE_DIAG"):
     a = a[live]
     t0 = a[:, 0].min()
     names = {0: "stem", 1: "wlds16", 2: "dma", 3: "reduce", 4: "pool"}
-    print("phase kind shape items | first start, last start, first end, last end (us) | mean item us | sum item us / 512 slots")
+    print("phase kind shape items | first start, last start, first end, last end (us) | mean / median / max item us | sum item us / 512 slots")
     for p in sorted(set(a[:, 2].tolist())):
         r = a[a[:, 2] == p]
         kind, shape = int(r[0, 3] >> 32), int(r[0, 3] & 0xffffffff)
         d = (r[:, 1] - r[:, 0]) / 100.0
-        print("%2d %-6s %6d %5d | %7.1f %7.1f %7.1f %7.1f | %6.1f | %6.1f" % (
+        print("%2d %-6s %6d %5d | %7.1f %7.1f %7.1f %7.1f | %6.1f %6.1f %6.1f | %6.1f" % (
             p, names[kind], shape if kind in (2, 3) else 0, len(r), (r[:, 0].min() - t0) / 100.0, (r[:, 0].max() - t0) / 100.0,
-            (r[:, 1].min() - t0) / 100.0, (r[:, 1].max() - t0) / 100.0, d.mean(), d.sum() / 512.0))
+            (r[:, 1].min() - t0) / 100.0, (r[:, 1].max() - t0) / 100.0, d.mean(), np.median(d), d.max(), d.sum() / 512.0))
+        if os.environ.get("STAGE_DIAG") == "2" and kind == 2:
+            st = np.sort((r[:, 0] - t0) / 100.0)
+            print("     starts (deciles):", " ".join("%.0f" % st[int(q * (len(st) - 1) / 10)] for q in range(11)),
+                  "| items (deciles):", " ".join("%.0f" % v for v in np.percentile(d, range(0, 101, 10))))
