@@ -149,9 +149,18 @@ def refine_loop(refiner, pred, points_inp, iteration=2, graph=False):
     F_pm = pred["F_Xo_p"].transpose(1, 2)                                 # (b,n,256) (a view when fused)
     b, n, _ = F_pm.shape
 
-    def body(rot, trans, F_pm, conf, pts):
+    def feature_term(F_pm, out=None):
+        # the feature half of the first shared layer: the same in every iteration, computed once per call
+        bias, W = f["MLP_share"][0][1], f["share0_feat"]
+        if F_pm.is_contiguous():                                  # point-major rows (what Network.forward hands over)
+            return torch.addmm(bias, F_pm.view(b * n, -1), W, out=out)
+        # channel-first features (the reference's own layout): a batched GEMM over the transposed operand, no transpose copy
+        o = torch.baddbmm(bias.view(1, 1, -1), F_pm, W.unsqueeze(0).expand(b, -1, -1),
+                          out=None if out is None else out.view(b, n, -1))
+        return o.view(b * n, -1)
+
+    def body(rot, trans, feat_term, conf, pts):
         conf_w = torch.softmax(conf.unsqueeze(1), dim=2)[:, 0, :1024].contiguous()
-        feat_term = torch.addmm(f["MLP_share"][0][1], F_pm.reshape(b * n, -1), f["share0_feat"])
         for _ in range(iteration):
             cur = torch.bmm(pts - trans.unsqueeze(1), rot).reshape(b * n, 3)
             dt, dR = refiner.forward_pm(cur, feat_term, conf_w)
@@ -161,11 +170,12 @@ def refine_loop(refiner, pred, points_inp, iteration=2, graph=False):
 
     with torch.no_grad():
         if not graph:
-            return body(rot0, trans0, F_pm, conf, points_inp)
+            return body(rot0, trans0, feature_term(F_pm), conf, points_inp)
         key = (b, n, iteration, conf.shape[1])
         cache = refiner.__dict__.setdefault("_graphs", {})
         if key not in cache:
-            static = [t.clone() for t in (rot0, trans0, F_pm.contiguous(), conf, points_inp)]
+            cc = lambda t: t.clone(memory_format=torch.contiguous_format)                     # noqa: E731
+            static = [cc(rot0), cc(trans0), feature_term(F_pm), cc(conf), cc(points_inp)]
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
@@ -177,10 +187,15 @@ def refine_loop(refiner, pred, points_inp, iteration=2, graph=False):
                 out = body(*static)
             cache[key] = (g, static, out)
         g, static, out = cache[key]
-        for dst, src in zip(static, (rot0, trans0, F_pm, conf, points_inp)):
-            dst.copy_(src)
+        # the 256-channel features are not copied into the graph (33 MB at 32 crops): their GEMM runs in front of the replay and
+        # writes the graph's static feature term; the small inputs are copied
+        feature_term(F_pm, out=static[2])
+        ops.pad_copy_many([(static[0].view(b, 9), rot0.reshape(b, 9)), (static[1], trans0.reshape(b, 3)),
+                           (static[3], conf.reshape(b, -1)), (static[4].view(b * n, 3), points_inp.reshape(b * n, 3))])
         g.replay()
-        return out[0].clone(), out[1].clone()
+        rot, trans = torch.empty_like(out[0]), torch.empty_like(out[1])     # (the graph's own outputs are overwritten by the next replay)
+        ops.pad_copy_many([(rot.view(b, 9), out[0].reshape(b, 9)), (trans, out[1].reshape(b, 3))])
+        return rot, trans
 
 
 def stage2_chain(model, refiner, data, iteration=2, graph=True):
