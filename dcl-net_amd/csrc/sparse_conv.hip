@@ -380,18 +380,27 @@ static bool conv_few_rows(int rows, bool capacity_mode) { return capacity_mode ?
 // ... unless the caller says how many rows it EXPECTS (DclConvSide::n_host beside n_dev: the backbone runner knows the batch
 // size and the level): a capacity says little -- level 4 of 32 crops has a capacity of 16384 rows and fills 3/4 of it, level 3
 // of 6 crops has one of 24576 and fills a fifth
-DCL_HOOK_INT(kConvFewRowsHint, 6144);
+// Up to 24576 expected rows a launch is better off as a few-row launch (short runs of chunks that never straddle two tiles,
+// combine as a launch of its own): whole forward, graph replay, 2 / 4 / 6 / 8 / 12 crops 0.616 -> 0.583 / 0.870 -> 0.790 /
+// 1.118 -> 1.060 / 1.325 -> 1.27 / 1.79 -> 1.76 ms against the former 6144 (tools/ab_hook.py dcl_debug_conv_few_hint).  A
+// launch that carries a row order keeps the 6144: the few-row form takes no order, and at 16 / 32 crops the deep levels lose
+// more by that (2.27 -> 2.31, 4.03 -> 4.21 ms) than the short runs win.
+DCL_HOOK_INT(kConvFewRowsHint, 24576);
+constexpr int kConvFewRowsOrdered = 6144;
 static bool conv_launch_is_few(const DclConvSides &sides, int nsides) {
   const bool capacity_mode = sides.s[0].n_dev != nullptr;
   int rows = 0;
-  bool hinted = capacity_mode;
+  bool hinted = capacity_mode, ordered = false;
   for (int i = 0; i < nsides; ++i) {
     const DclConvSide &S = sides.s[i];
     const int r_i = S.n_dev ? (S.n_host > 0 ? S.n_host : S.cap) : S.n_host;
     hinted = hinted && S.n_host > 0;
+    ordered = ordered || S.ord.order != nullptr;
     rows = r_i > rows ? r_i : rows;
   }
-  return hinted ? rows <= kConvFewRowsHint : conv_few_rows(rows, capacity_mode);
+  const int limit = ordered && kConvFewRowsHint > kConvFewRowsOrdered ? kConvFewRowsOrdered : (int)kConvFewRowsHint;
+  if (hinted || !capacity_mode) return rows <= limit;         // expected (capacity mode with a hint) or exact row counts
+  return conv_few_rows(rows, capacity_mode);
 }
 // A/B and tuning switches: process-wide atomics set through dcl_debug_* in the DIAGNOSTIC library (-DDCL_DIAG, tests/_diag/),
 // compile-time constants in the product library -- the product has no hooks, no superseded kernels and no getenv
@@ -426,7 +435,17 @@ static DclConvPlan plan_conv_dma(const DclConvSides &sides, int nsides, int CIN,
   // A handful of crops (one-image calls) is latency-bound on the chunk loop: stream-K with kFewChunks chunks per workgroup.
   const int nchunks = dcl_div_up(kvol * CIN, KC);
   constexpr int kFix = 4;
-  const int kFewChunks = g_conv_few_chunks;
+  // chunks per workgroup of a few-row launch: about four -- and a divisor of the tile's chunk count (27 -> 3, 54 -> 3, 14 -> 2,
+  // 108 -> 4) where there is one, so that no workgroup's run of chunks straddles two tiles: a straddling workgroup runs TWO
+  // segments -- two neighbour tables, two first fetches, two publishes, 16 us instead of 8 at one crop -- and the launch
+  // lasts as long as its longest workgroup
+  int kFewChunks = g_conv_few_chunks;
+  if (kFewChunks == 4) {
+    int best = 0;
+    for (int d = 2; d <= 6; ++d)
+      if (nchunks % d == 0 && (best == 0 || (d > 4 ? d - 4 : 4 - d) < (best > 4 ? best - 4 : 4 - best))) best = d;
+    if (best) kFewChunks = best;
+  }
   const long long units = (long long)tiles * nchunks;
   int stream_k = 0, aligned_ns = 0, G = tiles < 65535 * 16 ? tiles : 65535 * 16;
   bool deferred = false, counters = false, split = false;
