@@ -642,7 +642,8 @@ class Network(nn.Module):
                 # (capacity-form crops carry their live row count on the device: copied, not read)
                 v0 = d["v0_dev"].view(1, 1) if "v0_dev" in d else int(d["occupied_voxels"].shape[0])
                 jobs += [(st["feats"], d["feats"]), (st["occ"], d["occupied_voxels"]), (st["v2p"], d["v2p_maps"]),
-                         (st["v0"].view(1, 1) if torch.is_tensor(v0) else st["v0"], v0)]
+                         (st["v0"].view(1, 1) if torch.is_tensor(v0) else st["v0"], v0),
+                         (st["pb4"][:, 1:4], d["feats"][:, 4:7])]                  # (crop, xyz) rows of the read-out: no cat node in the graph
             ops.pad_copy_many(jobs)
         else:
             assert "v0_dev" not in data["inp"], "capacity-form crops must be resident, dense CUDA tensors"
@@ -650,6 +651,7 @@ class Network(nn.Module):
                 st, d = ent[s], data[s]
                 v0 = int(d["occupied_voxels"].shape[0])
                 st["feats"].copy_(d["feats"], non_blocking=True)
+                st["pb4"][:, 1:4].copy_(st["feats"][:, 4:7])
                 st["occ"][:v0].copy_(d["occupied_voxels"], non_blocking=True)
                 st["v2p"].zero_()
                 st["v2p"][:v0, :need_ma[s] + 1].copy_(d["v2p_maps"], non_blocking=True)
@@ -695,7 +697,9 @@ class Network(nn.Module):
             st["run"] = ops.BackboneRunCap(st["occ"], st["v0"], b, S)
             st["pf"] = torch.zeros((b * n, 480), dtype=torch.float32, device=dev)
             st["tmpbuf"] = torch.empty(st["run"].tmp_bytes(b * n), dtype=torch.uint8, device=dev)
-            st["bid"] = torch.arange(b, device=dev, dtype=torch.float32).repeat_interleave(n).unsqueeze(1)
+            # (crop index, x, y, z) per point for the level read-out: column 0 is constant, the coordinates arrive with the inputs
+            st["pb4"] = torch.zeros((b * n, 4), dtype=torch.float32, device=dev)
+            st["pb4"][:, 0] = torch.arange(b, device=dev, dtype=torch.float32).repeat_interleave(n)
             ent[s] = st
         # the graph's own GEMM scratch, one per branch, allocated before warm-up and capture (ops.lt_workspace_scope)
         ent["lt_ws"] = tuple(torch.empty(ops._LT_WORKSPACE_BYTES, dtype=torch.uint8, device=dev) for _ in range(2))
@@ -734,7 +738,7 @@ class Network(nn.Module):
                             st["run"].geometry()
                         elif stage == 1:
                             xs[s] = ops.voxelize_fp(st["feats"], st["v2p"], self.voxelization_mode)
-                            pb4s[s] = torch.cat([st["bid"], st["feats"][:, 4:7]], 1).contiguous()
+                            pb4s[s] = st["pb4"]
                         elif stage == 2:
                             st["run"].features(xs[s], *f[bb + "_ptrs"])
                         elif stage == 3:
