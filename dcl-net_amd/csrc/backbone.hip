@@ -23,7 +23,8 @@ int dcl_internal_sparse_conv_fwd(const float *feat, const DclNbrSrc &nbr, int ca
                                  const float *shift, int relu, float *out, float *scratch, int64_t scratch_floats,
                                  dclStream_t stream, int counters_ready = 0, const DclRowOrder *ord = nullptr);
 int dcl_internal_sparse_conv_fwd_sides(const DclConvSides &sides, int nsides, int cin, int cout, int kvol, int subm, int relu,
-                                       float *scratch, int64_t scratch_floats, dclStream_t stream, int counters_ready = 0);
+                                       float *scratch, int64_t scratch_floats, dclStream_t stream, int counters_ready = 0,
+                                       int *counters_state = nullptr);
 int dcl_internal_sparse_avgpool_fwd_sides(const DclConvSides &sides, int nsides, int c, int kvol, int32_t *rf,
                                           const int32_t *rf_in, dclStream_t stream);
 int dcl_internal_conv_split_cap(long long rows);
@@ -355,11 +356,12 @@ static int backbone_features(const SideArgs *sd, int nsides, int batch, int S, c
     for (int m = 0; m < kLevels; ++m)
       DCL_CHECK_ARG(a.counts_host[2 * m] <= L[i].conv[m].cap && a.counts_host[2 * m + 1] <= L[i].pool[m].cap);
   }
-  // split-K scratch (partial-tile slots + tile tickets) of the launches: side 0's; the tickets are zeroed once per pass,
+  // split-K scratch (partial-tile slots + tile tickets) of the launches: side 0's; the tickets are zeroed once per pass -- by
+  // the first launch that draws one (a pass of few-row launches, whose combine is a launch of its own, zeroes nothing) -- and
   // every split launch leaves them zero again
   float *scr = F[0].scratch_floats ? at<float>(sd[0].ws2, F[0].scratch) : nullptr;
   const int64_t scr_floats = (int64_t)F[0].scratch_floats;
-  if (scr) dcl_internal_zero_words(scr, kConvCounterWords, (hipStream_t)stream);
+  int tickets_zero = 0;
   int steps_left = dbg_steps();
   const bool explicit_nbr = dbg_explicit_nbr() && nsides == 1;
 #define DBG_STEP() do { if (--steps_left < 0) return 0; } while (0)
@@ -432,8 +434,8 @@ static int backbone_features(const SideArgs *sd, int nsides, int batch, int S, c
       }
       if (ns == 0) continue;
       DBG_STEP();
-      if (stage == 0) rc = dcl_internal_sparse_conv_fwd_sides(cs, ns, c0, c1, 27, 0, 1, scr, scr_floats, stream, 1);
-      else if (stage == 1) rc = dcl_internal_sparse_conv_fwd_sides(cs, ns, c1, c2, 27, 1, 1, scr, scr_floats, stream, 1);
+      if (stage == 0) rc = dcl_internal_sparse_conv_fwd_sides(cs, ns, c0, c1, 27, 0, 1, scr, scr_floats, stream, 0, &tickets_zero);
+      else if (stage == 1) rc = dcl_internal_sparse_conv_fwd_sides(cs, ns, c1, c2, 27, 1, 1, scr, scr_floats, stream, 0, &tickets_zero);
       else rc = dcl_internal_sparse_avgpool_fwd_sides(cs, ns, c2, 27, nullptr, nullptr, stream);
       if (rc) return rc;
     }

@@ -26,7 +26,8 @@ int dcl_internal_sparse_conv_fwd(const float *feat, const DclNbrSrc &nbr, int ca
 int dcl_internal_sparse_avgpool_fwd(const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev,
                                     int n_out_host, int c, int kvol, float *out, int32_t *rf, dclStream_t stream);
 int dcl_internal_sparse_conv_fwd_sides(const DclConvSides &sides, int nsides, int cin, int cout, int kvol, int subm, int relu,
-                                       float *scratch, int64_t scratch_floats, dclStream_t stream, int counters_ready = 0);
+                                       float *scratch, int64_t scratch_floats, dclStream_t stream, int counters_ready = 0,
+                                       int *counters_state = nullptr);
 int dcl_internal_sparse_avgpool_fwd_sides(const DclConvSides &sides, int nsides, int c, int kvol, int32_t *rf,
                                           const int32_t *rf_in, dclStream_t stream);
 
@@ -519,7 +520,7 @@ static DclConvPlan plan_conv_dma(const DclConvSides &sides, int nsides, int CIN,
 
 template <int CIN, int WR, int WCW, int NT>
 static void launch_conv_dma(const DclConvSides &sides, int nsides, int cout, int kvol, int subm, int relu, float *scratch,
-                            long long scratch_floats, int counters_ready, hipStream_t s) {
+                            long long scratch_floats, int counters_ready, int *counters_state, hipStream_t s) {
   constexpr int BM = 32 * WR, BN = 32 * NT * WCW, KC = 32;
   const size_t lds = (size_t)(2 * (BM * KC + KC * BN) + 27 * BM + 4 + BM) * sizeof(float);
   (void)hipFuncSetAttribute((const void *)k_sparse_conv_dma<CIN, WR, WCW, NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -540,7 +541,10 @@ static void launch_conv_dma(const DclConvSides &sides, int nsides, int cout, int
     partial = scratch + kConvCounterWords;
     if (P.counters) {
       counters = reinterpret_cast<int32_t *>(scratch);
-      if (!counters_ready) dcl_internal_zero_words(counters, kConvCounterWords, s);
+      // (counters_state: the caller's "the tickets are zero" flag of a pass -- the first launch that needs them zeroes them, a
+      // pass of few-row launches, whose combine is a launch of its own, never does)
+      if (!counters_ready && !(counters_state && *counters_state)) dcl_internal_zero_words(counters, kConvCounterWords, s);
+      if (counters_state) *counters_state = 1;
     }
   }
   DclConvSides sd = sides;
@@ -733,12 +737,13 @@ DCL_API int dcl_profile_conv_end(double *ms_total_host, int32_t *calls_host) {
 }
 
 static int conv_dispatch(const DclConvSides &sides, int nsides, int cin, int cout, int kvol, int subm, int relu, float *scratch,
-                         int64_t scratch_floats, int counters_ready, dclStream_t stream);
+                         int64_t scratch_floats, int counters_ready, int *counters_state, dclStream_t stream);
 
 // library-internal: one layer of up to two problems ("sides") in one launch; `src` may be an implicit rulebook (native
 // backbone runner).  Timed as ONE conv call by the measurement facility above.
 int dcl_internal_sparse_conv_fwd_sides(const DclConvSides &sides, int nsides, int cin, int cout, int kvol, int subm, int relu,
-                                       float *scratch, int64_t scratch_floats, dclStream_t stream, int counters_ready) {
+                                       float *scratch, int64_t scratch_floats, dclStream_t stream, int counters_ready,
+                                       int *counters_state) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   bool timed = false;
   {
@@ -750,7 +755,8 @@ int dcl_internal_sparse_conv_fwd_sides(const DclConvSides &sides, int nsides, in
     (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, (hipStream_t)stream);
   }
-  const int rc = conv_dispatch(sides, nsides, cin, cout, kvol, subm, relu, scratch, scratch_floats, counters_ready, stream);
+  const int rc = conv_dispatch(sides, nsides, cin, cout, kvol, subm, relu, scratch, scratch_floats, counters_ready, counters_state,
+                               stream);
   if (timed) {
     (void)hipEventRecord(e1, (hipStream_t)stream);
     std::lock_guard<std::mutex> lock(g_conv_prof.mu);
@@ -836,7 +842,7 @@ int dcl_internal_conv_plan(const DclConvSide &side, int cin, int cout, int kvol,
 }
 
 static int conv_dispatch(const DclConvSides &sides_in, int nsides_in, int cin, int cout, int kvol, int subm, int relu,
-                         float *scratch, int64_t scratch_floats, int counters_ready, dclStream_t stream) {
+                         float *scratch, int64_t scratch_floats, int counters_ready, int *counters_state, dclStream_t stream) {
   DCL_CHECK_ARG(nsides_in >= 1 && nsides_in <= 2 && cin > 0 && cout > 0 && kvol > 0 && kvol <= 27);
   // sides without rows drop out (an empty level of one backbone)
   DclConvSides sides{};
@@ -876,7 +882,7 @@ static int conv_dispatch(const DclConvSides &sides_in, int nsides_in, int cin, i
     return 0;
   }
   if (ch.family == DCL_CONV_DMA) {
-#define DMA_ARGS sides, nsides, cout, kvol, subm, relu, scratch, (long long)scratch_floats, counters_ready, s
+#define DMA_ARGS sides, nsides, cout, kvol, subm, relu, scratch, (long long)scratch_floats, counters_ready, counters_state, s
 #define DMA_CASE(WR_, WCW_, NT_)                                          \
     switch (cin) {                                                      \
       case 16: launch_conv_dma<16, WR_, WCW_, NT_>(DMA_ARGS); break;    \
