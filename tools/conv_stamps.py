@@ -45,6 +45,8 @@ n_wg = 16384
 buf = np.zeros((n_wg, 8), np.uint64)
 lib.dcl_debug_conv_stamps(buf.ctypes.data_as(ctypes.c_void_p), n_wg, 0)
 live = buf[buf[:, 0] > 0].astype(np.int64)
+if len(live) == 0:
+    sys.exit("layer L%d %s %d->%d: no stamps -- this launch ran a kernel family without them (filter-resident / stem)" % (level, which, cin, cout))
 t0 = live[:, 0].min()
 names = ["nbr table", "first fetch", "chunk loop", "publish", "ticket", "combine/exit"]
 print("layer L%d %s %d->%d rows %d: %.1f us, %d workgroups stamped" % (level, which, cin, cout, out.n, a.elapsed_time(e) * 1e3, len(live)))
