@@ -18,6 +18,19 @@
 #define DCL_HOOK_INT(name, dflt) static constexpr int name = dflt
 #endif
 
+// Launch census (diagnostic library only): every hipLaunchKernelGGL of the library notes the kernel's host stub before it
+// launches; dcl_debug_launch_census() lists demangled kernel names with their launch counts.  tests/test_kernel_census.py
+// uses it to prove that every kernel a committed profile names was launched by an oracle-comparing test.
+#ifdef DCL_DIAG
+void dcl_diag_note_launch(const void *host_stub);
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, ...)                    \
+  do {                                                         \
+    dcl_diag_note_launch((const void *)(kernelName));          \
+    hipLaunchKernelGGLInternal((kernelName), __VA_ARGS__);     \
+  } while (0)
+#endif
+
 void dcl_set_error(const char *fmt, ...);
 
 #define DCL_CHECK_ARG(cond)                                                          \

@@ -598,6 +598,12 @@ int dcl_debug_stage_stamps(unsigned long long *host, int n_items);
 /* Tuning hook for dcl_group_points' LDS-staged kernel: channel rows per workgroup, x-blocks, threads per workgroup,
  * store kind (2 = plain instead of nontemporal); 0 = built-in choice for each. */
 void dcl_debug_group_points_cfg(int cc, int xb, int threads, int nontemporal);
+/* Launch census: every kernel launch of the diagnostic library is counted by kernel (demangled name incl. template arguments).
+ * _census writes "name<TAB>launches<NEWLINE>" lines into buf (NUL-terminated, cut at cap) and returns the bytes the whole text
+ * needs; _reset empties the table.  tests/test_kernel_census.py: every kernel a committed profile names must have been
+ * launched by a test that compares with the oracle. */
+void dcl_debug_launch_census_reset(void);
+long long dcl_debug_launch_census(char *buf, long long cap);
 #endif /* DCL_DIAG */
 
 #ifdef __cplusplus

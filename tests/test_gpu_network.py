@@ -194,8 +194,14 @@ def test_bs40_config_forward(dcl, oracle, path):
     spread over the batch are checked against the CPU oracle graph run on exactly those crops (crops are independent);
     all 40 get the size-independent checks (valid rotations, confidences in (0,1), determinism, no NaN) and the metric
     table of the batch reduces to 40 frames"""
+    batch_of_reference_shape_crops_vs_oracle(dcl, oracle, 40, path)
+
+
+def batch_of_reference_shape_crops_vs_oracle(dcl, oracle, b, path):
+    """b crops of N = M = 1024: four of them against the oracle graph, all of them the size-independent checks (also run at
+    b = 32, the shape of profiles/*_ref_kernel_stats.csv, by tests/test_kernel_census.py)"""
     from oracle import graph as G
-    b, n = 40, 1024
+    n = 1024
     net, sd, cfg = _net(dcl, n, n, 1, graph_max_batch=8 if path == "default" else 0)
     assert (len(getattr(net, "_graphs", {})) == 0)
     data = dcl.synth.make_batch(b, n, n, first=100)
@@ -210,7 +216,7 @@ def test_bs40_config_forward(dcl, oracle, path):
     for k in ("rot_pred", "trans_pred", "conf"):
         assert torch.equal(p1[k], p2[k]), k
     assert len(net.__dict__.get("_graphs", {})) == (1 if path == "default" else 0)      # the path that was meant ran
-    for i in (0, 13, 27, 39):
+    for i in (0, 13, 27, b - 1):
         one = dcl.synth.make_batch(1, n, n, first=100 + i, voxelize_idx=lambda c, bs, mode: tuple(
             torch.from_numpy(a) for a in oracle.voxelize_idx(c.numpy(), bs, mode)))
         want = G.forward(sd, dict(cfg), one, mode="test")
@@ -227,19 +233,31 @@ def test_bs40_config_forward(dcl, oracle, path):
     assert int(table.sums[:, 0].sum()) == b
 
 
-def test_stress_shape_full_batch_properties(dcl):
-    """BASELINE configs[1] at its full size (b = 32, N = 12288, M = 2048; what bench.py times): valid rotations, finite
-    outputs, determinism, and batch invariance -- crops 3 and 30 recomputed alone (4-wave attention kernel, other conv
-    tilings) give the same pose"""
+def test_stress_shape_full_batch_properties(dcl, oracle):
+    """BASELINE configs[1] at its full size (b = 32, N = 12288, M = 2048; what bench.py times): crops 0 / 3 / 17 / 30 of the
+    batch against the CPU oracle graph run on each of them alone (the reference's arithmetic, oracle/graph.py), then the
+    size-independent checks on all 32 -- valid rotations, finite outputs, determinism -- and batch invariance of the HIP path
+    itself: crops 3 and 30 recomputed alone (4-wave attention kernel, other conv tilings) give the same pose"""
+    from oracle import graph as G
     n_inp, n_tmp, b = 12288, 2048, 32
     cfg = dcl.synth.default_cfg(n_inp, n_tmp)
     net = dcl.DCL_Net.Network(cfg, mode="test", graph_max_batch=0)
-    net.load_state_dict(dcl.synth.synth_state_dict(net, 1))
+    sd = dcl.synth.synth_state_dict(net, 1)
+    net.load_state_dict(sd)
     net = net.cuda().eval()
     data = dcl.synth.make_batch(b, n_inp, n_tmp)
     with torch.no_grad():
         full = net(data)
         again = net(data)
+    for i in (0, 3, 17, 30):
+        one = dcl.synth.make_batch(1, n_inp, n_tmp, first=i, voxelize_idx=lambda c, bs, mode: tuple(
+            torch.from_numpy(a) for a in oracle.voxelize_idx(c.numpy(), bs, mode)))
+        want = G.forward(sd, dict(cfg), one, mode="test")
+        assert float((full["rot_pred"][i].cpu() - want["rot_pred"][0]).abs().max()) <= R_TOL, i
+        assert float((full["trans_pred"][i].cpu() - want["trans_pred"][0]).abs().max()) <= T_TOL, i
+        assert float((full["conf"][i].cpu() - want["conf"][0]).abs().max()) <= 1e-4, i
+        wF = want["F_Xo_p"][0]
+        assert float((full["F_Xo_p"][i].cpu() - wF).abs().max()) <= 1e-4 * max(1.0, float(wF.abs().max())), i
     R = full["rot_pred"].double()
     assert float((R @ R.transpose(1, 2) - torch.eye(3, dtype=torch.float64, device="cuda")).abs().max()) <= 1e-5
     assert float((torch.linalg.det(R) - 1).abs().max()) <= 1e-5

@@ -525,6 +525,57 @@ def test_group_and_gather_bit_exact(dcl, oracle):
     assert np.array_equal(dcl.ops.gather_points(cuda(feats), cuda(gi)).cpu().numpy(), oracle.gather_points(feats, gi))
 
 
+def test_ball_query_and_group_points_at_the_benchmarked_shape(dcl, oracle):
+    """BASELINE's primitive shape, the one bench.py's `ball_query+group_points` roofline is quoted on: B = 32 clouds of the
+    synthetic crops, N = 12288, npoint = 2048 (FPS centres), r = 0.03, nsample = 64, C = 64.  ball_query is compared bit for
+    bit on every cloud; group_points -- whose LDS-staged kernel (k_group_points_lds, rows of 12288 floats) only runs from
+    npoint*nsample >= 4096 -- on clouds 0 / 13 / 31 of the full launch (the op is independent per cloud; 1 GiB of output is
+    not worth hauling to the host).  Reference semantics: libs/pointnet_lib/src/ball_query_gpu.cu:23-44,
+    group_points_gpu.cu:47-66."""
+    B, N, NP, NS, C, r = 32, 12288, 2048, 64, 64, 0.03
+    data = dcl.synth.make_batch(B, N, 64)
+    xyz = data["inp"]["feats"][:, 4:7].reshape(B, N, 3).contiguous()
+    fps = dcl.ops.furthest_point_sampling(xyz.cuda(), NP)
+    assert np.array_equal(fps[:2].cpu().numpy(), oracle.furthest_point_sample(xyz[:2].numpy(), NP))
+    new_xyz = torch.gather(xyz, 1, fps.cpu().long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    idx = dcl.ops.ball_query(r, NS, xyz.cuda(), new_xyz.cuda())
+    want_idx = oracle.ball_query(r, NS, xyz.numpy(), new_xyz.numpy())
+    assert np.array_equal(idx.cpu().numpy(), want_idx)
+    feats = torch.randn(B, C, N, generator=torch.Generator().manual_seed(5))
+    out = dcl.ops.group_points(feats.cuda(), idx)
+    assert tuple(out.shape) == (B, C, NP, NS)
+    for bi in (0, 13, 31):
+        want = oracle.group_points(feats[bi:bi + 1].numpy(), want_idx[bi:bi + 1])
+        assert np.array_equal(out[bi:bi + 1].cpu().numpy(), want), bi
+
+
+@pytest.mark.parametrize("n,c,npoint,ns", [
+    (12288, 5, 256, 16),       # 1 channel row per workgroup (rows of 6145..12288 floats), ragged channel count
+    (20000, 3, 128, 32),       # 1 row, longer than the 48 KiB target (80 KB of LDS)
+    (5000, 7, 64, 64),         # 2 rows per workgroup, last chunk holds one
+    (4000, 7, 512, 8),         # 3 rows, last chunk holds one
+    (3000, 10, 100, 44),       # 4 rows, last chunk holds two; npoint*nsample a multiple of 4 only
+    (700, 9, 1024, 4),         # 4 short rows
+])
+def test_group_points_lds_staged_rows_bit_exact(dcl, oracle, n, c, npoint, ns):
+    """every rows-per-workgroup choice of the LDS-staged grouping kernel (csrc/pointnet.hip, dcl_group_points_into: 1..4
+    channel rows by row length), with channel counts that leave a partial last chunk, and the fill-a-channel-block form
+    `out=` used by QueryAndGroup (the block's batch stride is the full tensor's)"""
+    rng = np.random.default_rng(n + c)
+    b = 2
+    assert npoint * ns >= 4096 and (npoint * ns) % 4 == 0 and n <= 36 * 1024
+    feats = rng.normal(size=(b, c, n)).astype(np.float32)
+    idx = rng.integers(0, n, (b, npoint, ns)).astype(np.int32)
+    idx[0, 0, :4] = [0, n - 1, 0, n - 1]
+    want = oracle.group_points(feats, idx)
+    assert np.array_equal(dcl.ops.group_points(cuda(feats), cuda(idx)).cpu().numpy(), want)
+    full = torch.full((b, c + 5, npoint, ns), -7.0, device="cuda")
+    dcl.ops.group_points(cuda(feats), cuda(idx), out=full[:, 3:3 + c])
+    got = full.cpu().numpy()
+    assert np.array_equal(got[:, 3:3 + c], want)
+    assert (got[:, :3] == -7.0).all() and (got[:, 3 + c:] == -7.0).all()          # nothing written outside the block
+
+
 def test_grouping_modules_match_the_composed_oracle(dcl, oracle):
     """QueryAndGroup / GroupAll / KNNAndGroup of the pointnet_lib mirror (forward composition of the primitives)"""
     import importlib
