@@ -596,8 +596,7 @@ def sparse_conv_roofline(dcl, net, data, dev, steps=3):
                         "stage, outside the timed conv calls: 2 launches per backbone, see profiles/)",
             "feature_stage": dict(feature_stage_times(dcl, net, data, dev),
                                   what="convs + pools of both backbones stand-alone: a launch per layer and side / one grouped "
-                                       "launch per layer / everything as ONE launch (Network(feature_stage=True); not the default: "
-                                       "inside the whole forward it ties with the two-stream schedule, DESIGN section 10)"),
+                                       "launch per layer"),
             "separate_launches": {"conv_ms_per_forward": round(timed["separate"][0], 4), "conv_calls_timed": timed["separate"][1],
                                   "frac": round(flop / (timed["separate"][0] * 1e-3) / 1e12 / PEAK_MFMA_F32, 4)
                                   if timed["separate"][0] > 0 else None,
@@ -606,9 +605,8 @@ def sparse_conv_roofline(dcl, net, data, dev, steps=3):
 
 
 def feature_stage_times(dcl, net, data, dev, reps=10):
-    """The sparse feature stage of BOTH backbones (8 convs + 4 pools each) on this batch, stand-alone, three ways: one launch
-    per layer and side, one grouped launch per layer (dcl_backbone_features_pair), and ONE launch for everything
-    (dcl_backbone_features_stage, csrc/feature_stage.hip).  HIP events around the calls; the stage's status word is checked."""
+    """The sparse feature stage of BOTH backbones (8 convs + 4 pools each) on this batch, stand-alone, two ways: one launch
+    per layer and side, and one grouped launch per layer (dcl_backbone_features_pair).  HIP events around the calls."""
     ops = dcl.ops
     f = net._fold()
     b = int(data["batch_offsets"].size(0)) - 1
@@ -621,7 +619,6 @@ def feature_stage_times(dcl, net, data, dev, reps=10):
             run.set_counts(run.counts_dev.cpu().tolist())
             runs.append(run)
             ptrs.append(f["backbone_%s_ptrs" % s])
-        status = ops.stage_status_buffer()
 
         def per_layer():
             for r, x, p in zip(runs, xs, ptrs):
@@ -630,11 +627,8 @@ def feature_stage_times(dcl, net, data, dev, reps=10):
         def pair():
             ops.backbone_features_pair(runs[0], xs[0], ptrs[0], runs[1], xs[1], ptrs[1])
 
-        def stage():
-            assert ops.backbone_features_stage(runs, xs, ptrs, status, slots=512)
-
         out = {}
-        for name, fn in (("per_layer_side_after_side", per_layer), ("per_layer_grouped", pair), ("one_launch_stage", stage)):
+        for name, fn in (("per_layer_side_after_side", per_layer), ("per_layer_grouped", pair)):
             for _ in range(2):
                 fn()
             torch.cuda.synchronize()
@@ -645,7 +639,6 @@ def feature_stage_times(dcl, net, data, dev, reps=10):
             e1.record()
             torch.cuda.synchronize()
             out[name + "_ms"] = round(e0.elapsed_time(e1) / reps, 4)
-        out["stage_status"] = int(status[0])
     return out
 
 

@@ -28,11 +28,6 @@ int dcl_internal_sparse_conv_fwd_sides(const DclConvSides &sides, int nsides, in
 int dcl_internal_sparse_avgpool_fwd_sides(const DclConvSides &sides, int nsides, int c, int kvol, int32_t *rf,
                                           const int32_t *rf_in, dclStream_t stream);
 int dcl_internal_conv_split_cap(long long rows);
-int dcl_internal_conv_plan(const DclConvSide &side, int cin, int cout, int kvol, bool have_scratch, long long scratch_floats,
-                           int slots, DclConvChoice *choice, DclConvPlan *plan);
-int dcl_internal_feature_stage_run(const DclStagePhase *phases_host, int nphases, void *table_dev, int32_t *sync_dev,
-                                   long long sync_words, int32_t *status_ext, int spin_limit, dclStream_t stream);
-size_t dcl_internal_feature_stage_table_bytes();
 int dcl_internal_order_rows(const DclOrderJobs &jobs, int njobs, dclStream_t stream);
 int dcl_internal_out_mask_k3(const uint32_t *in_mask, int batch, int S_in, int stride, uint32_t *out_mask,
                              dclStream_t stream);
@@ -449,279 +444,6 @@ static int backbone_features(const SideArgs *sd, int nsides, int batch, int S, c
   }
 #undef DBG_STEP
   return 0;
-}
-
-// ---- the feature stage as ONE launch (feature_stage.hip) -------------------------------------------------------------------
-// Workspace of a staged call: the phase table, the sync area (ticket, status, every tensor's group counters, the deferred
-// combines' arrival counters), per side and level the two intermediate tensors x1 (conv out) / x2 (subm out) -- NOT shared
-// between levels as in the per-layer path: a level's first items run while the previous level's last ones still read -- and
-// per conv phase its split-K scratch (tile tickets + two partial-tile slots per work item).
-namespace {
-struct StageSideLayout {
-  size_t x1[kLevels], x2[kLevels];
-  size_t scratch[kLevels][2];
-  long long scratch_floats[kLevels][2];
-  long long cnt_x1[kLevels], cnt_x2[kLevels], cnt_out[kLevels], arrive[kLevels][2], tickets[kLevels][2];   // offsets (ints) in the sync area
-};
-struct StageLayout {
-  size_t table, sync;
-  long long sync_words;
-  StageSideLayout side[2];
-  size_t total;
-};
-
-inline long long stage_groups(long long rows) { return (rows >> DCL_STAGE_SHIFT) + 2; }     // (ordered outputs use coarser groups: fewer)
-
-// counts[i] = row capacity of (conv set, pool set) per level of side i (live counts, or capacities in capacity mode)
-bool make_stage_layout(int nsides, const int32_t *const *counts, const int *chan /*9*/, int slots, StageLayout *L) {
-  size_t off = 0;
-  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
-  L->table = take(dcl_internal_feature_stage_table_bytes());
-  long long words = DCL_STAGE_SYNC_HEAD;
-  for (int i = 0; i < nsides; ++i) {
-    StageSideLayout &sl = L->side[i];
-    for (int m = 0; m < kLevels; ++m) {
-      const long long nc = counts[i][2 * m] > 0 ? counts[i][2 * m] : 0, np = counts[i][2 * m + 1] > 0 ? counts[i][2 * m + 1] : 0;
-      sl.cnt_x1[m] = words; words += stage_groups(nc);
-      sl.cnt_x2[m] = words; words += stage_groups(nc);
-      sl.cnt_out[m] = words; words += stage_groups(np);
-      for (int q = 0; q < 2; ++q) {                       // per tile of the layer (64-row tiles x 4 column tiles at most; a launch
-        const long long tiles = (nc + 63) / 64 * 4 + 1;    // with more than kConvCounterWords tiles is never split)
-        sl.arrive[m][q] = words;                          // deferred combine: arrived segments
-        words += tiles;
-        sl.tickets[m][q] = words;                         // in-launch combine: tickets (zeroed with the rest of the sync area
-        words += tiles < kConvCounterWords ? tiles : kConvCounterWords;   // every call -- a timed-out call may leave them dirty)
-      }
-    }
-  }
-  L->sync_words = words;
-  L->sync = take(sizeof(int32_t) * (size_t)words);
-  for (int i = 0; i < nsides; ++i) {
-    StageSideLayout &sl = L->side[i];
-    for (int m = 0; m < kLevels; ++m) {
-      const size_t nc = (size_t)(counts[i][2 * m] > 0 ? counts[i][2 * m] : 1);
-      sl.x1[m] = take(nc * chan[2 * m + 1] * sizeof(float));
-      sl.x2[m] = take(nc * chan[2 * m + 2] * sizeof(float));
-      for (int q = 0; q < 2; ++q) {
-        const size_t cout = (size_t)chan[2 * m + 1 + q];
-        sl.scratch_floats[m][q] = 0;
-        sl.scratch[m][q] = off;
-        if (cout % 32 != 0) continue;                     // (the stem: no split-K)
-        const size_t need = (size_t)2 * slots * 128 * (cout < 128 ? cout : 128);     // two partial-tile slots per work item
-        sl.scratch[m][q] = take(need * sizeof(float));
-        sl.scratch_floats[m][q] = (long long)need;
-      }
-    }
-  }
-  L->total = off;
-  return true;
-}
-}  // namespace
-
-// bytes of the stage workspace for `nsides` backbones (counts_host[i]: the 8 set sizes of side i, or dcl_backbone_caps' capacities)
-DCL_API int dcl_backbone_stage_ws_bytes(int nsides, const int32_t *const *counts_host, const int32_t *channels_host, int slots,
-                                        int64_t *bytes_host) {
-  StageLayout L;
-  DCL_CHECK_ARG(nsides >= 1 && nsides <= 2 && counts_host && counts_host[0] && (nsides == 1 || counts_host[1]) && channels_host &&
-                bytes_host && (slots & 0xffff) >= 1 && (slots & 0xffff) <= 512 &&
-                make_stage_layout(nsides, counts_host, channels_host, slots & 0xffff, &L));
-  *bytes_host = (int64_t)L.total;
-  return 0;
-}
-
-// Builds the phases of the staged feature stage and enqueues it.  Returns DCL_ESTAGE_UNSUPPORTED (no launch made) when a
-// layer has no staged form (shapes outside DCL-Net's backbone): the caller then takes the per-layer path.
-static int backbone_features_stage(const SideArgs *sd, int nsides, int batch, int S, const int32_t *channels_host, void *wst,
-                                   int64_t wst_bytes, int slots_flags, int spin_limit, int32_t *status_ext, dclStream_t stream) {
-  const int slots = slots_flags & 0xffff, flags = slots_flags >> 16;      // flags bit 0: spare waves of four-wave tiles issue the DMAs
-  DCL_CHECK_ARG(sd && nsides >= 1 && nsides <= 2 && channels_host && wst && slots >= 1 && slots <= 512 && spin_limit >= 1);
-  GeoLayout L[2];
-  StageLayout T;
-  const int32_t *counts[2] = {sd[0].counts_host, nsides > 1 ? sd[1].counts_host : nullptr};
-  for (int i = 0; i < nsides; ++i) {
-    const SideArgs &a = sd[i];
-    DCL_CHECK_ARG(a.ws && a.counts_host && a.weights && a.scales && a.shifts && a.level_out);
-    DCL_CHECK_ARG(make_geo_layout(batch, S, a.V0, &L[i]));
-    DCL_CHECK_ARG((a.counts_dev != nullptr) == (sd[0].counts_dev != nullptr));
-    for (int m = 0; m < kLevels; ++m)
-      DCL_CHECK_ARG(a.counts_host[2 * m] <= L[i].conv[m].cap && a.counts_host[2 * m + 1] <= L[i].pool[m].cap);
-  }
-  DCL_CHECK_ARG(make_stage_layout(nsides, counts, channels_host, slots, &T) && wst_bytes >= (int64_t)T.total);
-  DclStagePhase ph[DCL_STAGE_MAX_PHASES];
-  int nph = 0;
-  int32_t *sync = at<int32_t>(wst, T.sync);
-  struct Tensor { long long cnt; int shift, ncol; const int32_t *n_dev; int n_host; };
-  Tensor cur[2];                                           // what the next layer of a side reads
-  const float *x[2];
-  const uint32_t *in_mask[2];
-  const int32_t *in_wp[2], *in_perm[2];
-  for (int i = 0; i < nsides; ++i) {
-    x[i] = sd[i].vox_feats;
-    in_mask[i] = at<uint32_t>(sd[i].ws, L[i].mask0);
-    in_wp[i] = at<int32_t>(sd[i].ws, L[i].wprefix0);
-    in_perm[i] = at<int32_t>(sd[i].ws, L[i].perm0);
-    cur[i] = Tensor{-1, 0, 1, nullptr, 0};                 // voxel features: ready before the launch
-  }
-  int s = S;
-  auto clampi = [](long long v, long long lo, long long hi) { return (int)(v < lo ? lo : (v > hi ? hi : v)); };
-  for (int m = 0; m < kLevels; ++m) {
-    const int c0 = channels_host[2 * m], c1 = channels_host[2 * m + 1], c2 = channels_host[2 * m + 2];
-    for (int stage = 0; stage < 3; ++stage) {
-      for (int i = 0; i < nsides; ++i) {
-        const SideArgs &a = sd[i];
-        const SetLayout &c = L[i].conv[m], &p = L[i].pool[m];
-        const StageSideLayout &sl = T.side[i];
-        const int nc = a.counts_host[2 * m], np = a.counts_host[2 * m + 1];
-        const int32_t *nc_dev = a.counts_dev ? a.counts_dev + 2 * m : nullptr;
-        const int32_t *np_dev = a.counts_dev ? a.counts_dev + 2 * m + 1 : nullptr;
-        float *x1 = at<float>(wst, sl.x1[m]), *x2 = at<float>(wst, sl.x2[m]);
-        if (stage < 2 ? nc <= 0 : np <= 0) continue;       // an empty level (exact mode): nothing to run, nothing waits for it
-        DCL_CHECK_ARG(nph + 2 <= DCL_STAGE_MAX_PHASES);
-        DclStagePhase P{};
-        DclConvSide &Sd = P.side;
-        const int rows_cap = stage < 2 ? nc : np;
-        const int32_t *rows_dev = stage < 2 ? nc_dev : np_dev;
-        const int expect = rows_dev ? expect_rows(batch, m, rows_cap) : rows_cap;          // (pool sets: a quarter or so of it)
-        const OrderLayout &o = L[i].ord[m][stage == 1 ? 1 : 0];
-        long long out_cnt;
-        if (stage == 0) {
-          Sd.src = DclNbrSrc{nullptr, at<int32_t>(a.ws, c.indices), in_mask[i], in_wp[i], in_perm[i], s, 1, 1};
-          Sd.feat = x[i]; Sd.out = x1; Sd.W = a.weights[2 * m]; Sd.scale = a.scales[2 * m]; Sd.shift = a.shifts[2 * m];
-          out_cnt = sl.cnt_x1[m];
-        } else if (stage == 1) {
-          Sd.src = DclNbrSrc{nullptr, at<int32_t>(a.ws, c.indices), at<uint32_t>(a.ws, c.mask), at<int32_t>(a.ws, c.wprefix), nullptr, s, 1, 1};
-          Sd.feat = x1; Sd.out = x2; Sd.W = a.weights[2 * m + 1]; Sd.scale = a.scales[2 * m + 1]; Sd.shift = a.shifts[2 * m + 1];
-          out_cnt = sl.cnt_x2[m];
-        } else {
-          Sd.src = DclNbrSrc{nullptr, at<int32_t>(a.ws, p.indices), at<uint32_t>(a.ws, c.mask), at<int32_t>(a.ws, c.wprefix), nullptr, s, 2, 1};
-          Sd.feat = x2; Sd.out = a.level_out[m];
-          out_cnt = sl.cnt_out[m];
-        }
-        Sd.cap = rows_cap; Sd.n_dev = rows_dev; Sd.n_host = rows_dev ? (stage < 2 ? expect : 0) : rows_cap;
-        Sd.ord = (stage < 2 && o.on) ? DclRowOrder{at<int32_t>(a.ws, o.order), at<int32_t>(a.ws, o.bal), at<uint32_t>(a.ws, o.smask)}
-                                     : DclRowOrder{nullptr, nullptr, nullptr};
-        P.cin = stage == 0 ? c0 : (stage == 1 ? c1 : c2);
-        P.cout = stage == 0 ? c1 : c2;
-        P.subm = stage == 1 ? 1 : 0;
-        P.relu = 1;
-        P.dep_off = (int32_t)cur[i].cnt; P.dep_shift = cur[i].shift; P.dep_ncol = cur[i].ncol;
-        P.dep_n_dev = cur[i].n_dev; P.dep_n_host = cur[i].n_host;
-        P.out_off = (int32_t)out_cnt; P.out_shift = DCL_STAGE_SHIFT; P.arrive_off = -1;
-        P.xcd_remap = flags << 1;                          // bit 1: spare waves issue the DMAs; bits 2.. : timing experiments (diagnostic library)
-        int out_ncol = 1;
-        if (stage == 2) {
-          const int c4 = c2 / 4;
-          if (c2 % 4 != 0 || c4 < 8 || 512 % c4 != 0) return DCL_ESTAGE_UNSUPPORTED;
-          const int rpb = 512 / c4;
-          P.kind = DCL_PH_POOL;
-          // one block step (rpb output rows) per item while that makes at most `slots` items: a step is a chain of dependent
-          // loads (look-ups, then rows) which only other workgroups hide (measured, feature stage of both sides: one crop 343 ->
-          // 308 us, six crops 615 -> 518; with 2 x slots items at 32 crops 1466 -> 1528: every item has its fixed part)
-          P.items = clampi(((long long)(rows_dev ? expect / 3 : rows_cap) + rpb - 1) / rpb, 1, slots);
-          ph[nph++] = P;
-        } else {
-          DclConvChoice ch;
-          DclConvPlan pl;
-          const int q = stage;                             // scratch of (level, conv | subm)
-          float *scr = sl.scratch_floats[m][q] ? at<float>(wst, sl.scratch[m][q]) : nullptr;
-          // (the planner's scratch convention: tile tickets in front of the slots -- here the tickets live in the sync area)
-          int rc = dcl_internal_conv_plan(Sd, P.cin, P.cout, 27, scr != nullptr, sl.scratch_floats[m][q] + kConvCounterWords, slots,
-                                          &ch, &pl);
-          if (rc) return rc;
-          if (ch.family == DCL_CONV_STEM) {
-            P.kind = DCL_PH_STEM;
-            Sd.ord = DclRowOrder{nullptr, nullptr, nullptr};
-            P.items = clampi(((long long)expect + 127) / 128, 1, slots);              // one 128-row step per item while that fills the slots
-            ph[nph++] = P;
-          } else if (ch.family == DCL_CONV_WLDS && P.cin == 16 && P.cout == 32) {
-            P.kind = DCL_PH_WLDS16;
-            Sd.ord = DclRowOrder{nullptr, nullptr, nullptr};
-            P.items = clampi(((long long)expect + 255) / 256, 1, slots);          // one round of eight 32-row wave tiles per item, or more
-            ph[nph++] = P;
-          } else if (ch.family == DCL_CONV_DMA) {
-            const int BM = 32 * ch.WR, BN = 32 * ch.NT * ch.WCW;
-            P.kind = DCL_PH_DMA;
-            P.WR = ch.WR; P.WCW = ch.WCW; P.NT = ch.NT;
-            if (!pl.keep_order) Sd.ord = DclRowOrder{nullptr, nullptr, nullptr};
-            P.ord = Sd.ord.order != nullptr ? 1 : 0;
-            P.stream_k = pl.stream_k; P.aligned_ns = pl.aligned_ns; P.use_bal = pl.use_bal;
-            P.items = pl.G;
-            // capacity mode: the planner sizes a stream-K phase by the row CAPACITY; the items beyond the live work would only
-            // draw a ticket and leave (hundreds of empty workgroups per phase in front of the next phase's real ones), so the
-            // phase gets as many items as the EXPECTED rows need (x 1.5).  Any count is correct: U = max(ceil(live units / items),
-            // stream_k) is formed from the live rows in the kernel, more rows than expected only make the items longer.
-            if (rows_dev && pl.stream_k && !pl.aligned_ns) {
-              const long long ncol = P.cout / BN;
-              const long long units = (((long long)expect + BM - 1) / BM) * ncol * pl.nchunks;
-              const long long want = (units * 3 / 2 + pl.stream_k - 1) / pl.stream_k;
-              P.items = clampi(want, 1, pl.G);
-            }
-            P.nchunks = pl.nchunks; P.conv_items = P.items;
-            P.partial = scr;
-            P.tile_counters = pl.counters ? sync + sl.tickets[m][q] : nullptr;
-            if (pl.counters) DCL_CHECK_ARG((long long)pl.tiles <= ((long long)nc + 63) / 64 * 4 + 1);
-            out_ncol = P.cout / BN;
-            if (P.ord) P.out_shift = DCL_STAGE_SHIFT_ORD;
-            if (pl.deferred) {
-              DCL_CHECK_ARG((long long)pl.tiles <= ((long long)nc + 63) / 64 * 4 + 1);
-              P.arrive_off = (int32_t)sl.arrive[m][q];
-            }
-            ph[nph++] = P;
-            if (pl.deferred) {                             // the combine of the split tiles: a phase of its own
-              DclStagePhase R = P;
-              R.kind = DCL_PH_REDUCE;
-              R.items = clampi(rows_dev ? (((long long)expect + BM - 1) / BM) * (P.cout / BN) * 3 / 2 + 1 : (long long)pl.tiles, 1,
-                               2 * slots);                 // (a combine item walks tiles item, item + items, ...: any count is correct)
-              R.dep_off = -1;                              // (it waits for its tile's arrivals, not for rows)
-              ph[nph++] = R;
-            }
-          } else {
-            return DCL_ESTAGE_UNSUPPORTED;
-          }
-        }
-        cur[i] = Tensor{out_cnt, ph[nph - 1].out_shift, out_ncol, rows_dev, rows_dev ? 0 : rows_cap};
-      }
-    }
-    for (int i = 0; i < nsides; ++i) {
-      x[i] = sd[i].level_out[m];
-      in_mask[i] = at<uint32_t>(sd[i].ws, L[i].pool[m].mask);
-      in_wp[i] = at<int32_t>(sd[i].ws, L[i].pool[m].wprefix);
-      in_perm[i] = nullptr;
-    }
-    s = L[0].pool[m].S;
-  }
-  if (nph == 0) return 0;
-  int first = 0;
-  for (int k = 0; k < nph; ++k) { ph[k].first_item = first; first += ph[k].items; }
-  return dcl_internal_feature_stage_run(ph, nph, at<void>(wst, T.table), sync, T.sync_words, status_ext, spin_limit, stream);
-}
-
-// One or both backbones' feature stage as one launch.  Arrays of `nsides` as in dcl_backbone_features_pair; counts_dev != NULL =
-// capacity mode.  status_dev: device-visible int32 (e.g. pinned host memory) that a timed-out wait sets to 1 -- the call's
-// results are then invalid and the caller repeats it with dcl_backbone_features_pair / dcl_backbone_features; never cleared
-// here.  Returns DCL_ESTAGE_UNSUPPORTED, having launched nothing, when a layer has no staged form.
-DCL_API int dcl_backbone_features_stage(int nsides, int batch, int S, const int32_t *channels_host, const int32_t *V0, void *const *ws,
-                                        const int32_t *const *counts_host, const int32_t *const *counts_dev,
-                                        const float *const *vox_feats, const float *const *const *weights,
-                                        const float *const *const *scales, const float *const *const *shifts,
-                                        float *const *const *level_out, void *ws_stage, int64_t ws_stage_bytes, int slots,
-                                        int spin_limit, int32_t *status_dev, dclStream_t stream) {
-  DCL_CHECK_ARG(nsides >= 1 && nsides <= 2 && V0 && ws && vox_feats && weights && scales && shifts && level_out &&
-                (counts_dev || counts_host));
-  int32_t caps[2][8];
-  SideArgs a[2];
-  for (int i = 0; i < nsides; ++i) {
-    const int32_t *ch = counts_host ? counts_host[i] : nullptr;
-    const int32_t *cd = counts_dev ? counts_dev[i] : nullptr;
-    if (cd) {
-      const int rc = dcl_backbone_caps(batch, S, V0[i], caps[i]);
-      if (rc) return rc;
-      ch = caps[i];
-    }
-    DCL_CHECK_ARG(ch);
-    a[i] = SideArgs{V0[i], ws[i], ch, cd, vox_feats[i], weights[i], scales[i], shifts[i], nullptr, 0, level_out[i]};
-  }
-  return backbone_features_stage(a, nsides, batch, S, channels_host, ws_stage, ws_stage_bytes, slots, spin_limit, status_dev, stream);
 }
 
 DCL_API int dcl_backbone_features(const int32_t *occ, int V0, int batch, int S, void *ws, const int32_t *counts_host,

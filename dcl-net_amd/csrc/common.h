@@ -20,7 +20,7 @@
 
 // Launch census (diagnostic library only): every hipLaunchKernelGGL of the library notes the kernel's host stub before it
 // launches; dcl_debug_launch_census() lists demangled kernel names with their launch counts.  tests/test_kernel_census.py
-// uses it to prove that every kernel a committed profile names was launched by an oracle-comparing test.
+// uses it to prove that every kernel a committed profile names was launched by a parity test.
 #ifdef DCL_DIAG
 void dcl_diag_note_launch(const void *host_stub);
 #undef hipLaunchKernelGGL
@@ -159,26 +159,6 @@ enum { DCL_CONV_GENERIC = 0, DCL_CONV_STEM = 1, DCL_CONV_WLDS = 2, DCL_CONV_DMA 
 struct DclConvChoice {
   int family, WR, WCW, NT;
 };
-// ---- the persistent feature stage (feature_stage.hip): ONE launch runs every layer of the backbones; its work items are
-// dequeued in phase order.  A phase = one layer of ONE backbone (or the deferred combine of a few-row conv layer).
-enum { DCL_PH_STEM = 0, DCL_PH_WLDS16 = 1, DCL_PH_DMA = 2, DCL_PH_REDUCE = 3, DCL_PH_POOL = 4 };
-struct DclStagePhase {
-  DclConvSide side;               // the layer's problem (ord cleared when the plan drops the order)
-  float *partial;                 // split-K partial-tile slots of the phase (conv / reduce)
-  int32_t *tile_counters;         // tile tickets of the in-launch combine (nullptr: whole tiles or deferred)
-  const int32_t *dep_n_dev;       // live rows of the INPUT tensor (device) or nullptr -> dep_n_host
-  int32_t kind, first_item, items;
-  int32_t cin, cout, subm, relu;
-  int32_t WR, WCW, NT, ord;       // DMA / REDUCE: tile shape, row order present
-  int32_t stream_k, aligned_ns, use_bal, xcd_remap;
-  int32_t nchunks, conv_items;    // REDUCE: chunks per tile and work items of the conv phase it combines
-  int32_t dep_off, dep_shift, dep_ncol, dep_n_host;     // input tensor's group counters: offset (ints) in the sync area, -1 = none
-  int32_t out_off, out_shift, arrive_off, pad_;         // output tensor's group counters; deferred combine: per-tile arrivals (-1 none)
-};
-constexpr int DCL_STAGE_MAX_PHASES = 48;
-constexpr int DCL_STAGE_SYNC_HEAD = 16;          // ints in front of the counters: [0] ticket, [1] status
-constexpr int DCL_STAGE_SHIFT = 10;              // rows per group of a natural-order tensor: 1 << 10
-constexpr int DCL_STAGE_SHIFT_ORD = 13;          // ... of an ordered layer's output: one 8192-row window of the order
 #if defined(__HIPCC__)
 __device__ __forceinline__ int dcl_nbr_at(const DclNbrSrc &s, int cap, int k, int row) {
   if (s.nbr) return s.nbr[(size_t)k * cap + row];

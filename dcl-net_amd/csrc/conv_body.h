@@ -1,185 +1,11 @@
-// conv_body.h -- device bodies of the sparse feature stage (conv / combine / avg-pool items), shared by the per-layer kernels of
-// sparse_conv.hip (one launch per layer: item = blockIdx.x) and the persistent feature-stage kernel of feature_stage.hip (all
-// layers of both backbones in ONE launch: items are dequeued in layer order and meet their producers through completion
-// counters).  Reference: indiceConv<float> (libs/spconv/include/spconv/spconv_ops.h:253-349), indiceAvgPool
-// (pool_ops.h:141-208), Backbone_SPCONV.forward (models/Modules.py:153-159).
+// conv_body.h -- device bodies of the sparse feature stage (conv / combine / avg-pool work items) behind the per-layer kernels
+// of sparse_conv.hip (one launch per layer: item = blockIdx.x).  Reference: indiceConv<float>
+// (libs/spconv/include/spconv/spconv_ops.h:253-349), indiceAvgPool (pool_ops.h:141-208), Backbone_SPCONV.forward
+// (models/Modules.py:153-159).
 #pragma once
 #include "common.h"
 
 namespace {
-
-// ---- hand-off between the items of the persistent feature stage ----------------------------------------------------------
-// A layer's output rows are counted per ROW GROUP (1 << shift consecutive rows of the output set; a window of the row order
-// for ordered layers): an item that has finished writing rows adds (live rows) per column part to the group's counter after
-// an agent-scope release; a consumer item derives the input rows it can touch from the geometry (the x-slabs of its first
-// and last output row, +-1 slab), polls the groups' counters with relaxed device-scope loads until they hold
-// (rows in group) x (column parts of the producer), and acquires.  Every spin is bounded: on a time-out the item sets the
-// stage's status word and goes on WITHOUT waiting (the call's results are then invalid; the host sees the status and falls
-// back to per-layer launches) -- the kernel never hangs.  Items are dequeued in layer order from one ticket counter, and an
-// item only ever waits for rows of earlier layers, so the oldest unfinished item can always run: no co-residency is needed.
-// The phase's record sits in the launch's table and is read through the CONSTANT address space -- scalar loads at the point
-// of use, like kernel arguments: a body that kept the whole record in registers across its chunk loop would spill (the
-// eight-wave tiles run at the 128-VGPR / 106-SGPR limit of two workgroups per CU).
-#define DCL_CONST_AS __attribute__((address_space(4)))
-struct DclStageIo {
-  const DCL_CONST_AS DclStagePhase *P;   // the phase: its problem (side), the counters' offsets in the sync area
-  int32_t *sync;                         // [0] ticket, [1] status (!= 0: a wait timed out somewhere in this launch), counters
-  int spin_limit;                        // polls before an item gives up
-};
-// (the pointer is made opaque at every use so that the loads stay where they are written, not hoisted over the chunk loop)
-__device__ __forceinline__ const DCL_CONST_AS DclStagePhase *stage_phase(const DclStageIo &io) {
-  const DCL_CONST_AS DclStagePhase *p = io.P;
-  asm volatile("" : "+s"(p));
-  return p;
-}
-__device__ __forceinline__ DclConvSide stage_side(const DclStageIo &io) {
-  const DCL_CONST_AS DclStagePhase *P = stage_phase(io);
-  DclConvSide s;
-  s.feat = P->side.feat;
-  s.src.nbr = nullptr;
-  s.src.out_indices = P->side.src.out_indices;
-  s.src.in_mask = P->side.src.in_mask;
-  s.src.in_wprefix = P->side.src.in_wprefix;
-  s.src.in_perm = P->side.src.in_perm;
-  s.src.S_in = P->side.src.S_in;
-  s.src.stride = P->side.src.stride;
-  s.src.pad = P->side.src.pad;
-  s.n_dev = P->side.n_dev;
-  s.W = P->side.W;
-  s.scale = P->side.scale;
-  s.shift = P->side.shift;
-  s.out = P->side.out;
-  s.ord.order = P->side.ord.order;
-  s.ord.bal = P->side.ord.bal;
-  s.ord.smask = P->side.ord.smask;
-  s.cap = P->side.cap;
-  s.n_host = P->side.n_host;
-  return s;
-}
-__device__ __forceinline__ int stage_out_shift(const DclStageIo &io) { return stage_phase(io)->out_shift; }
-
-// threadIdx.x behind an opaque copy: inside the persistent kernel's dequeue loop everything derived from the thread index is
-// loop-invariant, and the compiler would hoist it out of the loop and keep it in registers across the whole body
-__device__ __forceinline__ int dcl_opaque_tid() {
-  int t = (int)threadIdx.x;
-  asm volatile("" : "+v"(t));
-  return t;
-}
-// pause between two polls of a counter: short at first (a hand-off that is about to happen costs its latency), longer once the
-// wait is clearly a long one (hundreds of pollers on one word slow the producers down: MI355X_MICROARCH.md, polling-cost)
-__device__ __forceinline__ void stage_backoff(int spins) {
-  if (spins < 4) __builtin_amdgcn_s_sleep(2);
-  else if (spins < 16) __builtin_amdgcn_s_sleep(8);
-  else __builtin_amdgcn_s_sleep(32);
-}
-__device__ __forceinline__ int stage_load_relaxed(const int32_t *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Input rows that output rows r_lo..r_hi (ascending linear index) of a k3 / pad 1 layer can touch: everything between the
-// first voxel of x-slab (b_lo, x_lo*stride - 1) and the last voxel of slab (b_hi, x_hi*stride + 1) of the input set, by rank.
-__device__ __forceinline__ void stage_input_rows(const DclNbrSrc &s, int r_lo, int r_hi, int *vmin, int *vmax) {
-  // (wave-uniform values, made scalar explicitly: the callers run at their register limit)
-  const int2 a2 = reinterpret_cast<const int2 *>(s.out_indices)[2 * r_lo];   // (b, x) of the first / last row
-  const int2 b2 = reinterpret_cast<const int2 *>(s.out_indices)[2 * r_hi];
-  const int ab = __builtin_amdgcn_readfirstlane(a2.x), ax = __builtin_amdgcn_readfirstlane(a2.y);
-  const int bb = __builtin_amdgcn_readfirstlane(b2.x), bx = __builtin_amdgcn_readfirstlane(b2.y);
-  int xa = ax * s.stride - s.pad, xb = bx * s.stride - s.pad + 2;
-  xa = xa < 0 ? 0 : xa;
-  xb = xb > s.S_in - 1 ? s.S_in - 1 : xb;
-  const int wa = ((ab * s.S_in + xa) * s.S_in * s.S_in) >> 5;
-  const int wb = ((bb * s.S_in + xb + 1) * s.S_in * s.S_in) >> 5;        // first word behind the last slab
-  *vmin = __builtin_amdgcn_readfirstlane(s.in_wprefix[wa]);
-  *vmax = __builtin_amdgcn_readfirstlane(s.in_wprefix[wb]) - 1;
-}
-
-// Wait until input rows vmin..vmax are complete.  Called by ALL threads of the workgroup with the same arguments (one barrier
-// inside); wave 0 polls.  Returns with the rows visible to every wave of the workgroup (the polling wave acquires at agent
-// scope and drains the invalidate before the barrier: cdna_hip_programming.md Guideline 16).
-// a wait ran out of its budget: the launch's status word (every other waiter gives up too) and the caller's (sync[2..3] hold
-// the address of a device-visible int32, or 0)
-__device__ __forceinline__ void stage_report_timeout(const DclStageIo &io) {
-  __hip_atomic_store(io.sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned long long ext = ((unsigned long long)(unsigned)io.sync[3] << 32) | (unsigned)io.sync[2];
-  if (ext) __hip_atomic_store(reinterpret_cast<int32_t *>(ext), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ bool stage_has_dep(const DclStageIo &io) { return stage_phase(io)->dep_off >= 0; }
-// The polling part alone, for ONE wave (all 64 lanes): the caller orders the other waves' loads behind it with a workgroup
-// barrier -- so the wave can poll and acquire while the others do work that needs the geometry only.
-__device__ __forceinline__ void stage_wait_rows_wave(const DclStageIo &io, int vmin, int vmax) {
-  const DCL_CONST_AS DclStagePhase *P = stage_phase(io);
-  if (P->dep_off < 0 || vmax < vmin) return;
-  {
-    const int32_t *dep_cnt = io.sync + P->dep_off, *status = io.sync + 1;
-    const int32_t *dep_n_dev = P->dep_n_dev;
-    const int n = dep_n_dev ? *dep_n_dev : P->dep_n_host;
-    const int dep_ncol = P->dep_ncol;
-    const int sh = P->dep_shift, g_lo = vmin >> sh, g_hi = vmax >> sh;
-    int spins = 0;
-    bool gave_up = false;
-    for (int g0 = g_lo; g0 <= g_hi && !gave_up; g0 += 64) {
-      const int g = g0 + (int)(threadIdx.x & 63);
-      int want = n - (g << sh);
-      want = want < 0 ? 0 : (want > (1 << sh) ? (1 << sh) : want);
-      want *= dep_ncol;
-      const bool mine = g <= g_hi;
-      for (;;) {
-        const int have = mine ? stage_load_relaxed(dep_cnt + g) : 0;
-        if (__all(!mine || have >= want)) break;
-        if (++spins > io.spin_limit || stage_load_relaxed(status) != 0) { gave_up = true; break; }
-        stage_backoff(spins);
-      }
-    }
-    if (gave_up && (threadIdx.x & 63) == 0) stage_report_timeout(io);
-#ifdef DCL_DIAG   // timing experiment of the diagnostic library only (flags bit 3): what the acquire costs
-    if (!(P->xcd_remap & 8))
-#endif
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-}
-__device__ __forceinline__ void stage_wait_rows(const DclStageIo &io, int vmin, int vmax) {
-  if (stage_phase(io)->dep_off < 0 || vmax < vmin) return;
-  if (threadIdx.x < 64) stage_wait_rows_wave(io, vmin, vmax);
-  __syncthreads();
-}
-
-// Completed output rows of an item, collected per row group in LDS and published once at the end of the item (one release
-// fence per item, not per tile).  s_sig: 1 + 2 * kStageSigMax ints of LDS ([0] = entries, then (group, rows) pairs).
-constexpr int kStageSigMax = 12;
-// called by ONE thread (thread 0), after the workgroup barrier that follows the rows' stores
-__device__ __forceinline__ void stage_note_rows(int32_t *s_sig, int group, int rows) {
-  const int k = s_sig[0];
-  for (int i = 0; i < k; ++i)
-    if (s_sig[1 + 2 * i] == group) { s_sig[2 + 2 * i] += rows; return; }
-  s_sig[1 + 2 * k] = group;
-  s_sig[2 + 2 * k] = rows;
-  s_sig[0] = k + 1;
-}
-// ALL threads of the workgroup: every wave drains its stores, barrier, thread 0 releases and adds the rows to their groups.
-__device__ __forceinline__ void stage_publish(const DclStageIo &io, int32_t *s_sig) {
-#ifdef STAGE_NO_NOTE
-  return;
-#endif
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const int k = s_sig[0];
-    if (k > 0) {
-#ifdef DCL_DIAG   // timing experiment of the diagnostic library only (flags bit 2: results may be stale): what the release costs
-      if (!(stage_phase(io)->xcd_remap & 4))
-#endif
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      int32_t *out_cnt = io.sync + stage_phase(io)->out_off;
-      for (int i = 0; i < k; ++i)
-        __hip_atomic_fetch_add(out_cnt + s_sig[1 + 2 * i], s_sig[2 + 2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_sig[0] = 0;
-    }
-  }
-  __syncthreads();
-}
-__device__ __forceinline__ bool stage_sig_full(const int32_t *s_sig) { return s_sig[0] >= kStageSigMax - 1; }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -196,49 +22,39 @@ __device__ __forceinline__ int offset_at(int step, int kvol, int subm) {
 // interleaved chains (lane g of the row's quad: offsets g, g + 4, ... in visiting order) added pairwise at the end,
 // (l0 + l1) + (l2 + l3) -- not the generic kernel's / the reference's one offset-sequential chain; the parity tests hold it
 // to 2e-5 against the CPU restatement, no test expects its bits.
-// NTB = threads of the workgroup (NTB / 4 output rows per step).  Per-layer launch: item = blockIdx.x of nitems = gridDim.x,
-// row blocks dealt round-robin.  STAGED (one side per phase): an item owns a contiguous run of row blocks and reports the rows
-// it has written to the output tensor's group counters.
-template <int CIN, int COUT, int NTB, bool STAGED>
+// NTB = threads of the workgroup (NTB / 4 output rows per step); item = blockIdx.x of nitems = gridDim.x, row blocks dealt
+// round-robin.
+template <int CIN, int COUT, int NTB>
 __device__ __forceinline__ void conv_stem_body(const DclConvSides &sides, int nsides, int kvol, int subm, int relu, float *Ws,
-                                               int item, int nitems, const DclStageIo *io, int32_t *s_sig) {
-  const int tix = STAGED ? dcl_opaque_tid() : (int)threadIdx.x;
+                                               int item, int nitems) {
+  const int tix = (int)threadIdx.x;
   // FOUR lanes per output row: lane g of a row's quad walks the kernel offsets s = g, g + 4, ... (each offset: neighbour
   // look-up, CIN loads, a CIN x COUT fmaf block -> one partial row added to the lane's sum in ascending s), then the four
   // lane sums are added as (l0 + l1) + (l2 + l3) by two butterfly rounds.  One thread per row made every row a serial chain
   // of 27 dependent look-ups -- 28 us for the 3 200 rows of a one-crop call, 23 us at 108 000 rows.
   // Ws: LDS, 2 * 27 * CIN * COUT floats (both sides' filters)
   static_assert(COUT % 16 == 0, "four lanes write COUT / 4 channels each as float4s");
-  DclConvSide St{};                                                                // STAGED: the phase's one problem
-  if (STAGED) St = stage_side(*io);
-  const DclConvSide &S0 = STAGED ? St : sides.s[0];
+  const DclConvSide &S0 = sides.s[0];
   int n0 = S0.n_dev ? *S0.n_dev : S0.n_host;
   n0 = n0 < S0.cap ? n0 : S0.cap;
   int n1 = 0;
-  if (!STAGED && nsides > 1) {
+  if (nsides > 1) {
     n1 = sides.s[1].n_dev ? *sides.s[1].n_dev : sides.s[1].n_host;
     n1 = n1 < sides.s[1].cap ? n1 : sides.s[1].cap;
   }
   constexpr int RB = NTB / 4;                                                     // output rows per workgroup step
   for (int i = tix; i < kvol * CIN * COUT; i += NTB) {
     Ws[i] = S0.W[i];
-    if (!STAGED && nsides > 1) Ws[27 * CIN * COUT + i] = sides.s[1].W[i];
+    if (nsides > 1) Ws[27 * CIN * COUT + i] = sides.s[1].W[i];
   }
   __syncthreads();
   const int g = tix & 3;
   const int nblocks = (n0 + n1 + RB - 1) / RB;
-  int b_lo = item, b_hi = nblocks, b_step = nitems;                               // round-robin row blocks
-  if (STAGED) {
-    const int per = (nblocks + nitems - 1) / nitems;
-    b_lo = item * per;
-    b_hi = b_lo + per < nblocks ? b_lo + per : nblocks;
-    b_step = 1;
-  }
-  for (int blk = b_lo; blk < b_hi; blk += b_step) {                               // whole quads stay together
+  for (int blk = item; blk < nblocks; blk += nitems) {                            // round-robin row blocks;                              // whole quads stay together
     const int q = blk * RB + (tix >> 2);
     const bool live = q < n0 + n1;
-    const int second = STAGED ? 0 : ((live && q >= n0) ? 1 : 0);
-    const DclConvSide &S = STAGED ? St : sides.s[second];
+    const int second = (live && q >= n0) ? 1 : 0;
+    const DclConvSide &S = sides.s[second];
     const int row = live ? q - (second ? n0 : 0) : 0;
     float acc[COUT];
 #pragma unroll
@@ -266,13 +82,6 @@ __device__ __forceinline__ void conv_stem_body(const DclConvSides &sides, int ns
       acc[co] = acc[co] + __shfl_xor(acc[co], 1, 64);
       acc[co] = acc[co] + __shfl_xor(acc[co], 2, 64);
     }
-    if (STAGED) {
-      if (((blk - b_lo) & 7) == 7) stage_publish(*io, s_sig);                     // (bounds the groups in flight per publish)
-      if (tix == 0) {
-        const int rows = n0 - blk * RB < RB ? n0 - blk * RB : RB;
-        stage_note_rows(s_sig, (blk * RB) >> stage_out_shift(*io), rows);                // published behind this block's stores
-      }
-    }
     if (!live) continue;
     constexpr int PER = COUT / 4;                        // channels written by each of the four lanes
     float o[PER];
@@ -290,7 +99,6 @@ __device__ __forceinline__ void conv_stem_body(const DclConvSides &sides, int ns
 #pragma unroll
     for (int j = 0; j < PER / 4; ++j) dst[j] = make_float4(o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]);
   }
-  if (STAGED) stage_publish(*io, s_sig);
 }
 // ---- MFMA kernel with the WHOLE filter resident in LDS: the wide, shallow layers (Cin 16 / 32 -> Cout 32) -----------------
 // The first two MFMA layers of a backbone have the most rows (10^5 at 32 crops) and the fewest channels: 27 * Cin * 32 floats
@@ -308,22 +116,18 @@ __device__ __forceinline__ void conv_stem_body(const DclConvSides &sides, int ns
 // flight: 8 waves at 256 registers, five offsets ahead)
 // Cout = 64 (the 32 -> 64 layer): blockIdx.y picks one of the two 32-column halves of the filter (108 KiB each); both halves
 // gather the same rows (L2 traffic, not HBM).
-// NTHR = threads of the workgroup; per-layer launch: item = blockIdx.x of G = gridDim.x, ycol = blockIdx.y.  STAGED (one side
-// per phase, the persistent feature stage): an item owns a contiguous run of 32-row wave tiles, waits for the input rows that
-// run can touch and reports the rows it has written.
-template <int CIN, int COUT_T, bool SUBM, int NTHR, bool STAGED>
+// NTHR = threads of the workgroup; item = blockIdx.x of G = gridDim.x, ycol = blockIdx.y.
+template <int CIN, int COUT_T, bool SUBM, int NTHR>
 __device__ __forceinline__ void conv_wlds_body(const DclConvSides &sides, int nsides, int relu, float *wl_lds /* [27][CIN][32] */,
-                                               int item, int G, int ycol, const DclStageIo *io, int32_t *s_sig) {
-  const int tix = STAGED ? dcl_opaque_tid() : (int)threadIdx.x;
+                                               int item, int G, int ycol) {
+  const int tix = (int)threadIdx.x;
   constexpr int COUT = 32, KV = 27, GRP = CIN / 16;                          // 32 columns per workgroup; 16-channel groups per row
   constexpr int NWAVE = NTHR / 64;
   const int col0 = ycol * COUT;
-  DclConvSide St{};                                                          // STAGED: the phase's one problem
-  if (STAGED) St = stage_side(*io);
-  int n0 = STAGED ? (St.n_dev ? *St.n_dev : St.n_host) : (sides.s[0].n_dev ? *sides.s[0].n_dev : sides.s[0].n_host);
-  n0 = n0 < (STAGED ? St.cap : sides.s[0].cap) ? n0 : (STAGED ? St.cap : sides.s[0].cap);
+  int n0 = sides.s[0].n_dev ? *sides.s[0].n_dev : sides.s[0].n_host;
+  n0 = n0 < sides.s[0].cap ? n0 : sides.s[0].cap;
   int n1 = 0;
-  if (!STAGED && nsides > 1) {
+  if (nsides > 1) {
     n1 = sides.s[1].n_dev ? *sides.s[1].n_dev : sides.s[1].n_host;
     n1 = n1 < sides.s[1].cap ? n1 : sides.s[1].cap;
   }
@@ -334,45 +138,23 @@ __device__ __forceinline__ void conv_wlds_body(const DclConvSides &sides, int ns
     g0 = g0 < 1 ? 1 : (g0 > G - 1 ? G - 1 : g0);
     if (t0 == 0) g0 = 0;
   }
-  const int second = STAGED ? 0 : (item >= g0 ? 1 : 0);
-  const DclConvSide &S = STAGED ? St : sides.s[second];
+  const int second = item >= g0 ? 1 : 0;
+  const DclConvSide &S = sides.s[second];
   const int n = second ? n1 : n0, ntiles = second ? t1 : t0;
   const int wg = item - (second ? g0 : 0), nwg = second ? G - g0 : g0;
   const int lane = tix & 63, wave = tix >> 6;
   const int r = lane & 31, h = lane >> 5;
   const float *__restrict__ feat = S.feat;
-  // per-layer launch: wave tiles dealt round-robin over the launch's waves.  STAGED: the item's run [t_lo, t_hi) of tiles, in
-  // sub-runs of at most 256 tiles (8 row groups of 1024 rows per wait / publish); wave 0 meets the producers of the first
-  // sub-run while the other waves load the filter
-  int t_lo = 0, t_hi = ntiles;
-  if (STAGED) {
-    const int per = (ntiles + nwg - 1) / nwg;
-    t_lo = wg * per;
-    t_hi = t_lo + per < ntiles ? t_lo + per : ntiles;
-  }
-  const bool staged_dep = STAGED && stage_has_dep(*io) && t_lo < t_hi;
-  if (staged_dep && wave == 0) {
-    const int sub_hi = t_lo + 256 < t_hi ? t_lo + 256 : t_hi;
-    int vmin = 0, vmax = -1;
-    stage_input_rows(S.src, t_lo * 32, (sub_hi * 32 < n ? sub_hi * 32 : n) - 1, &vmin, &vmax);
-    stage_wait_rows_wave(*io, vmin, vmax);
-  } else {
+  // wave tiles dealt round-robin over the launch's waves
+  {
     const float4 *Wg = reinterpret_cast<const float4 *>(S.W + col0);
     float4 *Wl = reinterpret_cast<float4 *>(wl_lds);
-    for (int i = staged_dep ? tix - 64 : tix; i < KV * CIN * COUT / 4; i += staged_dep ? NTHR - 64 : NTHR)
-      Wl[i] = Wg[(i >> 3) * (COUT_T / 4) + (i & 7)];
+    for (int i = tix; i < KV * CIN * COUT / 4; i += NTHR) Wl[i] = Wg[(i >> 3) * (COUT_T / 4) + (i & 7)];
   }
   __syncthreads();
   // (running the first tile's look-ups under the filter load was measured: the 27 live row numbers across the load push
   // the 16-wave variant over its 128 registers -- 43 -> 52 us)
-  for (int sub = t_lo; sub < t_hi; sub += 256) {
-  const int sub_hi = STAGED ? (sub + 256 < t_hi ? sub + 256 : t_hi) : t_hi;
-  if (STAGED && sub != t_lo) {
-    int vmin = 0, vmax = -1;
-    if (stage_has_dep(*io)) stage_input_rows(S.src, sub * 32, (sub_hi * 32 < n ? sub_hi * 32 : n) - 1, &vmin, &vmax);
-    stage_wait_rows(*io, vmin, vmax);
-  }
-  for (int tile = STAGED ? sub + wave : wg * NWAVE + wave; tile < sub_hi; tile += STAGED ? NWAVE : nwg * NWAVE) {
+  for (int tile = wg * NWAVE + wave; tile < ntiles; tile += nwg * NWAVE) {
     const int row = tile * 32 + r;
     const bool valid = row < n;
     int v[KV];                                                               // the 27 neighbour rows of this lane's output row
@@ -409,9 +191,7 @@ __device__ __forceinline__ void conv_wlds_body(const DclConvSides &sides, int ns
       }
     }
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // MFMA -> VALU read of the accumulator
-    DclConvSide Sl{};
-    if constexpr (STAGED) Sl = stage_side(*io);                   // (fetched late: not held across the offset loop)
-    const DclConvSide &Se = STAGED ? Sl : S;
+    const DclConvSide &Se = S;
     const float sc = Se.scale ? Se.scale[col0 + r] : 1.0f, sh = Se.scale ? Se.shift[col0 + r] : 0.0f;
     float *__restrict__ out = Se.out;
     const bool have_scale = Se.scale != nullptr;
@@ -425,20 +205,6 @@ __device__ __forceinline__ void conv_wlds_body(const DclConvSides &sides, int ns
         out[(size_t)orow * COUT_T + col0 + r] = x;
       }
     }
-  }
-  if (STAGED) {
-    if (tix == 0) {
-      const int r_lo = sub * 32, r_hi = sub_hi * 32 < n ? sub_hi * 32 : n;                  // rows [r_lo, r_hi) written by this sub-run
-      for (int g = r_lo >> stage_out_shift(*io); (g << stage_out_shift(*io)) < r_hi; ++g) {
-        const int a = g << stage_out_shift(*io) > r_lo ? g << stage_out_shift(*io) : r_lo;
-        const int b = (g + 1) << stage_out_shift(*io) < r_hi ? (g + 1) << stage_out_shift(*io) : r_hi;
-        stage_note_rows(s_sig, g, b - a);
-      }
-    }
-    stage_publish(*io, s_sig);
-  } else {
-    break;
-  }
   }
 }
 // ---- implicit-GEMM MFMA kernel fed by LDS-DMA (Cout % 64 == 0): same 64x64 output tile and virtual-channel walk as
@@ -507,22 +273,13 @@ __device__ __forceinline__ unsigned conv_lds_addr(const float *p) {
 // ORD: the launch carries a row order (sides.s[].ord; the two deep levels of a batch of 14 crops or more) -- a
 // compile-time switch, because the natural-order instantiation must not pay registers for the order's bookkeeping (the
 // 8-wave variants sit at the 128-VGPR limit of two workgroups per CU)
-// NTB = threads of the workgroup (>= 64 * WR * WCW: the waves behind the tile's WR * WCW compute waves only help with the
-// neighbour table and keep the barriers -- how the four-wave tile shapes run inside the 512-thread persistent kernel).
-// Per-layer launch: wid_in = blockIdx.x of G = gridDim.x.  STAGED (one side per phase): before its first operand fetch a
-// segment waits for the input rows its tile can touch (after the neighbour table: the table needs the geometry only),
-// finished tiles are reported to the output tensor's group counters at the end of the item, and a launch with a deferred
-// combine (conv_frag_reduce_body as the next phase) counts its published segments per tile in io->arrive.
-template <int CIN, int WR, int WCW, int NT, bool ORD, int NTB, bool STAGED>
+// wid_in = blockIdx.x of G = gridDim.x.
+template <int CIN, int WR, int WCW, int NT, bool ORD>
 __device__ __forceinline__ void conv_dma_body(
     const DclConvSides &sides, int nsides, int cout, int kvol, int subm, int relu, float *__restrict__ partial, int stream_k,
-    int aligned_ns, int xcd_remap, int32_t *__restrict__ tile_counters, int use_bal_arg, float *conv_lds, int wid_in, int G,
-    const DclStageIo *io, int32_t *s_sig) {
-  // (STAGED: partial, tile_counters and relu come from the phase record where they are used -- arguments would sit in scalar
-  // registers across the chunk loop, and the eight-wave tiles run at the SGPR limit)
+    int aligned_ns, int xcd_remap, int32_t *__restrict__ tile_counters, int use_bal_arg, float *conv_lds, int wid_in, int G) {
   const int use_bal = ORD ? use_bal_arg : 0;
-  constexpr int NW = WR * WCW, NTHR = NTB;
-  static_assert(NTB >= 64 * NW, "workgroup smaller than the tile's compute waves");
+  constexpr int NW = WR * WCW, NTHR = 64 * NW;
   constexpr int BM = 32 * WR, BN = 32 * NT * WCW, KC = 32;
   constexpr int AT = BM * KC, BT = KC * BN, ST = AT + BT;      // floats per stage
   constexpr int A_INSTR = BM / 8;                              // 1-KiB DMA instructions per A tile (8 rows of 128 B each)
@@ -538,28 +295,16 @@ __device__ __forceinline__ void conv_dma_body(
   // the launch's problems ("sides": the observed / template backbone of the same layer; one for a plain call): their
   // live row counts and tile counts -- every workgroup needs both to find its place in the common unit sequence
   int n0, n1 = 0;
-  if constexpr (STAGED) {
-    const DclConvSide h = stage_side(*io);
-    n0 = h.n_dev ? *h.n_dev : h.n_host;
-    n0 = n0 < h.cap ? n0 : h.cap;
-  } else {
-    n0 = sides.s[0].n_dev ? *sides.s[0].n_dev : sides.s[0].n_host;
-    n0 = n0 < sides.s[0].cap ? n0 : sides.s[0].cap;
-    if (nsides > 1) {
-      n1 = sides.s[1].n_dev ? *sides.s[1].n_dev : sides.s[1].n_host;
-      n1 = n1 < sides.s[1].cap ? n1 : sides.s[1].cap;
-    }
+  n0 = sides.s[0].n_dev ? *sides.s[0].n_dev : sides.s[0].n_host;
+  n0 = n0 < sides.s[0].cap ? n0 : sides.s[0].cap;
+  if (nsides > 1) {
+    n1 = sides.s[1].n_dev ? *sides.s[1].n_dev : sides.s[1].n_host;
+    n1 = n1 < sides.s[1].cap ? n1 : sides.s[1].cap;
   }
-  const int tid = STAGED ? dcl_opaque_tid() : (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int wr = wave / WCW, wc = wave % WCW;
-  const bool active = NTB == 64 * NW || wave < NW;             // a compute wave of the tile (the others: table + barriers only)
-  // who issues the chunk's operand DMAs: the compute waves themselves -- or, where the workgroup has NW spare waves (a four-wave
-  // tile inside the 512-thread stage) and the phase asks for it (xcd_remap bit 1), those: the compute waves then go from the
-  // barrier straight into their MFMA block
-  const bool producers = NTB >= 128 * NW && (xcd_remap & 2) != 0;
-  const bool issuer = producers ? (wave >= NW && wave < 2 * NW) : active;
-  const int iwave = producers ? wave - NW : wave;              // the issuing wave's share of the pieces
+  const int iwave = wave;                                      // every wave issues its share of the chunk's DMA pieces
   // Work decomposition ("stream-K").  The launch's work is the sequence of chunk units (tile 0: chunks 0..C-1, tile 1:
   // ..., tiles numbered column-tile-fastest); workgroup w owns the contiguous units [w*U, (w+1)*U) with U = ceil(total / G)
   // for the G workgroups of the launch, so every workgroup does the same amount of MFMA work whatever the number of
@@ -573,7 +318,7 @@ __device__ __forceinline__ void conv_dma_body(
   // workgroups sharing an XCD (= one L2) hold neighbouring unit ranges (column tiles of a row tile, neighbouring row
   // tiles, whose gathered input rows overlap) -- not in capacity mode, where the live work occupies the low ids only
   int wid = wid_in;
-  if (!STAGED && xcd_remap && sides.s[0].n_dev == nullptr) {
+  if (xcd_remap && sides.s[0].n_dev == nullptr) {
     const int xq = G >> 3, xr = G & 7, xcd = wid & 7;
     wid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (wid >> 3);
   }
@@ -587,13 +332,8 @@ __device__ __forceinline__ void conv_dma_body(
   // row tile with few used offsets costs its workgroups proportionally less.  The unit sequence of a grouped launch is side
   // 0's units followed by side 1's (tiles never straddle the sides).
   constexpr int CPKH = CIN >= KC ? CIN / KC : 1;
-  int units0, units1 = 0;
-  if constexpr (STAGED) {
-    units0 = use_bal ? stage_side(*io).ord.bal[nblk0] * ncol * CPKH : nblk0 * ncol * C;
-  } else {
-    units0 = use_bal ? sides.s[0].ord.bal[nblk0] * ncol * CPKH : nblk0 * ncol * C;
-    units1 = nsides > 1 ? (use_bal ? sides.s[1].ord.bal[nblk1] * ncol * CPKH : nblk1 * ncol * C) : 0;
-  }
+  const int units0 = use_bal ? sides.s[0].ord.bal[nblk0] * ncol * CPKH : nblk0 * ncol * C;
+  const int units1 = nsides > 1 ? (use_bal ? sides.s[1].ord.bal[nblk1] * ncol * CPKH : nblk1 * ncol * C) : 0;
   const int total = units0 + units1;
   const int nblk = nblk0 + nblk1;                              // row tiles of the launch (aligned split-K numbers them through)
   int U = C, u = wid * C, u_end = total;                       // stream_k == 0: tile wid, wid + G, ...
@@ -614,10 +354,8 @@ __device__ __forceinline__ void conv_dma_body(
     int tile, j_begin, nchunks, tile_lo, tile_hi, blk, by;
     bool whole;
     // which side this segment belongs to, and that side's problem (uniform: scalar loads of ONE side's descriptor)
-    const int second = STAGED ? 0 : (u >= units0 ? 1 : 0);
-    DclConvSide St{};                                          // STAGED: the phase's problem, fetched per segment like a kernel argument
-    if constexpr (STAGED) St = stage_side(*io);
-    const DclConvSide &S = STAGED ? St : sides.s[second];
+    const int second = u >= units0 ? 1 : 0;
+    const DclConvSide &S = sides.s[second];
     const float *__restrict__ feat = S.feat;
     const DclNbrSrc src = S.src;
     const int cap = S.cap;
@@ -685,21 +423,8 @@ __device__ __forceinline__ void conv_dma_body(
     unsigned mymask = 0;
     const int sx_lo = (j_begin * KC) / CIN;
     const int sx_hi = min(kvol - 1, (nchunks * KC - 1) / CIN);
-    // STAGED: wave 0 meets the producers meanwhile -- the rows this tile can gather must be complete: the tile's own row
-    // range, or (ordered rows are a permutation inside their 8192-row window) the window's; bounded poll + acquire, ordered
-    // before everybody's operand fetches by the barrier behind the table
-    const bool waits = STAGED && wave == 0 && stage_has_dep(*io);
-    if (waits) {
-      const int r_lo = ordered ? (row0 >> 13) << 13 : row0;
-      int r_hi = ordered ? ((row0 >> 13) + 1) << 13 : row0 + BM;
-      r_hi = (r_hi < n ? r_hi : n) - 1;
-      int vmin = 0, vmax = -1;
-      stage_input_rows(src, r_lo, r_hi, &vmin, &vmax);
-      stage_wait_rows_wave(*io, vmin, vmax);
-    }
-    const bool staged_dep = STAGED && stage_has_dep(*io);      // (uniform: then waves 1.. share the table among themselves)
 #pragma unroll NW == 4 ? 8 : 4                             // several rounds of lookups in flight (2-3 dependent loads each)
-    for (int e = waits ? (1 << 30) : (staged_dep ? tid - 64 : tid); e < (sx_hi - sx_lo + 1) * BM; e += staged_dep ? NTHR - 64 : NTHR) {
+    for (int e = tid; e < (sx_hi - sx_lo + 1) * BM; e += NTHR) {
       const int si = e / BM, rr = e - si * BM;
       const int k = offset_at(sx_lo + si, kvol, subm);
       const int orow = ordered ? s_rows[rr] : (row0 + rr < n ? row0 + rr : -1);
@@ -821,8 +546,7 @@ __device__ __forceinline__ void conv_dma_body(
       // workgroup per CU at dispatch time)
       int wrow = wr * 32 + r;
       asm volatile("" : "+v"(wrow));
-      if (active)
-        for (int sx = 0; sx < kvol; ++sx)
+      for (int sx = 0; sx < kvol; ++sx)
           if ((smask >> sx) & 1u)
             wsmask |= (__ballot(Ns[offset_at(sx, kvol, subm) * BM + wrow] >= 0) != 0ull ? 1u : 0u) << sx;
     }
@@ -839,8 +563,8 @@ __device__ __forceinline__ void conv_dma_body(
     // AFTER the next are prepared under the MFMA block (LDS reads of the neighbour table + address arithmetic), so that only
     // the DMA instructions themselves stand between the barrier and the MFMAs.  Eight-wave tiles prepare right before they
     // fire (128 x 128: at their 128 registers; 128 x 64: measured both ways, 80 / 70 us against 82 / 71 with the early prep).
-    constexpr bool PIPE = NW == 4 && NTB == 64 * NW;       // (inside the 512-thread persistent kernel the budget is 128 registers)
-    if (j < nchunks && issuer) {
+    constexpr bool PIPE = NW == 4;
+    if (j < nchunks) {
       prep(j);
       fire_all(0);
     }
@@ -859,7 +583,7 @@ __device__ __forceinline__ void conv_dma_body(
       __syncthreads();                                   // ... everyone's have, and stage cur^1 has no reader left
       PH(ph_bar);
       if (first_chunk) { CONV_STAMP(2); first_chunk = false; }
-      if (jn < nchunks && issuer) {                      // (spreading the pieces over the MFMA groups was measured: the wave
+      if (jn < nchunks) {                                // (spreading the pieces over the MFMA groups was measured: the wave
         if (!PIPE) prep(jn);                             //  pays the same per piece there, nothing is hidden)
         fire_all(cur ^ 1);
       }
@@ -919,29 +643,17 @@ __device__ __forceinline__ void conv_dma_body(
       // slot of a workgroup's segment of `tile`: 2*w if the tile holds w's first unit, else 2*w + 1
       // (w * U >= tile * C  <=>  the tile holds w's first unit, for the workgroups w that touch the tile at all)
       auto slot_of = [&](int w) -> size_t { return (size_t)(2 * w + ((aligned_ns || w * U >= tile_lo) ? 0 : 1)); };
-      if constexpr (STAGED) {
-        const DCL_CONST_AS DclStagePhase *Pq = stage_phase(*io);
-        partial = Pq->partial;
-        tile_counters = Pq->tile_counters;
-      }
       f32x4 *mine = reinterpret_cast<f32x4 *>(partial) + slot_of(wid) * tile_f4 + (size_t)wave * NT * 4 * 64 + lane;
-      if (active) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            f32x4 v;
-            v.x = acc[t][4 * q]; v.y = acc[t][4 * q + 1]; v.z = acc[t][4 * q + 2]; v.w = acc[t][4 * q + 3];
-            if (tile_counters || STAGED) conv_store16_wt(mine + (t * 4 + q) * 64, v);
-            else mine[(t * 4 + q) * 64] = v;                // deferred combine (k_conv_frag_reduce, next launch): plain stores
-          }
-      }
-      if (tile_counters == nullptr) {                      // few-row launches: the combine is a launch / a phase of its own
-        if (STAGED) {                                      // ... which counts the tile's published segments
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __syncthreads();
-          if (tid == 0) __hip_atomic_fetch_add(io->sync + stage_phase(*io)->arrive_off + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v;
+          v.x = acc[t][4 * q]; v.y = acc[t][4 * q + 1]; v.z = acc[t][4 * q + 2]; v.w = acc[t][4 * q + 3];
+          if (tile_counters) conv_store16_wt(mine + (t * 4 + q) * 64, v);
+          else mine[(t * 4 + q) * 64] = v;                  // deferred combine (k_conv_frag_reduce, next launch): plain stores
         }
+      if (tile_counters == nullptr) {                      // few-row launches: the combine is a launch of its own
         __syncthreads();
         continue;
       }
@@ -964,7 +676,7 @@ __device__ __forceinline__ void conv_dma_body(
       __syncthreads();
       CONV_STAMP(5);
       const bool last_arriver = s_kmask[1] != 0;
-      if (last_arriver && active) {
+      if (last_arriver) {
         // split-major: the NT*4 pieces of one split are independent loads in flight together; per element the sum is
         // P_0 + P_1 + ... in split order
         const f32x4 *base = reinterpret_cast<const f32x4 *>(partial) + (size_t)wave * NT * 4 * 64 + lane;
@@ -1004,12 +716,10 @@ __device__ __forceinline__ void conv_dma_body(
         }
         // (the epilogue's pointers are fetched from the side's descriptor HERE, through an opaque index, so that they are
         // not kept in scalar registers across the chunk loop: the kernel runs at the SGPR limit)
-        const int sec_e = STAGED ? 0 : __builtin_amdgcn_readfirstlane(second);
-        DclConvSide Se{};
-        if constexpr (STAGED) { Se = stage_side(*io); relu = stage_phase(*io)->relu; }
-        const float *__restrict__ scale = STAGED ? Se.scale : sides.s[sec_e].scale;
-        const float *__restrict__ shift = STAGED ? Se.shift : sides.s[sec_e].shift;
-        float *__restrict__ out = STAGED ? Se.out : sides.s[sec_e].out;
+        const int sec_e = __builtin_amdgcn_readfirstlane(second);
+        const float *__restrict__ scale = sides.s[sec_e].scale;
+        const float *__restrict__ shift = sides.s[sec_e].shift;
+        float *__restrict__ out = sides.s[sec_e].out;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const int co = col0 + wc * 32 * NT + 32 * t + r;
@@ -1030,20 +740,13 @@ __device__ __forceinline__ void conv_dma_body(
       }
       __syncthreads();
       CONV_STAMP(6);
-      if (STAGED) {
-        if (last_arriver && tid == 0) stage_note_rows(s_sig, row0 >> stage_out_shift(*io), n - row0 < BM ? n - row0 : BM);
-        __syncthreads();
-        if (stage_sig_full(s_sig)) stage_publish(*io, s_sig);
-      }
       continue;
     }
-    if (active) {
-    const int sec_e = STAGED ? 0 : __builtin_amdgcn_readfirstlane(second);
-    DclConvSide Se{};
-    if constexpr (STAGED) { Se = stage_side(*io); relu = stage_phase(*io)->relu; }
-    const float *__restrict__ scale = STAGED ? Se.scale : sides.s[sec_e].scale;
-    const float *__restrict__ shift = STAGED ? Se.shift : sides.s[sec_e].shift;
-    float *__restrict__ out = STAGED ? Se.out : sides.s[sec_e].out;
+    {
+    const int sec_e = __builtin_amdgcn_readfirstlane(second);
+    const float *__restrict__ scale = sides.s[sec_e].scale;
+    const float *__restrict__ shift = sides.s[sec_e].shift;
+    float *__restrict__ out = sides.s[sec_e].out;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int co = col0 + wc * 32 * NT + 32 * t + r;
@@ -1063,35 +766,23 @@ __device__ __forceinline__ void conv_dma_body(
     }
     }
     __syncthreads();
-    if (STAGED) {
-      if (tid == 0) stage_note_rows(s_sig, row0 >> stage_out_shift(*io), n - row0 < BM ? n - row0 : BM);
-      __syncthreads();
-      if (stage_sig_full(s_sig)) stage_publish(*io, s_sig);
-    }
   }
-  if (STAGED) stage_publish(*io, s_sig);
 }
 // Deferred combine of a stream-K launch (few-row launches: a tile has up to 27 segments, which the last arriver would have
 // to add in as many dependent rounds of loads -- here every thread owns one 16-B piece of a tile and has all of its
 // segments' loads in flight at once).  Same unit arithmetic as k_sparse_conv_dma; tiles owned by ONE workgroup were
 // written by it directly and are skipped.  grid = (tiles_cap, NW*NT*4*64/256), 256 threads.
-// Per-layer launch (NTB = 256): tile = item, one 16-B piece per thread (piece0 = blockIdx.y * 256).  STAGED (a phase of the
-// persistent feature stage, one side): the item walks tiles item, item + nitems, ...; a split tile is combined once the conv
-// phase has counted all of its segments in io->arrive (bounded poll + acquire), all pieces of the tile by this workgroup,
-// and the tile's rows are reported to the output tensor's group counters.
-template <int WR, int WCW, int NT, int NTB, bool STAGED>
+// tile = item, one 16-B piece per thread (piece0 = blockIdx.y * 256).
+template <int WR, int WCW, int NT>
 __device__ __forceinline__ void conv_frag_reduce_body(const float *__restrict__ partial, const DclConvSides &sides, int nsides,
-                                                      int cout, int C, int G, int min_u, int relu, int item, int nitems,
-                                                      int piece0, const DclStageIo *io, int32_t *s_sig) {
-  const int tix = STAGED ? dcl_opaque_tid() : (int)threadIdx.x;
+                                                      int cout, int C, int G, int min_u, int relu, int item, int piece0) {
+  const int tix = (int)threadIdx.x;
   constexpr int NW = WR * WCW, BM = 32 * WR, BN = 32 * NT * WCW;
-  DclConvSide St{};                                                          // STAGED: the phase's one problem
-  if (STAGED) St = stage_side(*io);
-  const DclConvSide &S0 = STAGED ? St : sides.s[0];
+  const DclConvSide &S0 = sides.s[0];
   int n0 = S0.n_dev ? *S0.n_dev : S0.n_host;
   n0 = n0 < S0.cap ? n0 : S0.cap;
   int n1 = 0;
-  if (!STAGED && nsides > 1) {
+  if (nsides > 1) {
     n1 = sides.s[1].n_dev ? *sides.s[1].n_dev : sides.s[1].n_host;
     n1 = n1 < sides.s[1].cap ? n1 : sides.s[1].cap;
   }
@@ -1101,98 +792,68 @@ __device__ __forceinline__ void conv_frag_reduce_body(const float *__restrict__ 
   int U = (total + G - 1) / G;
   if (U < min_u) U = min_u;
   constexpr int NP = NW * NT * 4 * 64;                                       // 16-B pieces of a tile
-  for (int tile = item; tile < tiles0 + tiles1; tile += nitems) {            // numbered over the whole launch: side 0's, then side 1's
-    const int w_first = (tile * C) / U, w_last = ((tile + 1) * C - 1) / U;
-    if (w_first == w_last) {                                                 // one owner: written (and reported) by the conv body
-      if (!STAGED) return;
-      continue;
-    }
-    if (STAGED) {
-      if (tix < 64) {
-        int spins = 0;
-        const int32_t *arrive = io->sync + stage_phase(*io)->arrive_off + tile;
-        while (stage_load_relaxed(arrive) < w_last - w_first + 1) {
-          if (++spins > io->spin_limit || stage_load_relaxed(io->sync + 1) != 0) {
-            if (tix == 0) stage_report_timeout(*io);
-            break;
-          }
-          stage_backoff(spins);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      __syncthreads();
-    }
-    const int second = STAGED ? 0 : (tile >= tiles0 ? 1 : 0);
-    const DclConvSide &S = STAGED ? St : sides.s[second];
-    const int n = second ? n1 : n0, lt = tile - (second ? tiles0 : 0);
-    const int blk = lt / ncol, by = lt - blk * ncol;
-    for (int piece = piece0 + (int)tix; piece < NP; piece += NTB) {  // [wave][t][q][lane] inside the tile
-      const int lane = piece & 63, q = (piece >> 6) & 3, t = (piece >> 8) % NT, wave = piece / (256 * NT);
-      const size_t tile_f4 = (size_t)NW * NT * 4 * 64;
-      const f32x4 *base = reinterpret_cast<const f32x4 *>(partial) + piece;
-      f32x4 a = {0.f, 0.f, 0.f, 0.f};
-      constexpr int ZR = 9;                                                  // segments in flight per round (27 = 3 rounds)
+  const int tile = item;                                                     // numbered over the whole launch: side 0's, then side 1's
+  if (tile >= tiles0 + tiles1) return;
+  const int w_first = (tile * C) / U, w_last = ((tile + 1) * C - 1) / U;
+  if (w_first == w_last) return;                                             // one owner: written by the conv body
+  const int second = tile >= tiles0 ? 1 : 0;
+  const DclConvSide &S = sides.s[second];
+  const int n = second ? n1 : n0, lt = tile - (second ? tiles0 : 0);
+  const int blk = lt / ncol, by = lt - blk * ncol;
+  const int piece = piece0 + tix;                                            // [wave][t][q][lane] inside the tile
+  if (piece >= NP) return;
+  const int lane = piece & 63, q = (piece >> 6) & 3, t = (piece >> 8) % NT, wave = piece / (256 * NT);
+  const size_t tile_f4 = (size_t)NW * NT * 4 * 64;
+  const f32x4 *base = reinterpret_cast<const f32x4 *>(partial) + piece;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  constexpr int ZR = 9;                                                      // segments in flight per round (27 = 3 rounds)
 #pragma unroll 1
-      for (int w0 = w_first; w0 <= w_last; w0 += ZR) {
-        f32x4 v[ZR];
+  for (int w0 = w_first; w0 <= w_last; w0 += ZR) {
+    f32x4 v[ZR];
 #pragma unroll
-        for (int i = 0; i < ZR; ++i) {
-          const int w = w0 + i <= w_last ? w0 + i : w_last;                  // clamped: loaded, not added
-          v[i] = base[(size_t)(2 * w + (w * U >= tile * C ? 0 : 1)) * tile_f4];
-        }
-#pragma unroll
-        for (int i = 0; i < ZR; ++i) {
-          const bool first = w0 + i == w_first, live = w0 + i <= w_last;
-          const f32x4 sum = {a.x + v[i].x, a.y + v[i].y, a.z + v[i].z, a.w + v[i].w};
-          a = first ? v[i] : (live ? sum : a);
-        }
-      }
-      const int r = lane & 31, h = lane >> 5, wr = wave / WCW, wc = wave % WCW;
-      const int co = by * BN + wc * 32 * NT + 32 * t + r;
-      const float sc = S.scale ? S.scale[co] : 1.0f, sh = S.scale ? S.shift[co] : 0.0f;
-      const float av[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int orow = blk * BM + wr * 32 + c + 8 * q + 4 * h;             // accumulator element e = 4 q + c
-        if (orow < n) {
-          float x = av[c];
-          if (S.scale) x = x * sc + sh;
-          if (relu) x = fmaxf(x, 0.0f);
-          S.out[(size_t)orow * cout + co] = x;
-        }
-      }
-      if (!STAGED) break;                                                    // per-layer launch: one piece per thread
+    for (int i = 0; i < ZR; ++i) {
+      const int w = w0 + i <= w_last ? w0 + i : w_last;                      // clamped: loaded, not added
+      v[i] = base[(size_t)(2 * w + (w * U >= tile * C ? 0 : 1)) * tile_f4];
     }
-    if (!STAGED) return;
-    __syncthreads();
-    if (tix == 0) stage_note_rows(s_sig, (blk * BM) >> stage_out_shift(*io), n - blk * BM < BM ? n - blk * BM : BM);
-    __syncthreads();
-    if (stage_sig_full(s_sig)) stage_publish(*io, s_sig);
+#pragma unroll
+    for (int i = 0; i < ZR; ++i) {
+      const bool first = w0 + i == w_first, live = w0 + i <= w_last;
+      const f32x4 sum = {a.x + v[i].x, a.y + v[i].y, a.z + v[i].z, a.w + v[i].w};
+      a = first ? v[i] : (live ? sum : a);
+    }
   }
-  if (STAGED) stage_publish(*io, s_sig);
+  const int r = lane & 31, h = lane >> 5, wr = wave / WCW, wc = wave % WCW;
+  const int co = by * BN + wc * 32 * NT + 32 * t + r;
+  const float sc = S.scale ? S.scale[co] : 1.0f, sh = S.scale ? S.shift[co] : 0.0f;
+  const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int orow = blk * BM + wr * 32 + c + 8 * q + 4 * h;                 // accumulator element e = 4 q + c
+    if (orow < n) {
+      float x = av[c];
+      if (S.scale) x = x * sc + sh;
+      if (relu) x = fmaxf(x, 0.0f);
+      S.out[(size_t)orow * cout + co] = x;
+    }
+  }
 }
 // ---- sparse average pool ------------------------------------------------------------------------
 // thread = (output row, 4 channels): rf = #valid offsets (summaryRF.cu:39), then
 // out = ((0 + f_k0/rf) + f_k1/rf) + ... in ascending offset order (avgpool.cu:130).
-// NTB = threads of the workgroup.  Per-layer launch: item = blockIdx.x of nitems = gridDim.x, row blocks round-robin.  STAGED
-// (one side per phase): an item owns a contiguous run of row blocks, walks it in sub-runs of at most 4096 output rows, waits
-// for the input rows a sub-run can touch and reports the rows it has written.
-template <int NTB, bool STAGED>
+// NTB = threads of the workgroup; item = blockIdx.x of nitems = gridDim.x, row blocks round-robin.
+template <int NTB>
 __device__ __forceinline__ void avgpool_body(const DclConvSides &sides, int nsides, int c, int kvol, int32_t *__restrict__ rf_out,
                                              const int32_t *__restrict__ rf_in, int32_t *s_v /* LDS: 64 * 27 ints */, int item,
-                                             int nitems, const DclStageIo *io, int32_t *s_sig) {
-  const int tix = STAGED ? dcl_opaque_tid() : (int)threadIdx.x;
+                                             int nitems) {
+  const int tix = (int)threadIdx.x;
   // the c/4 threads of an output row share its 27 neighbour rows through LDS (one lookup per (row, offset) per block).
   // Up to two problems per launch (the two backbones' pools of a level): the row blocks of side 0, then those of side 1;
   // rf_out / rf_in (the op-level API) belong to side 0 of a one-sided launch.
-  DclConvSide St{};                                        // STAGED: the phase's one problem
-  if (STAGED) St = stage_side(*io);
-  const DclConvSide &S0 = STAGED ? St : sides.s[0];
+  const DclConvSide &S0 = sides.s[0];
   int n0 = S0.n_dev ? *S0.n_dev : S0.n_host;
   n0 = n0 < S0.cap ? n0 : S0.cap;
   int n1 = 0;
-  if (!STAGED && nsides > 1) {
+  if (nsides > 1) {
     n1 = sides.s[1].n_dev ? *sides.s[1].n_dev : sides.s[1].n_host;
     n1 = n1 < sides.s[1].cap ? n1 : sides.s[1].cap;
   }
@@ -1201,24 +862,9 @@ __device__ __forceinline__ void avgpool_body(const DclConvSides &sides, int nsid
   const int tid = tix;
   const int rr = tid / c4, q = tid - rr * c4;
   const int nb0 = (n0 + rpb - 1) / rpb, nb1 = (n1 + rpb - 1) / rpb;
-  int b_lo = item, b_hi = nb0 + nb1, b_step = nitems;
-  if (STAGED) {
-    const int per = (nb0 + nitems - 1) / nitems;
-    b_lo = item * per;
-    b_hi = b_lo + per < nb0 ? b_lo + per : nb0;
-    b_step = 1;
-  }
-  const int sub_blocks = STAGED ? (4096 / rpb > 0 ? 4096 / rpb : 1) : (1 << 30);
-  for (int sub = b_lo; sub < b_hi; sub += STAGED ? sub_blocks : (1 << 30)) {
-  const int sub_hi = STAGED ? (sub + sub_blocks < b_hi ? sub + sub_blocks : b_hi) : b_hi;
-  if (STAGED) {
-    int vmin = 0, vmax = -1;
-    if (stage_has_dep(*io)) stage_input_rows(S0.src, sub * rpb, (sub_hi * rpb < n0 ? sub_hi * rpb : n0) - 1, &vmin, &vmax);
-    stage_wait_rows(*io, vmin, vmax);
-  }
-  for (int bi = sub; bi < sub_hi; bi += b_step) {
-    const int second = STAGED ? 0 : (bi >= nb0 ? 1 : 0);
-    const DclConvSide &S = STAGED ? St : sides.s[second];
+  for (int bi = item; bi < nb0 + nb1; bi += nitems) {
+    const int second = bi >= nb0 ? 1 : 0;
+    const DclConvSide &S = sides.s[second];
     const float *__restrict__ feat = S.feat;
     float *__restrict__ out = S.out;
     const int n = second ? n1 : n0, cap = S.cap;
@@ -1261,20 +907,6 @@ __device__ __forceinline__ void avgpool_body(const DclConvSides &sides, int nsid
     }
     reinterpret_cast<float4 *>(out + (size_t)row * c)[q] = acc;
     if (rf_out && q == 0) rf_out[row] = rf;
-  }
-  if (STAGED) {
-    if (tix == 0) {
-      const int r_lo = sub * rpb, r_hi = sub_hi * rpb < n0 ? sub_hi * rpb : n0;            // rows [r_lo, r_hi) written by this sub-run
-      for (int g = r_lo >> stage_out_shift(*io); (g << stage_out_shift(*io)) < r_hi; ++g) {
-        const int a = g << stage_out_shift(*io) > r_lo ? g << stage_out_shift(*io) : r_lo;
-        const int b = (g + 1) << stage_out_shift(*io) < r_hi ? (g + 1) << stage_out_shift(*io) : r_hi;
-        stage_note_rows(s_sig, g, b - a);
-      }
-    }
-    stage_publish(*io, s_sig);
-  } else {
-    break;
-  }
   }
 }
 

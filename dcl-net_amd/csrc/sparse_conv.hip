@@ -68,7 +68,7 @@ __global__ void k_sparse_conv_valu(const float *__restrict__ feat, const DclNbrS
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void k_sparse_conv_stem(const DclConvSides sides, int nsides, int kvol, int subm, int relu) {
   __shared__ __attribute__((aligned(16))) float Ws[2 * 27 * CIN * COUT];         // both sides' filters
-  conv_stem_body<CIN, COUT, 256, false>(sides, nsides, kvol, subm, relu, Ws, blockIdx.x, gridDim.x, nullptr, nullptr);
+  conv_stem_body<CIN, COUT, 256>(sides, nsides, kvol, subm, relu, Ws, blockIdx.x, gridDim.x);
 }
 
 
@@ -142,8 +142,7 @@ __global__ __launch_bounds__(256) void k_sparse_conv_mfma(
 template <int CIN, int COUT_T, bool SUBM>
 __global__ __launch_bounds__(CIN == 16 ? 1024 : 512) void k_sparse_conv_wlds(const DclConvSides sides, int nsides, int relu) {
   extern __shared__ __attribute__((aligned(16))) float wl_lds[];             // [27][CIN][32]
-  conv_wlds_body<CIN, COUT_T, SUBM, (CIN == 16 ? 1024 : 512), false>(sides, nsides, relu, wl_lds, blockIdx.x, gridDim.x, blockIdx.y,
-                                                                     nullptr, nullptr);
+  conv_wlds_body<CIN, COUT_T, SUBM, (CIN == 16 ? 1024 : 512)>(sides, nsides, relu, wl_lds, blockIdx.x, gridDim.x, blockIdx.y);
 }
 
 
@@ -329,9 +328,8 @@ __global__ __launch_bounds__(64 * WR * WCW, WR * WCW / 2) void k_sparse_conv_dma
     const DclConvSides sides, int nsides, int cout, int kvol, int subm, int relu, float *__restrict__ partial, int stream_k,
     int aligned_ns, int xcd_remap, int32_t *__restrict__ tile_counters, int use_bal_arg) {
   extern __shared__ __attribute__((aligned(16))) float conv_lds[];   // [stage 0: A|B][stage 1: A|B][Ns 27*BM][kmask (4)][rows BM]
-  conv_dma_body<CIN, WR, WCW, NT, ORD, 64 * WR * WCW, false>(sides, nsides, cout, kvol, subm, relu, partial, stream_k, aligned_ns,
-                                                             xcd_remap, tile_counters, use_bal_arg, conv_lds, blockIdx.x,
-                                                             gridDim.x, nullptr, nullptr);
+  conv_dma_body<CIN, WR, WCW, NT, ORD>(sides, nsides, cout, kvol, subm, relu, partial, stream_k, aligned_ns, xcd_remap, tile_counters,
+                                       use_bal_arg, conv_lds, blockIdx.x, gridDim.x);
 }
 
 
@@ -366,8 +364,7 @@ __global__ void k_conv_split_reduce(const float *__restrict__ partial, int nspli
 template <int WR, int WCW, int NT>
 __global__ __launch_bounds__(256) void k_conv_frag_reduce(const float *__restrict__ partial, const DclConvSides sides, int nsides,
                                                           int cout, int C, int G, int min_u, int relu) {
-  conv_frag_reduce_body<WR, WCW, NT, 256, false>(partial, sides, nsides, cout, C, G, min_u, relu, blockIdx.x, gridDim.x,
-                                                 blockIdx.y * 256, nullptr, nullptr);
+  conv_frag_reduce_body<WR, WCW, NT>(partial, sides, nsides, cout, C, G, min_u, relu, blockIdx.x, blockIdx.y * 256);
 }
 
 
@@ -415,8 +412,7 @@ DCL_HOOK_INT(g_conv_split, 0);       // 0 = automatic, n = force n-way split-K w
 static std::atomic<int> g_conv_order_mode{0};   // A/B: 0 = as given, 1 = ignore the row order (natural rows), 2 = order but nominal chunk units
 #endif
 
-// How one LDS-DMA conv launch (or one phase of the persistent feature stage) is decomposed: shared by launch_conv_dma and
-// the stage builder (dcl_internal_conv_plan), so that both paths issue the same segments and add them in the same order.
+// How one LDS-DMA conv launch is decomposed.
 static DclConvPlan plan_conv_dma(const DclConvSides &sides, int nsides, int CIN, int BM, int BN, int cout, int kvol, bool have_scratch,
                                  long long scratch_floats, int kSlots) {
   constexpr int KC = 32;
@@ -599,7 +595,7 @@ static void launch_conv_tile(int rows, const float *feat, const DclNbrSrc &nbr, 
 __global__ __launch_bounds__(256) void k_sparse_avgpool(const DclConvSides sides, int nsides, int c, int kvol,
                                                         int32_t *__restrict__ rf_out, const int32_t *__restrict__ rf_in) {
   __shared__ int32_t s_v[64 * 27];
-  avgpool_body<256, false>(sides, nsides, c, kvol, rf_out, rf_in, s_v, blockIdx.x, gridDim.x, nullptr, nullptr);
+  avgpool_body<256>(sides, nsides, c, kvol, rf_out, rf_in, s_v, blockIdx.x, gridDim.x);
 }
 
 
@@ -778,9 +774,8 @@ int dcl_internal_sparse_conv_fwd(const float *feat, const DclNbrSrc &nbr, int ca
                                             counters_ready);
 }
 
-// Which kernel family / tile shape a layer takes.  stage = 1: the choice for a phase of the persistent feature stage (one
-// side; the filter-resident kernel only in its 16-channel form -- the 32-channel one needs 256 registers and 108 KiB of LDS).
-static DclConvChoice conv_choose(const DclConvSides &sides, int nsides, int cin, int cout, int kvol, bool have_scratch, int stage) {
+// Which kernel family / tile shape a layer takes.
+static DclConvChoice conv_choose(const DclConvSides &sides, int nsides, int cin, int cout, int kvol, bool have_scratch) {
   DclConvChoice c{DCL_CONV_GENERIC, 0, 0, 0};
   const bool mfma_ok = g_force_valu != 1 && (cin % 8 == 0) && (cout % 32 == 0);
   const bool lds_ok = mfma_ok && g_force_valu != 2 && (cin == 16 || cin == 32 || cin == 64 || cin == 128);
@@ -802,14 +797,14 @@ static DclConvChoice conv_choose(const DclConvSides &sides, int nsides, int cin,
     // (the 32 -> 64 layer as two 32-column halves -- instantiated, measured, not used: 99 us against the DMA kernel's 86)
     // Two sides in one call (one-stream schedule): the 16-channel layer goes out as a launch per side (44 us each against 105
     // for the grouped LDS-DMA launch), the 32-channel one keeps the grouped LDS-DMA launch (72 us against 2 x 48).
-    const bool wlds32 = !stage && ((cin == 32 && cout == 32 && nsides == 1) || (g_conv_wlds == 2 && cout == 64 && cin == 32));
+    const bool wlds32 = ((cin == 32 && cout == 32 && nsides == 1) || (g_conv_wlds == 2 && cout == 64 && cin == 32));
     if (g_conv_wlds != 0 && ((cout == 32 && cin == 16) || wlds32) && kvol == 27 && !is_few) {
       c.family = DCL_CONV_WLDS;
       return c;
     }
     c.family = DCL_CONV_DMA;
 #ifdef DCL_DIAG
-    if (g_force_valu == 5 && cout % 128 != 0 && cout % 64 == 0 && !stage) { c.WR = 4; c.WCW = 1; c.NT = 2; return c; }   // A/B: the former 4 waves of 32x64
+    if (g_force_valu == 5 && cout % 128 != 0 && cout % 64 == 0) { c.WR = 4; c.WCW = 1; c.NT = 2; return c; }   // A/B: the former 4 waves of 32x64
 #endif
     if (few_tiles) {                                   // few rows: 64-row tiles, 64x128 (4 waves of 32x64) or 64x64 (4 waves of 32x32)
       c.WR = 2; c.WCW = 2; c.NT = cout % 128 == 0 ? 2 : 1;
@@ -829,18 +824,6 @@ static DclConvChoice conv_choose(const DclConvSides &sides, int nsides, int cin,
   return c;
 }
 
-// library-internal (backbone.hip, the stage builder): kernel choice + launch decomposition of one layer of one side
-int dcl_internal_conv_plan(const DclConvSide &side, int cin, int cout, int kvol, bool have_scratch, long long scratch_floats,
-                           int slots, DclConvChoice *choice, DclConvPlan *plan) {
-  DclConvSides sides{};
-  sides.s[0] = side;
-  *choice = conv_choose(sides, 1, cin, cout, kvol, have_scratch, 1);
-  *plan = DclConvPlan{};
-  if (choice->family == DCL_CONV_DMA)
-    *plan = plan_conv_dma(sides, 1, cin, 32 * choice->WR, 32 * choice->NT * choice->WCW, cout, kvol, have_scratch, scratch_floats, slots);
-  return 0;
-}
-
 static int conv_dispatch(const DclConvSides &sides_in, int nsides_in, int cin, int cout, int kvol, int subm, int relu,
                          float *scratch, int64_t scratch_floats, int counters_ready, int *counters_state, dclStream_t stream) {
   DCL_CHECK_ARG(nsides_in >= 1 && nsides_in <= 2 && cin > 0 && cout > 0 && kvol > 0 && kvol <= 27);
@@ -858,7 +841,7 @@ static int conv_dispatch(const DclConvSides &sides_in, int nsides_in, int cin, i
   }
   if (nsides == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  const DclConvChoice ch = conv_choose(sides, nsides, cin, cout, kvol, scratch != nullptr, 0);
+  const DclConvChoice ch = conv_choose(sides, nsides, cin, cout, kvol, scratch != nullptr);
   if (ch.family == DCL_CONV_WLDS) {
     const size_t lds = (size_t)27 * cin * 32 * sizeof(float);
     const dim3 grid(256 / (cout / 32), cout / 32), block(cin == 16 ? 1024 : 512);

@@ -66,8 +66,7 @@ def _fuser():
 
 class Network(nn.Module):
     def __init__(self, cfg, mode="train", fused=True, graph_max_batch=8, async_inputs=False, graph_max_points=98304,
-                 single_stream=False, pipeline_chunks=1, capture_graph=True, pair_features=None, feature_stage=False,
-                 stage_spin_limit=None, stage_slots=None, stage_flags=0):
+                 single_stream=False, pipeline_chunks=1, capture_graph=True, pair_features=None):
         """graph_max_batch > 0 (default 8): eval-mode calls with at most that many crops go through forward_graphed (one
         whole-forward hipGraph per batch size, captured on first use) -- the one-image-at-a-time eval loops of the
         reference (tools/test_LM.py:104-112: one object per call) are launch-bound otherwise: 0.53 instead of 1.1 ms
@@ -88,17 +87,8 @@ class Network(nn.Module):
         (single_stream: measured 1.63 -> 1.53 ms of conv time per bs-32 forward), separate otherwise -- with two side streams
         the sides' stages overlap each other and the first dense GEMMs, which a common feature stage would serialise (measured
         at N = M = 1024: bs 32 4.28 vs 4.40 ms per step, one crop 0.61 vs 0.65 ms).
-        feature_stage: True = the feature stage of BOTH backbones as ONE launch (ops.backbone_features_stage, csrc/feature_stage.hip:
-        every layer a phase of it, the phases' work items meet through completion counters; implies the paired schedule).  Its
-        waits are bounded (stage_spin_limit polls): if one ever times out, a pinned status word is set, the call's results are
-        invalid, and the instance says so at the next forward() / check_feature_stage() and goes back to per-layer launches.
         These are constructor arguments on purpose: nothing on the call path reads the environment."""
         super().__init__()
-        self.feature_stage = bool(feature_stage)
-        self.stage_spin_limit = stage_spin_limit
-        self.stage_flags = int(stage_flags)
-        self.stage_slots = stage_slots                   # work items a split conv phase is dealt over (None: 256 per side)
-        self._stage_status = None
         self.single_stream = bool(single_stream)
         self._pair_features = pair_features              # both backbones' layers as ONE launch each; None = automatic (see property)
         self.pipeline_chunks = int(pipeline_chunks)
@@ -136,36 +126,7 @@ class Network(nn.Module):
 
     @property
     def pair_features(self):
-        if self.feature_stage:
-            return True
         return self.single_stream if self._pair_features is None else bool(self._pair_features)
-
-    # ------------------------------------------------------------------ the feature stage as one launch
-    def _features_both(self, run_a, vox_a, ptrs_a, run_b, vox_b, ptrs_b):
-        """feature stage of both backbones on the current stream: ONE launch (feature_stage) or one launch per layer"""
-        if self.feature_stage:
-            if self._stage_status is None:
-                self._stage_status = ops.stage_status_buffer()
-            if ops.backbone_features_stage((run_a, run_b), (vox_a, vox_b), (ptrs_a, ptrs_b), self._stage_status,
-                                           slots=self.stage_slots, spin_limit=self.stage_spin_limit, flags=self.stage_flags):
-                return
-        ops.backbone_features_pair(run_a, vox_a, ptrs_a, run_b, vox_b, ptrs_b)
-
-    def check_feature_stage(self):
-        """True if no bounded wait of the staged feature stage has timed out since the last check.  Otherwise: the results
-        of the calls since then are invalid; the instance drops its captured graphs, switches to per-layer launches for good
-        and returns False (the caller repeats the call).  Reads a pinned host word: call it after synchronising."""
-        if self._stage_status is None or int(self._stage_status[0]) == 0:
-            return True
-        import warnings
-        warnings.warn("dcl-net_amd: a wait inside the staged feature stage timed out; the last results are invalid -- "
-                      "falling back to per-layer launches", RuntimeWarning)
-        self._stage_status.zero_()
-        self.feature_stage = False
-        for ent in list(self.__dict__.get("_graphs", {}).values()):
-            self._drop_graph(ent)
-        self.__dict__.get("_graphs", {}).clear()
-        return False
 
     # ------------------------------------------------------------------ parameter folding (eval mode)
     @staticmethod
@@ -396,8 +357,8 @@ class Network(nn.Module):
                     s_inp.wait_event(staged["tmp"])
                     for t in (vox["tmp"], runs["tmp", 0].ws):
                         t.record_stream(s_inp)
-                self._features_both(runs["inp", 0], vox["inp"], f["backbone_inp_ptrs"],
-                                    runs["tmp", 0], vox["tmp"], f["backbone_tmp_ptrs"])
+                ops.backbone_features_pair(runs["inp", 0], vox["inp"], f["backbone_inp_ptrs"],
+                                           runs["tmp", 0], vox["tmp"], f["backbone_tmp_ptrs"])
                 feat_done = torch.cuda.Event()
                 feat_done.record(s_inp)
                 if not single:
@@ -727,8 +688,8 @@ class Network(nn.Module):
                 if stage == 2 and self.pair_features:
                     # the feature stage of both backbones as ONE launch sequence on the main branch (join, run, fork again)
                     main.wait_stream(side_stream)
-                    self._features_both(ent["inp"]["run"], xs["inp"], f["backbone_inp_ptrs"],
-                                        ent["tmp"]["run"], xs["tmp"], f["backbone_tmp_ptrs"])
+                    ops.backbone_features_pair(ent["inp"]["run"], xs["inp"], f["backbone_inp_ptrs"],
+                                               ent["tmp"]["run"], xs["tmp"], f["backbone_tmp_ptrs"])
                     side_stream.wait_stream(main)
                     continue
                 for s, bb, stream, dside in sides:
@@ -864,9 +825,6 @@ class Network(nn.Module):
         """eval(): the fused inference pipeline -- outputs carry no autograd graph, whether or not the caller wrapped the call
         in torch.no_grad() (tools/test_LM.py:110 does not).  train() (or fused=False): the module path, differentiable."""
         if self.fused and not self.training:
-            if self._stage_status is not None and not self.check_feature_stage():
-                raise RuntimeError("dcl-net_amd: the staged feature stage reported a timed-out wait: the results of the previous "
-                                   "call(s) are invalid; this instance now runs per-layer launches -- repeat those calls")
             b = int(data["batch_offsets"].size(0)) - 1
             if self.replays_graph(b) and self._admit_graph(b, data):
                 return self.forward_graphed(data)

@@ -483,67 +483,6 @@ def backbone_features_pair(run_a, vox_a, ptrs_a, run_b, vox_b, ptrs_b):
     return run_a.levels, run_b.levels
 
 
-STAGE_SPIN_LIMIT = 4000000        # polls (~0.5 us each) before a wait inside the staged feature stage gives up
-DCL_ESTAGE_UNSUPPORTED = -2
-
-
-def stage_status_buffer():
-    """pinned (device-visible) int32 the staged feature stage sets to 1 when one of its bounded waits times out"""
-    t = torch.zeros(1, dtype=torch.int32).pin_memory()
-    return t
-
-
-def backbone_features_stage(runs, voxs, ptrs, status, slots=None, spin_limit=None, flags=0):
-    """The feature stage of one or both backbones (lists of 1 or 2 BackboneRun / BackboneRunCap, their voxel features and
-    (weights, scales, shifts) pointer arrays) as ONE launch (csrc/feature_stage.hip: dcl_backbone_features_stage): every layer is
-    a phase of it, the phases' work items meet through completion counters, no kernel boundary and no grid barrier in between.
-    `status`: pinned int32 tensor (stage_status_buffer) that a timed-out wait sets to 1 -- the results are then invalid and the
-    caller repeats the stage with backbone_features_pair / run.features().  Returns False (nothing launched) when a layer has
-    no staged form.  Fills run.levels like run.features()."""
-    n = len(runs)
-    assert n in (1, 2) and len(voxs) == n and len(ptrs) == n
-    cap_mode = isinstance(runs[0], BackboneRunCap)
-    assert all(isinstance(r, type(runs[0])) and r.batch == runs[0].batch and r.S == runs[0].S for r in runs)
-    assert status.dtype == torch.int32 and (status.is_cuda or status.is_pinned())
-    dev = voxs[0].device
-    slots = (256 if n == 2 else 512) if slots is None else int(slots)
-    slots_flags = slots | (int(flags) << 16)             # flags bit 0: the spare waves of four-wave tiles issue the operand DMAs
-    spin_limit = STAGE_SPIN_LIMIT if spin_limit is None else int(spin_limit)
-    if cap_mode:
-        counts_arr = [r.caps for r in runs]
-        counts_host, counts_dev = None, (C.c_void_p * n)(*[r.counts_dev.data_ptr() for r in runs])
-    else:
-        counts_arr = [r.ccounts for r in runs]
-        for r in runs:
-            r.levels = [torch.empty((r.counts[2 * m + 1], BACKBONE_CHANNELS[2 * m + 2]), dtype=torch.float32, device=dev)
-                        for m in range(4)]
-        counts_host, counts_dev = (C.POINTER(C.c_int32) * n)(*[C.cast(c, C.POINTER(C.c_int32)) for c in counts_arr]), None
-    key = (n, slots)
-    ws = runs[0].__dict__.get("_stage_ws") if cap_mode else None
-    if ws is None or ws[0] != key:
-        nbytes = C.c_int64(0)
-        N.check(N.lib().dcl_backbone_stage_ws_bytes(n, (C.POINTER(C.c_int32) * n)(*[C.cast(c, C.POINTER(C.c_int32)) for c in counts_arr]),
-                                                    runs[0].chan, slots, C.byref(nbytes)), "backbone_stage_ws_bytes")
-        ws = (key, torch.empty(nbytes.value, dtype=torch.uint8, device=dev))
-        if cap_mode:
-            runs[0]._stage_ws = ws
-    level_ptrs = [r.level_ptrs if cap_mode else _ptr_array(r.levels) for r in runs]
-    pp = lambda arrs: (C.c_void_p * n)(*[C.cast(a, C.c_void_p) for a in arrs])                # noqa: E731
-    rc = N.lib().dcl_backbone_features_stage(
-        n, runs[0].batch, runs[0].S, runs[0].chan, (C.c_int32 * n)(*[r.V0 for r in runs]),
-        (C.c_void_p * n)(*[r.ws.data_ptr() for r in runs]), counts_host, counts_dev,
-        (C.c_void_p * n)(*[v.data_ptr() for v in voxs]), pp([p[0] for p in ptrs]), pp([p[1] for p in ptrs]),
-        pp([p[2] for p in ptrs]), pp(level_ptrs), N.ptr(ws[1]), C.c_int64(ws[1].numel()), slots_flags, spin_limit,
-        C.c_void_p(status.data_ptr()), N.stream())
-    if rc == DCL_ESTAGE_UNSUPPORTED:
-        return False
-    N.check(rc, "backbone_features_stage")
-    if not cap_mode:
-        for r in runs:
-            r._ws2_keep = ws[1]                              # intermediates + counters live as long as the run
-    return True
-
-
 class BackboneRunCap(object):
     """Capacity-mode backbone pass (whole-forward hipGraph capture): every buffer is sized from (batch, S, V0_cap) alone,
     live row counts stay on the device, no host read-back.  `occ` is a STATIC (V0_cap,4) buffer whose first *v0_dev rows

@@ -27,7 +27,6 @@ extern "C" {
 #endif
 
 #define DCL_EINVAL (-1)
-#define DCL_ESTAGE_UNSUPPORTED (-2)   /* dcl_backbone_features_stage: a layer has no staged form, nothing was launched */
 typedef void *dclStream_t;
 
 const char *dcl_last_error(void);
@@ -273,30 +272,6 @@ int dcl_point_features_cap(int n, const float *points_b4, int batch, int S, int 
                            const float *const *level_feats_host, const float *voxel_extent_host, float offset,
                            float *out, int ld, void *tmp, int64_t tmp_bytes, dclStream_t stream);
 
-/* The feature stage of one or both backbones as ONE launch (csrc/feature_stage.hip).  Every layer (8 convs + 4 pools per
- * backbone, and the deferred combines of one-image calls) is a PHASE of that launch; the work items are the workgroups the
- * per-layer launches would have had -- same segments, same summation order, results bit-identical to dcl_backbone_features /
- * _pair -- numbered in phase order, one workgroup each, drawing its number from a ticket counter when it starts.  Items meet
- * their producers through completion counters per 1024 output rows (bounded polls, release / acquire at agent scope); there is
- * no kernel boundary and no grid-wide barrier between layers, and no co-residency assumption (an item only waits for rows of
- * earlier phases, whose items hold lower tickets and are therefore running or done).
- *   ws_stage: dcl_backbone_stage_ws_bytes(nsides, counts (or dcl_backbone_caps' capacities), channels, slots) bytes of device
- *             memory: phase table, counters, the levels' intermediate tensors, split-K scratch per conv phase.
- *   slots:    work items a split conv phase is dealt over (1..512; 256 per side suits two sides, 512 one).
- *   spin_limit: polls before a wait gives up (each ~0.5 us).  A wait that gives up sets *status_dev = 1 (device-visible int32,
- *             e.g. pinned host memory; may be NULL) and the launch runs to its end without further waiting: its results are
- *             then INVALID and the caller repeats the stage with dcl_backbone_features(_pair).  The kernel never hangs.
- * Returns DCL_ESTAGE_UNSUPPORTED, having launched nothing, when a layer has no staged form (channel counts other than the
- * backbone's [7,16,32,32,64,64,128,128,256] family).  counts_dev != NULL selects capacity mode as in _pair.
- * Replaces the layer loop of Backbone_SPCONV.forward (models/Modules.py:153-159; spconv_ops.h:284-344, pool_ops.h:170-208). */
-int dcl_backbone_stage_ws_bytes(int nsides, const int32_t *const *counts_host, const int32_t *channels_host, int slots,
-                                int64_t *bytes_host);
-int dcl_backbone_features_stage(int nsides, int batch, int S, const int32_t *channels_host, const int32_t *V0, void *const *ws,
-                                const int32_t *const *counts_host, const int32_t *const *counts_dev,
-                                const float *const *vox_feats, const float *const *const *weights,
-                                const float *const *const *scales, const float *const *const *shifts,
-                                float *const *const *level_out, void *ws_stage, int64_t ws_stage_bytes, int slots,
-                                int spin_limit, int32_t *status_dev, dclStream_t stream);
 /* byte offsets (inside ws) of pooled level `level`'s (b,x,y,z) rows and mask-word prefix, and its grid size */
 int dcl_backbone_level_info(int batch, int S, int V0, int level, int64_t *indices_off_host,
                             int64_t *wprefix_off_host, int32_t *S_level_host);
@@ -590,11 +565,6 @@ int dcl_debug_order_stamps(unsigned long long *host16);
 /* Tuning hook: 1 (default) = the LDS-DMA conv kernel renumbers its workgroups XCD-aware (column tiles of a row tile and
  * neighbouring row tiles share an L2), 0 = plain blockIdx order. */
 void dcl_debug_conv_xcd_remap(int on);
-/* Diagnostic: per work item of the last dcl_backbone_features_stage launch four uint64 -- its 100 MHz start and end stamps,
- * its phase, (kind << 32 | tile shape) -- for the first n_items items (tools/stage_debug.py).  In the diagnostic library the
- * `slots` argument of dcl_backbone_features_stage also carries experiment flags in bits 16..: 1 = the spare waves of four-wave
- * tiles issue the operand DMAs, 2 / 4 = skip the release / acquire fences (timing only: results may be stale). */
-int dcl_debug_stage_stamps(unsigned long long *host, int n_items);
 /* Tuning hook for dcl_group_points' LDS-staged kernel: channel rows per workgroup, x-blocks, threads per workgroup,
  * store kind (2 = plain instead of nontemporal); 0 = built-in choice for each. */
 void dcl_debug_group_points_cfg(int cc, int xb, int threads, int nontemporal);

@@ -55,6 +55,21 @@ def test_product_library_has_no_hooks_and_the_diagnostic_library_has_them_all(dc
     assert "getenv" not in und, "the product library must not read the environment"
 
 
+def test_no_one_launch_feature_stage_in_any_library(dcl):
+    """the persistent one-launch feature stage (spin waits between the layers' work items, a pinned status
+    word, a fall-back-for-good path) lost its A/B at every batch size (profiles/r4_stage_ab.txt) and is gone -- from the
+    header, from the product and from the diagnostic library; Network takes no such switch"""
+    import inspect
+    import subprocess
+    assert not [s for s in declared_symbols(diag=True) if "stage" in s and "backbone" in s]
+    for path in (dcl._native.SO_PATH, dcl._native.DIAG_SO_PATH):
+        if os.path.exists(path):
+            nm = subprocess.run(["nm", path], capture_output=True, text=True).stdout
+            assert "features_stage" not in nm and "k_feature_stage" not in nm and "k_stage_prepare" not in nm, path
+    assert "feature_stage" not in inspect.signature(dcl.DCL_Net.Network.__init__).parameters
+    assert not hasattr(dcl.ops, "backbone_features_stage")
+
+
 def test_bad_arguments_return_einval_without_touching_the_gpu(dcl):
     lib = dcl._native.lib()
     assert lib.dcl_voxelize_fp(None, None, None, 4, 1, 0, 1, None) == -1          # n_planes must be > 0

@@ -12,8 +12,7 @@ use_diag(dcl)
 dev = torch.device("cuda:0")
 for b in [int(x) for x in sys.argv[1:]] or [32]:
     data = bench.to_device(dcl.synth.make_batch(b, 1024, 1024), dev)
-    net = dcl.DCL_Net.Network(dcl.synth.default_cfg(1024, 1024), mode="test", graph_max_batch=64,
-                              feature_stage=bool(os.environ.get("STAGE")))          # STAGE=1: the feature stage as one launch
+    net = dcl.DCL_Net.Network(dcl.synth.default_cfg(1024, 1024), mode="test", graph_max_batch=64)
     net.load_state_dict(dcl.synth.synth_state_dict(net, 1))
     net = net.to(dev).eval()
     buf = torch.zeros(64, dtype=torch.int64, device=dev)
@@ -35,6 +34,6 @@ for b in [int(x) for x in sys.argv[1:]] or [32]:
         torch.cuda.synchronize()
     t = buf.cpu().numpy()[:len(names)].astype(np.int64)
     t0 = t[0]
-    print("b=%d%s (stamps of the last replay, us after the first):" % (b, " feature_stage=True" if os.environ.get("STAGE") else ""))
+    print("b=%d%s (stamps of the last replay, us after the first):" % (b, ""))
     for nm, x in sorted(zip(names, t), key=lambda p: p[1]):
         print("  %9.1f  %s" % ((x - t0) * 0.01, nm))

@@ -1,6 +1,6 @@
 """One whole-forward graph replay under `rocprofv3 --kernel-trace`: the kernels of the LAST replay as a timeline (start / end
 relative to the replay's first kernel, queue, name) -- where the branches of the captured forward really overlap.
-usage: rocprofv3 --kernel-trace -d DIR -o t --output-format csv -- python3 tools/graph_trace.py [b] [stage 0|1]
+usage: rocprofv3 --kernel-trace -d DIR -o t --output-format csv -- python3 tools/graph_trace.py [b]
        python3 tools/graph_trace.py --read DIR/.../t_kernel_trace.csv"""
 import importlib
 import os
@@ -40,10 +40,9 @@ def main():
     import torch
     dcl = importlib.import_module("dcl-net_amd")
     b = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-    stage = bool(int(sys.argv[2])) if len(sys.argv) > 2 else False
     n = 1024
     cfg = dcl.synth.default_cfg(n, n)
-    net = dcl.DCL_Net.Network(cfg, mode="test", graph_max_batch=64, feature_stage=stage)
+    net = dcl.DCL_Net.Network(cfg, mode="test", graph_max_batch=64)
     net.load_state_dict(dcl.synth.synth_state_dict(net, 1))
     net = net.cuda().eval()
     data = dcl.synth.make_batch(b, n, n)

@@ -5,7 +5,7 @@
 #                                       gpurun_out/r1_pmcprim_<COUNTER>/        (north-star primitives)
 # then, back in the container: python tools/summarize_profiles.py r1  (copies the summaries into profiles/).
 # PMC passes are separate runs with --kernel-trace only, as the pool requires.
-R=${1:-r4}
+R=${1:-r5}
 export TMPDIR=/tmp
 cd "$(dirname "$0")/.." || exit 1
 O=gpurun_out
@@ -19,12 +19,6 @@ stats stream python3 tools/profile_stream.py 1
 stats crops  python3 tools/bench_crops.py
 stats conv   python3 tools/bench_conv.py 1024 0
 stats refiner python3 tools/refiner_loop.py 10
-stats stage  python3 tools/stage_debug.py 1024 32 512
-# the one-launch feature stage from the inside (diagnostic library: per-item stamps -> per-phase timeline), no profiler
-{ for a in "1024 32 512" "1024 6 512" "1024 1 512"; do STAGE_DIAG=1 python3 tools/stage_debug.py $a; done
-  echo "capacity mode (what a captured graph runs), 40 crops:"; STAGE_CAP=1 STAGE_DIAG=1 python3 tools/stage_debug.py 1024 40 512
-} 2>&1 | grep -v "rep [12]\|amdgpu.ids" > $O/${R}_stage_timeline.txt
-python3 tools/stage_ab.py 1 6 16 32 40 2>&1 | grep -v amdgpu.ids > $O/${R}_stage_ab.txt
 python3 tools/bench_fps.py 2>&1 | grep FPS > $O/${R}_fps.txt
 for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
   pmc pmc $c python3 bench.py --steps 4 --warmup 2 --no-extras

@@ -15,12 +15,12 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
 for shape, tag in (("stress", "stress"), ("ref", "ref"), ("prim", "primitives"), ("stream", "stream_b1_graph"),
-                   ("crops", "crop_builder"), ("conv", "conv_layers"), ("refiner", "refiner_loop"), ("stage", "feature_stage")):
+                   ("crops", "crop_builder"), ("conv", "conv_layers"), ("refiner", "refiner_loop")):
     found = sorted(glob.glob(os.path.join(root, "gpurun_out", "%s_%s" % (rnd, shape), "**", "*kernel_stats.csv"),
                              recursive=True), key=os.path.getmtime)
     if found:                                                   # the newest run of that shape
         shutil.copy(found[-1], os.path.join(out, "%s_%s_kernel_stats.csv" % (rnd, tag)))
-for name in ("stage_timeline.txt", "stage_ab.txt", "fps.txt"):            # plain-text evidence of the round
+for name in ("fps.txt",):            # plain-text evidence of the round
     src = os.path.join(root, "gpurun_out", "%s_%s" % (rnd, name))
     if os.path.exists(src):
         shutil.copy(src, os.path.join(out, "%s_%s" % (rnd, name)))
