@@ -554,17 +554,24 @@ def conv_pairs_flop(dcl, net, data, dev):
     return flop, per_layer
 
 
+PEAK_L2_GATHER = 17800.0       # GB/s chip-wide, rows gathered from the XCDs' L2 into LDS (MI355X_MICROARCH.md "Indexed rows: gather into LDS": 16.8-18.8 TB/s)
+
+
 def sparse_conv_roofline(dcl, net, data, dev, steps=3):
     """roofline entry of the sparse-conv kernel family for one workload: algorithmic flop (measured pairs, above) divided by
-    the summed device time of all 16 conv calls of a forward, measured with HIP events on the launch streams inside the
-    library (dcl_profile_conv_begin/_end) during `steps` ordinary forwards run on ONE stream (net.single_stream, so that
-    the two backbones' kernels do not overlap each other inside the bracketed intervals)."""
+    the summed device time of all conv calls of a forward, measured with HIP events on the launch streams inside the
+    library (dcl_profile_conv_begin / _end_calls) during `steps` ordinary forwards run on ONE stream (net.single_stream, so that
+    the two backbones' kernels do not overlap each other inside the bracketed intervals).  layers[]: the same run call by
+    call -- per layer (both backbones in one grouped launch) its time, useful flop, gathered bytes (pairs x Cin x 4: every
+    pair's input row is fetched once per column tile at least) and the bound that binds it: the fp32 MFMA peak or the rate at
+    which rows can be gathered from L2 into LDS."""
     import ctypes
     flop, per_layer = conv_pairs_flop(dcl, net, data, dev)
     lib = dcl._native.lib()
     old, old_pair = net.single_stream, net._pair_features
     net.single_stream = True
-    timed = {}
+    timed, calls_of = {}, {}
+    CAP = 16 * steps + 16
     try:
         # one stream; first as the library schedules one stream (both backbones' layers grouped: 8 launches per forward),
         # then with each backbone's own launches (16): the second figure is the one comparable with earlier rounds
@@ -578,22 +585,46 @@ def sparse_conv_roofline(dcl, net, data, dev, steps=3):
                     net(data)
                 torch.cuda.synchronize()
                 ms, calls = ctypes.c_double(0), ctypes.c_int32(0)
-                lib.dcl_profile_conv_end(ctypes.byref(ms), ctypes.byref(calls))
+                per_ms, what = (ctypes.c_float * CAP)(), (ctypes.c_int32 * (4 * CAP))()
+                lib.dcl_profile_conv_end_calls(ctypes.byref(ms), ctypes.byref(calls), per_ms, what, CAP)
             timed[name] = (ms.value / steps, int(calls.value))
+            calls_of[name] = [(float(per_ms[i]), tuple(int(what[4 * i + q]) for q in range(4))) for i in range(min(int(calls.value), CAP))]
     finally:
         net.single_stream, net._pair_features = old, old_pair
-    ms, calls = ctypes.c_double(timed["grouped"][0] * steps), ctypes.c_int32(timed["grouped"][1])
-    ms_fwd = ms.value / steps
+    ms_fwd = timed["grouped"][0]
     ach = flop / (ms_fwd * 1e-3) / 1e12 if ms_fwd > 0 else float("nan")
     issued = sum(2.0 * 27 * n_out * ci * co for (_, ci, co, _, n_out, _) in per_layer)
+    # per layer: the calls of the grouped run in call order are layer 0..7 of both sides, `steps` times over
+    layers = []
+    nl = len(per_layer) // 2
+    per_fwd = timed["grouped"][1] // steps if steps else 0
+    if per_fwd == nl:
+        for i in range(nl):
+            (_, ci, co, subm, n_a, p_a), (_, _, _, _, n_b, p_b) = per_layer[i], per_layer[nl + i]
+            t = [calls_of["grouped"][k * nl + i] for k in range(steps)]
+            assert all(w[0] == ci and w[1] == co and w[2] == int(subm) for _, w in t), (t, ci, co, subm)
+            ms_l = sum(x for x, _ in t) / steps
+            fl = 2.0 * (p_a + p_b) * ci * co
+            gath = 4.0 * (p_a + p_b) * ci
+            t_mfma, t_gather = fl / (PEAK_MFMA_F32 * 1e12) * 1e3, gath / (PEAK_L2_GATHER * 1e9) * 1e3
+            layers.append({"layer": "L%d %s %d->%d" % (i // 2, "subm" if subm else "conv", ci, co), "rows": n_a + n_b,
+                           "pairs": p_a + p_b, "density": round((p_a + p_b) / (27.0 * (n_a + n_b)), 3) if n_a + n_b else None,
+                           "ms": round(ms_l, 4), "useful_flop": fl, "TFLOPs": round(fl / (ms_l * 1e-3) / 1e12, 2) if ms_l > 0 else None,
+                           "gathered_bytes": gath, "flop_per_gathered_byte": round(fl / gath, 1) if gath else None,
+                           "mfma_bound_ms": round(t_mfma, 4), "l2_gather_bound_ms": round(t_gather, 4),
+                           "bound": "mfma" if t_mfma >= t_gather else "l2-gather",
+                           "frac_of_bound": round(max(t_mfma, t_gather) / ms_l, 4) if ms_l > 0 else None})
     return {"kernel": "k_sparse_conv_* (8 conv layers x 2 backbones)", "bound": "mfma", "achieved": round(ach, 2),
             "peak": PEAK_MFMA_F32, "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F32, 4),
-            "flop_per_forward": flop, "conv_ms_per_forward": round(ms_fwd, 4), "conv_calls_timed": int(calls.value),
+            "flop_per_forward": flop, "conv_ms_per_forward": round(ms_fwd, 4), "conv_calls_timed": timed["grouped"][1],
             "rulebook_density": round(flop / issued, 4) if issued else None,
             "pairs_per_forward": int(sum(p[5] for p in per_layer)),
             "schedule": "one stream; every layer of the two backbones as ONE grouped launch (what Network(single_stream=True) "
                         "runs); rows of the two deep levels ordered on the device (the ordering launches run in the geometry "
                         "stage, outside the timed conv calls: 2 launches per backbone, see profiles/)",
+            "layers": layers,
+            "layers_note": "bound per layer: max(useful flop / fp32 MFMA peak, pairs x Cin x 4 B / %.1f TB/s L2->LDS gather rate); "
+                           "frac_of_bound = that time / measured time" % (PEAK_L2_GATHER / 1e3),
             "feature_stage": dict(feature_stage_times(dcl, net, data, dev),
                                   what="convs + pools of both backbones stand-alone: a launch per layer and side / one grouped "
                                        "launch per layer"),

@@ -174,6 +174,46 @@ __device__ __forceinline__ int dcl_nbr_at(const DclNbrSrc &s, int cap, int k, in
   const int r = s.in_wprefix[w] + __popc(m & (bit - 1));
   return s.in_perm ? s.in_perm[r] : r;
 }
+// The three z-neighbours (kz = 0, 1, 2: k = 3 * col + kz, col = 3 kx + ky) of output row `row` at once.  In the implicit
+// form the three cells are consecutive bits of the input set's occupancy mask: ONE mask word and ONE prefix word serve all
+// three (two of each where the run crosses a 32-cell boundary: z = 31 | 32 of a 64-wide grid), against three dependent
+// loads per neighbour taken one by one -- the look-ups of a conv tile drop from 81 loads per row to ~20, all independent.
+// q = dcl_nbr_row(s, row): the output row's (b, x, y, z), loaded ONCE for all of its columns.
+__device__ __forceinline__ int4 dcl_nbr_row(const DclNbrSrc &s, int row) {
+  return s.nbr ? make_int4(0, 0, 0, 0) : reinterpret_cast<const int4 *>(s.out_indices)[row];
+}
+__device__ __forceinline__ void dcl_nbr_col(const DclNbrSrc &s, int cap, int col, int row, const int4 q, int (&v)[3]) {
+  if (s.nbr) {
+#pragma unroll
+    for (int kz = 0; kz < 3; ++kz) v[kz] = s.nbr[(size_t)(3 * col + kz) * cap + row];
+    return;
+  }
+  v[0] = v[1] = v[2] = -1;
+  const int kx = col / 3, ky = col - 3 * kx;
+  const int px = q.y * s.stride - s.pad + kx, py = q.z * s.stride - s.pad + ky, pz0 = q.w * s.stride - s.pad;
+  if ((unsigned)px >= (unsigned)s.S_in || (unsigned)py >= (unsigned)s.S_in) return;
+  const int base = ((q.x * s.S_in + px) * s.S_in + py) * s.S_in;
+  const int z_lo = pz0 < 0 ? 0 : pz0, z_hi = pz0 + 2 > s.S_in - 1 ? s.S_in - 1 : pz0 + 2;
+  if (z_lo > z_hi) return;
+  const int w_lo = (base + z_lo) >> 5, w_hi = (base + z_hi) >> 5;
+  const uint32_t m_lo = s.in_mask[w_lo];
+  const int p_lo = s.in_wprefix[w_lo];
+  uint32_t m_hi = m_lo;
+  int p_hi = p_lo;
+  if (w_hi != w_lo) { m_hi = s.in_mask[w_hi]; p_hi = s.in_wprefix[w_hi]; }
+#pragma unroll
+  for (int kz = 0; kz < 3; ++kz) {
+    const int pz = pz0 + kz;
+    if (pz < z_lo || pz > z_hi) continue;
+    const int lin = base + pz;
+    const bool hi = (lin >> 5) != w_lo;
+    const uint32_t m = hi ? m_hi : m_lo;
+    const uint32_t bit = 1u << (lin & 31);
+    if (!(m & bit)) continue;
+    const int r = (hi ? p_hi : p_lo) + __popc(m & (bit - 1));
+    v[kz] = s.in_perm ? s.in_perm[r] : r;
+  }
+}
 #endif
 
 // a*b + c*d + e*f under the same policy.

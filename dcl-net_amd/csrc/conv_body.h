@@ -17,23 +17,25 @@ __device__ __forceinline__ int offset_at(int step, int kvol, int subm) {
   return step <= centre ? step - 1 : step;
 }
 // ---- stem kernel: small Cin/Cout known at compile time (DCL-Net: 7 -> 16) ------------------------------------
-// one thread per output row, all COUT channels in registers; W (kvol x CIN x COUT) lives in LDS and is read as
-// wave-uniform broadcasts.  Per offset an ascending-ci fmaf chain like the generic kernel; the OFFSETS of a row are summed as four
-// interleaved chains (lane g of the row's quad: offsets g, g + 4, ... in visiting order) added pairwise at the end,
-// (l0 + l1) + (l2 + l3) -- not the generic kernel's / the reference's one offset-sequential chain; the parity tests hold it
-// to 2e-5 against the CPU restatement, no test expects its bits.
-// NTB = threads of the workgroup (NTB / 4 output rows per step); item = blockIdx.x of nitems = gridDim.x, row blocks dealt
-// round-robin.
-template <int CIN, int COUT, int NTB>
+// ONE lane per output row, all COUT channels in registers, W (kvol x CIN x COUT) in LDS.  The stem's rulebook is thin -- the
+// dilated output set of level 0 has 3-4 of its 27 neighbours on average -- so a lane first looks its row's 27 neighbours up
+// (nine columns of three, common.h: dcl_nbr_col; kept in a lane-private strip of LDS), then walks ONLY the present ones, in
+// the reference's visiting order (spconv_ops.h:284-344: ascending k, the centre first for subm): per neighbour CIN loads and
+// a CIN x COUT fmaf block with an ascending-ci chain per output, added to the row's sum -- the reference's own summation
+// order.  (Until round 4 four lanes shared a row and every lane walked all of its seven offsets, present or not, because some
+// lane of the wave always had one: 85 us for the 280 000 rows of 32 crops against 1.5 us of arithmetic.)  The filter rows are
+// pitched CIN * COUT + 1 floats: lanes read different offsets' rows at the same (ci, co), and 112 floats apart they would
+// share four banks.  No barrier after the filter load: a lane only reads LDS it has written itself.
+// LPR = lanes per output row: 1 for launches of many rows; 4 for a handful of crops, where a row is a chain of dependent
+// loads per present neighbour and there are lanes to spare: lane g of the row's quad takes the present neighbours number g,
+// g + 4, ... (visiting order) and the four lane sums are added as (l0 + l1) + (l2 + l3).
+// NTB = threads of the workgroup, NTB / LPR output rows per step; item = blockIdx.x of nitems = gridDim.x, row blocks round-robin.
+template <int CIN, int COUT, int NTB, int LPR>
 __device__ __forceinline__ void conv_stem_body(const DclConvSides &sides, int nsides, int kvol, int subm, int relu, float *Ws,
-                                               int item, int nitems) {
+                                               int32_t *s_nb /* LDS: NTB * 27 ints */, int item, int nitems) {
   const int tix = (int)threadIdx.x;
-  // FOUR lanes per output row: lane g of a row's quad walks the kernel offsets s = g, g + 4, ... (each offset: neighbour
-  // look-up, CIN loads, a CIN x COUT fmaf block -> one partial row added to the lane's sum in ascending s), then the four
-  // lane sums are added as (l0 + l1) + (l2 + l3) by two butterfly rounds.  One thread per row made every row a serial chain
-  // of 27 dependent look-ups -- 28 us for the 3 200 rows of a one-crop call, 23 us at 108 000 rows.
-  // Ws: LDS, 2 * 27 * CIN * COUT floats (both sides' filters)
-  static_assert(COUT % 16 == 0, "four lanes write COUT / 4 channels each as float4s");
+  static_assert(COUT % 4 == 0, "rows are written as float4s");
+  constexpr int WP = CIN * COUT + 1;                                              // filter pitch per offset (floats)
   const DclConvSide &S0 = sides.s[0];
   int n0 = S0.n_dev ? *S0.n_dev : S0.n_host;
   n0 = n0 < S0.cap ? n0 : S0.cap;
@@ -42,62 +44,145 @@ __device__ __forceinline__ void conv_stem_body(const DclConvSides &sides, int ns
     n1 = sides.s[1].n_dev ? *sides.s[1].n_dev : sides.s[1].n_host;
     n1 = n1 < sides.s[1].cap ? n1 : sides.s[1].cap;
   }
-  constexpr int RB = NTB / 4;                                                     // output rows per workgroup step
   for (int i = tix; i < kvol * CIN * COUT; i += NTB) {
-    Ws[i] = S0.W[i];
-    if (nsides > 1) Ws[27 * CIN * COUT + i] = sides.s[1].W[i];
+    const int k = i / (CIN * COUT), j = i - k * (CIN * COUT);
+    Ws[k * WP + j] = S0.W[i];
+    if (nsides > 1) Ws[27 * WP + k * WP + j] = sides.s[1].W[i];
   }
   __syncthreads();
-  const int g = tix & 3;
+  static_assert(LPR == 1 || LPR == 4, "lanes per row");
+  constexpr int RB = NTB / LPR;                                                   // output rows per step
+  const int g = tix & (LPR - 1);
+  int32_t *nb = s_nb + (tix / LPR) * 27;                                          // the row's strip (stride 27: conflict-free)
   const int nblocks = (n0 + n1 + RB - 1) / RB;
-  for (int blk = item; blk < nblocks; blk += nitems) {                            // round-robin row blocks;                              // whole quads stay together
-    const int q = blk * RB + (tix >> 2);
+  for (int blk = item; blk < nblocks; blk += nitems) {
+    const int q = blk * RB + tix / LPR;
     const bool live = q < n0 + n1;
+    if (LPR == 1 && !live) continue;                                              // (LPR = 4: whole quads stay for the butterfly)
     const int second = (live && q >= n0) ? 1 : 0;
     const DclConvSide &S = sides.s[second];
     const int row = live ? q - (second ? n0 : 0) : 0;
+    unsigned present = 0;
+    if (kvol == 27) {
+      // LPR = 4: lane g looks up columns g, g + 4, g + 8; the quad shares the strip and ORs its masks
+      const int4 q4 = live ? dcl_nbr_row(S.src, row) : make_int4(0, 0, 0, 0);
+#pragma unroll
+      for (int c0 = 0; c0 < 9; c0 += LPR) {
+        const int col = c0 + g;
+        if (col < 9 && live) {
+          int t3[3];
+          dcl_nbr_col(S.src, S.cap, col, row, q4, t3);
+#pragma unroll
+          for (int kz = 0; kz < 3; ++kz) {
+            nb[3 * col + kz] = t3[kz];
+            present |= (t3[kz] >= 0 ? 1u : 0u) << (3 * col + kz);
+          }
+        }
+      }
+    } else {
+      for (int k = g; k < kvol; k += LPR) {
+        const int v = live ? dcl_nbr_at(S.src, S.cap, k, row) : -1;
+        nb[k] = v;
+        present |= (v >= 0 ? 1u : 0u) << k;
+      }
+    }
+    if (LPR == 4) {                                      // (the quad's lanes are neighbours in one wave: LDS writes above, reads below, in program order)
+      present |= __shfl_xor(present, 1, 64);
+      present |= __shfl_xor(present, 2, 64);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
     float acc[COUT];
 #pragma unroll
     for (int co = 0; co < COUT; ++co) acc[co] = 0.0f;
-    for (int s = g; s < kvol; s += 4) {
-      const int k = offset_at(s, kvol, subm);
-      const int v = live ? dcl_nbr_at(S.src, S.cap, k, row) : -1;
-      if (v < 0) continue;
-      float f[CIN];
+    const float *wside = Ws + second * 27 * WP;
+    const float *__restrict__ feat = S.feat;
+    const int centre = kvol / 2;
+    // this lane's neighbours: all present ones (LPR = 1) or number g, g + 4, ... of them in visiting order
+    bool centre_first = subm && ((present >> centre) & 1u);
+    unsigned mine = present;
+    if (LPR > 1) {
+      mine = 0;
+      unsigned rest = present;
+      int turn = 0;
+      if (centre_first) { if (g == 0) mine |= 1u << centre; rest &= ~(1u << centre); turn = 1; }
+      while (rest) {
+        const int k = __builtin_ctz(rest);
+        rest &= rest - 1u;
+        if (((turn++) & (LPR - 1)) == g) mine |= 1u << k;
+      }
+      centre_first = centre_first && g == 0;
+    }
+    auto next_k = [&]() -> int {                         // visiting order: the centre first for subm, then ascending k
+      int k;
+      if (centre_first) { k = centre; centre_first = false; } else { k = __builtin_ctz(mine); }
+      mine &= ~(1u << k);
+      return k;
+    };
+    auto add_offset = [&](const float (&f)[CIN], int k) {
+      const float *w = wside + k * WP;
 #pragma unroll
-      for (int ci = 0; ci < CIN; ++ci) f[ci] = S.feat[(size_t)v * CIN + ci];
-      const float *w = Ws + second * 27 * CIN * COUT + k * CIN * COUT;
-      float part[COUT];
+      for (int co = 0; co < COUT; ++co) {
+        float part = 0.0f;
 #pragma unroll
-      for (int co = 0; co < COUT; ++co) part[co] = 0.0f;
+        for (int ci = 0; ci < CIN; ++ci) part = __fmaf_rn(f[ci], w[ci * COUT + co], part);
+        acc[co] = acc[co] + part;
+      }
+    };
+    while (mine) {                                       // LPR = 4: two neighbours' rows in flight per round (a chain of latencies otherwise); added in visiting order
+      const int ka = next_k();
+      if (LPR == 1) {                                    // many rows: other waves hide the latency, a second row in flight only costs
+        const int va = nb[ka];
+        float fa[CIN];
 #pragma unroll
-      for (int ci = 0; ci < CIN; ++ci)
+        for (int ci = 0; ci < CIN; ++ci) fa[ci] = feat[(size_t)va * CIN + ci];
+        add_offset(fa, ka);
+        continue;
+      }
+      const int kb = mine ? next_k() : -1;
+      const int va = nb[ka], vb = nb[kb >= 0 ? kb : ka];
+      float fa[CIN], fb[CIN];
 #pragma unroll
-        for (int co = 0; co < COUT; ++co) part[co] = __fmaf_rn(f[ci], w[ci * COUT + co], part[co]);
+      for (int ci = 0; ci < CIN; ++ci) { fa[ci] = feat[(size_t)va * CIN + ci]; fb[ci] = feat[(size_t)vb * CIN + ci]; }
+      add_offset(fa, ka);
+      if (kb >= 0) add_offset(fb, kb);
+    }
+    if (LPR == 4) {
 #pragma unroll
-      for (int co = 0; co < COUT; ++co) acc[co] = acc[co] + part[co];
+      for (int co = 0; co < COUT; ++co) {                // (l0 + l1) + (l2 + l3): commutative adds, the same bits in all four lanes
+        acc[co] = acc[co] + __shfl_xor(acc[co], 1, 64);
+        acc[co] = acc[co] + __shfl_xor(acc[co], 2, 64);
+      }
+      if (!live) continue;
     }
 #pragma unroll
-    for (int co = 0; co < COUT; ++co) {                  // (l0 + l1) + (l2 + l3): commutative adds, the same bits in all four lanes
-      acc[co] = acc[co] + __shfl_xor(acc[co], 1, 64);
-      acc[co] = acc[co] + __shfl_xor(acc[co], 2, 64);
-    }
-    if (!live) continue;
-    constexpr int PER = COUT / 4;                        // channels written by each of the four lanes
-    float o[PER];
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-      float x = 0.f;
-#pragma unroll
-      for (int gg = 0; gg < 4; ++gg) x = g == gg ? acc[gg * PER + j] : x;       // static register indices
-      const int co = g * PER + j;
+    for (int co = 0; co < COUT; ++co) {
+      float x = acc[co];
       if (S.scale) x = x * S.scale[co] + S.shift[co];
       if (relu) x = fmaxf(x, 0.0f);
-      o[j] = x;
+      acc[co] = x;
     }
-    float4 *dst = reinterpret_cast<float4 *>(S.out + (size_t)row * COUT + g * PER);
+    float4 *dst = reinterpret_cast<float4 *>(S.out + (size_t)row * COUT);
+    if (LPR == 1) {
 #pragma unroll
-    for (int j = 0; j < PER / 4; ++j) dst[j] = make_float4(o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]);
+      for (int j = 0; j < COUT / 4; ++j) dst[j] = make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
+    } else {                                             // lane g writes quarter g of the row
+      static_assert(COUT % 16 == 0, "four lanes write COUT / 4 channels each as float4s");
+      constexpr int PER = COUT / 4;
+#pragma unroll
+      for (int j = 0; j < PER / 4; ++j) {
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = 0.f;
+#pragma unroll
+          for (int gg = 0; gg < 4; ++gg) x = g == gg ? acc[gg * PER + 4 * j + e] : x;   // static register indices
+          o[e] = x;
+        }
+        dst[g * (PER / 4) + j] = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
   }
 }
 // ---- MFMA kernel with the WHOLE filter resident in LDS: the wide, shallow layers (Cin 16 / 32 -> Cout 32) -----------------
@@ -158,8 +243,18 @@ __device__ __forceinline__ void conv_wlds_body(const DclConvSides &sides, int ns
     const int row = tile * 32 + r;
     const bool valid = row < n;
     int v[KV];                                                               // the 27 neighbour rows of this lane's output row
+    {
+      int vk[KV];                                                            // by offset k: nine columns of three z-neighbours
+      const int4 q = valid ? dcl_nbr_row(S.src, row) : make_int4(0, 0, 0, 0);
 #pragma unroll
-    for (int st = 0; st < KV; ++st) v[st] = valid ? dcl_nbr_at(S.src, S.cap, offset_at(st, KV, SUBM ? 1 : 0), row) : -1;
+      for (int col = 0; col < 9; ++col) {
+        int t3[3] = {-1, -1, -1};
+        if (valid) dcl_nbr_col(S.src, S.cap, col, row, q, t3);
+        vk[3 * col] = t3[0]; vk[3 * col + 1] = t3[1]; vk[3 * col + 2] = t3[2];
+      }
+#pragma unroll
+      for (int st = 0; st < KV; ++st) v[st] = vk[offset_at(st, KV, SUBM ? 1 : 0)];   // visiting order (a compile-time permutation)
+    }
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
@@ -216,14 +311,16 @@ __device__ __forceinline__ void conv_wlds_body(const DclConvSides &sides, int ns
 // column c ^ (r & 15) (A), and W rows with bit 2 of their index set swap their 32-column halves (B).
 __device__ float4 g_conv_zero_line = {0.f, 0.f, 0.f, 0.f};
 #ifdef DCL_CONV_STAMPS
-// diagnostic build only (tools/conv_stamps.py): s_memrealtime (100 MHz) of workgroup phases, 8 stamps per workgroup
-constexpr int kStampWgs = 16384;
-__device__ unsigned long long g_conv_stamps[kStampWgs * 8];
-__device__ unsigned long long g_conv_phase[kStampWgs * 8];     // wave 0's shader cycles in: DMA wait, barrier, issue, MFMA block; chunks
+// diagnostic build only (tools/conv_stamps.py): s_memrealtime (100 MHz) of workgroup phases, 8 stamps per segment of a
+// workgroup (its first kStampSegs segments), in the launches the host marks (bit 4 of xcd_remap)
+constexpr int kStampWgs = 1024, kStampSegs = 4;
+__device__ unsigned long long g_conv_stamps[kStampWgs * kStampSegs * 16];
+__device__ unsigned long long g_conv_phase[kStampWgs * kStampSegs * 16];     // wave 0's shader cycles in: DMA wait, barrier, issue, MFMA block; chunks
+#define CONV_STAMP_SLOT (((int)blockIdx.x * kStampSegs + seg__) * 16)
+#define CONV_STAMP_ON ((xcd_remap & 16) && threadIdx.x == 0 && (int)blockIdx.x < kStampWgs && seg__ < kStampSegs)
 #define CONV_STAMP(i)                                                                                          \
   do {                                                                                                         \
-    const int wg__ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                           \
-    if (threadIdx.x == 0 && wg__ < kStampWgs) g_conv_stamps[wg__ * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    if (CONV_STAMP_ON) g_conv_stamps[CONV_STAMP_SLOT + (i)] = __builtin_amdgcn_s_memrealtime();                \
   } while (0)
 #else
 #define CONV_STAMP(i) do { } while (0)
@@ -287,10 +384,11 @@ __device__ __forceinline__ void conv_dma_body(
   constexpr int B_INSTR = KC / B_ROWS_PER;
   static_assert(A_INSTR % NW == 0 && B_INSTR % NW == 0 && (BN == 32 || BN == 64 || BN == 128), "tile shape");
   constexpr int BSWZ = BN >= 64 ? 1 : 0;                       // W-row half swap (rows 32 floats wide have no halves to swap)
-  // conv_lds: [stage 0: A|B][stage 1: A|B][Ns 27*BM][kmask (4)][rows BM]
+  // conv_lds: [stage 0: A|B][stage 1: A|B][Ns 27*BM][kmask (8)][rows BM]
   int32_t *Ns = reinterpret_cast<int32_t *>(conv_lds + 2 * ST);
-  unsigned *s_kmask = reinterpret_cast<unsigned *>(Ns + 27 * BM);
-  int32_t *s_rows = reinterpret_cast<int32_t *>(s_kmask + 4);         // output row of every tile slot (-1 = none): the row order
+  unsigned *s_kmask = reinterpret_cast<unsigned *>(Ns + 27 * BM);     // [0..WR-1]: offsets with a neighbour among the 32 rows of row group g; [4]: last-arriver flag
+  int32_t *s_rows = reinterpret_cast<int32_t *>(s_kmask + 8);         // output row of every tile slot (-1 = none): the row order
+  static_assert(NTHR % BM == 0 && WR <= 4, "a thread looks up ONE tile row (tid % BM) under every offset: its mask bits are that row's");
 
   // the launch's problems ("sides": the observed / template backbone of the same layer; one for a plain call): their
   // live row counts and tile counts -- every workgroup needs both to find its place in the common unit sequence
@@ -350,7 +448,13 @@ __device__ __forceinline__ void conv_dma_body(
   if (u > total) u = total;
   const float *zero = reinterpret_cast<const float *>(&g_conv_zero_line);
 
+#ifdef DCL_CONV_STAMPS
+  int seg__ = -1;
+#endif
   while (u < u_end) {
+#ifdef DCL_CONV_STAMPS
+    ++seg__;
+#endif
     int tile, j_begin, nchunks, tile_lo, tile_hi, blk, by;
     bool whole;
     // which side this segment belongs to, and that side's problem (uniform: scalar loads of ONE side's descriptor)
@@ -407,42 +511,78 @@ __device__ __forceinline__ void conv_dma_body(
     const int row0 = blk * BM, col0 = by * BN;
     CONV_STAMP(0);
 #ifdef DCL_CONV_STAMPS
-    {
-      const int wg__ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-      if (threadIdx.x == 0 && wg__ < kStampWgs)
-        g_conv_stamps[wg__ * 8 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) |
-                                      (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // XCC_ID, HW_ID
-    }
+    if (CONV_STAMP_ON)
+      g_conv_stamps[CONV_STAMP_SLOT + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) |
+                                           (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // XCC_ID, HW_ID
 #endif
-    if (tid == 0) *s_kmask = 0;
+    if (tid < 4) s_kmask[tid] = 0;
     constexpr bool ordered = ORD;                          // (natural order: the slot -> row map is arithmetic, no LDS round trip)
     if (ordered)
       for (int rr = tid; rr < BM; rr += NTHR) s_rows[rr] = row0 + rr < n ? ord.order[row0 + rr] : -1;
     __syncthreads();
-    // neighbour rows of the offsets this workgroup's chunk range touches (all 27 without split-K)
+    CONV_STAMP(8);
+    // neighbour rows of the offsets this workgroup's chunk range touches (all 27 without split-K), by COLUMNS of three
+    // z-neighbours (common.h: dcl_nbr_col -- one mask word + one prefix word per column instead of three dependent loads per
+    // neighbour): a work item = (column, tile row); every thread's items are independent loads, all in flight at once
     unsigned mymask = 0;
     const int sx_lo = (j_begin * KC) / CIN;
     const int sx_hi = min(kvol - 1, (nchunks * KC - 1) / CIN);
-#pragma unroll NW == 4 ? 8 : 4                             // several rounds of lookups in flight (2-3 dependent loads each)
-    for (int e = tid; e < (sx_hi - sx_lo + 1) * BM; e += NTHR) {
-      const int si = e / BM, rr = e - si * BM;
-      const int k = offset_at(sx_lo + si, kvol, subm);
+    if (kvol == 27) {
+      unsigned cmask = 0;                                    // columns the segment's steps lie in
+      for (int sx = sx_lo; sx <= sx_hi; ++sx) cmask |= 1u << (offset_at(sx, kvol, subm) / 3);
+      const int ncols = __builtin_popcount(cmask);
+      constexpr int ITEMS = (9 * BM + NTHR - 1) / NTHR;
+      const int rr = tid % BM;                               // this thread's tile row, under every column it looks up
       const int orow = ordered ? s_rows[rr] : (row0 + rr < n ? row0 + rr : -1);
-      const int v = orow >= 0 ? dcl_nbr_at(src, cap, k, orow) : -1;
-      Ns[k * BM + rr] = v;
-      mymask |= (v >= 0 ? 1u : 0u) << k;
-    }
+      const int4 q4 = orow >= 0 ? dcl_nbr_row(src, orow) : make_int4(0, 0, 0, 0);
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) mymask |= __shfl_xor(mymask, d, 64);
-    if (lane == 0 && mymask) atomicOr(s_kmask, mymask);
+      for (int it = 0; it < ITEMS; ++it) {
+        const int ci = tid / BM + it * (NTHR / BM);
+        if (ci >= ncols) break;
+        unsigned m = cmask;
+        for (int q = ci; q > 0; --q) m &= m - 1u;
+        const int col = __builtin_ctz(m);
+        int v[3] = {-1, -1, -1};
+        if (orow >= 0) dcl_nbr_col(src, cap, col, orow, q4, v);
+#pragma unroll
+        for (int kz = 0; kz < 3; ++kz) {
+          Ns[(3 * col + kz) * BM + rr] = v[kz];
+          mymask |= (v[kz] >= 0 ? 1u : 0u) << (3 * col + kz);
+        }
+      }
+    } else {
+#pragma unroll NW == 4 ? 8 : 4
+      for (int e = tid; e < (sx_hi - sx_lo + 1) * BM; e += NTHR) {
+        const int si = e / BM, rr = e - si * BM;
+        const int k = offset_at(sx_lo + si, kvol, subm);
+        const int orow = ordered ? s_rows[rr] : (row0 + rr < n ? row0 + rr : -1);
+        const int v = orow >= 0 ? dcl_nbr_at(src, cap, k, orow) : -1;
+        Ns[k * BM + rr] = v;
+        mymask |= (v >= 0 ? 1u : 0u) << k;
+      }
+    }
+    CONV_STAMP(9);
+    // mymask = the offsets under which THIS thread's tile row (tid % BM) has a neighbour: OR over the 32 rows of a wave's row
+    // group -> the group's mask (what lets a compute wave skip a chunk's MFMA block), OR over the groups -> the tile's
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) mymask |= __shfl_xor(mymask, d, 64);
+    if ((lane & 31) == 0 && mymask) atomicOr(s_kmask + ((tid % BM) >> 5), mymask);
     __syncthreads();
-    const unsigned kmask = *s_kmask;
+    CONV_STAMP(10);
+    unsigned kmask = 0;
+#pragma unroll
+    for (int g = 0; g < WR; ++g) kmask |= s_kmask[g];
+    // offsets (k) -> steps (visiting order, offset_at): the centre offset moves to step 0 for subm
+    auto steps_of = [&](unsigned km) -> unsigned {
+      if (!subm) return km;
+      const int c = kvol / 2;
+      return ((km >> c) & 1u) | ((km & ((1u << c) - 1u)) << 1) | (km & ~((2u << c) - 1u));
+    };
     // ---- chunk control, scalar-light.  Steps (= kernel offsets in visiting order, offset_at) own CPK = CIN/KC chunks
     // each, or a chunk spans SPC = KC/CIN steps (CIN = 16).  `smask` marks the steps whose offset has a neighbour in this
     // tile, `wsmask` those with one among this wave's 32 rows; the next used chunk is a find-first-set away.
     constexpr int CPK = CIN >= KC ? CIN / KC : 1, SPC = CIN >= KC ? 1 : KC / CIN;
-    unsigned smask = 0;
-    for (int sx = 0; sx < kvol; ++sx) smask |= ((kmask >> offset_at(sx, kvol, subm)) & 1u) << sx;
+    const unsigned smask = steps_of(kmask);
     auto next_used = [&](int from) -> int {            // smallest used chunk >= from (or nchunks)
       if (from >= nchunks) return nchunks;
       if constexpr (SPC == 1) {
@@ -539,18 +679,8 @@ __device__ __forceinline__ void conv_dma_body(
       for (int g = 0; g < A_PER; g += AGRP) conv_glds16_group<AGRP>(psrc + g, conv_lds_addr(As + (iwave * A_PER + g) * 256));
     };
     // steps under which at least one of THIS WAVE's 32 rows has a neighbour (wave-level skip of a chunk's MFMA block)
-    unsigned wsmask = 0;
-    {
-      // (the lane's row is made opaque here so that its LDS address is formed per segment: hoisted out of the tile loop
-      // it was the one value the 8-wave variant spilled -- and a kernel with a scratch segment does not get its second
-      // workgroup per CU at dispatch time)
-      int wrow = wr * 32 + r;
-      asm volatile("" : "+v"(wrow));
-      for (int sx = 0; sx < kvol; ++sx)
-          if ((smask >> sx) & 1u)
-            wsmask |= (__ballot(Ns[offset_at(sx, kvol, subm) * BM + wrow] >= 0) != 0ull ? 1u : 0u) << sx;
-    }
-    wsmask = __builtin_amdgcn_readfirstlane(wsmask);
+    const unsigned wsmask = __builtin_amdgcn_readfirstlane(steps_of(s_kmask[wr]));
+    CONV_STAMP(11);
 
     f32x16 acc[NT];
 #pragma unroll
@@ -622,12 +752,10 @@ __device__ __forceinline__ void conv_dma_body(
       cur ^= 1;
     }
 #ifdef DCL_CONV_STAMPS
-    {
-      const int wg__ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-      if (threadIdx.x == 0 && wg__ < kStampWgs) {
-        g_conv_phase[wg__ * 8 + 0] = ph_wait; g_conv_phase[wg__ * 8 + 1] = ph_bar; g_conv_phase[wg__ * 8 + 2] = ph_issue;
-        g_conv_phase[wg__ * 8 + 3] = ph_mfma; g_conv_phase[wg__ * 8 + 4] = ph_n;
-      }
+    if (CONV_STAMP_ON) {
+      g_conv_phase[CONV_STAMP_SLOT + 0] = ph_wait; g_conv_phase[CONV_STAMP_SLOT + 1] = ph_bar; g_conv_phase[CONV_STAMP_SLOT + 2] = ph_issue;
+      g_conv_phase[CONV_STAMP_SLOT + 3] = ph_mfma; g_conv_phase[CONV_STAMP_SLOT + 4] = ph_n;
+      g_conv_phase[CONV_STAMP_SLOT + 5] = ((unsigned long long)(unsigned)tile << 32) | ((unsigned)j_begin << 16) | (unsigned)nchunks;
     }
 #endif
     CONV_STAMP(3);
@@ -671,11 +799,11 @@ __device__ __forceinline__ void conv_dma_body(
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        s_kmask[1] = last;
+        s_kmask[4] = last;
       }
       __syncthreads();
       CONV_STAMP(5);
-      const bool last_arriver = s_kmask[1] != 0;
+      const bool last_arriver = s_kmask[4] != 0;
       if (last_arriver) {
         // split-major: the NT*4 pieces of one split are independent loads in flight together; per element the sum is
         // P_0 + P_1 + ... in split order
@@ -870,10 +998,20 @@ __device__ __forceinline__ void avgpool_body(const DclConvSides &sides, int nsid
     const int n = second ? n1 : n0, cap = S.cap;
     const int row0 = (bi - (second ? nb0 : 0)) * rpb;
     __syncthreads();
-#pragma unroll 4                                           // the lookups of up to 4 rounds in flight together (2 dependent loads each)
-    for (int e = tid; e < rpb * kvol; e += NTB) {
-      const int r2 = e / kvol, k = e - r2 * kvol;
-      s_v[r2 * 27 + k] = row0 + r2 < n ? dcl_nbr_at(S.src, cap, k, row0 + r2) : -1;
+    if (kvol == 27) {                                      // by columns of three z-neighbours (common.h: dcl_nbr_col)
+#pragma unroll 3
+      for (int e = tid; e < rpb * 9; e += NTB) {
+        const int col = e / rpb, r2 = e - col * rpb;
+        int t3[3] = {-1, -1, -1};
+        if (row0 + r2 < n) dcl_nbr_col(S.src, cap, col, row0 + r2, dcl_nbr_row(S.src, row0 + r2), t3);
+        s_v[r2 * 27 + 3 * col] = t3[0]; s_v[r2 * 27 + 3 * col + 1] = t3[1]; s_v[r2 * 27 + 3 * col + 2] = t3[2];
+      }
+    } else {
+#pragma unroll 4
+      for (int e = tid; e < rpb * kvol; e += NTB) {
+        const int r2 = e / kvol, k = e - r2 * kvol;
+        s_v[r2 * 27 + k] = row0 + r2 < n ? dcl_nbr_at(S.src, cap, k, row0 + r2) : -1;
+      }
     }
     __syncthreads();
     const int row = row0 + rr;

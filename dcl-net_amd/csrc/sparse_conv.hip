@@ -17,6 +17,7 @@
 #include <atomic>
 #include <mutex>
 #include <utility>
+#include <array>
 #include <vector>
 
 int dcl_internal_sparse_conv_fwd(const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev,
@@ -65,10 +66,11 @@ __global__ void k_sparse_conv_valu(const float *__restrict__ feat, const DclNbrS
 }
 
 // ---- stem kernel (conv_body.h: conv_stem_body) ------------------------------------------------------------------
-template <int CIN, int COUT>
+template <int CIN, int COUT, int LPR>
 __global__ __launch_bounds__(256) void k_sparse_conv_stem(const DclConvSides sides, int nsides, int kvol, int subm, int relu) {
-  __shared__ __attribute__((aligned(16))) float Ws[2 * 27 * CIN * COUT];         // both sides' filters
-  conv_stem_body<CIN, COUT, 256>(sides, nsides, kvol, subm, relu, Ws, blockIdx.x, gridDim.x);
+  __shared__ __attribute__((aligned(16))) float Ws[2 * 27 * (CIN * COUT + 1)];   // both sides' filters, pitched per offset
+  __shared__ int32_t s_nb[256 * 27];                                             // every lane's 27 neighbour rows
+  conv_stem_body<CIN, COUT, 256, LPR>(sides, nsides, kvol, subm, relu, Ws, s_nb, blockIdx.x, gridDim.x);
 }
 
 
@@ -403,6 +405,9 @@ static bool conv_launch_is_few(const DclConvSides &sides, int nsides) {
 // A/B and tuning switches: process-wide atomics set through dcl_debug_* in the DIAGNOSTIC library (-DDCL_DIAG, tests/_diag/),
 // compile-time constants in the product library -- the product has no hooks, no superseded kernels and no getenv
 DCL_HOOK_INT(g_conv_xcd_remap, 1);   // 0 = plain blockIdx order
+#ifdef DCL_CONV_STAMPS
+static std::atomic<int> g_stamp_select{-1}, g_stamp_count{0};
+#endif
 DCL_HOOK_INT(g_conv_slots, 512);     // workgroups a launch is dealt over (2 x 256 resident slots)
 DCL_HOOK_INT(g_conv_wlds, 1);        // 1 = Cin 16 / 32 -> 32 layers with many rows on the filter-resident kernel, 0 = LDS-DMA kernel
 DCL_HOOK_INT(g_conv_few_tiles, 1);   // 1 = few-row launches on 64-row tiles, 0 = 128-row tiles for every launch
@@ -495,7 +500,15 @@ static DclConvPlan plan_conv_dma(const DclConvSides &sides, int nsides, int CIN,
   bool keep_order = false;
   if (have_order && !deferred && BM == 128) {
     keep_order = true;
-    if (have_bal && CIN >= 32 && (aligned_ns || stream_k) && have_scratch && scratch_floats > kConvCounterWords) {
+    // (round 5: also launches whose tiles would fit ONE round of whole tiles.  An ordered tile's cost is its USED chunks --
+    // 13 to 54 of 54 on the 64 -> 64 layer of 32 crops -- and one round of whole tiles lasted as long as its most expensive
+    // tile: workgroup life 76 us on average, 150 us for the last one; dealt in used chunks every workgroup gets the same share)
+    bool one_round_too = tiles * 2 > kSlots;
+#ifdef DCL_DIAG
+    if (g_conv_order_mode == 3) one_round_too = false;                                         // A/B: the former rule
+#endif
+    if (have_bal && CIN >= 32 && (aligned_ns || stream_k || one_round_too) && have_scratch && scratch_floats > kConvCounterWords &&
+        tiles <= kConvCounterWords && !never) {
       use_bal = 1;
       stream_k = 1;
       aligned_ns = 0;
@@ -518,7 +531,7 @@ template <int CIN, int WR, int WCW, int NT>
 static void launch_conv_dma(const DclConvSides &sides, int nsides, int cout, int kvol, int subm, int relu, float *scratch,
                             long long scratch_floats, int counters_ready, int *counters_state, hipStream_t s) {
   constexpr int BM = 32 * WR, BN = 32 * NT * WCW, KC = 32;
-  const size_t lds = (size_t)(2 * (BM * KC + KC * BN) + 27 * BM + 4 + BM) * sizeof(float);
+  const size_t lds = (size_t)(2 * (BM * KC + KC * BN) + 27 * BM + 8 + BM) * sizeof(float);
   (void)hipFuncSetAttribute((const void *)k_sparse_conv_dma<CIN, WR, WCW, NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
   (void)hipFuncSetAttribute((const void *)k_sparse_conv_dma<CIN, WR, WCW, NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -531,6 +544,15 @@ static void launch_conv_dma(const DclConvSides &sides, int nsides, int cout, int
   }
 #endif
   const DclConvPlan P = plan_conv_dma(sides, nsides, CIN, BM, BN, cout, kvol, scratch != nullptr, scratch_floats, g_conv_slots);
+#ifdef DCL_CONV_STAMPS
+  const int stamp_sel = g_stamp_select.load(), stamp_no = g_stamp_count.fetch_add(1);
+  const int stamp_bit = (stamp_sel < 0 || stamp_sel == stamp_no) ? 16 : 0;
+  if (stamp_bit)
+    fprintf(stderr, "stamped launch %d: Cin %d tile %dx%d sides %d  G %d stream_k %d aligned_ns %d use_bal %d deferred %d tiles %d chunks/tile %d\n",
+            stamp_no, CIN, BM, BN, nsides, P.G, P.stream_k, P.aligned_ns, P.use_bal, P.deferred, P.tiles, P.nchunks);
+#else
+  constexpr int stamp_bit = 0;
+#endif
   float *partial = scratch;
   int32_t *counters = nullptr;
   if (P.split) {
@@ -550,10 +572,10 @@ static void launch_conv_dma(const DclConvSides &sides, int nsides, int cout, int
   for (int i = 0; i < nsides; ++i) any_order = any_order || sd.s[i].ord.order != nullptr;
   if (any_order)
     hipLaunchKernelGGL((k_sparse_conv_dma<CIN, WR, WCW, NT, true>), dim3(P.G), dim3(64 * WR * WCW), lds, s, sd, nsides, cout, kvol,
-                       subm, relu, partial, P.stream_k, P.aligned_ns, (int)g_conv_xcd_remap, counters, P.use_bal);
+                       subm, relu, partial, P.stream_k, P.aligned_ns, (int)g_conv_xcd_remap | stamp_bit, counters, P.use_bal);
   else
     hipLaunchKernelGGL((k_sparse_conv_dma<CIN, WR, WCW, NT, false>), dim3(P.G), dim3(64 * WR * WCW), lds, s, sd, nsides, cout, kvol,
-                       subm, relu, partial, P.stream_k, P.aligned_ns, (int)g_conv_xcd_remap, counters, 0);
+                       subm, relu, partial, P.stream_k, P.aligned_ns, (int)g_conv_xcd_remap | stamp_bit, counters, 0);
   if (P.deferred)
     hipLaunchKernelGGL((k_conv_frag_reduce<WR, WCW, NT>), dim3(P.tiles, WR * WCW * NT), dim3(256), 0, s, partial, sd, nsides, cout,
                        P.nchunks, P.G, P.stream_k, relu);
@@ -640,15 +662,21 @@ DCL_API void dcl_debug_conv_slots(int n) { g_conv_slots = (n >= 64 && n <= 512) 
 DCL_API void dcl_debug_conv_xcd_remap(int on) { g_conv_xcd_remap = on; }
 #endif
 #ifdef DCL_CONV_STAMPS
-extern "C" __attribute__((visibility("default"))) int dcl_debug_conv_stamps(unsigned long long *host, int n_wg, int clear) {
+// host: kStampWgs * kStampSegs * 8 uint64 (the stamps; phase = 1: wave 0's per-phase cycle sums); clear = 1 zeroes both tables
+extern "C" __attribute__((visibility("default"))) int dcl_debug_conv_stamps(unsigned long long *host, int phase, int clear) {
+  constexpr size_t bytes = sizeof(unsigned long long) * kStampWgs * kStampSegs * 16;
   if (clear) {
-    static unsigned long long zeros[kStampWgs * 8];
-    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_conv_stamps), zeros, sizeof(zeros));
+    static unsigned long long zeros[kStampWgs * kStampSegs * 16];
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_conv_phase), zeros, bytes);
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_conv_stamps), zeros, bytes);
   }
-  if (n_wg > kStampWgs) n_wg = kStampWgs;
-  if (clear == 0 && n_wg < 0)
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_conv_phase), sizeof(unsigned long long) * 8 * (-n_wg));
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_conv_stamps), sizeof(unsigned long long) * 8 * n_wg);
+  if (phase) return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_conv_phase), bytes);
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_conv_stamps), bytes);
+}
+// stamp only the n-th LDS-DMA conv launch from now on (n < 0: every launch, each overwriting the last)
+extern "C" __attribute__((visibility("default"))) void dcl_debug_conv_stamps_select(int n) {
+  g_stamp_select = n;
+  g_stamp_count = 0;
 }
 #endif
 // most K-splits a conv launch over `rows` output rows may use (sizes the partial-sum scratch; backbone.hip)
@@ -704,6 +732,7 @@ struct ConvProfile {
   std::mutex mu;
   bool on = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  std::vector<std::array<int32_t, 4>> what;      // per call: cin, cout, subm, sides
 };
 ConvProfile g_conv_prof;
 }  // namespace
@@ -712,24 +741,38 @@ DCL_API int dcl_profile_conv_begin(void) {
   std::lock_guard<std::mutex> lock(g_conv_prof.mu);
   for (auto &e : g_conv_prof.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   g_conv_prof.ev.clear();
+  g_conv_prof.what.clear();
   g_conv_prof.on = true;
   return 0;
 }
 
-DCL_API int dcl_profile_conv_end(double *ms_total_host, int32_t *calls_host) {
+DCL_API int dcl_profile_conv_end_calls(double *ms_total_host, int32_t *calls_host, float *ms_per_call_host,
+                                       int32_t *what_per_call_host, int32_t cap) {
   std::lock_guard<std::mutex> lock(g_conv_prof.mu);
   g_conv_prof.on = false;
   double total = 0.0;
+  int32_t i = 0;
   for (auto &e : g_conv_prof.ev) {
     float ms = 0.f;
     if (hipEventSynchronize(e.second) == hipSuccess && hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) total += ms;
+    if (i < cap) {
+      if (ms_per_call_host) ms_per_call_host[i] = ms;
+      if (what_per_call_host)
+        for (int q = 0; q < 4; ++q) what_per_call_host[4 * i + q] = g_conv_prof.what[i][q];
+    }
+    ++i;
     (void)hipEventDestroy(e.first);
     (void)hipEventDestroy(e.second);
   }
   if (ms_total_host) *ms_total_host = total;
   if (calls_host) *calls_host = (int32_t)g_conv_prof.ev.size();
   g_conv_prof.ev.clear();
+  g_conv_prof.what.clear();
   return 0;
+}
+
+DCL_API int dcl_profile_conv_end(double *ms_total_host, int32_t *calls_host) {
+  return dcl_profile_conv_end_calls(ms_total_host, calls_host, nullptr, nullptr, 0);
 }
 
 static int conv_dispatch(const DclConvSides &sides, int nsides, int cin, int cout, int kvol, int subm, int relu, float *scratch,
@@ -757,6 +800,7 @@ int dcl_internal_sparse_conv_fwd_sides(const DclConvSides &sides, int nsides, in
     (void)hipEventRecord(e1, (hipStream_t)stream);
     std::lock_guard<std::mutex> lock(g_conv_prof.mu);
     g_conv_prof.ev.emplace_back(e0, e1);
+    g_conv_prof.what.push_back({cin, cout, subm, nsides});
   }
   return rc;
 }
@@ -887,10 +931,18 @@ static int conv_dispatch(const DclConvSides &sides_in, int nsides_in, int cin, i
     return 0;
   }
   if (ch.family == DCL_CONV_STEM) {
-    int rows = 0;
-    for (int i = 0; i < nsides; ++i) rows += sides.s[i].n_dev ? sides.s[i].cap : sides.s[i].n_host;
-    hipLaunchKernelGGL((k_sparse_conv_stem<7, 16>), dim3(dcl_grid_1d(rows, 64)), dim3(256), 0, s, sides, nsides, kvol, subm,
-                       relu);
+    int rows = 0, expect = 0;                            // capacity mode: the grid by capacity, the kernel form by the expected rows
+    for (int i = 0; i < nsides; ++i) {
+      rows += sides.s[i].n_dev ? sides.s[i].cap : sides.s[i].n_host;
+      expect += sides.s[i].n_dev ? (sides.s[i].n_host > 0 ? sides.s[i].n_host : sides.s[i].cap) : sides.s[i].n_host;
+    }
+    // many rows: a lane per row; a handful of crops: four lanes per row (conv_body.h: conv_stem_body)
+    if (expect > 49152)
+      hipLaunchKernelGGL((k_sparse_conv_stem<7, 16, 1>), dim3(dcl_grid_1d(rows, 256, 768)), dim3(256), 0, s, sides, nsides, kvol, subm,
+                         relu);
+    else
+      hipLaunchKernelGGL((k_sparse_conv_stem<7, 16, 4>), dim3(dcl_grid_1d(rows, 64, 768)), dim3(256), 0, s, sides, nsides, kvol, subm,
+                         relu);
     DCL_LAUNCH_CHECK();
     return 0;
   }

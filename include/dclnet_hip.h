@@ -505,6 +505,11 @@ int dcl_legacy_permutation_heads(uint32_t *key624, int32_t *pos_io, const int32_
  * event list); do not use under stream capture.                                                                          */
 int dcl_profile_conv_begin(void);
 int dcl_profile_conv_end(double *ms_total_host, int32_t *calls_host);
+/* The same, plus the calls one by one in call order: ms_per_call_host[i] = device milliseconds of call i and
+ * what_per_call_host[4 i ..] = its (Cin, Cout, subm, problems in the launch), for the first `cap` calls (either array may be NULL).
+ * bench.py's `roofline_sparse_conv.layers[]` is taken with it. */
+int dcl_profile_conv_end_calls(double *ms_total_host, int32_t *calls_host, float *ms_per_call_host, int32_t *what_per_call_host,
+                               int32_t cap);
 
 /* ---- DIAGNOSTIC library only (csrc/Makefile `make diag` -> tests/_diag/libdclnet_hip_diag.so, built with -DDCL_DIAG) ----
  * The dcl_debug_* entry points are TEST / TUNING hooks, not part of the operator API and NOT exported by the product library

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
-"""Where a sparse-conv workgroup spends its time: runs one backbone layer on the real active sets (bs 32) with the
-diagnostic library (make -C dcl-net_amd/csrc stamps; in-kernel s_memrealtime stamps, 100 MHz ticks) and prints the average
-phase durations over the workgroups.  usage: DCL_HIP_LIB=tests/_diag/libdclnet_hip_stamps.so tools/conv_stamps.py [level 0-3] [conv|subm] [split]"""
+"""Where the workgroups of ONE LDS-DMA sparse-conv launch of the backbone runner spend their time (the runner's own launches:
+implicit rulebooks, both backbones grouped or one side).  Needs the stamps library (make -C dcl-net_amd/csrc stamps:
+in-kernel s_memrealtime stamps, 100 MHz ticks, 8 per segment of a workgroup).
+usage: DCL_HIP_LIB=tests/_diag/libdclnet_hip_stamps.so tools/conv_stamps.py [launch 0-5] [pair|inp|tmp] [ref|stress] [b]
+launch = index among the LDS-DMA launches of a feature stage: 0 L1 conv 32->32 (pair only), 1 L1 subm 32->64, 2 L2 conv,
+3 L2 subm, 4 L3 conv, 5 L3 subm (one side: L1 conv runs the filter-resident kernel, so 0 = L1 subm, ...)."""
 import ctypes, importlib, os, sys
 import numpy as np
 import torch
@@ -9,78 +12,97 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 dcl = importlib.import_module("dcl-net_amd")
 from _diag import use_diag
-DIAG = use_diag(dcl)          # kernel-variant hooks exist in the diagnostic library only
-ops, sp = dcl.ops, dcl.spconv.ops
-level = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-which = sys.argv[2] if len(sys.argv) > 2 else "subm"
-if len(sys.argv) > 3:
-    ops.N.lib().dcl_debug_conv_split(int(sys.argv[3]))
-b, S = int(os.environ.get("DCL_BENCH_B", "32")), 64
-data = dcl.synth.make_batch(b, 1024, 64)
-aset = ops.grid_from_indices(data["inp"]["occupied_voxels"].int().cuda().contiguous(), b, S)
-chans = [7, 16, 32, 32, 64, 64, 128, 128, 256]
-for lvl in range(level + 1):
-    out, nbr1 = sp.build_rulebook(aset, 3, 1, 1, False)
-    _, nbr2 = sp.build_rulebook(out, 3, 1, 1, True)
-    pool, _ = sp.build_rulebook(out, 3, 2, 1, False)
-    aset = pool
-c0, c1, c2 = chans[2 * level], chans[2 * level + 1], chans[2 * level + 2]
-if which == "conv":
-    nbr, cin, cout, subm, rows_in = nbr1, c0, c1, False, nbr1.max().item() + 1
-else:
-    nbr, cin, cout, subm, rows_in = nbr2, c1, c2, True, out.n
-feat = torch.randn(rows_in, cin, device="cuda")
-W = torch.randn(27, cin, cout, device="cuda") * 0.05
+os.environ.setdefault("DCL_HIP_LIB", os.path.join(ROOT, "tests", "_diag", "libdclnet_hip_stamps.so"))
+DIAG = use_diag(dcl)
+ops = dcl.ops
+sel = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+mode = sys.argv[2] if len(sys.argv) > 2 else "pair"
+shape = sys.argv[3] if len(sys.argv) > 3 else "ref"
+b = int(sys.argv[4]) if len(sys.argv) > 4 else 32
+n_inp, n_tmp = (1024, 1024) if shape == "ref" else (12288, 2048)
+dev = torch.device("cuda:0")
+net = dcl.DCL_Net.Network(dcl.synth.default_cfg(n_inp, n_tmp), mode="test", graph_max_batch=0)
+net.load_state_dict(dcl.synth.synth_state_dict(net, 1))
+net = net.to(dev).eval()
+f = net._fold()
+data = dcl.synth.make_batch(b, n_inp, n_tmp)
+runs, xs, ptrs = {}, {}, {}
+for s in ("inp", "tmp"):
+    occ = data[s]["occupied_voxels"].to(dev).int().contiguous()
+    xs[s] = ops.voxelize_fp(data[s]["feats"].to(dev).float().contiguous(), data[s]["v2p_maps"].to(dev).int().contiguous(), 4)
+    run = ops.BackboneRun(occ, b, 64)
+    run.set_counts(run.counts_dev.cpu().tolist())
+    runs[s], ptrs[s] = run, f["backbone_%s_ptrs" % s]
+
+
+def stage():
+    if mode == "pair":
+        ops.backbone_features_pair(runs["inp"], xs["inp"], ptrs["inp"], runs["tmp"], xs["tmp"], ptrs["tmp"])
+    else:
+        runs[mode].features(xs[mode], *ptrs[mode])
+
+
 lib = ops.N.lib()
+lib.dcl_debug_conv_stamps_select(1 << 20)           # nothing stamped while warming up
 for _ in range(3):
-    ops.sparse_conv(feat, nbr, out.n, W, subm)
+    stage()
 torch.cuda.synchronize()
 lib.dcl_debug_conv_stamps(None, 0, 1)
-a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-a.record()
-ops.sparse_conv(feat, nbr, out.n, W, subm)
-e.record()
+lib.dcl_debug_conv_stamps_select(sel)
+stage()
 torch.cuda.synchronize()
-n_wg = 16384
-buf = np.zeros((n_wg, 8), np.uint64)
-lib.dcl_debug_conv_stamps(buf.ctypes.data_as(ctypes.c_void_p), n_wg, 0)
-live = buf[buf[:, 0] > 0].astype(np.int64)
-if len(live) == 0:
-    sys.exit("layer L%d %s %d->%d: no stamps -- this launch ran a kernel family without them (filter-resident / stem)" % (level, which, cin, cout))
-t0 = live[:, 0].min()
-names = ["nbr table", "first fetch", "chunk loop", "publish", "ticket", "combine/exit"]
-print("layer L%d %s %d->%d rows %d: %.1f us, %d workgroups stamped" % (level, which, cin, cout, out.n, a.elapsed_time(e) * 1e3, len(live)))
-tick = 0.01                                         # s_memrealtime runs at 100 MHz: us per tick
-for i, nm in enumerate(names):
-    d = (live[:, i + 1] - live[:, i])
-    ok = (live[:, i + 1] > 0) & (live[:, i] > 0)
+WG, SEG = 1024, 4
+st = np.zeros((WG, SEG, 16), np.uint64)
+ph = np.zeros((WG, SEG, 16), np.uint64)
+lib.dcl_debug_conv_stamps(st.ctypes.data_as(ctypes.c_void_p), 0, 0)
+lib.dcl_debug_conv_stamps(ph.ctypes.data_as(ctypes.c_void_p), 1, 0)
+st, ph = st.astype(np.int64), ph.astype(np.float64)
+live = st[:, :, 0] > 0
+if not live.any():
+    sys.exit("no stamps: launch %d of this stage is not an LDS-DMA launch" % sel)
+tick = 0.01                                          # us per tick
+t0 = st[:, :, 0][live].min()
+end_all = st[:, :, 1:7].max()
+print("launch %d (%s, %s, b=%d): %d workgroups, %d segments; first start -> last end %.1f us" % (
+    sel, mode, shape, b, int(live.any(1).sum()), int(live.sum()), (end_all - t0) * tick))
+names = ["head: rows + nbr table + masks", "first operand fetch", "chunk loop", "publish partial", "ticket", "combine + epilogue"]
+for sg in range(SEG):
+    L = live[:, sg]
+    if not L.any():
+        continue
+    S = st[L, sg]
+    print(" segment %d: %d workgroups, starts %.1f..%.1f us after the launch's first" % (
+        sg, int(L.sum()), (S[:, 0].min() - t0) * tick, (S[:, 0].max() - t0) * tick))
+    for i, nm in enumerate(names):
+        ok = (S[:, i + 1] > 0) & (S[:, i] > 0)
+        if ok.any():
+            d = (S[ok, i + 1] - S[ok, i]) * tick
+            print("   %-32s avg %7.2f  p50 %7.2f  max %7.2f us  (n=%d)" % (nm, d.mean(), np.median(d), d.max(), int(ok.sum())))
+    for a, z, nm in ((0, 8, "  rows + first barrier"), (8, 9, "  table loop (look-ups -> LDS)"), (9, 10, "  mask reduce + barrier"),
+                     (10, 11, "  step masks (27 ballots)"), (11, 1, "  accumulators, first chunk pick")):
+        ok = (S[:, z] > 0) & (S[:, a] > 0)
+        if ok.any():
+            d = (S[ok, z] - S[ok, a]) * tick
+            print("   %-32s avg %7.2f  p50 %7.2f  max %7.2f us" % (nm, d.mean(), np.median(d), d.max()))
+    e = S[:, 1:7].max(1)
+    # a whole-tile segment's epilogue (stores) lies after stamp 3 and carries no stamp of its own
+    print("   segment life (to its last stamp)  avg %7.2f us" % ((e - S[:, 0]).mean() * tick))
+    P = ph[L, sg]
+    ok = P[:, 4] > 0
     if ok.any():
-        print("  %-14s avg %7.2f us  max %7.2f us  (n=%d)" % (nm, d[ok].mean() * tick, d[ok].max() * tick, ok.sum()))
-end = live[:, 1:].max(axis=1)
-print("  (stamps are overwritten per segment: all figures are those of each workgroup's LAST segment)")
-print("  last-segment life avg %.2f us; first start -> last end %.2f us; starts spread %.2f us" % (
-    ((end - live[:, 0]).mean()) * tick, (end.max() - t0) * tick, (live[:, 0].max() - t0) * tick))
-st = np.sort(live[:, 0] - t0) * tick
-print("  last-segment starts by 20-us bucket:", np.histogram(st, bins=np.arange(0, st.max() + 20, 20))[0].tolist())
-ev = sorted([(x, 1) for x in (live[:, 0] - t0)] + [(x, -1) for x in (end - t0)])
-cur = peak = 0
-for _, d in ev:
-    cur += d
-    peak = max(peak, cur)
-print("  peak concurrent last segments: %d" % peak)
-hw = buf[buf[:, 0] > 0][:, 7]
-xcc, hwid = (hw >> np.uint64(32)).astype(np.int64) & 0xF, hw.astype(np.int64) & 0xFFFFFFFF
-cu_key = xcc * 100000 + ((hwid >> 8) & 0xF) * 1000 + ((hwid >> 13) & 0x7) * 100 + ((hwid >> 12) & 1) * 50   # cu_id, se_id, sh_id
-print("  distinct (xcc, se, sh, cu): %d; workgroups per XCC: %s" % (len(set(cu_key.tolist())), np.bincount(xcc, minlength=8).tolist()))
-ph = np.zeros((n_wg, 8), np.uint64)
-lib.dcl_debug_conv_stamps(ph.ctypes.data_as(ctypes.c_void_p), -n_wg, 0)
-ph = ph[buf[:, 0] > 0].astype(np.float64)
-ok = ph[:, 4] > 0
-if ok.any():
-    per = ph[ok, :4] / ph[ok, 4:5]
-    loop_us = ((live[:, 3] - live[:, 2]) * tick)[ok]
-    cyc = ph[ok, :4].sum(1)
-    print("  per chunk (wave 0, shader cycles): DMA wait %.0f  barrier %.0f  issue %.0f  MFMA block %.0f  | chunks/wg %.1f | clock %.2f GHz" % (
-        per[:, 0].mean(), per[:, 1].mean(), per[:, 2].mean(), per[:, 3].mean(), ph[ok, 4].mean(), (cyc / (loop_us * 1e3)).mean()))
-last = live[:, 6] > 0
-print("  last arrivers: %d" % int(last.sum()))
+        per = P[ok, :4] / P[ok, 4:5]
+        loop_us = ((S[:, 3] - S[:, 2]) * tick)[ok]
+        cyc = P[ok, :4].sum(1)
+        good = loop_us > 0
+        print("   per chunk (wave 0, shader cycles): DMA wait %.0f  barrier %.0f  issue %.0f  MFMA block %.0f | used chunks %.1f | clock %.2f GHz" % (
+            per[:, 0].mean(), per[:, 1].mean(), per[:, 2].mean(), per[:, 3].mean(), P[ok, 4].mean(),
+            (cyc[good] / (loop_us[good] * 1e3)).mean() if good.any() else float("nan")))
+# per workgroup: time inside segments vs life of the workgroup
+first = np.where(live, st[:, :, 0], np.iinfo(np.int64).max).min(1)
+last = np.where(live, st[:, :, 1:7].max(2), 0).max(1)
+w = live.any(1)
+life = (last[w] - first[w]) * tick
+print(" workgroup life avg %.1f us (min %.1f max %.1f); ends spread: p50 %.1f  p90 %.1f  max %.1f us after the launch's first start" % (
+    life.mean(), life.min(), life.max(), *[np.percentile((last[w] - t0) * tick, q) for q in (50, 90, 100)]))
+starts = (first[w] - t0) * tick
+print(" workgroup starts: p50 %.1f  p90 %.1f  max %.1f us" % (np.percentile(starts, 50), np.percentile(starts, 90), starts.max()))
