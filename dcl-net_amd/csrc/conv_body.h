@@ -99,54 +99,67 @@ __device__ __forceinline__ void conv_stem_body(const DclConvSides &sides, int ns
     const float *wside = Ws + second * 27 * WP;
     const float *__restrict__ feat = S.feat;
     const int centre = kvol / 2;
-    // this lane's neighbours: all present ones (LPR = 1) or number g, g + 4, ... of them in visiting order
     bool centre_first = subm && ((present >> centre) & 1u);
-    unsigned mine = present;
-    if (LPR > 1) {
-      mine = 0;
-      unsigned rest = present;
-      int turn = 0;
-      if (centre_first) { if (g == 0) mine |= 1u << centre; rest &= ~(1u << centre); turn = 1; }
-      while (rest) {
-        const int k = __builtin_ctz(rest);
-        rest &= rest - 1u;
-        if (((turn++) & (LPR - 1)) == g) mine |= 1u << k;
+    if constexpr (LPR == 1) {
+      // many rows: every present neighbour in visiting order; other waves hide the latency of the row loads
+      while (present) {
+        int k;
+        if (centre_first) { k = centre; centre_first = false; } else { k = __builtin_ctz(present); }
+        present &= ~(1u << k);
+        const int v = nb[k];
+        float f[CIN];
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) f[ci] = feat[(size_t)v * CIN + ci];
+        const float *w = wside + k * WP;
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+          float part = 0.0f;
+#pragma unroll
+          for (int ci = 0; ci < CIN; ++ci) part = __fmaf_rn(f[ci], w[ci * COUT + co], part);
+          acc[co] = acc[co] + part;
+        }
       }
-      centre_first = centre_first && g == 0;
-    }
-    auto next_k = [&]() -> int {                         // visiting order: the centre first for subm, then ascending k
-      int k;
-      if (centre_first) { k = centre; centre_first = false; } else { k = __builtin_ctz(mine); }
-      mine &= ~(1u << k);
-      return k;
-    };
-    auto add_offset = [&](const float (&f)[CIN], int k) {
-      const float *w = wside + k * WP;
-#pragma unroll
-      for (int co = 0; co < COUT; ++co) {
-        float part = 0.0f;
-#pragma unroll
-        for (int ci = 0; ci < CIN; ++ci) part = __fmaf_rn(f[ci], w[ci * COUT + co], part);
-        acc[co] = acc[co] + part;
+    } else {
+      // a handful of crops: this lane takes the present neighbours number g, g + 4, ... (visiting order), two rows in flight per
+      // round (a chain of latencies otherwise), added in visiting order
+      unsigned mine = 0;
+      {
+        unsigned rest = present;
+        int turn = 0;
+        if (centre_first) { if (g == 0) mine |= 1u << centre; rest &= ~(1u << centre); turn = 1; }
+        while (rest) {
+          const int k = __builtin_ctz(rest);
+          rest &= rest - 1u;
+          if (((turn++) & (LPR - 1)) == g) mine |= 1u << k;
+        }
+        centre_first = centre_first && g == 0;
       }
-    };
-    while (mine) {                                       // LPR = 4: two neighbours' rows in flight per round (a chain of latencies otherwise); added in visiting order
-      const int ka = next_k();
-      if (LPR == 1) {                                    // many rows: other waves hide the latency, a second row in flight only costs
-        const int va = nb[ka];
-        float fa[CIN];
+      auto next_k = [&]() -> int {
+        int k;
+        if (centre_first) { k = centre; centre_first = false; } else { k = __builtin_ctz(mine); }
+        mine &= ~(1u << k);
+        return k;
+      };
+      auto add_offset = [&](const float (&f)[CIN], int k) {
+        const float *w = wside + k * WP;
 #pragma unroll
-        for (int ci = 0; ci < CIN; ++ci) fa[ci] = feat[(size_t)va * CIN + ci];
+        for (int co = 0; co < COUT; ++co) {
+          float part = 0.0f;
+#pragma unroll
+          for (int ci = 0; ci < CIN; ++ci) part = __fmaf_rn(f[ci], w[ci * COUT + co], part);
+          acc[co] = acc[co] + part;
+        }
+      };
+      while (mine) {
+        const int ka = next_k();
+        const int kb = mine ? next_k() : -1;
+        const int va = nb[ka], vb = nb[kb >= 0 ? kb : ka];
+        float fa[CIN], fb[CIN];
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) { fa[ci] = feat[(size_t)va * CIN + ci]; fb[ci] = feat[(size_t)vb * CIN + ci]; }
         add_offset(fa, ka);
-        continue;
+        if (kb >= 0) add_offset(fb, kb);
       }
-      const int kb = mine ? next_k() : -1;
-      const int va = nb[ka], vb = nb[kb >= 0 ? kb : ka];
-      float fa[CIN], fb[CIN];
-#pragma unroll
-      for (int ci = 0; ci < CIN; ++ci) { fa[ci] = feat[(size_t)va * CIN + ci]; fb[ci] = feat[(size_t)vb * CIN + ci]; }
-      add_offset(fa, ka);
-      if (kb >= 0) add_offset(fb, kb);
     }
     if (LPR == 4) {
 #pragma unroll
@@ -185,6 +198,21 @@ __device__ __forceinline__ void conv_stem_body(const DclConvSides &sides, int ns
     }
   }
 }
+#ifdef DCL_CONV_STAMPS
+// diagnostic build only (tools/conv_stamps.py): s_memrealtime (100 MHz) of workgroup phases, 8 stamps per segment of a
+// workgroup (its first kStampSegs segments), in the launches the host marks (bit 4 of xcd_remap)
+constexpr int kStampWgs = 1024, kStampSegs = 4;
+__device__ unsigned long long g_conv_stamps[kStampWgs * kStampSegs * 16];
+__device__ unsigned long long g_conv_phase[kStampWgs * kStampSegs * 16];     // wave 0's shader cycles in: DMA wait, barrier, issue, MFMA block; chunks
+#define CONV_STAMP_SLOT (((int)blockIdx.x * kStampSegs + seg__) * 16)
+#define CONV_STAMP_ON ((xcd_remap & 16) && threadIdx.x == 0 && (int)blockIdx.x < kStampWgs && seg__ < kStampSegs)
+#define CONV_STAMP(i)                                                                                          \
+  do {                                                                                                         \
+    if (CONV_STAMP_ON) g_conv_stamps[CONV_STAMP_SLOT + (i)] = __builtin_amdgcn_s_memrealtime();                \
+  } while (0)
+#else
+#define CONV_STAMP(i) do { } while (0)
+#endif
 // ---- MFMA kernel with the WHOLE filter resident in LDS: the wide, shallow layers (Cin 16 / 32 -> Cout 32) -----------------
 // The first two MFMA layers of a backbone have the most rows (10^5 at 32 crops) and the fewest channels: 27 * Cin * 32 floats
 // of weights are 54 / 108 KiB -- they fit the CU's LDS whole.  In the LDS-DMA implicit GEMM these layers were bound by the
@@ -310,21 +338,6 @@ __device__ __forceinline__ void conv_wlds_body(const DclConvSides &sides, int ns
 // contiguous LDS, bank conflicts are avoided by swizzling instead of padding: the 16-B column c of row r is stored at
 // column c ^ (r & 15) (A), and W rows with bit 2 of their index set swap their 32-column halves (B).
 __device__ float4 g_conv_zero_line = {0.f, 0.f, 0.f, 0.f};
-#ifdef DCL_CONV_STAMPS
-// diagnostic build only (tools/conv_stamps.py): s_memrealtime (100 MHz) of workgroup phases, 8 stamps per segment of a
-// workgroup (its first kStampSegs segments), in the launches the host marks (bit 4 of xcd_remap)
-constexpr int kStampWgs = 1024, kStampSegs = 4;
-__device__ unsigned long long g_conv_stamps[kStampWgs * kStampSegs * 16];
-__device__ unsigned long long g_conv_phase[kStampWgs * kStampSegs * 16];     // wave 0's shader cycles in: DMA wait, barrier, issue, MFMA block; chunks
-#define CONV_STAMP_SLOT (((int)blockIdx.x * kStampSegs + seg__) * 16)
-#define CONV_STAMP_ON ((xcd_remap & 16) && threadIdx.x == 0 && (int)blockIdx.x < kStampWgs && seg__ < kStampSegs)
-#define CONV_STAMP(i)                                                                                          \
-  do {                                                                                                         \
-    if (CONV_STAMP_ON) g_conv_stamps[CONV_STAMP_SLOT + (i)] = __builtin_amdgcn_s_memrealtime();                \
-  } while (0)
-#else
-#define CONV_STAMP(i) do { } while (0)
-#endif
 typedef __attribute__((address_space(3))) void conv_lds_void_t;
 __device__ __forceinline__ void conv_glds16(const void *gsrc, unsigned lds_byte_addr) {
   unsigned keep;

@@ -841,7 +841,7 @@ static DclConvChoice conv_choose(const DclConvSides &sides, int nsides, int cin,
     // (the 32 -> 64 layer as two 32-column halves -- instantiated, measured, not used: 99 us against the DMA kernel's 86)
     // Two sides in one call (one-stream schedule): the 16-channel layer goes out as a launch per side (44 us each against 105
     // for the grouped LDS-DMA launch), the 32-channel one keeps the grouped LDS-DMA launch (72 us against 2 x 48).
-    const bool wlds32 = ((cin == 32 && cout == 32 && nsides == 1) || (g_conv_wlds == 2 && cout == 64 && cin == 32));
+    const bool wlds32 = ((cin == 32 && cout == 32 && (nsides == 1 || g_conv_wlds == 3)) || (g_conv_wlds == 2 && cout == 64 && cin == 32));
     if (g_conv_wlds != 0 && ((cout == 32 && cin == 16) || wlds32) && kvol == 27 && !is_few) {
       c.family = DCL_CONV_WLDS;
       return c;
