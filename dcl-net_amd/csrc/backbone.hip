@@ -422,7 +422,8 @@ static int backbone_features(const SideArgs *sd, int nsides, int batch, int S, c
           rc = source(i, at<int32_t>(a.ws, p.indices), np_dev, np, at<uint32_t>(a.ws, c.mask), at<int32_t>(a.ws, c.wprefix),
                       nullptr, 2, &Sd.src);
           if (rc) return rc;
-          Sd.feat = x2; Sd.out = a.level_out[m]; Sd.cap = np; Sd.n_dev = np_dev; Sd.n_host = np_dev ? 0 : np;
+          Sd.feat = x2; Sd.out = a.level_out[m]; Sd.cap = np; Sd.n_dev = np_dev;
+          Sd.n_host = np_dev ? (expect_rows(batch, m, 4 * np) + 3) / 4 : np;      // (a pooled set holds about a quarter of its conv set's rows)
           Sd.ord = DclRowOrder{nullptr, nullptr, nullptr};
         }
         ++ns;

@@ -982,7 +982,7 @@ __device__ __forceinline__ void conv_frag_reduce_body(const float *__restrict__ 
 // thread = (output row, 4 channels): rf = #valid offsets (summaryRF.cu:39), then
 // out = ((0 + f_k0/rf) + f_k1/rf) + ... in ascending offset order (avgpool.cu:130).
 // NTB = threads of the workgroup; item = blockIdx.x of nitems = gridDim.x, row blocks round-robin.
-template <int NTB>
+template <int NTB, int PF>
 __device__ __forceinline__ void avgpool_body(const DclConvSides &sides, int nsides, int c, int kvol, int32_t *__restrict__ rf_out,
                                              const int32_t *__restrict__ rf_in, int32_t *s_v /* LDS: 64 * 27 ints */, int item,
                                              int nitems) {
@@ -1041,7 +1041,8 @@ __device__ __forceinline__ void avgpool_body(const DclConvSides &sides, int nsid
     // and of 27 were measured too: 24 / 21 / 20 / 12 us for the four pools of 32 crops either way -- 27 in flight cost the
     // occupancy that 9 lacked in depth -- against 19 / 17 / 16 / 12 with two rounds of 14.  The kernel is bound by its chain of
     // dependent loads, not by the 108 divisions per thread: a three-instruction exact division changed nothing.)
-    constexpr int PF = 14;
+    // (PF = 27, the whole window in one round, for launches of a few thousand rows: there the launch IS its chain of dependent
+    //  loads and nothing else runs on the CU)
     for (int k0 = 0; k0 < kvol; k0 += PF) {
       float4 f[PF];
 #pragma unroll

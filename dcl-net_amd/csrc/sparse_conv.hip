@@ -614,10 +614,11 @@ static void launch_conv_tile(int rows, const float *feat, const DclNbrSrc &nbr, 
 #endif  // DCL_DIAG
 
 // ---- sparse average pool (conv_body.h: avgpool_body) ----------------------------------------------------------------
+template <int PF>
 __global__ __launch_bounds__(256) void k_sparse_avgpool(const DclConvSides sides, int nsides, int c, int kvol,
                                                         int32_t *__restrict__ rf_out, const int32_t *__restrict__ rf_in) {
   __shared__ int32_t s_v[64 * 27];
-  avgpool_body<256>(sides, nsides, c, kvol, rf_out, rf_in, s_v, blockIdx.x, gridDim.x);
+  avgpool_body<256, PF>(sides, nsides, c, kvol, rf_out, rf_in, s_v, blockIdx.x, gridDim.x);
 }
 
 
@@ -1038,7 +1039,7 @@ int dcl_internal_sparse_avgpool_fwd_sides(const DclConvSides &sides_in, int nsid
   DCL_CHECK_ARG(nsides_in >= 1 && nsides_in <= 2 && c > 0 && kvol > 0 && kvol <= 27 && (nsides_in == 1 || (!rf && !rf_in)));
   DclConvSides sides{};
   int nsides = 0;
-  long long rows = 0;
+  long long rows = 0, expect = 0;                        // capacity mode: the grid by capacity, the kernel form by the expected rows
   for (int i = 0; i < nsides_in; ++i) {
     const DclConvSide &S = sides_in.s[i];
     DCL_CHECK_ARG(S.feat && (S.src.nbr || (S.src.out_indices && S.src.in_mask && S.src.in_wprefix && kvol == 27)) && S.out && S.cap > 0);
@@ -1046,13 +1047,17 @@ int dcl_internal_sparse_avgpool_fwd_sides(const DclConvSides &sides_in, int nsid
     if (S.n_dev || S.n_host > 0) {
       sides.s[nsides++] = S;
       rows += S.n_dev ? S.cap : S.n_host;
+      expect += S.n_dev ? (S.n_host > 0 ? S.n_host : S.cap) : S.n_host;
     }
   }
   if (nsides == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const int c4 = c / 4;
   if (c % 4 == 0 && c4 >= 4 && c4 <= 64 && 256 % c4 == 0) {
-    hipLaunchKernelGGL(k_sparse_avgpool, dim3(dcl_grid_1d(rows * c4, 256, 2048)), dim3(256), 0, s, sides, nsides, c, kvol, rf, rf_in);
+    if (expect * c4 <= 256 * 512)                          // at most two workgroups per CU: one round of 27 gathers
+      hipLaunchKernelGGL(k_sparse_avgpool<27>, dim3(dcl_grid_1d(rows * c4, 256, 2048)), dim3(256), 0, s, sides, nsides, c, kvol, rf, rf_in);
+    else
+      hipLaunchKernelGGL(k_sparse_avgpool<14>, dim3(dcl_grid_1d(rows * c4, 256, 2048)), dim3(256), 0, s, sides, nsides, c, kvol, rf, rf_in);
   } else {
     for (int i = 0; i < nsides; ++i) {
       const DclConvSide &S = sides.s[i];
