@@ -985,13 +985,16 @@ def crop_points(depth, label, rgb, boxes, obj_ids, cam, rgb_mean, half_extent, m
     col = torch.empty((n, cap, 3), dtype=torch.float32, device=dev)
     centroid = torch.empty((n, 3), dtype=torch.float32, device=dev)
     counts = torch.zeros((n, 3), dtype=torch.int32, device=dev)
+    ws_ints = C.c_int64(0)
+    N.check(N.lib().dcl_crop_points_ws_ints(n, int(cap), C.byref(ws_ints)), "crop_points_ws_ints")
+    ws = torch.empty(max(int(ws_ints.value), 1), dtype=torch.int32, device=dev)
     cam_a = (C.c_float * 6)(*([float(v) for v in cam] + [1.0])[:6])
     mean_a = (C.c_double * 3)(*[float(v) for v in rgb_mean])
     he_a = (C.c_float * 3)(*[float(v) for v in half_extent])
     N.check(N.lib().dcl_crop_points(N.ptr(depth), N.ptr(label), N.ptr(rgb), H, W, rgb.shape[2], n, N.ptr(boxes),
                                     N.ptr(obj_ids), cam_a, mean_a, he_a, int(min_valid), int(bool(always_filter)), cap,
                                     N.ptr(raw_xyz),
-                                    N.ptr(raw_rgb), N.ptr(xyz), N.ptr(col), N.ptr(centroid), N.ptr(counts), N.stream()),
+                                    N.ptr(raw_rgb), N.ptr(xyz), N.ptr(col), N.ptr(centroid), N.ptr(counts), N.ptr(ws), N.stream()),
             "crop_points")
     return xyz, col, centroid, counts
 

@@ -449,7 +449,8 @@ int dcl_voxelize_bp(const float *d_out, const int32_t *rules, float *d_feats_zer
  * The per-object crop construction of the data loaders (YCBV/dataloader_test_YCBV.py:124-183), on the device, in the
  * reference's pixel order and float32/float64 arithmetic (results bit-identical to the numpy/torch code).
  *
- * dcl_crop_points (one workgroup per instance): pixels of box [rmin,rmax) x [cmin,cmax) with label == obj_ids[i] and
+ * dcl_crop_points (three launches: one workgroup per 4096-pixel chunk of a box -- one workgroup per instance for the
+ * sequential centroid sum -- one workgroup per 4096-row chunk): pixels of box [rmin,rmax) x [cmin,cmax) with label == obj_ids[i] and
  * depth != 0, in ascending flat order (:128-133); back-projection pt2 = d/scale, pt0 = (col-cx)*pt2/fx,
  * pt1 = (row-cy)*pt2/fy (:147-154); rgb = float(double(float(v)/255) - mean) (:143-145); centroid = row-order running
  * float32 sum / n (np.mean(axis=0), :156); points centred; those with |x|,|y|,|z| < half_extent kept when more than
@@ -459,12 +460,14 @@ int dcl_voxelize_bp(const float *d_out, const int32_t *rules, float *d_feats_zer
  *   post_div after back-projection (1000 for LineMOD, LM/dataloader_test_LM.py:156-160; 1 for YCB-V); always_filter: apply
  *   the grid filter whatever the count (LM eval mode, :197); cap >= every box area.
  *   raw_xyz/raw_rgb: scratch (n,cap,3); out_xyz/out_rgb (n,cap,3); centroid (n,3);
- *   counts (n,3) = {masked pixels, points inside the grid, rows written} (all zero: the reference skips the instance). */
+ *   counts (n,3) = {masked pixels, points inside the grid, rows written} (all zero: the reference skips the instance);
+ *   ws: dcl_crop_points_ws_ints(n, cap) int32 of device scratch (chunk counts and offsets; zeroed by the call). */
+int dcl_crop_points_ws_ints(int n_inst, int cap, int64_t *ints_host);
 int dcl_crop_points(const uint16_t *depth, const int32_t *label, const uint8_t *rgb, int H, int W, int rgb_channels,
                     int n_inst, const int32_t *boxes, const int32_t *obj_ids, const float *cam_host,
                     const double *rgb_mean_host, const float *half_extent_host, int min_valid, int always_filter, int cap,
                     float *raw_xyz, float *raw_rgb, float *out_xyz, float *out_rgb, float *centroid,
-                    int32_t *counts, dclStream_t stream);
+                    int32_t *counts, int32_t *ws, dclStream_t stream);
 /* Sampled points -> feats rows [1,r,g,b,x,y,z] (n*npoint,7) and voxelize_idx input rows [instance,ix,iy,iz] (n*npoint,4)
  * i64 (:166-176,186-190): voxel = trunc((xyz + half_extent0)/unit) in float32, clamped to [0,voxel_limit-1] first for
  * instances with counts[i][1] <= min_valid.  sample_idx (n,npoint) i64 = the caller's np.random.choice draws (NULL:
