@@ -512,3 +512,32 @@ def test_tail_side_by_side_equals_serial_tail(dcl):
         for k in ("rot_pred", "trans_pred", "conf"):
             assert torch.equal(res[False, path][k], res[True, path][k]), (path, k)
 
+
+
+def test_two_gpu_bench_over_rccl_when_the_box_has_two():
+    """the first multi-GPU run must be boring.  On a lease with >= 2 GPUs this starts bench.py the way the
+    driver does (torch.distributed.run, one rank per GPU, RCCL) for 3 steps and checks what the collective library saw: world 2,
+    backend nccl, two distinct devices, and a metric all-reduce that lost no frame (2 x 32).  Skipped on a 1-GPU lease -- there
+    the only RCCL path ever exercised is world = 1 (profiles/r2_rccl_smoke_world1.log)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (this lease has %d)" % torch.cuda.device_count())
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-extras",
+           "--no-traffic"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    rc = line["rccl"]
+    assert rc["world"] == 2 and rc["backend"] == "nccl" and rc["initialized"]
+    assert len(set(rc["device_per_rank"])) == 2
+    assert line["metric_frames_reduced"] == 64

@@ -148,6 +148,56 @@ def test_sparse_conv_matches_oracle(request, dcl, oracle, cin, cout, subm):
     assert np.abs(got2 - np.maximum(want * s + t, 0)).max() <= 2 * tol
 
 
+def test_conv_layers_of_a_32_crop_batch_op_by_op_match_the_oracle(dcl, oracle):
+    """the conv / pool ops called LAYER BY LAYER on the real active sets of 32 crops (explicit gather tables, the op-level
+    path tools/bench_conv.py profiles: profiles/*_conv_layers_kernel_stats.csv) -- every layer's output against the oracle's
+    indice_conv / indice_avgpool on the same inputs; the deep levels also in the runner's row order"""
+    ops, sp = dcl.ops, dcl.spconv.ops
+    b, S = 32, 64
+    data = dcl.synth.make_batch(b, 1024, 64)
+    occ = data["inp"]["occupied_voxels"].int()
+    aset = ops.grid_from_indices(occ.cuda().contiguous(), b, S)
+    idx_in = occ.numpy()
+    chans = [7, 16, 32, 32, 64, 64, 128, 128, 256]
+    rng = np.random.default_rng(5)
+    feat = rng.normal(size=(occ.shape[0], 7)).astype(np.float32)
+    for lvl in range(4):
+        c0, c1, c2 = chans[2 * lvl], chans[2 * lvl + 1], chans[2 * lvl + 2]
+        out, nbr1 = sp.build_rulebook(aset, 3, 1, 1, False)
+        _, nbr2 = sp.build_rulebook(out, 3, 1, 1, True)
+        pool, nbr3 = sp.build_rulebook(out, 3, 2, 1, False)
+        o_ids, o_pairs, o_num, oshape = oracle.get_indice_pairs(idx_in, b, [S] * 3, 3, 1, 1, 1, subm=False)
+        assert np.array_equal(out.indices[:out.n].cpu().numpy(), o_ids)
+        W1 = (rng.normal(size=(3, 3, 3, c0, c1)) / np.sqrt(9 * c0)).astype(np.float32)
+        W2 = (rng.normal(size=(3, 3, 3, c1, c2)) / np.sqrt(9 * c1)).astype(np.float32)
+        want1 = np.maximum(oracle.indice_conv(feat, W1, o_pairs, o_num, o_ids.shape[0], subm=False), 0)
+        got1 = ops.sparse_conv(cuda(feat), nbr1, out.n, cuda(W1).reshape(27, c0, c1).contiguous(), False, relu=True,
+                               scale=torch.ones(c1, device="cuda"), shift=torch.zeros(c1, device="cuda"))
+        tol = 2e-5 * max(1.0, np.abs(want1).max())
+        assert np.abs(got1.cpu().numpy() - want1).max() <= tol, (lvl, "conv")
+        s_ids, s_pairs, s_num, _ = oracle.get_indice_pairs(o_ids, b, oshape, 3, 1, 1, 1, subm=True)
+        want2 = oracle.indice_conv(want1, W2, s_pairs, s_num, o_ids.shape[0], subm=True)
+        W2d = cuda(W2).reshape(27, c1, c2).contiguous()
+        x1 = cuda(want1)
+        got2 = ops.sparse_conv(x1, nbr2, out.n, W2d, True)
+        tol2 = 2e-5 * max(1.0, np.abs(want2).max())
+        assert np.abs(got2.cpu().numpy() - want2).max() <= tol2, (lvl, "subm")
+        if lvl >= 2:                                            # the runner's row order for the deep levels
+            order = ops.order_rows(out, out.mask, True)
+            got2o = ops.sparse_conv(x1, nbr2, out.n, W2d, True, order=order)
+            assert np.abs(got2o.cpu().numpy() - want2).max() <= tol2, (lvl, "subm ordered")
+            order1 = ops.order_rows(out, aset.mask, False)
+            got1o = ops.sparse_conv(cuda(feat), nbr1, out.n, cuda(W1).reshape(27, c0, c1).contiguous(), False, relu=True,
+                                    scale=torch.ones(c1, device="cuda"), shift=torch.zeros(c1, device="cuda"), order=order1)
+            assert np.abs(got1o.cpu().numpy() - want1).max() <= tol, (lvl, "conv ordered")
+        p_ids, p_pairs, p_num, pshape = oracle.get_indice_pairs(o_ids, b, oshape, 3, 2, 1, 1, subm=False)
+        want3, _ = oracle.indice_avgpool(want2, p_pairs, p_num, p_ids.shape[0])
+        got3 = ops.sparse_avgpool(cuda(want2), nbr3, pool.n)
+        assert np.array_equal(pool.indices[:pool.n].cpu().numpy(), p_ids)
+        assert np.array_equal(got3.cpu().numpy(), want3), (lvl, "pool")
+        feat, idx_in, aset, S = want3, p_ids, pool, pshape[0]
+
+
 @pytest.mark.parametrize("cin,cout,subm", [(128, 256, True), (128, 128, False), (64, 128, True), (32, 64, True)])
 def test_sparse_conv_split_k_in_launch_combine(request, dcl, oracle, cin, cout, subm):
     """split-K launches combine their partial tiles inside the launch (last-arriver ticket per tile, partials added in split

@@ -94,6 +94,7 @@ def test_every_profiled_kernel_is_launched_by_an_oracle_comparing_test(request, 
     TC.test_one_launch_crop_voxelisation_equals_the_general_device_op(dcl, 6, 1024, 64)
     # -- <round>_conv_layers: the conv / pool ops called layer by layer on real active sets (32 crops)
     TN.test_backbone_levels_and_indices_bit_exact(dcl, oracle)
+    TO.test_conv_layers_of_a_32_crop_batch_op_by_op_match_the_oracle(dcl, oracle)
     seen = census(lib)
     rnd = latest_round()
     want = profiled_kernels(rnd)
