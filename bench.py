@@ -77,9 +77,10 @@ def measure_traffic_bytes(kernel_substr, shape, batch, timeout_s=300):
 
 def measure_kernel_shares(shape, batch, timeout_s=300):
     """Whose kernels the step's GPU time goes to, MEASURED IN THIS RUN: one more child process of this script (`--pmc-child`:
-    two launch-by-launch forwards of the same workload) under `rocprofv3 --kernel-trace` alone (no counters: kernels keep
-    their concurrency and their durations), this process idle meanwhile.  -> (dict or None, source string): per kernel family
-    the summed kernel time and its share of the sum over ALL kernels of the child."""
+    two launch-by-launch forwards of the same workload, a pause between them) under `rocprofv3 --kernel-trace` alone (no
+    counters: kernels keep their concurrency and their durations), this process idle meanwhile.  Only the kernels of the LAST
+    forward count -- everything before the trace's longest pause (set-up kernels, uploads, the cold first forward) is cut off.
+    -> (dict or None, source string): per kernel family the summed kernel time and its share of that forward's summed kernel time."""
     import csv
     import glob
     import shutil
@@ -96,23 +97,30 @@ def measure_kernel_shares(shape, batch, timeout_s=300):
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("DCL_FORCE_DIST", "RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    fam = {"attention (k_cross_attn*)": 0.0, "vendor_gemm (hipBLASLt Cijk_*)": 0.0, "sparse conv (k_sparse_conv*, k_conv_frag*)": 0.0,
-           "other": 0.0}
+    SPARSE = "sparse feature stage (k_sparse_conv*, k_conv_frag*, k_sparse_avgpool*)"
+    fam = {"attention (k_cross_attn*)": 0.0, "vendor_gemm (hipBLASLt Cijk_*)": 0.0, SPARSE: 0.0, "other": 0.0}
     launches = {k: 0 for k in fam}
     try:
         subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s,
                        check=True)
-        rows = 0
+        trace = []
         for f in glob.glob(os.path.join(tmp, "**", "*kernel_trace.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
-                name = r["Kernel_Name"]
-                dur = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
-                key = ("attention (k_cross_attn*)" if "k_cross_attn" in name else
-                       "vendor_gemm (hipBLASLt Cijk_*)" if name.startswith("Cijk_") else
-                       "sparse conv (k_sparse_conv*, k_conv_frag*)" if ("k_sparse_conv" in name or "k_conv_frag" in name) else "other")
-                fam[key] += dur
-                launches[key] += 1
-                rows += 1
+                trace.append((float(r["Start_Timestamp"]), float(r["End_Timestamp"]), r["Kernel_Name"]))
+        trace.sort()
+        cut, gap, busy_until = 0, -1.0, None                 # the last forward starts behind the longest pause of the trace
+        for i, (t0, t1, _) in enumerate(trace):
+            if busy_until is not None and t0 - busy_until > gap:
+                gap, cut = t0 - busy_until, i
+            busy_until = t1 if busy_until is None else max(busy_until, t1)
+        rows = 0
+        for t0, t1, name in trace[cut:]:
+            key = ("attention (k_cross_attn*)" if "k_cross_attn" in name else
+                   "vendor_gemm (hipBLASLt Cijk_*)" if name.startswith("Cijk_") else
+                   SPARSE if ("k_sparse_conv" in name or "k_conv_frag" in name or "k_sparse_avgpool" in name) else "other")
+            fam[key] += t1 - t0
+            launches[key] += 1
+            rows += 1
     except (subprocess.SubprocessError, OSError, KeyError, ValueError) as e:
         shutil.rmtree(tmp, ignore_errors=True)
         return None, "unmeasured: kernel-trace pass failed (%s)" % type(e).__name__
@@ -121,9 +129,10 @@ def measure_kernel_shares(shape, batch, timeout_s=300):
     if rows == 0 or total <= 0:
         return None, "unmeasured: empty kernel trace"
     out = {k: {"ns": v, "share": v / total, "launches": launches[k]} for k, v in fam.items()}
-    out["_forwards"] = 2
-    return out, ("measured in this run: child rocprofv3 --kernel-trace pass over two launch-by-launch forwards of the same "
-                 "workload; share = the family's summed kernel time / the summed kernel time of all kernels")
+    out["_forwards"] = 1
+    return out, ("measured in this run: child rocprofv3 --kernel-trace pass, the kernels of ONE launch-by-launch forward of the same "
+                 "workload (the trace behind its longest pause); share = the family's summed kernel time / the summed kernel "
+                 "time of that forward (kernels of the two side streams overlap: a share of summed kernel time, not of wall time)")
 
 
 def _flush_c_stdio(unbuffer=False):
@@ -812,6 +821,8 @@ def main():
     if args.pmc_child:
         with torch.no_grad():
             net(data)
+            torch.cuda.synchronize()
+            time.sleep(0.05)                              # the pause measure_kernel_shares cuts the trace at
             net(data)
         torch.cuda.synchronize()
         return
@@ -854,7 +865,8 @@ def main():
                                        "TFLOPs": round(gemm_flop / (gem["ns"] * 1e-9) / 1e12, 1) if gem["ns"] > 0 else None,
                                        "launches_per_forward": gem["launches"] // shares["_forwards"],
                                        "note": "hipBLASLt Tensile kernels (Cijk_*): every 1x1x1-conv / head layer of the dense half"}
-            roofline["sparse_conv_share_of_gpu_time"] = round(shares["sparse conv (k_sparse_conv*, k_conv_frag*)"]["share"], 4)
+            sp_key = [k for k in shares if k.startswith("sparse feature stage")][0]
+            roofline["sparse_stage_share_of_gpu_time"] = round(shares[sp_key]["share"], 4)     # convs + combines + pools
             roofline["note"] = ("k_cross_attn is the dominant hand-written kernel, not the dominant kernel family: the "
                                 "vendor GEMMs hold the largest share")
 
@@ -888,6 +900,10 @@ def main():
     rdata_for_pipe = None
     if rank == 0 and world == 1 and not args.no_extras:
         line["roofline_sparse_conv"] = {args.shape: sparse_conv_roofline(dcl, net_l, data, dev)}
+        # the conv family's share of the STEP: event-bracketed conv time of a forward (each backbone's own launches, what the
+        # timed forward issues) over the measured step time -- not a share of summed kernel time under a profiler
+        rsc = line["roofline_sparse_conv"][args.shape]
+        rsc["share_of_step_time"] = round(rsc["separate_launches"]["conv_ms_per_forward"] / (dt / args.steps * 1e3), 4)
         if args.shape != "ref":
             rn, rm = SHAPES["ref"]
             rcfg = dcl.synth.default_cfg(rn, rm)

@@ -245,29 +245,28 @@ __device__ __forceinline__ void conv_wlds_body(const DclConvSides &sides, int ns
     n1 = n1 < sides.s[1].cap ? n1 : sides.s[1].cap;
   }
   const int t0 = (n0 + 31) >> 5, t1 = (n1 + 31) >> 5;
-  int g0 = G;                                                                // workgroups of side 0
-  if (t1 > 0) {
-    g0 = (int)(((long long)G * t0 + (t0 + t1) / 2) / (t0 + t1));
-    g0 = g0 < 1 ? 1 : (g0 > G - 1 ? G - 1 : g0);
-    if (t0 == 0) g0 = 0;
-  }
-  const int second = item >= g0 ? 1 : 0;
-  const DclConvSide &S = sides.s[second];
-  const int n = second ? n1 : n0, ntiles = second ? t1 : t0;
-  const int wg = item - (second ? g0 : 0), nwg = second ? G - g0 : g0;
   const int lane = tix & 63, wave = tix >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const float *__restrict__ feat = S.feat;
-  // wave tiles dealt round-robin over the launch's waves
-  {
-    const float4 *Wg = reinterpret_cast<const float4 *>(S.W + col0);
-    float4 *Wl = reinterpret_cast<float4 *>(wl_lds);
+  // EVERY side's filter is resident (two sides: Cin = 16 only, 2 x 54 KiB), and the wave tiles of all sides are dealt
+  // round-robin over all waves of the launch: one launch for both backbones, and no side whose tiles come to "one and a bit"
+  // per wave (32 crops, a launch per side: 1.07 and 1.7 tiles per wave -- two rounds each, the second nearly empty)
+  for (int sd = 0; sd < nsides; ++sd) {
+    const float4 *Wg = reinterpret_cast<const float4 *>(sides.s[sd].W + col0);
+    float4 *Wl = reinterpret_cast<float4 *>(wl_lds) + sd * (KV * CIN * COUT / 4);
     for (int i = tix; i < KV * CIN * COUT / 4; i += NTHR) Wl[i] = Wg[(i >> 3) * (COUT_T / 4) + (i & 7)];
   }
   __syncthreads();
   // (running the first tile's look-ups under the filter load was measured: the 27 live row numbers across the load push
-  // the 16-wave variant over its 128 registers -- 43 -> 52 us)
-  for (int tile = wg * NWAVE + wave; tile < ntiles; tile += nwg * NWAVE) {
+  // the 16-wave variant over its 128 registers -- 43 -> 52 us.  Round 5, measured and dropped: the filter in MFMA-operand
+  // order (two ds_read_b128 instead of eight ds_read_b32 per group) with a zero line for missing neighbours -- no gain, 133
+  // -> 140 us; a software pipeline over a wave's tiles with eight 256-register waves -- 153 us.  Probes of this kernel at
+  // 32 crops: the gathers cost nothing measurable, the MFMAs 84 of 145 us, the look-ups 20, filter load + epilogue + launch 40.)
+  for (int gt = item * NWAVE + wave; gt < t0 + t1; gt += G * NWAVE) {
+    const int second = gt >= t0 ? 1 : 0;
+    const DclConvSide &S = sides.s[second];
+    const float *__restrict__ feat = S.feat;
+    const float *wl_side = wl_lds + second * (KV * CIN * COUT);
+    const int n = second ? n1 : n0, tile = gt - (second ? t0 : 0);
     const int row = tile * 32 + r;
     const bool valid = row < n;
     int v[KV];                                                               // the 27 neighbour rows of this lane's output row
@@ -301,7 +300,7 @@ __device__ __forceinline__ void conv_wlds_body(const DclConvSides &sides, int ns
       if (__ballot(v[st] >= 0) != 0ull) {
         const int k = offset_at(st, KV, SUBM ? 1 : 0);
         const bool have = v[st] >= 0;
-        const float *wk = wl_lds + (k * CIN + 8 * h) * COUT + r;
+        const float *wk = wl_side + (k * CIN + 8 * h) * COUT + r;
         const float4 (&cur)[2 * GRP] = ring[st % (PF + 1)];
 #pragma unroll
         for (int g = 0; g < GRP; ++g) {

@@ -888,19 +888,20 @@ static int conv_dispatch(const DclConvSides &sides_in, int nsides_in, int cin, i
   hipStream_t s = (hipStream_t)stream;
   const DclConvChoice ch = conv_choose(sides, nsides, cin, cout, kvol, scratch != nullptr);
   if (ch.family == DCL_CONV_WLDS) {
-    const size_t lds = (size_t)27 * cin * 32 * sizeof(float);
+    // Cin = 16: both sides' filters fit the LDS together (2 x 54 KiB) -> ONE launch over both sides' tiles; Cin = 32: a launch per
+    // side (one workgroup per CU is all a filter leaves room for)
+    const int per_launch = cin == 16 ? nsides : 1;
+    const size_t lds = (size_t)per_launch * 27 * cin * 32 * sizeof(float);
     const dim3 grid(256 / (cout / 32), cout / 32), block(cin == 16 ? 1024 : 512);
 #define WLDS_LAUNCH(CI, CO, SB)                                                                                              \
     do {                                                                                                                   \
       (void)hipFuncSetAttribute((const void *)k_sparse_conv_wlds<CI, CO, SB>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                 (int)lds);                                                                                 \
-      hipLaunchKernelGGL((k_sparse_conv_wlds<CI, CO, SB>), grid, block, lds, s, one, 1, relu);                             \
+      hipLaunchKernelGGL((k_sparse_conv_wlds<CI, CO, SB>), grid, block, lds, s, one, per_launch, relu);                    \
     } while (0)
-    // (a launch per side: one workgroup per CU is all the filter leaves room for, so two sides in one launch only halve
-    // each side's CUs -- measured 101 us for both against 2 x 44)
-    for (int side_i = 0; side_i < nsides; ++side_i) {
+    for (int side_i = 0; side_i < nsides; side_i += per_launch) {
       DclConvSides one{};
-      one.s[0] = sides.s[side_i];
+      for (int q = 0; q < per_launch; ++q) one.s[q] = sides.s[side_i + q];
       if (cin == 16) { if (subm) WLDS_LAUNCH(16, 32, true); else WLDS_LAUNCH(16, 32, false); }
       else if (cout == 32) { if (subm) WLDS_LAUNCH(32, 32, true); else WLDS_LAUNCH(32, 32, false); }
       else { if (subm) WLDS_LAUNCH(32, 64, true); else WLDS_LAUNCH(32, 64, false); }

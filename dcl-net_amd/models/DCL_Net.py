@@ -642,6 +642,12 @@ class Network(nn.Module):
             out["sym_flag"] = data["flags"].to(dev)                          # as in forward() (models/DCL_Net.py:249)
         data["labels"]["points_tmp"] = res["pts_tmp"]
         data["labels"]["points_inp"] = res["pts_inp"]
+        if "vi_info" in data["inp"]:
+            # capacity-form crops (crops.CropBuilder(capacity=True)) are never read back on the way in: their device-side error
+            # flag -- a voxel with more points than the row pitch holds (its row is truncated), or a point outside the grid --
+            # travels WITH the predictions (a 1-element int32 device tensor, no synchronisation here); a caller that tabulates
+            # these poses checks it once after its own synchronisation
+            out["crop_overflow"] = data["inp"]["vi_info"][2:3]
         return out
 
     def _capture(self, f, dev, b, S, ma):

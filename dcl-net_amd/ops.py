@@ -84,10 +84,10 @@ def voxelize_idx_crops(coords, batch_size, n_per, S=64, mode=4, pitch=33, occ_dt
     assert 1 <= b <= VI_CROPS_MAX_BATCH and 1 <= n_per <= VI_CROPS_MAX_POINTS and int(S) == VI_CROPS_S
     dev = coords.device
     key = dev.index if dev.index is not None else torch.cuda.current_device()
-    ent = _VI_COMM.get(key)
-    if ent is None:        # a ring of 64 regions of 2 ints per crop that persist between calls + the call counter: consecutive calls
-        ent = _VI_COMM[key] = [torch.zeros(64 * 2 * VI_CROPS_MAX_BATCH, dtype=torch.int32, device=dev), 0]   # (also on other streams / threads) use different words
-    with _VI_LOCK:
+    with _VI_LOCK:         # (the builder thread of a CropPrefetcher and the caller's thread may both arrive here first)
+        ent = _VI_COMM.get(key)
+        if ent is None:    # a ring of 64 regions of 2 ints per crop that persist between calls + the call counter: consecutive calls
+            ent = _VI_COMM[key] = [torch.zeros(64 * 2 * VI_CROPS_MAX_BATCH, dtype=torch.int32, device=dev), 0]   # (also on other streams / threads) use different words
         ent[1] = ent[1] % 0x3fffffff + 1
         gen = ent[1]
     comm = ent[0][(gen % 64) * 2 * VI_CROPS_MAX_BATCH:]

@@ -202,6 +202,9 @@ def test_capacity_form_crops_give_the_same_poses(dcl):
             again = net(dict(cap_d, labels={}))
         for k in ("rot_pred", "trans_pred", "conf"):
             assert torch.equal(want[k], got[k]) and torch.equal(want[k], again[k]), (graph, k)
+        if graph:       # the graph path never reads the crops' error flag on the way in: it hands it over with the poses
+            assert "crop_overflow" in got and got["crop_overflow"].is_cuda and int(got["crop_overflow"][0]) == 0
+            assert "crop_overflow" not in want
 
 
 @pytest.mark.gpu
