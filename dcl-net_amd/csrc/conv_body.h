@@ -261,7 +261,10 @@ __device__ __forceinline__ void conv_wlds_body(const DclConvSides &sides, int ns
   // order (two ds_read_b128 instead of eight ds_read_b32 per group) with a zero line for missing neighbours -- no gain, 133
   // -> 140 us; a software pipeline over a wave's tiles with eight 256-register waves -- 153 us.  Probes of this kernel at
   // 32 crops: the gathers cost nothing measurable, the MFMAs 84 of 145 us, the look-ups 20, filter load + epilogue + launch 40.)
-  for (int gt = item * NWAVE + wave; gt < t0 + t1; gt += G * NWAVE) {
+  // (slot = wave * G + item, not item * NWAVE + wave: the LAST, partly filled round of tiles then lands on every CU's first
+  // waves -- one per SIMD, which runs its MFMAs unshared -- instead of filling all sixteen waves of the first few CUs: at 2.14
+  // tiles per wave the third round of 578 tiles was a full round on 36 CUs while 220 waited)
+  for (int gt = wave * G + item; gt < t0 + t1; gt += G * NWAVE) {
     const int second = gt >= t0 ? 1 : 0;
     const DclConvSide &S = sides.s[second];
     const float *__restrict__ feat = S.feat;
