@@ -79,7 +79,7 @@ def measure_kernel_shares(shape, batch, timeout_s=300):
     """Whose kernels the step's GPU time goes to, MEASURED IN THIS RUN: one more child process of this script (`--pmc-child`:
     two launch-by-launch forwards of the same workload, a pause between them) under `rocprofv3 --kernel-trace` alone (no
     counters: kernels keep their concurrency and their durations), this process idle meanwhile.  Only the kernels of the LAST
-    forward count -- everything before the trace's longest pause (set-up kernels, uploads, the cold first forward) is cut off.
+    forward count -- everything before the trace's last pause of more than 20 ms (set-up kernels, uploads, the cold first forward) is cut off.
     -> (dict or None, source string): per kernel family the summed kernel time and its share of that forward's summed kernel time."""
     import csv
     import glob
@@ -108,10 +108,10 @@ def measure_kernel_shares(shape, batch, timeout_s=300):
             for r in csv.DictReader(open(f)):
                 trace.append((float(r["Start_Timestamp"]), float(r["End_Timestamp"]), r["Kernel_Name"]))
         trace.sort()
-        cut, gap, busy_until = 0, -1.0, None                 # the last forward starts behind the longest pause of the trace
-        for i, (t0, t1, _) in enumerate(trace):
-            if busy_until is not None and t0 - busy_until > gap:
-                gap, cut = t0 - busy_until, i
+        cut, busy_until = 0, None                            # the last forward starts behind the LAST long pause of the trace (the child
+        for i, (t0, t1, _) in enumerate(trace):              # sleeps 50 ms in front of it; plan creation inside the cold first forward pauses too)
+            if busy_until is not None and t0 - busy_until > 2e7:
+                cut = i
             busy_until = t1 if busy_until is None else max(busy_until, t1)
         rows = 0
         for t0, t1, name in trace[cut:]:
@@ -934,6 +934,8 @@ def main():
                                  "launch_by_launch": {"value": round(b * rsteps / ldt, 2), "ms_per_step": round(ldt / rsteps * 1e3, 3)},
                                  "attention_TFLOPs": round(rflop / (np.mean(ratt) * 1e-3) / 1e12, 2) if ratt else None}
             line["roofline_sparse_conv"]["ref"] = sparse_conv_roofline(dcl, rnet_l, rdata, dev)
+            line["roofline_sparse_conv"]["ref"]["share_of_step_time"] = round(
+                line["roofline_sparse_conv"]["ref"]["separate_launches"]["conv_ms_per_forward"] / (ldt / rsteps * 1e3), 4)
             # BASELINE configs[2]'s per-GPU shape: 40 crops per call (config_YCBV_bs40.yaml)
             d40 = to_device(dcl.synth.make_batch(40, rn, rm), dev)
             dt40, _ = run_forward_bench(dcl, rnet, d40, 20, 3, False)

@@ -20,6 +20,11 @@ stats crops  python3 tools/bench_crops.py
 stats conv   python3 tools/bench_conv.py 1024 0
 stats refiner python3 tools/refiner_loop.py 10
 python3 tools/bench_fps.py 2>&1 | grep FPS > $O/${R}_fps.txt
+# the sparse-conv stack layer by layer inside ordinary forwards (runner path, product library), and one launch from the inside
+{ for a in "ref 32" "stress 32" "ref 6" "ref 1"; do python3 tools/conv_layers.py $a; done; } 2>&1 | grep -v amdgpu.ids > $O/${R}_conv_layers_runner.txt
+{ for l in 0 1 2 3 4 5; do python3 tools/conv_stamps.py $l pair ref; done; } 2>&1 | grep -v "amdgpu.ids\|occupancy API" > $O/${R}_conv_stamps.txt
+{ python3 tools/stream_b1.py 300 1; python3 tools/stream_b1.py 200 6; python3 tools/graph_timeline.py 1 6 32; } 2>&1 | grep -v amdgpu.ids > $O/${R}_small_calls.txt
+python3 bench.py > $O/${R}_bench_default.log 2>&1; tail -1 $O/${R}_bench_default.log > $O/${R}_bench_default.jsonl
 for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
   pmc pmc $c python3 bench.py --steps 4 --warmup 2 --no-extras
 done
