@@ -96,7 +96,8 @@ struct GeoLayout {
 // ways: its launches are bound by the per-tile fixed cost, not by MFMA work -- ordered 55.9 / 89.6 us, natural 53 / 83 --
 // and its two sets are the largest ones to sort; level 0 runs the stem and a 16-channel layer (no used-chunk dealing).
 DCL_HOOK_INT(kOrderMinBatch, 14);   // same-job A/B, order on vs off: 10 crops +0.9 %, 12: +1.5 %, 13: +0.7 %, 14: -1.2 %, 16: -1.5 %, 32: -3.2 % (diagnostic library: dcl_debug_order_min_batch; a huge value = off)
-inline bool order_layer(int batch, int m, int which) { return batch >= kOrderMinBatch && m >= 2 && (which == 0 || which == 1); }
+DCL_HOOK_INT(kOrderMinLevel, 2);    // first level whose conv layers get a row order (diagnostic library: dcl_debug_order_min_level)
+inline bool order_layer(int batch, int m, int which) { return batch >= kOrderMinBatch && m >= kOrderMinLevel && (which == 0 || which == 1); }
 
 bool make_geo_layout(int batch, int S, int V0, GeoLayout *L) {
   if (batch <= 0 || S < 16 || (S & (S - 1)) || S > 64 || V0 < 0) return false;
@@ -297,6 +298,7 @@ static int backbone_geometry(const int32_t *occ, const int32_t *V0_dev, int V0, 
 
 #ifdef DCL_DIAG
 DCL_API void dcl_debug_order_min_batch(int n) { kOrderMinBatch = n; }
+DCL_API void dcl_debug_order_min_level(int m) { kOrderMinLevel = m; }
 // Test hook: 1 (default) = one-launch mask chain on 64^3 grids, 0 = the 8 chained launches (A/B of the two paths).
 DCL_API int dcl_debug_geometry_chain(int mode) {
   g_geo_chain.store(mode);

@@ -537,6 +537,8 @@ void dcl_debug_attention_xcd_remap(int on);
 int dcl_debug_geometry_chain(int mode);
 /* Tuning hook: smallest batch whose deep conv layers get a row order (default 12); a huge value switches the ordering off. */
 void dcl_debug_order_min_batch(int n);
+/* Tuning hook: first backbone level (0..3) whose conv layers get a row order (default 2: the two deep levels). */
+void dcl_debug_order_min_level(int m);
 /* Test hook, 3-NN of the point read-out: 1 (default) = grid-pruned search on the 32^3 / 16^3 levels, 0 = per-crop scan on
  * every level, 2 = grid kernel with its scan fallback forced for every query, 3 / 4 / 5 = grid kernel with one / four /
  * eight lanes per query whatever the number of points (automatic: eight up to 40960 points, four up to 131072, else
