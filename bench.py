@@ -256,6 +256,13 @@ def primitives_roofline(dcl, reps=5):
         torch.cuda.synchronize()
         ms = a.elapsed_time(b) / reps
         out[name] = {"ms": round(ms, 4), "GBps": round(nbytes / ms / 1e6, 1), "bytes": nbytes}
+    # three_nn / knn (k = 1) are exact searches over the same B x N x npoint pairs as ball_query: reported against the same
+    # brute-force vector-issue bound; above 1.0 = the bucketed walk tests fewer pairs than a full scan would
+    for name in ("three_nn", "knn1"):
+        s_ = out[name]["ms"] * 1e-3
+        out[name].update({"bound": "valu (packed f32 issue), brute-force-equivalent pair rate", "candidate_tests": tests,
+                          "tests_per_s": round(tests / s_, 1), "valu_bound_tests_per_s": round(valu_bound, 1),
+                          "frac_of_valu_bound": round(tests / s_ / valu_bound, 3)})
     return out
 
 

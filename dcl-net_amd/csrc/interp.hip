@@ -429,23 +429,28 @@ __global__ __launch_bounds__(256) void k_three_nn(int n, int m, const float *__r
 }
 
 // ---- pruned exact search for k = 1 and k = 3 (knn with k = 1 is what DCL-Net's get_cano_label calls; three_nn is k = 3):
-// the batch's known points are bucketed along the axis of their largest extent (256 buckets, counting sort in LDS, exact
-// per-bucket minimum / maximum coordinate), every query scans its own bucket and then walks outwards in both directions
-// until the squared coordinate gap to the next bucket already exceeds its current worst distance.  Exact: candidates are
-// 64-bit (d2, index) keys -- the reference's strict-'<' cascade over ascending k is the lexicographic order of those keys,
-// so the scan order is free -- and d2 = fma(dz,dz, fma(dx,dx, dy*dy)) >= fl(gap*gap) for the gap along ANY one axis
-// (rounding is monotonic), so a bucket whose nearest coordinate is further than the worst kept distance cannot contribute,
-// ties included (the walk stops on a strictly greater bound only).
+// the cloud's known points are bucketed along the axis of their largest extent (256 buckets, counting sort in LDS, exact
+// per-bucket minimum / maximum coordinate); the workgroup's QUERIES are sorted by their bucket too, so that the 64 queries of
+// a wave sit next to each other on the axis and walk the buckets TOGETHER: first the contiguous run of buckets the wave's own
+// queries fall into, then outwards in both directions, a group of buckets at a time, until no lane of the wave can still be
+// beaten (the squared coordinate gap to the next bucket exceeds its worst kept distance).  Every lane tests every point the
+// wave visits -- a superset of what it needs -- so the point reads are LDS broadcasts and the control flow is uniform.  (Round 4
+// let every lane walk its own buckets: 64 divergent walks per wave, 0.196 ms at B = 32, n = 12288, m = 2048; the plain scan 0.55.)
+// Exact: candidates are 64-bit (d2, index) keys -- the reference's strict-'<' cascade over ascending k is the lexicographic
+// order of those keys, so the scan order is free -- and d2 = fma(dz,dz, fma(dx,dx, dy*dy)) >= fl(gap*gap) for the gap along ANY
+// one axis (rounding is monotonic), so a bucket whose nearest coordinate is further than the worst kept distance cannot
+// contribute, ties included (the walk stops on a strictly greater bound only).
 constexpr int kNNBuckets = 256;
-constexpr int kNNThreads = 512;           // queries per workgroup: the bucket build (per workgroup) is shared by more of them
-template <int KB>
+constexpr int kNNThreads = 512;           // QPT queries per thread: the bucket build (per workgroup) is shared by 512 * QPT queries
+template <int KB, int QPT>
 __global__ __launch_bounds__(kNNThreads) void k_nn_bucketed(int n, int m, const float *__restrict__ unknown,
                                                      const float *__restrict__ known, float *__restrict__ dist2,
                                                      int32_t *__restrict__ idx) {
   extern __shared__ __attribute__((aligned(16))) float nn_lds[];
   float4 *pts = reinterpret_cast<float4 *>(nn_lds);                        // [m] (x, y, z, index bits), bucket by bucket
-  int *start = reinterpret_cast<int *>(nn_lds + 4 * (size_t)m);            // [kNNBuckets + 1]
-  int *fill = start + kNNBuckets + 1;                                      // [kNNBuckets] counts, then fill cursors
+  float4 *sq = pts + m;                                                    // [512 * QPT] the workgroup's queries (x, y, z, local index bits), bucket by bucket
+  int *start = reinterpret_cast<int *>(sq + kNNThreads * QPT);             // [kNNBuckets + 1]
+  int *fill = start + kNNBuckets + 1;                                      // [kNNBuckets] counts, then fill cursors (points, then queries)
   unsigned *bmin = reinterpret_cast<unsigned *>(fill + kNNBuckets);        // [kNNBuckets] monotone-uint minimum coordinate
   unsigned *bmax = bmin + kNNBuckets;                                      // [kNNBuckets]
   float *red = reinterpret_cast<float *>(bmax + kNNBuckets);               // [6][NWV] wave partials of the extent
@@ -504,16 +509,8 @@ __global__ __launch_bounds__(kNNThreads) void k_nn_bucketed(int n, int m, const 
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
   };
   auto unmono = [](unsigned u) -> float { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); };
-  // 2. counting sort into the buckets (the order inside a bucket is free: keys are a total order)
-  for (int i = tid; i < m; i += kNNThreads) {
-    const float c = K[i * 3 + axis];
-    const int q = bucket_of(c);
-    atomicAdd(&fill[q], 1);
-    atomicMin(&bmin[q], mono(c));
-    atomicMax(&bmax[q], mono(c));
-  }
-  __syncthreads();
-  {                                                                        // exclusive scan of the 256 counts (waves 0-3)
+  // exclusive scan of the 256 counts in fill[] -> cursors in fill[] (and start[] when `keep`); waves 0-3 hold the counts
+  auto scan_counts = [&](bool keep) {
     const int cnt = tid < kNNBuckets ? fill[tid] : 0;
     int inc = cnt;
 #pragma unroll
@@ -528,12 +525,24 @@ __global__ __launch_bounds__(kNNThreads) void k_nn_bucketed(int n, int m, const 
 #pragma unroll
     for (int w = 0; w < kNNBuckets / 64; ++w) base += w < wave ? __float_as_int(red[w]) : 0;
     if (tid < kNNBuckets) {
-      start[tid] = base + inc - cnt;
       fill[tid] = base + inc - cnt;                                        // fill cursor
-      if (tid == kNNBuckets - 1) start[kNNBuckets] = base + inc;
+      if (keep) {
+        start[tid] = base + inc - cnt;
+        if (tid == kNNBuckets - 1) start[kNNBuckets] = base + inc;
+      }
     }
+    __syncthreads();
+  };
+  // 2. counting sort of the known points into the buckets (the order inside a bucket is free: keys are a total order)
+  for (int i = tid; i < m; i += kNNThreads) {
+    const float c = K[i * 3 + axis];
+    const int q = bucket_of(c);
+    atomicAdd(&fill[q], 1);
+    atomicMin(&bmin[q], mono(c));
+    atomicMax(&bmax[q], mono(c));
   }
   __syncthreads();
+  scan_counts(true);
   for (int i = tid; i < m; i += kNNThreads) {
     const float x = K[i * 3], y = K[i * 3 + 1], z = K[i * 3 + 2];
     const float c = axis == 0 ? x : (axis == 1 ? y : z);
@@ -541,57 +550,140 @@ __global__ __launch_bounds__(kNNThreads) void k_nn_bucketed(int n, int m, const 
     pts[pos] = make_float4(x, y, z, __int_as_float(i));
   }
   __syncthreads();
-  // 3. the queries of this block
-  const int p = blockIdx.x * kNNThreads + tid;
-  if (p >= n) return;
-  const float *u = unknown + ((size_t)bs * n + p) * 3;
-  const float ux = u[0], uy = u[1], uz = u[2];
-  const float uc = axis == 0 ? ux : (axis == 1 ? uy : uz);
-  u64 key[KB];
+  // 3. this workgroup's queries, sorted by bucket (same counting sort; fill[] is free again)
+  const int q_base = blockIdx.x * kNNThreads * QPT;
+  const int nq = min(kNNThreads * QPT, n - q_base);
+  const float *U = unknown + ((size_t)bs * n + q_base) * 3;
+  if (tid < kNNBuckets) fill[tid] = 0;
+  __syncthreads();
+  float qx[QPT], qy[QPT], qz[QPT];
 #pragma unroll
-  for (int j = 0; j < KB; ++j) key[j] = kEmptyKey;
-  auto push = [&](u64 c) {
-#pragma unroll
-    for (int j = 0; j < KB; ++j) {
-      const u64 t = c < key[j] ? c : key[j];
-      c = c < key[j] ? key[j] : c;
-      key[j] = t;
+  for (int j = 0; j < QPT; ++j) {
+    const int p = j * kNNThreads + tid;
+    qx[j] = qy[j] = qz[j] = 0.f;
+    if (p < nq) {
+      qx[j] = U[p * 3]; qy[j] = U[p * 3 + 1]; qz[j] = U[p * 3 + 2];
+      atomicAdd(&fill[bucket_of(axis == 0 ? qx[j] : (axis == 1 ? qy[j] : qz[j]))], 1);
     }
-  };
-  float worst = INFINITY;                                                  // distance of the last kept key
-  auto scan = [&](int q) {
-    const int e = start[q + 1];
-    for (int i = start[q]; i < e; ++i) {
-      const float4 v = pts[i];
-      const float d = dcl_dist2(ux, uy, uz, v.x, v.y, v.z);
-      if (d > worst) continue;                                             // cannot enter (an equal distance may: lower index)
-      push(make_key(d, __float_as_int(v.w)));
+  }
+  __syncthreads();
+  scan_counts(false);
+#pragma unroll
+  for (int j = 0; j < QPT; ++j) {
+    const int p = j * kNNThreads + tid;
+    if (p < nq) {
+      const int pos = atomicAdd(&fill[bucket_of(axis == 0 ? qx[j] : (axis == 1 ? qy[j] : qz[j]))], 1);
+      sq[pos] = make_float4(qx[j], qy[j], qz[j], __int_as_float(p));
+    }
+  }
+  __syncthreads();
+  // 4. the sorted queries, 64 neighbours on the axis per wave
+#pragma unroll 1
+  for (int j = 0; j < QPT; ++j) {
+    const int sidx = j * kNNThreads + tid;
+    if (__ballot(sidx < nq) == 0ull) break;                                // (whole waves leave together: no barrier below)
+    const bool valid = sidx < nq;
+    const float4 me = sq[valid ? sidx : 0];
+    const float ux = me.x, uy = me.y, uz = me.z;
+    const float uc = axis == 0 ? ux : (axis == 1 ? uy : uz);
+    u64 key[KB];
+#pragma unroll
+    for (int t = 0; t < KB; ++t) key[t] = kEmptyKey;
+    float worst = INFINITY;                                                // distance of the last kept key
+    auto consider = [&](float d, float w) {
+      if (d > worst) return;                                               // cannot enter (an equal distance may: lower index)
+      u64 c = make_key(d, __float_as_int(w));
+#pragma unroll
+      for (int t = 0; t < KB; ++t) {
+        const u64 lo2 = c < key[t] ? c : key[t];
+        c = c < key[t] ? key[t] : c;
+        key[t] = lo2;
+      }
       worst = __uint_as_float((unsigned)(key[KB - 1] >> 32));
-    }
-  };
-  const int q0 = bucket_of(uc);
-  scan(q0);
-  for (int q = q0 + 1; q < kNNBuckets; ++q) {
-    if (start[q + 1] == start[q]) continue;
-    const float gap = unmono(bmin[q]) - uc;                                // every point from here on is at least this far along the axis
-    if (gap > 0.f && gap * gap > worst) break;
-    scan(q);
-  }
-  for (int q = q0 - 1; q >= 0; --q) {
-    if (start[q + 1] == start[q]) continue;
-    const float gap = uc - unmono(bmax[q]);
-    if (gap > 0.f && gap * gap > worst) break;
-    scan(q);
-  }
-  const size_t o = ((size_t)bs * n + p) * KB;
+    };
+    auto scan_range = [&](int i0, int i1) {                                // every lane tests points [i0, i1): uniform bounds, broadcast reads
+      int i = i0;
+      for (; i + 8 <= i1; i += 8) {                                        // eight points' reads and distances in flight, entered in order
+        float4 v[8];
+        float d[8];
 #pragma unroll
-  for (int j = 0; j < KB; ++j) {
-    dist2[o + j] = __uint_as_float((unsigned)(key[j] >> 32));
-    idx[o + j] = (int)(unsigned)key[j];
+        for (int e = 0; e < 8; ++e) v[e] = pts[i + e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d[e] = dcl_dist2(ux, uy, uz, v[e].x, v[e].y, v[e].z);
+        const float dm = fminf(fminf(fminf(d[0], d[1]), fminf(d[2], d[3])), fminf(fminf(d[4], d[5]), fminf(d[6], d[7])));
+        if (__ballot(dm <= worst) == 0ull) continue;                       // nobody in the wave can use any of the eight
+#pragma unroll
+        for (int e = 0; e < 8; ++e) consider(d[e], v[e].w);
+      }
+      for (; i + 4 <= i1; i += 4) {
+        const float4 v0 = pts[i], v1 = pts[i + 1], v2 = pts[i + 2], v3 = pts[i + 3];
+        const float d0 = dcl_dist2(ux, uy, uz, v0.x, v0.y, v0.z), d1 = dcl_dist2(ux, uy, uz, v1.x, v1.y, v1.z);
+        const float d2 = dcl_dist2(ux, uy, uz, v2.x, v2.y, v2.z), d3 = dcl_dist2(ux, uy, uz, v3.x, v3.y, v3.z);
+        if (__ballot(fminf(fminf(d0, d1), fminf(d2, d3)) <= worst) == 0ull) continue;
+        consider(d0, v0.w); consider(d1, v1.w); consider(d2, v2.w); consider(d3, v3.w);
+      }
+      for (; i < i1; ++i) {
+        const float4 v = pts[i];
+        consider(dcl_dist2(ux, uy, uz, v.x, v.y, v.z), v.w);
+      }
+    };
+    // the wave's own buckets: one contiguous run of the sorted points
+    const int q0 = bucket_of(uc);
+    int qlo = valid ? q0 : kNNBuckets, qhi = valid ? q0 : -1;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      qlo = min(qlo, __shfl_xor(qlo, d, 64));
+      qhi = max(qhi, __shfl_xor(qhi, d, 64));
+    }
+    qlo = __builtin_amdgcn_readfirstlane(qlo);
+    qhi = __builtin_amdgcn_readfirstlane(qhi);
+    scan_range(start[qlo], start[qhi + 1]);
+    // outwards, kStep buckets at a time: the group is scanned if ANY lane could still be beaten by its nearest bucket
+    constexpr int kStep = 4;
+    for (int q = qhi + 1; q < kNNBuckets; q += kStep) {
+      const int qe = min(q + kStep, kNNBuckets);
+      if (start[qe] == start[q]) continue;
+      int qn = q;                                                          // first non-empty bucket of the group: its minimum bounds the group
+      while (start[qn + 1] == start[qn]) ++qn;
+      const float gap = unmono(bmin[qn]) - uc;                             // every point from here on is at least this far along the axis
+      const bool done = !valid || (gap > 0.f && gap * gap > worst);
+      if (__ballot(!done) == 0ull) break;
+      scan_range(start[q], start[qe]);
+    }
+    for (int q = qlo - 1; q >= 0; q -= kStep) {
+      const int qb = max(q - kStep + 1, 0);
+      if (start[q + 1] == start[qb]) continue;
+      int qn = q;                                                          // last non-empty bucket of the group
+      while (start[qn + 1] == start[qn]) --qn;
+      const float gap = uc - unmono(bmax[qn]);
+      const bool done = !valid || (gap > 0.f && gap * gap > worst);
+      if (__ballot(!done) == 0ull) break;
+      scan_range(start[qb], start[q + 1]);
+    }
+    if (valid) {
+      const size_t o = ((size_t)bs * n + q_base + __float_as_int(me.w)) * KB;
+#pragma unroll
+      for (int t = 0; t < KB; ++t) {
+        dist2[o + t] = __uint_as_float((unsigned)(key[t] >> 32));
+        idx[o + t] = (int)(unsigned)key[t];
+      }
+    }
   }
 }
 constexpr int kNNBucketedMaxKnown = 8192;       // 128 KiB of staged points
-static size_t nn_bucketed_lds(int m) { return (size_t)m * 16 + (size_t)(4 * kNNBuckets + 1 + 6 * (kNNThreads / 64) + 4) * 4; }
+static size_t nn_bucketed_lds(int m, int qpt) {
+  return (size_t)m * 16 + (size_t)kNNThreads * qpt * 16 + (size_t)(4 * kNNBuckets + 1 + 6 * (kNNThreads / 64) + 4) * 4;
+}
+// queries per thread: as many as keep >= 256 workgroups in the launch and fit the LDS beside the staged points (more queries per
+// workgroup = tighter waves on the axis and fewer bucket builds)
+DCL_HOOK_INT(g_nn_qpt, 0);            // (diagnostic library) queries per thread of the bucketed search: 0 = automatic
+static int nn_bucketed_qpt(int b, int n, int m) {
+  if (g_nn_qpt >= 1 && g_nn_qpt <= 4 && nn_bucketed_lds(m, (int)g_nn_qpt) <= 150 * 1024) return (int)g_nn_qpt;
+  int qpt = 1;
+  for (int c = 2; c <= 4; ++c)
+    if ((long long)b * dcl_div_up(n, kNNThreads * c) >= 256 && nn_bucketed_lds(m, c) <= 150 * 1024) qpt = c;
+  return qpt;
+}
 
 // knn, k <= 200 (interpolate_gpu.cu:9-57): sorted list with strict-'<' insertion, one query per
 // thread, list kept in a per-thread LDS column (conflict-free: slot j of thread t at j*T + t).
@@ -664,6 +756,7 @@ DCL_HOOK_INT(g_nn_batched_mode, 0);   // (diagnostic library) 1 = the batched th
 #ifdef DCL_DIAG
 DCL_API void dcl_debug_three_nn_grid(int mode) { g_nn_grid = mode; }
 DCL_API void dcl_debug_nn_batched_mode(int mode) { g_nn_batched_mode = mode; }
+DCL_API void dcl_debug_nn_qpt(int q) { g_nn_qpt = q; }
 #endif
 
 // known_mask / S (optional): the level's occupancy bits and grid size; with them, levels of S = 16 or 32 go through the
@@ -792,10 +885,15 @@ DCL_API int dcl_three_nn(int b, int n, int m, const float *unknown, const float 
   if (b == 0 || n == 0) return 0;
   DCL_CHECK_ARG(unknown && dist2 && idx && (m == 0 || known) && b <= 65535);
   if (m >= 64 && m <= kNNBucketedMaxKnown && g_nn_batched_mode == 0) {        // bucketed exact search (same results as the scan)
-    const size_t lds = nn_bucketed_lds(m);
-    (void)hipFuncSetAttribute((const void *)k_nn_bucketed<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_nn_bucketed<3>, dim3(dcl_div_up(n, kNNThreads), b), dim3(kNNThreads), lds, (hipStream_t)stream, n, m, unknown, known,
-                       dist2, idx);
+    const int qpt = nn_bucketed_qpt(b, n, m);
+    const size_t lds = nn_bucketed_lds(m, qpt);
+#define NNB_LAUNCH(KB_, Q_)                                                                                                       \
+    do {                                                                                                                        \
+      (void)hipFuncSetAttribute((const void *)k_nn_bucketed<KB_, Q_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+      hipLaunchKernelGGL((k_nn_bucketed<KB_, Q_>), dim3(dcl_div_up(n, kNNThreads * Q_), b), dim3(kNNThreads), lds, (hipStream_t)stream, \
+                         n, m, unknown, known, dist2, idx);                                                                     \
+    } while (0)
+    if (qpt == 4) NNB_LAUNCH(3, 4); else if (qpt == 3) NNB_LAUNCH(3, 3); else if (qpt == 2) NNB_LAUNCH(3, 2); else NNB_LAUNCH(3, 1);
     DCL_LAUNCH_CHECK();
     return 0;
   }
@@ -811,10 +909,9 @@ DCL_API int dcl_knn(int b, int n, int m, int k, const float *unknown, const floa
   if (b == 0 || n == 0) return 0;
   DCL_CHECK_ARG(unknown && dist2 && idx && (m == 0 || known) && b <= 65535);
   if (k == 1 && m >= 64 && m <= kNNBucketedMaxKnown && g_nn_batched_mode == 0) {
-    const size_t lds1 = nn_bucketed_lds(m);
-    (void)hipFuncSetAttribute((const void *)k_nn_bucketed<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-    hipLaunchKernelGGL(k_nn_bucketed<1>, dim3(dcl_div_up(n, kNNThreads), b), dim3(kNNThreads), lds1, (hipStream_t)stream, n, m, unknown, known,
-                       dist2, idx);
+    const int qpt = nn_bucketed_qpt(b, n, m);
+    const size_t lds = nn_bucketed_lds(m, qpt);
+    if (qpt == 4) NNB_LAUNCH(1, 4); else if (qpt == 3) NNB_LAUNCH(1, 3); else if (qpt == 2) NNB_LAUNCH(1, 2); else NNB_LAUNCH(1, 1);
     DCL_LAUNCH_CHECK();
     return 0;
   }

@@ -546,6 +546,8 @@ void dcl_debug_order_min_level(int m);
 void dcl_debug_three_nn_grid(int mode);
 /* Test hook, batched three_nn / knn (k = 1): 0 (default) = bucketed exact search, 1 = the plain scan (A/B). */
 void dcl_debug_nn_batched_mode(int mode);
+/* Tuning hook: queries per thread of the bucketed batched search (1..4; 0 = automatic). */
+void dcl_debug_nn_qpt(int q);
 /* Tuning hook: 0 = automatic split-K choice in dcl_sparse_conv_fwd_ws, n = force n splits (when the scratch allows),
  * -1 = at most 8 splits even for few-row launches, -2 = never split. */
 void dcl_debug_conv_split(int n);
