@@ -726,6 +726,22 @@ def test_batched_three_nn_and_knn1_bucketed_search_is_exact(request, dcl, oracle
     assert torch.equal(idxs, idx) and torch.equal(d2s, d2)
 
 
+@pytest.mark.parametrize("B,n,m", [(1, 1, 64), (3, 513, 64), (2, 5000, 8192), (40, 300, 333), (32, 3100, 1024), (1, 20000, 4096)])
+def test_batched_nn_search_shapes(dcl, oracle, B, n, m):
+    """the wave-coherent bucketed search at the edges of its launch plan: one query, a ragged last workgroup, the smallest
+    and the largest staged cloud (64 / 8192 known points), every queries-per-thread choice (launches of few and of many
+    workgroups) -- (dist2, idx) of three_nn and knn(k = 1) bit for bit against the oracle's scans, duplicates included"""
+    rng = np.random.default_rng(B * 1000 + n + m)
+    kn, unk = _cloud(rng, B, m, dup=0.1), _cloud(rng, B, n, dup=0.0)
+    unk[:, : min(n, 7)] = kn[:, : min(n, 7)]                     # queries ON known points: zero distances and exact ties
+    wd, wi = oracle.three_nn(unk, kn)
+    d2, idx = dcl.ops.three_nn(cuda(unk), cuda(kn))
+    assert np.array_equal(idx.cpu().numpy(), wi) and np.array_equal(d2.cpu().numpy(), wd)
+    wd1, wi1 = oracle.knn(1, unk, kn)
+    d1, i1 = dcl.ops.knn(1, cuda(unk), cuda(kn))
+    assert np.array_equal(i1.cpu().numpy(), wi1) and np.array_equal(d1.cpu().numpy(), wd1)
+
+
 # ------------------------------------------------------------------------------------------- dense kernels
 def _attn_ref(Q, K, V):
     """torch fp64 reference of Aligner (models/Modules.py:166-169) on point-major operands"""
