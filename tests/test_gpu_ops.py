@@ -726,7 +726,8 @@ def test_batched_three_nn_and_knn1_bucketed_search_is_exact(request, dcl, oracle
     assert torch.equal(idxs, idx) and torch.equal(d2s, d2)
 
 
-@pytest.mark.parametrize("B,n,m", [(1, 1, 64), (3, 513, 64), (2, 5000, 8192), (40, 300, 333), (32, 3100, 1024), (1, 20000, 4096)])
+@pytest.mark.parametrize("B,n,m", [(1, 1, 64), (3, 513, 64), (2, 5000, 8192), (40, 300, 333), (32, 3100, 1024), (1, 20000, 4096),
+                                   (32, 12288, 2048)])                  # the last: BASELINE's primitive shape, what bench.py times
 def test_batched_nn_search_shapes(dcl, oracle, B, n, m):
     """the wave-coherent bucketed search at the edges of its launch plan: one query, a ragged last workgroup, the smallest
     and the largest staged cloud (64 / 8192 known points), every queries-per-thread choice (launches of few and of many

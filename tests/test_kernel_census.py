@@ -82,6 +82,7 @@ def test_every_profiled_kernel_is_launched_by_an_oracle_comparing_test(request, 
     # -- <round>_primitives: bench.py's primitive shapes
     TO.test_ball_query_and_group_points_at_the_benchmarked_shape(dcl, oracle)
     TO.test_batched_three_nn_and_knn1_bucketed_search_is_exact(request, dcl, oracle, "big")
+    TO.test_batched_nn_search_shapes(dcl, oracle, 32, 12288, 2048)
     TO.test_fps_bit_exact_with_ties(dcl, oracle, 12288, 64)
     TO.test_group_and_gather_bit_exact(dcl, oracle)
     TO.test_knn_three_nn_three_interpolate_batched(dcl, oracle)
