@@ -106,3 +106,50 @@ print(" workgroup life avg %.1f us (min %.1f max %.1f); ends spread: p50 %.1f  p
     life.mean(), life.min(), life.max(), *[np.percentile((last[w] - t0) * tick, q) for q in (50, 90, 100)]))
 starts = (first[w] - t0) * tick
 print(" workgroup starts: p50 %.1f  p90 %.1f  max %.1f us" % (np.percentile(starts, 50), np.percentile(starts, 90), starts.max()))
+# ---- who is slow?  per-chunk loop time of every segment against where the workgroup ran (XCC, CU) and what shared its CU
+hw = st[:, :, 7]
+xcc = (hw >> 32) & 0xF
+hwid = hw & 0xFFFFFFFF
+cu = xcc * 1000 + ((hwid >> 13) & 0x7) * 100 + ((hwid >> 12) & 1) * 50 + ((hwid >> 8) & 0xF)       # xcc, se, sh, cu
+rows = []
+for w in range(WG):
+    for sg in range(SEG):
+        if live[w, sg] and ph[w, sg, 4] > 0 and st[w, sg, 3] > st[w, sg, 2] > 0:
+            rows.append((int(xcc[w, sg]), int(cu[w, sg]), (st[w, sg, 3] - st[w, sg, 2]) * tick / ph[w, sg, 4], ph[w, sg, 4], w, sg))
+if rows:
+    R = np.array([(r[0], r[1], r[2], r[3]) for r in rows], dtype=np.float64)
+    big = R[:, 3] >= 8                                            # segments of at least 8 chunks
+    print(" us per used chunk (segments of >= 8 chunks): avg %.3f  p10 %.3f  p50 %.3f  p90 %.3f  max %.3f" % (
+        R[big, 2].mean(), *[np.percentile(R[big, 2], q) for q in (10, 50, 90, 100)]))
+    print(" by XCC: " + "  ".join("%d: %.3f (n=%d)" % (x, R[big & (R[:, 0] == x), 2].mean(), int((big & (R[:, 0] == x)).sum())) for x in range(8) if (big & (R[:, 0] == x)).any()))
+    per_cu = {}
+    for x, c, t, n_ in R[big]:
+        per_cu.setdefault(int(c), []).append(t)
+    occ = np.array([len(v) for v in per_cu.values()])
+    mean_by_occ = {k: np.mean([np.mean(v) for v in per_cu.values() if len(v) == k]) for k in sorted(set(occ.tolist()))}
+    print(" distinct CUs %d; segments per CU -> mean us per chunk: %s" % (len(per_cu), {k: round(v, 3) for k, v in mean_by_occ.items()}))
+    cu_means = np.array([np.mean(v) for v in per_cu.values()])
+    print(" CU-to-CU spread of the mean: p10 %.3f p50 %.3f p90 %.3f" % tuple(np.percentile(cu_means, q) for q in (10, 50, 90)))
+# ---- per CU: when do its workgroups end?  (a CU is done when its last workgroup is; a workgroup that outlives its mate runs alone)
+wg_cu = {}
+for w in range(WG):
+    if live[w].any():
+        sg0 = int(np.argmax(live[w]))
+        wg_cu.setdefault(int(cu[w, sg0]), []).append(((first[w] - t0) * tick, (last[w] - t0) * tick, w))
+ends = np.array([max(e for _, e, _ in v) for v in wg_cu.values()])
+pairs = [v for v in wg_cu.values() if len(v) == 2]
+if pairs:
+    gaps = np.array([abs(v[0][1] - v[1][1]) for v in pairs])
+    print(" CU end times: p10 %.1f p50 %.1f p90 %.1f max %.1f us; CUs with two workgroups %d: gap between their two ends p50 %.1f p90 %.1f max %.1f us" % (
+        *[np.percentile(ends, q) for q in (10, 50, 90, 100)], len(pairs), *[np.percentile(gaps, q) for q in (50, 90, 100)]))
+    ids = np.array([[v[0][2], v[1][2]] for v in pairs])
+    print(" workgroup ids sharing a CU (first five pairs): %s" % ids[:5].tolist())
+half = WG // 2 if int(live.any(1).sum()) > 300 else 0
+if half and rows:
+    Rw = np.array([(r[4], r[2], r[3]) for r in rows], dtype=np.float64)
+    bigw = Rw[:, 2] >= 8
+    n_live = int(live.any(1).sum())
+    lo_ids, hi_ids = Rw[:, 0] < 256, Rw[:, 0] >= 256
+    print(" us per chunk, workgroups 0..255 (first on their CU): %.3f   workgroups 256..: %.3f;  life: %.1f vs %.1f us" % (
+        Rw[bigw & lo_ids, 1].mean(), Rw[bigw & hi_ids, 1].mean(), life[:256].mean() if len(life) > 256 else float("nan"),
+        life[256:].mean() if len(life) > 256 else float("nan")))
