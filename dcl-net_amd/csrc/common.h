@@ -188,14 +188,16 @@ __device__ __forceinline__ void dcl_nbr_col(const DclNbrSrc &s, int cap, int col
     for (int kz = 0; kz < 3; ++kz) v[kz] = s.nbr[(size_t)(3 * col + kz) * cap + row];
     return;
   }
-  v[0] = v[1] = v[2] = -1;
-  const int kx = col / 3, ky = col - 3 * kx;
+  // (branch-free but for the rare second word: an out-of-grid column reads word 0 and keeps nothing.  Early returns cost
+  //  an exec-mask save / restore each and kept a caller's unrolled items from overlapping; in a launch of a few tiles the
+  //  look-up code runs once, from a cold instruction cache, and its size is its time)
+  const int S = s.S_in;
+  const int kx = (col * 11) >> 5, ky = col - 3 * kx;                   // col / 3 for col < 9
   const int px = q.y * s.stride - s.pad + kx, py = q.z * s.stride - s.pad + ky, pz0 = q.w * s.stride - s.pad;
-  if ((unsigned)px >= (unsigned)s.S_in || (unsigned)py >= (unsigned)s.S_in) return;
-  const int base = ((q.x * s.S_in + px) * s.S_in + py) * s.S_in;
-  const int z_lo = pz0 < 0 ? 0 : pz0, z_hi = pz0 + 2 > s.S_in - 1 ? s.S_in - 1 : pz0 + 2;
-  if (z_lo > z_hi) return;
-  const int w_lo = (base + z_lo) >> 5, w_hi = (base + z_hi) >> 5;
+  const int z_lo = pz0 < 0 ? 0 : pz0, z_hi = pz0 + 2 > S - 1 ? S - 1 : pz0 + 2;
+  const bool any = (unsigned)px < (unsigned)S && (unsigned)py < (unsigned)S && z_lo <= z_hi;
+  const int base = any ? ((q.x * S + px) * S + py) * S : 0;
+  const int w_lo = any ? (base + z_lo) >> 5 : 0, w_hi = any ? (base + z_hi) >> 5 : 0;
   const uint32_t m_lo = s.in_mask[w_lo];
   const int p_lo = s.in_wprefix[w_lo];
   uint32_t m_hi = m_lo;
@@ -203,15 +205,20 @@ __device__ __forceinline__ void dcl_nbr_col(const DclNbrSrc &s, int cap, int col
   if (w_hi != w_lo) { m_hi = s.in_mask[w_hi]; p_hi = s.in_wprefix[w_hi]; }
 #pragma unroll
   for (int kz = 0; kz < 3; ++kz) {
-    const int pz = pz0 + kz;
-    if (pz < z_lo || pz > z_hi) continue;
-    const int lin = base + pz;
+    const int pz = pz0 + kz, lin = base + pz;
     const bool hi = (lin >> 5) != w_lo;
     const uint32_t m = hi ? m_hi : m_lo;
     const uint32_t bit = 1u << (lin & 31);
-    if (!(m & bit)) continue;
+    const bool present = any && pz >= z_lo && pz <= z_hi && (m & bit);
     const int r = (hi ? p_hi : p_lo) + __popc(m & (bit - 1));
-    v[kz] = s.in_perm ? s.in_perm[r] : r;
+    v[kz] = present ? r : -1;
+  }
+  if (s.in_perm) {
+#pragma unroll
+    for (int kz = 0; kz < 3; ++kz) {
+      const int r = s.in_perm[v[kz] < 0 ? 0 : v[kz]];
+      v[kz] = v[kz] < 0 ? -1 : r;
+    }
   }
 }
 #endif

@@ -984,11 +984,13 @@ __device__ __forceinline__ void conv_frag_reduce_body(const float *__restrict__ 
 // thread = (output row, 4 channels): rf = #valid offsets (summaryRF.cu:39), then
 // out = ((0 + f_k0/rf) + f_k1/rf) + ... in ascending offset order (avgpool.cu:130).
 // NTB = threads of the workgroup; item = blockIdx.x of nitems = gridDim.x, row blocks round-robin.
-template <int NTB, int PF>
-__device__ __forceinline__ void avgpool_body(const DclConvSides &sides, int nsides, int c, int kvol, int32_t *__restrict__ rf_out,
+template <int NTB, int PF, bool K27>
+__device__ __forceinline__ void avgpool_body(const DclConvSides &sides, int nsides, int c, int kvol_in, int32_t *__restrict__ rf_out,
                                              const int32_t *__restrict__ rf_in, int32_t *s_v /* LDS: 64 * 27 ints */, int item,
                                              int nitems) {
+  constexpr int kLookupUnroll = PF == 27 ? 1 : 3;
   const int tix = (int)threadIdx.x;
+  const int kvol = K27 ? 27 : kvol_in;                     // K27: the 3^3 window of the network's pools, known to the compiler
   // the c/4 threads of an output row share its 27 neighbour rows through LDS (one lookup per (row, offset) per block).
   // Up to two problems per launch (the two backbones' pools of a level): the row blocks of side 0, then those of side 1;
   // rf_out / rf_in (the op-level API) belong to side 0 of a one-sided launch.
@@ -1013,8 +1015,10 @@ __device__ __forceinline__ void avgpool_body(const DclConvSides &sides, int nsid
     const int n = second ? n1 : n0, cap = S.cap;
     const int row0 = (bi - (second ? nb0 : 0)) * rpb;
     __syncthreads();
-    if (kvol == 27) {                                      // by columns of three z-neighbours (common.h: dcl_nbr_col)
-#pragma unroll 3
+    if (K27) {                                             // by columns of three z-neighbours (common.h: dcl_nbr_col)
+      // (PF = 27 is the kernel of launches of a few thousand rows, which run their code once from a cold instruction
+      //  cache: its look-up loop stays rolled -- see the note on code size below)
+#pragma unroll kLookupUnroll
       for (int e = tid; e < rpb * 9; e += NTB) {
         const int col = e / rpb, r2 = e - col * rpb;
         int t3[3] = {-1, -1, -1};
@@ -1022,7 +1026,7 @@ __device__ __forceinline__ void avgpool_body(const DclConvSides &sides, int nsid
         s_v[r2 * 27 + 3 * col] = t3[0]; s_v[r2 * 27 + 3 * col + 1] = t3[1]; s_v[r2 * 27 + 3 * col + 2] = t3[2];
       }
     } else {
-#pragma unroll 4
+#pragma unroll 1
       for (int e = tid; e < rpb * kvol; e += NTB) {
         const int r2 = e / kvol, k = e - r2 * kvol;
         s_v[r2 * 27 + k] = row0 + r2 < n ? dcl_nbr_at(S.src, cap, k, row0 + r2) : -1;
@@ -1041,10 +1045,18 @@ __device__ __forceinline__ void avgpool_body(const DclConvSides &sides, int nsid
     // window used to be 27 dependent steps -- a branch on the LDS value in front of each -- which is what a pool of a few
     // hundred rows (one-image calls) spent its time on.  The terms are still added in ascending offset order.  (Rounds of 9
     // and of 27 were measured too: 24 / 21 / 20 / 12 us for the four pools of 32 crops either way -- 27 in flight cost the
-    // occupancy that 9 lacked in depth -- against 19 / 17 / 16 / 12 with two rounds of 14.  The kernel is bound by its chain of
-    // dependent loads, not by the 108 divisions per thread: a three-instruction exact division changed nothing.)
+    // occupancy that 9 lacked in depth -- against 19 / 17 / 16 / 12 with two rounds of 14.)
     // (PF = 27, the whole window in one round, for launches of a few thousand rows: there the launch IS its chain of dependent
     //  loads and nothing else runs on the CU)
+    //
+    // f / d of the reference's kernel, correctly rounded, in three instructions instead of the IEEE division's dozen: with
+    // r = RN(1 / d), q0 = RN(f r), e = f - q0 d (exact in an FMA), RN(q0 + e r) = RN(f / d) for every d of a pooling window
+    // (1..27) and every f whose quotient stays clear of the subnormals -- tests/test_pool_division.py walks all 2^23
+    // significands of every d -- and a row whose window holds anything else (tiny, huge, inf, nan) is redone with the
+    // division itself, neighbour by neighbour.  Why it matters: a pool of a few hundred rows runs its code ONCE, from a
+    // cold instruction cache, and the 108 expanded divisions were a third of what it had to fetch.
+    const float r = 1.0f / d;
+    uint32_t hi = 0u, lo = 0xffffffffu;                    // largest / smallest non-zero |f| of the window, as bit patterns
     for (int k0 = 0; k0 < kvol; k0 += PF) {
       float4 f[PF];
 #pragma unroll
@@ -1055,8 +1067,26 @@ __device__ __forceinline__ void avgpool_body(const DclConvSides &sides, int nsid
 #pragma unroll
       for (int j = 0; j < PF; ++j) {
         const bool ok = k0 + j < kvol && v[k0 + j] >= 0;
-        acc.x = ok ? acc.x + f[j].x / d : acc.x; acc.y = ok ? acc.y + f[j].y / d : acc.y;
-        acc.z = ok ? acc.z + f[j].z / d : acc.z; acc.w = ok ? acc.w + f[j].w / d : acc.w;
+        const float4 g = f[j];
+        const uint32_t a0 = __float_as_uint(g.x) & 0x7fffffffu, a1 = __float_as_uint(g.y) & 0x7fffffffu;
+        const uint32_t a2 = __float_as_uint(g.z) & 0x7fffffffu, a3 = __float_as_uint(g.w) & 0x7fffffffu;
+        hi = max(max(hi, max(a0, a1)), max(a2, a3));       // (rows loaded for missing neighbours included: cheap and safe)
+        lo = min(min(lo, min(a0 - 1u, a1 - 1u)), min(a2 - 1u, a3 - 1u));      // (zero wraps to the top and drops out)
+        const float q0 = g.x * r, q1 = g.y * r, q2 = g.z * r, q3 = g.w * r;
+        const float t0 = __fmaf_rn(__fmaf_rn(-q0, d, g.x), r, q0), t1 = __fmaf_rn(__fmaf_rn(-q1, d, g.y), r, q1);
+        const float t2 = __fmaf_rn(__fmaf_rn(-q2, d, g.z), r, q2), t3 = __fmaf_rn(__fmaf_rn(-q3, d, g.w), r, q3);
+        acc.x = ok ? acc.x + t0 : acc.x; acc.y = ok ? acc.y + t1 : acc.y;
+        acc.z = ok ? acc.z + t2 : acc.z; acc.w = ok ? acc.w + t3 : acc.w;
+      }
+    }
+    if (!(hi <= 0x71800000u && lo >= 0x0d800000u - 1u)) {  // not all of 2^-100 <= |f| <= 2^100 or f == 0
+      acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+      for (int k = 0; k < kvol; ++k) {
+        const int vk = v[k];
+        if (vk < 0) continue;
+        const float4 g = reinterpret_cast<const float4 *>(feat + (size_t)vk * c)[q];
+        acc.x = acc.x + g.x / d; acc.y = acc.y + g.y / d; acc.z = acc.z + g.z / d; acc.w = acc.w + g.w / d;
       }
     }
     reinterpret_cast<float4 *>(out + (size_t)row * c)[q] = acc;

@@ -306,6 +306,15 @@ __global__ void __launch_bounds__(kChainThreads) k_mask_chain64(const uint32_t *
 // before the launch; crop c waits for crops < c only, and workgroups are dispatched in index order, so the wait cannot
 // deadlock), then writes word prefixes, decoded rows and the level-0 permutation of its own crop at the ranks
 // base(crops before it) + local rank -- the same ascending linear-index numbering as the separate launches, bit for bit.
+#ifdef DCL_DIAG
+// tools/geo_stamps.py: s_memrealtime (100 MHz) at the phase boundaries of workgroup 0, thread 0 -- diagnostic library only
+__device__ unsigned long long g_geo_stamps[32];
+#define GEO_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_geo_stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define GEO_STAMP_END(i) do { __syncthreads(); GEO_STAMP(i); } while (0)
+#else
+#define GEO_STAMP(i) do { } while (0)
+#define GEO_STAMP_END(i) do { } while (0)
+#endif
 DCL_HOOK_INT(kGeoSmallBatch, 8);      // most crops of a pass that takes the one-launch geometry stage (comm holds 64 crops)
 constexpr int kGeoSmallMax = 64, kGeoCommStride = 16;
 struct GeoSmallArgs {
@@ -314,43 +323,48 @@ struct GeoSmallArgs {
   uint32_t *mask0;
   int32_t *wprefix0, *perm0, *comm;
 };
-// nine independent exclusive scans over the 1024 threads of the workgroup at once (one barrier pair for all of them);
-// the per-thread values sit in LDS (s_ex[s][thread]: count in, exclusive prefix out) so that the set loop stays rolled --
-// unrolled, the nine sets' pointers and prefixes spilled the kernel's 128 registers
-__device__ __forceinline__ void block_excl_scan9_1024(int (*s_ex)[kChainThreads], int *s_tot, int (*s_w)[16]) {
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-#pragma unroll 1
-  for (int s = 0; s < 9; ++s) {
-    const int v = s_ex[s][tid];
-    const int inc = wave_incl_scan(v);
-    if (lane == 63) s_w[s][wid] = inc;
-    s_ex[s][tid] = inc - v;                              // exclusive inside the wave
-  }
-  __syncthreads();
-#pragma unroll 1
-  for (int s = 0; s < 9; ++s) {
-    int base = 0, tot = 0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int t = s_w[s][i];
-      base += i < wid ? t : 0;
-      tot += t;
-    }
-    s_ex[s][tid] += base;
-    if (tid == 0) s_tot[s] = tot;
-  }
-  __syncthreads();
+// ---- k_geometry_small, second form.  What the first form (one thread = 8 consecutive words, nine rolled 1024-thread scans,
+// per-thread row decoding) spent its 34 us on, by stamps (tools/geo_stamps.py, one crop): 12 us in the mask chain -- 4 of
+// them in the first stage (36 guarded LDS row reads per thread) and ~1 us per later stage, each of which waited at its
+// barrier for its own global stores to LAND (__syncthreads waits for vmcnt(0)); 5.5 us in the scans (every thread summing
+// 9 x 16 wave totals); 12 us decoding rows, because a crop's voxels sit in a few hundred neighbouring words and the threads
+// that owned them walked 100+ bits each while the rest of the workgroup waited.  This form:
+//   * barriers that wait for LDS only (the stage's global stores stay in flight); all nine sets stay in LDS (sets 2..8 in
+//     their own 9 KiB), so nothing is read back from memory;
+//   * the first stage reads 18 rows per thread for 4 outputs (a thread owns 4 consecutive x at one y);
+//   * ownership interleaved inside a wave (lane L owns words 64 j + L of the wave's 512), the counts of set 0, set 1 and
+//     of set 1's non-empty words packed into ONE DPP scan per round, one more packed scan for sets 2 + 3, one for 4..8;
+//     wave totals are scanned by ONE wave per set;
+//   * set 1 (5/8 of all rows) is decoded from a list of its non-empty words dealt round-robin over the 1024 threads.
+// Same ranks, same rows, bit for bit (the ranks are prefix sums of the same popcounts in the same word order).
+constexpr int kSmallOff2 = 0, kSmallOff3 = 1024, kSmallOff4 = 2048, kSmallWords = 2048 + 128 + 128 + 16 + 16 + 2;
+__device__ __forceinline__ void lds_barrier() { __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// inclusive scan over the 64 lanes by DPP (row_shr 1/2/4/8 inside rows of 16, then row_bcast 15 / 31); fields packed into
+// v scan independently as long as none overflows into the next
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
+  return v;
 }
+__device__ __forceinline__ unsigned long long dilate_z64(unsigned long long u) { return u | (u << 1) | (u >> 1); }
+
 __global__ void __launch_bounds__(kChainThreads) k_geometry_small(const GeoSmallArgs a, const DclGeoSets g) {
-  __shared__ __attribute__((aligned(16))) uint32_t buf[2][kChainWords];
-  __shared__ int s_w[9][16], s_base[9], s_tot[9];
-  __shared__ int s_ex[9][kChainThreads];               // per set: the thread's bit count, then its exclusive prefix
-  __shared__ uint32_t s_mw[7][kChainThreads];          // sets 2..8: the thread's word (the loops over sets stay rolled)
-  const int c = blockIdx.x, tid = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) uint32_t buf[2][kChainWords];     // sets 0 and 1 (64^3), kept to the end
+  __shared__ __attribute__((aligned(16))) uint32_t small[kSmallWords + 6];  // sets 2..8 back to back
+  __shared__ uint32_t s_list[kChainWords];              // non-empty words of set 1: word | rank inside the crop << 13
+  __shared__ int32_t s_wp0[kChainWords];                // set 0's word prefixes (the level-0 permutation reads them back)
+  __shared__ int s_w[10][16], s_wbase[10][16], s_tot[10], s_base[9];     // [9] = set 1's non-empty words
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  GEO_STAMP(0);
   if (c == 0 && tid < 16 && g.zero_words) g.zero_words[tid] = 0;            // tickets of later launches of the pass
   // 1. this crop's occupancy (rows of other crops are skipped; rows are re-based by batch_lo)
   for (int i = tid; i < kChainWords / 4; i += kChainThreads) reinterpret_cast<uint4 *>(buf[0])[i] = make_uint4(0u, 0u, 0u, 0u);
-  __syncthreads();
+  if (tid < 160) s_w[tid >> 4][tid & 15] = 0;
+  lds_barrier();
   const int n = a.n_dev ? min(*a.n_dev, a.n_host) : a.n_host;
   for (int i = tid; i < n; i += kChainThreads) {
     const int4 p = reinterpret_cast<const int4 *>(a.occ)[i];
@@ -358,51 +372,113 @@ __global__ void __launch_bounds__(kChainThreads) k_geometry_small(const GeoSmall
     const int lin = ((((p.y << 6) + p.z) << 6)) + p.w;
     atomicOr(&buf[0][lin >> 5], 1u << (lin & 31));
   }
-  __syncthreads();
-  // (thread t owns words 8t .. 8t+7 of the two 64^3 sets, word t of the 32^3 sets, ... in step 3: same split here)
+  lds_barrier();
+  GEO_STAMP(1);
   {
-    const uint4 lo = reinterpret_cast<const uint4 *>(buf[0])[2 * tid], hi = reinterpret_cast<const uint4 *>(buf[0])[2 * tid + 1];
     uint4 *m0 = reinterpret_cast<uint4 *>(a.mask0 + (size_t)c * kChainWords);
-    m0[2 * tid] = lo;
-    m0[2 * tid + 1] = hi;
-    s_ex[0][tid] = ((__popc(lo.x) + __popc(lo.y)) + (__popc(lo.z) + __popc(lo.w))) + ((__popc(hi.x) + __popc(hi.y)) + (__popc(hi.z) + __popc(hi.w)));
+    m0[2 * tid] = reinterpret_cast<const uint4 *>(buf[0])[2 * tid];
+    m0[2 * tid + 1] = reinterpret_cast<const uint4 *>(buf[0])[2 * tid + 1];
   }
-  // 2. the mask chain (as k_mask_chain64): every stage's result goes to global memory and stays in LDS for the next stage
-  int S_in = kChainS, cur = 0;
-#pragma unroll 1
-  for (int i = 0; i < 8; ++i) {
-    const int S_out = g.S[i], nw = (S_out * S_out * S_out) >> 5;
-    uint32_t *gout = const_cast<uint32_t *>(g.mask[i]) + (size_t)c * nw;
-    if (i & 1) chain_stage<2>(buf[cur], buf[cur ^ 1], gout, S_in, S_out, tid);
-    else chain_stage<1>(buf[cur], buf[cur ^ 1], gout, S_in, S_out, tid);
-    __syncthreads();
-    cur ^= 1;
-    S_in = S_out;
-  }
-  // 3. this thread's words of the nine sets (the workgroup's own writes, barriers since), all loads in flight; the 2 x 8
-  // words of the 64^3 sets are parked in LDS (the chain's buffers are free now; every thread touches its own words only)
-  uint32_t mw[7];                                      // sets 2..8: at most one word per thread
+  GEO_STAMP(2);
+  // 2. the mask chain.  Stage 0 (conv set of level 0, 64^3 -> 64^3): thread = (y, 4 consecutive x); the 3 x 3 neighbourhood
+  // of its four rows is 6 x-columns of 3 rows, OR-ed over y first.  Lanes walk y: every 64-bit LDS read is conflict-free.
   {
-    const uint4 *m0 = reinterpret_cast<const uint4 *>(a.mask0 + (size_t)c * kChainWords);
-    const uint4 *m1 = reinterpret_cast<const uint4 *>(g.mask[0] + (size_t)c * kChainWords);
-    const uint4 lo0 = m0[2 * tid], hi0 = m0[2 * tid + 1], lo = m1[2 * tid], hi = m1[2 * tid + 1];
+    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(buf[0]);
+    unsigned long long *dst = reinterpret_cast<unsigned long long *>(buf[1]);
+    uint2 *gout = reinterpret_cast<uint2 *>(const_cast<uint32_t *>(g.mask[0]) + (size_t)c * kChainWords);
+    const int y = lane, x0 = wid << 2;
+    const int ym = y > 0 ? y - 1 : y, yp = y < 63 ? y + 1 : y;          // (a clamped row ORs in the row itself: harmless)
+    unsigned long long u[6];
 #pragma unroll
-    for (int s = 2; s < 9; ++s) {
-      const int S = g.S[s - 1], nw = (S * S * S) >> 5;
-      mw[s - 2] = tid < nw ? g.mask[s - 1][(size_t)c * nw + tid] : 0u;
+    for (int d = 0; d < 6; ++d) {
+      const int x = x0 - 1 + d;
+      u[d] = 0ull;
+      if ((unsigned)x < 64u) u[d] = src[(x << 6) + ym] | src[(x << 6) + y] | src[(x << 6) + yp];      // (wave-uniform test)
     }
-    reinterpret_cast<uint4 *>(buf[0])[2 * tid] = lo0;
-    reinterpret_cast<uint4 *>(buf[0])[2 * tid + 1] = hi0;
-    reinterpret_cast<uint4 *>(buf[1])[2 * tid] = lo;
-    reinterpret_cast<uint4 *>(buf[1])[2 * tid + 1] = hi;
-    s_ex[1][tid] = ((__popc(lo.x) + __popc(lo.y)) + (__popc(lo.z) + __popc(lo.w))) + ((__popc(hi.x) + __popc(hi.y)) + (__popc(hi.z) + __popc(hi.w)));
-  }
 #pragma unroll
-  for (int s = 2; s < 9; ++s) {
-    s_ex[s][tid] = __popc(mw[s - 2]);
-    s_mw[s - 2][tid] = mw[s - 2];
+    for (int k = 0; k < 4; ++k) {
+      const unsigned long long t = dilate_z64(u[k] | u[k + 1] | u[k + 2]);
+      const int row = ((x0 + k) << 6) + y;
+      dst[row] = t;
+      gout[row] = make_uint2((uint32_t)t, (uint32_t)(t >> 32));
+    }
   }
-  block_excl_scan9_1024(s_ex, s_tot, s_w);
+  lds_barrier();
+  GEO_STAMP(16);
+  {
+    const uint32_t *src = buf[1];
+    int S_in = kChainS, off = 0;
+#pragma unroll 1
+    for (int i = 1; i < 8; ++i) {
+      const int S_out = g.S[i], nw = (S_out * S_out * S_out) >> 5;
+      uint32_t *gout = const_cast<uint32_t *>(g.mask[i]) + (size_t)c * nw;
+      uint32_t *dst = small + off;
+      if (i & 1) chain_stage<2>(src, dst, gout, S_in, S_out, tid);
+      else chain_stage<1>(src, dst, gout, S_in, S_out, tid);
+      lds_barrier();
+      GEO_STAMP(16 + i);
+      src = dst;
+      off += nw;
+      S_in = S_out;
+    }
+  }
+  GEO_STAMP(3);
+  // 3. counts.  Sets 0 / 1: lane L of wave W owns words 512 W + 64 j + L, j = 0..7 -- neighbouring words, where a crop's
+  // voxels cluster, go to different lanes.  Per round ONE scan of  popc(set 0) | popc(set 1) << 12 | (set 1 word != 0) << 24
+  // (<= 2048 | 2048 | 64 per round: no field overflows); e01[j] / en[j] = this word's exclusive ranks inside the wave.
+  uint32_t e01[8], en[8];
+  {
+    uint32_t run0 = 0, run1 = 0, runn = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int w = (wid << 9) + (j << 6) + lane;
+      const uint32_t m1 = buf[1][w];
+      const uint32_t p = (uint32_t)__popc(buf[0][w]) | ((uint32_t)__popc(m1) << 12) | ((m1 ? 1u : 0u) << 24);
+      const uint32_t inc = wave_incl_scan_dpp(p);
+      const uint32_t ex = inc - p, tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+      e01[j] = (run0 + (ex & 0xfffu)) | ((run1 + ((ex >> 12) & 0xfffu)) << 16);          // <= 16384 each
+      en[j] = runn + (ex >> 24);
+      run0 += tot & 0xfffu; run1 += (tot >> 12) & 0xfffu; runn += tot >> 24;
+    }
+    if (lane == 0) { s_w[0][wid] = (int)run0; s_w[1][wid] = (int)run1; s_w[9][wid] = (int)runn; }
+  }
+  // sets 2 / 3 (32^3: 1024 words, word t to thread t), one packed scan
+  uint32_t e23;
+  {
+    const uint32_t p = (uint32_t)__popc(small[kSmallOff2 + tid]) | ((uint32_t)__popc(small[kSmallOff3 + tid]) << 16);
+    const uint32_t inc = wave_incl_scan_dpp(p);
+    e23 = inc - p;
+    if (lane == 63) { s_w[2][wid] = (int)(inc & 0xffffu); s_w[3][wid] = (int)(inc >> 16); }
+  }
+  // sets 4..8 (128 + 128 + 16 + 16 + 2 words, back to back in `small`): item v = tid < 290.  Set 4 = waves 0, 1; set 5 = waves
+  // 2, 3; sets 6 / 7 / 8 = lanes 0..15 / 16..31 / 32, 33 of wave 4: one plain scan per wave, set boundaries by readlane.
+  int sv = -1, wv = 0, e48 = 0;                         // this thread's item: set, word inside the set, exclusive rank
+  if (wid < 5) {                                        // (wave-uniform)
+    const bool has = tid < 290;
+    const uint32_t p = has ? (uint32_t)__popc(small[kSmallOff4 + tid]) : 0u;
+    const uint32_t inc = wave_incl_scan_dpp(p);
+    const int ex = (int)(inc - p);
+    if (wid < 4) {
+      sv = 4 + (wid >> 1); wv = tid & 127; e48 = ex;
+      if (lane == 63) s_w[sv][wid] = (int)inc;
+    } else {
+      const int at16 = __builtin_amdgcn_readlane(ex, 16), at32 = __builtin_amdgcn_readlane(ex, 32), end = __builtin_amdgcn_readlane((int)inc, 33);
+      if (lane < 16) { sv = 6; wv = lane; e48 = ex; }
+      else if (lane < 32) { sv = 7; wv = lane - 16; e48 = ex - at16; }
+      else if (lane < 34) { sv = 8; wv = lane - 32; e48 = ex - at32; }
+      if (lane == 0) { s_w[6][4] = at16; s_w[7][4] = at32 - at16; s_w[8][4] = end - at32; }
+    }
+  }
+  GEO_STAMP(4);
+  lds_barrier();
+  if (wid < 10) {                                       // wave s: exclusive scan of set s's 16 wave totals
+    const int v = lane < 16 ? s_w[wid][lane] : 0;
+    const int inc = (int)wave_incl_scan_dpp((uint32_t)v);
+    if (lane < 16) s_wbase[wid][lane] = inc - v;
+    if (lane == 15) s_tot[wid] = inc;
+  }
+  lds_barrier();
+  GEO_STAMP(5);
   // 4. counts out, bases in
   int32_t *mine = a.comm + c * kGeoCommStride;
   if (tid == 0) {
@@ -418,15 +494,13 @@ __global__ void __launch_bounds__(kChainThreads) k_geometry_small(const GeoSmall
     }
     s_base[tid] = base;
   }
-  __syncthreads();
-  // 5. word prefixes and decoded rows at base(crops before this one) + local rank (set 0 = the input grid: no rows)
-  const bool last = c == a.batch - 1;
-  auto emit = [&](int s, int S, int w, uint32_t m, int &r) __attribute__((always_inline)) {
-    const int lg = 31 - __clz(S), nw = (S * S * S) >> 5;
-    (s == 0 ? a.wprefix0 : g.wprefix[s - 1])[(size_t)c * nw + w] = r;
-    if (s == 0) { r += __popc(m); return; }
-    int4 *rows = reinterpret_cast<int4 *>(g.indices[s - 1]);
-    const int cap = g.cap[s - 1];
+  lds_barrier();
+  GEO_STAMP(6);
+  // 5. word prefixes (every set) and decoded rows (sets 1..8) at base(crops before this one) + rank inside the crop
+  auto decode = [&](int set, int S, int w, uint32_t m, int r) __attribute__((always_inline)) {
+    const int lg = 31 - __clz(S);
+    int4 *rows = reinterpret_cast<int4 *>(g.indices[set - 1]);
+    const int cap = g.cap[set - 1];
     while (m) {
       const int bit = __ffs(m) - 1;
       m &= m - 1;
@@ -436,40 +510,59 @@ __global__ void __launch_bounds__(kChainThreads) k_geometry_small(const GeoSmall
     }
   };
   {
-    int r0 = s_ex[0][tid] + s_base[0], r1 = s_ex[1][tid] + s_base[1];
-#pragma unroll 1
+    const int b0 = s_base[0] + s_wbase[0][wid], b1 = s_wbase[1][wid], bn = s_wbase[9][wid], g1 = s_base[1];
+    int32_t *wp0 = a.wprefix0 + (size_t)c * kChainWords, *wp1 = g.wprefix[0] + (size_t)c * kChainWords;
+#pragma unroll
     for (int j = 0; j < 8; ++j) {
-      emit(0, kChainS, 8 * tid + j, buf[0][8 * tid + j], r0);
-      emit(1, kChainS, 8 * tid + j, buf[1][8 * tid + j], r1);
+      const int w = (wid << 9) + (j << 6) + lane;
+      const int r0 = b0 + (int)(e01[j] & 0xffffu), r1 = b1 + (int)(e01[j] >> 16);       // r1: inside the crop
+      wp0[w] = r0;
+      s_wp0[w] = r0;
+      wp1[w] = g1 + r1;
+      if (buf[1][w]) s_list[bn + (int)en[j]] = (uint32_t)w | ((uint32_t)r1 << 13);
     }
+  }
+  {
+    const int r2 = s_base[2] + s_wbase[2][wid] + (int)(e23 & 0xffffu), r3 = s_base[3] + s_wbase[3][wid] + (int)(e23 >> 16);
+    g.wprefix[1][(size_t)c * 1024 + tid] = r2;
+    g.wprefix[2][(size_t)c * 1024 + tid] = r3;
+    decode(2, 32, tid, small[kSmallOff2 + tid], r2);
+    decode(3, 32, tid, small[kSmallOff3 + tid], r3);
+  }
+  if (sv >= 0) {
+    const int S = g.S[sv - 1], nw = (S * S * S) >> 5;
+    const int r = s_base[sv] + s_wbase[sv][wid] + e48;
+    g.wprefix[sv - 1][(size_t)c * nw + wv] = r;
+    decode(sv, S, wv, small[kSmallOff4 + tid], r);
+  }
+  lds_barrier();                                        // set 1's list and set 0's prefixes are in LDS
+  {
+    const int ne = s_tot[9], g1 = s_base[1];
 #pragma unroll 1
-    for (int s = 2; s < 9; ++s) {
-      const int S = g.S[s - 1], nw = (S * S * S) >> 5;
-      int r = s_ex[s][tid] + s_base[s];
-      if (tid < nw) emit(s, S, tid, s_mw[s - 2][tid], r);
+    for (int e = tid; e < ne; e += kChainThreads) {
+      const uint32_t ent = s_list[e];
+      const int w = (int)(ent & 0x1fffu);
+      decode(1, kChainS, w, buf[1][w], g1 + (int)(ent >> 13));
     }
   }
-  if (last && tid == 0) {
-    for (int s = 0; s < 9; ++s) {
-      const int S = s == 0 ? kChainS : g.S[s - 1], nw = (S * S * S) >> 5;
-      const int total = s_base[s] + s_tot[s];
-      (s == 0 ? a.wprefix0 : g.wprefix[s - 1])[(size_t)a.batch * nw] = total;
-      if (s > 0 && g.n_out[s - 1]) *g.n_out[s - 1] = total;
-    }
+  GEO_STAMP(7);
+  if (c == a.batch - 1 && tid < 9) {                    // totals: the entry past the last crop's words, and the live counts
+    const int s = tid, S = s == 0 ? kChainS : g.S[s - 1], nw = (S * S * S) >> 5;
+    const int total = s_base[s] + s_tot[s];
+    (s == 0 ? a.wprefix0 : g.wprefix[s - 1])[(size_t)a.batch * nw] = total;
+    if (s > 0 && g.n_out[s - 1]) *g.n_out[s - 1] = total;
   }
-  __syncthreads();
-  // 6. level-0 permutation: rank -> row of the caller's voxel list
+  GEO_STAMP(8);
+  // 6. level-0 permutation: rank -> row of the caller's voxel list (mask and prefixes of set 0 are still in LDS)
   if (a.perm0) {
-    const uint32_t *m0 = a.mask0 + (size_t)c * kChainWords;
-    const int32_t *wp0 = a.wprefix0 + (size_t)c * kChainWords;
     for (int i = tid; i < n; i += kChainThreads) {
       const int4 p = reinterpret_cast<const int4 *>(a.occ)[i];
       if (p.x - a.batch_lo != c) continue;
       const int lin = ((((p.y << 6) + p.z) << 6)) + p.w;
-      const uint32_t mword = m0[lin >> 5];
-      a.perm0[wp0[lin >> 5] + __popc(mword & ((1u << (lin & 31)) - 1u))] = i;
+      a.perm0[s_wp0[lin >> 5] + __popc(buf[0][lin >> 5] & ((1u << (lin & 31)) - 1u))] = i;
     }
   }
+  GEO_STAMP_END(9);
 }
 
 // decode every set bit into its (b,x,y,z) row at its rank (assignGridAndIndiceOutKernel,
@@ -805,11 +898,14 @@ int dcl_internal_mask_chain(const uint32_t *mask0, int batch, const DclGeoSets &
 bool dcl_internal_geometry_small_ok(int batch, int S) { return S == kChainS && batch >= 1 && batch <= kGeoSmallBatch && batch <= kGeoSmallMax; }
 #ifdef DCL_DIAG
 DCL_API void dcl_debug_geometry_small_batch(int n) { kGeoSmallBatch = n; }
+DCL_API int dcl_debug_geometry_small_stamps(unsigned long long *host32) {
+  return hipMemcpyFromSymbol(host32, HIP_SYMBOL(g_geo_stamps), sizeof(g_geo_stamps)) == hipSuccess ? 0 : DCL_EINVAL;
+}
 #endif
 int dcl_internal_geometry_small(const int32_t *occ, const int32_t *n_dev, int n_host, int batch_lo, int batch, uint32_t *mask0,
                                 int32_t *wprefix0, int32_t *perm0, int32_t *comm, const DclGeoSets &g, dclStream_t stream) {
   DCL_CHECK_ARG(dcl_internal_geometry_small_ok(batch, kChainS) && mask0 && wprefix0 && comm && (n_host == 0 || occ));
-  for (int i = 0; i < 8; ++i) DCL_CHECK_ARG(g.mask[i] && g.wprefix[i] && g.indices[i] && g.S[i] > 0);
+  for (int i = 0; i < 8; ++i) DCL_CHECK_ARG(g.mask[i] && g.wprefix[i] && g.indices[i] && g.S[i] == kChainS >> ((i + 1) >> 1));      // 64, 32, 32, 16, 16, 8, 8, 4
   hipStream_t s = (hipStream_t)stream;
   dcl_internal_zero_words(comm, (long long)kGeoSmallMax * kGeoCommStride, s);
   GeoSmallArgs a{occ, n_dev, n_host, batch_lo, batch, mask0, wprefix0, perm0, comm};

@@ -614,11 +614,11 @@ static void launch_conv_tile(int rows, const float *feat, const DclNbrSrc &nbr, 
 #endif  // DCL_DIAG
 
 // ---- sparse average pool (conv_body.h: avgpool_body) ----------------------------------------------------------------
-template <int PF>
+template <int PF, bool K27>
 __global__ __launch_bounds__(256) void k_sparse_avgpool(const DclConvSides sides, int nsides, int c, int kvol,
                                                         int32_t *__restrict__ rf_out, const int32_t *__restrict__ rf_in) {
   __shared__ int32_t s_v[64 * 27];
-  avgpool_body<256, PF>(sides, nsides, c, kvol, rf_out, rf_in, s_v, blockIdx.x, gridDim.x);
+  avgpool_body<256, PF, K27>(sides, nsides, c, kvol, rf_out, rf_in, s_v, blockIdx.x, gridDim.x);
 }
 
 
@@ -1055,10 +1055,13 @@ int dcl_internal_sparse_avgpool_fwd_sides(const DclConvSides &sides_in, int nsid
   hipStream_t s = (hipStream_t)stream;
   const int c4 = c / 4;
   if (c % 4 == 0 && c4 >= 4 && c4 <= 64 && 256 % c4 == 0) {
-    if (expect * c4 <= 256 * 512)                          // at most two workgroups per CU: one round of 27 gathers
-      hipLaunchKernelGGL(k_sparse_avgpool<27>, dim3(dcl_grid_1d(rows * c4, 256, 2048)), dim3(256), 0, s, sides, nsides, c, kvol, rf, rf_in);
+    const dim3 grid(dcl_grid_1d(rows * c4, 256, 2048));
+    if (kvol != 27)                                        // (op-level calls with another window: the network's pools are 3^3)
+      hipLaunchKernelGGL((k_sparse_avgpool<14, false>), grid, dim3(256), 0, s, sides, nsides, c, kvol, rf, rf_in);
+    else if (expect * c4 <= 256 * 512)                     // at most two workgroups per CU: one round of 27 gathers
+      hipLaunchKernelGGL((k_sparse_avgpool<27, true>), grid, dim3(256), 0, s, sides, nsides, c, kvol, rf, rf_in);
     else
-      hipLaunchKernelGGL(k_sparse_avgpool<14>, dim3(dcl_grid_1d(rows * c4, 256, 2048)), dim3(256), 0, s, sides, nsides, c, kvol, rf, rf_in);
+      hipLaunchKernelGGL((k_sparse_avgpool<14, true>), grid, dim3(256), 0, s, sides, nsides, c, kvol, rf, rf_in);
   } else {
     for (int i = 0; i < nsides; ++i) {
       const DclConvSide &S = sides.s[i];

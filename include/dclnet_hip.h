@@ -559,6 +559,7 @@ void dcl_debug_conv_few_tiles(int on);
 void dcl_debug_conv_wlds(int on);
 /* Tuning hook: most crops of a pass whose geometry stage runs as one launch (k_geometry_small; default 8, at most 64). */
 void dcl_debug_geometry_small_batch(int n);
+int dcl_debug_geometry_small_stamps(unsigned long long *host32);   /* s_memrealtime (100 MHz) at the phase boundaries of workgroup 0 of the last k_geometry_small (0..9), after each mask-chain stage (16..23) */
 /* Diagnostic: a one-thread launch that writes the 100 MHz wall clock into *slot_dev (a time stamp inside a stream or a
  * captured graph: tools/graph_timeline.py). */
 int dcl_debug_stamp(unsigned long long *slot_dev, dclStream_t stream);
