@@ -229,38 +229,40 @@ __global__ void k_out_mask_k3(const uint32_t *__restrict__ in_mask, int batch, i
 constexpr int kChainS = 64, kChainWords = kChainS * kChainS * kChainS / 32, kChainThreads = 1024;
 // (branch-free: an out-of-range neighbour row reads row (0, 0) and is masked out, so that the nine rows' LDS reads of an
 // output row are independent loads in flight together instead of nine guarded round trips)
+template <bool IN64>   // IN64: the input grid is 64 wide (two words per row), known to the compiler -- a uniform branch on S
+                       // around the LDS read made every one of the nine reads of an output row wait for the one before it
 __device__ __forceinline__ unsigned long long local_zrow(const uint32_t *m, int x, int y, int S, int lg) {
   const bool ok = (unsigned)x < (unsigned)S && (unsigned)y < (unsigned)S;
   const int off = (((ok ? x : 0) << lg) + (ok ? y : 0)) << lg;          // bit offset of the z-row inside the crop
   const int w = off >> 5;
   unsigned long long v;
-  if (S == 64) v = (unsigned long long)m[w] | ((unsigned long long)m[w + 1] << 32);
+  if constexpr (IN64) v = (unsigned long long)m[w] | ((unsigned long long)m[w + 1] << 32);
   else {
     const uint32_t r = m[w] >> (off & 31);
-    v = (unsigned long long)(S == 32 ? r : r & ((1u << S) - 1u));
+    v = (unsigned long long)(r & (S == 32 ? ~0u : (1u << S) - 1u));
   }
   return ok ? v : 0ull;
 }
-template <int STRIDE>
+template <int STRIDE, bool IN64>
 __device__ __forceinline__ unsigned long long local_out_row(const uint32_t *src, int row, int S_in, int lg_in, int lg_out) {
   const int ox = row >> lg_out, oy = row & ((1 << lg_out) - 1);
   unsigned long long u = 0ull;
 #pragma unroll
   for (int dx = -1; dx <= 1; ++dx)
 #pragma unroll
-    for (int dy = -1; dy <= 1; ++dy) u |= local_zrow(src, ox * STRIDE + dx, oy * STRIDE + dy, S_in, lg_in);
-  unsigned long long t = (u | (u << 1) | (u >> 1)) & (S_in == 64 ? ~0ull : ((1ull << S_in) - 1ull));
+    for (int dy = -1; dy <= 1; ++dy) u |= local_zrow<IN64>(src, ox * STRIDE + dx, oy * STRIDE + dy, S_in, lg_in);
+  unsigned long long t = (u | (u << 1) | (u >> 1)) & (IN64 ? ~0ull : ((1ull << S_in) - 1ull));
   if (STRIDE == 2) t = compress_even_bits(t);
   return t;
 }
-template <int STRIDE>
+template <int STRIDE, bool IN64>
 __device__ __forceinline__ void chain_stage(const uint32_t *src, uint32_t *dst, uint32_t *__restrict__ gout, int S_in,
                                             int S_out, int tid) {
   const int lg_in = 31 - __clz(S_in), lg_out = 31 - __clz(S_out);
   const int rows = S_out << lg_out;
   if (S_out == 64) {                                                    // one thread per row = two words
     for (int row = tid; row < rows; row += kChainThreads) {
-      const unsigned long long t = local_out_row<STRIDE>(src, row, S_in, lg_in, lg_out);
+      const unsigned long long t = local_out_row<STRIDE, IN64>(src, row, S_in, lg_in, lg_out);
       const uint2 v = make_uint2((uint32_t)t, (uint32_t)(t >> 32));
       reinterpret_cast<uint2 *>(dst)[row] = v;
       reinterpret_cast<uint2 *>(gout)[row] = v;
@@ -271,7 +273,7 @@ __device__ __forceinline__ void chain_stage(const uint32_t *src, uint32_t *dst, 
     // levels to a handful of threads walking 4-8 rows each -- they were the longest stages of the chain)
     const int lg_rpw = 5 - lg_out, sub = tid & ((1 << lg_rpw) - 1);
     uint32_t bits = 0;
-    if (tid < rows) bits = (uint32_t)local_out_row<STRIDE>(src, tid, S_in, lg_in, lg_out) << (sub << lg_out);
+    if (tid < rows) bits = (uint32_t)local_out_row<STRIDE, IN64>(src, tid, S_in, lg_in, lg_out) << (sub << lg_out);
     for (int d = 1; d < (1 << lg_rpw); d <<= 1) bits |= __shfl_xor(bits, d, 64);
     if (tid < rows && sub == 0) {
       dst[tid >> lg_rpw] = bits;
@@ -279,20 +281,52 @@ __device__ __forceinline__ void chain_stage(const uint32_t *src, uint32_t *dst, 
     }
   }
 }
+// barrier that waits for the workgroup's LDS traffic only: __syncthreads() also waits for vmcnt(0), i.e. every stage of the
+// chain would wait for its own global stores to land (~1 us each) before the next one may read LDS
+__device__ __forceinline__ void lds_barrier() { __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ unsigned long long dilate_z64(unsigned long long u) { return u | (u << 1) | (u >> 1); }
+// Stage 0 (conv set of level 0, 64^3 -> 64^3) for 1024 threads: thread = (y, 4 consecutive x); the 3 x 3 neighbourhoods of
+// its four rows are 6 x-columns of 3 rows, OR-ed over y first: 18 row reads for 4 outputs instead of 36 guarded ones.  Lanes
+// walk y: every 64-bit LDS read is conflict-free.
+__device__ __forceinline__ void chain_stage0_64(const uint32_t *src32, uint32_t *dst32, uint32_t *__restrict__ gout32, int tid) {
+  const unsigned long long *src = reinterpret_cast<const unsigned long long *>(src32);
+  unsigned long long *dst = reinterpret_cast<unsigned long long *>(dst32);
+  uint2 *gout = reinterpret_cast<uint2 *>(gout32);
+  const int y = tid & 63, x0 = (tid >> 6) << 2;
+  const int ym = y > 0 ? y - 1 : y, yp = y < 63 ? y + 1 : y;            // (a clamped row ORs in the row itself: harmless)
+  unsigned long long u[6];
+#pragma unroll
+  for (int d = 0; d < 6; ++d) {
+    const int x = x0 - 1 + d;
+    u[d] = 0ull;
+    if ((unsigned)x < 64u) u[d] = src[(x << 6) + ym] | src[(x << 6) + y] | src[(x << 6) + yp];        // (wave-uniform test)
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const unsigned long long t = dilate_z64(u[k] | u[k + 1] | u[k + 2]);
+    const int row = ((x0 + k) << 6) + y;
+    dst[row] = t;
+    gout[row] = make_uint2((uint32_t)t, (uint32_t)(t >> 32));
+  }
+}
 __global__ void __launch_bounds__(kChainThreads) k_mask_chain64(const uint32_t *__restrict__ mask0, const DclGeoSets g) {
   __shared__ __attribute__((aligned(16))) uint32_t buf[2][kChainWords];
   const int b = blockIdx.x, tid = threadIdx.x;
   for (int i = tid; i < kChainWords / 4; i += kChainThreads)
     reinterpret_cast<uint4 *>(buf[0])[i] = reinterpret_cast<const uint4 *>(mask0 + (size_t)b * kChainWords)[i];
-  __syncthreads();
-  int S_in = kChainS, cur = 0;
+  lds_barrier();
+  chain_stage0_64(buf[0], buf[1], const_cast<uint32_t *>(g.mask[0]) + (size_t)b * kChainWords, tid);
+  lds_barrier();
+  chain_stage<2, true>(buf[1], buf[0], const_cast<uint32_t *>(g.mask[1]) + (size_t)b * 1024, kChainS, kChainS / 2, tid);
+  lds_barrier();
+  int S_in = kChainS / 2, cur = 0;
 #pragma unroll 1
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 2; i < 8; ++i) {
     const int S_out = g.S[i];
     uint32_t *gout = const_cast<uint32_t *>(g.mask[i]) + (size_t)b * ((S_out * S_out * S_out) >> 5);
-    if (i & 1) chain_stage<2>(buf[cur], buf[cur ^ 1], gout, S_in, S_out, tid);
-    else chain_stage<1>(buf[cur], buf[cur ^ 1], gout, S_in, S_out, tid);
-    __syncthreads();
+    if (i & 1) chain_stage<2, false>(buf[cur], buf[cur ^ 1], gout, S_in, S_out, tid);
+    else chain_stage<1, false>(buf[cur], buf[cur ^ 1], gout, S_in, S_out, tid);
+    lds_barrier();
     cur ^= 1;
     S_in = S_out;
   }
@@ -338,7 +372,6 @@ struct GeoSmallArgs {
 //   * set 1 (5/8 of all rows) is decoded from a list of its non-empty words dealt round-robin over the 1024 threads.
 // Same ranks, same rows, bit for bit (the ranks are prefix sums of the same popcounts in the same word order).
 constexpr int kSmallOff2 = 0, kSmallOff3 = 1024, kSmallOff4 = 2048, kSmallWords = 2048 + 128 + 128 + 16 + 16 + 2;
-__device__ __forceinline__ void lds_barrier() { __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // inclusive scan over the 64 lanes by DPP (row_shr 1/2/4/8 inside rows of 16, then row_bcast 15 / 31); fields packed into
 // v scan independently as long as none overflows into the next
 __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
@@ -350,7 +383,6 @@ __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
   return v;
 }
-__device__ __forceinline__ unsigned long long dilate_z64(unsigned long long u) { return u | (u << 1) | (u >> 1); }
 
 __global__ void __launch_bounds__(kChainThreads) k_geometry_small(const GeoSmallArgs a, const DclGeoSets g) {
   __shared__ __attribute__((aligned(16))) uint32_t buf[2][kChainWords];     // sets 0 and 1 (64^3), kept to the end
@@ -362,10 +394,10 @@ __global__ void __launch_bounds__(kChainThreads) k_geometry_small(const GeoSmall
   GEO_STAMP(0);
   if (c == 0 && tid < 16 && g.zero_words) g.zero_words[tid] = 0;            // tickets of later launches of the pass
   // 1. this crop's occupancy (rows of other crops are skipped; rows are re-based by batch_lo)
+  const int n = a.n_dev ? min(*a.n_dev, a.n_host) : a.n_host;        // (asked for before the zeroing: two dependent round trips)
   for (int i = tid; i < kChainWords / 4; i += kChainThreads) reinterpret_cast<uint4 *>(buf[0])[i] = make_uint4(0u, 0u, 0u, 0u);
   if (tid < 160) s_w[tid >> 4][tid & 15] = 0;
   lds_barrier();
-  const int n = a.n_dev ? min(*a.n_dev, a.n_host) : a.n_host;
   for (int i = tid; i < n; i += kChainThreads) {
     const int4 p = reinterpret_cast<const int4 *>(a.occ)[i];
     if (p.x - a.batch_lo != c) continue;
@@ -380,41 +412,23 @@ __global__ void __launch_bounds__(kChainThreads) k_geometry_small(const GeoSmall
     m0[2 * tid + 1] = reinterpret_cast<const uint4 *>(buf[0])[2 * tid + 1];
   }
   GEO_STAMP(2);
-  // 2. the mask chain.  Stage 0 (conv set of level 0, 64^3 -> 64^3): thread = (y, 4 consecutive x); the 3 x 3 neighbourhood
-  // of its four rows is 6 x-columns of 3 rows, OR-ed over y first.  Lanes walk y: every 64-bit LDS read is conflict-free.
-  {
-    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(buf[0]);
-    unsigned long long *dst = reinterpret_cast<unsigned long long *>(buf[1]);
-    uint2 *gout = reinterpret_cast<uint2 *>(const_cast<uint32_t *>(g.mask[0]) + (size_t)c * kChainWords);
-    const int y = lane, x0 = wid << 2;
-    const int ym = y > 0 ? y - 1 : y, yp = y < 63 ? y + 1 : y;          // (a clamped row ORs in the row itself: harmless)
-    unsigned long long u[6];
-#pragma unroll
-    for (int d = 0; d < 6; ++d) {
-      const int x = x0 - 1 + d;
-      u[d] = 0ull;
-      if ((unsigned)x < 64u) u[d] = src[(x << 6) + ym] | src[(x << 6) + y] | src[(x << 6) + yp];      // (wave-uniform test)
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const unsigned long long t = dilate_z64(u[k] | u[k + 1] | u[k + 2]);
-      const int row = ((x0 + k) << 6) + y;
-      dst[row] = t;
-      gout[row] = make_uint2((uint32_t)t, (uint32_t)(t >> 32));
-    }
-  }
+  // 2. the mask chain: stage 0 (chain_stage0_64), stage 1 out of the 64-wide grid, then the six stages of the narrow grids
+  chain_stage0_64(buf[0], buf[1], const_cast<uint32_t *>(g.mask[0]) + (size_t)c * kChainWords, tid);
   lds_barrier();
   GEO_STAMP(16);
+  chain_stage<2, true>(buf[1], small, const_cast<uint32_t *>(g.mask[1]) + (size_t)c * 1024, kChainS, kChainS / 2, tid);
+  lds_barrier();
+  GEO_STAMP(17);
   {
-    const uint32_t *src = buf[1];
-    int S_in = kChainS, off = 0;
+    const uint32_t *src = small;
+    int S_in = kChainS / 2, off = 1024;
 #pragma unroll 1
-    for (int i = 1; i < 8; ++i) {
+    for (int i = 2; i < 8; ++i) {
       const int S_out = g.S[i], nw = (S_out * S_out * S_out) >> 5;
       uint32_t *gout = const_cast<uint32_t *>(g.mask[i]) + (size_t)c * nw;
       uint32_t *dst = small + off;
-      if (i & 1) chain_stage<2>(src, dst, gout, S_in, S_out, tid);
-      else chain_stage<1>(src, dst, gout, S_in, S_out, tid);
+      if (i & 1) chain_stage<2, false>(src, dst, gout, S_in, S_out, tid);
+      else chain_stage<1, false>(src, dst, gout, S_in, S_out, tid);
       lds_barrier();
       GEO_STAMP(16 + i);
       src = dst;
@@ -479,21 +493,23 @@ __global__ void __launch_bounds__(kChainThreads) k_geometry_small(const GeoSmall
   }
   lds_barrier();
   GEO_STAMP(5);
-  // 4. counts out, bases in
-  int32_t *mine = a.comm + c * kGeoCommStride;
-  if (tid == 0) {
-    for (int s = 0; s < 9; ++s) __hip_atomic_store(mine + s, s_tot[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(mine + 15, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  if (tid < 9) {
-    int base = 0;
-    for (int c2 = 0; c2 < c; ++c2) {
-      const int32_t *theirs = a.comm + c2 * kGeoCommStride;
-      while (__hip_atomic_load(theirs + 15, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(2);
-      base += __hip_atomic_load(theirs + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // 4. counts out, bases in (a pass of ONE crop has nobody to tell)
+  if (a.batch > 1) {
+    int32_t *mine = a.comm + c * kGeoCommStride;
+    if (tid == 0) {
+      for (int s = 0; s < 9; ++s) __hip_atomic_store(mine + s, s_tot[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(mine + 15, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
-    s_base[tid] = base;
-  }
+    if (tid < 9) {
+      int base = 0;
+      for (int c2 = 0; c2 < c; ++c2) {
+        const int32_t *theirs = a.comm + c2 * kGeoCommStride;
+        while (__hip_atomic_load(theirs + 15, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(2);
+        base += __hip_atomic_load(theirs + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      s_base[tid] = base;
+    }
+  } else if (tid < 9) s_base[tid] = 0;
   lds_barrier();
   GEO_STAMP(6);
   // 5. word prefixes (every set) and decoded rows (sets 1..8) at base(crops before this one) + rank inside the crop
@@ -542,7 +558,19 @@ __global__ void __launch_bounds__(kChainThreads) k_geometry_small(const GeoSmall
     for (int e = tid; e < ne; e += kChainThreads) {
       const uint32_t ent = s_list[e];
       const int w = (int)(ent & 0x1fffu);
-      decode(1, kChainS, w, buf[1][w], g1 + (int)(ent >> 13));
+      // (a word of a 64-wide grid is half a z-row: x, y and the z half are the word's, only the bit moves)
+      uint32_t m = buf[1][w];
+      int r = g1 + (int)(ent >> 13);
+      int4 row = make_int4(c, w >> 7, (w >> 1) & 63, (w & 1) << 5);
+      int4 *rows = reinterpret_cast<int4 *>(g.indices[0]) + r;
+      int left = g.cap[0] - r;
+      while (m) {
+        const int bit = __ffs(m) - 1;
+        m &= m - 1;
+        if (left > 0) *rows = make_int4(row.x, row.y, row.z, row.w + bit);
+        ++rows;
+        --left;
+      }
     }
   }
   GEO_STAMP(7);
@@ -888,6 +916,7 @@ int dcl_internal_out_mask_k3(const uint32_t *in_mask, int batch, int S_in, int s
 bool dcl_internal_mask_chain_ok(int S) { return S == kChainS; }
 int dcl_internal_mask_chain(const uint32_t *mask0, int batch, const DclGeoSets &g, dclStream_t stream) {
   if (batch <= 0) return 0;
+  for (int i = 0; i < 8; ++i) DCL_CHECK_ARG(g.mask[i] && g.S[i] == kChainS >> ((i + 1) >> 1));      // 64, 32, 32, 16, 16, 8, 8, 4
   hipLaunchKernelGGL(k_mask_chain64, dim3(batch), dim3(kChainThreads), 0, (hipStream_t)stream, mask0, g);
   DCL_LAUNCH_CHECK();
   return 0;

@@ -14,8 +14,8 @@ b = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 dev = torch.device("cuda:0")
 data = dcl.synth.make_batch(b, 1024, 1024)
 occ = data["inp"]["occupied_voxels"].to(dev).int().contiguous()
-names = ["zero LDS, n, occupancy scatter", "mask0 out + popc", "8-stage mask chain", "own words back from memory", "nine scans",
-         "counts out / bases in", "word prefixes + decoded rows", "totals (one thread)", "level-0 permutation"]
+names = ["n, zero LDS, occupancy scatter", "set 0 out", "8-stage mask chain", "counts: packed wave scans", "wave totals scanned",
+         "counts out / bases in", "word prefixes + decoded rows", "totals", "level-0 permutation"]
 lib = ops.N.lib()
 acc = np.zeros(9)
 chain = np.zeros(8)
