@@ -351,6 +351,7 @@ __device__ unsigned long long g_geo_stamps[32];
 #endif
 DCL_HOOK_INT(kGeoSmallBatch, 8);      // most crops of a pass that takes the one-launch geometry stage (comm holds 64 crops)
 constexpr int kGeoSmallMax = 64, kGeoCommStride = 16;
+static_assert(kGeoSmallMax * kGeoCommStride == kChainThreads, "k_geometry_small: one thread per exchange word");
 struct GeoSmallArgs {
   const int32_t *occ, *n_dev;
   int n_host, batch_lo, batch;
@@ -397,6 +398,7 @@ __global__ void __launch_bounds__(kChainThreads) k_geometry_small(const GeoSmall
   const int n = a.n_dev ? min(*a.n_dev, a.n_host) : a.n_host;        // (asked for before the zeroing: two dependent round trips)
   for (int i = tid; i < kChainWords / 4; i += kChainThreads) reinterpret_cast<uint4 *>(buf[0])[i] = make_uint4(0u, 0u, 0u, 0u);
   if (tid < 160) s_w[tid >> 4][tid & 15] = 0;
+  if (tid < 9) s_base[tid] = 0;
   lds_barrier();
   for (int i = tid; i < n; i += kChainThreads) {
     const int4 p = reinterpret_cast<const int4 *>(a.occ)[i];
@@ -493,23 +495,21 @@ __global__ void __launch_bounds__(kChainThreads) k_geometry_small(const GeoSmall
   }
   lds_barrier();
   GEO_STAMP(5);
-  // 4. counts out, bases in (a pass of ONE crop has nobody to tell)
+  // 4. counts out, bases in (a pass of ONE crop has nobody to tell).  Thread (c2, s) fetches set s's count of crop c2 < c: all
+  // crops' flags and counts in flight together (nine lanes walking the crops one after the other were 2 round trips per crop)
   if (a.batch > 1) {
     int32_t *mine = a.comm + c * kGeoCommStride;
     if (tid == 0) {
       for (int s = 0; s < 9; ++s) __hip_atomic_store(mine + s, s_tot[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(mine + 15, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (tid < 9) {
-      int base = 0;
-      for (int c2 = 0; c2 < c; ++c2) {
-        const int32_t *theirs = a.comm + c2 * kGeoCommStride;
-        while (__hip_atomic_load(theirs + 15, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(2);
-        base += __hip_atomic_load(theirs + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      s_base[tid] = base;
+    const int c2 = tid >> 4, s = tid & 15;              // (kGeoSmallMax crops x kGeoCommStride words = the 1024 threads)
+    if (c2 < c && s < 9) {
+      const int32_t *theirs = a.comm + c2 * kGeoCommStride;
+      while (__hip_atomic_load(theirs + 15, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(2);
+      atomicAdd(&s_base[s], __hip_atomic_load(theirs + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
-  } else if (tid < 9) s_base[tid] = 0;
+  }
   lds_barrier();
   GEO_STAMP(6);
   // 5. word prefixes (every set) and decoded rows (sets 1..8) at base(crops before this one) + rank inside the crop
@@ -936,7 +936,7 @@ int dcl_internal_geometry_small(const int32_t *occ, const int32_t *n_dev, int n_
   DCL_CHECK_ARG(dcl_internal_geometry_small_ok(batch, kChainS) && mask0 && wprefix0 && comm && (n_host == 0 || occ));
   for (int i = 0; i < 8; ++i) DCL_CHECK_ARG(g.mask[i] && g.wprefix[i] && g.indices[i] && g.S[i] == kChainS >> ((i + 1) >> 1));      // 64, 32, 32, 16, 16, 8, 8, 4
   hipStream_t s = (hipStream_t)stream;
-  dcl_internal_zero_words(comm, (long long)kGeoSmallMax * kGeoCommStride, s);
+  if (batch > 1) dcl_internal_zero_words(comm, (long long)kGeoSmallMax * kGeoCommStride, s);      // (one crop exchanges nothing)
   GeoSmallArgs a{occ, n_dev, n_host, batch_lo, batch, mask0, wprefix0, perm0, comm};
   hipLaunchKernelGGL(k_geometry_small, dim3(batch), dim3(kChainThreads), 0, s, a, g);
   DCL_LAUNCH_CHECK();
