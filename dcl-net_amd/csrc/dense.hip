@@ -742,12 +742,12 @@ DCL_API int dcl_cross_attention(int b, int nq, int nk, const float *Q, int ldq, 
 }
 
 DCL_API int dcl_cross_attention_scratch_floats(int b, int nq, int64_t *floats_host) {
-  // upper bound of what dcl_cross_attention_ws can use for (b, nq): small launches split up to 8 ways, large ones only
+  // upper bound of what dcl_cross_attention_ws can use for (b, nq): small launches split up to 16 ways, large ones only
   // while the records stay below 128 Mi floats
   DCL_CHECK_ARG(b >= 0 && nq >= 0 && floats_host);
   const long long per = (long long)b * nq * kAttnPartPitch;
   const long long blocks8 = (long long)b * dcl_div_up(nq > 0 ? nq : 1, 256);
-  long long z = 8;
+  long long z = 16;
   if (blocks8 >= 256) {
     z = 1;
     double best = (double)dcl_div_up(blocks8, 256);
@@ -810,7 +810,7 @@ DCL_API int dcl_cross_attention_ws(int b, int nq, int nk, const float *Q, int ld
         hipLaunchKernelGGL(k_cross_attn_combine, dim3(dcl_grid_1d((long long)b * nq * 80, 256)), dim3(256), 0, s, b * nq,
                            nsplit, scratch, O1, ldo1, O2, ldo2);
     } else {
-      // few workgroups (small batches): split the keys over up to 8 workgroups per query block, >= 2 tiles per split
+      // few workgroups (small batches): split the keys over up to 16 workgroups per query block, >= 2 tiles per split
       const long long blocks4 = (long long)b * dcl_div_up(nq, 128);
       int nsplit = 1;
       if (scratch) {
@@ -820,7 +820,8 @@ DCL_API int dcl_cross_attention_ws(int b, int nq, int nk, const float *Q, int ld
         // rounds(z) = ceil(T z / 256) with T = 2 x blocks -- the two directions of a call run side by side (parallel branches
         // of the whole-forward graph, the path every call this small takes); the second term is the combine launch.  Fitted
         // to same-job A/B runs on the whole forward (tools/ab_hook.py dcl_debug_attention_split), best z at 1 / 2 / 4 / 6 / 8 /
-        // 12 / 16 / 20 / 32 crops of 1024 x 1024: 8 / 8 / 4 / 2 / 2 / 1 / 1 / 2 / 1 -- what this picks; against the former rule
+        // 12 / 16 / 20 / 32 crops of 1024 x 1024: 16 / 8 / 4 / 2 / 2 / 1 / 1 / 2 / 1 -- what this picks (one crop: 16 splits of two
+        // tiles against 8 of four, whole forward 0.414 vs 0.419 ms; two crops 0.547 vs 0.527: not there); against the former rule
         // (fill 256 workgroups per launch) 4 crops -3 %, 6: -1.8 %, 8: -1.3 %, 12: -5.4 %, 16: -1.6 %, 20: -2.5 %.
         if (g_attn_split > 0) {
           nsplit = g_attn_split;
@@ -828,14 +829,14 @@ DCL_API int dcl_cross_attention_ws(int b, int nq, int nk, const float *Q, int ld
           const long long T = 2 * blocks4;
           const double tiles_us = 1.1 * dcl_div_up(nk, 32);
           double best = 1e30;
-          for (int z = 1; z <= 8; z *= 2) {
+          for (int z = 1; z <= 16; z *= 2) {
             const double cost = (double)dcl_div_up(T * z, 256) * (tiles_us / z + 4.0) +
                                 (z > 1 ? 4.0 + 0.15 * z * (double)b * nq / 1024.0 : 0.0);
             if (cost < best - 1e-9) { best = cost; nsplit = z; }
           }
         }
         const int ntiles = dcl_div_up(nk, 32);
-        if (nsplit > 8) nsplit = 8;
+        if (nsplit > 16) nsplit = 16;
         if (nsplit > ntiles / 2) nsplit = ntiles / 2;
         while (nsplit > 1 && (long long)nsplit * b * nq * kAttnPartPitch > scratch_floats) --nsplit;
         if (nsplit < 1) nsplit = 1;
