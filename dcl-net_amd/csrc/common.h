@@ -160,6 +160,11 @@ struct DclConvChoice {
   int family, WR, WCW, NT;
 };
 #if defined(__HIPCC__)
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also waits for vmcnt(0): a loop that ends
+// an iteration with global stores and opens the next with a barrier (to reuse LDS) stalls there until its own stores have
+// LANDED, ~1 us each time.  Use where the barrier orders LDS accesses only; LDS-DMA loads (counted by vmcnt) need their own
+// explicit wait, as in the conv kernel's chunk loop.
+__device__ __forceinline__ void dcl_lds_barrier() { __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ int dcl_nbr_at(const DclNbrSrc &s, int cap, int k, int row) {
   if (s.nbr) return s.nbr[(size_t)k * cap + row];
   const int4 q = reinterpret_cast<const int4 *>(s.out_indices)[row];

@@ -534,7 +534,7 @@ __device__ __forceinline__ void conv_dma_body(
     constexpr bool ordered = ORD;                          // (natural order: the slot -> row map is arithmetic, no LDS round trip)
     if (ordered)
       for (int rr = tid; rr < BM; rr += NTHR) s_rows[rr] = row0 + rr < n ? ord.order[row0 + rr] : -1;
-    __syncthreads();
+    dcl_lds_barrier();
     CONV_STAMP(8);
     // neighbour rows of the offsets this workgroup's chunk range touches (all 27 without split-K), by COLUMNS of three
     // z-neighbours (common.h: dcl_nbr_col -- one mask word + one prefix word per column instead of three dependent loads per
@@ -582,7 +582,7 @@ __device__ __forceinline__ void conv_dma_body(
 #pragma unroll
     for (int d = 16; d >= 1; d >>= 1) mymask |= __shfl_xor(mymask, d, 64);
     if ((lane & 31) == 0 && mymask) atomicOr(s_kmask + ((tid % BM) >> 5), mymask);
-    __syncthreads();
+    dcl_lds_barrier();
     CONV_STAMP(10);
     unsigned kmask = 0;
 #pragma unroll
@@ -797,7 +797,7 @@ __device__ __forceinline__ void conv_dma_body(
           else mine[(t * 4 + q) * 64] = v;                  // deferred combine (k_conv_frag_reduce, next launch): plain stores
         }
       if (tile_counters == nullptr) {                      // few-row launches: the combine is a launch of its own
-        __syncthreads();
+        dcl_lds_barrier();
         continue;
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -881,7 +881,7 @@ __device__ __forceinline__ void conv_dma_body(
           }
         }
       }
-      __syncthreads();
+      dcl_lds_barrier();
       CONV_STAMP(6);
       continue;
     }
@@ -908,7 +908,7 @@ __device__ __forceinline__ void conv_dma_body(
       }
     }
     }
-    __syncthreads();
+    dcl_lds_barrier();
   }
 }
 // Deferred combine of a stream-K launch (few-row launches: a tile has up to 27 segments, which the last arriver would have
@@ -1014,7 +1014,7 @@ __device__ __forceinline__ void avgpool_body(const DclConvSides &sides, int nsid
     float *__restrict__ out = S.out;
     const int n = second ? n1 : n0, cap = S.cap;
     const int row0 = (bi - (second ? nb0 : 0)) * rpb;
-    __syncthreads();
+    dcl_lds_barrier();
     if (K27) {                                             // by columns of three z-neighbours (common.h: dcl_nbr_col)
       // (PF = 27 is the kernel of launches of a few thousand rows, which run their code once from a cold instruction
       //  cache: its look-up loop stays rolled -- see the note on code size below)
@@ -1032,7 +1032,7 @@ __device__ __forceinline__ void avgpool_body(const DclConvSides &sides, int nsid
         s_v[r2 * 27 + k] = row0 + r2 < n ? dcl_nbr_at(S.src, cap, k, row0 + r2) : -1;
       }
     }
-    __syncthreads();
+    dcl_lds_barrier();
     const int row = row0 + rr;
     if (row >= n) continue;
     const int32_t *v = s_v + rr * 27;

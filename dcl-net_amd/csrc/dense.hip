@@ -741,14 +741,32 @@ DCL_API int dcl_cross_attention(int b, int nq, int nk, const float *Q, int ldq, 
                                 stream);
 }
 
+// Key split of a 4-wave attention launch (fewer than 256 eight-wave workgroups): see the launcher below for the model.
+static int attn_small_split(int b, int nq, int ntiles) {
+  const int forced = g_attn_split;
+  if (forced > 0) return forced > 16 ? 16 : forced;
+  const long long T = 2ll * b * dcl_div_up(nq, 128);
+  const double tiles_us = 1.1 * ntiles;
+  double best = 1e30;
+  int nsplit = 1;
+  for (int z = 1; z <= 16; z *= 2) {
+    const double cost = (double)dcl_div_up(T * z, 256) * (tiles_us / z + 4.0) + (z > 1 ? 4.0 + 0.15 * z * (double)b * nq / 1024.0 : 0.0);
+    if (cost < best - 1e-9) { best = cost; nsplit = z; }
+  }
+  if (nsplit > ntiles / 2) nsplit = ntiles / 2;
+  return nsplit < 1 ? 1 : nsplit;
+}
+
 DCL_API int dcl_cross_attention_scratch_floats(int b, int nq, int64_t *floats_host) {
-  // upper bound of what dcl_cross_attention_ws can use for (b, nq): small launches split up to 16 ways, large ones only
-  // while the records stay below 128 Mi floats
+  // upper bound of what dcl_cross_attention_ws can use for (b, nq): small launches by their split model (up to 16 ways),
+  // large ones only while the records stay below 128 Mi floats
   DCL_CHECK_ARG(b >= 0 && nq >= 0 && floats_host);
   const long long per = (long long)b * nq * kAttnPartPitch;
   const long long blocks8 = (long long)b * dcl_div_up(nq > 0 ? nq : 1, 256);
-  long long z = 16;
-  if (blocks8 >= 256) {
+  long long z = 1;
+  if (blocks8 < 256) {                                     // (the key count is not known here: the most any count would take)
+    for (int ntiles = 2; ntiles <= (1 << 16); ntiles *= 2) z = max(z, (long long)attn_small_split(b, nq, ntiles));
+  } else {
     z = 1;
     double best = (double)dcl_div_up(blocks8, 256);
     for (int c = 2; c <= 8; c *= 2) {
@@ -811,7 +829,6 @@ DCL_API int dcl_cross_attention_ws(int b, int nq, int nk, const float *Q, int ld
                            nsplit, scratch, O1, ldo1, O2, ldo2);
     } else {
       // few workgroups (small batches): split the keys over up to 16 workgroups per query block, >= 2 tiles per split
-      const long long blocks4 = (long long)b * dcl_div_up(nq, 128);
       int nsplit = 1;
       if (scratch) {
         // Key split of a 4-wave launch (one workgroup per CU): a power of two z (the 32 key tiles of a 1024-key crop divide
@@ -823,18 +840,7 @@ DCL_API int dcl_cross_attention_ws(int b, int nq, int nk, const float *Q, int ld
         // 12 / 16 / 20 / 32 crops of 1024 x 1024: 16 / 8 / 4 / 2 / 2 / 1 / 1 / 2 / 1 -- what this picks (one crop: 16 splits of two
         // tiles against 8 of four, whole forward 0.414 vs 0.419 ms; two crops 0.547 vs 0.527: not there); against the former rule
         // (fill 256 workgroups per launch) 4 crops -3 %, 6: -1.8 %, 8: -1.3 %, 12: -5.4 %, 16: -1.6 %, 20: -2.5 %.
-        if (g_attn_split > 0) {
-          nsplit = g_attn_split;
-        } else {
-          const long long T = 2 * blocks4;
-          const double tiles_us = 1.1 * dcl_div_up(nk, 32);
-          double best = 1e30;
-          for (int z = 1; z <= 16; z *= 2) {
-            const double cost = (double)dcl_div_up(T * z, 256) * (tiles_us / z + 4.0) +
-                                (z > 1 ? 4.0 + 0.15 * z * (double)b * nq / 1024.0 : 0.0);
-            if (cost < best - 1e-9) { best = cost; nsplit = z; }
-          }
-        }
+        nsplit = attn_small_split(b, nq, dcl_div_up(nk, 32));
         const int ntiles = dcl_div_up(nk, 32);
         if (nsplit > 16) nsplit = 16;
         if (nsplit > ntiles / 2) nsplit = ntiles / 2;

@@ -281,9 +281,7 @@ __device__ __forceinline__ void chain_stage(const uint32_t *src, uint32_t *dst, 
     }
   }
 }
-// barrier that waits for the workgroup's LDS traffic only: __syncthreads() also waits for vmcnt(0), i.e. every stage of the
-// chain would wait for its own global stores to land (~1 us each) before the next one may read LDS
-__device__ __forceinline__ void lds_barrier() { __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// (barriers: common.h dcl_lds_barrier -- a stage must not wait for its own global stores to land before the next reads LDS)
 __device__ __forceinline__ unsigned long long dilate_z64(unsigned long long u) { return u | (u << 1) | (u >> 1); }
 // Stage 0 (conv set of level 0, 64^3 -> 64^3) for 1024 threads: thread = (y, 4 consecutive x); the 3 x 3 neighbourhoods of
 // its four rows are 6 x-columns of 3 rows, OR-ed over y first: 18 row reads for 4 outputs instead of 36 guarded ones.  Lanes
@@ -314,11 +312,11 @@ __global__ void __launch_bounds__(kChainThreads) k_mask_chain64(const uint32_t *
   const int b = blockIdx.x, tid = threadIdx.x;
   for (int i = tid; i < kChainWords / 4; i += kChainThreads)
     reinterpret_cast<uint4 *>(buf[0])[i] = reinterpret_cast<const uint4 *>(mask0 + (size_t)b * kChainWords)[i];
-  lds_barrier();
+  dcl_lds_barrier();
   chain_stage0_64(buf[0], buf[1], const_cast<uint32_t *>(g.mask[0]) + (size_t)b * kChainWords, tid);
-  lds_barrier();
+  dcl_lds_barrier();
   chain_stage<2, true>(buf[1], buf[0], const_cast<uint32_t *>(g.mask[1]) + (size_t)b * 1024, kChainS, kChainS / 2, tid);
-  lds_barrier();
+  dcl_lds_barrier();
   int S_in = kChainS / 2, cur = 0;
 #pragma unroll 1
   for (int i = 2; i < 8; ++i) {
@@ -326,7 +324,7 @@ __global__ void __launch_bounds__(kChainThreads) k_mask_chain64(const uint32_t *
     uint32_t *gout = const_cast<uint32_t *>(g.mask[i]) + (size_t)b * ((S_out * S_out * S_out) >> 5);
     if (i & 1) chain_stage<2, false>(buf[cur], buf[cur ^ 1], gout, S_in, S_out, tid);
     else chain_stage<1, false>(buf[cur], buf[cur ^ 1], gout, S_in, S_out, tid);
-    lds_barrier();
+    dcl_lds_barrier();
     cur ^= 1;
     S_in = S_out;
   }
@@ -399,14 +397,14 @@ __global__ void __launch_bounds__(kChainThreads) k_geometry_small(const GeoSmall
   for (int i = tid; i < kChainWords / 4; i += kChainThreads) reinterpret_cast<uint4 *>(buf[0])[i] = make_uint4(0u, 0u, 0u, 0u);
   if (tid < 160) s_w[tid >> 4][tid & 15] = 0;
   if (tid < 9) s_base[tid] = 0;
-  lds_barrier();
+  dcl_lds_barrier();
   for (int i = tid; i < n; i += kChainThreads) {
     const int4 p = reinterpret_cast<const int4 *>(a.occ)[i];
     if (p.x - a.batch_lo != c) continue;
     const int lin = ((((p.y << 6) + p.z) << 6)) + p.w;
     atomicOr(&buf[0][lin >> 5], 1u << (lin & 31));
   }
-  lds_barrier();
+  dcl_lds_barrier();
   GEO_STAMP(1);
   {
     uint4 *m0 = reinterpret_cast<uint4 *>(a.mask0 + (size_t)c * kChainWords);
@@ -416,10 +414,10 @@ __global__ void __launch_bounds__(kChainThreads) k_geometry_small(const GeoSmall
   GEO_STAMP(2);
   // 2. the mask chain: stage 0 (chain_stage0_64), stage 1 out of the 64-wide grid, then the six stages of the narrow grids
   chain_stage0_64(buf[0], buf[1], const_cast<uint32_t *>(g.mask[0]) + (size_t)c * kChainWords, tid);
-  lds_barrier();
+  dcl_lds_barrier();
   GEO_STAMP(16);
   chain_stage<2, true>(buf[1], small, const_cast<uint32_t *>(g.mask[1]) + (size_t)c * 1024, kChainS, kChainS / 2, tid);
-  lds_barrier();
+  dcl_lds_barrier();
   GEO_STAMP(17);
   {
     const uint32_t *src = small;
@@ -431,7 +429,7 @@ __global__ void __launch_bounds__(kChainThreads) k_geometry_small(const GeoSmall
       uint32_t *dst = small + off;
       if (i & 1) chain_stage<2, false>(src, dst, gout, S_in, S_out, tid);
       else chain_stage<1, false>(src, dst, gout, S_in, S_out, tid);
-      lds_barrier();
+      dcl_lds_barrier();
       GEO_STAMP(16 + i);
       src = dst;
       off += nw;
@@ -486,14 +484,14 @@ __global__ void __launch_bounds__(kChainThreads) k_geometry_small(const GeoSmall
     }
   }
   GEO_STAMP(4);
-  lds_barrier();
+  dcl_lds_barrier();
   if (wid < 10) {                                       // wave s: exclusive scan of set s's 16 wave totals
     const int v = lane < 16 ? s_w[wid][lane] : 0;
     const int inc = (int)wave_incl_scan_dpp((uint32_t)v);
     if (lane < 16) s_wbase[wid][lane] = inc - v;
     if (lane == 15) s_tot[wid] = inc;
   }
-  lds_barrier();
+  dcl_lds_barrier();
   GEO_STAMP(5);
   // 4. counts out, bases in (a pass of ONE crop has nobody to tell).  Thread (c2, s) fetches set s's count of crop c2 < c: all
   // crops' flags and counts in flight together (nine lanes walking the crops one after the other were 2 round trips per crop)
@@ -510,7 +508,7 @@ __global__ void __launch_bounds__(kChainThreads) k_geometry_small(const GeoSmall
       atomicAdd(&s_base[s], __hip_atomic_load(theirs + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
   }
-  lds_barrier();
+  dcl_lds_barrier();
   GEO_STAMP(6);
   // 5. word prefixes (every set) and decoded rows (sets 1..8) at base(crops before this one) + rank inside the crop
   auto decode = [&](int set, int S, int w, uint32_t m, int r) __attribute__((always_inline)) {
@@ -551,7 +549,7 @@ __global__ void __launch_bounds__(kChainThreads) k_geometry_small(const GeoSmall
     g.wprefix[sv - 1][(size_t)c * nw + wv] = r;
     decode(sv, S, wv, small[kSmallOff4 + tid], r);
   }
-  lds_barrier();                                        // set 1's list and set 0's prefixes are in LDS
+  dcl_lds_barrier();                                        // set 1's list and set 0's prefixes are in LDS
   {
     const int ne = s_tot[9], g1 = s_base[1];
 #pragma unroll 1
