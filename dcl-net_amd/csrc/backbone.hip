@@ -34,7 +34,7 @@ int dcl_internal_out_mask_k3(const uint32_t *in_mask, int batch, int S_in, int s
 int dcl_internal_scan_enumerate_sets(const DclGeoSets &g, int nsets, dclStream_t stream);
 bool dcl_internal_mask_chain_ok(int S);
 int dcl_internal_mask_chain(const uint32_t *mask0, int batch, const DclGeoSets &g, dclStream_t stream);
-bool dcl_internal_geometry_small_ok(int batch, int S);
+bool dcl_internal_geometry_small_ok(int batch, int S, int rows);
 int dcl_internal_geometry_small(const int32_t *occ, const int32_t *n_dev, int n_host, int batch_lo, int batch, uint32_t *mask0,
                                 int32_t *wprefix0, int32_t *perm0, int32_t *comm, const DclGeoSets &g, dclStream_t stream);
 bool dcl_internal_readout_fused_ok(const DclReadoutLevels &L, int ld, bool need_search);
@@ -223,7 +223,7 @@ static int backbone_geometry(const int32_t *occ, const int32_t *V0_dev, int V0, 
   DCL_CHECK_ARG(V0 == 0 || occ);
   int32_t *scratch = at<int32_t>(ws, L.scratch);
   // a handful of crops on 64^3 grids: the whole stage is ONE launch (rulebook.hip: k_geometry_small)
-  const bool one_launch = dcl_internal_geometry_small_ok(batch, S) && g_geo_chain == 1;
+  const bool one_launch = dcl_internal_geometry_small_ok(batch, S, V0) && g_geo_chain == 1;
   int rc = 0;
   if (!one_launch) {
     rc = dcl_internal_grid_from_indices(occ, V0_dev, V0, batch_lo, batch, S, at<uint32_t>(ws, L.mask0),

@@ -331,7 +331,7 @@ __global__ void __launch_bounds__(kChainThreads) k_mask_chain64(const uint32_t *
 }
 
 // ---- the WHOLE geometry stage of a pass of a handful of crops in one launch ------------------------------------------------
-// (64^3 grids, at most kGeoSmallBatch crops: one-image calls, where the stage's 8 launches -- zero, mark, scan, fill_perm,
+// (64^3 grids, at most kGeoSmallBatch crops: one-image calls and small batches, where the stage's 8 launches -- zero, mark, scan, fill_perm,
 // mask chain, block counts, word prefixes, enumerate -- are a third of the sparse half's critical path.)  One workgroup
 // per crop: marks the crop's voxels in an LDS bitmask, walks the 8-stage mask chain in LDS (as k_mask_chain64), counts
 // every set, exchanges the nine counts with the other crops' workgroups (a flag per crop in `comm`, zeroed by the caller
@@ -347,7 +347,12 @@ __device__ unsigned long long g_geo_stamps[32];
 #define GEO_STAMP(i) do { } while (0)
 #define GEO_STAMP_END(i) do { } while (0)
 #endif
-DCL_HOOK_INT(kGeoSmallBatch, 8);      // most crops of a pass that takes the one-launch geometry stage (comm holds 64 crops)
+DCL_HOOK_INT(kGeoSmallBatch, 16);     // most crops of a pass that takes the one-launch geometry stage (comm holds 64 crops).
+// (Stage time by HIP events, one launch vs the separate launches, 1024-point crops: 8 crops 22 us either way (the former limit),
+//  12: 26 vs 36, 20: 55 vs 63, 32: 62 vs 71, 40: 65 vs 74 -- but the whole forward of 32 crops does not move (3.884 vs 3.887 ms:
+//  the stage hides behind the point branch there) and 12 crops gain 0.6 %; every workgroup walks the whole voxel list, so at
+//  32 x 12288-point crops (41k rows) the one launch is the slower one, 75 vs 72 us: hence also a bound on the rows.)
+constexpr int kGeoSmallRows = 32768;
 constexpr int kGeoSmallMax = 64, kGeoCommStride = 16;
 static_assert(kGeoSmallMax * kGeoCommStride == kChainThreads, "k_geometry_small: one thread per exchange word");
 struct GeoSmallArgs {
@@ -398,11 +403,19 @@ __global__ void __launch_bounds__(kChainThreads) k_geometry_small(const GeoSmall
   if (tid < 160) s_w[tid >> 4][tid & 15] = 0;
   if (tid < 9) s_base[tid] = 0;
   dcl_lds_barrier();
-  for (int i = tid; i < n; i += kChainThreads) {
-    const int4 p = reinterpret_cast<const int4 *>(a.occ)[i];
-    if (p.x - a.batch_lo != c) continue;
-    const int lin = ((((p.y << 6) + p.z) << 6)) + p.w;
-    atomicOr(&buf[0][lin >> 5], 1u << (lin & 31));
+  // (every crop's workgroup walks the whole voxel list: the crop ids of four rows first -- independent 4-byte loads -- then
+  //  the rows that are this crop's)
+  for (int i0 = tid; i0 < n; i0 += 4 * kChainThreads) {
+    int bx[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bx[u] = i0 + u * kChainThreads < n ? a.occ[4 * (size_t)(i0 + u * kChainThreads)] : a.batch_lo - 1;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (bx[u] - a.batch_lo != c) continue;
+      const int4 p = reinterpret_cast<const int4 *>(a.occ)[i0 + u * kChainThreads];
+      const int lin = ((((p.y << 6) + p.z) << 6)) + p.w;
+      atomicOr(&buf[0][lin >> 5], 1u << (lin & 31));
+    }
   }
   dcl_lds_barrier();
   GEO_STAMP(1);
@@ -581,11 +594,18 @@ __global__ void __launch_bounds__(kChainThreads) k_geometry_small(const GeoSmall
   GEO_STAMP(8);
   // 6. level-0 permutation: rank -> row of the caller's voxel list (mask and prefixes of set 0 are still in LDS)
   if (a.perm0) {
-    for (int i = tid; i < n; i += kChainThreads) {
-      const int4 p = reinterpret_cast<const int4 *>(a.occ)[i];
-      if (p.x - a.batch_lo != c) continue;
-      const int lin = ((((p.y << 6) + p.z) << 6)) + p.w;
-      a.perm0[s_wp0[lin >> 5] + __popc(buf[0][lin >> 5] & ((1u << (lin & 31)) - 1u))] = i;
+    for (int i0 = tid; i0 < n; i0 += 4 * kChainThreads) {
+      int bx[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) bx[u] = i0 + u * kChainThreads < n ? a.occ[4 * (size_t)(i0 + u * kChainThreads)] : a.batch_lo - 1;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (bx[u] - a.batch_lo != c) continue;
+        const int i = i0 + u * kChainThreads;
+        const int4 p = reinterpret_cast<const int4 *>(a.occ)[i];
+        const int lin = ((((p.y << 6) + p.z) << 6)) + p.w;
+        a.perm0[s_wp0[lin >> 5] + __popc(buf[0][lin >> 5] & ((1u << (lin & 31)) - 1u))] = i;
+      }
     }
   }
   GEO_STAMP_END(9);
@@ -922,7 +942,9 @@ int dcl_internal_mask_chain(const uint32_t *mask0, int batch, const DclGeoSets &
 
 // the geometry stage of a pass of a handful of crops in one launch (+ the zeroing of its exchange words); see
 // k_geometry_small.  comm: kGeoSmallMax * 16 ints of scratch.
-bool dcl_internal_geometry_small_ok(int batch, int S) { return S == kChainS && batch >= 1 && batch <= kGeoSmallBatch && batch <= kGeoSmallMax; }
+bool dcl_internal_geometry_small_ok(int batch, int S, int rows) {
+  return S == kChainS && batch >= 1 && batch <= kGeoSmallBatch && batch <= kGeoSmallMax && (batch <= 8 || rows <= kGeoSmallRows);
+}
 #ifdef DCL_DIAG
 DCL_API void dcl_debug_geometry_small_batch(int n) { kGeoSmallBatch = n; }
 DCL_API int dcl_debug_geometry_small_stamps(unsigned long long *host32) {
@@ -931,7 +953,7 @@ DCL_API int dcl_debug_geometry_small_stamps(unsigned long long *host32) {
 #endif
 int dcl_internal_geometry_small(const int32_t *occ, const int32_t *n_dev, int n_host, int batch_lo, int batch, uint32_t *mask0,
                                 int32_t *wprefix0, int32_t *perm0, int32_t *comm, const DclGeoSets &g, dclStream_t stream) {
-  DCL_CHECK_ARG(dcl_internal_geometry_small_ok(batch, kChainS) && mask0 && wprefix0 && comm && (n_host == 0 || occ));
+  DCL_CHECK_ARG(dcl_internal_geometry_small_ok(batch, kChainS, n_host) && mask0 && wprefix0 && comm && (n_host == 0 || occ));
   for (int i = 0; i < 8; ++i) DCL_CHECK_ARG(g.mask[i] && g.wprefix[i] && g.indices[i] && g.S[i] == kChainS >> ((i + 1) >> 1));      // 64, 32, 32, 16, 16, 8, 8, 4
   hipStream_t s = (hipStream_t)stream;
   if (batch > 1) dcl_internal_zero_words(comm, (long long)kGeoSmallMax * kGeoCommStride, s);      // (one crop exchanges nothing)

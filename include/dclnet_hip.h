@@ -557,7 +557,8 @@ void dcl_debug_conv_few_chunks(int n);
 void dcl_debug_conv_few_tiles(int on);
 /* Tuning hook: 1 (default) = the Cin 16 / 32 -> 32 conv layers of many rows run the filter-resident kernel, 0 = LDS-DMA kernel. */
 void dcl_debug_conv_wlds(int on);
-/* Tuning hook: most crops of a pass whose geometry stage runs as one launch (k_geometry_small; default 8, at most 64). */
+/* Tuning hook: most crops of a pass whose geometry stage runs as one launch (k_geometry_small; default 16, at most 64;
+ * passes of more than 8 crops also need at most 32768 voxel rows). */
 void dcl_debug_geometry_small_batch(int n);
 int dcl_debug_geometry_small_stamps(unsigned long long *host32);   /* s_memrealtime (100 MHz) at the phase boundaries of workgroup 0 of the last k_geometry_small (0..9), after each mask-chain stage (16..23) */
 /* Diagnostic: a one-thread launch that writes the 100 MHz wall clock into *slot_dev (a time stamp inside a stream or a

@@ -1246,14 +1246,14 @@ def test_geometry_one_launch_mask_chain_equals_chained_launches(request, dcl):
 
 @pytest.mark.gpu
 def test_geometry_stage_in_one_launch_equals_the_separate_launches(request, dcl):
-    """a pass of at most 8 crops runs its whole geometry stage as ONE launch (k_geometry_small: mark, mask chain, counts
+    """a pass of at most 16 crops runs its whole geometry stage as ONE launch (k_geometry_small: mark, mask chain, counts
     exchanged between the crops' workgroups, prefixes, rows, permutation); against the separate launches: same counts, same
     voxel rows, and -- through masks, prefixes, conv-set rows and the level-0 permutation -- bit-identical features"""
     lib = enter_diag(dcl, request)
     rng = np.random.default_rng(5)
     occ_e, b_e = _edge_voxels(rng)
     cases = [(cuda(occ_e), b_e)]
-    for b in (1, 2, 8):
+    for b in (1, 2, 8, 16):
         d = dcl.synth.make_batch(b, 1024, 64, first=7 + b)
         occ = d["inp"]["occupied_voxels"].int()
         perm = torch.cat([torch.randperm(int((occ[:, 0] == i).sum())) + int((occ[:, 0] < i).sum()) for i in range(b)])
