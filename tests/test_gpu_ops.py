@@ -386,6 +386,34 @@ def test_sparse_avgpool_bit_exact(dcl, oracle, c):
     assert np.array_equal(got.cpu().numpy(), want)             # same divide-then-add order, k ascending
 
 
+def test_sparse_avgpool_quotients_outside_the_fast_range_bit_exact(dcl, oracle):
+    """the pool's f / rf is computed as RN(1/rf) and two FMAs where that is provably the IEEE quotient (2^-100 <= |f| <= 2^100,
+    tests/test_pool_division.py) and by the division itself for any window that holds something else: subnormals, values
+    whose quotient would be subnormal, huge values, infinities, NaNs, signed zeros -- sprinkled so that some windows stay on the
+    fast path and some leave it; every finite result bit for bit, non-finite ones in kind"""
+    rng = np.random.default_rng(77)
+    b, S, c = 3, 16, 32
+    idx = rand_voxels(rng, b, S, 500)
+    feat = rng.normal(size=(idx.shape[0], c)).astype(np.float32)
+    special = np.array([1e-42, -3e-44, 1e-35, -2.5e-33, 7.0e-31, 1.3e30, -4e35, 3e38, np.inf, -np.inf, np.nan, -0.0, 0.0,
+                        np.float32(2.0) ** -100, np.float32(2.0) ** 100, -np.float32(2.0) ** -101], np.float32)
+    rows = rng.choice(idx.shape[0], size=idx.shape[0] // 6, replace=False)           # most windows keep ordinary values only
+    for r in rows:
+        cols = rng.choice(c, size=int(rng.integers(1, 5)), replace=False)
+        feat[r, cols] = rng.choice(special, size=cols.size)
+    aset = dcl.ops.grid_from_indices(cuda(idx), b, S)
+    out, nbr = dcl.spconv.ops.build_rulebook(aset, 3, 2, 1, False)
+    r_out, r_pairs, r_num, _ = oracle.get_indice_pairs(idx, b, [S] * 3, 3, 2, 1, 1)
+    with np.errstate(all="ignore"):
+        want, want_rf = oracle.indice_avgpool(feat, r_pairs, r_num, r_out.shape[0])
+    got = dcl.ops.sparse_avgpool(cuda(feat), nbr, out.n).cpu().numpy()
+    fin = np.isfinite(want)
+    assert fin.any() and (~fin).any() and np.any((np.abs(want) < 1.2e-38) & (want != 0))        # the cases are really there
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    ok = ~np.isnan(want)
+    assert np.array_equal(got[ok].view(np.uint32), want[ok].view(np.uint32))
+
+
 # ------------------------------------------------------------------------------------------- spconv op-level boundary
 def _shuffled_pairs(rng, pairs, num):
     """the reference fills each offset's pair list by atomicAdd (indice.cu.h:57): any order inside an offset is legal"""
