@@ -782,6 +782,15 @@ DCL_API int dcl_cross_attention_ws(int b, int nq, int nk, const float *Q, int ld
                                    const float *V1, int dv1, int ldv1, float *O1, int ldo1, const float *V2, int dv2,
                                    int ldv2, float *O2, int ldo2, float *scratch, int64_t scratch_floats,
                                    dclStream_t stream) {
+  return dcl_cross_attention_ws2(b, nq, nk, Q, ldq, K, ldk, V1, dv1, ldv1, O1, ldo1, V2, dv2, ldv2, O2, ldo2, scratch,
+                                 scratch_floats, 1, stream);
+}
+
+DCL_API int dcl_cross_attention_ws2(int b, int nq, int nk, const float *Q, int ldq, const float *K, int ldk,
+                                    const float *V1, int dv1, int ldv1, float *O1, int ldo1, const float *V2, int dv2,
+                                    int ldv2, float *O2, int ldo2, float *scratch, int64_t scratch_floats,
+                                    int concurrent_launches, dclStream_t stream) {
+  DCL_CHECK_ARG(concurrent_launches == 1 || concurrent_launches == 2);
   DCL_CHECK_ARG(b >= 0 && nq >= 0 && nk > 0 && dv1 > 0 && dv1 % 32 == 0 && dv2 >= 0 && dv2 % 32 == 0);
   if (b == 0 || nq == 0) return 0;
   DCL_CHECK_ARG(Q && K && V1 && O1 && (dv2 == 0 || (V2 && O2)) && b <= 65535);
@@ -796,7 +805,13 @@ DCL_API int dcl_cross_attention_ws(int b, int nq, int nk, const float *Q, int ld
   const long long blocks8 = (long long)b * dcl_div_up(nq, 256);
   if (dv1 == 256 && dv2 == 64 && (g_attn_variant == 0 || g_attn_variant == 3 || g_attn_variant == 4)) {
     // LDS-DMA pipeline: 8 waves (256 queries) per workgroup when that fills the chip, else 4 waves (128 queries)
-    const bool w8 = g_attn_variant == 3 || (g_attn_variant == 0 && blocks8 >= 256);
+    // Two launches side by side (the two directions of a forward on parallel branches) whose 8-wave workgroups TOGETHER make
+    // one round of the chip -- 32 crops of 1024 x 1024, the shipped configuration -- also take the 8-wave form, unsplit: the
+    // 4-wave workgroups (402 registers, one wave per SIMD) of the two launches cannot share a CU, so they run one after the
+    // other at one wave per SIMD; same-job A/B of the whole forward, 8-wave vs 4-wave: 32 crops 3.813 vs 3.880 ms; 28 (224
+    // workgroups) 3.706 vs 3.696, 36: 4.72 vs 4.69, 40: 4.97 vs 4.97, 24: 3.20 vs 3.15, 16: 2.31 vs 2.16 -- hence the window.
+    const bool pair8 = concurrent_launches == 2 && 2 * blocks8 > 240 && 2 * blocks8 <= 256;
+    const bool w8 = g_attn_variant == 3 || (g_attn_variant == 0 && (blocks8 >= 256 || pair8));
     const int W = w8 ? 8 : 4;
     const size_t lds = (size_t)(32 * kKPitch + 2 * 32 * 256 + 2 * 32 * 64 + W * 32 * kKPitch) * sizeof(float);
     if (w8) {
@@ -805,7 +820,7 @@ DCL_API int dcl_cross_attention_ws(int b, int nq, int nk, const float *Q, int ld
       // shorter: cost(Z) = ceil(blocks8*Z/256)/Z full-workgroup times; taken when it saves >= 0.2 of one and the partial
       // records stay below ~512 MiB
       int nsplit = 1;
-      if (scratch) {
+      if (scratch && !(pair8 && g_attn_split == 0)) {
         if (g_attn_split > 0) {
           nsplit = g_attn_split;
         } else {

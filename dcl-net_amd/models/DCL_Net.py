@@ -500,6 +500,7 @@ class Network(nn.Module):
                 if side is not None:
                     self_inner.ctx.__exit__(*a)
         second = _Both()
+        par = 2 if side is not None else 1             # the two attention launches run side by side: told to the launcher
 
         def join():
             if side is not None:
@@ -518,11 +519,11 @@ class Network(nn.Module):
                 F = self._lin_relu(F, Wt, bias)
             return self._mlp(conf_in, conf_layers), F
         with second:
-            ops.cross_attention(b, act["Yom2"], act["Xcm2"], act["Xcp2"], fuse2[:, :256], act["Xcm2"], conf_in2[:, :64])
+            ops.cross_attention(b, act["Yom2"], act["Xcm2"], act["Xcp2"], fuse2[:, :256], act["Xcm2"], conf_in2[:, :64], concurrent=par)
             logit2, Fp2 = conf_and_fuser(conf_in2, fuse2, f["regressor_conf_bi"], l2)
             if side is not None:
                 logit2.record_stream(main); Fp2.record_stream(main)          # allocated on `side`, read on `main` below
-        ops.cross_attention(b, act["Xcm1"], act["Yom1"], act["Yop1"], fuse1[:, 256:], act["Yom1"], conf_in1[:, 64:])
+        ops.cross_attention(b, act["Xcm1"], act["Yom1"], act["Yop1"], fuse1[:, 256:], act["Yom1"], conf_in1[:, 64:], concurrent=par)
         logit1, Fp1 = conf_and_fuser(conf_in1, fuse1, f["regressor_conf"], l1)   # (b*N, 1), (b*N, 1024)
         join()
         # trailing BNs after pooling: F_p_wei = sA*P1 + tA*sum(w1) + sB*P2 + tB*sum(w2), finished inside the pooling op

@@ -685,12 +685,14 @@ def _ld(t):
     return t.stride(0) if t.shape[0] > 1 else t.shape[1]
 
 
-def cross_attention(b, Q, K, V1, O1, V2=None, O2=None):
+def cross_attention(b, Q, K, V1, O1, V2=None, O2=None, concurrent=1):
     """One direction of the correspondence attention on POINT-major 2-D operands (row = point):
     Q (b*nq, 64), K (b*nk, 64), V1 (b*nk, dv1) -> O1 (b*nq, dv1) [, V2 -> O2].  Operands may be
     column blocks of wider buffers (row stride honoured).  The PRODUCT library carries DCL-Net's own channel split only,
     dv1 = 256 with dv2 = 64 (anything else: DCL_EINVAL at run time -- include/dclnet_hip.h says so at dcl_cross_attention);
-    the general-shape kernels (dv1, dv2 multiples of 32) live in the diagnostic library."""
+    the general-shape kernels (dv1, dv2 multiples of 32) live in the diagnostic library.
+    concurrent = 2: another launch of the same size runs side by side on a second stream (the other direction of a forward) --
+    a hint for the launcher's choice of workgroup shape (dcl_cross_attention_ws2)."""
     N.need_cuda(Q, K, V1, O1, V2, O2)
     nq, nk = Q.shape[0] // b, K.shape[0] // b
     assert Q.shape[1] == 64 and K.shape[1] == 64 and V1.shape[0] == K.shape[0] and O1.shape[0] == Q.shape[0]
@@ -706,10 +708,10 @@ def cross_attention(b, Q, K, V1, O1, V2=None, O2=None):
         N.check(N.lib().dcl_cross_attention_scratch_floats(b, nq, C.byref(need)), "cross_attention_scratch_floats")
         if need.value:
             scratch = torch.empty(need.value, dtype=torch.float32, device=Q.device)
-    N.check(N.lib().dcl_cross_attention_ws(b, nq, nk, N.ptr(Q), _ld(Q), N.ptr(K), _ld(K), N.ptr(V1), dv1, _ld(V1),
-                                           N.ptr(O1), _ld(O1), N.ptr(V2), dv2, 0 if V2 is None else _ld(V2), N.ptr(O2),
-                                           0 if O2 is None else _ld(O2), N.ptr(scratch),
-                                           C.c_int64(0 if scratch is None else scratch.numel()), N.stream()),
+    N.check(N.lib().dcl_cross_attention_ws2(b, nq, nk, N.ptr(Q), _ld(Q), N.ptr(K), _ld(K), N.ptr(V1), dv1, _ld(V1),
+                                            N.ptr(O1), _ld(O1), N.ptr(V2), dv2, 0 if V2 is None else _ld(V2), N.ptr(O2),
+                                            0 if O2 is None else _ld(O2), N.ptr(scratch),
+                                            C.c_int64(0 if scratch is None else scratch.numel()), int(concurrent), N.stream()),
             "cross_attention")
     if ev is not None:
         ev[1].record()

@@ -367,6 +367,13 @@ int dcl_cross_attention_ws(int b, int nq, int nk, const float *Q, int ldq, const
                            const float *V1, int dv1, int ldv1, float *O1, int ldo1,
                            const float *V2, int dv2, int ldv2, float *O2, int ldo2,
                            float *scratch, int64_t scratch_floats, dclStream_t stream);
+/* Same; concurrent_launches = 2 tells the launcher that ANOTHER attention launch of the same size runs side by side on a second
+ * stream / graph branch (the two directions of a forward): the workgroup shape is then chosen for the pair (1 = a lone launch =
+ * dcl_cross_attention_ws).  A hint for speed only: results do not depend on it beyond the summation order of a key split. */
+int dcl_cross_attention_ws2(int b, int nq, int nk, const float *Q, int ldq, const float *K, int ldk,
+                            const float *V1, int dv1, int ldv1, float *O1, int ldo1,
+                            const float *V2, int dv2, int ldv2, float *O2, int ldo2,
+                            float *scratch, int64_t scratch_floats, int concurrent_launches, dclStream_t stream);
 int dcl_cross_attention_scratch_floats(int b, int nq, int64_t *floats_host);
 
 /* Confidence pooling (models/DCL_Net.py:217-228): conf = sigmoid(cat[logit1 (b,n1), logit2
