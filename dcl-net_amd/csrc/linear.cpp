@@ -149,3 +149,70 @@ DCL_API int dcl_linear_fwd(const float *x, int64_t ldx, const float *Wt, int64_t
                            p->ws, (hipStream_t)stream));
   return 0;
 }
+
+#ifdef DCL_DIAG
+// Diagnostic: the library's first `ncand` heuristic candidates for y[M x N] = relu(x[M x K] Wt[K x N] + bias) (dense pitches),
+// each timed on the current device (3 warm-up runs, then 10 runs between events): ms_out[i] = mean milliseconds of candidate
+// i (candidate 0 is the one dcl_linear_fwd takes), *found_out = how many there were.  tools/gemm_candidates.py.
+DCL_API int dcl_debug_linear_candidates(int M, int N, int K, int ncand, float *ms_out, int *found_out) {
+  DCL_CHECK_ARG(M > 0 && N > 0 && K > 0 && ncand >= 1 && ncand <= 64 && ms_out && found_out);
+  std::lock_guard<std::mutex> lock(g_mu);
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) return DCL_EINVAL;
+  hipblasLtHandle_t h = nullptr;
+  int rc = get_handle(device, &h);
+  if (rc) return rc;
+  float *x = nullptr, *w = nullptr, *y = nullptr, *bias = nullptr;
+  void *ws = nullptr;
+  const size_t ws_bytes = 32u << 20;
+  if (hipMalloc(&x, sizeof(float) * (size_t)M * K) != hipSuccess || hipMalloc(&w, sizeof(float) * (size_t)K * N) != hipSuccess ||
+      hipMalloc(&y, sizeof(float) * (size_t)M * N) != hipSuccess || hipMalloc(&bias, sizeof(float) * N) != hipSuccess ||
+      hipMalloc(&ws, ws_bytes) != hipSuccess) {
+    dcl_set_error("dcl_debug_linear_candidates: out of memory");
+    return DCL_EINVAL;
+  }
+  (void)hipMemset(x, 0, sizeof(float) * (size_t)M * K); (void)hipMemset(w, 0, sizeof(float) * (size_t)K * N); (void)hipMemset(bias, 0, sizeof(float) * N);
+  hipblasLtMatmulDesc_t desc = nullptr;
+  hipblasLtMatrixLayout_t lw = nullptr, lx = nullptr, ly = nullptr;
+  LT_CHECK(hipblasLtMatmulDescCreate(&desc, HIPBLAS_COMPUTE_32F, HIP_R_32F));
+  const int32_t opn = HIPBLAS_OP_N;
+  LT_CHECK(hipblasLtMatmulDescSetAttribute(desc, HIPBLASLT_MATMUL_DESC_TRANSA, &opn, sizeof(opn)));
+  LT_CHECK(hipblasLtMatmulDescSetAttribute(desc, HIPBLASLT_MATMUL_DESC_TRANSB, &opn, sizeof(opn)));
+  const uint32_t epi = HIPBLASLT_EPILOGUE_RELU_BIAS;
+  LT_CHECK(hipblasLtMatmulDescSetAttribute(desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof(epi)));
+  const int32_t bt = HIP_R_32F;
+  LT_CHECK(hipblasLtMatmulDescSetAttribute(desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bt, sizeof(bt)));
+  LT_CHECK(hipblasLtMatmulDescSetAttribute(desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)));
+  LT_CHECK(hipblasLtMatrixLayoutCreate(&lw, HIP_R_32F, (uint64_t)N, (uint64_t)K, N));
+  LT_CHECK(hipblasLtMatrixLayoutCreate(&lx, HIP_R_32F, (uint64_t)K, (uint64_t)M, K));
+  LT_CHECK(hipblasLtMatrixLayoutCreate(&ly, HIP_R_32F, (uint64_t)N, (uint64_t)M, N));
+  hipblasLtMatmulPreference_t pref = nullptr;
+  LT_CHECK(hipblasLtMatmulPreferenceCreate(&pref));
+  const uint64_t max_ws = ws_bytes;
+  LT_CHECK(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &max_ws, sizeof(max_ws)));
+  hipblasLtMatmulHeuristicResult_t res[64];
+  int found = 0;
+  LT_CHECK(hipblasLtMatmulAlgoGetHeuristic(h, desc, lw, lx, ly, ly, pref, ncand, res, &found));
+  hipblasLtMatmulPreferenceDestroy(pref);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  const float one = 1.0f, zero = 0.0f;
+  for (int i = 0; i < found; ++i) {
+    ms_out[i] = -1.0f;
+    bool ok = true;
+    for (int r = 0; r < 13 && ok; ++r) {
+      if (r == 3) (void)hipEventRecord(e0, nullptr);
+      ok = hipblasLtMatmul(h, desc, &one, w, lw, x, lx, &zero, y, ly, y, ly, &res[i].algo, ws, res[i].workspaceSize, nullptr) == HIPBLAS_STATUS_SUCCESS;
+    }
+    (void)hipEventRecord(e1, nullptr);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) ms_out[i] = ms / 10.0f;
+  }
+  *found_out = found;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  hipblasLtMatrixLayoutDestroy(lw); hipblasLtMatrixLayoutDestroy(lx); hipblasLtMatrixLayoutDestroy(ly); hipblasLtMatmulDescDestroy(desc);
+  (void)hipFree(x); (void)hipFree(w); (void)hipFree(y); (void)hipFree(bias); (void)hipFree(ws);
+  return 0;
+}
+#endif

@@ -566,6 +566,9 @@ void dcl_debug_conv_few_tiles(int on);
 void dcl_debug_conv_wlds(int on);
 /* Tuning hook: most crops of a pass whose geometry stage runs as one launch (k_geometry_small; default 16, at most 64;
  * passes of more than 8 crops also need at most 32768 voxel rows). */
+/* Diagnostic: times the GEMM library's first ncand heuristic candidates for an (M, N, K) linear layer; ms_out[0] is the one
+ * dcl_linear_fwd takes. */
+int dcl_debug_linear_candidates(int M, int N, int K, int ncand, float *ms_out, int *found_out);
 void dcl_debug_geometry_small_batch(int n);
 int dcl_debug_geometry_small_stamps(unsigned long long *host32);   /* s_memrealtime (100 MHz) at the phase boundaries of workgroup 0 of the last k_geometry_small (0..9), after each mask-chain stage (16..23) */
 /* Diagnostic: a one-thread launch that writes the 100 MHz wall clock into *slot_dev (a time stamp inside a stream or a
