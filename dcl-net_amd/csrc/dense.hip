@@ -1106,7 +1106,104 @@ __global__ __launch_bounds__(1024) void k_heads_l23(int b, const float *__restri
     if (threadIdx.x == 0) ortho9d_one(o9s, R + (size_t)crop * 9, 0);
   }
 }
+
+// ---- the confidence regressor as ONE launch (models/DCL_Net.py:115-126, 217-218: Head_MultiLayerPerceptron [128, 128, 128, 1],
+// ReLU, ReLU, none) ---------------------------------------------------------------------------------------------------------
+// logit[m] = w3 . relu(W2t^T relu(W1t^T x[m] + b1) + b2) + b3.  Three library GEMMs of K = 128 are three launches of 9-14 us
+// with nothing to do (M x 128 x 128: 0.03-1 GFLOP) and two round trips of the hidden rows through memory; here a workgroup
+// keeps both 128 x 128 filters in LDS (136 KB with the row tile: one workgroup per CU), walks 32-row tiles, and a tile's hidden
+// rows never leave the CU: wave w owns output columns 32w..32w+31 (64 fp32 MFMAs 32x32x2 per layer), layer 1's rows go
+// through the x tile's LDS, layer 2's are dotted with w3 in registers and summed over the columns in a fixed order.
+constexpr int kMlpXP = 130, kMlpWP = 33;               // LDS pitches: x rows (even / odd k on even / odd banks), filter rows
+__global__ __launch_bounds__(256) void k_mlp128_to1(int M, const float *__restrict__ x, long long ldx,
+                                                    const float *__restrict__ W1t, const float *__restrict__ b1,
+                                                    const float *__restrict__ W2t, const float *__restrict__ b2,
+                                                    const float *__restrict__ w3, long long ldw3, const float *__restrict__ b3,
+                                                    float *__restrict__ out) {
+  extern __shared__ float mlp_lds[];
+  float *Ws1 = mlp_lds;                                // [4 waves][128 k][33]
+  float *Ws2 = Ws1 + 4 * 128 * kMlpWP;
+  float *xs = Ws2 + 4 * 128 * kMlpWP;                  // [32 rows][130]
+  float *red = xs + 32 * kMlpXP;                       // [4 waves][32 rows]
+  const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
+  // both filters: wave w stages its 32 columns of each (16 float4 loads per lane and filter)
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int k = i * 8 + (lane >> 3), c4 = (lane & 7) * 4;
+    const float4 a = *reinterpret_cast<const float4 *>(W1t + (size_t)k * 128 + 32 * w + c4);
+    const float4 b = *reinterpret_cast<const float4 *>(W2t + (size_t)k * 128 + 32 * w + c4);
+    float *d1 = Ws1 + (w * 128 + k) * kMlpWP + c4, *d2 = Ws2 + (w * 128 + k) * kMlpWP + c4;
+    d1[0] = a.x; d1[1] = a.y; d1[2] = a.z; d1[3] = a.w;
+    d2[0] = b.x; d2[1] = b.y; d2[2] = b.z; d2[3] = b.w;
+  }
+  const float bias1 = b1[32 * w + r], bias2 = b2[32 * w + r], w3c = w3[(size_t)(32 * w + r) * ldw3], bias3 = b3[0];
+  const int ntiles = (M + 31) >> 5;
+  for (int t = (int)blockIdx.x; t < ntiles; t += (int)gridDim.x) {
+    const int row0 = t * 32;
+    dcl_lds_barrier();                                 // the previous tile's readers of xs / red are done
+    // x tile: 32 rows x 128 floats, thread = (row, 16 floats)
+    {
+      const int row = tid >> 3, c0 = (tid & 7) * 16;
+      const float *src = x + (size_t)(row0 + row) * ldx + c0;
+      float *dst = xs + row * kMlpXP + c0;
+      const bool live = row0 + row < M;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = live ? *reinterpret_cast<const float4 *>(src + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        dst[4 * q] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
+      }
+    }
+    __syncthreads();
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    {
+      const float *arow = xs + r * kMlpXP + h, *brow = Ws1 + (w * 128 + h) * kMlpWP + r;
+#pragma unroll 16
+      for (int k0 = 0; k0 < 128; k0 += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[k0], brow[k0 * kMlpWP], acc, 0, 0, 0);
+    }
+    dcl_lds_barrier();                                 // every wave has read the x tile: it becomes the hidden tile
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = (e & 3) + 8 * (e >> 2) + 4 * h;
+      xs[m * kMlpXP + 32 * w + r] = fmaxf(acc[e] + bias1, 0.0f);
+    }
+    dcl_lds_barrier();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    {
+      const float *arow = xs + r * kMlpXP + h, *brow = Ws2 + (w * 128 + h) * kMlpWP + r;
+#pragma unroll 16
+      for (int k0 = 0; k0 < 128; k0 += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[k0], brow[k0 * kMlpWP], acc, 0, 0, 0);
+    }
+    // layer 3: this lane's column of the 16 rows it holds, times w3; summed over the 32 columns of the wave (lanes of one half)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      float v = fmaxf(acc[e] + bias2, 0.0f) * w3c;
+#pragma unroll
+      for (int d = 16; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+      if (r == 0) red[w * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] = v;
+    }
+    dcl_lds_barrier();
+    if (tid < 32 && row0 + tid < M) out[row0 + tid] = ((red[tid] + red[32 + tid]) + (red[64 + tid] + red[96 + tid])) + bias3;
+  }
+}
 }  // namespace
+
+DCL_API int dcl_mlp128_to1(const float *x, int64_t ldx, int M, const float *W1t, const float *b1, const float *W2t,
+                           const float *b2, const float *w3, int64_t ldw3, const float *b3, float *out, dclStream_t stream) {
+  DCL_CHECK_ARG(M >= 0 && ldx >= 128 && ldx % 4 == 0 && ldw3 >= 1);
+  if (M == 0) return 0;
+  DCL_CHECK_ARG(x && W1t && b1 && W2t && b2 && w3 && b3 && out);
+  DCL_CHECK_ARG((((uintptr_t)x | (uintptr_t)W1t | (uintptr_t)W2t) & 15) == 0);
+  const size_t lds = (size_t)(2 * 4 * 128 * kMlpWP + 32 * kMlpXP + 4 * 32) * sizeof(float);
+  (void)hipFuncSetAttribute((const void *)k_mlp128_to1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int tiles = (M + 31) / 32;
+  hipLaunchKernelGGL(k_mlp128_to1, dim3(tiles < 256 ? tiles : 256), dim3(256), lds, (hipStream_t)stream, M, x, (long long)ldx, W1t, b1,
+                     W2t, b2, w3, (long long)ldw3, b3, out);
+  DCL_LAUNCH_CHECK();
+  return 0;
+}
 
 DCL_API int dcl_pose_heads(int b, const float *pooled, const float *const *rot_layers, const float *const *trans_layers,
                            float *h1_scratch, float *o9, float *trans, float *R, dclStream_t stream) {

@@ -517,7 +517,7 @@ class Network(nn.Module):
             F = fuse
             for Wt, bias in fuser_layers:
                 F = self._lin_relu(F, Wt, bias)
-            return self._mlp(conf_in, conf_layers), F
+            return ops.mlp128_to1(conf_in, conf_layers), F              # (three K = 128 layers in one launch)
         with second:
             ops.cross_attention(b, act["Yom2"], act["Xcm2"], act["Xcp2"], fuse2[:, :256], act["Xcm2"], conf_in2[:, :64], concurrent=par)
             logit2, Fp2 = conf_and_fuser(conf_in2, fuse2, f["regressor_conf_bi"], l2)

@@ -901,6 +901,26 @@ def pad_linear_weight(Wt):
     return buf[:, :n]
 
 
+def mlp128_to1(x, layers, out=None):
+    """The confidence regressor (models/DCL_Net.py:115-126: Head_MultiLayerPerceptron [128, 128, 128, 1], ReLU, ReLU, none) on
+    point rows in ONE launch (csrc/dense.hip: k_mlp128_to1): x (M, 128) rows of pitch >= 128 (a column block of a wider buffer
+    is fine), layers = [(W1t (128,128), b1), (W2t (128,128), b2), (W3t (128,1), b3)] as Network._fold() keeps them.
+    Returns (M, 1) logits."""
+    (W1t, b1), (W2t, b2), (W3t, b3) = layers
+    N.need_cuda(x, W1t, W2t, W3t)
+    M = x.shape[0]
+    assert x.dim() == 2 and x.shape[1] == 128 and x.dtype == torch.float32 and (x.stride(1) == 1) and x.stride(0) % 4 == 0
+    for W in (W1t, W2t):
+        assert W.shape == (128, 128) and W.is_contiguous() and W.dtype == torch.float32
+    assert W3t.shape == (128, 1) and b1.numel() == 128 and b2.numel() == 128 and b3.numel() == 1
+    if out is None:
+        out = torch.empty((M, 1), dtype=torch.float32, device=x.device)
+    assert out.is_contiguous() and out.numel() == M
+    N.check(N.lib().dcl_mlp128_to1(N.ptr(x), C.c_int64(int(x.stride(0)) if M > 1 else 128), int(M), N.ptr(W1t), N.ptr(b1), N.ptr(W2t),
+                                   N.ptr(b2), N.ptr(W3t), C.c_int64(int(W3t.stride(0))), N.ptr(b3), N.ptr(out), N.stream()), "mlp128_to1")
+    return out
+
+
 def ortho9d_to_matrix(o9):
     """ortho9d2matrix (models/DCL_Net.py:15-36): (b,9) -> (b,3,3)."""
     N.need_cuda(o9)

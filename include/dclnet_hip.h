@@ -401,6 +401,11 @@ int dcl_affine3_relu(int64_t rows, int c, const float *xyz, const float *W3, con
  * crops (one-image calls); large batches use library GEMMs.  rot_layers / trans_layers: {W1t (1024,512), b1, W2t (512,128),
  * b2, W3t (128,9|3), b3}, matrices stored (in, out) row-major.  h1_scratch: 2*b*512 floats.  R (b,3,3), may be NULL: the
  * rotation matrices ortho9d2matrix (dcl_ortho9d_to_matrix) makes of o9, formed by the second launch itself.              */
+/* The confidence regressor (models/DCL_Net.py:115-126, 217-218: Head_MultiLayerPerceptron [128, 128, 128, 1], ReLU, ReLU, none)
+ * on point rows, one launch: out[m] = w3 . relu(W2t^T relu(W1t^T x[m] + b1) + b2) + b3.  x (M rows, pitch ldx >= 128, 16-B
+ * aligned), W1t / W2t (128 x 128, row = input channel, dense), w3 element k at w3[k * ldw3], b3 one float, out (M).  fp32 MFMA. */
+int dcl_mlp128_to1(const float *x, int64_t ldx, int M, const float *W1t, const float *b1, const float *W2t,
+                   const float *b2, const float *w3, int64_t ldw3, const float *b3, float *out, dclStream_t stream);
 int dcl_pose_heads(int b, const float *pooled, const float *const *rot_layers, const float *const *trans_layers,
                    float *h1_scratch, float *o9, float *trans, float *R, dclStream_t stream);
 

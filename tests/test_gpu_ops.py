@@ -893,6 +893,24 @@ def test_cross_attention_dma_variant_ragged_and_rescale(request, dcl):
         lib.dcl_debug_attention_variant(0)
 
 
+@pytest.mark.parametrize("M,wide", [(1024, False), (1000, True), (33, False), (32 * 1024, True), (1, False)])
+def test_confidence_regressor_in_one_launch_matches_its_three_layers(dcl, M, wide):
+    """dcl_mlp128_to1 (the regressor_conf stack, models/DCL_Net.py:115-126, in one launch) against the three layers in float64
+    and against the three library GEMMs it replaces; x as a column block of a wider buffer too"""
+    g = torch.Generator().manual_seed(M)
+    buf = torch.randn((M, 192 if wide else 128), generator=g).cuda()
+    x = buf[:, 64:192] if wide else buf
+    W1, W2 = (torch.randn((128, 128), generator=g) / 11.3).cuda(), (torch.randn((128, 128), generator=g) / 11.3).cuda()
+    W3 = dcl.ops.pad_linear_weight((torch.randn((128, 1), generator=g) / 11.3).cuda())
+    b1, b2, b3 = (torch.randn(128, generator=g) * 0.1).cuda(), (torch.randn(128, generator=g) * 0.1).cuda(), torch.randn(1, generator=g).cuda()
+    got = dcl.ops.mlp128_to1(x, [(W1, b1), (W2, b2), (W3, b3)])
+    ref = (((x.double() @ W1.double() + b1.double()).relu() @ W2.double() + b2.double()).relu() @ W3.double() + b3.double())
+    assert got.shape == (M, 1)
+    assert float((got.double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    lib3 = dcl.ops.linear(dcl.ops.linear(dcl.ops.linear(x, W1, b1, True), W2, b2, True), W3, b3, False)
+    assert float((got - lib3).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
 def test_conf_pool_matches_torch(dcl):
     g = torch.Generator().manual_seed(1)
     b, n1, n2, c = 3, 300, 170, 1024
