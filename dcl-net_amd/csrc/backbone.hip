@@ -40,6 +40,9 @@ int dcl_internal_geometry_small(const int32_t *occ, const int32_t *n_dev, int n_
 bool dcl_internal_readout_fused_ok(const DclReadoutLevels &L, int ld, bool need_search);
 int dcl_internal_readout_neighbours(int n, const float *points_b4, const DclReadoutLevels &L, int nbatch, float off,
                                     float *dist2, int32_t *idx, dclStream_t stream);
+bool dcl_internal_readout_one_launch_ok(int n);
+int dcl_internal_readout_one_launch(int n, const float *points_b4, const DclReadoutLevels &L, int nbatch, float off, float *dist2,
+                                    int32_t *idx, float *out, int ld, dclStream_t stream);
 int dcl_internal_readout_interpolate(int n, const DclReadoutLevels &L, const int32_t *idx, const float *dist2, float *out,
                                      int ld, dclStream_t stream);
 int dcl_internal_sparse_avgpool_fwd(const float *feat, const DclNbrSrc &nbr, int cap, const int32_t *n_out_dev,
@@ -580,6 +583,7 @@ static int point_features(int n, const float *points_b4, int batch, int S, int V
   if (tmp_bytes >= (int64_t)(2 * blk) && dcl_internal_readout_fused_ok(R, ld, true)) {
     float *d4 = at<float>(tmp, 0);
     int32_t *i4 = at<int32_t>(tmp, blk);
+    if (dcl_internal_readout_one_launch_ok(n)) return dcl_internal_readout_one_launch(n, points_b4, R, batch, offset, d4, i4, out, ld, stream);
     int rc4 = dcl_internal_readout_neighbours(n, points_b4, R, batch, offset, d4, i4, stream);
     if (rc4) return rc4;
     return dcl_internal_readout_interpolate(n, R, i4, d4, out, ld, stream);

@@ -305,49 +305,95 @@ __global__ __launch_bounds__(256) void k_three_nn_grid_levels(int n, const float
 // threads: most of the kernel's VALU work), then the 480 channels stream out as 16-B nontemporal stores (the rows are
 // read once, much later, by the disengage GEMM: no point in allocating them in L2).  Same arithmetic, same bits.
 constexpr int kInterpPts = 32;
+// one block of kInterpPts points (p0 ..) by NT threads: weights into LDS, then the 480 channels
+template <int NT>
+__device__ __forceinline__ void interpolate_block(int n, int p0, const DclReadoutLevels &L, const int32_t *__restrict__ idx,
+                                                  const float *__restrict__ dist2, float *__restrict__ out, int ld,
+                                                  float (*s_w)[3], int32_t (*s_i)[3]) {
+  const int q0 = L.c[0] >> 2, q1 = q0 + (L.c[1] >> 2), q2 = q1 + (L.c[2] >> 2), qn = q2 + (L.c[3] >> 2);
+  if (threadIdx.x < kInterpPts * 4) {
+    const int pl = threadIdx.x / 4, m = threadIdx.x & 3, p = p0 + pl;
+    if (p < n) {
+      const size_t o = ((size_t)m * n + p) * 3;
+      const float r0 = 1.0f / (sqrtf(dist2[o]) + 1e-8f), r1 = 1.0f / (sqrtf(dist2[o + 1]) + 1e-8f),
+                  r2 = 1.0f / (sqrtf(dist2[o + 2]) + 1e-8f);
+      const float norm = (r0 + r1) + r2;
+      s_w[threadIdx.x][0] = r0 / norm; s_w[threadIdx.x][1] = r1 / norm; s_w[threadIdx.x][2] = r2 / norm;
+      s_i[threadIdx.x][0] = idx[o]; s_i[threadIdx.x][1] = idx[o + 1]; s_i[threadIdx.x][2] = idx[o + 2];
+    }
+  }
+  __syncthreads();
+  const int npts = n - p0 < kInterpPts ? n - p0 : kInterpPts;
+  for (int t = threadIdx.x; t < npts * qn; t += NT) {
+    const int pl = t / qn;
+    int q = t - pl * qn;
+    const int m = q < q0 ? 0 : (q < q1 ? 1 : (q < q2 ? 2 : 3));
+    q -= m == 0 ? 0 : (m == 1 ? q0 : (m == 2 ? q1 : q2));
+    const int e = pl * 4 + m;
+    const float w0 = s_w[e][0], w1 = s_w[e][1], w2 = s_w[e][2];
+    const int c = L.c[m];
+    const float *__restrict__ F = L.feats[m];
+    const float4 a = reinterpret_cast<const float4 *>(F + (size_t)s_i[e][0] * c)[q];
+    const float4 b = reinterpret_cast<const float4 *>(F + (size_t)s_i[e][1] * c)[q];
+    const float4 d = reinterpret_cast<const float4 *>(F + (size_t)s_i[e][2] * c)[q];
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 v;
+    v.x = dcl_wsum3(w0, a.x, w1, b.x, w2, d.x);
+    v.y = dcl_wsum3(w0, a.y, w1, b.y, w2, d.y);
+    v.z = dcl_wsum3(w0, a.z, w1, b.z, w2, d.z);
+    v.w = dcl_wsum3(w0, a.w, w1, b.w, w2, d.w);
+    __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(out + (size_t)(p0 + pl) * ld + L.col[m]) + q);
+  }
+}
 __global__ __launch_bounds__(256) void k_three_interpolate_levels(int n, const DclReadoutLevels L,
                                                                   const int32_t *__restrict__ idx,
                                                                   const float *__restrict__ dist2, float *__restrict__ out,
                                                                   int ld) {
   __shared__ float s_w[kInterpPts * 4][3];
   __shared__ int32_t s_i[kInterpPts * 4][3];
-  const int q0 = L.c[0] >> 2, q1 = q0 + (L.c[1] >> 2), q2 = q1 + (L.c[2] >> 2), qn = q2 + (L.c[3] >> 2);
   for (int p0 = blockIdx.x * kInterpPts; p0 < n; p0 += gridDim.x * kInterpPts) {
     __syncthreads();
-    if (threadIdx.x < kInterpPts * 4) {
-      const int pl = threadIdx.x / 4, m = threadIdx.x & 3, p = p0 + pl;
-      if (p < n) {
-        const size_t o = ((size_t)m * n + p) * 3;
-        const float r0 = 1.0f / (sqrtf(dist2[o]) + 1e-8f), r1 = 1.0f / (sqrtf(dist2[o + 1]) + 1e-8f),
-                    r2 = 1.0f / (sqrtf(dist2[o + 2]) + 1e-8f);
-        const float norm = (r0 + r1) + r2;
-        s_w[threadIdx.x][0] = r0 / norm; s_w[threadIdx.x][1] = r1 / norm; s_w[threadIdx.x][2] = r2 / norm;
-        s_i[threadIdx.x][0] = idx[o]; s_i[threadIdx.x][1] = idx[o + 1]; s_i[threadIdx.x][2] = idx[o + 2];
-      }
-    }
-    __syncthreads();
-    const int npts = n - p0 < kInterpPts ? n - p0 : kInterpPts;
-    for (int t = threadIdx.x; t < npts * qn; t += 256) {
-      const int pl = t / qn;
-      int q = t - pl * qn;
-      const int m = q < q0 ? 0 : (q < q1 ? 1 : (q < q2 ? 2 : 3));
-      q -= m == 0 ? 0 : (m == 1 ? q0 : (m == 2 ? q1 : q2));
-      const int e = pl * 4 + m;
-      const float w0 = s_w[e][0], w1 = s_w[e][1], w2 = s_w[e][2];
-      const int c = L.c[m];
-      const float *__restrict__ F = L.feats[m];
-      const float4 a = reinterpret_cast<const float4 *>(F + (size_t)s_i[e][0] * c)[q];
-      const float4 b = reinterpret_cast<const float4 *>(F + (size_t)s_i[e][1] * c)[q];
-      const float4 d = reinterpret_cast<const float4 *>(F + (size_t)s_i[e][2] * c)[q];
-      typedef float f4 __attribute__((ext_vector_type(4)));
-      f4 v;
-      v.x = dcl_wsum3(w0, a.x, w1, b.x, w2, d.x);
-      v.y = dcl_wsum3(w0, a.y, w1, b.y, w2, d.y);
-      v.z = dcl_wsum3(w0, a.z, w1, b.z, w2, d.z);
-      v.w = dcl_wsum3(w0, a.w, w1, b.w, w2, d.w);
-      __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(out + (size_t)(p0 + pl) * ld + L.col[m]) + q);
-    }
+    interpolate_block<256>(n, p0, L, idx, dist2, out, ld, s_w, s_i);
   }
+}
+
+// The whole read-out of 32 points in ONE workgroup of 1024 threads (calls of up to kNnCoop8MaxQueries points, where the two
+// launches above are a search of 8 lanes per query and level followed by an interpolation that waits for it): threads 256 m ..
+// 256 m + 255 search level m exactly as k_three_nn_grid_levels<8> does (the crop's occupancy words and rank prefixes of all four
+// levels staged in LDS), a barrier, then all 1024 threads interpolate the block's 32 x 480 channels -- dist2 / idx still go to
+// memory (callers may ask for them) and come back from the CU's own cache.  One launch and one launch gap less per backbone.
+__global__ __launch_bounds__(1024) void k_readout_levels(int n, const float4 *__restrict__ unknown, const DclReadoutLevels L,
+                                                         int nbatch, float off, float *__restrict__ dist2,
+                                                         int32_t *__restrict__ idx, int force_scan, float *__restrict__ out, int ld) {
+  __shared__ uint32_t s_mask[4][kNnLdsWords];
+  __shared__ int32_t s_pre[4][kNnLdsWords];
+  __shared__ float s_w[kInterpPts * 4][3];
+  __shared__ int32_t s_i[kInterpPts * 4][3];
+  constexpr int LPQ = 8, QPB = 256 / LPQ;
+  static_assert(QPB == kInterpPts, "one block of the interpolation per block of the search");
+  const int m = (int)threadIdx.x >> 8, tl = (int)threadIdx.x & 255;
+  const int p0 = blockIdx.x * QPB, p = p0 + tl / LPQ, sub = tl % LPQ;
+  const int wpc = L.wpc[m];
+  const float4 u = p < n ? unknown[p] : make_float4(-1.f, 0.f, 0.f, 0.f);
+  const float4 u0 = unknown[p0];                                            // uniform: the block's first point
+  const int b0 = (int)u0.x;
+  const bool crop_ok = b0 >= 0 && b0 < nbatch && (float)b0 == u0.x;
+  const int same = __syncthreads_and((p >= n || u.x == u0.x) ? 1 : 0);
+  const bool staged = crop_ok && same && wpc <= kNnLdsWords;                // (per level: wave-group uniform)
+  if (crop_ok && same) {                                                    // (block-uniform: the barrier below is reached by all)
+    if (staged)
+      for (int i = tl; i < wpc; i += 256) {
+        s_mask[m][i] = L.mask[m][(size_t)b0 * wpc + i];
+        s_pre[m][i] = L.wprefix[m][(size_t)b0 * wpc + i];
+      }
+    __syncthreads();
+  }
+  if (p < n)
+    three_nn_grid_point<LPQ>(p, sub, u, reinterpret_cast<const int4 *>(L.indices[m]), L.mask[m], L.wprefix[m], nbatch, L.S[m], wpc,
+                             L.ve[m], off, dist2 + (size_t)m * n * 3, idx + (size_t)m * n * 3, force_scan,
+                             staged ? s_mask[m] : L.mask[m], staged ? s_pre[m] : L.wprefix[m], staged ? b0 * wpc : 0);
+  __syncthreads();                                                          // the block's dist2 / idx are written (and visible)
+  interpolate_block<1024>(n, p0, L, idx, dist2, out, ld, s_w, s_i);
 }
 
 // voxel centres (Ops_tensor2points, models/Modules.py:204-211): fp32, left to right.
@@ -816,6 +862,17 @@ int dcl_internal_readout_neighbours(int n, const float *points_b4, const DclRead
   else
     hipLaunchKernelGGL(k_three_nn_grid_levels<1>, dim3(dcl_div_up(n, 256), 4), dim3(256), 0, (hipStream_t)stream, n,
                        reinterpret_cast<const float4 *>(points_b4), L, nbatch, off, dist2, idx, mode == 2 ? 1 : 0);
+  DCL_LAUNCH_CHECK();
+  return 0;
+}
+
+// search + interpolation of all levels in one launch (k_readout_levels); false = the caller takes the two launches
+bool dcl_internal_readout_one_launch_ok(int n) { return g_nn_grid == 1 && n <= kNnCoop8MaxQueries; }
+int dcl_internal_readout_one_launch(int n, const float *points_b4, const DclReadoutLevels &L, int nbatch, float off, float *dist2,
+                                    int32_t *idx, float *out, int ld, dclStream_t stream) {
+  DCL_CHECK_ARG(n > 0 && points_b4 && dist2 && idx && out && nbatch > 0 && dcl_internal_readout_one_launch_ok(n));
+  hipLaunchKernelGGL(k_readout_levels, dim3(dcl_div_up(n, kInterpPts)), dim3(1024), 0, (hipStream_t)stream, n,
+                     reinterpret_cast<const float4 *>(points_b4), L, nbatch, off, dist2, idx, 0, out, ld);
   DCL_LAUNCH_CHECK();
   return 0;
 }
