@@ -1044,12 +1044,46 @@ __device__ __forceinline__ float heads_tree16(const float (*part)[64], int o) {
   return v[0];
 }
 
-__global__ __launch_bounds__(1024) void k_heads_l1(int b, const float *__restrict__ x, HeadWeights hw, float *__restrict__ h1) {
+// the pooled feature still as the pooling's slice partials (calls of a handful of crops: k_pool_finish folded into this launch)
+struct PoolParts {
+  const float *part1, *part2, *wsum, *sA, *tA, *sB, *tB;
+  int nslices;
+};
+// out[ch] of k_pool_finish for (crop, ch), the same operations in the same order
+__device__ __forceinline__ float pool_finish_one(const PoolParts &P, int c, int b, int ch) {
+  float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+  const float *q1 = P.part1 + (size_t)b * P.nslices * c + ch, *q2 = P.part2 + (size_t)b * P.nslices * c + ch;
+  int s = 0;
+  for (; s + 4 <= P.nslices; s += 4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      a1[j] += q1[(size_t)(s + j) * c];
+      a2[j] += q2[(size_t)(s + j) * c];
+    }
+  }
+  for (int j = 0; s < P.nslices; ++s, ++j) {
+    a1[j] += q1[(size_t)s * c];
+    a2[j] += q2[(size_t)s * c];
+  }
+  const float p1 = (a1[0] + a1[1]) + (a1[2] + a1[3]), p2 = (a2[0] + a2[1]) + (a2[2] + a2[3]);
+  const float w0 = P.wsum[2 * b], w1 = P.wsum[2 * b + 1];
+  return ((P.sA[ch] * p1 + P.tA[ch] * w0) + P.sB[ch] * p2) + P.tB[ch] * w1;
+}
+
+template <bool FROM_PARTS>
+__global__ __launch_bounds__(1024) void k_heads_l1(int b, const float *__restrict__ x, const PoolParts P, HeadWeights hw,
+                                                   float *__restrict__ h1) {
   __shared__ float part[kHeadSlices][64];
+  __shared__ float xs[FROM_PARTS ? 1024 : 1];
   const int head = blockIdx.z, crop = blockIdx.y, o0 = blockIdx.x * 64;
   const int o = threadIdx.x & 63, ks = threadIdx.x >> 6;                   // 16 slices of 64 terms
   const float *w = hw.w1[head] + (size_t)(ks * 64) * 512 + o0 + o;
   const float *xv = x + (size_t)crop * 1024 + ks * 64;
+  if constexpr (FROM_PARTS) {
+    xs[threadIdx.x] = pool_finish_one(P, 1024, crop, (int)threadIdx.x);    // (every workgroup of the crop forms the 1024 inputs itself)
+    __syncthreads();
+    xv = xs + ks * 64;
+  }
   float acc = 0.f;
 #pragma unroll 16
   for (int i = 0; i < 64; ++i) acc = __fmaf_rn(xv[i], w[(size_t)i * 512], acc);
@@ -1217,7 +1251,28 @@ DCL_API int dcl_pose_heads(int b, const float *pooled, const float *const *rot_l
     hw.w1[h] = L[0]; hw.b1[h] = L[1]; hw.w2[h] = L[2]; hw.b2[h] = L[3]; hw.w3[h] = L[4]; hw.b3[h] = L[5];
   }
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_heads_l1, dim3(512 / 64, b, 2), dim3(1024), 0, s, b, pooled, hw, h1_scratch);
+  hipLaunchKernelGGL(k_heads_l1<false>, dim3(512 / 64, b, 2), dim3(1024), 0, s, b, pooled, PoolParts{}, hw, h1_scratch);
+  hipLaunchKernelGGL(k_heads_l23, dim3(b, 2), dim3(1024), 0, s, b, h1_scratch, hw, o9, trans, R);
+  DCL_LAUNCH_CHECK();
+  return 0;
+}
+
+DCL_API int dcl_pose_heads_parts(int b, int nslices, const float *part1, const float *part2, const float *wsum,
+                                 const float *scale1, const float *shift1, const float *scale2, const float *shift2,
+                                 const float *const *rot_layers, const float *const *trans_layers, float *h1_scratch, float *o9,
+                                 float *trans, float *R, dclStream_t stream) {
+  DCL_CHECK_ARG(b >= 0 && b <= 65535 && nslices >= 1);
+  if (b == 0) return 0;
+  DCL_CHECK_ARG(part1 && part2 && wsum && scale1 && shift1 && scale2 && shift2 && rot_layers && trans_layers && h1_scratch && o9 && trans);
+  HeadWeights hw;
+  for (int h = 0; h < 2; ++h) {
+    const float *const *L = h == 0 ? rot_layers : trans_layers;         // {W1t, b1, W2t, b2, W3t, b3}
+    for (int i = 0; i < 6; ++i) DCL_CHECK_ARG(L[i] != nullptr);
+    hw.w1[h] = L[0]; hw.b1[h] = L[1]; hw.w2[h] = L[2]; hw.b2[h] = L[3]; hw.w3[h] = L[4]; hw.b3[h] = L[5];
+  }
+  const PoolParts P{part1, part2, wsum, scale1, shift1, scale2, shift2, nslices};
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_heads_l1<true>, dim3(512 / 64, b, 2), dim3(1024), 0, s, b, nullptr, P, hw, h1_scratch);
   hipLaunchKernelGGL(k_heads_l23, dim3(b, 2), dim3(1024), 0, s, b, h1_scratch, hw, o9, trans, R);
   DCL_LAUNCH_CHECK();
   return 0;

@@ -439,6 +439,7 @@ class Network(nn.Module):
     _DIS_TAGS = (("p1", 256), ("m1", 64), ("p2", 256), ("m2", 64))
     POSE_HEADS_MAX = 128      # crops up to which the two pose heads run as dcl_pose_heads (two launches) instead of six library
                               # GEMMs + glue (same-job A/B: 8 crops -3.4 %, 12: -2.8 %, 16: -2 %, 32: -0.9 %, 40: -1.2 % of the forward)
+    POSE_PARTS_MAX = 8        # crops up to which the pooling's finish is folded into the heads' first launch (a launch less)
     PAR_TAIL = None           # None = by shape (_tail_parallel); True / False force the dense tail's two directions onto two
                               # streams / one (A/B runs)
     GROUP_ROWS = 2 * 1024     # calls of at most this many points per side issue independent MLP layers as ONE launch each
@@ -527,8 +528,16 @@ class Network(nn.Module):
         logit1, Fp1 = conf_and_fuser(conf_in1, fuse1, f["regressor_conf"], l1)   # (b*N, 1), (b*N, 1024)
         join()
         # trailing BNs after pooling: F_p_wei = sA*P1 + tA*sum(w1) + sB*P2 + tB*sum(w2), finished inside the pooling op
-        conf, F_p_wei = ops.conf_pool(b, logit1.reshape(-1), logit2.reshape(-1), Fp1, Fp2, affine=(sA, tA, sB, tB))
-        if b <= self.POSE_HEADS_MAX:                   # up to this many crops: both heads in two launches (csrc/dense.hip)
+        if b <= self.POSE_PARTS_MAX:                   # a handful of crops: the pooling's finish inside the heads' first launch
+            conf, parts = ops.conf_pool(b, logit1.reshape(-1), logit2.reshape(-1), Fp1, Fp2, affine=(sA, tA, sB, tB), finish=False)
+            o9, trans_pred, rot_pred = ops.pose_heads_parts(parts, (sA, tA, sB, tB), f["regressor_rot"], f["regressor_trans"],
+                                                            with_rotation=True)
+            F_p_wei = None
+        else:
+            conf, F_p_wei = ops.conf_pool(b, logit1.reshape(-1), logit2.reshape(-1), Fp1, Fp2, affine=(sA, tA, sB, tB))
+        if F_p_wei is None:
+            pass
+        elif b <= self.POSE_HEADS_MAX:                 # up to this many crops: both heads in two launches (csrc/dense.hip)
             o9, trans_pred, rot_pred = ops.pose_heads(F_p_wei, f["regressor_rot"], f["regressor_trans"], with_rotation=True)
         else:
             with second:

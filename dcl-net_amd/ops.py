@@ -719,11 +719,12 @@ def cross_attention(b, Q, K, V1, O1, V2=None, O2=None, concurrent=1):
     return O1, O2
 
 
-def conf_pool(b, logit1, logit2, F1, F2, affine=None):
+def conf_pool(b, logit1, logit2, F1, F2, affine=None, finish=True):
     """Confidence pooling: logits (b*n1,)/(b*n2,), F1 (b*n1,C), F2 (b*n2,C) point-major ->
     conf (b,n1+n2), pooled1 (b,C), pooled2 (b,C), wsum (b,2).
     affine = (s1, t1, s2, t2), each (C,): returns (conf, ((s1*P1 + t1*wsum1) + s2*P2) + t2*wsum2) instead -- the pooled
-    feature behind trailing BatchNorms that were not applied to F1 / F2 -- finished in one launch."""
+    feature behind trailing BatchNorms that were not applied to F1 / F2 -- finished in one launch; finish=False: (conf, parts)
+    with the slice partials for pose_heads_parts, which finishes them inside its first launch."""
     N.need_cuda(logit1, logit2, F1, F2)
     n1, n2 = F1.shape[0] // b, F2.shape[0] // b
     c = F1.shape[1]
@@ -743,6 +744,8 @@ def conf_pool(b, logit1, logit2, F1, F2, affine=None):
         s1, t1, s2, t2 = affine
         N.need_cuda(s1, t1, s2, t2)
         assert all(t.is_contiguous() and t.numel() == c and t.dtype == torch.float32 for t in affine)
+        if not finish:                                 # the caller folds the finish into its next launch (pose_heads_parts)
+            return conf, (nslices, part1, part2, ws)
         out = torch.empty((b, c), dtype=torch.float32, device=dev)
         N.check(N.lib().dcl_pool_finish(b, c, nslices, N.ptr(part1), N.ptr(part2), N.ptr(ws), N.ptr(s1), N.ptr(t1),
                                         N.ptr(s2), N.ptr(t2), N.ptr(out), N.stream()), "pool_finish")
@@ -780,6 +783,26 @@ def pose_heads(pooled, rot_layers, trans_layers, with_rotation=False):
     R = torch.empty((b, 3, 3), dtype=torch.float32, device=dev) if with_rotation else None
     N.check(N.lib().dcl_pose_heads(b, N.ptr(pooled), flat(rot_layers), flat(trans_layers), N.ptr(h1), N.ptr(o9), N.ptr(trans),
                                    N.ptr(R), N.stream()), "pose_heads")
+    return (o9, trans, R) if with_rotation else (o9, trans)
+
+
+def pose_heads_parts(parts, affine, rot_layers, trans_layers, with_rotation=False):
+    """pose_heads on the pooled feature still in parts (conf_pool(..., affine, finish=False)): the pooling's finish runs inside
+    the heads' first launch -- a launch less for a handful of crops, bit-identical to conf_pool(finish=True) + pose_heads."""
+    nslices, part1, part2, ws = parts
+    s1, t1, s2, t2 = affine
+    b, dev = part1.shape[0], part1.device
+    assert part1.shape[2] == 1024 and tuple(rot_layers[0][0].shape) == (1024, 512) and tuple(rot_layers[2][0].shape) == (128, 9)
+    assert tuple(trans_layers[1][0].shape) == (512, 128) and tuple(trans_layers[2][0].shape) == (128, 3)
+    flat = lambda layers: _ptr_array([t for pair in layers for t in pair])                    # noqa: E731
+    assert all(t.is_contiguous() and t.dtype == torch.float32 for layers in (rot_layers, trans_layers) for p in layers for t in p)
+    h1 = torch.empty((2, b, 512), dtype=torch.float32, device=dev)
+    o9 = torch.empty((b, 9), dtype=torch.float32, device=dev)
+    trans = torch.empty((b, 3), dtype=torch.float32, device=dev)
+    R = torch.empty((b, 3, 3), dtype=torch.float32, device=dev) if with_rotation else None
+    N.check(N.lib().dcl_pose_heads_parts(b, int(nslices), N.ptr(part1), N.ptr(part2), N.ptr(ws), N.ptr(s1), N.ptr(t1), N.ptr(s2),
+                                         N.ptr(t2), flat(rot_layers), flat(trans_layers), N.ptr(h1), N.ptr(o9), N.ptr(trans),
+                                         N.ptr(R), N.stream()), "pose_heads_parts")
     return (o9, trans, R) if with_rotation else (o9, trans)
 
 

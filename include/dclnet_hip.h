@@ -408,6 +408,13 @@ int dcl_mlp128_to1(const float *x, int64_t ldx, int M, const float *W1t, const f
                    const float *b2, const float *w3, int64_t ldw3, const float *b3, float *out, dclStream_t stream);
 int dcl_pose_heads(int b, const float *pooled, const float *const *rot_layers, const float *const *trans_layers,
                    float *h1_scratch, float *o9, float *trans, float *R, dclStream_t stream);
+/* The same heads fed with the confidence pooling's slice partials instead of the finished pooled feature (dcl_conf_pool's part1 /
+ * part2 / wsum + the fusers' trailing BatchNorm affines, as dcl_pool_finish takes them): the finish is folded into the first
+ * launch -- every workgroup of a crop forms the 1024 inputs itself, same operations, same bits.  For a handful of crops. */
+int dcl_pose_heads_parts(int b, int nslices, const float *part1, const float *part2, const float *wsum,
+                         const float *scale1, const float *shift1, const float *scale2, const float *shift2,
+                         const float *const *rot_layers, const float *const *trans_layers, float *h1_scratch, float *o9,
+                         float *trans, float *R, dclStream_t stream);
 
 /* One per-point linear layer -- Conv1d(k=1) / 1x1x1 Conv3d with its BatchNorm folded in (models/Modules.py:58-97, 173-201;
  * the reference runs them as cuDNN pointwise convolutions): y[M x N] = act(x[M x K] Wt[K x N] + bias[N]), row-major, every

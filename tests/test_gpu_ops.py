@@ -893,6 +893,25 @@ def test_cross_attention_dma_variant_ragged_and_rescale(request, dcl):
         lib.dcl_debug_attention_variant(0)
 
 
+@pytest.mark.parametrize("b", [1, 3, 8])
+def test_pose_heads_fed_with_pooling_parts_are_bit_identical(dcl, b):
+    """dcl_pose_heads_parts (the pooling's finish folded into the heads' first launch) == dcl_pool_finish + dcl_pose_heads"""
+    g = torch.Generator().manual_seed(b)
+    n1 = n2 = 256
+    F1, F2 = torch.randn((b * n1, 1024), generator=g).cuda(), torch.randn((b * n2, 1024), generator=g).cuda()
+    l1, l2 = torch.randn(b * n1, generator=g).cuda(), torch.randn(b * n2, generator=g).cuda()
+    aff = tuple(torch.randn(1024, generator=g).cuda() for _ in range(4))
+    mk = lambda i, o: ((torch.randn((i, o), generator=g) / i ** 0.5).cuda(), (torch.randn(o, generator=g) * 0.1).cuda())     # noqa: E731
+    rot, tr = [mk(1024, 512), mk(512, 128), mk(128, 9)], [mk(1024, 512), mk(512, 128), mk(128, 3)]
+    conf_a, pooled = dcl.ops.conf_pool(b, l1, l2, F1, F2, affine=aff)
+    want = dcl.ops.pose_heads(pooled, rot, tr, with_rotation=True)
+    conf_b, parts = dcl.ops.conf_pool(b, l1, l2, F1, F2, affine=aff, finish=False)
+    got = dcl.ops.pose_heads_parts(parts, aff, rot, tr, with_rotation=True)
+    assert torch.equal(conf_a, conf_b)
+    for a, c in zip(got, want):
+        assert torch.equal(a, c)
+
+
 @pytest.mark.parametrize("M,wide", [(1024, False), (1000, True), (33, False), (32 * 1024, True), (1, False)])
 def test_confidence_regressor_in_one_launch_matches_its_three_layers(dcl, M, wide):
     """dcl_mlp128_to1 (the regressor_conf stack, models/DCL_Net.py:115-126, in one launch) against the three layers in float64
