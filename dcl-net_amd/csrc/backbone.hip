@@ -36,7 +36,8 @@ bool dcl_internal_mask_chain_ok(int S);
 int dcl_internal_mask_chain(const uint32_t *mask0, int batch, const DclGeoSets &g, dclStream_t stream);
 bool dcl_internal_geometry_small_ok(int batch, int S, int rows);
 int dcl_internal_geometry_small(const int32_t *occ, const int32_t *n_dev, int n_host, int batch_lo, int batch, uint32_t *mask0,
-                                int32_t *wprefix0, int32_t *perm0, int32_t *comm, const DclGeoSets &g, dclStream_t stream);
+                                int32_t *wprefix0, int32_t *perm0, int32_t *comm, const DclGeoSets &g, const DclVoxelizeRider *vx,
+                                dclStream_t stream);
 bool dcl_internal_readout_fused_ok(const DclReadoutLevels &L, int ld, bool need_search);
 int dcl_internal_readout_neighbours(int n, const float *points_b4, const DclReadoutLevels &L, int nbatch, float off,
                                     float *dist2, int32_t *idx, dclStream_t stream);
@@ -197,7 +198,7 @@ DCL_API int dcl_backbone_ws_bytes(int batch, int S, int V0, int64_t *bytes_host)
 }
 
 static int backbone_geometry(const int32_t *occ, const int32_t *V0_dev, int V0, int batch_lo, int batch, int S, void *ws,
-                             int64_t ws_bytes, int32_t *counts_dev, dclStream_t stream);
+                             int64_t ws_bytes, int32_t *counts_dev, dclStream_t stream, const DclVoxelizeRider *vx = nullptr);
 
 DCL_API int dcl_backbone_geometry(const int32_t *occ, int V0, int batch, int S, void *ws, int64_t ws_bytes,
                                   int32_t *counts_dev, dclStream_t stream) {
@@ -219,8 +220,18 @@ DCL_API int dcl_backbone_geometry_cap(const int32_t *occ, const int32_t *V0_dev,
   return backbone_geometry(occ, V0_dev, V0_cap, 0, batch, S, ws, ws_bytes, counts_dev, stream);
 }
 
+// the same + PG_OP.voxelize_fp of the pass's points (out[row][plane], rules = v2p maps of `rows` rows with max_active + 1 columns):
+// a pass that takes the one-launch geometry stage carries it in that launch, any other issues it as a launch of its own
+DCL_API int dcl_backbone_geometry_cap_vox(const int32_t *occ, const int32_t *V0_dev, int V0_cap, int batch, int S, void *ws,
+                                          int64_t ws_bytes, int32_t *counts_dev, const float *feats, const int32_t *rules,
+                                          float *vox_out, int rows, int max_active, int planes, int average, dclStream_t stream) {
+  DCL_CHECK_ARG(V0_dev && rows >= 0 && max_active >= 0 && planes > 0 && (rows == 0 || (feats && rules && vox_out)));
+  const DclVoxelizeRider vx{feats, rules, vox_out, rows, max_active, planes, average};
+  return backbone_geometry(occ, V0_dev, V0_cap, 0, batch, S, ws, ws_bytes, counts_dev, stream, &vx);
+}
+
 static int backbone_geometry(const int32_t *occ, const int32_t *V0_dev, int V0, int batch_lo, int batch, int S, void *ws,
-                             int64_t ws_bytes, int32_t *counts_dev, dclStream_t stream) {
+                             int64_t ws_bytes, int32_t *counts_dev, dclStream_t stream, const DclVoxelizeRider *vx) {
   GeoLayout L;
   DCL_CHECK_ARG(ws && counts_dev && make_geo_layout(batch, S, V0, &L) && ws_bytes >= (int64_t)L.total);
   DCL_CHECK_ARG(V0 == 0 || occ);
@@ -264,14 +275,19 @@ static int backbone_geometry(const int32_t *occ, const int32_t *V0_dev, int V0, 
   }
   if (one_launch) {
     rc = dcl_internal_geometry_small(occ, V0_dev, V0, batch_lo, batch, at<uint32_t>(ws, L.mask0), at<int32_t>(ws, L.wprefix0),
-                                     at<int32_t>(ws, L.perm0), at<int32_t>(ws, L.comm), g, stream);
+                                     at<int32_t>(ws, L.perm0), at<int32_t>(ws, L.comm), g, vx, stream);
     if (rc) return rc;
+    vx = nullptr;                                      // done: rode on the stage's launch
   } else {
     if (fused_chain) {
       rc = dcl_internal_mask_chain(at<uint32_t>(ws, L.mask0), batch, g, stream);
       if (rc) return rc;
     }
     rc = dcl_internal_scan_enumerate_sets(g, 2 * kLevels, stream);
+    if (rc) return rc;
+  }
+  if (vx && vx->rows > 0) {                            // (the separate-launch stage: the voxelisation as its own launch)
+    rc = dcl_voxelize_fp(vx->feats, vx->rules, vx->out, vx->rows, vx->max_active, vx->planes, vx->average, stream);
     if (rc) return rc;
   }
   // row orders of the MFMA-bound conv layers (depends on the geometry only): all jobs of the pass in five launches

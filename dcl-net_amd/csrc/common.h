@@ -94,6 +94,13 @@ struct DclGeoSets {
   int nwords[8], S[8], cap[8];
   int32_t *zero_words;      // optional: 16 int32 the first batched launch zeroes (tickets of the row-order launch of the pass)
 };
+// PG_OP.voxelize_fp of a pass's points riding on the one-launch geometry stage (rulebook.hip: k_geometry_small)
+struct DclVoxelizeRider {
+  const float *feats;
+  const int32_t *rules;
+  float *out;
+  int rows, max_active, planes, average;
+};
 // Row ordering of one conv layer (row_order.hip): tile slot i of the launch computes output row order[i]; bal[t] = number of
 // used kernel-offset steps of the 128-row tiles in front of tile t (bal[ntiles] = all of them), smask[t] = tile t's step mask.
 struct DclRowOrder {

@@ -360,6 +360,12 @@ struct GeoSmallArgs {
   int n_host, batch_lo, batch;
   uint32_t *mask0;
   int32_t *wprefix0, *perm0, *comm;
+  // optional rider: PG_OP.voxelize_fp of the pass's points (voxelize.hip: voxelize_fp_kernel, same arithmetic) by the
+  // workgroups behind the crops' -- it depends on the input only, and the launch otherwise leaves all but `batch` CUs idle
+  const float *vx_feats;
+  const int32_t *vx_rules;
+  float *vx_out;
+  int vx_rows, vx_ma, vx_planes, vx_avg;
 };
 // ---- k_geometry_small, second form.  What the first form (one thread = 8 consecutive words, nine rolled 1024-thread scans,
 // per-thread row decoding) spent its 34 us on, by stamps (tools/geo_stamps.py, one crop): 12 us in the mask chain -- 4 of
@@ -395,6 +401,20 @@ __global__ void __launch_bounds__(kChainThreads) k_geometry_small(const GeoSmall
   __shared__ int32_t s_wp0[kChainWords];                // set 0's word prefixes (the level-0 permutation reads them back)
   __shared__ int s_w[10][16], s_wbase[10][16], s_tot[10], s_base[9];     // [9] = set 1's non-empty words
   const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (c >= a.batch) {                                   // rider workgroups: voxelize_fp (see GeoSmallArgs)
+    const long long total = (long long)a.vx_rows * a.vx_planes;
+    for (long long t = (long long)(c - a.batch) * kChainThreads + tid; t < total; t += (long long)(gridDim.x - a.batch) * kChainThreads) {
+      const int row = (int)(t / a.vx_planes);
+      const int plane = (int)(t - (long long)row * a.vx_planes);
+      const int32_t *r = a.vx_rules + (size_t)row * (a.vx_ma + 1);
+      const int n_active = r[0];
+      const float mult = (a.vx_avg && n_active > 0) ? 1.0f / (float)n_active : 1.0f;
+      float acc = 0.0f;
+      for (int i = 1; i <= n_active; ++i) acc = acc + mult * a.vx_feats[(size_t)r[i] * a.vx_planes + plane];
+      a.vx_out[t] = acc;
+    }
+    return;
+  }
   GEO_STAMP(0);
   if (c == 0 && tid < 16 && g.zero_words) g.zero_words[tid] = 0;            // tickets of later launches of the pass
   // 1. this crop's occupancy (rows of other crops are skipped; rows are re-based by batch_lo)
@@ -952,13 +972,22 @@ DCL_API int dcl_debug_geometry_small_stamps(unsigned long long *host32) {
 }
 #endif
 int dcl_internal_geometry_small(const int32_t *occ, const int32_t *n_dev, int n_host, int batch_lo, int batch, uint32_t *mask0,
-                                int32_t *wprefix0, int32_t *perm0, int32_t *comm, const DclGeoSets &g, dclStream_t stream) {
+                                int32_t *wprefix0, int32_t *perm0, int32_t *comm, const DclGeoSets &g, const DclVoxelizeRider *vx,
+                                dclStream_t stream) {
   DCL_CHECK_ARG(dcl_internal_geometry_small_ok(batch, kChainS, n_host) && mask0 && wprefix0 && comm && (n_host == 0 || occ));
   for (int i = 0; i < 8; ++i) DCL_CHECK_ARG(g.mask[i] && g.wprefix[i] && g.indices[i] && g.S[i] == kChainS >> ((i + 1) >> 1));      // 64, 32, 32, 16, 16, 8, 8, 4
   hipStream_t s = (hipStream_t)stream;
   if (batch > 1) dcl_internal_zero_words(comm, (long long)kGeoSmallMax * kGeoCommStride, s);      // (one crop exchanges nothing)
-  GeoSmallArgs a{occ, n_dev, n_host, batch_lo, batch, mask0, wprefix0, perm0, comm};
-  hipLaunchKernelGGL(k_geometry_small, dim3(batch), dim3(kChainThreads), 0, s, a, g);
+  GeoSmallArgs a{occ, n_dev, n_host, batch_lo, batch, mask0, wprefix0, perm0, comm, nullptr, nullptr, nullptr, 0, 0, 1, 0};
+  int riders = 0;
+  if (vx && vx->rows > 0) {
+    a.vx_feats = vx->feats; a.vx_rules = vx->rules; a.vx_out = vx->out;
+    a.vx_rows = vx->rows; a.vx_ma = vx->max_active; a.vx_planes = vx->planes; a.vx_avg = vx->average;
+    const long long total = (long long)vx->rows * vx->planes;
+    riders = (int)((total + kChainThreads - 1) / kChainThreads);
+    if (riders > 240) riders = 240;                    // (a workgroup of this kernel takes a CU to itself)
+  }
+  hipLaunchKernelGGL(k_geometry_small, dim3(batch + riders), dim3(kChainThreads), 0, s, a, g);
   DCL_LAUNCH_CHECK();
   return 0;
 }

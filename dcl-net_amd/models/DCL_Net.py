@@ -711,10 +711,9 @@ class Network(nn.Module):
                 for s, bb, stream, dside in sides:
                     with torch.cuda.stream(stream):
                         st = ent[s]
-                        if stage == 0:
-                            st["run"].geometry()
+                        if stage == 0:                   # (the voxelisation rides on the geometry stage's launch up to 16 crops)
+                            xs[s] = st["run"].geometry(voxelize=(st["feats"], st["v2p"], self.voxelization_mode))
                         elif stage == 1:
-                            xs[s] = ops.voxelize_fp(st["feats"], st["v2p"], self.voxelization_mode)
                             pb4s[s] = st["pb4"]
                         elif stage == 2:
                             st["run"].features(xs[s], *f[bb + "_ptrs"])

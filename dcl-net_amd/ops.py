@@ -509,10 +509,23 @@ class BackboneRunCap(object):
                        for m in range(4)]
         self.level_ptrs = _ptr_array(self.levels)
 
-    def geometry(self):
-        N.check(N.lib().dcl_backbone_geometry_cap(N.ptr(self.occ), N.ptr(self.v0_dev), self.V0, self.batch, self.S,
-                                                  N.ptr(self.ws), self.ws_bytes, N.ptr(self.counts_dev), N.stream()),
-                "backbone_geometry_cap")
+    def geometry(self, voxelize=None):
+        """voxelize = (feats (N,C) f32, map_rule (M, 1 + maxActive) i32, mode): also returns voxelize_fp(feats, map_rule, mode),
+        carried by the geometry stage's own launch where that is one launch (up to 16 crops)"""
+        if voxelize is None:
+            N.check(N.lib().dcl_backbone_geometry_cap(N.ptr(self.occ), N.ptr(self.v0_dev), self.V0, self.batch, self.S,
+                                                      N.ptr(self.ws), self.ws_bytes, N.ptr(self.counts_dev), N.stream()),
+                    "backbone_geometry_cap")
+            return None
+        feats, rule, mode = voxelize
+        N.need_cuda(feats, rule)
+        assert feats.is_contiguous() and rule.is_contiguous() and feats.dtype == torch.float32 and rule.dtype == torch.int32
+        out = torch.empty((rule.shape[0], feats.shape[1]), dtype=torch.float32, device=feats.device)
+        N.check(N.lib().dcl_backbone_geometry_cap_vox(N.ptr(self.occ), N.ptr(self.v0_dev), self.V0, self.batch, self.S,
+                                                      N.ptr(self.ws), self.ws_bytes, N.ptr(self.counts_dev), N.ptr(feats),
+                                                      N.ptr(rule), N.ptr(out), rule.shape[0], rule.shape[1] - 1, feats.shape[1],
+                                                      int(mode == 4), N.stream()), "backbone_geometry_cap_vox")
+        return out
 
     def features(self, vox_feats, weights_arr, scales_arr, shifts_arr):
         N.check(N.lib().dcl_backbone_features_cap(N.ptr(self.occ), self.V0, self.batch, self.S, N.ptr(self.ws),

@@ -252,6 +252,11 @@ int dcl_backbone_features(const int32_t *occ, int V0, int batch, int S, void *ws
 int dcl_backbone_caps(int batch, int S, int V0_cap, int32_t *caps_host /* i32[8] */);
 int dcl_backbone_geometry_cap(const int32_t *occ, const int32_t *V0_dev, int V0_cap, int batch, int S, void *ws,
                               int64_t ws_bytes, int32_t *counts_dev, dclStream_t stream);
+/* dcl_backbone_geometry_cap + dcl_voxelize_fp(feats, rules, vox_out, rows, max_active, planes, average) of the pass's points:
+ * a pass of up to 16 crops carries the voxelisation in its one geometry launch (it depends on the input only). */
+int dcl_backbone_geometry_cap_vox(const int32_t *occ, const int32_t *V0_dev, int V0_cap, int batch, int S, void *ws,
+                                  int64_t ws_bytes, int32_t *counts_dev, const float *feats, const int32_t *rules,
+                                  float *vox_out, int rows, int max_active, int planes, int average, dclStream_t stream);
 int dcl_backbone_features_cap(const int32_t *occ, int V0_cap, int batch, int S, void *ws, const int32_t *counts_dev,
                               const int32_t *channels_host, const float *vox_feats, const float *const *weights_host,
                               const float *const *scales_host, const float *const *shifts_host, void *ws2,

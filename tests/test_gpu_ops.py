@@ -893,6 +893,29 @@ def test_cross_attention_dma_variant_ragged_and_rescale(request, dcl):
         lib.dcl_debug_attention_variant(0)
 
 
+@pytest.mark.parametrize("b", [1, 6, 20])
+def test_voxelisation_riding_on_the_geometry_launch_is_bit_identical(dcl, b):
+    """BackboneRunCap.geometry(voxelize=...) -- PG_OP.voxelize_fp carried by the one-launch geometry stage (up to 16 crops), a
+    launch of its own otherwise -- against ops.voxelize_fp, and the geometry itself against a run without the rider"""
+    d = dcl.synth.make_batch(b, 1024, 64, first=31 + b)["inp"]
+    occ = d["occupied_voxels"].int().cuda().contiguous()
+    feats, v2p = d["feats"].float().cuda().contiguous(), d["v2p_maps"].int().cuda().contiguous()
+    v0 = torch.tensor([occ.shape[0]], dtype=torch.int32, device="cuda")
+    cap = torch.zeros((b * 1024, 4), dtype=torch.int32, device="cuda")
+    cap[:occ.shape[0]] = occ
+    rules = torch.zeros((b * 1024, v2p.shape[1]), dtype=torch.int32, device="cuda")
+    rules[:v2p.shape[0]] = v2p
+    plain, ride = dcl.ops.BackboneRunCap(cap, v0, b, 64), dcl.ops.BackboneRunCap(cap, v0, b, 64)
+    plain.geometry()
+    got = ride.geometry(voxelize=(feats, rules, 4))
+    want = dcl.ops.voxelize_fp(feats, rules, 4)
+    assert torch.equal(got, want) and float(got[:v2p.shape[0]].abs().sum()) > 0
+    assert torch.equal(plain.counts_dev, ride.counts_dev) and int(plain.counts_dev[0]) > 0
+    n = int(plain.counts_dev[0])
+    assert torch.equal(plain.ws[:1 << 16], ride.ws[:1 << 16])      # the level-0 mask (first bytes of the workspace)
+    del n
+
+
 @pytest.mark.parametrize("b", [1, 3, 8])
 def test_pose_heads_fed_with_pooling_parts_are_bit_identical(dcl, b):
     """dcl_pose_heads_parts (the pooling's finish folded into the heads' first launch) == dcl_pool_finish + dcl_pose_heads"""
