@@ -1084,9 +1084,13 @@ __global__ __launch_bounds__(1024) void k_heads_l1(int b, const float *__restric
     __syncthreads();
     xv = xs + ks * 64;
   }
+  // (all 64 weight loads of the slice in flight: in rounds of 16 a call of one crop waited four round trips here)
+  float wv[64];
+#pragma unroll
+  for (int i = 0; i < 64; ++i) wv[i] = w[(size_t)i * 512];
   float acc = 0.f;
-#pragma unroll 16
-  for (int i = 0; i < 64; ++i) acc = __fmaf_rn(xv[i], w[(size_t)i * 512], acc);
+#pragma unroll
+  for (int i = 0; i < 64; ++i) acc = __fmaf_rn(xv[i], wv[i], acc);
   part[ks][o] = acc;
   __syncthreads();
   if (ks == 0) {
@@ -1104,9 +1108,12 @@ __global__ __launch_bounds__(1024) void k_heads_l23(int b, const float *__restri
   __syncthreads();
   const int o = threadIdx.x & 127, ks = threadIdx.x >> 7;                  // 8 slices of 64 terms
   const float *w = hw.w2[head] + (size_t)(ks * 64) * 128 + o;
+  float wv[64];                                                            // (as in layer 1: one round of loads)
+#pragma unroll
+  for (int i = 0; i < 64; ++i) wv[i] = w[(size_t)i * 128];
   float acc = 0.f;
-#pragma unroll 16
-  for (int i = 0; i < 64; ++i) acc = __fmaf_rn(xs[ks * 64 + i], w[(size_t)i * 128], acc);
+#pragma unroll
+  for (int i = 0; i < 64; ++i) acc = __fmaf_rn(xs[ks * 64 + i], wv[i], acc);
   part[ks][o] = acc;
   __syncthreads();
   if (ks == 0)
@@ -1160,16 +1167,25 @@ __global__ __launch_bounds__(256) void k_mlp128_to1(int M, const float *__restri
   float *xs = Ws2 + 4 * 128 * kMlpWP;                  // [32 rows][130]
   float *red = xs + 32 * kMlpXP;                       // [4 waves][32 rows]
   const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
-  // both filters: wave w stages its 32 columns of each (16 float4 loads per lane and filter)
-#pragma unroll 4
-  for (int i = 0; i < 16; ++i) {
-    const int k = i * 8 + (lane >> 3), c4 = (lane & 7) * 4;
-    const float4 a = *reinterpret_cast<const float4 *>(W1t + (size_t)k * 128 + 32 * w + c4);
-    const float4 b = *reinterpret_cast<const float4 *>(W2t + (size_t)k * 128 + 32 * w + c4);
-    float *d1 = Ws1 + (w * 128 + k) * kMlpWP + c4, *d2 = Ws2 + (w * 128 + k) * kMlpWP + c4;
-    d1[0] = a.x; d1[1] = a.y; d1[2] = a.z; d1[3] = a.w;
-    d2[0] = b.x; d2[1] = b.y; d2[2] = b.z; d2[3] = b.w;
-  }
+  // the filters: wave w stages its 32 columns of each -- 16 float4 loads per lane and filter, all of a filter's in flight; the
+  // second filter's are asked for before the first tile's layer 1 and parked in LDS after it (a call of one crop is one tile
+  // per workgroup: the 64 KB would otherwise be a second exposed round trip)
+  float4 wreg[16];
+  auto ask = [&](const float *__restrict__ Wt) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) wreg[i] = *reinterpret_cast<const float4 *>(Wt + (size_t)(i * 8 + (lane >> 3)) * 128 + 32 * w + (lane & 7) * 4);
+  };
+  auto park = [&](float *Ws) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float *d = Ws + (w * 128 + i * 8 + (lane >> 3)) * kMlpWP + (lane & 7) * 4;
+      d[0] = wreg[i].x; d[1] = wreg[i].y; d[2] = wreg[i].z; d[3] = wreg[i].w;
+    }
+  };
+  ask(W1t);
+  park(Ws1);
+  ask(W2t);
+  bool w2_parked = false;
   const float bias1 = b1[32 * w + r], bias2 = b2[32 * w + r], w3c = w3[(size_t)(32 * w + r) * ldw3], bias3 = b3[0];
   const int ntiles = (M + 31) >> 5;
   for (int t = (int)blockIdx.x; t < ntiles; t += (int)gridDim.x) {
@@ -1196,6 +1212,7 @@ __global__ __launch_bounds__(256) void k_mlp128_to1(int M, const float *__restri
 #pragma unroll 16
       for (int k0 = 0; k0 < 128; k0 += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[k0], brow[k0 * kMlpWP], acc, 0, 0, 0);
     }
+    if (!w2_parked) { park(Ws2); w2_parked = true; }   // (wave w's own columns: read by wave w only, after the barriers below)
     dcl_lds_barrier();                                 // every wave has read the x tile: it becomes the hidden tile
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
