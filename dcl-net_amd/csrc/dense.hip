@@ -646,6 +646,102 @@ __global__ __launch_bounds__(256) void k_weighted_colsum(int c, int n1, int n2, 
   }
 }
 
+// Both kernels above in one launch for calls of a handful of crops (L = n1 + n2 <= 256 * EPT logits per crop): EVERY workgroup of
+// a crop forms the crop's softmax itself -- k_conf_softmax's operations in k_conf_softmax's order, values in registers, the
+// normalised weights into LDS -- and then runs k_weighted_colsum's loop on them; the workgroup (0, 0, crop) also writes conf and
+// wsum.  2048 logits are 16 transcendentals per thread: cheaper than a launch and its gap on a path that has nothing else to do.
+template <int EPT>
+__global__ __launch_bounds__(256) void k_conf_pool_small(int c, int n1, int n2, int nslices, const float *__restrict__ logit1,
+                                                         const float *__restrict__ logit2, float *__restrict__ conf,
+                                                         float *__restrict__ wsum, const float *__restrict__ F1, int ld1,
+                                                         float *__restrict__ part1, const float *__restrict__ F2, int ld2,
+                                                         float *__restrict__ part2) {
+  __shared__ float wl[256 * EPT];
+  __shared__ float redf[4], r1[4], r2[4];
+  __shared__ float4 red[4][64];
+  const int L = n1 + n2;
+  const int second = (int)blockIdx.y >= nslices ? 1 : 0;
+  const int b = blockIdx.z, slice = blockIdx.y - second * nslices;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool writer = blockIdx.x == 0 && blockIdx.y == 0;
+  float sv[EPT];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int j = tid + 256 * k;
+    if (j < L) {
+      const float x = j < n1 ? logit1[(size_t)b * n1 + j] : logit2[(size_t)b * n2 + (j - n1)];
+      sv[k] = 1.0f / (1.0f + expf(-x));
+      if (writer) conf[(size_t)b * L + j] = sv[k];
+      mx = fmaxf(mx, sv[k]);
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+  if (lane == 0) redf[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+  __syncthreads();
+  float sum = 0.0f;
+#pragma unroll
+  for (int k = 0; k < EPT; ++k)
+    if (tid + 256 * k < L) {
+      sv[k] = expf(sv[k] - mx);
+      sum += sv[k];
+    }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+  if (lane == 0) redf[wave] = sum;
+  __syncthreads();
+  sum = (redf[0] + redf[1]) + (redf[2] + redf[3]);
+  const float inv = 1.0f / sum;
+  float w1 = 0.f, w2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int j = tid + 256 * k;
+    if (j < L) {
+      const float v = sv[k] * inv;
+      wl[j] = v;
+      if (j < n1) w1 += v; else w2 += v;
+    }
+  }
+  if (writer) {                                        // (block-uniform)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { w1 += __shfl_xor(w1, d, 64); w2 += __shfl_xor(w2, d, 64); }
+    if (lane == 0) { r1[wave] = w1; r2[wave] = w2; }
+  }
+  __syncthreads();
+  if (writer && tid == 0) { wsum[b * 2] = (r1[0] + r1[1]) + (r1[2] + r1[3]); wsum[b * 2 + 1] = (r2[0] + r2[1]) + (r2[2] + r2[3]); }
+  // ---- k_weighted_colsum's body, the weights from LDS
+  const int n = second ? n2 : n1, ld = second ? ld2 : ld1, w_off = second ? n1 : 0;
+  const float *__restrict__ F = second ? F2 : F1;
+  float *__restrict__ part = second ? part2 : part1;
+  const int ch = blockIdx.x * 256 + lane * 4;
+  const int per = (n + nslices - 1) / nslices;
+  const int j0 = slice * per, j1 = min(n, j0 + per);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ch < c) {
+    const float *wp = wl + w_off;
+    const float *fp = F + (size_t)b * n * ld + ch;
+    for (int j = j0 + wave; j < j1; j += 4) {
+      const float wj = wp[j];
+      const float4 f = *reinterpret_cast<const float4 *>(fp + (size_t)j * ld);
+      acc.x = __fmaf_rn(f.x, wj, acc.x); acc.y = __fmaf_rn(f.y, wj, acc.y);
+      acc.z = __fmaf_rn(f.z, wj, acc.z); acc.w = __fmaf_rn(f.w, wj, acc.w);
+    }
+  }
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && ch < c) {
+    float4 o;
+    o.x = (red[0][lane].x + red[1][lane].x) + (red[2][lane].x + red[3][lane].x);
+    o.y = (red[0][lane].y + red[1][lane].y) + (red[2][lane].y + red[3][lane].y);
+    o.z = (red[0][lane].z + red[1][lane].z) + (red[2][lane].z + red[3][lane].z);
+    o.w = (red[0][lane].w + red[1][lane].w) + (red[2][lane].w + red[3][lane].w);
+    *reinterpret_cast<float4 *>(part + ((size_t)b * nslices + slice) * c + ch) = o;
+  }
+}
+
 // ---- ortho9d2matrix (models/DCL_Net.py:15-36) ------------------------------------------------------
 // R = U diag(1,1,det(U V^T)) V^T of the column-stacked, normalised raw vectors: one thread per crop,
 // one-sided Jacobi SVD in fp64 (the reference calls a batched LAPACK/MAGMA gesdd, ms-scale latency).
@@ -927,6 +1023,12 @@ DCL_API int dcl_conf_pool(int b, int c, int n1, int n2, const float *logit1, con
   DCL_CHECK_ARG(conf && w_scratch && part1 && part2 && wsum && logit1 && F1 && logit2 && F2 && b <= 65535 &&
                 nslices <= 32767);
   hipStream_t s = (hipStream_t)stream;
+  if (b <= 8 && n1 + n2 <= 256 * 8) {                  // a handful of crops of the shipped size: one launch (k_conf_pool_small)
+    hipLaunchKernelGGL(k_conf_pool_small<8>, dim3(dcl_div_up(c, 256), 2 * nslices, b), dim3(256), 0, s, c, n1, n2, nslices, logit1,
+                       logit2, conf, wsum, F1, ld1, part1, F2, ld2, part2);
+    DCL_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(k_conf_softmax, dim3(b), dim3(256), 0, s, n1, n2, logit1, logit2, conf, w_scratch, wsum);
   hipLaunchKernelGGL(k_weighted_colsum, dim3(dcl_div_up(c, 256), 2 * nslices, b), dim3(256), 0, s, c, n1, n2, nslices,
                      w_scratch, F1, ld1, part1, F2, ld2, part2);

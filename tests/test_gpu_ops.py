@@ -977,6 +977,22 @@ def test_conf_pool_matches_torch(dcl):
     assert float((pooled.cpu().double() - want2).abs().max()) <= 2e-5
 
 
+def test_conf_pool_of_a_handful_of_crops_in_one_launch_equals_the_two_launches(dcl):
+    """up to 8 crops of at most 2048 logits: dcl_conf_pool is ONE launch (every workgroup forms its crop's softmax itself);
+    the same crops inside a larger batch take the two launches: conf and the weight sums bit for bit, the pooled rows to
+    rounding (the slice count, hence the order of the partial sums, depends on the batch)"""
+    g = torch.Generator().manual_seed(4)
+    b, n1, n2, c = 12, 1024, 1024, 1024
+    l1, l2 = (torch.randn(b, n1, generator=g) * 3).cuda(), (torch.randn(b, n2, generator=g) * 3).cuda()
+    F1, F2 = torch.randn(b, n1, c, generator=g).cuda(), torch.randn(b, n2, c, generator=g).cuda()
+    big = dcl.ops.conf_pool(b, l1.reshape(-1), l2.reshape(-1), F1.reshape(-1, c), F2.reshape(-1, c))
+    k = 5
+    small = dcl.ops.conf_pool(k, l1[:k].reshape(-1), l2[:k].reshape(-1), F1[:k].reshape(-1, c), F2[:k].reshape(-1, c))
+    assert torch.equal(small[0], big[0][:k]) and torch.equal(small[3], big[3][:k])
+    for a, w in ((small[1], big[1][:k]), (small[2], big[2][:k])):
+        assert float((a - w).abs().max()) <= 1e-5 * max(1.0, float(w.abs().max()))
+
+
 def test_ortho9d_matches_torch_svd(dcl):
     g = torch.Generator().manual_seed(2)
     o9 = torch.randn(64, 9, generator=g)
