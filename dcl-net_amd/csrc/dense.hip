@@ -1284,27 +1284,30 @@ __global__ __launch_bounds__(256) void k_mlp128_to1(int M, const float *__restri
       d[0] = wreg[i].x; d[1] = wreg[i].y; d[2] = wreg[i].z; d[3] = wreg[i].w;
     }
   };
+  // a tile's x rows: thread = (row, 16 floats); the first tile's are asked for together with the first filter
+  const int ntiles = (M + 31) >> 5;
+  float4 xr[4];
+  auto ask_x = [&](int t) __attribute__((always_inline)) {
+    const int row = t * 32 + (tid >> 3);
+    const float *src = x + (size_t)row * ldx + (tid & 7) * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) xr[q] = row < M ? *reinterpret_cast<const float4 *>(src + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  if ((int)blockIdx.x < ntiles) ask_x((int)blockIdx.x);
   ask(W1t);
   park(Ws1);
   ask(W2t);
   bool w2_parked = false;
   const float bias1 = b1[32 * w + r], bias2 = b2[32 * w + r], w3c = w3[(size_t)(32 * w + r) * ldw3], bias3 = b3[0];
-  const int ntiles = (M + 31) >> 5;
   for (int t = (int)blockIdx.x; t < ntiles; t += (int)gridDim.x) {
     const int row0 = t * 32;
     dcl_lds_barrier();                                 // the previous tile's readers of xs / red are done
-    // x tile: 32 rows x 128 floats, thread = (row, 16 floats)
     {
-      const int row = tid >> 3, c0 = (tid & 7) * 16;
-      const float *src = x + (size_t)(row0 + row) * ldx + c0;
-      float *dst = xs + row * kMlpXP + c0;
-      const bool live = row0 + row < M;
+      float *dst = xs + (tid >> 3) * kMlpXP + (tid & 7) * 16;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 v = live ? *reinterpret_cast<const float4 *>(src + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-        dst[4 * q] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
-      }
+      for (int q = 0; q < 4; ++q) { dst[4 * q] = xr[q].x; dst[4 * q + 1] = xr[q].y; dst[4 * q + 2] = xr[q].z; dst[4 * q + 3] = xr[q].w; }
     }
+    if (t + (int)gridDim.x < ntiles) ask_x(t + (int)gridDim.x);     // the next tile's rows travel under this tile's layers
     __syncthreads();
     f32x16 acc;
 #pragma unroll
