@@ -837,6 +837,21 @@ DCL_API int dcl_cross_attention(int b, int nq, int nk, const float *Q, int ldq, 
                                 stream);
 }
 
+// crops of a PAIR of launches (the two directions side by side) that fill whole rounds of 8-wave workgroups: 256 workgroups per
+// round for the pair = 128 / ceil(nq / 256) crops of each direction (32 at nq = 1024); 0 = no such split for this call
+DCL_HOOK_INT(g_attn_pair_split, 1);  // (diagnostic library: dcl_debug_attention_pair_split; 0 = off)
+static int attn_pair_full_crops(int b, int nq, int dv1, int dv2, int concurrent_launches) {
+  if (!g_attn_pair_split || g_attn_variant != 0 || concurrent_launches != 2 || dv1 != 256 || dv2 != 64 || nq <= 0) return 0;
+  const int qb8 = dcl_div_up(nq, 256);
+  if (qb8 > 128 || 128 % qb8 != 0) return 0;
+  const int per_round = 128 / qb8;
+  const int full = b / per_round * per_round;
+  return full > 0 && full < b ? full : 0;
+}
+#ifdef DCL_DIAG
+DCL_API void dcl_debug_attention_pair_split(int on) { g_attn_pair_split = on; }
+#endif
+
 // Key split of a 4-wave attention launch (fewer than 256 eight-wave workgroups): see the launcher below for the model.
 static int attn_small_split(int b, int nq, int ntiles) {
   const int forced = g_attn_split;
@@ -870,7 +885,16 @@ DCL_API int dcl_cross_attention_scratch_floats(int b, int nq, int64_t *floats_ho
       if (cost <= best - 0.2 && c * per <= (128ll << 20)) { best = cost; z = c; }
     }
   }
-  *floats_host = z > 1 ? z * per : 0;
+  long long need = z > 1 ? z * per : 0;
+  // a pair call that is split into whole rounds + a rest (dcl_cross_attention_ws2): the rest is a call of its own size
+  const int full = attn_pair_full_crops(b, nq, 256, 64, 2);
+  if (full) {
+    int64_t rest = 0;
+    const int rc = dcl_cross_attention_scratch_floats(b - full, nq, &rest);
+    if (rc) return rc;
+    if (rest > need) need = rest;
+  }
+  *floats_host = need;
   return 0;
 }
 
@@ -882,11 +906,35 @@ DCL_API int dcl_cross_attention_ws(int b, int nq, int nk, const float *Q, int ld
                                  scratch_floats, 1, stream);
 }
 
+static int attn_dispatch(int b, int nq, int nk, const float *Q, int ldq, const float *K, int ldk, const float *V1, int dv1, int ldv1,
+                         float *O1, int ldo1, const float *V2, int dv2, int ldv2, float *O2, int ldo2, float *scratch,
+                         int64_t scratch_floats, int concurrent_launches, dclStream_t stream);
+
 DCL_API int dcl_cross_attention_ws2(int b, int nq, int nk, const float *Q, int ldq, const float *K, int ldk,
                                     const float *V1, int dv1, int ldv1, float *O1, int ldo1, const float *V2, int dv2,
                                     int ldv2, float *O2, int ldo2, float *scratch, int64_t scratch_floats,
                                     int concurrent_launches, dclStream_t stream) {
   DCL_CHECK_ARG(concurrent_launches == 1 || concurrent_launches == 2);
+  // A pair of launches whose 8-wave workgroups make one or more WHOLE rounds of the chip plus a rest (40 crops of 1024 x 1024: 1.25
+  // rounds): the whole rounds go as they are (8-wave, two waves per SIMD), the rest as the call of that many crops that it is
+  // (4-wave workgroups, keys split) -- a quarter-filled last round costs a whole one.  Same results per crop.
+  const int full = (b > 0 && Q && K && V1 && O1) ? attn_pair_full_crops(b, nq, dv1, dv2, concurrent_launches) : 0;
+  if (full) {
+    int rc = attn_dispatch(full, nq, nk, Q, ldq, K, ldk, V1, dv1, ldv1, O1, ldo1, V2, dv2, ldv2, O2, ldo2, scratch, scratch_floats,
+                           concurrent_launches, stream);
+    if (rc) return rc;
+    const size_t qo = (size_t)full * nq, ko = (size_t)full * nk;
+    return attn_dispatch(b - full, nq, nk, Q + qo * ldq, ldq, K + ko * ldk, ldk, V1 + ko * ldv1, dv1, ldv1, O1 + qo * ldo1, ldo1,
+                         V2 ? V2 + ko * ldv2 : nullptr, dv2, ldv2, O2 ? O2 + qo * ldo2 : nullptr, ldo2, scratch, scratch_floats,
+                         concurrent_launches, stream);
+  }
+  return attn_dispatch(b, nq, nk, Q, ldq, K, ldk, V1, dv1, ldv1, O1, ldo1, V2, dv2, ldv2, O2, ldo2, scratch, scratch_floats,
+                       concurrent_launches, stream);
+}
+
+static int attn_dispatch(int b, int nq, int nk, const float *Q, int ldq, const float *K, int ldk, const float *V1, int dv1, int ldv1,
+                         float *O1, int ldo1, const float *V2, int dv2, int ldv2, float *O2, int ldo2, float *scratch,
+                         int64_t scratch_floats, int concurrent_launches, dclStream_t stream) {
   DCL_CHECK_ARG(b >= 0 && nq >= 0 && nk > 0 && dv1 > 0 && dv1 % 32 == 0 && dv2 >= 0 && dv2 % 32 == 0);
   if (b == 0 || nq == 0) return 0;
   DCL_CHECK_ARG(Q && K && V1 && O1 && (dv2 == 0 || (V2 && O2)) && b <= 65535);

@@ -104,17 +104,27 @@ int get_plan(const PlanKey &key, hipblasLtHandle_t g_handle, Plan **out) {
   LT_CHECK(hipblasLtMatmulPreferenceCreate(&pref));
   const uint64_t max_ws = (uint64_t)key.ws;
   LT_CHECK(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &max_ws, sizeof(max_ws)));
-  hipblasLtMatmulHeuristicResult_t res[1];
+  // The library's fp32 kernels on gfx950 are stream-K hybrids: when a problem's tiles do not divide into whole rounds of the
+  // chip (33 crops of 1024 points: M = 33792) the heuristic's first choice hands the leftover tiles around between workgroups
+  // through the workspace, SPINNING on flags -- which needs all of its workgroups resident at once.  The forward runs GEMMs of
+  // its two branches side by side on two streams: two such kernels each holding part of the chip wait for workgroups the
+  // other one keeps out -- the GPU hangs (seen at 33 crops, whole-forward graph and launch by launch alike).  An algorithm
+  // that asks for NO workspace cannot exchange anything: take the first of those (the heuristic's own order otherwise).
+  constexpr int kCand = 64;
+  hipblasLtMatmulHeuristicResult_t res[kCand];
   int found = 0;
-  hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(g_handle, p.desc, p.w, p.x, p.y, p.y, pref, 1, res, &found);
+  hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(g_handle, p.desc, p.w, p.x, p.y, p.y, pref, kCand, res, &found);
   hipblasLtMatmulPreferenceDestroy(pref);
   if (st != HIPBLAS_STATUS_SUCCESS || found < 1) {
     dcl_set_error("dcl_linear_fwd: no hipBLASLt algorithm for M=%lld N=%lld K=%lld (status %d)", (long long)key.M,
                   (long long)key.N, (long long)key.K, (int)st);
     return DCL_EINVAL;
   }
-  p.algo = res[0].algo;
-  p.ws = res[0].workspaceSize;
+  int pick = 0;
+  for (int i = 0; i < found; ++i)
+    if (res[i].workspaceSize == 0) { pick = i; break; }
+  p.algo = res[pick].algo;
+  p.ws = res[pick].workspaceSize;
   auto ins = g_plans.emplace(key, p);
   *out = &ins.first->second;
   return 0;
@@ -151,6 +161,18 @@ DCL_API int dcl_linear_fwd(const float *x, int64_t ldx, const float *Wt, int64_t
 }
 
 #ifdef DCL_DIAG
+// Diagnostic: bytes of workspace the algorithm dcl_linear_fwd would take for (M, N, K) asks for (32 MiB offered): > 0 means the
+// library's stream-K kernel will exchange partial tiles between workgroups through it.
+DCL_API long long dcl_debug_linear_plan_workspace(int M, int N, int K) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) return -1;
+  hipblasLtHandle_t h = nullptr;
+  if (get_handle(device, &h)) return -1;
+  Plan *p = nullptr;
+  if (get_plan(PlanKey{M, N, K, K, N, N, (int)HIPBLASLT_EPILOGUE_RELU_BIAS, 32ll << 20, device}, h, &p)) return -1;
+  return (long long)p->ws;
+}
 // Diagnostic: the library's first `ncand` heuristic candidates for y[M x N] = relu(x[M x K] Wt[K x N] + bias) (dense pitches),
 // each timed on the current device (3 warm-up runs, then 10 runs between events): ms_out[i] = mean milliseconds of candidate
 // i (candidate 0 is the one dcl_linear_fwd takes), *found_out = how many there were.  tools/gemm_candidates.py.

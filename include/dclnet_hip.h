@@ -586,6 +586,10 @@ void dcl_debug_conv_wlds(int on);
 /* Diagnostic: times the GEMM library's first ncand heuristic candidates for an (M, N, K) linear layer; ms_out[0] is the one
  * dcl_linear_fwd takes. */
 int dcl_debug_linear_candidates(int M, int N, int K, int ncand, float *ms_out, int *found_out);
+long long dcl_debug_linear_plan_workspace(int M, int N, int K);   /* bytes of workspace the chosen GEMM algorithm asks for */
+/* Tuning hook: 1 (default) = a pair of attention launches (dcl_cross_attention_ws2, concurrent = 2) that makes whole rounds of
+ * 8-wave workgroups plus a rest is issued as two launches (rounds, rest); 0 = one launch. */
+void dcl_debug_attention_pair_split(int on);
 void dcl_debug_geometry_small_batch(int n);
 int dcl_debug_geometry_small_stamps(unsigned long long *host32);   /* s_memrealtime (100 MHz) at the phase boundaries of workgroup 0 of the last k_geometry_small (0..9), after each mask-chain stage (16..23) */
 /* Diagnostic: a one-thread launch that writes the 100 MHz wall clock into *slot_dev (a time stamp inside a stream or a

@@ -197,6 +197,16 @@ def test_bs40_config_forward(dcl, oracle, path):
     batch_of_reference_shape_crops_vs_oracle(dcl, oracle, 40, path)
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("path", ["launch by launch", "default"])
+def test_forward_of_a_batch_that_does_not_tile_the_chip(dcl, oracle, path):
+    """33 crops of N = M = 1024: M = 33792 rows do not divide into whole rounds of GEMM tiles over 256 CUs -- the shape at
+    which the GEMM library's first-choice algorithms exchange partial tiles between workgroups and two of them, side by side on
+    the forward's two streams, hung the GPU (csrc/linear.cpp: get_plan).  Same checks as the other batch sizes; also the batch
+    at which the attention pair is issued as 32 + 1 crops."""
+    batch_of_reference_shape_crops_vs_oracle(dcl, oracle, 33, path)
+
+
 def batch_of_reference_shape_crops_vs_oracle(dcl, oracle, b, path):
     """b crops of N = M = 1024: four of them against the oracle graph, all of them the size-independent checks (also run at
     b = 32, the shape of profiles/*_ref_kernel_stats.csv, by tests/test_kernel_census.py)"""

@@ -893,6 +893,42 @@ def test_cross_attention_dma_variant_ragged_and_rescale(request, dcl):
         lib.dcl_debug_attention_variant(0)
 
 
+def test_library_gemms_never_take_a_workspace_exchanging_algorithm(request, dcl):
+    """dcl_linear_fwd must not pick a GEMM algorithm that asks for workspace: the library's stream-K kernels hand leftover tiles
+    around between workgroups through it, spinning on flags, and two of them side by side on the forward's two streams hang the
+    GPU (seen at 33 crops of 1024 points, where M = 33792 does not tile into whole rounds of the chip)"""
+    import ctypes
+    lib = enter_diag(dcl, request)
+    lib.dcl_debug_linear_plan_workspace.restype = ctypes.c_longlong
+    torch.zeros(1, device="cuda")
+    for b in (1, 6, 32, 33, 35, 37, 40, 41, 47):
+        for K, n in ((480, 1024), (256, 256), (256, 64), (512, 512), (512, 1024), (1024, 512), (512, 128)):
+            assert lib.dcl_debug_linear_plan_workspace(b * 1024, n, K) == 0, (b, K, n)
+
+
+@pytest.mark.timeout(300)
+def test_attention_pair_of_whole_rounds_plus_rest_matches_the_lone_launch(dcl):
+    """dcl_cross_attention_ws2(concurrent = 2) issues 40 crops of 1024 x 1024 as 32 (one round of 8-wave workgroups with the
+    other direction) + 8 (4-wave, keys split): same attention per crop as the lone launch, to the rounding of the key split"""
+    g = torch.Generator().manual_seed(40)
+    b, nq, nk = 40, 1024, 1024
+    Q, K = torch.randn((b * nq, 64), generator=g).cuda(), torch.randn((b * nk, 64), generator=g).cuda()
+    V1, V2 = torch.randn((b * nk, 256), generator=g).cuda(), torch.randn((b * nk, 64), generator=g).cuda()
+    outs = []
+    for conc in (1, 2):
+        O1, O2 = torch.full((b * nq, 256), float("nan"), device="cuda"), torch.full((b * nq, 64), float("nan"), device="cuda")
+        dcl.ops.cross_attention(b, Q, K, V1, O1, V2, O2, concurrent=conc)
+        outs.append((O1, O2))
+    for a, c in zip(outs[0], outs[1]):
+        assert bool(torch.isfinite(c).all()) and float((a - c).abs().max()) <= 2e-5
+    # one crop against the float64 definition (Aligner.forward + the extra bmm, models/Modules.py:162-169)
+    i = 37
+    S = (K[i * nk:(i + 1) * nk].double() @ Q[i * nq:(i + 1) * nq].double().t())
+    A = torch.softmax(S, dim=0)
+    want = A.t() @ V1[i * nk:(i + 1) * nk].double()
+    assert float((outs[1][0][i * nq:(i + 1) * nq].double() - want).abs().max()) <= 5e-5
+
+
 @pytest.mark.parametrize("b", [1, 6, 20])
 def test_voxelisation_riding_on_the_geometry_launch_is_bit_identical(dcl, b):
     """BackboneRunCap.geometry(voxelize=...) -- PG_OP.voxelize_fp carried by the one-launch geometry stage (up to 16 crops), a
