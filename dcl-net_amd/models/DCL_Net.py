@@ -439,6 +439,9 @@ class Network(nn.Module):
     _DIS_TAGS = (("p1", 256), ("m1", 64), ("p2", 256), ("m2", 64))
     POSE_HEADS_MAX = 128      # crops up to which the two pose heads run as dcl_pose_heads (two launches) instead of six library
                               # GEMMs + glue (same-job A/B: 8 crops -3.4 %, 12: -2.8 %, 16: -2 %, 32: -0.9 %, 40: -1.2 % of the forward)
+    CONF_MLP_ROWS = 1 << 30   # point rows up to which the confidence regressor runs as one launch (ops.mlp128_to1; same-job A/B
+                              # against the three library GEMMs, graph replay: 12 crops 1.654 vs 1.663 ms, 16: 2.135 vs 2.142,
+                              # 24: 3.195 vs 3.205, 32: 3.774 vs 3.785, 40: 4.816 vs 4.816 -- never slower, so no bound)
     POSE_PARTS_MAX = 8        # crops up to which the pooling's finish is folded into the heads' first launch (a launch less)
     PAR_TAIL = None           # None = by shape (_tail_parallel); True / False force the dense tail's two directions onto two
                               # streams / one (A/B runs)
@@ -518,7 +521,9 @@ class Network(nn.Module):
             F = fuse
             for Wt, bias in fuser_layers:
                 F = self._lin_relu(F, Wt, bias)
-            return ops.mlp128_to1(conf_in, conf_layers), F              # (three K = 128 layers in one launch)
+            if conf_in.shape[0] <= self.CONF_MLP_ROWS:
+                return ops.mlp128_to1(conf_in, conf_layers), F          # (three K = 128 layers in one launch)
+            return self._mlp(conf_in, conf_layers), F
         with second:
             ops.cross_attention(b, act["Yom2"], act["Xcm2"], act["Xcp2"], fuse2[:, :256], act["Xcm2"], conf_in2[:, :64], concurrent=par)
             logit2, Fp2 = conf_and_fuser(conf_in2, fuse2, f["regressor_conf_bi"], l2)
