@@ -234,8 +234,12 @@ class Network(nn.Module):
     # ------------------------------------------------------------------ fused pipeline
     @staticmethod
     def _lin_relu(x, Wt, bias):
-        # (the same layers through dcl_linear_fwd -- our own call of the same library -- replay in the same time: 4.018 vs 4.017 ms)
-        return torch._addmm_activation(bias, x, Wt)          # relu(x @ Wt + bias), one GEMM with epilogue
+        # relu(x @ Wt + bias), one library GEMM with epilogue -- through dcl_linear_fwd, NOT torch._addmm_activation (same library,
+        # same time: 4.018 vs 4.017 ms): the forward runs these layers of its two branches side by side, and torch takes the
+        # library's first-choice algorithm -- for row counts that do not tile the chip evenly (25, 33, ... crops of 1024 points) a
+        # stream-K kernel that spins on flags in the workspace; two of those at once hang the GPU.  csrc/linear.cpp only takes
+        # algorithms that ask for no workspace.
+        return ops.linear(x, Wt, bias, True)
 
     def _mlp(self, x, layers):
         x = self._lin_relu(x, *layers[0])

@@ -198,13 +198,14 @@ def test_bs40_config_forward(dcl, oracle, path):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("path", ["launch by launch", "default"])
-def test_forward_of_a_batch_that_does_not_tile_the_chip(dcl, oracle, path):
+@pytest.mark.parametrize("b,path", [(33, "launch by launch"), (33, "default"), (25, "default")])
+def test_forward_of_a_batch_that_does_not_tile_the_chip(dcl, oracle, b, path):
     """33 crops of N = M = 1024: M = 33792 rows do not divide into whole rounds of GEMM tiles over 256 CUs -- the shape at
     which the GEMM library's first-choice algorithms exchange partial tiles between workgroups and two of them, side by side on
-    the forward's two streams, hung the GPU (csrc/linear.cpp: get_plan).  Same checks as the other batch sizes; also the batch
-    at which the attention pair is issued as 32 + 1 crops."""
-    batch_of_reference_shape_crops_vs_oracle(dcl, oracle, 33, path)
+    the forward's two streams, hung the GPU (csrc/linear.cpp: get_plan; 25 crops: the same through torch's own call of the
+    library, which the forward no longer makes -- models/DCL_Net.py: _lin_relu).  Same checks as the other batch sizes; 33 is
+    also the batch at which the attention pair is issued as 32 + 1 crops.  tools/batch_sweep.py walks 1..48."""
+    batch_of_reference_shape_crops_vs_oracle(dcl, oracle, b, path)
 
 
 def batch_of_reference_shape_crops_vs_oracle(dcl, oracle, b, path):
@@ -226,7 +227,7 @@ def batch_of_reference_shape_crops_vs_oracle(dcl, oracle, b, path):
     for k in ("rot_pred", "trans_pred", "conf"):
         assert torch.equal(p1[k], p2[k]), k
     assert len(net.__dict__.get("_graphs", {})) == (1 if path == "default" else 0)      # the path that was meant ran
-    for i in (0, 13, 27, b - 1):
+    for i in sorted({0, min(13, b - 1), min(27, b - 1), b - 1}):
         one = dcl.synth.make_batch(1, n, n, first=100 + i, voxelize_idx=lambda c, bs, mode: tuple(
             torch.from_numpy(a) for a in oracle.voxelize_idx(c.numpy(), bs, mode)))
         want = G.forward(sd, dict(cfg), one, mode="test")
