@@ -94,8 +94,10 @@ class Refiner(nn.Module):
         # first shared layer: the K = 3 product + the constant term + ReLU in one pass (ops.affine3_relu; a library GEMM and a
         # ReLU sweep before: 49 -> ~27 us per iteration at 32 768 rows)
         h = ops.affine3_relu(xyz_pm.contiguous(), f["share0_xyz"], feat_term)
-        h = torch._addmm_activation(f["MLP_share"][1][1], h, f["MLP_share"][1][0])
-        h = torch._addmm_activation(f["MLP_share"][2][1], h, f["MLP_share"][2][0])          # (b*n, 1024)
+        # (library GEMMs through dcl_linear_fwd, which never takes a workspace-exchanging algorithm -- a refiner that a caller
+        #  overlaps with another forward's GEMMs must not be able to hang the GPU; see models/DCL_Net.py: _lin_relu)
+        h = ops.linear(h, f["MLP_share"][1][0], f["MLP_share"][1][1], True)
+        h = ops.linear(h, f["MLP_share"][2][0], f["MLP_share"][2][1], True)                  # (b*n, 1024)
         shared = torch.bmm(conf_w.unsqueeze(1), h.view(b, n, -1)).squeeze(1)                 # (b, 1024)
         # both pose heads (1024 -> 512 -> 128 -> 9 | 3) and the rotation in two launches (ops.pose_heads, as in stage 1) instead of
         # six library GEMMs of 5-14 us each on 32 rows + the ortho kernel; larger batches keep the library
@@ -104,9 +106,9 @@ class Refiner(nn.Module):
             return dt, dR
 
         def head(x, layers):
-            x = torch._addmm_activation(layers[0][1], x, layers[0][0])
-            x = torch._addmm_activation(layers[1][1], x, layers[1][0])
-            return torch.addmm(layers[2][1], x, layers[2][0])
+            x = ops.linear(x, layers[0][0], layers[0][1], True)
+            x = ops.linear(x, layers[1][0], layers[1][1], True)
+            return ops.linear(x, layers[2][0], layers[2][1], False)
         o9 = head(shared, f["regressor_rot2"])
         return head(shared, f["regressor_trans2"]), ops.ortho9d_to_matrix(o9)
 
