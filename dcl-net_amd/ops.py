@@ -890,6 +890,58 @@ def linear(x, Wt, bias=None, relu=False, out=None):
     return out
 
 
+def linear_dma_ok(x, Wt):
+    """can linear_dma take this layer?  (K in whole 32-chunks, 16-byte aligned operands and pitches: csrc/linear_dma.hip)"""
+    K, n = Wt.shape
+    pw = int(Wt.stride(0)) if K > 1 else n
+    px = int(x.stride(0)) if x.shape[0] > 1 else K
+    return (K >= 32 and K % 32 == 0 and px % 4 == 0 and pw % 4 == 0 and x.data_ptr() % 16 == 0 and Wt.data_ptr() % 16 == 0 and
+            pw >= (n + 3) // 4 * 4)
+
+
+def linear_dma(x, Wt, bias=None, relu=False, out=None):
+    """linear() on the library's OWN fp32 MFMA GEMM core (csrc/linear_dma.hip; no vendor library): act(x @ Wt + bias), same
+    conventions -- x (M,K), Wt (K,N), out (M,N) row-major with free row pitches."""
+    N.need_cuda(x, Wt)
+    assert x.dim() == 2 and Wt.dim() == 2 and x.shape[1] == Wt.shape[0] and x.dtype == Wt.dtype == torch.float32
+    M, K = x.shape
+    n = Wt.shape[1]
+    if out is None:
+        out = torch.empty((M, n), dtype=torch.float32, device=x.device)
+    assert out.shape == (M, n) and out.dtype == torch.float32 and out.is_cuda
+    for t in (x, Wt, out):
+        assert t.stride(1) == 1 or t.shape[1] == 1, "rows must be dense"
+    if bias is not None:
+        assert bias.is_cuda and bias.dtype == torch.float32 and bias.numel() == n and bias.is_contiguous()
+    pitch = lambda t: int(t.stride(0)) if t.shape[0] > 1 else max(int(t.stride(0)), int(t.shape[1]))   # noqa: E731
+    N.check(N.lib().dcl_linear_dma_fwd(N.ptr(x), C.c_int64(pitch(x)), N.ptr(Wt), C.c_int64(pitch(Wt)), N.ptr(bias), N.ptr(out),
+                                       C.c_int64(pitch(out)), int(M), int(n), int(K), int(bool(relu)), N.stream()), "linear_dma_fwd")
+    return out
+
+
+LINEAR_POOL_TILE = 128         # rows per partial of linear_pool (the GEMM's row tile)
+
+
+def linear_pool(x, Wt, bias, roww, relu=True, part=None):
+    """The last fuser layer with the confidence-weighted pooling as its epilogue (csrc/linear_dma.hip, EPI = 1):
+    part[t] = sum over rows j of row tile t (128 rows) of roww[j] * act(x[j] @ Wt + bias) -- (ceil(M/128), N); the (M, N)
+    activation is never stored.  With every crop a whole number of tiles, a crop's pooled feature is the sum of its tiles'
+    partials (pool_finish_tiles adds them in tile order)."""
+    N.need_cuda(x, Wt, roww)
+    M, K = x.shape
+    n = Wt.shape[1]
+    assert roww.is_contiguous() and roww.numel() == M and roww.dtype == torch.float32
+    tiles = (M + LINEAR_POOL_TILE - 1) // LINEAR_POOL_TILE
+    if part is None:
+        part = torch.empty((tiles, n), dtype=torch.float32, device=x.device)
+    assert part.shape == (tiles, n) and part.stride(1) == 1
+    pitch = lambda t: int(t.stride(0)) if t.shape[0] > 1 else max(int(t.stride(0)), int(t.shape[1]))   # noqa: E731
+    N.check(N.lib().dcl_linear_pool_fwd(N.ptr(x), C.c_int64(pitch(x)), N.ptr(Wt), C.c_int64(pitch(Wt)), N.ptr(bias), N.ptr(roww),
+                                        N.ptr(part), C.c_int64(pitch(part)), int(M), int(n), int(K), int(bool(relu)), N.stream()),
+            "linear_pool_fwd")
+    return part
+
+
 class _LinearJob(C.Structure):
     _fields_ = [("x", C.c_void_p), ("ldx", C.c_int64), ("Wt", C.c_void_p), ("ldw", C.c_int64), ("bias", C.c_void_p),
                 ("y", C.c_void_p), ("ldy", C.c_int64), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("relu", C.c_int32)]

@@ -425,9 +425,24 @@ int dcl_pose_heads_parts(int b, int nslices, const float *part1, const float *pa
  * the reference runs them as cuDNN pointwise convolutions): y[M x N] = act(x[M x K] Wt[K x N] + bias[N]), row-major, every
  * matrix with its own row pitch (ldx >= K, ldw >= N, ldy >= N floats) so that x, Wt and y can be column blocks of wider
  * buffers.  A library GEMM (hipBLASLt, fp32, bias / ReLU epilogue); bias may be NULL, relu 0/1.  workspace: device scratch
- * the library may use (0 bytes allowed; it then picks an algorithm that needs none) -- not shared between streams.      */
+ * the caller may pass (kept for ABI stability) -- NEVER used: only algorithms that ask for no workspace are taken, and the call
+ * fails with DCL_EINVAL when the library has none for the shape (two workspace-exchanging stream-K kernels side by side on
+ * two streams hang the GPU; csrc/linear.cpp).                                                                            */
 int dcl_linear_fwd(const float *x, int64_t ldx, const float *Wt, int64_t ldw, const float *bias, float *y, int64_t ldy,
                    int M, int N, int K, int relu, void *workspace, int64_t workspace_bytes, dclStream_t stream);
+
+/* The same layer on the library's OWN fp32 MFMA GEMM core (csrc/linear_dma.hip: 128 x 128 / 128 x 64 / 64 x 64 tiles, LDS-DMA
+ * operand rings, v_mfma_f32_32x32x2_f32; no vendor library, no workspace).  Same argument meaning as dcl_linear_fwd; needs
+ * K % 32 == 0, 16-byte aligned x / Wt and ldx % 4 == ldw % 4 == 0, a row of Wt holding N rounded up to 4 floats (DCL_EINVAL
+ * otherwise: such layers stay on dcl_linear_fwd).  Per output element the sum is ONE fmaf chain over k.                  */
+int dcl_linear_dma_fwd(const float *x, int64_t ldx, const float *Wt, int64_t ldw, const float *bias, float *y, int64_t ldy,
+                       int M, int N, int K, int relu, dclStream_t stream);
+/* The last fuser layer WITH the confidence-weighted pooling of models/DCL_Net.py:223-228 as its epilogue: instead of storing
+ * F = act(x Wt + bias) (M x N) it leaves  part[t][c] = sum over the rows j of row tile t (128 rows) of roww[j] * F[j][c]  for
+ * t = 0 .. ceil(M / 128) - 1 (row pitch ldp >= N): with every crop a whole number of tiles, dcl_pool_finish adds a crop's
+ * partials in tile order.  roww: M floats (the softmax weights of the rows).  Same shape constraints as dcl_linear_dma_fwd. */
+int dcl_linear_pool_fwd(const float *x, int64_t ldx, const float *Wt, int64_t ldw, const float *bias, const float *roww,
+                        float *part, int64_t ldp, int M, int N, int K, int relu, dclStream_t stream);
 
 /* Several INDEPENDENT per-point linear layers in one launch (csrc/linear_group.hip), for calls of a handful of crops: the
  * reference issues every Conv1d(k=1) / 1x1x1 Conv3d of its MLP stacks as its own launch (models/Modules.py:58-97,173-201; the
@@ -581,15 +596,24 @@ void dcl_debug_conv_few_chunks(int n);
 void dcl_debug_conv_few_tiles(int on);
 /* Tuning hook: 1 (default) = the Cin 16 / 32 -> 32 conv layers of many rows run the filter-resident kernel, 0 = LDS-DMA kernel. */
 void dcl_debug_conv_wlds(int on);
-/* Tuning hook: most crops of a pass whose geometry stage runs as one launch (k_geometry_small; default 16, at most 64;
- * passes of more than 8 crops also need at most 32768 voxel rows). */
-/* Diagnostic: times the GEMM library's first ncand heuristic candidates for an (M, N, K) linear layer; ms_out[0] is the one
- * dcl_linear_fwd takes. */
-int dcl_debug_linear_candidates(int M, int N, int K, int ncand, float *ms_out, int *found_out);
-long long dcl_debug_linear_plan_workspace(int M, int N, int K);   /* bytes of workspace the chosen GEMM algorithm asks for */
+/* Tuning hooks of the own GEMM core: tile shape (0 = automatic, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 64x128), XCD-aware
+ * workgroup renumbering (default 1). */
+void dcl_debug_linear_tile(int t);
+void dcl_debug_linear_xcd_remap(int on);
+void dcl_debug_linear_stagger(int n);   /* workgroups in odd wave slots start n x 8128 cycles late (0 = off) */
+/* Diagnostic: times the GEMM library's first ncand heuristic candidates (32 MiB of workspace on offer) for an (M, N, K)
+ * linear layer, each alone on the GPU; ms_out[i] = mean ms, ws_out[i] (may be NULL) = the workspace candidate i asks for.
+ * dcl_linear_fwd itself only ever takes an algorithm that asks for none (it queries with a maximum of 0 bytes and refuses
+ * the call when nothing is left), so candidates with ws_out[i] > 0 are the ones it can never run. */
+int dcl_debug_linear_candidates(int M, int N, int K, int ncand, float *ms_out, long long *ws_out, int *found_out);
+/* Diagnostic: bytes of workspace the algorithm dcl_linear_fwd takes for (M, N, K) asks for: 0, or -1 = the library has no
+ * zero-workspace algorithm for the shape (dcl_linear_fwd returns DCL_EINVAL then -- never a workspace-exchanging kernel). */
+long long dcl_debug_linear_plan_workspace(int M, int N, int K);
 /* Tuning hook: 1 (default) = a pair of attention launches (dcl_cross_attention_ws2, concurrent = 2) that makes whole rounds of
  * 8-wave workgroups plus a rest is issued as two launches (rounds, rest); 0 = one launch. */
 void dcl_debug_attention_pair_split(int on);
+/* Tuning hook: most crops of a pass whose geometry stage runs as one launch (k_geometry_small; default 16, at most 64;
+ * passes of more than 8 crops also need at most 32768 voxel rows). */
 void dcl_debug_geometry_small_batch(int n);
 int dcl_debug_geometry_small_stamps(unsigned long long *host32);   /* s_memrealtime (100 MHz) at the phase boundaries of workgroup 0 of the last k_geometry_small (0..9), after each mask-chain stage (16..23) */
 /* Diagnostic: a one-thread launch that writes the 100 MHz wall clock into *slot_dev (a time stamp inside a stream or a
