@@ -561,51 +561,65 @@ __global__ void k_cross_attn_combine(int rows, int nsplit, const float *__restri
 // Two kernels: (1) one block per crop: sigmoid, max, exp, sum -> w (b,L) + conf + wsum;
 // (2) HBM-streaming weighted column sums: block = 256 channels (float4 per lane, 1 KiB per wave per point row)
 // x one slice of the point axis; slice partials are combined in a fixed order by the caller (deterministic).
-__global__ __launch_bounds__(256) void k_conf_softmax(int n1, int n2, const float *__restrict__ logit1,
-                                                      const float *__restrict__ logit2, float *__restrict__ conf,
-                                                      float *__restrict__ w, float *__restrict__ wsum) {
-  __shared__ float red[4];
+// NT threads per crop: 256 in dcl_conf_pool (the one-launch kernel below repeats that order bit for bit), 1024 in dcl_conf_softmax
+// (the forward whose last fuser layer pools: the softmax sits on its critical path, and 14336 logits per crop are 56 strided
+// passes of a 256-thread workgroup)
+template <int NT>
+__device__ __forceinline__ float conf_block_reduce(float v, float *red, int lane, int wave, bool is_max) {
+  constexpr int NW = NT / 64;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = is_max ? fmaxf(v, __shfl_xor(v, d, 64)) : v + __shfl_xor(v, d, 64);
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float r;
+  if (NW == 4) {
+    r = is_max ? fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) : (red[0] + red[1]) + (red[2] + red[3]);
+  } else {
+    float t[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) t[i] = red[i];
+#pragma unroll
+    for (int step = 1; step < NW; step <<= 1)
+#pragma unroll
+      for (int i = 0; i + step < NW; i += 2 * step) t[i] = is_max ? fmaxf(t[i], t[i + step]) : t[i] + t[i + step];
+    r = t[0];
+  }
+  __syncthreads();
+  return r;
+}
+template <int NT>
+__global__ __launch_bounds__(NT) void k_conf_softmax(int n1, int n2, const float *__restrict__ logit1,
+                                                     const float *__restrict__ logit2, float *__restrict__ conf,
+                                                     float *__restrict__ w, float *__restrict__ wsum) {
+  __shared__ float red[NT / 64];
   const int L = n1 + n2;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   float mx = -INFINITY;
-  for (int j = tid; j < L; j += 256) {
+  for (int j = tid; j < L; j += NT) {
     const float x = j < n1 ? logit1[(size_t)b * n1 + j] : logit2[(size_t)b * n2 + (j - n1)];
     const float s = 1.0f / (1.0f + expf(-x));
     conf[(size_t)b * L + j] = s;
     mx = fmaxf(mx, s);
   }
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
-  if (lane == 0) red[wave] = mx;
-  __syncthreads();
-  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  __syncthreads();
+  mx = conf_block_reduce<NT>(mx, red, lane, wave, true);
   float sum = 0.0f;
-  for (int j = tid; j < L; j += 256) {
+  for (int j = tid; j < L; j += NT) {
     const float e = expf(conf[(size_t)b * L + j] - mx);      // own writes: same thread wrote conf[j]
     w[(size_t)b * L + j] = e;
     sum += e;
   }
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
-  if (lane == 0) red[wave] = sum;
-  __syncthreads();
-  sum = (red[0] + red[1]) + (red[2] + red[3]);
-  __syncthreads();
+  sum = conf_block_reduce<NT>(sum, red, lane, wave, false);
   const float inv = 1.0f / sum;
   float w1 = 0.f, w2 = 0.f;
-  for (int j = tid; j < L; j += 256) {
+  for (int j = tid; j < L; j += NT) {
     const float v = w[(size_t)b * L + j] * inv;
     w[(size_t)b * L + j] = v;
     if (j < n1) w1 += v; else w2 += v;
   }
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) { w1 += __shfl_xor(w1, d, 64); w2 += __shfl_xor(w2, d, 64); }
-  __shared__ float r1[4], r2[4];
-  if (lane == 0) { r1[wave] = w1; r2[wave] = w2; }
-  __syncthreads();
-  if (tid == 0) { wsum[b * 2] = (r1[0] + r1[1]) + (r1[2] + r1[3]); wsum[b * 2 + 1] = (r2[0] + r2[1]) + (r2[2] + r2[3]); }
+  w1 = conf_block_reduce<NT>(w1, red, lane, wave, false);
+  w2 = conf_block_reduce<NT>(w2, red, lane, wave, false);
+  if (tid == 0) { wsum[b * 2] = w1; wsum[b * 2 + 1] = w2; }
 }
 
 // part[b][slice][c] = sum over this slice's points of w[j] * F[j][c]
@@ -1077,7 +1091,7 @@ DCL_API int dcl_conf_pool(int b, int c, int n1, int n2, const float *logit1, con
     DCL_LAUNCH_CHECK();
     return 0;
   }
-  hipLaunchKernelGGL(k_conf_softmax, dim3(b), dim3(256), 0, s, n1, n2, logit1, logit2, conf, w_scratch, wsum);
+  hipLaunchKernelGGL(k_conf_softmax<256>, dim3(b), dim3(256), 0, s, n1, n2, logit1, logit2, conf, w_scratch, wsum);
   hipLaunchKernelGGL(k_weighted_colsum, dim3(dcl_div_up(c, 256), 2 * nslices, b), dim3(256), 0, s, c, n1, n2, nslices,
                      w_scratch, F1, ld1, part1, F2, ld2, part2);
   DCL_LAUNCH_CHECK();
@@ -1086,39 +1100,57 @@ DCL_API int dcl_conf_pool(int b, int c, int n1, int n2, const float *logit1, con
 
 // out[b][ch] = ((sA*P1 + tA*w0) + sB*P2) + tB*w1 with P = slice partials added in a fixed order: the pooled feature of
 // both directions behind the fusers' trailing BatchNorms (sum_i w_i (s x_i + t) = s sum w x + t sum w), one launch
-__global__ void k_pool_finish(int c, int nslices, const float *__restrict__ part1, const float *__restrict__ part2,
+__global__ void k_pool_finish(int c, int nslices1, int nslices2, const float *__restrict__ part1, const float *__restrict__ part2,
                               const float *__restrict__ wsum, const float *__restrict__ sA, const float *__restrict__ tA,
                               const float *__restrict__ sB, const float *__restrict__ tB, float *__restrict__ out) {
   const int b = blockIdx.y, ch = blockIdx.x * blockDim.x + threadIdx.x;
   if (ch >= c) return;
   // slice s goes to accumulator s % 4 (four independent load chains), the four are combined in a fixed order
   float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
-  const float *q1 = part1 + (size_t)b * nslices * c + ch, *q2 = part2 + (size_t)b * nslices * c + ch;
+  const float *q1 = part1 + (size_t)b * nslices1 * c + ch, *q2 = part2 + (size_t)b * nslices2 * c + ch;
   int s = 0;
-  for (; s + 4 <= nslices; s += 4) {
+  for (; s + 4 <= nslices1; s += 4) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      a1[j] += q1[(size_t)(s + j) * c];
-      a2[j] += q2[(size_t)(s + j) * c];
-    }
+    for (int j = 0; j < 4; ++j) a1[j] += q1[(size_t)(s + j) * c];
   }
-  for (int j = 0; s < nslices; ++s, ++j) {
-    a1[j] += q1[(size_t)s * c];
-    a2[j] += q2[(size_t)s * c];
+  for (int j = 0; s < nslices1; ++s, ++j) a1[j] += q1[(size_t)s * c];
+  for (s = 0; s + 4 <= nslices2; s += 4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a2[j] += q2[(size_t)(s + j) * c];
   }
+  for (int j = 0; s < nslices2; ++s, ++j) a2[j] += q2[(size_t)s * c];
   const float p1 = (a1[0] + a1[1]) + (a1[2] + a1[3]), p2 = (a2[0] + a2[1]) + (a2[2] + a2[3]);
   const float w0 = wsum[2 * b], w1 = wsum[2 * b + 1];
   out[(size_t)b * c + ch] = ((sA[ch] * p1 + tA[ch] * w0) + sB[ch] * p2) + tB[ch] * w1;
 }
 
+DCL_API int dcl_pool_finish2(int b, int c, int nslices1, int nslices2, const float *part1, const float *part2, const float *wsum,
+                             const float *scale1, const float *shift1, const float *scale2, const float *shift2,
+                             float *out, dclStream_t stream) {
+  DCL_CHECK_ARG(b >= 0 && c > 0 && nslices1 >= 1 && nslices2 >= 1);
+  if (b == 0) return 0;
+  DCL_CHECK_ARG(part1 && part2 && wsum && scale1 && shift1 && scale2 && shift2 && out && b <= 65535);
+  hipLaunchKernelGGL(k_pool_finish, dim3(dcl_div_up(c, 256), b), dim3(256), 0, (hipStream_t)stream, c, nslices1, nslices2, part1,
+                     part2, wsum, scale1, shift1, scale2, shift2, out);
+  DCL_LAUNCH_CHECK();
+  return 0;
+}
 DCL_API int dcl_pool_finish(int b, int c, int nslices, const float *part1, const float *part2, const float *wsum,
                             const float *scale1, const float *shift1, const float *scale2, const float *shift2,
                             float *out, dclStream_t stream) {
-  DCL_CHECK_ARG(b >= 0 && c > 0 && nslices >= 1);
+  return dcl_pool_finish2(b, c, nslices, nslices, part1, part2, wsum, scale1, shift1, scale2, shift2, out, stream);
+}
+
+// the softmax half of dcl_conf_pool on its own (k_conf_softmax): conf (b, n1 + n2) = sigmoid(logits), w (b, n1 + n2) = softmax of
+// conf over a crop's n1 + n2 points, wsum (b, 2) = the two directions' weight sums -- for the forward whose last fuser layer
+// carries the pooling as its epilogue (dcl_linear_pool_fwd) and needs the weights BEFORE that layer
+DCL_API int dcl_conf_softmax(int b, int n1, int n2, const float *logit1, const float *logit2, float *conf, float *w, float *wsum,
+                             dclStream_t stream) {
+  DCL_CHECK_ARG(b >= 0 && n1 > 0 && n2 > 0);
   if (b == 0) return 0;
-  DCL_CHECK_ARG(part1 && part2 && wsum && scale1 && shift1 && scale2 && shift2 && out && b <= 65535);
-  hipLaunchKernelGGL(k_pool_finish, dim3(dcl_div_up(c, 256), b), dim3(256), 0, (hipStream_t)stream, c, nslices, part1,
-                     part2, wsum, scale1, shift1, scale2, shift2, out);
+  DCL_CHECK_ARG(logit1 && logit2 && conf && w && wsum && b <= 65535);
+  if (n1 + n2 > 4096) hipLaunchKernelGGL(k_conf_softmax<1024>, dim3(b), dim3(1024), 0, (hipStream_t)stream, n1, n2, logit1, logit2, conf, w, wsum);
+  else hipLaunchKernelGGL(k_conf_softmax<256>, dim3(b), dim3(256), 0, (hipStream_t)stream, n1, n2, logit1, logit2, conf, w, wsum);
   DCL_LAUNCH_CHECK();
   return 0;
 }

@@ -29,51 +29,30 @@ typedef float ld_f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void ld_lds_void_t;
 
 constexpr int kLdKC = 32;                                            // k per chunk
-__device__ __attribute__((aligned(256))) float g_ld_zero[1024];      // the zero line (static storage: all zero); 4 KiB so that
-                                                                     // the pre-decremented piece pointers below stay inside it
 
 __device__ __forceinline__ unsigned ld_lds_addr(const float *p) {
   return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(ld_lds_void_t *)p);
 }
-// N pieces of one LDS-DMA group: 64 lanes x 16 B each from per-lane global addresses to LDS at (wave-uniform) base + piece *
-// 1 KiB + lane * 16, all under ONE M0 value.  The instruction's offset field moves the global address too, so source pointer
-// i arrives pre-decremented by i KiB.  Inline asm on purpose (cdna guide 5.7; dense.hip: glds16): issued through the builtin
-// hipcc drains the DMA before the next ds_read of the array; an asm load is not in the compiler's counters, the kernel
-// waits for it itself.
-__device__ __forceinline__ void ld_glds16_x4(const float *g0, const float *g1, const float *g2, const float *g3, unsigned lds_byte_addr) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
-               "global_load_lds_dwordx4 %1, off\n\t"
-               "global_load_lds_dwordx4 %2, off offset:1024\n\t"
-               "global_load_lds_dwordx4 %3, off offset:2048\n\t"
-               "global_load_lds_dwordx4 %4, off offset:3072\n\t"
-               "s_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(g0), "v"(g1), "v"(g2), "v"(g3), "s"(lds_byte_addr) : "memory");
-}
-// one piece: per-lane 32-bit byte offset + wave-uniform 64-bit base (SGPR pair)
+// One LDS-DMA piece: 64 lanes x 16 B from (wave-uniform 64-bit base in an SGPR pair) + (per-lane 32-bit byte offset) to LDS at
+// (wave-uniform) lds_byte_addr + lane * 16.  Inline asm on purpose (cdna guide 5.7; dense.hip: glds16): issued through the
+// builtin hipcc drains the DMA before the next ds_read of the array; an asm load is not in the compiler's counters, the
+// kernel waits for it itself.  M0 is saved / restored inside the statement.
 __device__ __forceinline__ void ld_glds16_s(unsigned voff, const float *sbase, unsigned lds_byte_addr) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
 }
-__device__ __forceinline__ void ld_glds16_x2(const float *g0, const float *g1, unsigned lds_byte_addr) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-               "global_load_lds_dwordx4 %1, off\n\t"
-               "global_load_lds_dwordx4 %2, off offset:1024\n\t"
-               "s_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(g0), "v"(g1), "s"(lds_byte_addr) : "memory");
-}
-
 struct LinDmaArgs {
   const float *x, *Wt, *bias;
   float *y;
   long long ldx, ldw, ldy;
   int M, N, K, relu;
-  const float *roww;     // EPI 1: weight of every row of x (M floats)
+  const float *roww;     // EPI 1: row j (crop j / rows_per_crop, point j % rows_per_crop) weighs roww[crop * w_stride + point]
+  int rows_per_crop;
+  long long w_stride;
   float *part;           // EPI 1: [row tiles][ldp] partial weighted column sums
   long long ldp;
-  int xcd_remap, stagger;
+  int xcd_remap;
 };
 
 __device__ __forceinline__ int ld_rowmap(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
@@ -89,62 +68,76 @@ __global__ __launch_bounds__(256, 2) void k_linear_dma(const LinDmaArgs a) {
   static_assert(BPW == 2 || BPW == 4, "Wt pieces per wave");
   constexpr int BLPR = BN / 4;                           // lanes per k-row of the Wt tile
   constexpr int BKPP = 64 / BLPR;                        // k-rows per Wt piece
-  extern __shared__ __attribute__((aligned(16))) float ld_lds[];    // 2 stages x [A BM x 32 | B 32 x BN]
+  extern __shared__ __attribute__((aligned(16))) float ld_lds[];    // 2 stages x [A BM x 32 | B 32 x BN] (+ EPI 1: weights, sums)
 
-  const int ntn = (a.N + BN - 1) / BN;
-  // XCD-aware renumbering (speed only): workgroup ids are dealt round-robin over the 8 XCDs; give each XCD a contiguous range
-  // of tiles in (row block, column block) order
-  int tile;
+  // ---- which tiles: the workgroup is PERSISTENT (2 per CU resident: gridDim = 512, fewer for small problems) and walks its
+  // tiles in a loop, so that the first chunk of tile t + 1 is fetched under the last chunk of tile t and a tile costs no
+  // dispatch, no address set-up round trip and no exposed first fetch.  Workgroup ids are dealt round-robin over the 8 XCDs:
+  // XCD x owns a contiguous range of tiles in (row block, column block) order and its workgroups (slot = id / 8) walk it
+  // with stride gridDim / 8 -- the workgroups that share an L2 work on neighbouring tiles of the same row blocks.
+  const int ntn = (a.N + BN - 1) / BN, ntm = (a.M + BM - 1) / BM, tiles = ntm * ntn;
+  int t_lo, t_hi, t_stride;                                // this workgroup's tiles: t_lo, t_lo + t_stride, ... < t_hi
   {
-    const int nwg = gridDim.x, id = blockIdx.x;
-    const int xq = nwg >> 3, xr = nwg & 7, xcd = id & 7;
-    tile = !a.xcd_remap ? id : (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (id >> 3);
+    const int id = blockIdx.x, nwg = gridDim.x;
+    if (a.xcd_remap && (nwg & 7) == 0) {
+      const int xq = tiles >> 3, xr = tiles & 7, xcd = id & 7;
+      const int x_lo = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
+      t_lo = x_lo + (id >> 3);
+      t_hi = x_lo + xq + (xcd < xr ? 1 : 0);
+      t_stride = nwg >> 3;
+    } else {
+      t_lo = id; t_hi = tiles; t_stride = nwg;
+    }
   }
-  const int tm = tile / ntn, tn = tile - tm * ntn;
-  const int row0 = tm * BM, col0 = tn * BN;
+  if (t_lo >= t_hi) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int wr = wave / WGC, wc = wave - wr * WGC;
-
-  // ---- this wave's DMA pieces: x pieces APW*wave .. (8 rows of 128 B each), Wt pieces BPW*wave .. (BKPP k-rows each).  A piece's
-  // source = a wave-uniform base (SGPR pair, advanced per chunk by scalar adds) + a per-lane byte offset that never changes
-  // (one VGPR per piece).  Rows >= M / columns >= N are fetched from the last valid row / column group instead of a zero
-  // line: they only feed accumulators that are never stored (EPI 1: that get weight 0).
-  unsigned aoff[APW], boff[BPW];
-#pragma unroll
-  for (int i = 0; i < APW; ++i) {
-    const int arow = (APW * wave + i) * 8 + (lane >> 3);                        // tile row
-    const int achs = ((lane & 7) ^ ((arow >> 1) & 7)) << 2;                     // source column inside the chunk (swizzle)
-    const int srow = min(row0 + arow, a.M - 1) - row0;
-    aoff[i] = (unsigned)(((long long)srow * a.ldx + achs) * 4);
-  }
-  const int n4 = (a.N + 3) & ~3;
-#pragma unroll
-  for (int i = 0; i < BPW; ++i) {
-    const int bkk = (BPW * wave + i) * BKPP + lane / BLPR;                      // k-row inside the chunk
-    const int bcol = min(col0 + ((lane % BLPR) << 2), n4 - 4) - col0;           // (a row of Wt holds N rounded up to 4 floats)
-    boff[i] = (unsigned)(((long long)bkk * a.ldw + bcol) * 4);
-  }
-  const float *abase = a.x + (size_t)row0 * a.ldx;         // chunk 0 of the tile's rows / columns (wave-uniform)
-  const float *bbase = a.Wt + col0;
+  const int nchunks = a.K / kLdKC;
   const long long bchunk = (long long)kLdKC * a.ldw;
   const unsigned lds0 = ld_lds_addr(ld_lds);
+  const int n4 = (a.N + 3) & ~3;
 
-  ld_f32x16 acc[MB][NB];
+  // ---- the producer: which chunk of which tile is fetched next.  A wave's DMA pieces per chunk: x pieces APW*wave .. (8 rows of
+  // 128 B each), Wt pieces BPW*wave .. (BKPP k-rows each); a piece's source = a wave-uniform base (SGPR pair, advanced per chunk
+  // by scalar adds) + a per-lane byte offset that only changes with the tile (one VGPR per piece).  Rows >= M / columns >= N are
+  // fetched from the last valid row / column group instead of a zero line: they only feed accumulators that are never stored
+  // (EPI 1: that get weight 0).
+  unsigned aoff[APW], boff[BPW];
+  const float *abase, *bbase;
+  int p_tile = t_lo, p_chunk = 0;
+  auto producer_tile = [&]() {                             // offsets and bases of tile p_tile, chunk 0
+    const int ptm = p_tile / ntn, ptn = p_tile - ptm * ntn;
+    const int prow0 = ptm * BM, pcol0 = ptn * BN;
 #pragma unroll
-  for (int m = 0; m < MB; ++m)
+    for (int i = 0; i < APW; ++i) {
+      const int arow = (APW * wave + i) * 8 + (lane >> 3);                      // tile row
+      const int achs = ((lane & 7) ^ ((arow >> 1) & 7)) << 2;                   // source column inside the chunk (swizzle)
+      const int srow = min(prow0 + arow, a.M - 1) - prow0;
+      aoff[i] = (unsigned)(((long long)srow * a.ldx + achs) * 4);
+    }
 #pragma unroll
-    for (int n = 0; n < NB; ++n)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.0f;
+    for (int i = 0; i < BPW; ++i) {
+      const int bkk = (BPW * wave + i) * BKPP + lane / BLPR;                    // k-row inside the chunk
+      const int bcol = min(pcol0 + ((lane % BLPR) << 2), n4 - 4) - pcol0;       // (a row of Wt holds N rounded up to 4 floats)
+      boff[i] = (unsigned)(((long long)bkk * a.ldw + bcol) * 4);
+    }
+    abase = a.x + (size_t)prow0 * a.ldx;
+    bbase = a.Wt + pcol0;
+  };
+  auto producer_advance = [&]() {                          // behind the last piece of a chunk
+    if (++p_chunk < nchunks) {
+      abase += kLdKC;
+      bbase += bchunk;
+    } else {
+      p_chunk = 0;
+      p_tile += t_stride;
+      if (p_tile < t_hi) producer_tile();
+    }
+  };
+  auto issue_a = [&](int i, int stage) { ld_glds16_s(aoff[i], abase, lds0 + (unsigned)((stage * ST + (APW * wave + i) * 256) * 4)); };
+  auto issue_b = [&](int i, int stage) { ld_glds16_s(boff[i], bbase, lds0 + (unsigned)((stage * ST + AT + (BPW * wave + i) * 256) * 4)); };
 
-  if (a.stagger > 0) {                                     // (diagnostic) the workgroup in the odd wave slots starts late
-    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | 4);             // HW_REG_HW_ID[3:0]: wave slot on the SIMD
-    if (slot & 1)
-      for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-  }
-
-  const int nchunks = a.K / kLdKC;
   const int sw = (r >> 1) & 7;
   const float *arow0 = ld_lds + (wr * WM + r) * kLdKC;
   const float *bcol0 = ld_lds + AT + wc * WN + r + 4 * h * BN;
@@ -160,6 +153,7 @@ __global__ __launch_bounds__(256, 2) void k_linear_dma(const LinDmaArgs a) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) f.b[n][q] = bcol[(8 * i + q) * BN + n * 32];
   };
+  ld_f32x16 acc[MB][NB];
   auto mfma_group = [&](const Frag &f, int q) {
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
@@ -168,121 +162,157 @@ __global__ __launch_bounds__(256, 2) void k_linear_dma(const LinDmaArgs a) {
       for (int n = 0; n < NB; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, f.b[n][q], acc[m][n], 0, 0, 0);
     }
   };
-  auto issue_a = [&](int i, int stage) { ld_glds16_s(aoff[i], abase, lds0 + (unsigned)((stage * ST + (APW * wave + i) * 256) * 4)); };
-  auto issue_b = [&](int i, int stage) { ld_glds16_s(boff[i], bbase, lds0 + (unsigned)((stage * ST + AT + (BPW * wave + i) * 256) * 4)); };
+
+  producer_tile();
 #pragma unroll
   for (int i = 0; i < BPW; ++i) issue_b(i, 0);
 #pragma unroll
   for (int i = 0; i < APW; ++i) issue_a(i, 0);
-  for (int c = 0; c < nchunks; ++c) {
-    const int st = c & 1;
-    const bool more = c + 1 < nchunks;
-    abase += kLdKC;                                        // -> chunk c + 1
-    bbase += bchunk;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of chunk c have landed
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                          // everyone's have; nobody reads chunk c - 1's stage any more ...
-    // ... which chunk c + 1 lands in, under this chunk's MFMAs.  One instruction stream that keeps the matrix pipe fed by
-    // itself: the chunk is 4 k steps x 4 groups of MB x NB MFMAs; behind every group goes ONE piece of other work -- a slice of
-    // the NEXT step's fragment reads, or one DMA piece of the next chunk (steps 0 and 1: they need the rest of the chunk to
-    // land) -- so that nothing but the first fragment of a chunk is ever waited for.  The scheduler is pinned group by group
-    // (left alone it reads each step's operands right before using them and issues the DMAs back to back).
-    Frag f[2];
-    load_a(f[0], st, 0);
-#pragma unroll
-    for (int n = 0; n < NB; ++n) load_b(f[0], st, 0, n);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        mfma_group(f[i & 1], q);
-        if (i < 3) {
-          if (q == 0) load_a(f[(i + 1) & 1], st, i + 1);
-          else if (q - 1 < NB) load_b(f[(i + 1) & 1], st, i + 1, q - 1);
-        }
-        if (more && i == 0 && q < BPW) issue_b(q, st ^ 1);
-        if (more && i == 1 && q < APW) issue_a(q, st ^ 1);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  }
-  asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");        // MFMA -> VALU read of the accumulators
-
-  if constexpr (EPI == 0) {
-    float *__restrict__ y = a.y;
-    const bool whole = row0 + BM <= a.M && col0 + BN <= a.N;       // (workgroup-uniform) interior tile: no per-element checks
-    float bias[NB];
-#pragma unroll
-    for (int n = 0; n < NB; ++n) {
-      const int co = col0 + wc * WN + n * 32 + r;
-      bias[n] = (a.bias && co < a.N) ? a.bias[co] : 0.0f;
-    }
-    if (whole) {
-#pragma unroll
-      for (int m = 0; m < MB; ++m)
-#pragma unroll
-        for (int n = 0; n < NB; ++n) {
-          float *yp = y + (size_t)(row0 + wr * WM + m * 32 + 4 * h) * a.ldy + (col0 + wc * WN + n * 32 + r);
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            float v = acc[m][n][e] + bias[n];
-            if (a.relu) v = fmaxf(v, 0.0f);
-            yp[(size_t)((e & 3) + 8 * (e >> 2)) * a.ldy] = v;
-          }
-        }
-    } else {
-#pragma unroll
-      for (int m = 0; m < MB; ++m)
-#pragma unroll
-        for (int n = 0; n < NB; ++n) {
-          const int co = col0 + wc * WN + n * 32 + r;
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int orow = row0 + wr * WM + m * 32 + ld_rowmap(e, h);
-            float v = acc[m][n][e] + bias[n];
-            if (a.relu) v = fmaxf(v, 0.0f);
-            if (orow < a.M && co < a.N) y[(size_t)orow * a.ldy + co] = v;
-          }
-        }
-    }
-  } else {
-    // weighted column sums of the tile's rows: per wave over its WM rows (registers, then the two lane halves), then the WGR
-    // waves of a column through LDS in wave order -- a fixed order, the same bits every run
-    float wrow[MB][16];
+  producer_advance();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's pieces of the first chunk have landed
+  int cc = 0;                                              // chunks consumed so far: chunk cc sits in stage cc & 1
+  for (int tile = t_lo; tile < t_hi; tile += t_stride) {
+    const int tm = tile / ntn, tn = tile - tm * ntn;
+    const int row0 = tm * BM, col0 = tn * BN;
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int orow = row0 + wr * WM + m * 32 + ld_rowmap(e, h);
-        wrow[m][e] = orow < a.M ? a.roww[orow] : 0.0f;
+      for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.0f;
+    if constexpr (EPI == 1) {                              // the tile's row weights -> LDS behind the ring (read by the epilogue;
+      if (tid < BM) {                                      //  the previous tile's epilogue ended with a barrier)
+        const int row = row0 + tid, crop = row / a.rows_per_crop;
+        ld_lds[2 * ST + tid] = row < a.M ? a.roww[(size_t)crop * a.w_stride + (row - crop * a.rows_per_crop)] : 0.0f;
       }
-    __syncthreads();                                       // (all waves are past their last LDS reads: reuse it)
-    float *red = ld_lds;                                   // [WGR][BN]
-#pragma unroll
-    for (int n = 0; n < NB; ++n) {
-      const int cl = wc * WN + n * 32 + r, co = col0 + cl;
-      const float bias = (a.bias && co < a.N) ? a.bias[co] : 0.0f;
-      float s = 0.0f;
-#pragma unroll
-      for (int m = 0; m < MB; ++m)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          float v = acc[m][n][e] + bias;
-          if (a.relu) v = fmaxf(v, 0.0f);
-          s = __fmaf_rn(v, wrow[m][e], s);
-        }
-      s += __shfl_xor(s, 32, 64);
-      if (h == 0) red[wr * BN + cl] = s;
     }
-    __syncthreads();
-    if (tid < BN && col0 + tid < a.N) {
-      float s = red[tid];
+    for (int c = 0; c < nchunks; ++c, ++cc) {
+      const int st = cc & 1;
+      const bool more = p_tile < t_hi;                     // the producer still has a chunk to fetch (this tile's next, or the
+                                                           // NEXT tile's first: it lands under this tile's last chunk + epilogue)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (every wave has waited for its own pieces of this chunk: end of the
+      __builtin_amdgcn_s_barrier();                        //  previous one) everyone's are in; nobody reads the other stage any more ...
+      // ... which the producer's chunk lands in, under this chunk's MFMAs.  One instruction stream that keeps the matrix pipe
+      // fed by itself: the chunk is 4 k steps x 4 groups of MB x NB MFMAs; behind every group goes ONE piece of other work -- a
+      // slice of the NEXT step's fragment reads, or one DMA piece (steps 0 and 1: they need the rest of the chunk to land) --
+      // so that nothing but the first fragment of a chunk is ever waited for.  The scheduler is pinned group by group (left
+      // alone it reads each step's operands right before using them and issues the DMAs back to back).
+      Frag f[2];
+      load_a(f[0], st, 0);
 #pragma unroll
-      for (int w = 1; w < WGR; ++w) s += red[w * BN + tid];
-      a.part[(size_t)tm * a.ldp + col0 + tid] = s;
+      for (int n = 0; n < NB; ++n) load_b(f[0], st, 0, n);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          mfma_group(f[i & 1], q);
+          if (i < 3) {
+            if (q == 0) load_a(f[(i + 1) & 1], st, i + 1);
+            else if (q - 1 < NB) load_b(f[(i + 1) & 1], st, i + 1, q - 1);
+          }
+          if (more && i == 0 && q < BPW) issue_b(q, st ^ 1);
+          if (more && i == 1 && q < APW) issue_a(q, st ^ 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (more) producer_advance();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of the next chunk have landed (and, once per tile,
+                                                           // the previous tile's stores: long done)
+    }
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");      // MFMA -> VALU read of the accumulators
+
+    if constexpr (EPI == 0) {
+      float *__restrict__ y = a.y;
+      const bool whole = row0 + BM <= a.M && col0 + BN <= a.N;     // (workgroup-uniform) interior tile: no per-element checks
+      float bias[NB];
+#pragma unroll
+      for (int n = 0; n < NB; ++n) {
+        const int co = col0 + wc * WN + n * 32 + r;
+        bias[n] = (a.bias && co < a.N) ? a.bias[co] : 0.0f;
+      }
+      if (whole) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+          for (int n = 0; n < NB; ++n) {
+            float *yp = y + (size_t)(row0 + wr * WM + m * 32 + 4 * h) * a.ldy + (col0 + wc * WN + n * 32 + r);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              float v = acc[m][n][e] + bias[n];
+              if (a.relu) v = fmaxf(v, 0.0f);
+              yp[(size_t)((e & 3) + 8 * (e >> 2)) * a.ldy] = v;
+            }
+          }
+      } else {
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+          for (int n = 0; n < NB; ++n) {
+            const int co = col0 + wc * WN + n * 32 + r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int orow = row0 + wr * WM + m * 32 + ld_rowmap(e, h);
+              float v = acc[m][n][e] + bias[n];
+              if (a.relu) v = fmaxf(v, 0.0f);
+              if (orow < a.M && co < a.N) y[(size_t)orow * a.ldy + co] = v;
+            }
+          }
+      }
+    } else {
+      // weighted column sums of the tile's rows: per wave over its WM rows (registers, then the two lane halves), then the WGR
+      // waves of a column through LDS in wave order -- a fixed order, the same bits every run.  (The tile's row weights sit
+      // in LDS behind the ring since the tile's first barrier; the sums go behind them: the ring itself may be receiving the
+      // next tile's first chunk.)
+      const float *wl = ld_lds + 2 * ST + wr * WM + 4 * h;
+      float *red = ld_lds + 2 * ST + BM;                   // [WGR][BN]
+#pragma unroll
+      for (int n = 0; n < NB; ++n) {
+        const int cl = wc * WN + n * 32 + r, co = col0 + cl;
+        const float bias = (a.bias && co < a.N) ? a.bias[co] : 0.0f;
+        float s = 0.0f;
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 w4 = *reinterpret_cast<const float4 *>(wl + m * 32 + 8 * g4);    // rows 8 g4 + 4 h + 0..3 = e 4 g4 .. + 3
+            const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float v = acc[m][n][4 * g4 + j] + bias;
+              if (a.relu) v = fmaxf(v, 0.0f);
+              s = __fmaf_rn(v, wv[j], s);
+            }
+          }
+        s += __shfl_xor(s, 32, 64);
+        if (h == 0) red[wr * BN + cl] = s;
+      }
+      dcl_lds_barrier();
+      if (tid < BN && col0 + tid < a.N) {
+        float s = red[tid];
+#pragma unroll
+        for (int w = 1; w < WGR; ++w) s += red[w * BN + tid];
+        a.part[(size_t)tm * a.ldp + col0 + tid] = s;
+      }
+      dcl_lds_barrier();                                   // (the next tile rewrites the weights / sums)
     }
   }
+}
+
+DCL_HOOK_INT(g_lin_tile, 0);          // diagnostic: 0 = automatic tile shape, 1 = 128x128, 2 = 128x64, 3 = 64x64
+DCL_HOOK_INT(g_lin_xcd, 1);
+DCL_HOOK_INT(g_lin_persist, 4);       // rounds of resident workgroups from which a launch is persistent (a huge value: never)
+
+int lin_cu_count() {                    // CUs of the current device (cached per device)
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (!cus[dev]) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus[dev] = n;
+  }
+  return cus[dev];
 }
 
 template <int BM, int BN, int WGR, int EPI>
@@ -292,26 +322,29 @@ int launch_linear_dma(const LinDmaArgs &a, hipStream_t stream) {
     dcl_set_error("dcl_linear_fwd: too many tiles");
     return DCL_EINVAL;
   }
-  constexpr size_t lds = (size_t)2 * (BM + BN) * kLdKC * sizeof(float);
+  // persistent workgroups: as many per CU as its 160 KiB of LDS admit (2 of the 128 x 128 tile's 64 KiB rings, 3 at 48 KiB, 4 at
+  // 32 KiB: small tiles are what launches of few rows take, and those want the extra waves), a multiple of 8 (XCD tile ranges)
+  constexpr size_t lds = (size_t)2 * (BM + BN) * kLdKC * sizeof(float) + (EPI == 1 ? (BM + WGR * BN) * sizeof(float) : 0);
+  constexpr int per_cu = (160 * 1024) / (int)lds > 4 ? 4 : (160 * 1024) / (int)lds;
+  // ... while a launch of fewer than four rounds of them is one workgroup per tile: the dispatcher balances what a fixed
+  // tile -> workgroup assignment would leave to the slowest workgroup (1.5 rounds = 2 tiles for some, 1 for the others)
+  const long long slots = (long long)per_cu * lin_cu_count();
+  const unsigned grid = (unsigned)(tiles >= (long long)g_lin_persist * slots ? slots : tiles);
   static bool attr_set = false;                            // (idempotent; a race sets it twice)
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void *)k_linear_dma<BM, BN, WGR, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_linear_dma<BM, BN, WGR, EPI>), dim3((unsigned)tiles), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((k_linear_dma<BM, BN, WGR, EPI>), dim3(grid), dim3(256), lds, stream, a);
   return 0;
 }
-
-DCL_HOOK_INT(g_lin_tile, 0);          // diagnostic: 0 = automatic tile shape, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 64x128
-DCL_HOOK_INT(g_lin_xcd, 1);
-DCL_HOOK_INT(g_lin_stagger, 0);
 
 }  // namespace
 
 #ifdef DCL_DIAG
 DCL_API void dcl_debug_linear_tile(int t) { g_lin_tile = t; }
 DCL_API void dcl_debug_linear_xcd_remap(int on) { g_lin_xcd = on; }
-DCL_API void dcl_debug_linear_stagger(int n) { g_lin_stagger = n; }
+DCL_API void dcl_debug_linear_persist(int rounds) { g_lin_persist = rounds; }
 #endif
 
 // can this layer run on the own core?  (16-byte DMA pieces: aligned bases and pitches; K in whole chunks)
@@ -320,13 +353,24 @@ static bool lin_dma_ok(const float *x, int64_t ldx, const float *Wt, int64_t ldw
          ldw >= (N + 3) / 4 * 4;
 }
 
+// Tile shape by a cost model: a CU works its tiles off at a fixed MFMA rate however many workgroups share it, so a launch
+// lasts  ceil(tiles / CUs) * BM * BN / eff  (eff: smaller wave tiles re-read more operands per MFMA).  1 = 128 x 128,
+// 2 = 128 x 64, 3 = 64 x 64.
 static int lin_pick_tile(int M, int N) {
   const int forced = (int)g_lin_tile;
-  if (forced) return forced;
-  if (N <= 64) return M >= 128 * 512 ? 2 : 3;                     // 128x64 while that still fills the 512 slots, else 64x64
-  const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128);
-  if (t128 >= 384) return 1;
-  return (N % 128) > 64 || (N % 128) == 0 ? 3 : 3;
+  if (forced >= 1 && forced <= 3) return forced;
+  const int cus = lin_cu_count();
+  static const int bm[3] = {128, 128, 64}, bn[3] = {128, 64, 64};
+  static const double eff[3] = {1.0, 0.96, 0.93};
+  int best = 3;
+  double best_cost = 0.0;
+  for (int i = 0; i < 3; ++i) {
+    if (N <= 64 && bn[i] > 64) continue;
+    const long long t = (long long)((M + bm[i] - 1) / bm[i]) * ((N + bn[i] - 1) / bn[i]);
+    const double cost = (double)((t + cus - 1) / cus) * bm[i] * bn[i] / eff[i];
+    if (best_cost == 0.0 || cost < best_cost) { best = i + 1; best_cost = cost; }
+  }
+  return best;
 }
 
 DCL_API int dcl_linear_dma_fwd(const float *x, int64_t ldx, const float *Wt, int64_t ldw, const float *bias, float *y, int64_t ldy,
@@ -334,12 +378,11 @@ DCL_API int dcl_linear_dma_fwd(const float *x, int64_t ldx, const float *Wt, int
   DCL_CHECK_ARG(M >= 0 && N > 0 && K > 0 && x && Wt && y && ldx >= K && ldw >= N && ldy >= N);
   DCL_CHECK_ARG(lin_dma_ok(x, ldx, Wt, ldw, N, K));
   if (M == 0) return 0;
-  LinDmaArgs a{x, Wt, bias, y, ldx, ldw, ldy, M, N, K, relu, nullptr, nullptr, 0, (int)g_lin_xcd, (int)g_lin_stagger};
+  LinDmaArgs a{x, Wt, bias, y, ldx, ldw, ldy, M, N, K, relu, nullptr, 1, 0, nullptr, 0, (int)g_lin_xcd};
   int rc;
   switch (lin_pick_tile(M, N)) {
     case 1: rc = launch_linear_dma<128, 128, 2, 0>(a, (hipStream_t)stream); break;
     case 2: rc = launch_linear_dma<128, 64, 2, 0>(a, (hipStream_t)stream); break;
-    case 4: rc = launch_linear_dma<64, 128, 2, 0>(a, (hipStream_t)stream); break;
     default: rc = launch_linear_dma<64, 64, 2, 0>(a, (hipStream_t)stream); break;
   }
   if (rc) return rc;
@@ -348,10 +391,12 @@ DCL_API int dcl_linear_dma_fwd(const float *x, int64_t ldx, const float *Wt, int
 }
 
 DCL_API int dcl_linear_pool_fwd(const float *x, int64_t ldx, const float *Wt, int64_t ldw, const float *bias, const float *roww,
-                                float *part, int64_t ldp, int M, int N, int K, int relu, dclStream_t stream) {
-  DCL_CHECK_ARG(M > 0 && N > 0 && K > 0 && x && Wt && roww && part && ldx >= K && ldw >= N && ldp >= N);
+                                int rows_per_crop, int64_t w_stride, float *part, int64_t ldp, int M, int N, int K, int relu,
+                                dclStream_t stream) {
+  DCL_CHECK_ARG(M > 0 && N > 0 && K > 0 && x && Wt && roww && part && ldx >= K && ldw >= N && ldp >= N && rows_per_crop >= 1 &&
+                w_stride >= 0);
   DCL_CHECK_ARG(lin_dma_ok(x, ldx, Wt, ldw, N, K));
-  LinDmaArgs a{x, Wt, bias, nullptr, ldx, ldw, 0, M, N, K, relu, roww, part, ldp, (int)g_lin_xcd, (int)g_lin_stagger};
+  LinDmaArgs a{x, Wt, bias, nullptr, ldx, ldw, 0, M, N, K, relu, roww, rows_per_crop, w_stride, part, ldp, (int)g_lin_xcd};
   int rc = launch_linear_dma<128, 128, 2, 1>(a, (hipStream_t)stream);
   if (rc) return rc;
   DCL_LAUNCH_CHECK();

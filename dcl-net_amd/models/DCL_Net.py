@@ -213,10 +213,15 @@ class Network(nn.Module):
             for name in ("regressor_conf", "regressor_conf_bi", "regressor_rot", "regressor_trans", "regressor_Xo",
                          "regressor_Yc"):
                 L = getattr(self, name).layers
-                # (the confidence heads' last layer, one output column, sits in rows padded to 4 floats: what
-                # ops.linear_group's 16-byte pieces want; the library GEMM takes the row pitch as its leading dimension)
-                pad = ops.pad_linear_weight if name.startswith("regressor_conf") else (lambda w: w.contiguous())
+                # (a last layer of one / three / nine output columns sits in rows padded to 4 floats: what the 16-byte DMA
+                # pieces of ops.linear_group want
+                # and the own GEMM core's: every head that runs through _mlp keeps its last layer that way).  The two-launch
+                # pose heads (ops.pose_heads) take dense (128, 9) / (128, 3) matrices; the padded twins serve batches beyond them
+                dense = name in ("regressor_rot", "regressor_trans")
+                pad = (lambda w: w.contiguous()) if dense else ops.pad_linear_weight
                 f[name] = [(pad(L[i].weight[:, :, 0].t()), L[i].bias.contiguous()) for i in (0, 2, 4)]
+                if dense:
+                    f[name + "_padded"] = [(ops.pad_linear_weight(Wt), bv) for Wt, bv in f[name]]
             for name in ("neck_fuser", "neck_fuser_bi"):
                 L = getattr(self, name).layers      # Conv,ReLU,BN, Conv,ReLU,BN, Conv,ReLU,BN
                 out, s_prev, t_prev = [], None, None
@@ -234,18 +239,17 @@ class Network(nn.Module):
     # ------------------------------------------------------------------ fused pipeline
     @staticmethod
     def _lin_relu(x, Wt, bias):
-        # relu(x @ Wt + bias), one library GEMM with epilogue -- through dcl_linear_fwd, NOT torch._addmm_activation (same library,
-        # same time: 4.018 vs 4.017 ms): the forward runs these layers of its two branches side by side, and torch takes the
-        # library's first-choice algorithm -- for row counts that do not tile the chip evenly (25, 33, ... crops of 1024 points) a
-        # stream-K kernel that spins on flags in the workspace; two of those at once hang the GPU.  csrc/linear.cpp only takes
-        # algorithms that ask for no workspace.
+        # relu(x @ Wt + bias) on the own fp32 MFMA GEMM core (ops.linear -> csrc/linear_dma.hip); never torch._addmm_activation:
+        # torch takes the vendor library's first-choice algorithm -- for row counts that do not tile the chip evenly (25, 33, ...
+        # crops of 1024 points) a stream-K kernel that spins on flags in a workspace, and two of those side by side on the
+        # forward's two branches hang the GPU
         return ops.linear(x, Wt, bias, True)
 
     def _mlp(self, x, layers):
         x = self._lin_relu(x, *layers[0])
         x = self._lin_relu(x, *layers[1])
-        # last layer: bias, no activation -- through dcl_linear_fwd (bias epilogue); torch.addmm would first broadcast the
-        # bias into the output with an elementwise kernel and then accumulate onto it
+        # last layer: bias, no activation (torch.addmm would first broadcast the bias into the output with an elementwise
+        # kernel and then accumulate onto it)
         return ops.linear(x, layers[2][0], layers[2][1], False)
 
     def _side_stream(self, dev, which=0):
@@ -378,10 +382,22 @@ class Network(nn.Module):
                 done["tmp", 0] = torch.cuda.Event()
                 done["tmp", 0].record(s_tmp)
         paired = bool(done)
+        # Small calls issue BOTH sides' geometry stages before either side's level sizes are waited for: the second side's
+        # feature stage then reaches the GPU ~0.25 ms after the first side's and the two run side by side (same-job A/B at
+        # N = M = 1024, 32 crops: 4.005 -> 3.928 ms).  Large point counts keep one side after the other: their conv launches fill
+        # the chip alone, and two stream-K launches side by side only take each other's workgroup slots (N = 12288 / M = 2048,
+        # 32 crops: 23.65 -> 24.8 ms; issuing a side's disengage GEMMs under the other side's feature stage: 23.64, no gain --
+        # the conv launch that meets a GEMM takes 3.2 ms instead of 0.13).
+        both_first = (self.HEAD_ORDER == 1 if self.HEAD_ORDER is not None else b * max(self.n_inp, self.n_tmp) <= 65536) and not paired
+        if both_first:
+            for side in ("inp", "tmp"):
+                geometry(side)
+                stage(side)
         for side, bb in (() if paired else (("inp", "backbone_inp"), ("tmp", "backbone_tmp"))):
             n = npts[side]
-            geometry(side)
-            stage(side)                                                # runs underneath the geometry
+            if not both_first:
+                geometry(side)
+                stage(side)                                            # runs underneath the geometry
             geo[side].synchronize()                                    # the host waits for THIS side's geometry only
             counts = counts_host[side].tolist()
             mark("counts read back " + side)
@@ -452,6 +468,8 @@ class Network(nn.Module):
     GROUP_ROWS = 2 * 1024     # calls of at most this many points per side issue independent MLP layers as ONE launch each
                               # (ops.linear_group; same-job A/B: -2 % at one crop, +1.3 % at four, 0 at eight); larger ones
                               # keep one library GEMM per layer
+    HEAD_ORDER = None         # launch by launch: 0 = one side after the other (geometry, level sizes, features), 1 = both geometry
+                              # stages first, None = by size (A/B switch: tools/ab_attr.py)
     MAX_GRAPHS = 8            # captured whole-forward graphs kept per instance (one per batch size; least recently used goes)
     GRAPH_ADMIT = 3           # with a full cache, a new batch size is captured (evicting the LRU one) on its 3rd call
 
@@ -525,35 +543,66 @@ class Network(nn.Module):
             F = fuse
             for Wt, bias in fuser_layers:
                 F = self._lin_relu(F, Wt, bias)
+            return conf_logits(conf_in, conf_layers), F
+        def conf_logits(conf_in, conf_layers):
             if conf_in.shape[0] <= self.CONF_MLP_ROWS:
-                return ops.mlp128_to1(conf_in, conf_layers), F          # (three K = 128 layers in one launch)
-            return self._mlp(conf_in, conf_layers), F
-        with second:
-            ops.cross_attention(b, act["Yom2"], act["Xcm2"], act["Xcp2"], fuse2[:, :256], act["Xcm2"], conf_in2[:, :64], concurrent=par)
-            logit2, Fp2 = conf_and_fuser(conf_in2, fuse2, f["regressor_conf_bi"], l2)
-            if side is not None:
-                logit2.record_stream(main); Fp2.record_stream(main)          # allocated on `side`, read on `main` below
-        ops.cross_attention(b, act["Xcm1"], act["Yom1"], act["Yop1"], fuse1[:, 256:], act["Yom1"], conf_in1[:, 64:], concurrent=par)
-        logit1, Fp1 = conf_and_fuser(conf_in1, fuse1, f["regressor_conf"], l1)   # (b*N, 1), (b*N, 1024)
-        join()
-        # trailing BNs after pooling: F_p_wei = sA*P1 + tA*sum(w1) + sB*P2 + tB*sum(w2), finished inside the pooling op
-        if b <= self.POSE_PARTS_MAX:                   # a handful of crops: the pooling's finish inside the heads' first launch
-            conf, parts = ops.conf_pool(b, logit1.reshape(-1), logit2.reshape(-1), Fp1, Fp2, affine=(sA, tA, sB, tB), finish=False)
-            o9, trans_pred, rot_pred = ops.pose_heads_parts(parts, (sA, tA, sB, tB), f["regressor_rot"], f["regressor_trans"],
-                                                            with_rotation=True)
-            F_p_wei = None
+                return ops.mlp128_to1(conf_in, conf_layers)                 # (three K = 128 layers in one launch)
+            return self._mlp(conf_in, conf_layers)
+        fused_pool = (b > self.POSE_PARTS_MAX and self.n_inp % ops.LINEAR_POOL_TILE == 0 and
+                      self.n_tmp % ops.LINEAR_POOL_TILE == 0)
+        if fused_pool:
+            # The last fuser layer carries the pooling as its epilogue (ops.linear_pool): F_p -- b * (N + M) rows of 1024 floats,
+            # 1.9 GB at the stress shape -- is never stored and the weighted column sums are no kernel of their own.  The
+            # weights are the softmax over BOTH directions' confidences, so the two confidence regressors run first and the
+            # directions meet once more in the middle: attention + logits | softmax | fuser layers 1, 2, 3 + pool | finish.
+            with second:
+                ops.cross_attention(b, act["Yom2"], act["Xcm2"], act["Xcp2"], fuse2[:, :256], act["Xcm2"], conf_in2[:, :64], concurrent=par)
+                logit2 = conf_logits(conf_in2, f["regressor_conf_bi"])
+                if side is not None:
+                    logit2.record_stream(main)
+            ops.cross_attention(b, act["Xcm1"], act["Yom1"], act["Yop1"], fuse1[:, 256:], act["Yom1"], conf_in1[:, 64:], concurrent=par)
+            logit1 = conf_logits(conf_in1, f["regressor_conf"])
+            join()
+            conf, w, wsum = ops.conf_softmax(b, logit1.reshape(-1), logit2.reshape(-1))
+            L = self.n_inp + self.n_tmp
+            with second:                                   # (forks again behind the softmax)
+                if side is not None:
+                    w.record_stream(side)
+                H = self._lin_relu(self._lin_relu(fuse2, *l2[0]), *l2[1])
+                part2 = ops.linear_pool(H, l2[2][0], l2[2][1], w.view(-1)[self.n_inp:], relu=True, rows_per_crop=self.n_tmp, w_stride=L)
+                if side is not None:
+                    part2.record_stream(main)
+            H = self._lin_relu(self._lin_relu(fuse1, *l1[0]), *l1[1])
+            part1 = ops.linear_pool(H, l1[2][0], l1[2][1], w.view(-1), relu=True, rows_per_crop=self.n_inp, w_stride=L)
+            join()
+            F_p_wei = ops.pool_finish2(part1, part2, wsum, (sA, tA, sB, tB))
         else:
-            conf, F_p_wei = ops.conf_pool(b, logit1.reshape(-1), logit2.reshape(-1), Fp1, Fp2, affine=(sA, tA, sB, tB))
+            with second:
+                ops.cross_attention(b, act["Yom2"], act["Xcm2"], act["Xcp2"], fuse2[:, :256], act["Xcm2"], conf_in2[:, :64], concurrent=par)
+                logit2, Fp2 = conf_and_fuser(conf_in2, fuse2, f["regressor_conf_bi"], l2)
+                if side is not None:
+                    logit2.record_stream(main); Fp2.record_stream(main)          # allocated on `side`, read on `main` below
+            ops.cross_attention(b, act["Xcm1"], act["Yom1"], act["Yop1"], fuse1[:, 256:], act["Yom1"], conf_in1[:, 64:], concurrent=par)
+            logit1, Fp1 = conf_and_fuser(conf_in1, fuse1, f["regressor_conf"], l1)   # (b*N, 1), (b*N, 1024)
+            join()
+            # trailing BNs after pooling: F_p_wei = sA*P1 + tA*sum(w1) + sB*P2 + tB*sum(w2), finished inside the pooling op
+            if b <= self.POSE_PARTS_MAX:                   # a handful of crops: the pooling's finish inside the heads' first launch
+                conf, parts = ops.conf_pool(b, logit1.reshape(-1), logit2.reshape(-1), Fp1, Fp2, affine=(sA, tA, sB, tB), finish=False)
+                o9, trans_pred, rot_pred = ops.pose_heads_parts(parts, (sA, tA, sB, tB), f["regressor_rot"], f["regressor_trans"],
+                                                                with_rotation=True)
+                F_p_wei = None
+            else:
+                conf, F_p_wei = ops.conf_pool(b, logit1.reshape(-1), logit2.reshape(-1), Fp1, Fp2, affine=(sA, tA, sB, tB))
         if F_p_wei is None:
             pass
         elif b <= self.POSE_HEADS_MAX:                 # up to this many crops: both heads in two launches (csrc/dense.hip)
             o9, trans_pred, rot_pred = ops.pose_heads(F_p_wei, f["regressor_rot"], f["regressor_trans"], with_rotation=True)
         else:
             with second:
-                trans_pred = self._mlp(F_p_wei, f["regressor_trans"])
+                trans_pred = self._mlp(F_p_wei, f["regressor_trans_padded"])
                 if side is not None:
                     trans_pred.record_stream(main)
-            o9 = self._mlp(F_p_wei, f["regressor_rot"])
+            o9 = self._mlp(F_p_wei, f["regressor_rot_padded"])
             rot_pred = ops.ortho9d_to_matrix(o9)
             join()
         F_Xo_p = fuse1[:, 256:].reshape(b, self.n_inp, 256).transpose(1, 2)  # (b,256,N) view
@@ -687,14 +736,8 @@ class Network(nn.Module):
             st["pb4"] = torch.zeros((b * n, 4), dtype=torch.float32, device=dev)
             st["pb4"][:, 0] = torch.arange(b, device=dev, dtype=torch.float32).repeat_interleave(n)
             ent[s] = st
-        # the graph's own GEMM scratch, one per branch, allocated before warm-up and capture (ops.lt_workspace_scope)
-        ent["lt_ws"] = tuple(torch.empty(ops._LT_WORKSPACE_BYTES, dtype=torch.uint8, device=dev) for _ in range(2))
 
         def body():
-            with ops.lt_workspace_scope(ent["lt_ws"][0], ent["lt_ws"][1], self._side_stream(dev)):
-                return body_()
-
-        def body_():
             # Two parallel branches in the graph, one per side.  The eager path also runs each side's 3-NN searches on a
             # helper stream beside its convolutions; in a graph that does not pay (bare replay at b=1: 1.04 ms with two
             # branches, 1.22 ms with four -- every cross-branch edge costs a barrier packet), and ROCm 7.2 crashes in
@@ -746,7 +789,7 @@ class Network(nn.Module):
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                for _ in range(2):                                         # warm-up: lazy inits, allocator, hipBLASLt plans
+                for _ in range(2):                                         # warm-up: lazy inits, allocator
                     body()
             torch.cuda.current_stream().wait_stream(side)
             try:

@@ -94,11 +94,17 @@ class Refiner(nn.Module):
         # first shared layer: the K = 3 product + the constant term + ReLU in one pass (ops.affine3_relu; a library GEMM and a
         # ReLU sweep before: 49 -> ~27 us per iteration at 32 768 rows)
         h = ops.affine3_relu(xyz_pm.contiguous(), f["share0_xyz"], feat_term)
-        # (library GEMMs through dcl_linear_fwd, which never takes a workspace-exchanging algorithm -- a refiner that a caller
-        #  overlaps with another forward's GEMMs must not be able to hang the GPU; see models/DCL_Net.py: _lin_relu)
+        # (the own GEMM core, ops.linear -> csrc/linear_dma.hip: no vendor kernel that a caller overlapping the refiner with
+        #  another forward's GEMMs could hang the GPU with; see models/DCL_Net.py: _lin_relu)
         h = ops.linear(h, f["MLP_share"][1][0], f["MLP_share"][1][1], True)
-        h = ops.linear(h, f["MLP_share"][2][0], f["MLP_share"][2][1], True)                  # (b*n, 1024)
-        shared = torch.bmm(conf_w.unsqueeze(1), h.view(b, n, -1)).squeeze(1)                 # (b, 1024)
+        if n % ops.LINEAR_POOL_TILE == 0:
+            # the last shared layer with the confidence-weighted sum over the points as its epilogue: the (b*n, 1024) activation
+            # is never stored; a crop's n / 128 tile partials are added in tile order
+            part = ops.linear_pool(h, f["MLP_share"][2][0], f["MLP_share"][2][1], conf_w.reshape(-1), relu=True)
+            shared = part.view(b, n // ops.LINEAR_POOL_TILE, -1).sum(dim=1)                  # (b, 1024)
+        else:
+            h = ops.linear(h, f["MLP_share"][2][0], f["MLP_share"][2][1], True)              # (b*n, 1024)
+            shared = torch.bmm(conf_w.unsqueeze(1), h.view(b, n, -1)).squeeze(1)             # (b, 1024)
         # both pose heads (1024 -> 512 -> 128 -> 9 | 3) and the rotation in two launches (ops.pose_heads, as in stage 1) instead of
         # six library GEMMs of 5-14 us each on 32 rows + the ortho kernel; larger batches keep the library
         if b <= self.POSE_HEADS_MAX:
@@ -137,7 +143,7 @@ class Refiner(nn.Module):
             b, _, n = x.shape
             conf_w = torch.softmax(conf.unsqueeze(1), dim=2)[:, 0, :1024].contiguous()       # refiner.py:81
             pm = x.transpose(1, 2).reshape(b * n, -1)
-            feat_term = torch.addmm(f["MLP_share"][0][1], pm[:, 3:], f["share0_feat"])
+            feat_term = ops.linear(pm[:, 3:], f["share0_feat"], f["MLP_share"][0][1], False)
             dt, dR = self.forward_pm(pm[:, :3].contiguous(), feat_term, conf_w)
         return {"trans_pred": dt, "rot_pred": dR}
 
@@ -155,7 +161,7 @@ def refine_loop(refiner, pred, points_inp, iteration=2, graph=False):
         # the feature half of the first shared layer: the same in every iteration, computed once per call
         bias, W = f["MLP_share"][0][1], f["share0_feat"]
         if F_pm.is_contiguous():                                  # point-major rows (what Network.forward hands over)
-            return torch.addmm(bias, F_pm.view(b * n, -1), W, out=out)
+            return ops.linear(F_pm.view(b * n, -1), W, bias, False, out=out)
         # channel-first features (the reference's own layout): a batched GEMM over the transposed operand, no transpose copy
         o = torch.baddbmm(bias.view(1, 1, -1), F_pm, W.unsqueeze(0).expand(b, -1, -1),
                           out=None if out is None else out.view(b, n, -1))

@@ -819,58 +819,24 @@ def pose_heads_parts(parts, affine, rot_layers, trans_layers, with_rotation=Fals
     return (o9, trans, R) if with_rotation else (o9, trans)
 
 
-_LT_WORKSPACES = {}            # (device index, stream handle) -> uint8 scratch the GEMM library may use on that stream
-_LT_WORKSPACE_BYTES = 32 << 20
-_LT_WORKSPACES_MAX = 8         # eager scratches kept per process (long-lived streams only: captures bring their own, below)
-_LT_SCOPE = threading.local()
-
-
-class lt_workspace_scope(object):
-    """GEMM scratch of a captured forward.  A whole-forward hipGraph owns its scratch: `main_ws` for the branch on the
-    capturing stream, `side_ws` for the branch on `side_stream` -- allocated by the caller BEFORE the warm-up runs and the
-    capture, and named explicitly here, so that (i) warm-up and capture query the library with the same workspace size
-    (same plans, same rounding as the eager path), (ii) no scratch is baked into two graphs (two graphs replayed on
-    different streams would share it unsynchronised) and (iii) nothing is left behind per warm-up stream."""
-
-    def __init__(self, main_ws, side_ws, side_stream):
-        self.main_ws, self.side_ws = main_ws, side_ws
-        self.side_handle = side_stream.cuda_stream if side_stream is not None else None
-
-    def __enter__(self):
-        self.prev = getattr(_LT_SCOPE, "scope", None)
-        _LT_SCOPE.scope = self
-        return self
-
-    def __exit__(self, *exc):
-        _LT_SCOPE.scope = self.prev
-        return False
-
-    def pick(self, dev):
-        on_side = self.side_handle is not None and torch.cuda.current_stream(dev).cuda_stream == self.side_handle
-        return self.side_ws if on_side else self.main_ws
-
-
-def _lt_workspace(dev):
-    scope = getattr(_LT_SCOPE, "scope", None)
-    if scope is not None:
-        return scope.pick(dev)
-    if torch.cuda.is_current_stream_capturing():
-        # a foreign capture without a scope: run without scratch -- never hand out an eager scratch here: its address would be
-        # baked into the graph, and a later eviction below would give the memory back while the graph's GEMMs still write there
-        return None
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
-    ws = _LT_WORKSPACES.get(key)
-    if ws is None:
-        while len(_LT_WORKSPACES) >= _LT_WORKSPACES_MAX:   # bounded: the oldest stream's scratch goes back to the allocator
-            _LT_WORKSPACES.pop(next(iter(_LT_WORKSPACES)))
-        ws = _LT_WORKSPACES[key] = torch.empty(_LT_WORKSPACE_BYTES, dtype=torch.uint8, device=dev)
-    return ws
+VENDOR_GEMM = False           # tools / tests only: True sends linear() to the vendor library whatever the shape (A/B runs)
 
 
 def linear(x, Wt, bias=None, relu=False, out=None):
-    """One per-point linear layer (Conv1d k=1 / 1x1x1 Conv3d + folded BN of the reference's MLP stacks): act(x @ Wt + bias)
-    as a library GEMM with bias / ReLU epilogue, called through the C-ABI.  x (M,K), Wt (K,N), out (M,N) are row-major 2-D
-    tensors whose rows may be strided (column blocks of wider buffers): `out=buf[:, 256:512]` is written in place, no copy."""
+    """One per-point linear layer (Conv1d k=1 / 1x1x1 Conv3d + folded BN of the reference's MLP stacks): act(x @ Wt + bias).
+    x (M,K), Wt (K,N), out (M,N) are row-major 2-D tensors whose rows may be strided (column blocks of wider buffers):
+    `out=buf[:, 256:512]` is written in place, no copy.  Runs on the library's OWN fp32 MFMA GEMM core (linear_dma,
+    csrc/linear_dma.hip) -- every layer shape of the forward does; a shape that core does not take (K no multiple of 32,
+    operands not 16-byte aligned) goes to the vendor library (linear_lt)."""
+    if not VENDOR_GEMM and x.is_cuda and Wt.is_cuda and x.dim() == 2 and Wt.dim() == 2 and linear_dma_ok(x, Wt):
+        return linear_dma(x, Wt, bias, relu, out)
+    return linear_lt(x, Wt, bias, relu, out)
+
+
+def linear_lt(x, Wt, bias=None, relu=False, out=None):
+    """linear() as a vendor-library GEMM (hipBLASLt, bias / ReLU epilogue) called through the C-ABI (dcl_linear_fwd): only
+    algorithms that ask for NO workspace are ever taken (csrc/linear.cpp: two workspace-exchanging stream-K kernels side by
+    side hang the GPU); the call fails when the library has none for the shape."""
     N.need_cuda(x, Wt)
     assert x.dim() == 2 and Wt.dim() == 2 and x.shape[1] == Wt.shape[0] and x.dtype == Wt.dtype == torch.float32
     M, K = x.shape
@@ -883,10 +849,9 @@ def linear(x, Wt, bias=None, relu=False, out=None):
     if bias is not None:
         assert bias.is_cuda and bias.dtype == torch.float32 and bias.numel() == n and bias.is_contiguous()
     pitch = lambda t: int(t.stride(0)) if t.shape[0] > 1 else max(int(t.stride(0)), int(t.shape[1]))   # noqa: E731
-    ws = _lt_workspace(x.device)
     N.check(N.lib().dcl_linear_fwd(N.ptr(x), C.c_int64(pitch(x)), N.ptr(Wt), C.c_int64(pitch(Wt)), N.ptr(bias), N.ptr(out),
-                                   C.c_int64(pitch(out)), int(M), int(n), int(K), int(bool(relu)), N.ptr(ws),
-                                   C.c_int64(0 if ws is None else ws.numel()), N.stream()), "linear_fwd")
+                                   C.c_int64(pitch(out)), int(M), int(n), int(K), int(bool(relu)), None,
+                                   C.c_int64(0), N.stream()), "linear_fwd")
     return out
 
 
@@ -922,24 +887,55 @@ def linear_dma(x, Wt, bias=None, relu=False, out=None):
 LINEAR_POOL_TILE = 128         # rows per partial of linear_pool (the GEMM's row tile)
 
 
-def linear_pool(x, Wt, bias, roww, relu=True, part=None):
+def linear_pool(x, Wt, bias, roww, relu=True, part=None, rows_per_crop=None, w_stride=0):
     """The last fuser layer with the confidence-weighted pooling as its epilogue (csrc/linear_dma.hip, EPI = 1):
-    part[t] = sum over rows j of row tile t (128 rows) of roww[j] * act(x[j] @ Wt + bias) -- (ceil(M/128), N); the (M, N)
-    activation is never stored.  With every crop a whole number of tiles, a crop's pooled feature is the sum of its tiles'
-    partials (pool_finish_tiles adds them in tile order)."""
+    part[t] = sum over rows j of row tile t (128 rows) of w_j * act(x[j] @ Wt + bias) -- (ceil(M/128), N); the (M, N)
+    activation is never stored.  w_j = roww[j] by default; with rows_per_crop / w_stride, row j = (crop, point) weighs
+    roww[crop * w_stride + point] (a direction's block of conf_softmax's (b, n1 + n2) weights).  With every crop a whole
+    number of tiles, a crop's pooled feature is the sum of its tiles' partials (pool_finish2 adds them in tile order)."""
     N.need_cuda(x, Wt, roww)
     M, K = x.shape
     n = Wt.shape[1]
-    assert roww.is_contiguous() and roww.numel() == M and roww.dtype == torch.float32
+    if rows_per_crop is None:
+        rows_per_crop, w_stride = M, 0
+        assert roww.is_contiguous() and roww.numel() == M
+    assert roww.dtype == torch.float32 and M % rows_per_crop == 0
     tiles = (M + LINEAR_POOL_TILE - 1) // LINEAR_POOL_TILE
     if part is None:
         part = torch.empty((tiles, n), dtype=torch.float32, device=x.device)
     assert part.shape == (tiles, n) and part.stride(1) == 1
     pitch = lambda t: int(t.stride(0)) if t.shape[0] > 1 else max(int(t.stride(0)), int(t.shape[1]))   # noqa: E731
     N.check(N.lib().dcl_linear_pool_fwd(N.ptr(x), C.c_int64(pitch(x)), N.ptr(Wt), C.c_int64(pitch(Wt)), N.ptr(bias), N.ptr(roww),
-                                        N.ptr(part), C.c_int64(pitch(part)), int(M), int(n), int(K), int(bool(relu)), N.stream()),
-            "linear_pool_fwd")
+                                        int(rows_per_crop), C.c_int64(int(w_stride)), N.ptr(part), C.c_int64(pitch(part)), int(M),
+                                        int(n), int(K), int(bool(relu)), N.stream()), "linear_pool_fwd")
     return part
+
+
+def conf_softmax(b, logit1, logit2):
+    """the softmax half of conf_pool alone: logits (b*n1,), (b*n2,) -> conf (b, n1+n2) = sigmoid, w (b, n1+n2) = softmax(conf)
+    per crop, wsum (b, 2) (models/DCL_Net.py:217-222)"""
+    N.need_cuda(logit1, logit2)
+    assert logit1.is_contiguous() and logit2.is_contiguous() and logit1.numel() % b == 0 and logit2.numel() % b == 0
+    n1, n2 = logit1.numel() // b, logit2.numel() // b
+    dev = logit1.device
+    conf = torch.empty((b, n1 + n2), dtype=torch.float32, device=dev)
+    w = torch.empty((b, n1 + n2), dtype=torch.float32, device=dev)
+    ws = torch.empty((b, 2), dtype=torch.float32, device=dev)
+    N.check(N.lib().dcl_conf_softmax(b, n1, n2, N.ptr(logit1), N.ptr(logit2), N.ptr(conf), N.ptr(w), N.ptr(ws), N.stream()),
+            "conf_softmax")
+    return conf, w, ws
+
+
+def pool_finish2(part1, part2, ws, affine):
+    """pooled (b, c) = ((s1*P1 + t1*wsum1) + s2*P2) + t2*wsum2 with P = a crop's tile partials added in tile order: part1
+    (b*ns1, c), part2 (b*ns2, c) as linear_pool leaves them"""
+    b, c = ws.shape[0], part1.shape[1]
+    s1, t1, s2, t2 = affine
+    assert part1.is_contiguous() and part2.is_contiguous() and part1.shape[0] % b == 0 and part2.shape[0] % b == 0
+    out = torch.empty((b, c), dtype=torch.float32, device=part1.device)
+    N.check(N.lib().dcl_pool_finish2(b, c, part1.shape[0] // b, part2.shape[0] // b, N.ptr(part1), N.ptr(part2), N.ptr(ws),
+                                     N.ptr(s1), N.ptr(t1), N.ptr(s2), N.ptr(t2), N.ptr(out), N.stream()), "pool_finish2")
+    return out
 
 
 class _LinearJob(C.Structure):

@@ -438,11 +438,22 @@ int dcl_linear_fwd(const float *x, int64_t ldx, const float *Wt, int64_t ldw, co
 int dcl_linear_dma_fwd(const float *x, int64_t ldx, const float *Wt, int64_t ldw, const float *bias, float *y, int64_t ldy,
                        int M, int N, int K, int relu, dclStream_t stream);
 /* The last fuser layer WITH the confidence-weighted pooling of models/DCL_Net.py:223-228 as its epilogue: instead of storing
- * F = act(x Wt + bias) (M x N) it leaves  part[t][c] = sum over the rows j of row tile t (128 rows) of roww[j] * F[j][c]  for
- * t = 0 .. ceil(M / 128) - 1 (row pitch ldp >= N): with every crop a whole number of tiles, dcl_pool_finish adds a crop's
- * partials in tile order.  roww: M floats (the softmax weights of the rows).  Same shape constraints as dcl_linear_dma_fwd. */
+ * F = act(x Wt + bias) (M x N) it leaves  part[t][c] = sum over the rows j of row tile t (128 rows) of w_j * F[j][c]  for
+ * t = 0 .. ceil(M / 128) - 1 (row pitch ldp >= N), with w_j = roww[(j / rows_per_crop) * w_stride + j % rows_per_crop] (the
+ * softmax weights as dcl_conf_softmax leaves them: one row of n1 + n2 weights per crop, a direction's block addressed through
+ * the base pointer).  With every crop a whole number of tiles, dcl_pool_finish2 adds a crop's partials in tile order.
+ * Same shape constraints as dcl_linear_dma_fwd. */
 int dcl_linear_pool_fwd(const float *x, int64_t ldx, const float *Wt, int64_t ldw, const float *bias, const float *roww,
-                        float *part, int64_t ldp, int M, int N, int K, int relu, dclStream_t stream);
+                        int rows_per_crop, int64_t w_stride, float *part, int64_t ldp, int M, int N, int K, int relu,
+                        dclStream_t stream);
+/* The softmax half of dcl_conf_pool alone: conf (b, n1 + n2) = sigmoid(cat[logit1, logit2]), w (b, n1 + n2) = softmax(conf) per
+ * crop, wsum (b, 2) = the weight sums of the two directions (models/DCL_Net.py:217-222). */
+int dcl_conf_softmax(int b, int n1, int n2, const float *logit1, const float *logit2, float *conf, float *w, float *wsum,
+                     dclStream_t stream);
+/* dcl_pool_finish with a slice count per direction: part1 (b, nslices1, c), part2 (b, nslices2, c). */
+int dcl_pool_finish2(int b, int c, int nslices1, int nslices2, const float *part1, const float *part2, const float *wsum,
+                     const float *scale1, const float *shift1, const float *scale2, const float *shift2, float *out,
+                     dclStream_t stream);
 
 /* Several INDEPENDENT per-point linear layers in one launch (csrc/linear_group.hip), for calls of a handful of crops: the
  * reference issues every Conv1d(k=1) / 1x1x1 Conv3d of its MLP stacks as its own launch (models/Modules.py:58-97,173-201; the
@@ -596,11 +607,11 @@ void dcl_debug_conv_few_chunks(int n);
 void dcl_debug_conv_few_tiles(int on);
 /* Tuning hook: 1 (default) = the Cin 16 / 32 -> 32 conv layers of many rows run the filter-resident kernel, 0 = LDS-DMA kernel. */
 void dcl_debug_conv_wlds(int on);
-/* Tuning hooks of the own GEMM core: tile shape (0 = automatic, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 64x128), XCD-aware
+/* Tuning hooks of the own GEMM core: tile shape (0 = automatic, 1 = 128x128, 2 = 128x64, 3 = 64x64), XCD-aware
  * workgroup renumbering (default 1). */
 void dcl_debug_linear_tile(int t);
 void dcl_debug_linear_xcd_remap(int on);
-void dcl_debug_linear_stagger(int n);   /* workgroups in odd wave slots start n x 8128 cycles late (0 = off) */
+void dcl_debug_linear_persist(int rounds);   /* rounds of resident workgroups from which a GEMM launch is persistent (default 4) */
 /* Diagnostic: times the GEMM library's first ncand heuristic candidates (32 MiB of workspace on offer) for an (M, N, K)
  * linear layer, each alone on the GPU; ms_out[i] = mean ms, ws_out[i] (may be NULL) = the workspace candidate i asks for.
  * dcl_linear_fwd itself only ever takes an algorithm that asks for none (it queries with a maximum of 0 bytes and refuses

@@ -901,9 +901,37 @@ def test_library_gemms_never_take_a_workspace_exchanging_algorithm(request, dcl)
     lib = enter_diag(dcl, request)
     lib.dcl_debug_linear_plan_workspace.restype = ctypes.c_longlong
     torch.zeros(1, device="cuda")
-    for b in (1, 6, 32, 33, 35, 37, 40, 41, 47):
-        for K, n in ((480, 1024), (256, 256), (256, 64), (512, 512), (512, 1024), (1024, 512), (512, 128)):
-            assert lib.dcl_debug_linear_plan_workspace(b * 1024, n, K) == 0, (b, K, n)
+    shapes = ((480, 1024), (256, 256), (256, 64), (512, 512), (512, 1024), (1024, 512), (512, 128))
+    rows = set(b * 1024 for b in (1, 6, 25, 32, 33, 35, 37, 40, 41, 47))
+    rows |= set(b * n for b in range(1, 41, 3) for n in (12288, 2048))       # the stress shape's two sides
+    rows |= set(b * n for b in (1, 2, 3, 7, 25, 33) for n in (333, 517, 500))  # odd point counts (the oracle-graph tests feed them)
+    for M in sorted(rows):
+        for K, n in shapes:
+            # 0: an algorithm without workspace was found and is the one taken; -1 would mean the library has none and
+            # dcl_linear_fwd FAILS for the shape (it never falls through to a workspace-exchanging kernel)
+            assert lib.dcl_debug_linear_plan_workspace(M, n, K) == 0, (M, K, n)
+
+
+@pytest.mark.timeout(120)
+def test_vendor_gemm_refuses_instead_of_taking_a_workspace_algorithm(dcl):
+    """ops.linear_lt never hands the library a workspace (csrc/linear.cpp queries with a maximum of 0 bytes and calls with
+    (NULL, 0)): the awkward row counts -- 25 / 33 crops of 1024 points -- run, two side by side on two streams, and finish"""
+    g = torch.Generator(device="cuda").manual_seed(2)
+    s2 = torch.cuda.Stream()
+    for M in (25 * 1024, 33 * 1024, 33 * 333):
+        x = torch.randn(M, 512, device="cuda", generator=g)
+        Wt = torch.randn(512, 512, device="cuda", generator=g) * 0.05
+        bias = torch.randn(512, device="cuda", generator=g)
+        y1, y2 = torch.empty(M, 512, device="cuda"), torch.empty(M, 512, device="cuda")
+        torch.cuda.synchronize()
+        for _ in range(4):
+            dcl.ops.linear_lt(x, Wt, bias, True, out=y1)
+            with torch.cuda.stream(s2):
+                dcl.ops.linear_lt(x, Wt, bias, True, out=y2)
+        torch.cuda.synchronize()
+        want = torch.relu(x[:64].double() @ Wt.double() + bias.double())
+        assert float((y1[:64].double() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+        assert torch.equal(y1, y2)
 
 
 @pytest.mark.timeout(300)
@@ -985,7 +1013,7 @@ def test_confidence_regressor_in_one_launch_matches_its_three_layers(dcl, M, wid
     ref = (((x.double() @ W1.double() + b1.double()).relu() @ W2.double() + b2.double()).relu() @ W3.double() + b3.double())
     assert got.shape == (M, 1)
     assert float((got.double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
-    lib3 = dcl.ops.linear(dcl.ops.linear(dcl.ops.linear(x, W1, b1, True), W2, b2, True), W3, b3, False)
+    lib3 = dcl.ops.linear_lt(dcl.ops.linear_lt(dcl.ops.linear_lt(x, W1, b1, True), W2, b2, True), W3, b3, False)
     assert float((got - lib3).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
 
 
@@ -1111,26 +1139,28 @@ def test_pose_heads_match_the_module_heads(dcl):
 
 
 def test_linear_layer_writes_column_blocks_in_place(dcl):
-    """dcl_linear_fwd (library GEMM + bias / ReLU epilogue behind the C-ABI) against torch on dense and on strided operands:
-    x a column block of a wider buffer, out a column block of another -- the neighbouring columns must stay untouched"""
+    """ops.linear_lt (dcl_linear_fwd: vendor GEMM + bias / ReLU epilogue behind the C-ABI, what shapes the own core does not take
+    fall back to) and ops.linear (the dispatcher: own core where it can) against torch on dense and on strided operands: x a
+    column block of a wider buffer, out a column block of another -- the neighbouring columns must stay untouched"""
     g = torch.Generator().manual_seed(11)
-    for M, K, n in ((1000, 256, 64), (4096, 480, 1024), (37, 128, 1), (2048, 512, 512), (5, 1024, 9)):
-        wide = torch.randn(M, K + 40, generator=g).cuda()
-        x = wide[:, 8:8 + K]
-        Wt = (torch.randn(K, n, generator=g) * 0.05).cuda()
-        bias = torch.randn(n, generator=g).cuda()
-        for relu, with_bias in ((True, True), (False, True), (False, False), (True, False)):
-            want = x @ Wt + (bias if with_bias else 0.0)
-            want = torch.relu(want) if relu else want
-            got = dcl.ops.linear(x, Wt, bias if with_bias else None, relu)
-            tol = 2e-5 * max(1.0, float(want.abs().max()))
-            assert float((got - want).abs().max()) <= tol, (M, K, n, relu, with_bias)
-            buf = torch.full((M, n + 24), 7.0).cuda()
-            dcl.ops.linear(x, Wt, bias if with_bias else None, relu, out=buf[:, 16:16 + n])
-            assert float((buf[:, 16:16 + n] - want).abs().max()) <= tol
-            assert bool((buf[:, :16] == 7.0).all()) and bool((buf[:, 16 + n:] == 7.0).all())
-    with pytest.raises(RuntimeError):
-        dcl.ops.linear(torch.zeros(4, 8), torch.zeros(8, 2))               # host tensors are refused
+    for fn in (dcl.ops.linear_lt, dcl.ops.linear):
+        for M, K, n in ((1000, 256, 64), (4096, 480, 1024), (37, 128, 1), (2048, 512, 512), (5, 1024, 9), (300, 259, 512)):
+            wide = torch.randn(M, K + 40, generator=g).cuda()
+            x = wide[:, 8:8 + K]
+            Wt = (torch.randn(K, n, generator=g) * 0.05).cuda()
+            bias = torch.randn(n, generator=g).cuda()
+            for relu, with_bias in ((True, True), (False, True), (False, False), (True, False)):
+                want = x @ Wt + (bias if with_bias else 0.0)
+                want = torch.relu(want) if relu else want
+                got = fn(x, Wt, bias if with_bias else None, relu)
+                tol = 2e-5 * max(1.0, float(want.abs().max()))
+                assert float((got - want).abs().max()) <= tol, (M, K, n, relu, with_bias)
+                buf = torch.full((M, n + 24), 7.0).cuda()
+                fn(x, Wt, bias if with_bias else None, relu, out=buf[:, 16:16 + n])
+                assert float((buf[:, 16:16 + n] - want).abs().max()) <= tol
+                assert bool((buf[:, :16] == 7.0).all()) and bool((buf[:, 16 + n:] == 7.0).all())
+        with pytest.raises(RuntimeError):
+            fn(torch.zeros(4, 8), torch.zeros(8, 2))                       # host tensors are refused
 
 
 def test_linear_group_equals_separate_layers(dcl):
@@ -1166,6 +1196,79 @@ def test_linear_group_equals_separate_layers(dcl):
             assert float((a.double() - w).abs().max()) <= 2e-5 * max(1.0, float(w.abs().max())), M
     with pytest.raises(RuntimeError):
         dcl.ops.linear_group([(torch.zeros(64, 48).cuda(), torch.zeros(48, 64).cuda(), None, False, None)])   # K % 32 != 0
+
+
+def test_own_gemm_core_matches_float64_on_every_tile_shape(request, dcl):
+    """dcl_linear_dma_fwd (csrc/linear_dma.hip: the own fp32 MFMA GEMM core that replaces the vendor library on the forward)
+    against float64 products: the model's layer shapes, ragged row counts (rows past M are fetched from the last valid row and
+    never stored), column counts that are no multiple of a tile, a lone output column (zero-padded weight), operands and outputs
+    that are column blocks of wider buffers (the neighbouring columns must stay untouched) -- for every tile shape"""
+    lib = enter_diag(dcl, request)
+    g = torch.Generator().manual_seed(21)
+    try:
+        for tile in (0, 1, 2, 3):
+            lib.dcl_debug_linear_tile(tile)
+            for M, K, n in ((1000, 256, 64), (4096, 480, 1024), (37, 128, 1), (2048, 512, 512), (333, 512, 96), (517, 256, 256),
+                            (129, 32, 260)):
+                wide = torch.randn(M, K + 40, generator=g).cuda()
+                x = wide[:, 8:8 + K]                                               # pitch K + 40, 32-byte offset
+                Wt = dcl.ops.pad_linear_weight((torch.randn(K, n, generator=g) * 0.05).cuda())
+                bias = torch.randn(n, generator=g).cuda()
+                for relu, with_bias in ((True, True), (False, False)):
+                    want = x.double() @ Wt.double() + (bias.double() if with_bias else 0.0)
+                    want = torch.relu(want) if relu else want
+                    tol = 2e-5 * max(1.0, float(want.abs().max()))
+                    got = dcl.ops.linear_dma(x, Wt, bias if with_bias else None, relu)
+                    assert float((got.double() - want).abs().max()) <= tol, (tile, M, K, n, relu)
+                    buf = torch.full((M, n + 24), 7.0).cuda()
+                    dcl.ops.linear_dma(x, Wt, bias if with_bias else None, relu, out=buf[:, 16:16 + n])
+                    assert float((buf[:, 16:16 + n].double() - want).abs().max()) <= tol, (tile, M, K, n, relu)
+                    assert bool((buf[:, :16] == 7.0).all()) and bool((buf[:, 16 + n:] == 7.0).all())
+    finally:
+        lib.dcl_debug_linear_tile(0)
+    with pytest.raises(RuntimeError):
+        dcl.ops.linear_dma(torch.zeros(64, 48).cuda(), torch.zeros(48, 64).cuda())     # K % 32 != 0: stays on dcl_linear_fwd
+    assert not dcl.ops.linear_dma_ok(torch.zeros(64, 48).cuda(), torch.zeros(48, 64).cuda())
+
+
+@pytest.mark.timeout(300)
+def test_own_gemm_core_at_the_benchmarked_row_counts(dcl):
+    """the stress shape's rows (32 crops x 12288 points) through the three big layer shapes: sampled rows against float64, every
+    row finite, and the same bits from two launches (one fmaf chain per element: no split-K, no atomics, no order that depends
+    on scheduling)"""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    M = 32 * 12288
+    for K, n in ((480, 1024), (512, 512), (256, 64)):
+        x = torch.randn(M, K, device="cuda", generator=g)
+        Wt = torch.randn(K, n, device="cuda", generator=g) * 0.05
+        bias = torch.randn(n, device="cuda", generator=g)
+        y1 = dcl.ops.linear_dma(x, Wt, bias, True)
+        y2 = dcl.ops.linear_dma(x, Wt, bias, True)
+        assert torch.equal(y1, y2) and bool(torch.isfinite(y1).all())
+        rows = torch.cat([torch.randint(0, M, (509,), device="cuda", generator=g), torch.tensor([0, 127, 128, M - 129, M - 1], device="cuda")])
+        want = torch.relu(x[rows].double() @ Wt.double() + bias.double())
+        assert float((y1[rows].double() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+        del x, y1, y2
+
+
+def test_last_fuser_layer_with_the_pooling_as_its_epilogue(dcl):
+    """dcl_linear_pool_fwd: part[t] = sum over the rows j of row tile t of w[j] * relu(x[j] @ Wt + bias) -- against float64, for
+    whole tiles, a ragged last tile (rows past M weigh nothing) and a column count that is no multiple of the tile; two
+    launches give the same bits (fixed summation order)"""
+    g = torch.Generator().manual_seed(8)
+    for M, K, n in ((1024, 512, 1024), (4096, 512, 1024), (300, 128, 96), (2048 + 77, 256, 512)):
+        x = torch.randn(M, K, generator=g).cuda()
+        Wt = (torch.randn(K, n, generator=g) * 0.05).cuda()
+        bias = torch.randn(n, generator=g).cuda()
+        w = torch.rand(M, generator=g).cuda() / M
+        part = dcl.ops.linear_pool(x, Wt, bias, w)
+        assert torch.equal(part, dcl.ops.linear_pool(x, Wt, bias, w))
+        F = torch.relu(x.double() @ Wt.double() + bias.double()) * w.double()[:, None]
+        T = dcl.ops.LINEAR_POOL_TILE
+        tiles = (M + T - 1) // T
+        want = torch.stack([F[t * T:(t + 1) * T].sum(0) for t in range(tiles)])
+        assert part.shape == (tiles, n)
+        assert float((part.double() - want).abs().max()) <= 2e-5 * max(1e-3, float(want.abs().max())), (M, K, n)
 
 
 def test_pad_copy_many_stages_and_hands_over_in_one_launch(dcl):

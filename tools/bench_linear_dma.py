@@ -17,7 +17,7 @@ if TILES:
     L = use_diag(dcl)
 
 
-def timeit(fn, reps=10):
+def timeit(fn, reps=20):
     for _ in range(3): fn()
     torch.cuda.synchronize()
     a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -45,12 +45,16 @@ for M, K, n, ldx, ldy in SHAPES:
     yw = torch.empty(M, ldy, device="cuda")
     y = yw[:, ldy - n:]
     fl = 2.0 * M * K * n
-    t_lib = timeit(lambda: dcl.ops.linear(x, Wt, bias, True, out=y))
+    t_lib = timeit(lambda: dcl.ops.linear_lt(x, Wt, bias, True, out=y))
     t_own = timeit(lambda: dcl.ops.linear_dma(x, Wt, bias, True, out=y))
     line = "M=%6d K=%4d N=%4d: hipBLASLt %8.1f us (%5.1f TF)  own %8.1f us (%5.1f TF)  own/lib %.3f" % (
         M, K, n, t_lib, fl / t_lib / 1e6, t_own, fl / t_own / 1e6, t_own / t_lib)
+    if n == 1024 and K == 512:                            # the last fuser layer: the pooling epilogue instead of the store
+        w = torch.rand(M, device="cuda", generator=g)
+        t_pool = timeit(lambda: dcl.ops.linear_pool(x, Wt, bias, w))
+        line += "  pool-epilogue %8.1f us (%5.1f TF)" % (t_pool, fl / t_pool / 1e6)
     if TILES:
-        for t, name in ((1, "128x128"), (2, "128x64"), (3, "64x64"), (4, "64x128")):
+        for t, name in ((1, "128x128"), (2, "128x64"), (3, "64x64")):
             L.dcl_debug_linear_tile(t)
             tt = timeit(lambda: dcl.ops.linear_dma(x, Wt, bias, True, out=y))
             line += "  %s %.1f" % (name, fl / tt / 1e6)
@@ -60,7 +64,7 @@ for M, K, n, ldx, ldy in SHAPES:
         want = torch.relu(x[rows].double() @ Wt.double() + bias.double())
         dcl.ops.linear_dma(x, Wt, bias, True, out=y)
         e_own = float((y[rows].double() - want).abs().max())
-        dcl.ops.linear(x, Wt, bias, True, out=y)
+        dcl.ops.linear_lt(x, Wt, bias, True, out=y)
         e_lib = float((y[rows].double() - want).abs().max())
         line += "  |err| own %.2e lib %.2e" % (e_own, e_lib)
     print(line, flush=True)

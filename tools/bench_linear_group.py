@@ -52,5 +52,5 @@ for b in [int(x) for x in sys.argv[1:]] or [1, 2, 6]:
     print("b=%d conf + fuser stacks (3 + 3 layers): separate %.1f us, grouped %.1f us" % (b, graph_us(sep2), graph_us(grp2)))
     for d, (K, n) in enumerate(((512, 512), (512, 1024), (256, 256), (128, 128), (480, 1024))):
         x = torch.randn(M, K, device=dev); W = torch.randn(K, n, device=dev) * 0.03; bb = torch.randn(n, device=dev); o = torch.empty(M, n, device=dev)
-        print("   b=%d single %dx%dx%d: library %.1f us, own %.1f us" % (b, M, n, K, graph_us(lambda: ops.linear(x, W, bb, True, out=o)),
+        print("   b=%d single %dx%dx%d: library %.1f us, own %.1f us" % (b, M, n, K, graph_us(lambda: ops.linear_lt(x, W, bb, True, out=o)),
                                                                    graph_us(lambda: ops.linear_group([(x, W, bb, True, o)]))))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One linear-layer shape, one implementation, a few launches -- the subject of a rocprofv3 pass.
-usage: tools/lin_one.py M K N own|lib|pool [reps] [tile] [stagger]"""
+usage: tools/lin_one.py M K N own|lib|pool [reps] [tile]"""
 import importlib, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,15 +14,14 @@ if len(sys.argv) > 6:
     from _diag import use_diag
     L = use_diag(dcl)
     L.dcl_debug_linear_tile(int(sys.argv[6]))
-    if len(sys.argv) > 7:
-        L.dcl_debug_linear_stagger(int(sys.argv[7]))
+
 g = torch.Generator(device="cuda").manual_seed(1)
 x = torch.randn(M, K, device="cuda", generator=g)
 Wt = torch.randn(K, n, device="cuda", generator=g) * 0.05
 bias = torch.randn(n, device="cuda", generator=g)
 y = torch.empty(M, n, device="cuda")
 w = torch.rand(M, device="cuda", generator=g)
-fn = {"own": lambda: dcl.ops.linear_dma(x, Wt, bias, True, out=y), "lib": lambda: dcl.ops.linear(x, Wt, bias, True, out=y),
+fn = {"own": lambda: dcl.ops.linear_dma(x, Wt, bias, True, out=y), "lib": lambda: dcl.ops.linear_lt(x, Wt, bias, True, out=y),
       "pool": lambda: dcl.ops.linear_pool(x, Wt, bias, w)}[which]
 for _ in range(reps):
     fn()

@@ -1,7 +1,7 @@
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-ends = [i for i, r in enumerate(rows) if "k_ortho9d" in r["Kernel_Name"]]
+ends = [i for i, r in enumerate(rows) if "k_ortho9d" in r["Kernel_Name"]] or [i for i, r in enumerate(rows) if "k_heads_l23" in r["Kernel_Name"]]
 k = len(ends) // 2
 t0 = int(rows[ends[k]]["End_Timestamp"])
 step = rows[ends[k] + 1:ends[k + 1] + 1]

@@ -6,7 +6,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 min_us = float(sys.argv[2]) if len(sys.argv) > 2 else 40.0
 until = float(sys.argv[3]) if len(sys.argv) > 3 else 1e12
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-ends = [i for i, r in enumerate(rows) if "k_ortho9d" in r["Kernel_Name"]]
+ends = [i for i, r in enumerate(rows) if "k_ortho9d" in r["Kernel_Name"]] or [i for i, r in enumerate(rows) if "k_heads_l23" in r["Kernel_Name"]]
 k = len(ends) // 2
 t0 = int(rows[ends[k]]["End_Timestamp"])
 step = rows[ends[k] + 1:ends[k + 1] + 1]
