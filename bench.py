@@ -98,7 +98,8 @@ def measure_kernel_shares(shape, batch, timeout_s=300):
     for k in ("DCL_FORCE_DIST", "RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     SPARSE = "sparse feature stage (k_sparse_conv*, k_conv_frag*, k_sparse_avgpool*)"
-    fam = {"attention (k_cross_attn*)": 0.0, "vendor_gemm (hipBLASLt Cijk_*)": 0.0, SPARSE: 0.0, "other": 0.0}
+    fam = {"attention (k_cross_attn*)": 0.0, "own_gemm (k_linear_dma*, k_linear_group, k_mlp128_to1)": 0.0,
+           "vendor_gemm (hipBLASLt Cijk_*)": 0.0, SPARSE: 0.0, "other": 0.0}
     launches = {k: 0 for k in fam}
     try:
         subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s,
@@ -116,6 +117,8 @@ def measure_kernel_shares(shape, batch, timeout_s=300):
         rows = 0
         for t0, t1, name in trace[cut:]:
             key = ("attention (k_cross_attn*)" if "k_cross_attn" in name else
+                   "own_gemm (k_linear_dma*, k_linear_group, k_mlp128_to1)" if ("k_linear_dma" in name or "k_linear_group" in name
+                                                                                 or "k_mlp128_to1" in name) else
                    "vendor_gemm (hipBLASLt Cijk_*)" if name.startswith("Cijk_") else
                    SPARSE if ("k_sparse_conv" in name or "k_conv_frag" in name or "k_sparse_avgpool" in name) else "other")
             fam[key] += t1 - t0
@@ -213,18 +216,30 @@ def primitives_roofline(dcl, reps=5):
         torch.cuda.synchronize()
         ms = a.elapsed_time(b) / reps
         out[name] = {"ms": round(ms, 4), "GBps": round(nbytes / ms / 1e6, 1), "bytes": nbytes}
-    # ball_query is an exact brute-force search: its bound is the vector-instruction issue rate, not HBM.  Per
-    # candidate test the kernel issues 4.5 vector instructions (two tests per 3 packed subtractions + packed mul + 2 packed fma +
-    # packed compare-subtract + 2 v_alignbit); the chip issues 256 CUs x 64 lanes x 2.4 GHz lane-instructions per second.
+    # ball_query is an exact search: its bound is the vector-instruction issue rate, not HBM.  Per candidate
+    # test the kernel issues 4.5 vector instructions (two tests per 3 packed subtractions + packed mul + 2 packed fma + packed
+    # compare-subtract + 2 v_alignbit); the chip issues 256 CUs x 64 lanes x 2.4 GHz lane-instructions per second.  `frac` is
+    # priced on the tests the kernel EXECUTES: a workgroup of 16 centres scans the cloud in super-tiles of 1024
+    # candidates and stops before the first one that starts with all its centres full -- which the kernel's own output tells:
+    # a centre is full iff its last slot differs from its first (slots past the hit count repeat the first hit, ascending
+    # indices), and then the index in its last slot is where its scan could end.
     tests = float(B) * NP * N
+    idx = dcl.ops.ball_query(r, NS, xyz, new_xyz).long()
+    full = idx[:, :, -1] != idx[:, :, 0]
+    end_pt = torch.where(full, idx[:, :, -1] + 1, torch.full_like(idx[:, :, -1], N))           # candidates a centre needs scanned
+    wg_end = end_pt.view(B, NP // 16, 16).max(dim=2).values                                     # ... its workgroup (16 centres)
+    tiles = torch.clamp((wg_end + 1023) // 1024, max=(N + 1023) // 1024)
+    executed = float((torch.clamp(tiles * 1024, max=N) * 16).sum().item())
     bq_s = out["ball_query"]["ms"] * 1e-3
     valu_bound = 256 * 64 * 2.4e9 / 4.5
-    out["ball_query"].update({"bound": "valu (packed f32 issue)", "candidate_tests": tests,
-                              "tests_per_s": round(tests / bq_s, 1), "valu_bound_tests_per_s": round(valu_bound, 1),
-                              "frac_of_valu_bound": round(tests / bq_s / valu_bound, 3),
-                              "note": "brute-force-equivalent rate; above 1.0 because a workgroup stops scanning once its 16 "
-                                      "centres hold nsample hits (r = 0.03, nsample = 64 on these clouds: about half of the "
-                                      "candidates are never tested)"})
+    out["ball_query"].update({"bound": "valu (packed f32 issue)", "candidate_tests_brute_force": tests,
+                              "candidate_tests_executed": executed,
+                              "tests_per_s": round(executed / bq_s, 1), "valu_bound_tests_per_s": round(valu_bound, 1),
+                              "frac_of_valu_bound": round(executed / bq_s / valu_bound, 3),
+                              "speedup_over_scan": round(tests / executed, 3),
+                              "note": "frac = executed (centre, candidate) tests per second / the vector-issue bound; "
+                                      "speedup_over_scan = brute-force pairs / executed pairs (a workgroup stops scanning once "
+                                      "its 16 centres hold nsample hits)"})
     tot_b = out["ball_query"]["bytes"] + out["group_points"]["bytes"]
     tot_ms = out["ball_query"]["ms"] + out["group_points"]["ms"]
     out["ball_query+group_points"] = {"bound": "hbm", "achieved": round(tot_b / tot_ms / 1e6, 1), "peak": PEAK_HBM,
@@ -256,13 +271,33 @@ def primitives_roofline(dcl, reps=5):
         torch.cuda.synchronize()
         ms = a.elapsed_time(b) / reps
         out[name] = {"ms": round(ms, 4), "GBps": round(nbytes / ms / 1e6, 1), "bytes": nbytes}
-    # three_nn / knn (k = 1) are exact searches over the same B x N x npoint pairs as ball_query: reported against the same
-    # brute-force vector-issue bound; above 1.0 = the bucketed walk tests fewer pairs than a full scan would
+    # three_nn / knn (k = 1) are exact searches over the same B x N x npoint pairs as ball_query; the bucketed walk executes a
+    # fraction of them.  `frac` is priced on the EXECUTED (query, point) tests -- counted by the diagnostic build of the same
+    # kernels on the same inputs (tests/_diag: an atomic per scanned range; deterministic for given inputs) -- at 4 vector
+    # instructions per test (3 subtractions, mul, 2 fma: dcl_dist2; the key compare-exchanges are the kept minority);
+    # speedup_over_scan = brute-force pairs / executed pairs.
+    executed_nn = {}
+    try:
+        import ctypes
+        with dcl._native.diagnostic_library() as L:
+            L.dcl_debug_nn_tests_executed.restype = ctypes.c_ulonglong
+            for name, fn in (("three_nn", lambda: dcl.ops.three_nn(xyz, new_xyz)), ("knn1", lambda: dcl.ops.knn(1, xyz, new_xyz))):
+                L.dcl_debug_nn_tests_executed(1)
+                fn()
+                executed_nn[name] = float(L.dcl_debug_nn_tests_executed(1))
+    except (RuntimeError, AttributeError, OSError) as e:                  # no diagnostic library on this box: say so
+        executed_nn = {"error": str(e)[:120]}
+    valu_bound_nn = 256 * 64 * 2.4e9 / 6.0
     for name in ("three_nn", "knn1"):
         s_ = out[name]["ms"] * 1e-3
-        out[name].update({"bound": "valu (packed f32 issue), brute-force-equivalent pair rate", "candidate_tests": tests,
-                          "tests_per_s": round(tests / s_, 1), "valu_bound_tests_per_s": round(valu_bound, 1),
-                          "frac_of_valu_bound": round(tests / s_ / valu_bound, 3)})
+        ex = executed_nn.get(name)
+        out[name].update({"bound": "valu (f32 issue), 6 vector instructions per executed test", "candidate_tests_brute_force": tests,
+                          "candidate_tests_executed": ex, "valu_bound_tests_per_s": round(valu_bound_nn, 1),
+                          "tests_per_s": round(ex / s_, 1) if ex else None,
+                          "frac_of_valu_bound": round(ex / s_ / valu_bound_nn, 3) if ex else None,
+                          "speedup_over_scan": round(tests / ex, 3) if ex else None})
+        if not ex:
+            out[name]["note"] = "diagnostic library unavailable: executed tests not counted (%s)" % executed_nn.get("error")
     return out
 
 
@@ -632,25 +667,33 @@ def sparse_conv_roofline(dcl, net, data, dev, steps=3):
                            "mfma_bound_ms": round(t_mfma, 4), "l2_gather_bound_ms": round(t_gather, 4),
                            "bound": "mfma" if t_mfma >= t_gather else "l2-gather",
                            "frac_of_bound": round(max(t_mfma, t_gather) / ms_l, 4) if ms_l > 0 else None})
-    return {"kernel": "k_sparse_conv_* (8 conv layers x 2 backbones)", "bound": "mfma", "achieved": round(ach, 2),
-            "peak": PEAK_MFMA_F32, "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F32, 4),
-            "flop_per_forward": flop, "conv_ms_per_forward": round(ms_fwd, 4), "conv_calls_timed": timed["grouped"][1],
+    ms_sep = timed["separate"][0]
+    ach_sep = flop / (ms_sep * 1e-3) / 1e12 if ms_sep > 0 else float("nan")
+    # `achieved` / `frac` = the schedule the DEFAULT forward runs: each backbone's own launches; the grouped
+    # one-stream schedule (Network(single_stream=True)) under its own key, with the per-layer table taken on it
+    return {"kernel": "k_sparse_conv_* (8 conv layers x 2 backbones)", "bound": "mfma", "achieved": round(ach_sep, 2),
+            "peak": PEAK_MFMA_F32, "unit": "TFLOP/s", "frac": round(ach_sep / PEAK_MFMA_F32, 4),
+            "flop_per_forward": flop, "conv_ms_per_forward": round(ms_sep, 4), "conv_calls_timed": timed["separate"][1],
             "rulebook_density": round(flop / issued, 4) if issued else None,
             "pairs_per_forward": int(sum(p[5] for p in per_layer)),
-            "schedule": "one stream; every layer of the two backbones as ONE grouped launch (what Network(single_stream=True) "
-                        "runs); rows of the two deep levels ordered on the device (the ordering launches run in the geometry "
-                        "stage, outside the timed conv calls: 2 launches per backbone, see profiles/)",
+            "schedule": "each backbone's own launches (16 conv launches per forward: what the default two-stream forward "
+                        "issues), timed on one stream by HIP events inside the library",
+            "separate_launches": {"conv_ms_per_forward": round(ms_sep, 4), "conv_calls_timed": timed["separate"][1],
+                                  "frac": round(ach_sep / PEAK_MFMA_F32, 4) if ms_sep > 0 else None,
+                                  "what": "= the headline figures above (key kept for comparison with earlier rounds)"},
+            "grouped_single_stream": {
+                "conv_ms_per_forward": round(ms_fwd, 4), "conv_calls_timed": timed["grouped"][1], "achieved": round(ach, 2),
+                "frac": round(ach / PEAK_MFMA_F32, 4),
+                "schedule": "one stream; every layer of the two backbones as ONE grouped launch (what Network(single_stream=True) "
+                            "runs); rows of the two deep levels ordered on the device (the ordering launches run in the geometry "
+                            "stage, outside the timed conv calls: 2 launches per backbone, see profiles/)"},
             "layers": layers,
-            "layers_note": "bound per layer: max(useful flop / fp32 MFMA peak, pairs x Cin x 4 B / %.1f TB/s L2->LDS gather rate); "
-                           "frac_of_bound = that time / measured time" % (PEAK_L2_GATHER / 1e3),
+            "layers_note": "per layer of the GROUPED schedule (both backbones per launch).  bound per layer: max(useful flop / fp32 "
+                           "MFMA peak, pairs x Cin x 4 B / %.1f TB/s L2->LDS gather rate); frac_of_bound = that time / measured time"
+                           % (PEAK_L2_GATHER / 1e3),
             "feature_stage": dict(feature_stage_times(dcl, net, data, dev),
                                   what="convs + pools of both backbones stand-alone: a launch per layer and side / one grouped "
-                                       "launch per layer"),
-            "separate_launches": {"conv_ms_per_forward": round(timed["separate"][0], 4), "conv_calls_timed": timed["separate"][1],
-                                  "frac": round(flop / (timed["separate"][0] * 1e-3) / 1e12 / PEAK_MFMA_F32, 4)
-                                  if timed["separate"][0] > 0 else None,
-                                  "what": "the same forwards with each backbone's own launches (the default two-stream "
-                                          "schedule issues these, on two streams)"}}
+                                       "launch per layer")}
 
 
 def feature_stage_times(dcl, net, data, dev, reps=10):
@@ -860,24 +903,33 @@ def main():
                 "traffic_algorithmic": int(4 * b * (64 * (n_inp + n_tmp) + 320 * (n_inp + n_tmp))),
                 "avg_launch_ms": round(att_avg_ms, 4), "launches_timed": len(att_ms),
                 "flop_per_launch": flop_dir[0]}
-    # whose kernels the step's GPU time goes to: the named kernel is the dominant HAND-WRITTEN one; the
-    # largest single share belongs to the vendor library's GEMMs, like-for-like with the reference's cuBLAS / cuDNN calls
-    roofline["share_of_gpu_time"], roofline["vendor_gemm"] = None, None
+    # whose kernels the step's GPU time goes to: since round 6 the per-point linear layers run on the
+    # library's OWN fp32 MFMA GEMM core (csrc/linear_dma.hip; the last fuser layer with the pooling as its epilogue) -- no
+    # vendor GEMM is left on the forward, `vendor_gemm` reports what the trace still finds of it (expected: nothing)
+    roofline["share_of_gpu_time"], roofline["own_gemm"], roofline["vendor_gemm"] = None, None, None
     roofline["share_source"] = "not collected (N > 1, --no-extras or --no-traffic)"
     if rank == 0 and world == 1 and not args.no_extras and not args.no_traffic:
         shares, roofline["share_source"] = measure_kernel_shares(args.shape, b)
         if shares is not None:
             att, gem = shares["attention (k_cross_attn*)"], shares["vendor_gemm (hipBLASLt Cijk_*)"]
+            own = shares["own_gemm (k_linear_dma*, k_linear_group, k_mlp128_to1)"]
             gemm_flop = 3473664.0 * b * (n_inp + n_tmp) * shares["_forwards"]       # test-mode dense flop per point
             roofline["share_of_gpu_time"] = round(att["share"], 4)
+            own_tf = gemm_flop / (own["ns"] * 1e-9) / 1e12 if own["ns"] > 0 else None
+            roofline["own_gemm"] = {"kernels": "k_linear_dma<128,128 | 128,64 | 64,64> (+ pooling epilogue), k_linear_group, k_mlp128_to1",
+                                    "share_of_gpu_time": round(own["share"], 4), "bound": "mfma",
+                                    "achieved": round(own_tf, 1) if own_tf else None, "peak": PEAK_MFMA_F32, "unit": "TFLOP/s",
+                                    "frac": round(own_tf / PEAK_MFMA_F32, 4) if own_tf else None,
+                                    "launches_per_forward": own["launches"] // shares["_forwards"],
+                                    "note": "every 1x1x1-conv / head layer of the dense half: SURVEY 8d's dense flop per point over the "
+                                            "family's summed kernel time in the traced forward"}
             roofline["vendor_gemm"] = {"share_of_gpu_time": round(gem["share"], 4),
-                                       "TFLOPs": round(gemm_flop / (gem["ns"] * 1e-9) / 1e12, 1) if gem["ns"] > 0 else None,
                                        "launches_per_forward": gem["launches"] // shares["_forwards"],
-                                       "note": "hipBLASLt Tensile kernels (Cijk_*): every 1x1x1-conv / head layer of the dense half"}
+                                       "note": "hipBLASLt Tensile kernels (Cijk_*) found in the traced forward: none expected since round 6"}
             sp_key = [k for k in shares if k.startswith("sparse feature stage")][0]
             roofline["sparse_stage_share_of_gpu_time"] = round(shares[sp_key]["share"], 4)     # convs + combines + pools
-            roofline["note"] = ("k_cross_attn is the dominant hand-written kernel, not the dominant kernel family: the "
-                                "vendor GEMMs hold the largest share")
+            roofline["note"] = ("k_cross_attn is the dominant single kernel; the own GEMM family holds the largest share of the "
+                                "step -- both hand-written fp32 MFMA kernels of this library")
 
     # metric reduction over RCCL (outside the timed region): ADD-S table of this rank's crops
     with torch.no_grad():
@@ -977,6 +1029,20 @@ def main():
         line["primitives"] = primitives_roofline(dcl)
         line["refiner"] = refiner_bench(dcl, dev, b)
         line["cpu_baseline"] = cpu_baseline(dcl, sd, cfg, n_inp, n_tmp)
+    if world > 1 and not args.no_extras:
+        # BASELINE configs[2] ("YCB-V bs=40, 8 x MI355X frame-sharded"): every rank runs 40 crops of the shipped shape per call
+        # (N = M = 1024), same barrier-bracketed timing, MAX over ranks -- so that the first multi-GPU run measures the config
+        # BASELINE names and not only the stress one.  Every rank takes part (collectives inside).
+        rn, rm = SHAPES["ref"]
+        net40 = dcl.DCL_Net.Network(dcl.synth.default_cfg(rn, rm), mode="test")
+        net40.load_state_dict(dcl.synth.synth_state_dict(net40, 1))
+        net40 = net40.to(dev).eval()
+        d40 = to_device(dcl.synth.make_batch(40, rn, rm, first=40 * rank), dev)
+        dt40, _ = run_forward_bench(dcl, net40, d40, 20, 3, distributed)
+        line["bs40_per_rank"] = {"workload": "N=M=1024, bs=40 per GPU x %d GPUs (config_YCBV_bs40.yaml batch, frames sharded)" % world,
+                                 "unit": "frames/s", "value": round(world * 40 * 20 / dt40, 2), "n_gpus": world,
+                                 "ms_per_step": round(dt40 / 20 * 1e3, 3), "scaling": "weak"}
+        del net40, d40
     # the JSON line is the LAST thing on stdout: RCCL writes its banner ("RCCL version ...", "Librccl path ...") through C
     # stdio, which on a pipe is only flushed at exit -- i.e. behind a line printed here.  C stdout was made unbuffered in
     # main(); every rank flushes once more, and rank 0 prints after a barrier behind those flushes.

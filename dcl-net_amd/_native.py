@@ -25,9 +25,16 @@ def build(verbose=False, diag=False):
     return SO_PATH
 
 
+ABI_VERSION = 2                 # include/dclnet_hip.h: DCL_ABI_VERSION this package's ctypes calls are written against
+
+
 def _open(path):
     L = C.CDLL(path)
     L.dcl_last_error.restype = C.c_char_p
+    got = int(L.dcl_abi_version())
+    if got != ABI_VERSION:
+        raise RuntimeError("%s speaks C-ABI version %d, this package calls version %d (include/dclnet_hip.h): rebuild the "
+                           "library (make -C dcl-net_amd/csrc)" % (path, got, ABI_VERSION))
     return L
 
 

@@ -13,7 +13,7 @@ void dcl_set_error(const char *fmt, ...) {
 }
 
 extern "C" __attribute__((visibility("default"))) const char *dcl_last_error(void) { return g_err; }
-extern "C" __attribute__((visibility("default"))) int dcl_abi_version(void) { return 1; }
+extern "C" __attribute__((visibility("default"))) int dcl_abi_version(void) { return DCL_ABI_VERSION; }
 
 #ifdef DCL_DIAG
 // launch census of the diagnostic library (common.h): host stub -> launches since the last reset

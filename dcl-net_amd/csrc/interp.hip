@@ -486,6 +486,11 @@ __global__ __launch_bounds__(256) void k_three_nn(int n, int m, const float *__r
 // order of those keys, so the scan order is free -- and d2 = fma(dz,dz, fma(dx,dx, dy*dy)) >= fl(gap*gap) for the gap along ANY
 // one axis (rounding is monotonic), so a bucket whose nearest coordinate is further than the worst kept distance cannot
 // contribute, ties included (the walk stops on a strictly greater bound only).
+#ifdef DCL_DIAG
+// diagnostic library: (query, point) distance evaluations the bucketed search EXECUTES (every lane of a wave tests every point
+// the wave visits) -- bench.py prices the kernel against these, not against the brute-force pair count it no longer performs
+__device__ unsigned long long g_nn_tests_executed;
+#endif
 constexpr int kNNBuckets = 256;
 constexpr int kNNThreads = 512;           // QPT queries per thread: the bucket build (per workgroup) is shared by 512 * QPT queries
 template <int KB, int QPT>
@@ -649,6 +654,9 @@ __global__ __launch_bounds__(kNNThreads) void k_nn_bucketed(int n, int m, const 
     };
     auto scan_range = [&](int i0, int i1) {                                // every lane tests points [i0, i1): uniform bounds, broadcast reads
       int i = i0;
+#ifdef DCL_DIAG
+      if (lane == 0 && i1 > i0) atomicAdd(&g_nn_tests_executed, (unsigned long long)(i1 - i0) * 64ull);
+#endif
       for (; i + 8 <= i1; i += 8) {                                        // eight points' reads and distances in flight, entered in order
         float4 v[8];
         float d[8];
@@ -803,6 +811,17 @@ DCL_HOOK_INT(g_nn_batched_mode, 0);   // (diagnostic library) 1 = the batched th
 DCL_API void dcl_debug_three_nn_grid(int mode) { g_nn_grid = mode; }
 DCL_API void dcl_debug_nn_batched_mode(int mode) { g_nn_batched_mode = mode; }
 DCL_API void dcl_debug_nn_qpt(int q) { g_nn_qpt = q; }
+DCL_API unsigned long long dcl_debug_nn_tests_executed(int reset) {
+  unsigned long long v = 0;
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_nn_tests_executed), sizeof(v));
+  if (reset) {
+    const unsigned long long z = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_nn_tests_executed), &z, sizeof(z));
+  }
+  return v;
+}
+
 #endif
 
 // known_mask / S (optional): the level's occupancy bits and grid size; with them, levels of S = 16 or 32 go through the

@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void k_linear_dma(const LinDmaArgs a) {
 
 DCL_HOOK_INT(g_lin_tile, 0);          // diagnostic: 0 = automatic tile shape, 1 = 128x128, 2 = 128x64, 3 = 64x64
 DCL_HOOK_INT(g_lin_xcd, 1);
-DCL_HOOK_INT(g_lin_persist, 4);       // rounds of resident workgroups from which a launch is persistent (a huge value: never)
+DCL_HOOK_INT(g_lin_persist, 1 << 20); // rounds of resident workgroups from which a launch is PERSISTENT (default: never, see launch_linear_dma)
 
 int lin_cu_count() {                    // CUs of the current device (cached per device)
   static int cus[64] = {0};
@@ -322,12 +322,15 @@ int launch_linear_dma(const LinDmaArgs &a, hipStream_t stream) {
     dcl_set_error("dcl_linear_fwd: too many tiles");
     return DCL_EINVAL;
   }
-  // persistent workgroups: as many per CU as its 160 KiB of LDS admit (2 of the 128 x 128 tile's 64 KiB rings, 3 at 48 KiB, 4 at
-  // 32 KiB: small tiles are what launches of few rows take, and those want the extra waves), a multiple of 8 (XCD tile ranges)
+  // One workgroup per tile.  (The kernel's tile loop also runs PERSISTENT -- gridDim = the resident slots, every workgroup walking
+  // its share of the tiles with the next tile's first chunk fetched under the current tile's last one -- and alone on the GPU
+  // that is worth 5 % on the K = 256 layers (8 chunks per tile) and nothing at K = 480 / 512.  Inside a forward it measured
+  // nothing either way, and persistent workgroups hold their CU slots for the whole launch: whatever runs beside them -- the
+  // other direction's launches, the next call's sparse stage on its high-priority streams -- only gets in at their end.
+  // Same-job A/B of the stress step: 23.60 ms persistent, 23.52 one workgroup per tile, 23.46 with the side streams at high
+  // priority.  The diagnostic library keeps the switch: dcl_debug_linear_persist.)
   constexpr size_t lds = (size_t)2 * (BM + BN) * kLdKC * sizeof(float) + (EPI == 1 ? (BM + WGR * BN) * sizeof(float) : 0);
   constexpr int per_cu = (160 * 1024) / (int)lds > 4 ? 4 : (160 * 1024) / (int)lds;
-  // ... while a launch of fewer than four rounds of them is one workgroup per tile: the dispatcher balances what a fixed
-  // tile -> workgroup assignment would leave to the slowest workgroup (1.5 rounds = 2 tiles for some, 1 for the others)
   const long long slots = (long long)per_cu * lin_cu_count();
   const unsigned grid = (unsigned)(tiles >= (long long)g_lin_persist * slots ? slots : tiles);
   static bool attr_set = false;                            // (idempotent; a race sets it twice)

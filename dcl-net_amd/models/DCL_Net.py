@@ -32,6 +32,9 @@ from .Modules import (Aligner, Backbone_SPCONV, BasicBlock_3DCONV, Head_MultiLay
                       Ops_GetPointFeat_spconv)
 
 HOST_TIMES = None                   # tools/host_timeline.py sets this to a list: (label, perf_counter) marks of _forward_fused
+SIDE_STREAM_PRIORITY = -1    # the side streams carry the sparse half -- chains of short, latency-bound launches -- and get dispatch
+                            # priority over whatever GEMM / attention launch they meet (the previous call's tail under
+                            # async_inputs, the other direction's); read when a side stream is first made (0: A/B)
 _SIDE_STREAMS = {}          # (device index, which) -> torch.cuda.Stream, shared by every Network of the process
 SCALE_LISTS = [2, 4, 6, 8]          # sic -- reference models/DCL_Net.py:54 (true strides are 2,4,8,16)
 VOXEL_NUM_LIMIT = [64, 64, 64]
@@ -262,7 +265,7 @@ class Network(nn.Module):
         # second instance)
         key = (dev.index if dev.index is not None else torch.cuda.current_device(), which)
         if key not in _SIDE_STREAMS:
-            _SIDE_STREAMS[key] = torch.cuda.Stream(dev)
+            _SIDE_STREAMS[key] = torch.cuda.Stream(dev, priority=SIDE_STREAM_PRIORITY)
         return _SIDE_STREAMS[key]
 
     def _pipeline_chunks(self, b):
@@ -388,12 +391,14 @@ class Network(nn.Module):
         # the chip alone, and two stream-K launches side by side only take each other's workgroup slots (N = 12288 / M = 2048,
         # 32 crops: 23.65 -> 24.8 ms; issuing a side's disengage GEMMs under the other side's feature stage: 23.64, no gain --
         # the conv launch that meets a GEMM takes 3.2 ms instead of 0.13).
-        both_first = (self.HEAD_ORDER == 1 if self.HEAD_ORDER is not None else b * max(self.n_inp, self.n_tmp) <= 65536) and not paired
+        both_first = (self.HEAD_ORDER >= 1 if self.HEAD_ORDER is not None else b * max(self.n_inp, self.n_tmp) <= 65536) and not paired
+        early_dense = self.HEAD_ORDER == 2 and not paired
         if both_first:
             for side in ("inp", "tmp"):
                 geometry(side)
                 stage(side)
-        for side, bb in (() if paired else (("inp", "backbone_inp"), ("tmp", "backbone_tmp"))):
+        act = {}
+        for side, bb, dside in (() if paired else (("inp", "backbone_inp", "Xc"), ("tmp", "backbone_tmp", "Yo"))):
             n = npts[side]
             if not both_first:
                 geometry(side)
@@ -410,15 +415,21 @@ class Network(nn.Module):
                     runs[side, c].point_features(pb4[side][rows], extents, off, out=pf[side][rows])
                     done[side, c] = torch.cuda.Event()
                     done[side, c].record(sstream[side])
-        act = {}
-        for side, key in (("Xc", "inp"), ("Yo", "tmp")):
-            act.update(self._disengage_buffers(side, b * npts[key], dev))
+            if early_dense:
+                act.update(self._disengage_buffers(dside, b * n, dev))
+                for c in range(K):
+                    main.wait_event(done[side, c])
+                    rows = slice(c * bc * n, (c + 1) * bc * n)
+                    self._disengage(f, dside, pf[side][rows], act, rows)
         mark("sparse issued")
-        for c in range(K):                                                     # dense stage 1, chunk by chunk on main
+        if not early_dense:
             for side, key in (("Xc", "inp"), ("Yo", "tmp")):
-                main.wait_event(done[key, c])
-                rows = slice(c * bc * npts[key], (c + 1) * bc * npts[key])
-                self._disengage(f, side, pf[key][rows], act, rows)
+                act.update(self._disengage_buffers(side, b * npts[key], dev))
+            for c in range(K):                                                     # dense stage 1, chunk by chunk on main
+                for side, key in (("Xc", "inp"), ("Yo", "tmp")):
+                    main.wait_event(done[key, c])
+                    rows = slice(c * bc * npts[key], (c + 1) * bc * npts[key])
+                    self._disengage(f, side, pf[key][rows], act, rows)
         for st in sstream.values():
             main.wait_stream(st)
         # (launch by launch too, the tail's two directions run side by side -- on the observed side's stream, idle by now --

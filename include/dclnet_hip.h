@@ -30,6 +30,12 @@ extern "C" {
 typedef void *dclStream_t;
 
 const char *dcl_last_error(void);
+/* Version of THIS header's C ABI; a caller built against another version must not call in (dcl-net_amd/_native.py refuses to).
+ *   1  rounds 1-4
+ *   2  round 5-6: dcl_crop_points gained `int32_t *ws` in front of `stream`; dcl_backbone_features_stage,
+ *      dcl_backbone_stage_ws_bytes and DCL_ESTAGE_UNSUPPORTED are gone; dcl_linear_fwd ignores its workspace arguments;
+ *      new: dcl_linear_dma_fwd, dcl_linear_pool_fwd, dcl_conf_softmax, dcl_pool_finish2                                     */
+#define DCL_ABI_VERSION 2
 int dcl_abi_version(void);
 
 /* ------------------------------------------------------------------ PG_OP ---
@@ -598,6 +604,9 @@ void dcl_debug_three_nn_grid(int mode);
 void dcl_debug_nn_batched_mode(int mode);
 /* Tuning hook: queries per thread of the bucketed batched search (1..4; 0 = automatic). */
 void dcl_debug_nn_qpt(int q);
+/* Diagnostic: (query, point) distance evaluations the bucketed three_nn / knn searches have executed since the last reset
+ * (synchronises the device; reset != 0 zeroes the counter) -- what bench.py prices those kernels against. */
+unsigned long long dcl_debug_nn_tests_executed(int reset);
 /* Tuning hook: 0 = automatic split-K choice in dcl_sparse_conv_fwd_ws, n = force n splits (when the scratch allows),
  * -1 = at most 8 splits even for few-row launches, -2 = never split. */
 void dcl_debug_conv_split(int n);
@@ -611,7 +620,7 @@ void dcl_debug_conv_wlds(int on);
  * workgroup renumbering (default 1). */
 void dcl_debug_linear_tile(int t);
 void dcl_debug_linear_xcd_remap(int on);
-void dcl_debug_linear_persist(int rounds);   /* rounds of resident workgroups from which a GEMM launch is persistent (default 4) */
+void dcl_debug_linear_persist(int rounds);   /* rounds of resident workgroups from which a GEMM launch is persistent (default: never) */
 /* Diagnostic: times the GEMM library's first ncand heuristic candidates (32 MiB of workspace on offer) for an (M, N, K)
  * linear layer, each alone on the GPU; ms_out[i] = mean ms, ws_out[i] (may be NULL) = the workspace candidate i asks for.
  * dcl_linear_fwd itself only ever takes an algorithm that asks for none (it queries with a maximum of 0 bytes and refuses

@@ -35,7 +35,7 @@ def test_library_loads_and_exports_every_declared_symbol(dcl):
     lib = dcl._native.lib()
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
     assert not missing, missing
-    assert lib.dcl_abi_version() >= 1
+    assert lib.dcl_abi_version() == 2 == dcl._native.ABI_VERSION        # include/dclnet_hip.h: DCL_ABI_VERSION
 
 
 def test_product_library_has_no_hooks_and_the_diagnostic_library_has_them_all(dcl):
