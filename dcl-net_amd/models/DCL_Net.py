@@ -388,17 +388,16 @@ class Network(nn.Module):
         # Small calls issue BOTH sides' geometry stages before either side's level sizes are waited for: the second side's
         # feature stage then reaches the GPU ~0.25 ms after the first side's and the two run side by side (same-job A/B at
         # N = M = 1024, 32 crops: 4.005 -> 3.928 ms).  Large point counts keep one side after the other: their conv launches fill
-        # the chip alone, and two stream-K launches side by side only take each other's workgroup slots (N = 12288 / M = 2048,
-        # 32 crops: 23.65 -> 24.8 ms; issuing a side's disengage GEMMs under the other side's feature stage: 23.64, no gain --
-        # the conv launch that meets a GEMM takes 3.2 ms instead of 0.13).
-        both_first = (self.HEAD_ORDER >= 1 if self.HEAD_ORDER is not None else b * max(self.n_inp, self.n_tmp) <= 65536) and not paired
-        early_dense = self.HEAD_ORDER == 2 and not paired
+        # the chip alone (N = 12288 / M = 2048, 32 crops: both first 23.47 against 23.46 ms; measured the same within 0.1 %: the
+        # second side's convs chained behind the first side's by an event instead of by the host; a side's disengage GEMMs
+        # issued right behind its read-out, under the other side's feature stage -- the conv launch that meets a GEMM takes
+        # 3.2 ms instead of 0.13, the sparse prefix of the stress step is GPU time, not host time).
+        both_first = (self.HEAD_ORDER == 1 if self.HEAD_ORDER is not None else b * max(self.n_inp, self.n_tmp) <= 65536) and not paired
         if both_first:
             for side in ("inp", "tmp"):
                 geometry(side)
                 stage(side)
-        act = {}
-        for side, bb, dside in (() if paired else (("inp", "backbone_inp", "Xc"), ("tmp", "backbone_tmp", "Yo"))):
+        for side, bb in (() if paired else (("inp", "backbone_inp"), ("tmp", "backbone_tmp"))):
             n = npts[side]
             if not both_first:
                 geometry(side)
@@ -415,21 +414,15 @@ class Network(nn.Module):
                     runs[side, c].point_features(pb4[side][rows], extents, off, out=pf[side][rows])
                     done[side, c] = torch.cuda.Event()
                     done[side, c].record(sstream[side])
-            if early_dense:
-                act.update(self._disengage_buffers(dside, b * n, dev))
-                for c in range(K):
-                    main.wait_event(done[side, c])
-                    rows = slice(c * bc * n, (c + 1) * bc * n)
-                    self._disengage(f, dside, pf[side][rows], act, rows)
+        act = {}
+        for side, key in (("Xc", "inp"), ("Yo", "tmp")):
+            act.update(self._disengage_buffers(side, b * npts[key], dev))
         mark("sparse issued")
-        if not early_dense:
+        for c in range(K):                                                     # dense stage 1, chunk by chunk on main
             for side, key in (("Xc", "inp"), ("Yo", "tmp")):
-                act.update(self._disengage_buffers(side, b * npts[key], dev))
-            for c in range(K):                                                     # dense stage 1, chunk by chunk on main
-                for side, key in (("Xc", "inp"), ("Yo", "tmp")):
-                    main.wait_event(done[key, c])
-                    rows = slice(c * bc * npts[key], (c + 1) * bc * npts[key])
-                    self._disengage(f, side, pf[key][rows], act, rows)
+                main.wait_event(done[key, c])
+                rows = slice(c * bc * npts[key], (c + 1) * bc * npts[key])
+                self._disengage(f, side, pf[key][rows], act, rows)
         for st in sstream.values():
             main.wait_stream(st)
         # (launch by launch too, the tail's two directions run side by side -- on the observed side's stream, idle by now --
