@@ -57,12 +57,18 @@ struct LinDmaArgs {
 
 __device__ __forceinline__ int ld_rowmap(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
 
-template <int BM, int BN, int WGR, int EPI>
-__global__ __launch_bounds__(256, 2) void k_linear_dma(const LinDmaArgs a) {
+// KS = 2 (launches of few tiles: a handful of crops): EIGHT waves per tile, two groups of four that take the even / the odd
+// 32-deep chunks of K -- a tile's chain of chunks is half as long, which is what a launch that cannot fill the chip is bound
+// by -- each group with its own half of every ring stage; at the end group 1 hands its accumulators over through LDS and
+// group 0 adds them (acc0 + acc1: one fixed order) and runs the epilogue.
+template <int BM, int BN, int WGR, int EPI, int KS>
+__global__ __launch_bounds__(256 * KS, 2) void k_linear_dma(const LinDmaArgs a) {
   constexpr int WGC = 4 / WGR;
   constexpr int WM = BM / WGR, WN = BN / WGC;            // a wave's tile
   constexpr int MB = WM / 32, NB = WN / 32;              // ... in 32 x 32 MFMA blocks
-  constexpr int AT = BM * kLdKC, BT = kLdKC * BN, ST = AT + BT;     // floats per stage
+  constexpr int AT = BM * kLdKC, BT = kLdKC * BN, ST = AT + BT;     // floats per stage and wave group
+  constexpr int RING = 2 * KS * ST;                      // the whole ring: 2 stages x KS groups
+  static_assert(KS == 1 || (KS == 2 && EPI == 0), "the K split comes with the plain epilogue");
   constexpr int APW = BM / 32, BPW = BN / 32;            // 1-KiB DMA pieces per wave and chunk (A: 8 rows each; B: 1 KiB of k-rows)
   static_assert(APW == 2 || APW == 4, "x pieces per wave");
   static_assert(BPW == 2 || BPW == 4, "Wt pieces per wave");
@@ -90,10 +96,12 @@ __global__ __launch_bounds__(256, 2) void k_linear_dma(const LinDmaArgs a) {
     }
   }
   if (t_lo >= t_hi) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid = threadIdx.x, lane = tid & 63, wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = KS == 1 ? 0 : wave8 >> 2, wave = KS == 1 ? wave8 : (wave8 & 3);      // K group, wave inside it
   const int r = lane & 31, h = lane >> 5;
   const int wr = wave / WGC, wc = wave - wr * WGC;
-  const int nchunks = a.K / kLdKC;
+  const int kchunks = a.K / kLdKC;                         // 32-deep chunks of K
+  const int nchunks = (kchunks + KS - 1) / KS;             // steps of the chunk loop: group g takes chunk step * KS + g
   const long long bchunk = (long long)kLdKC * a.ldw;
   const unsigned lds0 = ld_lds_addr(ld_lds);
   const int n4 = (a.N + 3) & ~3;
@@ -122,34 +130,42 @@ __global__ __launch_bounds__(256, 2) void k_linear_dma(const LinDmaArgs a) {
       const int bcol = min(pcol0 + ((lane % BLPR) << 2), n4 - 4) - pcol0;       // (a row of Wt holds N rounded up to 4 floats)
       boff[i] = (unsigned)(((long long)bkk * a.ldw + bcol) * 4);
     }
-    abase = a.x + (size_t)prow0 * a.ldx;
-    bbase = a.Wt + pcol0;
+    abase = a.x + (size_t)prow0 * a.ldx + grp * kLdKC;
+    bbase = a.Wt + pcol0 + (size_t)grp * bchunk;
   };
   auto producer_advance = [&]() {                          // behind the last piece of a chunk
     if (++p_chunk < nchunks) {
-      abase += kLdKC;
-      bbase += bchunk;
+      abase += KS * kLdKC;
+      bbase += KS * bchunk;
     } else {
       p_chunk = 0;
       p_tile += t_stride;
       if (p_tile < t_hi) producer_tile();
     }
   };
-  auto issue_a = [&](int i, int stage) { ld_glds16_s(aoff[i], abase, lds0 + (unsigned)((stage * ST + (APW * wave + i) * 256) * 4)); };
-  auto issue_b = [&](int i, int stage) { ld_glds16_s(boff[i], bbase, lds0 + (unsigned)((stage * ST + AT + (BPW * wave + i) * 256) * 4)); };
+  // (a group whose chunk of the producer's step lies past K -- the odd group in the last step of an odd chunk count -- fetches
+  //  nothing and, below, multiplies nothing)
+  auto issue_a = [&](int i, int stage) {
+    if (KS == 1 || p_chunk * KS + grp < kchunks)
+      ld_glds16_s(aoff[i], abase, lds0 + (unsigned)(((stage * KS + grp) * ST + (APW * wave + i) * 256) * 4));
+  };
+  auto issue_b = [&](int i, int stage) {
+    if (KS == 1 || p_chunk * KS + grp < kchunks)
+      ld_glds16_s(boff[i], bbase, lds0 + (unsigned)(((stage * KS + grp) * ST + AT + (BPW * wave + i) * 256) * 4));
+  };
 
   const int sw = (r >> 1) & 7;
-  const float *arow0 = ld_lds + (wr * WM + r) * kLdKC;
-  const float *bcol0 = ld_lds + AT + wc * WN + r + 4 * h * BN;
+  const float *arow0 = ld_lds + grp * ST + (wr * WM + r) * kLdKC;
+  const float *bcol0 = ld_lds + grp * ST + AT + wc * WN + r + 4 * h * BN;
   // operand fragments of one 8-deep k step: x[row][8i + 4h .. +3] per 32-row block (one b128), Wt[8i + 4h + q][col] per column block
   struct Frag { float4 a[MB]; float b[NB][4]; };
   auto load_a = [&](Frag &f, int stage, int i) {
-    const float *arow = arow0 + stage * ST;
+    const float *arow = arow0 + stage * KS * ST;
 #pragma unroll
     for (int m = 0; m < MB; ++m) f.a[m] = *reinterpret_cast<const float4 *>(arow + m * 32 * kLdKC + (((2 * i + h) ^ sw) << 2));
   };
   auto load_b = [&](Frag &f, int stage, int i, int n) {
-    const float *bcol = bcol0 + stage * ST;
+    const float *bcol = bcol0 + stage * KS * ST;
 #pragma unroll
     for (int q = 0; q < 4; ++q) f.b[n][q] = bcol[(8 * i + q) * BN + n * 32];
   };
@@ -183,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void k_linear_dma(const LinDmaArgs a) {
     if constexpr (EPI == 1) {                              // the tile's row weights -> LDS behind the ring (read by the epilogue;
       if (tid < BM) {                                      //  the previous tile's epilogue ended with a barrier)
         const int row = row0 + tid, crop = row / a.rows_per_crop;
-        ld_lds[2 * ST + tid] = row < a.M ? a.roww[(size_t)crop * a.w_stride + (row - crop * a.rows_per_crop)] : 0.0f;
+        ld_lds[RING + tid] = row < a.M ? a.roww[(size_t)crop * a.w_stride + (row - crop * a.rows_per_crop)] : 0.0f;
       }
     }
     for (int c = 0; c < nchunks; ++c, ++cc) {
@@ -197,19 +213,24 @@ __global__ __launch_bounds__(256, 2) void k_linear_dma(const LinDmaArgs a) {
       // slice of the NEXT step's fragment reads, or one DMA piece (steps 0 and 1: they need the rest of the chunk to land) --
       // so that nothing but the first fragment of a chunk is ever waited for.  The scheduler is pinned group by group (left
       // alone it reads each step's operands right before using them and issues the DMAs back to back).
+      const bool mine = KS == 1 || c * KS + grp < kchunks;  // (wave-uniform) this group has a chunk in this step
       Frag f[2];
-      load_a(f[0], st, 0);
+      if (mine) {
+        load_a(f[0], st, 0);
 #pragma unroll
-      for (int n = 0; n < NB; ++n) load_b(f[0], st, 0, n);
+        for (int n = 0; n < NB; ++n) load_b(f[0], st, 0, n);
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          mfma_group(f[i & 1], q);
-          if (i < 3) {
-            if (q == 0) load_a(f[(i + 1) & 1], st, i + 1);
-            else if (q - 1 < NB) load_b(f[(i + 1) & 1], st, i + 1, q - 1);
+          if (mine) {
+            mfma_group(f[i & 1], q);
+            if (i < 3) {
+              if (q == 0) load_a(f[(i + 1) & 1], st, i + 1);
+              else if (q - 1 < NB) load_b(f[(i + 1) & 1], st, i + 1, q - 1);
+            }
           }
           if (more && i == 0 && q < BPW) issue_b(q, st ^ 1);
           if (more && i == 1 && q < APW) issue_a(q, st ^ 1);
@@ -222,7 +243,30 @@ __global__ __launch_bounds__(256, 2) void k_linear_dma(const LinDmaArgs a) {
     }
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");      // MFMA -> VALU read of the accumulators
 
+    if constexpr (KS == 2) {
+      // group 1's partial sums -> LDS behind the ring (the ring may already be receiving the next tile's first chunk) -> group 0
+      float *xch = ld_lds + RING + ((wave * MB * NB) * 16) * 64 + lane;
+      if (grp == 1) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+          for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) xch[((m * NB + n) * 16 + e) * 64] = acc[m][n][e];
+      }
+      dcl_lds_barrier();
+      if (grp == 0) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+          for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][n][e] = acc[m][n][e] + xch[((m * NB + n) * 16 + e) * 64];
+      }
+      dcl_lds_barrier();                                   // (the next tile's group 1 rewrites the exchange area)
+    }
     if constexpr (EPI == 0) {
+      if (KS == 2 && grp == 1) continue;                   // group 0 holds the sums
       float *__restrict__ y = a.y;
       const bool whole = row0 + BM <= a.M && col0 + BN <= a.N;     // (workgroup-uniform) interior tile: no per-element checks
       float bias[NB];
@@ -264,8 +308,8 @@ __global__ __launch_bounds__(256, 2) void k_linear_dma(const LinDmaArgs a) {
       // waves of a column through LDS in wave order -- a fixed order, the same bits every run.  (The tile's row weights sit
       // in LDS behind the ring since the tile's first barrier; the sums go behind them: the ring itself may be receiving the
       // next tile's first chunk.)
-      const float *wl = ld_lds + 2 * ST + wr * WM + 4 * h;
-      float *red = ld_lds + 2 * ST + BM;                   // [WGR][BN]
+      const float *wl = ld_lds + RING + wr * WM + 4 * h;
+      float *red = ld_lds + RING + BM;                     // [WGR][BN]
 #pragma unroll
       for (int n = 0; n < NB; ++n) {
         const int cl = wc * WN + n * 32 + r, co = col0 + cl;
@@ -299,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void k_linear_dma(const LinDmaArgs a) {
   }
 }
 
-DCL_HOOK_INT(g_lin_tile, 0);          // diagnostic: 0 = automatic tile shape, 1 = 128x128, 2 = 128x64, 3 = 64x64
+DCL_HOOK_INT(g_lin_tile, 0);          // diagnostic: 0 = automatic tile shape, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 64x64 with K split over 8 waves
 DCL_HOOK_INT(g_lin_xcd, 1);
 DCL_HOOK_INT(g_lin_persist, 1 << 20); // rounds of resident workgroups from which a launch is PERSISTENT (default: never, see launch_linear_dma)
 
@@ -315,7 +359,7 @@ int lin_cu_count() {                    // CUs of the current device (cached per
   return cus[dev];
 }
 
-template <int BM, int BN, int WGR, int EPI>
+template <int BM, int BN, int WGR, int EPI, int KS = 1>
 int launch_linear_dma(const LinDmaArgs &a, hipStream_t stream) {
   const long long tiles = (long long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   if (tiles > 0x7fffffffll) {
@@ -329,16 +373,17 @@ int launch_linear_dma(const LinDmaArgs &a, hipStream_t stream) {
   // other direction's launches, the next call's sparse stage on its high-priority streams -- only gets in at their end.
   // Same-job A/B of the stress step: 23.60 ms persistent, 23.52 one workgroup per tile, 23.46 with the side streams at high
   // priority.  The diagnostic library keeps the switch: dcl_debug_linear_persist.)
-  constexpr size_t lds = (size_t)2 * (BM + BN) * kLdKC * sizeof(float) + (EPI == 1 ? (BM + WGR * BN) * sizeof(float) : 0);
+  constexpr size_t lds = (size_t)2 * KS * (BM + BN) * kLdKC * sizeof(float) + (EPI == 1 ? (BM + WGR * BN) * sizeof(float) : 0) +
+                         (KS == 2 ? (size_t)BM * BN * sizeof(float) : 0);
   constexpr int per_cu = (160 * 1024) / (int)lds > 4 ? 4 : (160 * 1024) / (int)lds;
   const long long slots = (long long)per_cu * lin_cu_count();
   const unsigned grid = (unsigned)(tiles >= (long long)g_lin_persist * slots ? slots : tiles);
   static bool attr_set = false;                            // (idempotent; a race sets it twice)
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)k_linear_dma<BM, BN, WGR, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void *)k_linear_dma<BM, BN, WGR, EPI, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_linear_dma<BM, BN, WGR, EPI>), dim3(grid), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((k_linear_dma<BM, BN, WGR, EPI, KS>), dim3(grid), dim3(256 * KS), lds, stream, a);
   return 0;
 }
 
@@ -361,7 +406,7 @@ static bool lin_dma_ok(const float *x, int64_t ldx, const float *Wt, int64_t ldw
 // 2 = 128 x 64, 3 = 64 x 64.
 static int lin_pick_tile(int M, int N) {
   const int forced = (int)g_lin_tile;
-  if (forced >= 1 && forced <= 3) return forced;
+  if (forced >= 1 && forced <= 4) return forced;
   const int cus = lin_cu_count();
   static const int bm[3] = {128, 128, 64}, bn[3] = {128, 64, 64};
   static const double eff[3] = {1.0, 0.96, 0.93};
@@ -382,10 +427,14 @@ DCL_API int dcl_linear_dma_fwd(const float *x, int64_t ldx, const float *Wt, int
   DCL_CHECK_ARG(lin_dma_ok(x, ldx, Wt, ldw, N, K));
   if (M == 0) return 0;
   LinDmaArgs a{x, Wt, bias, y, ldx, ldw, ldy, M, N, K, relu, nullptr, 1, 0, nullptr, 0, (int)g_lin_xcd};
-  int rc;
-  switch (lin_pick_tile(M, N)) {
+  int rc, tile = lin_pick_tile(M, N);
+  // a launch of 64 x 64 tiles that cannot even give every CU two of them is bound by ONE tile's chain of chunks: eight waves per
+  // tile then, the two halves of K side by side (k_linear_dma<.., KS = 2>)
+  if (tile == 3 && (int)g_lin_tile == 0 && (long long)((M + 63) / 64) * ((N + 63) / 64) <= 2ll * lin_cu_count() && K >= 4 * kLdKC) tile = 4;
+  switch (tile) {
     case 1: rc = launch_linear_dma<128, 128, 2, 0>(a, (hipStream_t)stream); break;
     case 2: rc = launch_linear_dma<128, 64, 2, 0>(a, (hipStream_t)stream); break;
+    case 4: rc = launch_linear_dma<64, 64, 2, 0, 2>(a, (hipStream_t)stream); break;
     default: rc = launch_linear_dma<64, 64, 2, 0>(a, (hipStream_t)stream); break;
   }
   if (rc) return rc;

@@ -54,7 +54,7 @@ for M, K, n, ldx, ldy in SHAPES:
         t_pool = timeit(lambda: dcl.ops.linear_pool(x, Wt, bias, w))
         line += "  pool-epilogue %8.1f us (%5.1f TF)" % (t_pool, fl / t_pool / 1e6)
     if TILES:
-        for t, name in ((1, "128x128"), (2, "128x64"), (3, "64x64")):
+        for t, name in ((1, "128x128"), (2, "128x64"), (3, "64x64"), (4, "64x64 K/2")):
             L.dcl_debug_linear_tile(t)
             tt = timeit(lambda: dcl.ops.linear_dma(x, Wt, bias, True, out=y))
             line += "  %s %.1f" % (name, fl / tt / 1e6)
