@@ -50,7 +50,8 @@ struct LinDmaArgs {
   const float *roww;     // EPI 1: row j (crop j / rows_per_crop, point j % rows_per_crop) weighs roww[crop * w_stride + point]
   int rows_per_crop;
   long long w_stride;
-  float *part;           // EPI 1: [row tiles][ldp] partial weighted column sums
+  float *part;           // EPI 1: [row tiles][ldp] partial weighted column sums;  EPI 2: out[M] (roww = w3 with stride w_stride)
+  const float *b3;       // EPI 2: the last layer's bias (one float)
   long long ldp;
   int xcd_remap;
 };
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(256 * KS, 2) void k_linear_dma(const LinDmaArgs a) 
   constexpr int AT = BM * kLdKC, BT = kLdKC * BN, ST = AT + BT;     // floats per stage and wave group
   constexpr int RING = 2 * KS * ST;                      // the whole ring: 2 stages x KS groups
   static_assert(KS == 1 || (KS == 2 && EPI == 0), "the K split comes with the plain epilogue");
+  static_assert(EPI != 2 || WGR * WGC == 4, "row-dot epilogue");
   constexpr int APW = BM / 32, BPW = BN / 32;            // 1-KiB DMA pieces per wave and chunk (A: 8 rows each; B: 1 KiB of k-rows)
   static_assert(APW == 2 || APW == 4, "x pieces per wave");
   static_assert(BPW == 2 || BPW == 4, "Wt pieces per wave");
@@ -303,6 +305,37 @@ __global__ __launch_bounds__(256 * KS, 2) void k_linear_dma(const LinDmaArgs a) 
             }
           }
       }
+    } else if constexpr (EPI == 2) {
+      // row-dot epilogue (the confidence regressor's last two layers, models/DCL_Net.py:115-126: ... -> 128 -> 1): the tile
+      // spans all N <= BN columns;  out[row] = sum_c relu(acc[row][c] + bias[c]) * w3[c] + b3  -- per lane over its column
+      // blocks, over the 32 lanes of a half wave by a butterfly, over the WGC waves of a row through LDS in wave order.
+      float w3c[NB], bias[NB];
+#pragma unroll
+      for (int n = 0; n < NB; ++n) {
+        const int co = col0 + wc * WN + n * 32 + r;
+        bias[n] = (a.bias && co < a.N) ? a.bias[co] : 0.0f;
+        w3c[n] = co < a.N ? a.roww[(size_t)co * a.w_stride] : 0.0f;
+      }
+      float *red = ld_lds + RING;                          // [WGC][BM]
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          float sdot = 0.0f;
+#pragma unroll
+          for (int n = 0; n < NB; ++n) sdot = __fmaf_rn(fmaxf(acc[m][n][e] + bias[n], 0.0f), w3c[n], sdot);
+#pragma unroll
+          for (int d = 16; d >= 1; d >>= 1) sdot += __shfl_xor(sdot, d, 64);
+          if (r == 0) red[wc * BM + wr * WM + m * 32 + ld_rowmap(e, h)] = sdot;
+        }
+      dcl_lds_barrier();
+      if (tid < BM && row0 + tid < a.M) {
+        float sdot = red[tid];
+#pragma unroll
+        for (int w = 1; w < WGC; ++w) sdot += red[w * BM + tid];
+        a.part[row0 + tid] = sdot + a.b3[0];
+      }
+      dcl_lds_barrier();                                   // (the next tile rewrites the sums)
     } else {
       // weighted column sums of the tile's rows: per wave over its WM rows (registers, then the two lane halves), then the WGR
       // waves of a column through LDS in wave order -- a fixed order, the same bits every run.  (The tile's row weights sit
@@ -345,7 +378,7 @@ __global__ __launch_bounds__(256 * KS, 2) void k_linear_dma(const LinDmaArgs a) 
 
 DCL_HOOK_INT(g_lin_tile, 0);          // diagnostic: 0 = automatic tile shape, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 64x64 with K split over 8 waves
 DCL_HOOK_INT(g_lin_xcd, 1);
-DCL_HOOK_INT(g_lin_persist, 1 << 20); // rounds of resident workgroups from which a launch is PERSISTENT (default: never, see launch_linear_dma)
+DCL_HOOK_INT(g_lin_persist, 1 << 20); // rounds of resident workgroups from which a launch is PERSISTENT (1 << 20: by K, see launch_linear_dma)
 
 int lin_cu_count() {                    // CUs of the current device (cached per device)
   static int cus[64] = {0};
@@ -372,12 +405,16 @@ int launch_linear_dma(const LinDmaArgs &a, hipStream_t stream) {
   // nothing either way, and persistent workgroups hold their CU slots for the whole launch: whatever runs beside them -- the
   // other direction's launches, the next call's sparse stage on its high-priority streams -- only gets in at their end.
   // Same-job A/B of the stress step: 23.60 ms persistent, 23.52 one workgroup per tile, 23.46 with the side streams at high
-  // priority.  The diagnostic library keeps the switch: dcl_debug_linear_persist.)
+  // priority.  So only the short-K launches walk (below); the diagnostic library has the switch: dcl_debug_linear_persist.)
   constexpr size_t lds = (size_t)2 * KS * (BM + BN) * kLdKC * sizeof(float) + (EPI == 1 ? (BM + WGR * BN) * sizeof(float) : 0) +
+                         (EPI == 2 ? (size_t)(4 / WGR) * BM * sizeof(float) : 0) +
                          (KS == 2 ? (size_t)BM * BN * sizeof(float) : 0);
   constexpr int per_cu = (160 * 1024) / (int)lds > 4 ? 4 : (160 * 1024) / (int)lds;
   const long long slots = (long long)per_cu * lin_cu_count();
-  const unsigned grid = (unsigned)(tiles >= (long long)g_lin_persist * slots ? slots : tiles);
+  // (short K -- the K = 128 / 256 layers, 4-8 chunks per tile -- is where the walk pays: a tile's first fetch is a quarter of
+  //  its life; those launches are persistent from four rounds of slots on)
+  const long long rounds = (int)g_lin_persist != (1 << 20) ? (long long)g_lin_persist : (a.K <= 256 ? 4 : (1 << 20));
+  const unsigned grid = (unsigned)(tiles >= rounds * slots ? slots : tiles);
   static bool attr_set = false;                            // (idempotent; a race sets it twice)
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void *)k_linear_dma<BM, BN, WGR, EPI, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -426,7 +463,7 @@ DCL_API int dcl_linear_dma_fwd(const float *x, int64_t ldx, const float *Wt, int
   DCL_CHECK_ARG(M >= 0 && N > 0 && K > 0 && x && Wt && y && ldx >= K && ldw >= N && ldy >= N);
   DCL_CHECK_ARG(lin_dma_ok(x, ldx, Wt, ldw, N, K));
   if (M == 0) return 0;
-  LinDmaArgs a{x, Wt, bias, y, ldx, ldw, ldy, M, N, K, relu, nullptr, 1, 0, nullptr, 0, (int)g_lin_xcd};
+  LinDmaArgs a{x, Wt, bias, y, ldx, ldw, ldy, M, N, K, relu, nullptr, 1, 0, nullptr, nullptr, 0, (int)g_lin_xcd};
   int rc, tile = lin_pick_tile(M, N);
   // a launch of 64 x 64 tiles that cannot even give every CU two of them is bound by ONE tile's chain of chunks: eight waves per
   // tile then, the two halves of K side by side (k_linear_dma<.., KS = 2>)
@@ -448,8 +485,20 @@ DCL_API int dcl_linear_pool_fwd(const float *x, int64_t ldx, const float *Wt, in
   DCL_CHECK_ARG(M > 0 && N > 0 && K > 0 && x && Wt && roww && part && ldx >= K && ldw >= N && ldp >= N && rows_per_crop >= 1 &&
                 w_stride >= 0);
   DCL_CHECK_ARG(lin_dma_ok(x, ldx, Wt, ldw, N, K));
-  LinDmaArgs a{x, Wt, bias, nullptr, ldx, ldw, 0, M, N, K, relu, roww, rows_per_crop, w_stride, part, ldp, (int)g_lin_xcd};
+  LinDmaArgs a{x, Wt, bias, nullptr, ldx, ldw, 0, M, N, K, relu, roww, rows_per_crop, w_stride, part, nullptr, ldp, (int)g_lin_xcd};
   int rc = launch_linear_dma<128, 128, 2, 1>(a, (hipStream_t)stream);
+  if (rc) return rc;
+  DCL_LAUNCH_CHECK();
+  return 0;
+}
+
+DCL_API int dcl_linear_rowdot_fwd(const float *x, int64_t ldx, const float *Wt, int64_t ldw, const float *bias, const float *w3,
+                                  int64_t ldw3, const float *b3, float *out, int M, int N, int K, dclStream_t stream) {
+  DCL_CHECK_ARG(M >= 0 && N > 0 && N <= 128 && K > 0 && x && Wt && w3 && b3 && out && ldx >= K && ldw >= N && ldw3 >= 1);
+  DCL_CHECK_ARG(lin_dma_ok(x, ldx, Wt, ldw, N, K));
+  if (M == 0) return 0;
+  LinDmaArgs a{x, Wt, bias, nullptr, ldx, ldw, 0, M, N, K, 1, w3, 1, ldw3, out, b3, 0, (int)g_lin_xcd};
+  int rc = launch_linear_dma<128, 128, 2, 2>(a, (hipStream_t)stream);
   if (rc) return rc;
   DCL_LAUNCH_CHECK();
   return 0;

@@ -463,9 +463,10 @@ class Network(nn.Module):
     _DIS_TAGS = (("p1", 256), ("m1", 64), ("p2", 256), ("m2", 64))
     POSE_HEADS_MAX = 128      # crops up to which the two pose heads run as dcl_pose_heads (two launches) instead of six library
                               # GEMMs + glue (same-job A/B: 8 crops -3.4 %, 12: -2.8 %, 16: -2 %, 32: -0.9 %, 40: -1.2 % of the forward)
-    CONF_MLP_ROWS = 1 << 30   # point rows up to which the confidence regressor runs as one launch (ops.mlp128_to1; same-job A/B
-                              # against the three library GEMMs, graph replay: 12 crops 1.654 vs 1.663 ms, 16: 2.135 vs 2.142,
-                              # 24: 3.195 vs 3.205, 32: 3.774 vs 3.785, 40: 4.816 vs 4.816 -- never slower, so no bound)
+    CONF_MLP_ROWS = 16384     # point rows up to which the confidence regressor runs as ONE launch (ops.mlp128_to1: both filters in LDS,
+                              # the hidden rows never leave the CU -- one workgroup per CU, 0.4 of the MFMA rate); beyond, as two GEMMs
+                              # of the own core, the second with the 128 -> 1 row dot as its epilogue (ops.linear_rowdot): stand-alone
+                              # 393216 rows 421 -> 259 us, 65536: 72 -> 49, 32768: 37 -> 32, 6144: 12 against 23 (hence the bound)
     POSE_PARTS_MAX = 8        # crops up to which the pooling's finish is folded into the heads' first launch (a launch less)
     PAR_TAIL = None           # None = by shape (_tail_parallel); True / False force the dense tail's two directions onto two
                               # streams / one (A/B runs)
@@ -551,7 +552,8 @@ class Network(nn.Module):
         def conf_logits(conf_in, conf_layers):
             if conf_in.shape[0] <= self.CONF_MLP_ROWS:
                 return ops.mlp128_to1(conf_in, conf_layers)                 # (three K = 128 layers in one launch)
-            return self._mlp(conf_in, conf_layers)
+            (W1t, b1), (W2t, b2), (W3t, b3) = conf_layers
+            return ops.linear_rowdot(self._lin_relu(conf_in, W1t, b1), W2t, b2, W3t, b3)
         fused_pool = (b > self.POSE_PARTS_MAX and self.n_inp % ops.LINEAR_POOL_TILE == 0 and
                       self.n_tmp % ops.LINEAR_POOL_TILE == 0)
         if fused_pool:

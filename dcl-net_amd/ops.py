@@ -911,6 +911,24 @@ def linear_pool(x, Wt, bias, roww, relu=True, part=None, rows_per_crop=None, w_s
     return part
 
 
+def linear_rowdot(x, Wt, bias, w3, b3, out=None):
+    """out[m] = w3 . relu(x[m] @ Wt + bias) + b3: the last two layers of a one-output head (regressor_conf: 128 -> 128 -> 1) as ONE
+    GEMM of the own core with the row dot as its epilogue (csrc/linear_dma.hip, EPI = 2) -- the hidden columns are never stored.
+    x (M,K), Wt (K,N <= 128), bias (N,), w3 (N,1) (rows may be padded: pad_linear_weight), b3 (1,) -> (M,1)."""
+    N.need_cuda(x, Wt, w3, b3)
+    M, K = x.shape
+    n = Wt.shape[1]
+    assert n <= 128 and w3.shape == (n, 1) and b3.numel() == 1 and bias.numel() == n
+    if out is None:
+        out = torch.empty((M, 1), dtype=torch.float32, device=x.device)
+    assert out.is_contiguous() and out.numel() == M
+    pitch = lambda t: int(t.stride(0)) if t.shape[0] > 1 else max(int(t.stride(0)), int(t.shape[1]))   # noqa: E731
+    N.check(N.lib().dcl_linear_rowdot_fwd(N.ptr(x), C.c_int64(pitch(x)), N.ptr(Wt), C.c_int64(pitch(Wt)), N.ptr(bias), N.ptr(w3),
+                                          C.c_int64(int(w3.stride(0))), N.ptr(b3), N.ptr(out), int(M), int(n), int(K), N.stream()),
+            "linear_rowdot_fwd")
+    return out
+
+
 def conf_softmax(b, logit1, logit2):
     """the softmax half of conf_pool alone: logits (b*n1,), (b*n2,) -> conf (b, n1+n2) = sigmoid, w (b, n1+n2) = softmax(conf)
     per crop, wsum (b, 2) (models/DCL_Net.py:217-222)"""

@@ -34,7 +34,7 @@ const char *dcl_last_error(void);
  *   1  rounds 1-4
  *   2  round 5-6: dcl_crop_points gained `int32_t *ws` in front of `stream`; dcl_backbone_features_stage,
  *      dcl_backbone_stage_ws_bytes and DCL_ESTAGE_UNSUPPORTED are gone; dcl_linear_fwd ignores its workspace arguments;
- *      new: dcl_linear_dma_fwd, dcl_linear_pool_fwd, dcl_conf_softmax, dcl_pool_finish2                                     */
+ *      new: dcl_linear_dma_fwd, dcl_linear_pool_fwd, dcl_linear_rowdot_fwd, dcl_conf_softmax, dcl_pool_finish2                                   */
 #define DCL_ABI_VERSION 2
 int dcl_abi_version(void);
 
@@ -452,6 +452,11 @@ int dcl_linear_dma_fwd(const float *x, int64_t ldx, const float *Wt, int64_t ldw
 int dcl_linear_pool_fwd(const float *x, int64_t ldx, const float *Wt, int64_t ldw, const float *bias, const float *roww,
                         int rows_per_crop, int64_t w_stride, float *part, int64_t ldp, int M, int N, int K, int relu,
                         dclStream_t stream);
+/* The last TWO layers of a head whose last layer has one output (the confidence regressor, models/DCL_Net.py:115-126: 128 ->
+ * 128 -> 1) on the own GEMM core: out[m] = w3 . relu(x[m] Wt + bias) + b3 with the N <= 128 hidden columns never stored (the
+ * row dot is the GEMM's epilogue).  w3: N floats with stride ldw3 (a (N, 1) weight with padded rows); b3: one float. */
+int dcl_linear_rowdot_fwd(const float *x, int64_t ldx, const float *Wt, int64_t ldw, const float *bias, const float *w3,
+                          int64_t ldw3, const float *b3, float *out, int M, int N, int K, dclStream_t stream);
 /* The softmax half of dcl_conf_pool alone: conf (b, n1 + n2) = sigmoid(cat[logit1, logit2]), w (b, n1 + n2) = softmax(conf) per
  * crop, wsum (b, 2) = the weight sums of the two directions (models/DCL_Net.py:217-222). */
 int dcl_conf_softmax(int b, int n1, int n2, const float *logit1, const float *logit2, float *conf, float *w, float *wsum,

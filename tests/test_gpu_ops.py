@@ -1040,6 +1040,28 @@ def test_confidence_regressor_in_one_launch_matches_its_three_layers(dcl, M, wid
     assert float((got - lib3).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("M", [1024, 1000, 33, 32 * 1024 + 37, 393216])
+def test_confidence_regressor_as_two_gemms_with_a_row_dot_epilogue(dcl, M):
+    """ops.linear (128 -> 128, ReLU) + ops.linear_rowdot (128 -> 128 -> 1: the row dot is the second GEMM's epilogue, csrc/
+    linear_dma.hip EPI = 2) -- what large batches run instead of dcl_mlp128_to1 -- against the three layers in float64 and
+    against dcl_mlp128_to1; x a column block of a wider buffer; two launches give the same bits"""
+    g = torch.Generator().manual_seed(M % 1000)
+    buf = torch.randn((M, 192), generator=g).cuda()
+    x = buf[:, 64:192]
+    W1, W2 = (torch.randn((128, 128), generator=g) / 11.3).cuda(), (torch.randn((128, 128), generator=g) / 11.3).cuda()
+    W3 = dcl.ops.pad_linear_weight((torch.randn((128, 1), generator=g) / 11.3).cuda())
+    b1, b2, b3 = (torch.randn(128, generator=g) * 0.1).cuda(), (torch.randn(128, generator=g) * 0.1).cuda(), torch.randn(1, generator=g).cuda()
+    h1 = dcl.ops.linear(x, W1, b1, True)
+    got = dcl.ops.linear_rowdot(h1, W2, b2, W3, b3)
+    assert got.shape == (M, 1) and torch.equal(got, dcl.ops.linear_rowdot(h1, W2, b2, W3, b3))
+    rows = torch.arange(M) if M <= 40000 else torch.cat([torch.randint(0, M, (2000,), generator=g), torch.tensor([0, M - 1])])
+    xr = x[rows.cuda()].double()
+    ref = (((xr @ W1.double() + b1.double()).relu() @ W2.double() + b2.double()).relu() @ W3.double() + b3.double())
+    assert float((got[rows.cuda()].double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    one = dcl.ops.mlp128_to1(x, [(W1, b1), (W2, b2), (W3, b3)])
+    assert float((got - one).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
 def test_conf_pool_matches_torch(dcl):
     g = torch.Generator().manual_seed(1)
     b, n1, n2, c = 3, 300, 170, 1024
