@@ -5,7 +5,7 @@
 #                                       gpurun_out/r1_pmcprim_<COUNTER>/        (north-star primitives)
 # then, back in the container: python tools/summarize_profiles.py r1  (copies the summaries into profiles/).
 # PMC passes are separate runs with --kernel-trace only, as the pool requires.
-R=${1:-r5}
+R=${1:-r6}
 export TMPDIR=/tmp
 cd "$(dirname "$0")/.." || exit 1
 O=gpurun_out
@@ -20,6 +20,8 @@ stats crops  python3 tools/bench_crops.py
 stats conv   python3 tools/bench_conv.py 1024 0
 stats refiner python3 tools/refiner_loop.py 10
 python3 tools/bench_fps.py 2>&1 | grep FPS > $O/${R}_fps.txt
+# the own GEMM core against the vendor library, layer shape by layer shape (+ float64 check)
+python3 tools/bench_linear_dma.py --check 2>&1 | grep -v amdgpu.ids > $O/${R}_gemm_ab.txt
 # the sparse-conv stack layer by layer inside ordinary forwards (runner path, product library), and one launch from the inside
 { for a in "ref 32" "stress 32" "ref 6" "ref 1"; do python3 tools/conv_layers.py $a; done; } 2>&1 | grep -v amdgpu.ids > $O/${R}_conv_layers_runner.txt
 { for l in 0 1 2 3 4 5; do python3 tools/conv_stamps.py $l pair ref; done; } 2>&1 | grep -v "amdgpu.ids\|occupancy API" > $O/${R}_conv_stamps.txt
