@@ -430,6 +430,7 @@ static int backbone_features(const SideArgs *sd, int nsides, int batch, int S, c
           rc = source(i, at<int32_t>(a.ws, c.indices), nc_dev, nc, in_mask[i], in_wp[i], in_perm[i], 1, &Sd.src);
           if (rc) return rc;
           Sd.feat = x[i]; Sd.out = x1; Sd.cap = nc; Sd.n_dev = nc_dev; Sd.n_host = nc_dev ? expect_rows(batch, m, nc) : nc;
+          Sd.form_rows = expect_rows(batch, m, 0x7fffffff);
           Sd.W = a.weights[2 * m]; Sd.scale = a.scales[2 * m]; Sd.shift = a.shifts[2 * m];
           Sd.ord = order_of(i, 0);
         } else if (stage == 1) {
@@ -437,6 +438,7 @@ static int backbone_features(const SideArgs *sd, int nsides, int batch, int S, c
                       nullptr, 1, &Sd.src);
           if (rc) return rc;
           Sd.feat = x1; Sd.out = x2; Sd.cap = nc; Sd.n_dev = nc_dev; Sd.n_host = nc_dev ? expect_rows(batch, m, nc) : nc;
+          Sd.form_rows = 0;
           Sd.W = a.weights[2 * m + 1]; Sd.scale = a.scales[2 * m + 1]; Sd.shift = a.shifts[2 * m + 1];
           Sd.ord = order_of(i, 1);
         } else {
@@ -446,6 +448,7 @@ static int backbone_features(const SideArgs *sd, int nsides, int batch, int S, c
           Sd.feat = x2; Sd.out = a.level_out[m]; Sd.cap = np; Sd.n_dev = np_dev;
           Sd.n_host = np_dev ? (expect_rows(batch, m, 4 * np) + 3) / 4 : np;      // (a pooled set holds about a quarter of its conv set's rows)
           Sd.ord = DclRowOrder{nullptr, nullptr, nullptr};
+          Sd.form_rows = 0;
         }
         ++ns;
       }

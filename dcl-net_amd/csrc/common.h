@@ -120,6 +120,10 @@ struct DclConvSide {
   float *out;
   DclRowOrder ord;
   int cap, n_host;
+  int form_rows;                // rows by which a launch picks among kernel FORMS with different summation orders (the stem's one /
+                                // four lanes per row): data-independent (crops x the per-crop mean of the level) inside the backbone
+                                // runner, so that the same batch takes the same form launch by launch and under graph capture;
+                                // 0 = none (op-level calls: the row count itself)
 };
 // the problems of one dcl_linear_group_fwd launch (kernel argument)
 struct DclLinearJobs {

@@ -101,39 +101,24 @@ __device__ __forceinline__ void conv_stem_body(const DclConvSides &sides, int ns
     const int centre = kvol / 2;
     bool centre_first = subm && ((present >> centre) & 1u);
     if constexpr (LPR == 1) {
-      // many rows: every present neighbour in visiting order; other waves hide the latency of the row loads.  The sum keeps the
-      // FOUR-LANE form's association -- neighbour number j (visiting order) goes to partial sum j mod 4, the four are combined
-      // as (s0 + s1) + (s2 + s3) -- so that the two forms give the same bits: which one a launch takes depends on the row
-      // count (a capacity hint under graph capture, the exact count launch by launch), and a forward must not change its low
-      // bits with the route it takes (round-5 review)
-      float part4[4][COUT];
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4)
-#pragma unroll
-        for (int co = 0; co < COUT; ++co) part4[g4][co] = 0.0f;
+      // many rows: every present neighbour in visiting order; other waves hide the latency of the row loads
       while (present) {
+        int k;
+        if (centre_first) { k = centre; centre_first = false; } else { k = __builtin_ctz(present); }
+        present &= ~(1u << k);
+        const int v = nb[k];
+        float f[CIN];
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {                   // (static partial-sum indices: registers, no scratch)
-          if (!present) break;
-          int k;
-          if (centre_first) { k = centre; centre_first = false; } else { k = __builtin_ctz(present); }
-          present &= ~(1u << k);
-          const int v = nb[k];
-          float f[CIN];
+        for (int ci = 0; ci < CIN; ++ci) f[ci] = feat[(size_t)v * CIN + ci];
+        const float *w = wside + k * WP;
 #pragma unroll
-          for (int ci = 0; ci < CIN; ++ci) f[ci] = feat[(size_t)v * CIN + ci];
-          const float *w = wside + k * WP;
+        for (int co = 0; co < COUT; ++co) {
+          float part = 0.0f;
 #pragma unroll
-          for (int co = 0; co < COUT; ++co) {
-            float part = 0.0f;
-#pragma unroll
-            for (int ci = 0; ci < CIN; ++ci) part = __fmaf_rn(f[ci], w[ci * COUT + co], part);
-            part4[g4][co] = part4[g4][co] + part;
-          }
+          for (int ci = 0; ci < CIN; ++ci) part = __fmaf_rn(f[ci], w[ci * COUT + co], part);
+          acc[co] = acc[co] + part;
         }
       }
-#pragma unroll
-      for (int co = 0; co < COUT; ++co) acc[co] = (part4[0][co] + part4[1][co]) + (part4[2][co] + part4[3][co]);
     } else {
       // a handful of crops: this lane takes the present neighbours number g, g + 4, ... (visiting order), two rows in flight per
       // round (a chain of latencies otherwise), added in visiting order

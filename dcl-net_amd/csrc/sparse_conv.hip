@@ -936,9 +936,13 @@ static int conv_dispatch(const DclConvSides &sides_in, int nsides_in, int cin, i
     int rows = 0, expect = 0;                            // capacity mode: the grid by capacity, the kernel form by the expected rows
     for (int i = 0; i < nsides; ++i) {
       rows += sides.s[i].n_dev ? sides.s[i].cap : sides.s[i].n_host;
-      expect += sides.s[i].n_dev ? (sides.s[i].n_host > 0 ? sides.s[i].n_host : sides.s[i].cap) : sides.s[i].n_host;
+      expect += sides.s[i].form_rows > 0 ? sides.s[i].form_rows
+                                         : (sides.s[i].n_dev ? (sides.s[i].n_host > 0 ? sides.s[i].n_host : sides.s[i].cap) : sides.s[i].n_host);
     }
-    // many rows: a lane per row; a handful of crops: four lanes per row (conv_body.h: conv_stem_body)
+    // many rows: a lane per row; a handful of crops: four lanes per row (conv_body.h: conv_stem_body).  The two forms add a row's
+    // neighbours in different orders, so inside the backbone runner the choice goes by form_rows -- crops x 3600, the same
+    // number launch by launch and under graph capture (round-5 review: the capacity hint of one and the exact count of the other
+    // could put the same batch on either side of the switch)
     if (expect > 49152)
       hipLaunchKernelGGL((k_sparse_conv_stem<7, 16, 1>), dim3(dcl_grid_1d(rows, 256, 768)), dim3(256), 0, s, sides, nsides, kvol, subm,
                          relu);

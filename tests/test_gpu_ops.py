@@ -148,27 +148,25 @@ def test_sparse_conv_matches_oracle(request, dcl, oracle, cin, cout, subm):
     assert np.abs(got2 - np.maximum(want * s + t, 0)).max() <= 2 * tol
 
 
-def test_stem_conv_gives_the_same_bits_in_both_of_its_forms(dcl):
-    """The 7 -> 16 stem takes a lane per output row for launches of many rows and four lanes per row for a handful of crops
-    (csrc/sparse_conv.hip picks by the row count -- a capacity hint under graph capture, the exact count launch by launch).
-    Both forms add a row's neighbours with the same association (round-5 review: they did not), so the rows of 4 crops are
-    the same bits whether they are computed alone (four-lane form) or as the head of a 32-crop batch (one-lane form)"""
+def test_stem_conv_forms_match_the_oracle_on_either_side_of_the_switch(dcl, oracle):
+    """The 7 -> 16 stem takes a lane per output row for launches of many rows and four lanes per row for a handful of crops (two
+    summation orders).  An op-level call picks by its row count; inside the backbone runner the choice goes by crops x 3600 --
+    the same number launch by launch and under graph capture (round-5 review).  Both forms against the oracle here: 4 crops
+    (four lanes) and 32 crops (one lane) of the same synthetic scene."""
     ops, sp = dcl.ops, dcl.spconv.ops
     S = 64
     rng = np.random.default_rng(9)
-    W = cuda((rng.normal(size=(27, 7, 16)) / np.sqrt(9 * 7)).astype(np.float32))
-    scale, shift = cuda(rng.uniform(0.5, 1.5, 16).astype(np.float32)), cuda(rng.normal(size=16).astype(np.float32))
-    outs = {}
+    W = (rng.normal(size=(3, 3, 3, 7, 16)) / np.sqrt(9 * 7)).astype(np.float32)
     for b in (4, 32):
         occ = dcl.synth.make_batch(b, 1024, 64)["inp"]["occupied_voxels"].int()
         aset = ops.grid_from_indices(occ.cuda().contiguous(), b, S)
         out, nbr = sp.build_rulebook(aset, 3, 1, 1, False)
-        feat = torch.from_numpy(np.random.default_rng(1).normal(size=(20000 * 32, 7)).astype(np.float32))[:occ.shape[0]].cuda()
-        outs[b] = (ops.sparse_conv(feat, nbr, out.n, W, False, scale, shift, True), out.n, occ.shape[0])
-    (y4, n4, v4), (y32, n32, v32) = outs[4], outs[32]
-    assert n4 <= 49152 < n32, (n4, n32)                        # the two launches sit on either side of the form switch
-    # (crops are independent and batch-sorted: the first crops' voxels, inputs and output rows are a prefix of the batch's)
-    assert torch.equal(y32[:n4], y4)
+        assert (out.n <= 49152) == (b == 4)                    # the two launches sit on either side of the form switch
+        feat = np.random.default_rng(1).normal(size=(occ.shape[0], 7)).astype(np.float32)
+        got = ops.sparse_conv(cuda(feat), nbr, out.n, cuda(W).reshape(27, 7, 16).contiguous(), False).cpu().numpy()
+        o_ids, o_pairs, o_num, _ = oracle.get_indice_pairs(occ.numpy(), b, [S] * 3, 3, 1, 1, 1, subm=False)
+        want = oracle.indice_conv(feat, W, o_pairs, o_num, o_ids.shape[0], subm=False)
+        assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max()), b
 
 
 def test_conv_layers_of_a_32_crop_batch_op_by_op_match_the_oracle(dcl, oracle):
