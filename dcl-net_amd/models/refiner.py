@@ -160,8 +160,11 @@ def refine_loop(refiner, pred, points_inp, iteration=2, graph=False):
     def feature_term(F_pm, out=None):
         # the feature half of the first shared layer: the same in every iteration, computed once per call
         bias, W = f["MLP_share"][0][1], f["share0_feat"]
-        if F_pm.is_contiguous():                                  # point-major rows (what Network.forward hands over)
-            return ops.linear(F_pm.view(b * n, -1), W, bias, False, out=out)
+        # point-major rows (what Network.forward hands over: dense from a graph replay, a 256-column block of the 512-wide fuser
+        # input -- row pitch 512 -- launch by launch): one GEMM of the own core on the (b*n, 256) rows as they lie
+        if F_pm.stride(2) == 1 and F_pm.stride(0) == n * F_pm.stride(1):
+            rows = F_pm.as_strided((b * n, F_pm.shape[2]), (F_pm.stride(1), 1))
+            return ops.linear(rows, W, bias, False, out=out)
         # channel-first features (the reference's own layout): a batched GEMM over the transposed operand, no transpose copy
         o = torch.baddbmm(bias.view(1, 1, -1), F_pm, W.unsqueeze(0).expand(b, -1, -1),
                           out=None if out is None else out.view(b, n, -1))

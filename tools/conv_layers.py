@@ -19,9 +19,11 @@ net.load_state_dict(dcl.synth.synth_state_dict(net, 1))
 net = net.to(dev).eval()
 data = bench.to_device(dcl.synth.make_batch(b, n_inp, n_tmp), dev)
 r = bench.sparse_conv_roofline(dcl, net, data, dev, steps=5)
-print("%s b=%d: conv %.4f ms per forward (grouped), frac %.4f, density %.3f; separate launches %.4f ms; feature stage %s" % (
-    shape, b, r["conv_ms_per_forward"], r["frac"], r["rulebook_density"], r["separate_launches"]["conv_ms_per_forward"],
-    {k: v for k, v in r["feature_stage"].items() if k != "what"}))
+g = r["grouped_single_stream"]
+print("%s b=%d: conv %.4f ms per forward, frac %.4f (each backbone's own launches: the default schedule); grouped one-stream "
+      "schedule %.4f ms, frac %.4f (the layer table below); density %.3f; feature stage %s" % (
+          shape, b, r["conv_ms_per_forward"], r["frac"], g["conv_ms_per_forward"], g["frac"], r["rulebook_density"],
+          {k: v for k, v in r["feature_stage"].items() if k != "what"}))
 for L in r["layers"]:
     print("  %-18s rows %7d dens %.2f  %7.1f us  %5.1f TF  mfma %6.1f us  gather %6.1f us  %-9s frac %.3f" % (
         L["layer"], L["rows"], L["density"], L["ms"] * 1e3, L["TFLOPs"], L["mfma_bound_ms"] * 1e3, L["l2_gather_bound_ms"] * 1e3,
