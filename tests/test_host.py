@@ -267,6 +267,29 @@ def test_graph_routing_rule(dcl):
     assert [mk(1024, 1024, graph_max_batch=4, graph_max_points=0).replays_graph(b) for b in (4, 5)] == [True, False]
 
 
+def test_own_gemm_core_eligibility_rule(dcl):
+    """which layers ops.linear sends to the own GEMM core (host logic only: shapes, pitches, alignment -- csrc/linear_dma.hip wants
+    K in whole 32-chunks, 16-byte aligned operands, row pitches of whole float4s, a Wt row holding N rounded up to 4 floats);
+    every layer shape of the forward qualifies, the refiner's reference-layout entry (K = 259) and unpadded thin weights do not"""
+    import torch
+    ok = dcl.ops.linear_dma_ok
+    z = lambda r, c: torch.zeros(r, c)                                     # noqa: E731
+    for K, n in ((480, 1024), (256, 256), (256, 64), (512, 512), (512, 1024), (128, 128), (1024, 512), (512, 128)):
+        assert ok(z(64, K), z(K, n)), (K, n)
+    assert ok(z(64, 1024)[:, 256:512], z(256, 64))                          # a column block of a wider buffer: pitch 1024
+    assert ok(z(64, 128), dcl.ops.pad_linear_weight(z(128, 9))) and ok(z(64, 128), dcl.ops.pad_linear_weight(z(128, 1)))
+    assert not ok(z(64, 128), z(128, 9))                                    # rows of 9 floats: not whole float4s
+    assert not ok(z(64, 259), z(259, 512)) and not ok(z(64, 48), z(48, 64)) and not ok(z(64, 16), z(16, 64))
+    assert not ok(z(64, 260)[:, 2:258], z(256, 64))                         # 8-byte offset: x not 16-byte aligned
+    # the folded head weights of a Network: every last layer that goes through _mlp sits in padded rows
+    net = dcl.DCL_Net.Network(dcl.synth.default_cfg(256, 256), mode="test")
+    f = net._fold()
+    for name in ("regressor_conf", "regressor_conf_bi", "regressor_Xo", "regressor_Yc", "regressor_rot_padded", "regressor_trans_padded"):
+        Wt = f[name][2][0]
+        assert Wt.stride(0) % 4 == 0 and ok(z(8, Wt.shape[0]), Wt), name
+    assert all(t.is_contiguous() for pair in f["regressor_rot"] + f["regressor_trans"] for t in pair)   # what dcl_pose_heads takes
+
+
 def test_tail_parallel_rule(dcl):
     """do the dense tail's two directions run side by side?  (host logic only) -- always while both attention launches are
     small (every N = M = 1024 call), at N = 12288 only for the batch sizes whose grid of 256-query workgroups ends in a
