@@ -63,13 +63,13 @@ __device__ __forceinline__ int ld_rowmap(int e, int h) { return (e & 3) + 8 * (e
 // by -- each group with its own half of every ring stage; at the end group 1 hands its accumulators over through LDS and
 // group 0 adds them (acc0 + acc1: one fixed order) and runs the epilogue.
 template <int BM, int BN, int WGR, int EPI, int KS>
-__global__ __launch_bounds__(256 * KS, 2) void k_linear_dma(const LinDmaArgs a) {
+__global__ __launch_bounds__(256 * KS, KS == 4 ? 4 : 2) void k_linear_dma(const LinDmaArgs a) {
   constexpr int WGC = 4 / WGR;
   constexpr int WM = BM / WGR, WN = BN / WGC;            // a wave's tile
   constexpr int MB = WM / 32, NB = WN / 32;              // ... in 32 x 32 MFMA blocks
   constexpr int AT = BM * kLdKC, BT = kLdKC * BN, ST = AT + BT;     // floats per stage and wave group
   constexpr int RING = 2 * KS * ST;                      // the whole ring: 2 stages x KS groups
-  static_assert(KS == 1 || (KS == 2 && EPI == 0), "the K split comes with the plain epilogue");
+  static_assert(KS == 1 || ((KS == 2 || KS == 4) && EPI == 0), "the K split comes with the plain epilogue");
   static_assert(EPI != 2 || WGR * WGC == 4, "row-dot epilogue");
   constexpr int APW = BM / 32, BPW = BN / 32;            // 1-KiB DMA pieces per wave and chunk (A: 8 rows each; B: 1 KiB of k-rows)
   static_assert(APW == 2 || APW == 4, "x pieces per wave");
@@ -245,30 +245,34 @@ __global__ __launch_bounds__(256 * KS, 2) void k_linear_dma(const LinDmaArgs a) 
     }
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");      // MFMA -> VALU read of the accumulators
 
-    if constexpr (KS == 2) {
-      // group 1's partial sums -> LDS behind the ring (the ring may already be receiving the next tile's first chunk) -> group 0
-      float *xch = ld_lds + RING + ((wave * MB * NB) * 16) * 64 + lane;
-      if (grp == 1) {
+    if constexpr (KS > 1) {
+      // groups 1 .. KS-1 hand their partial sums over through LDS -- the ring itself: a K-split launch is one tile per workgroup
+      // (launch_linear_dma), nothing is being fetched any more -- and group 0 adds them in group order (one fixed order)
+      dcl_lds_barrier();                                   // every wave is past its last fragment read
+      float *xch = ld_lds + ((wave * MB * NB) * 16) * 64 + lane;
+      constexpr int XG = 4 * MB * NB * 16 * 64;            // floats of one group's accumulators
+      if (grp > 0) {
 #pragma unroll
         for (int m = 0; m < MB; ++m)
 #pragma unroll
           for (int n = 0; n < NB; ++n)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) xch[((m * NB + n) * 16 + e) * 64] = acc[m][n][e];
+            for (int e = 0; e < 16; ++e) xch[(grp - 1) * XG + ((m * NB + n) * 16 + e) * 64] = acc[m][n][e];
       }
       dcl_lds_barrier();
       if (grp == 0) {
 #pragma unroll
-        for (int m = 0; m < MB; ++m)
+        for (int gsrc = 0; gsrc < KS - 1; ++gsrc)
 #pragma unroll
-          for (int n = 0; n < NB; ++n)
+          for (int m = 0; m < MB; ++m)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[m][n][e] = acc[m][n][e] + xch[((m * NB + n) * 16 + e) * 64];
+            for (int n = 0; n < NB; ++n)
+#pragma unroll
+              for (int e = 0; e < 16; ++e) acc[m][n][e] = acc[m][n][e] + xch[gsrc * XG + ((m * NB + n) * 16 + e) * 64];
       }
-      dcl_lds_barrier();                                   // (the next tile's group 1 rewrites the exchange area)
     }
     if constexpr (EPI == 0) {
-      if (KS == 2 && grp == 1) continue;                   // group 0 holds the sums
+      if (KS > 1 && grp > 0) continue;                     // group 0 holds the sums
       float *__restrict__ y = a.y;
       const bool whole = row0 + BM <= a.M && col0 + BN <= a.N;     // (workgroup-uniform) interior tile: no per-element checks
       float bias[NB];
@@ -376,7 +380,7 @@ __global__ __launch_bounds__(256 * KS, 2) void k_linear_dma(const LinDmaArgs a) 
   }
 }
 
-DCL_HOOK_INT(g_lin_tile, 0);          // diagnostic: 0 = automatic tile shape, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 64x64 with K split over 8 waves
+DCL_HOOK_INT(g_lin_tile, 0);          // diagnostic: 0 = automatic tile shape, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 / 5 = 64x64 with K split over 8 / 16 waves
 DCL_HOOK_INT(g_lin_xcd, 1);
 DCL_HOOK_INT(g_lin_persist, 1 << 20); // rounds of resident workgroups from which a launch is PERSISTENT (1 << 20: by K, see launch_linear_dma)
 
@@ -408,13 +412,14 @@ int launch_linear_dma(const LinDmaArgs &a, hipStream_t stream) {
   // priority.  So only the short-K launches walk (below); the diagnostic library has the switch: dcl_debug_linear_persist.)
   constexpr size_t lds = (size_t)2 * KS * (BM + BN) * kLdKC * sizeof(float) + (EPI == 1 ? (BM + WGR * BN) * sizeof(float) : 0) +
                          (EPI == 2 ? (size_t)(4 / WGR) * BM * sizeof(float) : 0) +
-                         (KS == 2 ? (size_t)BM * BN * sizeof(float) : 0);
+                         0;
+  static_assert(KS == 1 || (size_t)(KS - 1) * BM * BN <= (size_t)2 * KS * (BM + BN) * kLdKC, "the K groups' exchange fits the ring");
   constexpr int per_cu = (160 * 1024) / (int)lds > 4 ? 4 : (160 * 1024) / (int)lds;
   const long long slots = (long long)per_cu * lin_cu_count();
   // (short K -- the K = 128 / 256 layers, 4-8 chunks per tile -- is where the walk pays: a tile's first fetch is a quarter of
   //  its life; those launches are persistent from four rounds of slots on)
   const long long rounds = (int)g_lin_persist != (1 << 20) ? (long long)g_lin_persist : (a.K <= 256 ? 4 : (1 << 20));
-  const unsigned grid = (unsigned)(tiles >= rounds * slots ? slots : tiles);
+  const unsigned grid = (unsigned)(KS == 1 && tiles >= rounds * slots ? slots : tiles);      // (K-split launches: one tile per workgroup)
   static bool attr_set = false;                            // (idempotent; a race sets it twice)
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void *)k_linear_dma<BM, BN, WGR, EPI, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -443,7 +448,7 @@ static bool lin_dma_ok(const float *x, int64_t ldx, const float *Wt, int64_t ldw
 // 2 = 128 x 64, 3 = 64 x 64.
 static int lin_pick_tile(int M, int N) {
   const int forced = (int)g_lin_tile;
-  if (forced >= 1 && forced <= 4) return forced;
+  if (forced >= 1 && forced <= 5) return forced;
   const int cus = lin_cu_count();
   static const int bm[3] = {128, 128, 64}, bn[3] = {128, 64, 64};
   static const double eff[3] = {1.0, 0.96, 0.93};
@@ -467,11 +472,14 @@ DCL_API int dcl_linear_dma_fwd(const float *x, int64_t ldx, const float *Wt, int
   int rc, tile = lin_pick_tile(M, N);
   // a launch of 64 x 64 tiles that cannot even give every CU two of them is bound by ONE tile's chain of chunks: eight waves per
   // tile then, the two halves of K side by side (k_linear_dma<.., KS = 2>)
-  if (tile == 3 && (int)g_lin_tile == 0 && (long long)((M + 63) / 64) * ((N + 63) / 64) <= 2ll * lin_cu_count() && K >= 4 * kLdKC) tile = 4;
+  // (and a launch that cannot give every CU even one: sixteen waves, four quarters of K)
+  const long long t64 = (long long)((M + 63) / 64) * ((N + 63) / 64);
+  if (tile == 3 && (int)g_lin_tile == 0 && t64 <= 2ll * lin_cu_count() && K >= 4 * kLdKC) tile = t64 <= lin_cu_count() && K >= 8 * kLdKC ? 5 : 4;
   switch (tile) {
     case 1: rc = launch_linear_dma<128, 128, 2, 0>(a, (hipStream_t)stream); break;
     case 2: rc = launch_linear_dma<128, 64, 2, 0>(a, (hipStream_t)stream); break;
     case 4: rc = launch_linear_dma<64, 64, 2, 0, 2>(a, (hipStream_t)stream); break;
+    case 5: rc = launch_linear_dma<64, 64, 2, 0, 4>(a, (hipStream_t)stream); break;
     default: rc = launch_linear_dma<64, 64, 2, 0>(a, (hipStream_t)stream); break;
   }
   if (rc) return rc;

@@ -621,8 +621,8 @@ void dcl_debug_conv_few_chunks(int n);
 void dcl_debug_conv_few_tiles(int on);
 /* Tuning hook: 1 (default) = the Cin 16 / 32 -> 32 conv layers of many rows run the filter-resident kernel, 0 = LDS-DMA kernel. */
 void dcl_debug_conv_wlds(int on);
-/* Tuning hooks of the own GEMM core: tile shape (0 = automatic, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 64x64 with the
- * two halves of K on two wave groups), XCD-aware
+/* Tuning hooks of the own GEMM core: tile shape (0 = automatic, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 / 5 = 64x64 with
+ * the two halves / four quarters of K on two / four wave groups), XCD-aware
  * workgroup renumbering (default 1). */
 void dcl_debug_linear_tile(int t);
 void dcl_debug_linear_xcd_remap(int on);

@@ -1249,7 +1249,7 @@ def test_own_gemm_core_matches_float64_on_every_tile_shape(request, dcl):
     lib = enter_diag(dcl, request)
     g = torch.Generator().manual_seed(21)
     try:
-        for tile in (0, 1, 2, 3, 4):
+        for tile in (0, 1, 2, 3, 4, 5):
             lib.dcl_debug_linear_tile(tile)
             for M, K, n in ((1000, 256, 64), (4096, 480, 1024), (37, 128, 1), (2048, 512, 512), (333, 512, 96), (517, 256, 256),
                             (129, 32, 260)):
