@@ -929,6 +929,83 @@ def linear_rowdot(x, Wt, bias, w3, b3, out=None):
     return out
 
 
+class SplitWeight:
+    """A layer's weight prepared for the split-bf16 GEMM core (csrc/linear_split.hip): its three bf16 pieces in the kernel's
+    tile order (`planes`), beside the (K, N) fp32 weight they were made from."""
+    __slots__ = ("Wt", "planes", "K", "n")
+
+    def __init__(self, Wt):
+        N.need_cuda(Wt)
+        assert Wt.dim() == 2 and Wt.dtype == torch.float32 and (Wt.stride(1) == 1 or Wt.shape[1] == 1)
+        self.Wt, (self.K, self.n) = Wt, Wt.shape
+        lib = N.lib()
+        lib.dcl_linear_split_weight_bytes.restype = C.c_int64
+        nbytes = int(lib.dcl_linear_split_weight_bytes(int(self.K), int(self.n)))
+        assert nbytes > 0, "split-bf16 GEMM core: K must be a multiple of 16"
+        self.planes = torch.empty(nbytes, dtype=torch.uint8, device=Wt.device)
+        pw = int(Wt.stride(0)) if self.K > 1 else self.n
+        N.check(lib.dcl_linear_split_weight(N.ptr(Wt), C.c_int64(pw), int(self.K), int(self.n), N.ptr(self.planes), N.stream()),
+                "linear_split_weight")
+
+
+def linear_split_ok(x, K):
+    """can the split-bf16 core take this operand?  (K in whole 16-chunks, 16-byte aligned rows)"""
+    px = int(x.stride(0)) if x.shape[0] > 1 else K
+    return K >= 16 and K % 16 == 0 and px % 4 == 0 and x.data_ptr() % 16 == 0
+
+
+def linear_split(x, sw, bias=None, relu=False, out=None):
+    """linear() on the split-bf16 GEMM core (csrc/linear_split.hip): act(x @ sw.Wt + bias) with fp32-sized errors at the bf16
+    matrix pipe's rate (three bf16 pieces per operand, six piece products per product, fp32 accumulation).  sw: SplitWeight."""
+    N.need_cuda(x)
+    assert x.dim() == 2 and x.shape[1] == sw.K and x.dtype == torch.float32 and (x.stride(1) == 1 or x.shape[1] == 1)
+    M, K, n = x.shape[0], sw.K, sw.n
+    if out is None:
+        out = torch.empty((M, n), dtype=torch.float32, device=x.device)
+    assert out.shape == (M, n) and out.dtype == torch.float32 and out.is_cuda and (out.stride(1) == 1 or n == 1)
+    if bias is not None:
+        assert bias.is_cuda and bias.dtype == torch.float32 and bias.numel() == n and bias.is_contiguous()
+    pitch = lambda t: int(t.stride(0)) if t.shape[0] > 1 else max(int(t.stride(0)), int(t.shape[1]))   # noqa: E731
+    N.check(N.lib().dcl_linear_split_fwd(N.ptr(x), C.c_int64(pitch(x)), N.ptr(sw.planes), N.ptr(bias), N.ptr(out), C.c_int64(pitch(out)),
+                                         int(M), int(n), int(K), int(bool(relu)), N.stream()), "linear_split_fwd")
+    return out
+
+
+def linear_split_pool(x, sw, bias, roww, relu=True, part=None, rows_per_crop=None, w_stride=0):
+    """linear_pool() on the split-bf16 core: same partials layout (one row of `part` per 128 rows of x)"""
+    N.need_cuda(x, roww)
+    M, K, n = x.shape[0], sw.K, sw.n
+    assert x.shape[1] == K
+    if rows_per_crop is None:
+        rows_per_crop, w_stride = M, 0
+        assert roww.is_contiguous() and roww.numel() == M
+    assert roww.dtype == torch.float32 and M % rows_per_crop == 0
+    tiles = (M + LINEAR_POOL_TILE - 1) // LINEAR_POOL_TILE
+    if part is None:
+        part = torch.empty((tiles, n), dtype=torch.float32, device=x.device)
+    assert part.shape == (tiles, n) and part.stride(1) == 1
+    pitch = lambda t: int(t.stride(0)) if t.shape[0] > 1 else max(int(t.stride(0)), int(t.shape[1]))   # noqa: E731
+    N.check(N.lib().dcl_linear_split_pool_fwd(N.ptr(x), C.c_int64(pitch(x)), N.ptr(sw.planes), N.ptr(bias), N.ptr(roww), int(rows_per_crop),
+                                              C.c_int64(int(w_stride)), N.ptr(part), C.c_int64(pitch(part)), int(M), int(n), int(K),
+                                              int(bool(relu)), N.stream()), "linear_split_pool_fwd")
+    return part
+
+
+def linear_split_rowdot(x, sw, bias, w3, b3, out=None):
+    """linear_rowdot() on the split-bf16 core"""
+    N.need_cuda(x, w3, b3)
+    M, K, n = x.shape[0], sw.K, sw.n
+    assert x.shape[1] == K and n <= 128 and w3.shape == (n, 1) and b3.numel() == 1 and bias.numel() == n
+    if out is None:
+        out = torch.empty((M, 1), dtype=torch.float32, device=x.device)
+    assert out.is_contiguous() and out.numel() == M
+    pitch = lambda t: int(t.stride(0)) if t.shape[0] > 1 else max(int(t.stride(0)), int(t.shape[1]))   # noqa: E731
+    N.check(N.lib().dcl_linear_split_rowdot_fwd(N.ptr(x), C.c_int64(pitch(x)), N.ptr(sw.planes), N.ptr(bias), N.ptr(w3),
+                                                C.c_int64(int(w3.stride(0))), N.ptr(b3), N.ptr(out), int(M), int(n), int(K), N.stream()),
+            "linear_split_rowdot_fwd")
+    return out
+
+
 def conf_softmax(b, logit1, logit2):
     """the softmax half of conf_pool alone: logits (b*n1,), (b*n2,) -> conf (b, n1+n2) = sigmoid, w (b, n1+n2) = softmax(conf)
     per crop, wsum (b, 2) (models/DCL_Net.py:217-222)"""

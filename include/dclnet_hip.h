@@ -34,7 +34,8 @@ const char *dcl_last_error(void);
  *   1  rounds 1-4
  *   2  round 5-6: dcl_crop_points gained `int32_t *ws` in front of `stream`; dcl_backbone_features_stage,
  *      dcl_backbone_stage_ws_bytes and DCL_ESTAGE_UNSUPPORTED are gone; dcl_linear_fwd ignores its workspace arguments;
- *      new: dcl_linear_dma_fwd, dcl_linear_pool_fwd, dcl_linear_rowdot_fwd, dcl_conf_softmax, dcl_pool_finish2                                   */
+ *      new: dcl_linear_dma_fwd, dcl_linear_pool_fwd, dcl_linear_rowdot_fwd, dcl_conf_softmax, dcl_pool_finish2,
+ *      dcl_linear_split_weight(_bytes), dcl_linear_split_fwd, dcl_linear_split_pool_fwd, dcl_linear_split_rowdot_fwd                            */
 #define DCL_ABI_VERSION 2
 int dcl_abi_version(void);
 
@@ -457,6 +458,22 @@ int dcl_linear_pool_fwd(const float *x, int64_t ldx, const float *Wt, int64_t ld
  * row dot is the GEMM's epilogue).  w3: N floats with stride ldw3 (a (N, 1) weight with padded rows); b3: one float. */
 int dcl_linear_rowdot_fwd(const float *x, int64_t ldx, const float *Wt, int64_t ldw, const float *bias, const float *w3,
                           int64_t ldw3, const float *b3, float *out, int M, int N, int K, dclStream_t stream);
+/* The same layers on the bf16 matrix pipe with fp32 results (csrc/linear_split.hip): every fp32 operand is the exact sum of
+ * three bf16 pieces and a product is accumulated as its six piece products of weight >= 2^-16, in fp32 accumulators (what is dropped
+ * is below the rounding of an fp32 FMA chain).  A layer's weight is prepared ONCE: dcl_linear_split_weight writes its pieces, in the
+ * kernel's tile order, into `planes` (dcl_linear_split_weight_bytes(K, N) bytes, 16-byte aligned; 0 = K is no multiple of 16).
+ * dcl_linear_split_fwd / _pool_fwd / _rowdot_fwd then mirror dcl_linear_dma_fwd / dcl_linear_pool_fwd / dcl_linear_rowdot_fwd with
+ * `planes` in the place of (Wt, ldw); x 16-byte aligned, ldx % 4 == 0, K % 16 == 0; workgroup tiles of 256 rows x 128 columns: for
+ * launches of at least a few hundred tiles (the fp32-MFMA core keeps the rest). */
+int64_t dcl_linear_split_weight_bytes(int K, int N);
+int dcl_linear_split_weight(const float *Wt, int64_t ldw, int K, int N, void *planes, dclStream_t stream);
+int dcl_linear_split_fwd(const float *x, int64_t ldx, const void *planes, const float *bias, float *y, int64_t ldy, int M, int N,
+                         int K, int relu, dclStream_t stream);
+int dcl_linear_split_pool_fwd(const float *x, int64_t ldx, const void *planes, const float *bias, const float *roww,
+                              int rows_per_crop, int64_t w_stride, float *part, int64_t ldp, int M, int N, int K, int relu,
+                              dclStream_t stream);
+int dcl_linear_split_rowdot_fwd(const float *x, int64_t ldx, const void *planes, const float *bias, const float *w3, int64_t ldw3,
+                                const float *b3, float *out, int M, int N, int K, dclStream_t stream);
 /* The softmax half of dcl_conf_pool alone: conf (b, n1 + n2) = sigmoid(cat[logit1, logit2]), w (b, n1 + n2) = softmax(conf) per
  * crop, wsum (b, 2) = the weight sums of the two directions (models/DCL_Net.py:217-222). */
 int dcl_conf_softmax(int b, int n1, int n2, const float *logit1, const float *logit2, float *conf, float *w, float *wsum,

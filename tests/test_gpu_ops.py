@@ -1622,3 +1622,58 @@ def test_point_neighbours_grid_search_is_exact(request, dcl, scales, unit):
     whole = run.point_features(pb4, extents, off)
     halves = run.point_interpolate(*run.point_neighbours(pb4, extents, off))
     assert torch.equal(torch.nan_to_num(whole), torch.nan_to_num(halves))     # NaN rows: queries without any voxel
+
+
+def test_split_bf16_gemm_core_matches_float64_like_the_fp32_core(dcl):
+    """dcl_linear_split_fwd (csrc/linear_split.hip: three bf16 pieces per fp32 operand, six piece products, fp32 accumulators)
+    against float64 products, beside the fp32-MFMA core on the same operands: errors of the same size (the bound asserted is the
+    fp32 core's tolerance), ragged row counts, column counts that are no multiple of a tile, a lone output column, operands and
+    outputs that are column blocks of wider buffers (neighbours untouched), values spread over many binades, exact zeros"""
+    g = torch.Generator().manual_seed(33)
+    worst = 0.0
+    for M, K, n in ((1000, 256, 64), (4096, 480, 1024), (37, 128, 1), (2048, 512, 512), (333, 512, 96), (517, 256, 256), (129, 16, 260),
+                    (70000, 48, 130)):
+        wide = torch.randn(M, K + 40, generator=g) * torch.exp2(torch.randint(-6, 7, (M, 1), generator=g).float())
+        wide[::7, ::5] = 0.0
+        wide = wide.cuda()
+        x = wide[:, 8:8 + K]
+        Wt = (torch.randn(K, n, generator=g) * 0.05).cuda()
+        bias = torch.randn(n, generator=g).cuda()
+        sw = dcl.ops.SplitWeight(Wt)
+        for relu, with_bias in ((True, True), (False, False)):
+            want = x.double() @ Wt.double() + (bias.double() if with_bias else 0.0)
+            want = torch.relu(want) if relu else want
+            tol = 2e-5 * max(1.0, float(want.abs().max()))
+            got = dcl.ops.linear_split(x, sw, bias if with_bias else None, relu)
+            err = float((got.double() - want).abs().max())
+            assert err <= tol, (M, K, n, relu, err, tol)
+            if K % 32 == 0:
+                ref = dcl.ops.linear_dma(x, dcl.ops.pad_linear_weight(Wt), bias if with_bias else None, relu)
+                err32 = float((ref.double() - want).abs().max())
+                worst = max(worst, err / max(err32, 1e-30))
+            buf = torch.full((M, n + 24), 7.0).cuda()
+            dcl.ops.linear_split(x, sw, bias if with_bias else None, relu, out=buf[:, 16:16 + n])
+            assert torch.equal(buf[:, 16:16 + n], got)
+            assert bool((buf[:, :16] == 7.0).all()) and bool((buf[:, 16 + n:] == 7.0).all())
+    assert worst <= 4.0, "split-bf16 errors against float64 should be the size of the fp32 core's: worst ratio %.2f" % worst
+    with pytest.raises(AssertionError):
+        dcl.ops.SplitWeight(torch.zeros(40, 64).cuda())                                # K % 16 != 0
+
+
+def test_split_bf16_pieces_sum_to_the_operand_exactly(dcl):
+    """the three bf16 pieces dcl_linear_split_weight writes add up to the fp32 weight EXACTLY (h + m + l in float64 == w), for
+    normal values over the whole exponent range the network sees and for zeros"""
+    g = torch.Generator().manual_seed(5)
+    K, n = 64, 200
+    Wt = torch.randn(K, n, generator=g) * torch.exp2(torch.randint(-20, 21, (K, n), generator=g).float())
+    Wt[::3, ::4] = 0.0
+    sw = dcl.ops.SplitWeight(Wt.cuda())
+    planes = sw.planes.cpu().view(torch.bfloat16).view(K // 16, 2, 3, 128, 2, 8)       # [chunk][column tile][piece][column][half slot][k]
+    total = planes.double().sum(2)                                                       # h + m + l
+    for kc in range(K // 16):
+        for c in range(n):
+            for hs in range(2):
+                hh = hs ^ ((c % 128 >> 3) & 1)
+                want = Wt[kc * 16 + 8 * hh: kc * 16 + 8 * hh + 8, c].double()
+                assert torch.equal(total[kc, c // 128, c % 128, hs], want), (kc, c, hs)
+    assert float(planes[:, 1, :, 200 - 128:].float().abs().max()) == 0.0                # columns past N are zero

@@ -73,6 +73,9 @@ def test_every_profiled_kernel_is_launched_by_an_oracle_comparing_test(request, 
     #    ADD-S kernel of the bench's metric leg against the reference's expression
     TN.test_stress_shape_full_batch_properties(dcl, oracle)
     TO.test_add_s_matches_reference_expression(dcl)
+    #    ... and every tile shape / K-split of the GEMM core (the cost model picks among them by row count) against float64
+    TO.test_own_gemm_core_matches_float64_on_every_tile_shape(request, dcl)
+    TO.test_own_gemm_core_at_the_benchmarked_row_counts(dcl)
     # -- <round>_ref: 32 crops of N = M = 1024 the way a default Network runs them, four against the oracle graph
     TN.batch_of_reference_shape_crops_vs_oracle(dcl, oracle, 32, "default")
     TN.batch_of_reference_shape_crops_vs_oracle(dcl, oracle, 32, "launch by launch")

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""The own fp32 MFMA GEMM core (dcl_linear_dma_fwd, csrc/linear_dma.hip) against the vendor library (dcl_linear_fwd ->
+"""The own GEMM cores (fp32 MFMA: dcl_linear_dma_fwd, csrc/linear_dma.hip; split-bf16: dcl_linear_split_fwd, csrc/linear_split.hip)
+against the vendor library (dcl_linear_fwd ->
 hipBLASLt) on the linear layers of a forward: us per call and TFLOP/s per layer shape, at the stress shape (32 crops of 12288 /
 2048 points), the reference shape (32 x 1024) and a handful of crops.  usage: tools/bench_linear_dma.py [--tiles] [--check]
   --tiles  also every tile shape of the own core (diagnostic library)   --check  compare both with a float64 product"""
@@ -47,12 +48,15 @@ for M, K, n, ldx, ldy in SHAPES:
     fl = 2.0 * M * K * n
     t_lib = timeit(lambda: dcl.ops.linear_lt(x, Wt, bias, True, out=y))
     t_own = timeit(lambda: dcl.ops.linear_dma(x, Wt, bias, True, out=y))
-    line = "M=%6d K=%4d N=%4d: hipBLASLt %8.1f us (%5.1f TF)  own %8.1f us (%5.1f TF)  own/lib %.3f" % (
-        M, K, n, t_lib, fl / t_lib / 1e6, t_own, fl / t_own / 1e6, t_own / t_lib)
+    sw = dcl.ops.SplitWeight(Wt)
+    t_sp = timeit(lambda: dcl.ops.linear_split(x, sw, bias, True, out=y))
+    line = "M=%6d K=%4d N=%4d: hipBLASLt %8.1f us (%5.1f TF)  own fp32-MFMA %8.1f us (%5.1f TF)  own split-bf16 %8.1f us (%5.1f TF)  own/lib %.3f" % (
+        M, K, n, t_lib, fl / t_lib / 1e6, t_own, fl / t_own / 1e6, t_sp, fl / t_sp / 1e6, min(t_own, t_sp) / t_lib)
     if n == 1024 and K == 512:                            # the last fuser layer: the pooling epilogue instead of the store
         w = torch.rand(M, device="cuda", generator=g)
         t_pool = timeit(lambda: dcl.ops.linear_pool(x, Wt, bias, w))
-        line += "  pool-epilogue %8.1f us (%5.1f TF)" % (t_pool, fl / t_pool / 1e6)
+        t_pool_sp = timeit(lambda: dcl.ops.linear_split_pool(x, sw, bias, w))
+        line += "  pool-epilogue %8.1f us (%5.1f TF), split-bf16 %8.1f us (%5.1f TF)" % (t_pool, fl / t_pool / 1e6, t_pool_sp, fl / t_pool_sp / 1e6)
     if TILES:
         for t, name in ((1, "128x128"), (2, "128x64"), (3, "64x64"), (4, "64x64 K/2")):
             L.dcl_debug_linear_tile(t)
@@ -66,5 +70,7 @@ for M, K, n, ldx, ldy in SHAPES:
         e_own = float((y[rows].double() - want).abs().max())
         dcl.ops.linear_lt(x, Wt, bias, True, out=y)
         e_lib = float((y[rows].double() - want).abs().max())
-        line += "  |err| own %.2e lib %.2e" % (e_own, e_lib)
+        dcl.ops.linear_split(x, sw, bias, True, out=y)
+        e_sp = float((y[rows].double() - want).abs().max())
+        line += "  |err| fp32-MFMA %.2e split-bf16 %.2e lib %.2e" % (e_own, e_sp, e_lib)
     print(line, flush=True)
