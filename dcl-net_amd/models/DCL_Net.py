@@ -236,6 +236,19 @@ class Network(nn.Module):
                     out.append((W.t().contiguous(), bvec.contiguous()))
                     s_prev, t_prev = self._bn_affine(L[bi])
                 f[name] = (out, s_prev.contiguous(), t_prev.contiguous())   # last BN is applied after pooling
+            # the dense layers' weights prepared for the split-bf16 GEMM core (ops.prepare_linear: three bf16 pieces per weight, in
+            # the kernel's tile order): their launches of many crops run there, at fp32-sized errors (csrc/linear_split.hip)
+            for side in ("Xc", "Yo"):
+                W1t, _, second = f["dis_" + side]
+                ops.prepare_linear(W1t)
+                for Wt, _ in second:
+                    ops.prepare_linear(Wt)
+            for name in ("regressor_conf", "regressor_conf_bi", "regressor_Xo", "regressor_Yc"):
+                for Wt, _ in f[name][:2]:
+                    ops.prepare_linear(Wt)
+            for name in ("neck_fuser", "neck_fuser_bi"):
+                for Wt, _ in f[name][0]:
+                    ops.prepare_linear(Wt)
         self._folded = f
         return f
 

@@ -83,6 +83,9 @@ class Refiner(nn.Module):
                 # split the 259-row first weight: rows 0..2 act on xyz, rows 3.. on F_Xo_p
                 Wt, bias = f["MLP_share"][0]
                 f["share0_xyz"], f["share0_feat"] = Wt[:3].contiguous(), Wt[3:].contiguous()
+                # the big layers prepared for the split-bf16 GEMM core (ops.prepare_linear; models/DCL_Net.py: _fold)
+                for Wt in (f["share0_feat"], f["MLP_share"][1][0], f["MLP_share"][2][0]):
+                    ops.prepare_linear(Wt)
             self._folded = f
         return self._folded
 

@@ -7,6 +7,8 @@ library on torch's current stream.  No function here has a CPU fallback.
 import ctypes as C
 import threading
 
+import weakref
+
 import torch
 
 from . import _native as N
@@ -827,9 +829,15 @@ def linear(x, Wt, bias=None, relu=False, out=None):
     x (M,K), Wt (K,N), out (M,N) are row-major 2-D tensors whose rows may be strided (column blocks of wider buffers):
     `out=buf[:, 256:512]` is written in place, no copy.  Runs on the library's OWN fp32 MFMA GEMM core (linear_dma,
     csrc/linear_dma.hip) -- every layer shape of the forward does; a shape that core does not take (K no multiple of 32,
-    operands not 16-byte aligned) goes to the vendor library (linear_lt)."""
-    if not VENDOR_GEMM and x.is_cuda and Wt.is_cuda and x.dim() == 2 and Wt.dim() == 2 and linear_dma_ok(x, Wt):
-        return linear_dma(x, Wt, bias, relu, out)
+    operands not 16-byte aligned) goes to the vendor library (linear_lt).  A layer whose weight has been PREPARED
+    (prepare_linear: the Network's and the Refiner's folded weights are) runs its big launches on the split-bf16 core
+    (linear_split, csrc/linear_split.hip: fp32-sized errors at 1.5x the fp32 MFMA's rate)."""
+    if not VENDOR_GEMM and x.is_cuda and Wt.is_cuda and x.dim() == 2 and Wt.dim() == 2:
+        sw = prepared_linear(Wt, x)
+        if sw is not None:
+            return linear_split(x, sw, bias, relu, out)
+        if linear_dma_ok(x, Wt):
+            return linear_dma(x, Wt, bias, relu, out)
     return linear_lt(x, Wt, bias, relu, out)
 
 
@@ -884,6 +892,42 @@ def linear_dma(x, Wt, bias=None, relu=False, out=None):
     return out
 
 
+GEMM_SPLIT = True              # big launches of prepared layers run on the split-bf16 core (False: the fp32-MFMA core everywhere)
+SPLIT_MIN_TILES = 192          # ... from this many 256 x 128 tiles on (fewer cannot fill the chip: the fp32 core's smaller tiles win)
+_PREPARED = {}                 # id(Wt) -> (weakref to Wt, SplitWeight)
+
+
+def prepare_linear(Wt):
+    """Prepare a layer's (K, N) weight for the split-bf16 GEMM core: its three bf16 pieces in tile order, kept beside the weight
+    for as long as the weight tensor lives.  The weight must not be modified in place afterwards (the models' folded weights are
+    rebuilt, never modified).  Layers of at most 64 output columns or with K no multiple of 16 stay on the fp32 core."""
+    K, n = Wt.shape
+    if not Wt.is_cuda or n <= 64 or K % 16 or K < 16:
+        return None
+    ent = _PREPARED.get(id(Wt))
+    if ent is not None and ent[0]() is Wt:
+        return ent[1]
+    sw = SplitWeight(Wt)
+    sw.Wt = None                                            # (the registry must not keep the weight alive)
+    key = id(Wt)
+    _PREPARED[key] = (weakref.ref(Wt, lambda _r, key=key: _PREPARED.pop(key, None)), sw)
+    return sw
+
+
+def prepared_linear(Wt, x):
+    """the SplitWeight of a prepared layer if this launch should run on the split-bf16 core, else None"""
+    if not GEMM_SPLIT:
+        return None
+    ent = _PREPARED.get(id(Wt))
+    if ent is None or ent[0]() is not Wt:
+        return None
+    sw = ent[1]
+    M = x.shape[0]
+    if ((M + 255) // 256) * ((sw.n + 127) // 128) < SPLIT_MIN_TILES or not linear_split_ok(x, sw.K):
+        return None
+    return sw
+
+
 LINEAR_POOL_TILE = 128         # rows per partial of linear_pool (the GEMM's row tile)
 
 
@@ -894,6 +938,9 @@ def linear_pool(x, Wt, bias, roww, relu=True, part=None, rows_per_crop=None, w_s
     roww[crop * w_stride + point] (a direction's block of conf_softmax's (b, n1 + n2) weights).  With every crop a whole
     number of tiles, a crop's pooled feature is the sum of its tiles' partials (pool_finish2 adds them in tile order)."""
     N.need_cuda(x, Wt, roww)
+    sw = prepared_linear(Wt, x)
+    if sw is not None:
+        return linear_split_pool(x, sw, bias, roww, relu, part, rows_per_crop, w_stride)
     M, K = x.shape
     n = Wt.shape[1]
     if rows_per_crop is None:
@@ -916,6 +963,9 @@ def linear_rowdot(x, Wt, bias, w3, b3, out=None):
     GEMM of the own core with the row dot as its epilogue (csrc/linear_dma.hip, EPI = 2) -- the hidden columns are never stored.
     x (M,K), Wt (K,N <= 128), bias (N,), w3 (N,1) (rows may be padded: pad_linear_weight), b3 (1,) -> (M,1)."""
     N.need_cuda(x, Wt, w3, b3)
+    sw = prepared_linear(Wt, x)
+    if sw is not None:
+        return linear_split_rowdot(x, sw, bias, w3, b3, out)
     M, K = x.shape
     n = Wt.shape[1]
     assert n <= 128 and w3.shape == (n, 1) and b3.numel() == 1 and bias.numel() == n
