@@ -529,6 +529,240 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_cross_attn_dma(
   }
 }
 
+// ---- the same attention with the P.V product (5/6 of its flop) on the bf16 matrix pipe at fp32-sized errors ------------------
+// (the scheme of linear_split.hip: every fp32 operand = the exact sum of three bf16 pieces, a product = its six piece products of
+//  weight >= 2^-16, fp32 accumulators).  V is the shared operand: a pre-pass (k_attn_split_v) writes each crop's [V1 | V2] rows as
+// pieces, per 16-key half tile in exactly the order the MFMA's A operand wants them (lane (r, h) of channel block t: the eight keys
+// (e & 3) + 8 (e >> 2) + 4 h of the half tile for channel 32 t + r -- the key order the S accumulators already have), 30 KiB per
+// half tile, so a half tile is ONE linear LDS-DMA copy and a fragment ONE ds_read_b128.  P = exp(S - m) is split in registers, once
+// per tile and wave (the S accumulators become the B operand as before, piece by piece).  S = K Q^T (1/6 of the flop) stays on the
+// fp32 MFMA: its Q operand would need 96 KiB of LDS as pieces.  Per 32-key tile and wave: 32 fp32 MFMAs (2048 cycles) + 120 bf16
+// MFMAs (3840) against 192 fp32 MFMAs (12288).  Half tiles A / B of a tile sit in two LDS buffers; A(t+1) is fetched under P.V of
+// B(t), B(t+1) under S and P.V of A(t+1): three barriers per tile.
+typedef __bf16 at_bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 at_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float at_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned at_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kAttnHalfBytes = 3 * 320 * 2 * 16;   // one 16-key half tile of V pieces: [piece][channel][lane half][8 keys] bf16 = 30 KiB
+
+__device__ __forceinline__ unsigned at_cvt2(float a, float b) {
+  const at_f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, at_bf16x2));
+}
+__device__ __forceinline__ void at_split2(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {     // x = h + m + l exactly
+  h = at_cvt2(x0, x1);
+  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+  m = at_cvt2(r0, r1);
+  const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+  l = at_cvt2(s0, s1);
+}
+__device__ __forceinline__ at_bf16x8 at_bf(at_u32x4 v) { return __builtin_bit_cast(at_bf16x8, v); }
+
+// planes[crop][half tile][piece][channel c][slot hs][8] (bf16), slot hs holds lane half h = hs ^ bit 3 of c (bank swizzle), element
+// e = key 16 ht + (e & 3) + 8 (e >> 2) + 4 h; keys >= nk are zeros.  One thread per (crop, half tile, c, hs).
+__global__ __launch_bounds__(256) void k_attn_split_v(int nk, int nht, const float *__restrict__ V1, int ldv1, const float *__restrict__ V2,
+                                                      int ldv2, unsigned *__restrict__ planes, long long total) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int hs = (int)(i & 1);
+    const long long q = i >> 1;
+    const int c = (int)(q % 320);
+    const long long cht = q / 320;                         // crop * nht + half tile
+    const int ht = (int)(cht % nht), crop = (int)(cht / nht);
+    const int h = hs ^ ((c >> 3) & 1);
+    const float *col = c < 256 ? V1 + c : V2 + (c - 256);
+    const int ld = c < 256 ? ldv1 : ldv2;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int key = 16 * ht + (e & 3) + 8 * (e >> 2) + 4 * h;
+      v[e] = key < nk ? col[((size_t)crop * nk + key) * ld] : 0.0f;
+    }
+    unsigned ph[4], pm[4], pl[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) at_split2(v[2 * e], v[2 * e + 1], ph[e], pm[e], pl[e]);
+    unsigned *dst = planes + (size_t)cht * (kAttnHalfBytes / 4) + (size_t)(c * 2 + hs) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { dst[e] = ph[e]; dst[320 * 2 * 4 + e] = pm[e]; dst[2 * 320 * 2 * 4 + e] = pl[e]; }
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void k_cross_attn_split(
+    int nq, int nk, const float *__restrict__ Q, int ldq, const float *__restrict__ K, int ldk, const unsigned char *__restrict__ planes,
+    float *__restrict__ O1, int ldo1, float *__restrict__ O2, int ldo2, float *__restrict__ part, int xcd_remap) {
+  constexpr int NVT = 10, WAVES = 8;
+  constexpr int KT = 32 * kKPitch;
+  extern __shared__ float attn_lds[];              // [K tile fp32][V pieces: half tile A | half tile B][Q x8 fp32]
+  float *Ks = attn_lds;
+  unsigned char *Vp = reinterpret_cast<unsigned char *>(Ks + KT);
+  int bx, b;
+  {
+    const int nwg = gridDim.x * gridDim.y, id = blockIdx.x + gridDim.x * blockIdx.y;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = id & 7;
+    const int swz = !xcd_remap ? id : (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (id >> 3);
+    bx = swz % (int)gridDim.x;
+    b = swz / (int)gridDim.x;
+  }
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  constexpr int QB = WAVES * 32;
+  const int q = bx * QB + wave * 32 + r;
+  const bool qlive = q < nq;
+  float *Qs = reinterpret_cast<float *>(Vp + 2 * kAttnHalfBytes) + wave * 32 * kKPitch;
+  for (int i = lane; i < 32 * 16; i += 64) {
+    const int qr = i >> 4, c4 = (i & 15) * 4;
+    const int qq = bx * QB + wave * 32 + qr;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (qq < nq) v = *reinterpret_cast<const float4 *>(Q + ((size_t)b * nq + qq) * ldq + c4);
+    *reinterpret_cast<float4 *>(Qs + qr * kKPitch + c4) = v;
+  }
+  const int last_key = nk - 1;
+  const size_t krow0 = (size_t)b * nk;
+  const int nht = 2 * ((nk + 31) >> 5);
+  const unsigned char *vsrc = planes + (size_t)b * nht * kAttnHalfBytes + lane * 16;
+  const unsigned vp0 = lds_addr_of(reinterpret_cast<const float *>(Vp));
+  // a half tile = 30 one-KiB DMA pieces: wave w issues pieces w, w + 8, w + 16, w + 24 (< 30)
+  auto dma_half = [&](int ht, int buf) {
+    const unsigned char *src = vsrc + (size_t)ht * kAttnHalfBytes;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int piece = wave + 8 * i;
+      if (piece < 30) glds16(src + piece * 1024, vp0 + (unsigned)(buf * kAttnHalfBytes + piece * 1024));
+    }
+  };
+  // this thread's float4 of the K tile (512 per tile over 512 threads)
+  const int kkey = tid >> 4, kc4 = (tid & 15) * 4;
+  float4 knext = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto load_k = [&](int kb) { knext = *reinterpret_cast<const float4 *>(K + (krow0 + min(kb + kkey, last_key)) * ldk + kc4); };
+  auto store_k = [&]() { *reinterpret_cast<float4 *>(Ks + kkey * kKPitch + kc4) = knext; };
+
+  f32x16 O[NVT];
+#pragma unroll
+  for (int t = 0; t < NVT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) O[t][e] = 0.0f;
+  float m_ref = -INFINITY, l_part = 0.0f;
+
+  const int ntiles = (nk + 31) >> 5;
+  const int kb_begin = (int)((long long)blockIdx.z * ntiles / gridDim.z) * 32;
+  const int kb_end = min((int)((long long)(blockIdx.z + 1) * ntiles / gridDim.z) * 32, nk);
+  load_k(kb_begin);
+  store_k();
+  dma_half(kb_begin >> 4, 0);
+  dma_half((kb_begin >> 4) + 1, 1);
+  // fragment address of (piece 0, channel block 0) in buffer 0: slot (h ^ bit 3 of r) of channel r
+  const unsigned char *vfrag = Vp + ((r * 2 + (h ^ ((r >> 3) & 1))) << 4);
+  for (int kb = kb_begin; kb < kb_end; kb += 32) {
+    const bool more = kb + 32 < kb_end;
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): this wave's DMA pieces of half tile A (first tile: and B) have landed
+    __syncthreads();                                       // A: K tile and half tile A visible; everyone is done with half tile B of the last tile
+    if (kb > kb_begin) dma_half((kb >> 4) + 1, 1);         // half tile B of THIS tile: lands under S and P.V of A
+
+    f32x16 S;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) S[e] = 0.0f;
+    {
+      const float *krow = Ks + r * kKPitch + 32 * h;
+      const float *qrow = Qs + r * kKPitch + 32 * h;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float4 a = *reinterpret_cast<const float4 *>(krow + 4 * i);
+        const float4 qv = *reinterpret_cast<const float4 *>(qrow + 4 * i);
+        S = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qv.x, S, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qv.y, S, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qv.z, S, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qv.w, S, 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);                    // lgkmcnt(0) only: the DMA stays in flight
+    __builtin_amdgcn_s_barrier();                          // B: every wave is done with the K tile
+    if (more) load_k(kb + 32);
+
+    float m_tile = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      if (kb + rowmap(e, h) >= nk) S[e] = -INFINITY;
+      m_tile = fmaxf(m_tile, S[e]);
+    }
+    m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
+    if (__ballot(m_tile > m_ref + kThr) != 0ull) {
+      const float m_new = fmaxf(m_ref, m_tile);
+      const float f = __expf(m_ref - m_new);
+      l_part *= f;
+#pragma unroll
+      for (int t = 0; t < NVT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) O[t][e] *= f;
+      m_ref = m_new;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      S[e] = __expf(S[e] - m_ref);
+      l_part += S[e];
+    }
+    // the tile's weights as bf16 pieces: half tile A = accumulators 0..7, B = 8..15 (lane half h: keys (e & 3) + 8 (e >> 2) + 4 h)
+    at_u32x4 pp[2][3];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        unsigned ph, pm, pl;
+        at_split2(S[8 * hf + 2 * e], S[8 * hf + 2 * e + 1], ph, pm, pl);
+        pp[hf][0][e] = ph; pp[hf][1][e] = pm; pp[hf][2][e] = pl;
+      }
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      if (hf == 1) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this wave's pieces of half tile B (and its K float4)
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();                      // C: half tile B visible; everyone is done with half tile A ...
+        if (more) dma_half((kb >> 4) + 2, 0);              // ... which the next tile's A lands in, under P.V of B
+      }
+      const unsigned char *vb = vfrag + hf * kAttnHalfBytes;
+#pragma unroll
+      for (int t = 0; t < NVT; ++t) {
+        const at_u32x4 vh = *reinterpret_cast<const at_u32x4 *>(vb + t * 1024);
+        const at_u32x4 vm = *reinterpret_cast<const at_u32x4 *>(vb + 320 * 32 + t * 1024);
+        const at_u32x4 vl = *reinterpret_cast<const at_u32x4 *>(vb + 2 * 320 * 32 + t * 1024);
+        O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_bf(vl), at_bf(pp[hf][0]), O[t], 0, 0, 0);
+        O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_bf(vh), at_bf(pp[hf][2]), O[t], 0, 0, 0);
+        O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_bf(vm), at_bf(pp[hf][1]), O[t], 0, 0, 0);
+        O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_bf(vm), at_bf(pp[hf][0]), O[t], 0, 0, 0);
+        O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_bf(vh), at_bf(pp[hf][1]), O[t], 0, 0, 0);
+        O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_bf(vh), at_bf(pp[hf][0]), O[t], 0, 0, 0);
+      }
+    }
+    if (more) store_k();
+  }
+
+  asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+  const float l_tot = l_part + __shfl_xor(l_part, 32, 64);
+  if (qlive && gridDim.z > 1) {
+    const size_t rows = (size_t)gridDim.y * nq;
+    float *P = part + ((size_t)blockIdx.z * rows + (size_t)b * nq + q) * kAttnPartPitch;
+#pragma unroll
+    for (int t = 0; t < NVT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4 *>(P + t * 32 + 8 * g + 4 * h) =
+            make_float4(O[t][4 * g], O[t][4 * g + 1], O[t][4 * g + 2], O[t][4 * g + 3]);
+    if (h == 0) { P[320] = m_ref; P[321] = l_tot; }
+  } else if (qlive) {
+    const size_t row = (size_t)b * nq + q;
+#pragma unroll
+    for (int t = 0; t < NVT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = t * 32 + 8 * g + 4 * h;
+        float4 v;
+        v.x = O[t][4 * g] / l_tot; v.y = O[t][4 * g + 1] / l_tot;
+        v.z = O[t][4 * g + 2] / l_tot; v.w = O[t][4 * g + 3] / l_tot;
+        if (c < 256) *reinterpret_cast<float4 *>(O1 + row * ldo1 + c) = v;
+        else *reinterpret_cast<float4 *>(O2 + row * ldo2 + (c - 256)) = v;
+      }
+  }
+}
+
 // out[row][c] = sum_z e^{m_z - m} O_z[c] / sum_z e^{m_z - m} l_z, m = max_z m_z (splits in index order); thread = 4 channels
 __global__ void k_cross_attn_combine(int rows, int nsplit, const float *__restrict__ part, float *__restrict__ O1, int ldo1,
                                      float *__restrict__ O2, int ldo2) {
@@ -922,12 +1156,40 @@ DCL_API int dcl_cross_attention_ws(int b, int nq, int nk, const float *Q, int ld
 
 static int attn_dispatch(int b, int nq, int nk, const float *Q, int ldq, const float *K, int ldk, const float *V1, int dv1, int ldv1,
                          float *O1, int ldo1, const float *V2, int dv2, int ldv2, float *O2, int ldo2, float *scratch,
-                         int64_t scratch_floats, int concurrent_launches, dclStream_t stream);
+                         int64_t scratch_floats, int concurrent_launches, void *planes, int64_t planes_bytes, dclStream_t stream);
+
+// does a call of this size take the 8-wave workgroup form (see attn_dispatch), the one the split-bf16 kernel exists for?
+DCL_HOOK_INT(g_attn_bf16, 1);        // (diagnostic library: dcl_debug_attention_bf16; 0 = fp32 MFMA everywhere)
+static bool attn_takes_w8(int b, int nq, int concurrent_launches) {
+  const long long blocks8 = (long long)b * dcl_div_up(nq, 256);
+  const bool pair8 = concurrent_launches == 2 && 2 * blocks8 > 240 && 2 * blocks8 <= 256;
+  return g_attn_variant == 3 || (g_attn_variant == 0 && (blocks8 >= 256 || pair8));
+}
+#ifdef DCL_DIAG
+DCL_API void dcl_debug_attention_bf16(int on) { g_attn_bf16 = on; }
+#endif
+
+DCL_API int64_t dcl_cross_attention_planes_bytes(int b, int nq, int nk, int concurrent_launches) {
+  if (b <= 0 || nq <= 0 || nk <= 0 || !g_attn_bf16) return 0;
+  int crops = b;
+  const int full = attn_pair_full_crops(b, nq, 256, 64, concurrent_launches);
+  if (full) crops = full;                                  // (the rest of such a call runs as a small call: 4-wave workgroups)
+  if (!attn_takes_w8(crops, nq, concurrent_launches)) return 0;
+  return (int64_t)crops * 2 * dcl_div_up(nk, 32) * kAttnHalfBytes;
+}
 
 DCL_API int dcl_cross_attention_ws2(int b, int nq, int nk, const float *Q, int ldq, const float *K, int ldk,
                                     const float *V1, int dv1, int ldv1, float *O1, int ldo1, const float *V2, int dv2,
                                     int ldv2, float *O2, int ldo2, float *scratch, int64_t scratch_floats,
                                     int concurrent_launches, dclStream_t stream) {
+  return dcl_cross_attention_ws3(b, nq, nk, Q, ldq, K, ldk, V1, dv1, ldv1, O1, ldo1, V2, dv2, ldv2, O2, ldo2, scratch, scratch_floats,
+                                 concurrent_launches, nullptr, 0, stream);
+}
+
+DCL_API int dcl_cross_attention_ws3(int b, int nq, int nk, const float *Q, int ldq, const float *K, int ldk,
+                                    const float *V1, int dv1, int ldv1, float *O1, int ldo1, const float *V2, int dv2,
+                                    int ldv2, float *O2, int ldo2, float *scratch, int64_t scratch_floats,
+                                    int concurrent_launches, void *planes, int64_t planes_bytes, dclStream_t stream) {
   DCL_CHECK_ARG(concurrent_launches == 1 || concurrent_launches == 2);
   // A pair of launches whose 8-wave workgroups make one or more WHOLE rounds of the chip plus a rest (40 crops of 1024 x 1024: 1.25
   // rounds): the whole rounds go as they are (8-wave, two waves per SIMD), the rest as the call of that many crops that it is
@@ -935,20 +1197,20 @@ DCL_API int dcl_cross_attention_ws2(int b, int nq, int nk, const float *Q, int l
   const int full = (b > 0 && Q && K && V1 && O1) ? attn_pair_full_crops(b, nq, dv1, dv2, concurrent_launches) : 0;
   if (full) {
     int rc = attn_dispatch(full, nq, nk, Q, ldq, K, ldk, V1, dv1, ldv1, O1, ldo1, V2, dv2, ldv2, O2, ldo2, scratch, scratch_floats,
-                           concurrent_launches, stream);
+                           concurrent_launches, planes, planes_bytes, stream);
     if (rc) return rc;
     const size_t qo = (size_t)full * nq, ko = (size_t)full * nk;
     return attn_dispatch(b - full, nq, nk, Q + qo * ldq, ldq, K + ko * ldk, ldk, V1 + ko * ldv1, dv1, ldv1, O1 + qo * ldo1, ldo1,
                          V2 ? V2 + ko * ldv2 : nullptr, dv2, ldv2, O2 ? O2 + qo * ldo2 : nullptr, ldo2, scratch, scratch_floats,
-                         concurrent_launches, stream);
+                         concurrent_launches, nullptr, 0, stream);
   }
   return attn_dispatch(b, nq, nk, Q, ldq, K, ldk, V1, dv1, ldv1, O1, ldo1, V2, dv2, ldv2, O2, ldo2, scratch, scratch_floats,
-                       concurrent_launches, stream);
+                       concurrent_launches, planes, planes_bytes, stream);
 }
 
 static int attn_dispatch(int b, int nq, int nk, const float *Q, int ldq, const float *K, int ldk, const float *V1, int dv1, int ldv1,
                          float *O1, int ldo1, const float *V2, int dv2, int ldv2, float *O2, int ldo2, float *scratch,
-                         int64_t scratch_floats, int concurrent_launches, dclStream_t stream) {
+                         int64_t scratch_floats, int concurrent_launches, void *planes, int64_t planes_bytes, dclStream_t stream) {
   DCL_CHECK_ARG(b >= 0 && nq >= 0 && nk > 0 && dv1 > 0 && dv1 % 32 == 0 && dv2 >= 0 && dv2 % 32 == 0);
   if (b == 0 || nq == 0) return 0;
   DCL_CHECK_ARG(Q && K && V1 && O1 && (dv2 == 0 || (V2 && O2)) && b <= 65535);
@@ -994,9 +1256,22 @@ static int attn_dispatch(int b, int nq, int nk, const float *Q, int ldq, const f
         while (nsplit > 1 && (long long)nsplit * b * nq * kAttnPartPitch > scratch_floats) --nsplit;
         if (nsplit < 1) nsplit = 1;
       }
-      (void)hipFuncSetAttribute((const void *)k_cross_attn_dma<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(k_cross_attn_dma<8>, dim3(dcl_div_up(nq, 256), b, nsplit), dim3(512), lds, s, nq, nk, Q, ldq, K, ldk,
-                         V1, ldv1, O1, ldo1, V2, ldv2, O2, ldo2, scratch, (int)g_attn_xcd_remap);
+      const int nht = 2 * dcl_div_up(nk, 32);
+      const int64_t planes_need = (int64_t)b * nht * kAttnHalfBytes;
+      if (planes && planes_bytes >= planes_need && g_attn_bf16 && (((uintptr_t)planes) & 15) == 0) {
+        // P.V on the bf16 matrix pipe at fp32-sized errors: V as three exact bf16 pieces in tile order (one pass), then the sweep
+        const long long total = (long long)b * nht * 320 * 2;
+        hipLaunchKernelGGL(k_attn_split_v, dim3(dcl_grid_1d(total, 256)), dim3(256), 0, s, nk, nht, V1, ldv1, V2, ldv2,
+                           (unsigned *)planes, total);
+        const size_t lds_sp = (size_t)(32 * kKPitch + 8 * 32 * kKPitch) * sizeof(float) + 2 * kAttnHalfBytes;
+        (void)hipFuncSetAttribute((const void *)k_cross_attn_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp);
+        hipLaunchKernelGGL(k_cross_attn_split, dim3(dcl_div_up(nq, 256), b, nsplit), dim3(512), lds_sp, s, nq, nk, Q, ldq, K, ldk,
+                           (const unsigned char *)planes, O1, ldo1, O2, ldo2, scratch, (int)g_attn_xcd_remap);
+      } else {
+        (void)hipFuncSetAttribute((const void *)k_cross_attn_dma<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_cross_attn_dma<8>, dim3(dcl_div_up(nq, 256), b, nsplit), dim3(512), lds, s, nq, nk, Q, ldq, K, ldk,
+                           V1, ldv1, O1, ldo1, V2, ldv2, O2, ldo2, scratch, (int)g_attn_xcd_remap);
+      }
       if (nsplit > 1)
         hipLaunchKernelGGL(k_cross_attn_combine, dim3(dcl_grid_1d((long long)b * nq * 80, 256)), dim3(256), 0, s, b * nq,
                            nsplit, scratch, O1, ldo1, O2, ldo2);

@@ -700,6 +700,9 @@ def _ld(t):
     return t.stride(0) if t.shape[0] > 1 else t.shape[1]
 
 
+ATTENTION_SPLIT = True        # large attention calls: P.V on the bf16 matrix pipe at fp32-sized errors (False: fp32 MFMA everywhere)
+
+
 def cross_attention(b, Q, K, V1, O1, V2=None, O2=None, concurrent=1):
     """One direction of the correspondence attention on POINT-major 2-D operands (row = point):
     Q (b*nq, 64), K (b*nk, 64), V1 (b*nk, dv1) -> O1 (b*nq, dv1) [, V2 -> O2].  Operands may be
@@ -723,10 +726,18 @@ def cross_attention(b, Q, K, V1, O1, V2=None, O2=None, concurrent=1):
         N.check(N.lib().dcl_cross_attention_scratch_floats(b, nq, C.byref(need)), "cross_attention_scratch_floats")
         if need.value:
             scratch = torch.empty(need.value, dtype=torch.float32, device=Q.device)
-    N.check(N.lib().dcl_cross_attention_ws2(b, nq, nk, N.ptr(Q), _ld(Q), N.ptr(K), _ld(K), N.ptr(V1), dv1, _ld(V1),
+    planes = None
+    if dv1 == 256 and dv2 == 64 and ATTENTION_SPLIT:   # large calls: V's bf16 pieces for the split-bf16 P.V (csrc/dense.hip)
+        lib = N.lib()
+        lib.dcl_cross_attention_planes_bytes.restype = C.c_int64
+        pb = int(lib.dcl_cross_attention_planes_bytes(b, nq, nk, int(concurrent)))
+        if pb:
+            planes = torch.empty(pb, dtype=torch.uint8, device=Q.device)
+    N.check(N.lib().dcl_cross_attention_ws3(b, nq, nk, N.ptr(Q), _ld(Q), N.ptr(K), _ld(K), N.ptr(V1), dv1, _ld(V1),
                                             N.ptr(O1), _ld(O1), N.ptr(V2), dv2, 0 if V2 is None else _ld(V2), N.ptr(O2),
                                             0 if O2 is None else _ld(O2), N.ptr(scratch),
-                                            C.c_int64(0 if scratch is None else scratch.numel()), int(concurrent), N.stream()),
+                                            C.c_int64(0 if scratch is None else scratch.numel()), int(concurrent), N.ptr(planes),
+                                            C.c_int64(0 if planes is None else planes.numel()), N.stream()),
             "cross_attention")
     if ev is not None:
         ev[1].record()

@@ -35,7 +35,7 @@ const char *dcl_last_error(void);
  *   2  round 5-6: dcl_crop_points gained `int32_t *ws` in front of `stream`; dcl_backbone_features_stage,
  *      dcl_backbone_stage_ws_bytes and DCL_ESTAGE_UNSUPPORTED are gone; dcl_linear_fwd ignores its workspace arguments;
  *      new: dcl_linear_dma_fwd, dcl_linear_pool_fwd, dcl_linear_rowdot_fwd, dcl_conf_softmax, dcl_pool_finish2,
- *      dcl_linear_split_weight(_bytes), dcl_linear_split_fwd, dcl_linear_split_pool_fwd, dcl_linear_split_rowdot_fwd                            */
+ *      dcl_linear_split_weight(_bytes), dcl_linear_split_fwd / _pool_fwd / _rowdot_fwd, dcl_cross_attention_ws3 (+ _planes_bytes)                         */
 #define DCL_ABI_VERSION 2
 int dcl_abi_version(void);
 
@@ -386,6 +386,15 @@ int dcl_cross_attention_ws2(int b, int nq, int nk, const float *Q, int ldq, cons
                             const float *V1, int dv1, int ldv1, float *O1, int ldo1,
                             const float *V2, int dv2, int ldv2, float *O2, int ldo2,
                             float *scratch, int64_t scratch_floats, int concurrent_launches, dclStream_t stream);
+/* dcl_cross_attention_ws2 with the P.V product of large calls on the bf16 matrix pipe at fp32-sized errors (csrc/dense.hip:
+ * k_cross_attn_split; the scheme of dcl_linear_split_fwd): `planes` is scratch for V's three bf16 pieces in tile order,
+ * dcl_cross_attention_planes_bytes(b, nq, nk, concurrent_launches) bytes (0 = a call of this size keeps the fp32-MFMA kernel;
+ * planes = NULL or fewer bytes: likewise), 16-byte aligned.  V must be [256 | 64] channels. */
+int64_t dcl_cross_attention_planes_bytes(int b, int nq, int nk, int concurrent_launches);
+int dcl_cross_attention_ws3(int b, int nq, int nk, const float *Q, int ldq, const float *K, int ldk,
+                            const float *V1, int dv1, int ldv1, float *O1, int ldo1, const float *V2, int dv2,
+                            int ldv2, float *O2, int ldo2, float *scratch, int64_t scratch_floats,
+                            int concurrent_launches, void *planes, int64_t planes_bytes, dclStream_t stream);
 int dcl_cross_attention_scratch_floats(int b, int nq, int64_t *floats_host);
 
 /* Confidence pooling (models/DCL_Net.py:217-228): conf = sigmoid(cat[logit1 (b,n1), logit2
@@ -655,6 +664,9 @@ long long dcl_debug_linear_plan_workspace(int M, int N, int K);
 /* Tuning hook: 1 (default) = a pair of attention launches (dcl_cross_attention_ws2, concurrent = 2) that makes whole rounds of
  * 8-wave workgroups plus a rest is issued as two launches (rounds, rest); 0 = one launch. */
 void dcl_debug_attention_pair_split(int on);
+/* Tuning hook: 0 = large attention calls keep the fp32-MFMA kernel even when `planes` are handed in (dcl_cross_attention_ws3);
+ * dcl_cross_attention_planes_bytes then returns 0.  1 (default) = P.V on the bf16 matrix pipe (k_cross_attn_split). */
+void dcl_debug_attention_bf16(int on);
 /* Tuning hook: most crops of a pass whose geometry stage runs as one launch (k_geometry_small; default 16, at most 64;
  * passes of more than 8 crops also need at most 32768 voxel rows). */
 void dcl_debug_geometry_small_batch(int n);

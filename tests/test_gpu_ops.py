@@ -1677,3 +1677,44 @@ def test_split_bf16_pieces_sum_to_the_operand_exactly(dcl):
                 want = Wt[kc * 16 + 8 * hh: kc * 16 + 8 * hh + 8, c].double()
                 assert torch.equal(total[kc, c // 128, c % 128, hs], want), (kc, c, hs)
     assert float(planes[:, 1, :, 200 - 128:].float().abs().max()) == 0.0                # columns past N are zero
+
+
+def test_cross_attention_split_bf16_form_matches_float64_like_the_fp32_form(request, dcl):
+    """k_cross_attn_split (csrc/dense.hip: the 8-wave attention with P.V as six bf16 piece products per fp32 product, V's pieces
+    written by k_attn_split_v) beside k_cross_attn_dma<8> on the same operands, both against float64: ragged query / key counts
+    (keys past nk are zero pieces and -inf scores), large logits, a score spike that forces the lazy rescale late in the key axis,
+    a forced key split (partial records + combine), V2 aliasing K as in the forward; errors of the same size"""
+    lib = enter_diag(dcl, request)
+    lib.dcl_debug_attention_variant(3)                                   # the 8-wave form whatever the size
+    worst = 0.0
+    try:
+        for b, nq, nk, scale, split in ((2, 256, 256, 1.0, 0), (1, 200, 500, 1.0, 0), (3, 64, 96, 6.0, 0), (1, 1000, 132, 0.3, 0),
+                                        (2, 300, 1029, 1.0, 0), (2, 300, 1029, 1.0, 4), (1, 96, 320, 1.0, 0)):
+            g = torch.Generator().manual_seed(nq + nk + split)
+            Q = torch.randn(b, nq, 64, generator=g) * scale
+            K = torch.randn(b, nk, 64, generator=g)
+            if nk == 320:                                                # spikes in tiles 6 and 9
+                K = K * 0.1
+                K[0, 200] = Q[0, 5] * 3.0
+                K[0, 300] = Q[0, 40] * 5.0
+            V1 = torch.randn(b, nk, 256, generator=g) * torch.exp2(torch.randint(-4, 5, (b, nk, 1), generator=g).float())
+            Q, K, V1 = Q.cuda(), K.cuda(), V1.cuda()
+            want = _attn_ref(Q, K, torch.cat([V1, K], 2))
+            tol = 2e-5 * max(1.0, float(want.abs().max()))
+            errs = {}
+            for bf16 in (1, 0):
+                lib.dcl_debug_attention_bf16(bf16)
+                lib.dcl_debug_attention_split(split)
+                O1 = torch.full((b * nq, 256 + 8), 7.0, device="cuda")
+                O2 = torch.empty(b * nq, 64, device="cuda")
+                dcl.ops.cross_attention(b, Q.reshape(-1, 64), K.reshape(-1, 64), V1.reshape(-1, 256), O1[:, :256], K.reshape(-1, 64), O2)
+                got = torch.cat([O1[:, :256].reshape(b, nq, 256), O2.view(b, nq, 64)], 2).double()
+                errs[bf16] = float((got - want).abs().max())
+                assert errs[bf16] <= tol, (b, nq, nk, split, bf16, errs[bf16], tol)
+                assert bool((O1[:, 256:] == 7.0).all())
+            worst = max(worst, errs[1] / max(errs[0], 1e-30))
+    finally:
+        lib.dcl_debug_attention_variant(0)
+        lib.dcl_debug_attention_bf16(1)
+        lib.dcl_debug_attention_split(0)
+    assert worst <= 4.0, "split-bf16 attention errors against float64 should be the size of the fp32 form's: worst ratio %.2f" % worst

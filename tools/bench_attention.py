@@ -22,12 +22,15 @@ Xm, Ym = rnd(b * n, 64, 0.3), rnd(b * m, 64, 0.3)
 Xp, Yp = rnd(b * n, 256), rnd(b * m, 256)
 for name, (Q, K, V1, V2) in (("N->M", (Xm, Ym, Yp, Ym)), ("M->N", (Ym, Xm, Xp, Xm))):
     nq, nk = Q.shape[0] // b, K.shape[0] // b
-    O1 = torch.empty(b * nq, 256, device="cuda"); O2 = torch.empty(b * nq, 64, device="cuda")
-    ops.cross_attention(b, Q, K, V1, O1, V2, O2); torch.cuda.synchronize()
-    a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(reps):
-        ops.cross_attention(b, Q, K, V1, O1, V2, O2)
-    e.record(); torch.cuda.synchronize()
-    ms = a.elapsed_time(e) / reps
-    print("%s b=%d nq=%d nk=%d: %.3f ms  %.1f TFLOP/s" % (name, b, nq, nk, ms, 2.0 * 384 * nq * nk * b / ms / 1e9), flush=True)
+    for bf16, form in ((1, "split-bf16 P.V (incl. the V piece pass)"), (0, "fp32 MFMA")):
+        DIAG.dcl_debug_attention_bf16(bf16)
+        O1 = torch.empty(b * nq, 256, device="cuda"); O2 = torch.empty(b * nq, 64, device="cuda")
+        ops.cross_attention(b, Q, K, V1, O1, V2, O2); torch.cuda.synchronize()
+        a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            ops.cross_attention(b, Q, K, V1, O1, V2, O2)
+        e.record(); torch.cuda.synchronize()
+        ms = a.elapsed_time(e) / reps
+        print("%s b=%d nq=%d nk=%d  %-42s %.3f ms  %.1f TFLOP/s" % (name, b, nq, nk, form + ":", ms, 2.0 * 384 * nq * nk * b / ms / 1e9), flush=True)
+    DIAG.dcl_debug_attention_bf16(1)
