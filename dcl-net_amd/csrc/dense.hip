@@ -550,10 +550,17 @@ __device__ __forceinline__ unsigned at_cvt2(float a, float b) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, at_bf16x2));
 }
 __device__ __forceinline__ void at_split2(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {     // x = h + m + l exactly
+  // (the empty asm statements keep a pair's subtractions scalar: see linear_split.hip, sp_split2)
   h = at_cvt2(x0, x1);
-  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+  float r0 = x0 - __uint_as_float(h << 16);
+  asm volatile("" : "+v"(r0));
+  float r1 = x1 - __uint_as_float(h & 0xffff0000u);
+  asm volatile("" : "+v"(r1));
   m = at_cvt2(r0, r1);
-  const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+  float s0 = r0 - __uint_as_float(m << 16);
+  asm volatile("" : "+v"(s0));
+  float s1 = r1 - __uint_as_float(m & 0xffff0000u);
+  asm volatile("" : "+v"(s1));
   l = at_cvt2(s0, s1);
 }
 __device__ __forceinline__ at_bf16x8 at_bf(at_u32x4 v) { return __builtin_bit_cast(at_bf16x8, v); }

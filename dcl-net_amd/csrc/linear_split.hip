@@ -55,10 +55,18 @@ __device__ __forceinline__ unsigned sp_cvt2(float a, float b) {
 }
 // (x0, x1) -> packed pieces h, m, l with x = h + m + l exactly
 __device__ __forceinline__ void sp_split2(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
+  // (the empty asm statements keep the two subtractions of a pair from being fused into one v_pk_add_f32: packed fp32 VALU beside
+  //  MFMAs costs more than the two scalar instructions it replaces -- MI355X_MICROARCH.md, cycle constants)
   h = sp_cvt2(x0, x1);
-  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+  float r0 = x0 - __uint_as_float(h << 16);
+  asm volatile("" : "+v"(r0));
+  float r1 = x1 - __uint_as_float(h & 0xffff0000u);
+  asm volatile("" : "+v"(r1));
   m = sp_cvt2(r0, r1);
-  const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+  float s0 = r0 - __uint_as_float(m << 16);
+  asm volatile("" : "+v"(s0));
+  float s1 = r1 - __uint_as_float(m & 0xffff0000u);
+  asm volatile("" : "+v"(s1));
   l = sp_cvt2(s0, s1);
 }
 __device__ __forceinline__ sp_bf16x8 sp_bf(sp_u32x4 v) { return __builtin_bit_cast(sp_bf16x8, v); }
@@ -150,14 +158,16 @@ __global__ __launch_bounds__(256, 2) void k_linear_split(const LinSplitArgs a) {
     const unsigned boff = (unsigned)tid * 16u;
     const float *abase = a.x + (size_t)row0 * a.ldx;
     const unsigned char *bbase = a.planes + (size_t)tn * kSpB;
-    auto issue = [&](int stage) {
+    // the 7 DMA pieces of a chunk: 3 of the weight pieces, 4 x-row groups; bases advance behind the last one
+    auto issue_piece = [&](int k, int stage) {
       const unsigned s0 = lds0 + (unsigned)(stage * kSpST);
+      if (k < 3) sp_glds16(boff + (unsigned)(k * 4096), bbase, s0 + (unsigned)(kSpA + k * 4096 + wave * 1024));
+      else sp_glds16(aoff[k - 3], abase, s0 + (unsigned)((wave * 64 + (k - 3) * 16) * 64));
+      if (k == 6) { abase += kSpKC; bbase += bstep; }
+    };
+    auto issue = [&](int stage) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i) sp_glds16(boff + (unsigned)(i * 4096), bbase, s0 + (unsigned)(kSpA + i * 4096 + wave * 1024));
-#pragma unroll
-      for (int i = 0; i < 4; ++i) sp_glds16(aoff[i], abase, s0 + (unsigned)((wave * 64 + i * 16) * 64));
-      abase += kSpKC;
-      bbase += bstep;
+      for (int k = 0; k < 7; ++k) issue_piece(k, stage);
     };
     sp_f32x16 acc[2][4];
 #pragma unroll
@@ -179,38 +189,51 @@ __global__ __launch_bounds__(256, 2) void k_linear_split(const LinSplitArgs a) {
       const int st = c & 1;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // everyone's pieces of chunk c are in (each wave waited for its own at the
       __builtin_amdgcn_s_barrier();                        //  end of the previous chunk); nobody reads the other stage any more ...
-      if (c + 1 < nchunks) issue(st ^ 1);                  // ... which chunk c + 1 lands in, under this chunk's MFMAs
+      // ... which chunk c + 1 lands in, under this chunk's MFMAs.  One instruction stream, pinned group by group (left alone the
+      // compiler splits all of x first, reads every weight fragment next and -- worst -- hoists the wait for the NEXT chunk's DMA in
+      // front of this chunk's MFMAs): first the fragment reads of row block 0 and column block 0 with the DMA issue under their
+      // latency, the split of row block 0, then eight blocks of six MFMAs, the first four each with a quarter of row block 1's
+      // split and the next column block's reads beside them.
+      const bool more = c + 1 < nchunks;
       const unsigned char *sa = afrag + st * kSpST, *sb = bfrag + st * kSpST;
       float4 av[2][2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
+      sp_u32x4 ap[2][3], bp[4][3];
+      auto read_a = [&](int i) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) av[i][q] = *reinterpret_cast<const float4 *>(sa + i * 32 * 64 + (((2 * h + q) ^ asw) << 4));
-      sp_u32x4 bp[4][3];
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
+      };
+      auto read_b = [&](int j) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) bp[j][p] = *reinterpret_cast<const sp_u32x4 *>(sb + p * kSpP + j * 32 * 32);
-      sp_u32x4 ap[2][3];
+      };
+      auto split_a = [&](int i, int part) {                // values 2 part, 2 part + 1 of the row block's eight
+        unsigned ph, pm, pl;
+        const float4 v = av[i][part >> 1];
+        if (part & 1) sp_split2(v.z, v.w, ph, pm, pl); else sp_split2(v.x, v.y, ph, pm, pl);
+        ap[i][0][part] = ph; ap[i][1][part] = pm; ap[i][2][part] = pl;
+      };
+      read_a(0);
+      read_b(0);
+      read_a(1);
+      if (more) issue(st ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int part = 0; part < 4; ++part) split_a(0, part);
+      read_b(1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          unsigned ph, pm, pl;
-          sp_split2(av[i][q].x, av[i][q].y, ph, pm, pl); ap[i][0][2 * q] = ph; ap[i][1][2 * q] = pm; ap[i][2][2 * q] = pl;
-          sp_split2(av[i][q].z, av[i][q].w, ph, pm, pl); ap[i][0][2 * q + 1] = ph; ap[i][1][2 * q + 1] = pm; ap[i][2][2 * q + 1] = pl;
-        }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {                      // small terms first
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(ap[i][2]), sp_bf(bp[j][0]), acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(ap[i][0]), sp_bf(bp[j][2]), acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(ap[i][1]), sp_bf(bp[j][1]), acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(ap[i][1]), sp_bf(bp[j][0]), acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(ap[i][0]), sp_bf(bp[j][1]), acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(ap[i][0]), sp_bf(bp[j][0]), acc[i][j], 0, 0, 0);
-        }
+      for (int blk = 0; blk < 8; ++blk) {
+        const int i = blk >> 2, j = blk & 3;               // small terms first
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(ap[i][2]), sp_bf(bp[j][0]), acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(ap[i][0]), sp_bf(bp[j][2]), acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(ap[i][1]), sp_bf(bp[j][1]), acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(ap[i][1]), sp_bf(bp[j][0]), acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(ap[i][0]), sp_bf(bp[j][1]), acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(ap[i][0]), sp_bf(bp[j][0]), acc[i][j], 0, 0, 0);
+        if (blk < 4) split_a(1, blk);
+        if (blk < 2) read_b(blk + 2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of the next chunk have landed
     }
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");      // MFMA -> VALU read of the accumulators
@@ -234,8 +257,8 @@ __global__ __launch_bounds__(256, 2) void k_linear_split(const LinSplitArgs a) {
             for (int e = 0; e < 16; ++e) {
               float v = acc[i][j][e] + bias[j];
               if (a.relu) v = fmaxf(v, 0.0f);
-              yp[(size_t)((e & 3) + 8 * (e >> 2)) * a.ldy] = v;
-            }
+              __builtin_nontemporal_store(v, yp + (size_t)((e & 3) + 8 * (e >> 2)) * a.ldy);   // (an activation of hundreds of MB: read
+            }                                                                                  //  once by the next layer, from HBM anyway)
           }
       } else {
 #pragma unroll
