@@ -544,6 +544,8 @@ typedef __bf16 at_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float at_f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned at_u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kAttnHalfBytes = 3 * 320 * 2 * 16;   // one 16-key half tile of V pieces: [piece][channel][lane half][8 keys] bf16 = 30 KiB
+constexpr int kAttnKTileBytes = 3 * 32 * 128;      // one 32-key tile of K pieces: [piece][key][8 groups of 8 channels] bf16 = 12 KiB
+constexpr int kAttnTileBytes = 2 * kAttnHalfBytes + kAttnKTileBytes;     // scratch per 32-key tile and crop
 
 __device__ __forceinline__ unsigned at_cvt2(float a, float b) {
   const at_f32x2 v = {a, b};
@@ -593,14 +595,40 @@ __global__ __launch_bounds__(256) void k_attn_split_v(int nk, int nht, const flo
   }
 }
 
+// K's pieces: kplanes[crop][32-key tile][piece][key][slot ps][8 channels] (bf16), slot ps holds channel group p = ps ^ ((key >> 1) & 7)
+// (bank swizzle: the A-operand fragment of lane (key, h) in k step s is group 2 s + h).  One thread per (crop, tile, key, ps).
+__global__ __launch_bounds__(256) void k_attn_split_k(int nk, int ntiles, const float *__restrict__ K, int ldk, unsigned *__restrict__ kplanes,
+                                                      long long total) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int ps = (int)(i & 7), key = (int)((i >> 3) & 31);
+    const long long ct = i >> 8;                           // crop * ntiles + tile
+    const int tile = (int)(ct % ntiles), crop = (int)(ct / ntiles);
+    const int p = ps ^ ((key >> 1) & 7), kk = tile * 32 + key;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (kk < nk) {
+      const float *row = K + ((size_t)crop * nk + kk) * ldk + 8 * p;
+      a = *reinterpret_cast<const float4 *>(row);
+      b = *reinterpret_cast<const float4 *>(row + 4);
+    }
+    unsigned ph[4], pm[4], pl[4];
+    at_split2(a.x, a.y, ph[0], pm[0], pl[0]);
+    at_split2(a.z, a.w, ph[1], pm[1], pl[1]);
+    at_split2(b.x, b.y, ph[2], pm[2], pl[2]);
+    at_split2(b.z, b.w, ph[3], pm[3], pl[3]);
+    unsigned *dst = kplanes + (size_t)ct * (kAttnKTileBytes / 4) + (size_t)(key * 8 + ps) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { dst[e] = ph[e]; dst[32 * 32 + e] = pm[e]; dst[2 * 32 * 32 + e] = pl[e]; }
+  }
+}
+
 __global__ __launch_bounds__(512, 2) void k_cross_attn_split(
-    int nq, int nk, const float *__restrict__ Q, int ldq, const float *__restrict__ K, int ldk, const unsigned char *__restrict__ planes,
-    float *__restrict__ O1, int ldo1, float *__restrict__ O2, int ldo2, float *__restrict__ part, int xcd_remap) {
+    int nq, int nk, const float *__restrict__ Q, int ldq, const unsigned char *__restrict__ planes,
+    const unsigned char *__restrict__ kplanes, float *__restrict__ O1, int ldo1, float *__restrict__ O2, int ldo2,
+    float *__restrict__ part, int xcd_remap) {
   constexpr int NVT = 10, WAVES = 8;
-  constexpr int KT = 32 * kKPitch;
-  extern __shared__ float attn_lds[];              // [K tile fp32][V pieces: half tile A | half tile B][Q x8 fp32]
-  float *Ks = attn_lds;
-  unsigned char *Vp = reinterpret_cast<unsigned char *>(Ks + KT);
+  extern __shared__ float attn_lds[];              // [K pieces of a tile][V pieces: half tile A | half tile B][Q x8 fp32]
+  unsigned char *Kp = reinterpret_cast<unsigned char *>(attn_lds);
+  unsigned char *Vp = Kp + kAttnKTileBytes;
   int bx, b;
   {
     const int nwg = gridDim.x * gridDim.y, id = blockIdx.x + gridDim.x * blockIdx.y;
@@ -623,11 +651,11 @@ __global__ __launch_bounds__(512, 2) void k_cross_attn_split(
     if (qq < nq) v = *reinterpret_cast<const float4 *>(Q + ((size_t)b * nq + qq) * ldq + c4);
     *reinterpret_cast<float4 *>(Qs + qr * kKPitch + c4) = v;
   }
-  const int last_key = nk - 1;
-  const size_t krow0 = (size_t)b * nk;
   const int nht = 2 * ((nk + 31) >> 5);
   const unsigned char *vsrc = planes + (size_t)b * nht * kAttnHalfBytes + lane * 16;
+  const unsigned char *ksrc = kplanes + (size_t)b * (nht >> 1) * kAttnKTileBytes + lane * 16;
   const unsigned vp0 = lds_addr_of(reinterpret_cast<const float *>(Vp));
+  const unsigned kp0 = lds_addr_of(reinterpret_cast<const float *>(Kp));
   // a half tile = 30 one-KiB DMA pieces: wave w issues pieces w, w + 8, w + 16, w + 24 (< 30)
   auto dma_half = [&](int ht, int buf) {
     const unsigned char *src = vsrc + (size_t)ht * kAttnHalfBytes;
@@ -637,11 +665,12 @@ __global__ __launch_bounds__(512, 2) void k_cross_attn_split(
       if (piece < 30) glds16(src + piece * 1024, vp0 + (unsigned)(buf * kAttnHalfBytes + piece * 1024));
     }
   };
-  // this thread's float4 of the K tile (512 per tile over 512 threads)
-  const int kkey = tid >> 4, kc4 = (tid & 15) * 4;
-  float4 knext = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto load_k = [&](int kb) { knext = *reinterpret_cast<const float4 *>(K + (krow0 + min(kb + kkey, last_key)) * ldk + kc4); };
-  auto store_k = [&]() { *reinterpret_cast<float4 *>(Ks + kkey * kKPitch + kc4) = knext; };
+  // a tile of K pieces = 12 one-KiB DMA pieces: wave w issues piece w, and piece w + 8 if w < 4
+  auto dma_k = [&](int tile) {
+    const unsigned char *src = ksrc + (size_t)tile * kAttnKTileBytes;
+    glds16(src + wave * 1024, kp0 + (unsigned)(wave * 1024));
+    if (wave < 4) glds16(src + (wave + 8) * 1024, kp0 + (unsigned)((wave + 8) * 1024));
+  };
 
   f32x16 O[NVT];
 #pragma unroll
@@ -653,37 +682,51 @@ __global__ __launch_bounds__(512, 2) void k_cross_attn_split(
   const int ntiles = (nk + 31) >> 5;
   const int kb_begin = (int)((long long)blockIdx.z * ntiles / gridDim.z) * 32;
   const int kb_end = min((int)((long long)(blockIdx.z + 1) * ntiles / gridDim.z) * 32, nk);
-  load_k(kb_begin);
-  store_k();
+  dma_k(kb_begin >> 5);
   dma_half(kb_begin >> 4, 0);
   dma_half((kb_begin >> 4) + 1, 1);
   // fragment address of (piece 0, channel block 0) in buffer 0: slot (h ^ bit 3 of r) of channel r
   const unsigned char *vfrag = Vp + ((r * 2 + (h ^ ((r >> 3) & 1))) << 4);
+  const unsigned char *kfrag = Kp + r * 128;       // key r's row of channel groups; group 2 s + h sits in slot (2 s + h) ^ ((r >> 1) & 7)
+  const int ksw = (r >> 1) & 7;
   for (int kb = kb_begin; kb < kb_end; kb += 32) {
     const bool more = kb + 32 < kb_end;
     __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): this wave's DMA pieces of half tile A (first tile: and B) have landed
-    __syncthreads();                                       // A: K tile and half tile A visible; everyone is done with half tile B of the last tile
+    __syncthreads();                                       // A: K pieces and half tile A visible; everyone is done with half tile B of the last tile
     if (kb > kb_begin) dma_half((kb >> 4) + 1, 1);         // half tile B of THIS tile: lands under S and P.V of A
 
+    // S = K Q^T, 64 deep = four k steps: K's pieces from LDS (A operand: lane (key, h) = channels 16 s + 8 h ..), the wave's Q rows
+    // read as fp32 and split here (B operand: lane (query, h), same channels) -- six piece products per step, smallest first
     f32x16 S;
 #pragma unroll
     for (int e = 0; e < 16; ++e) S[e] = 0.0f;
     {
-      const float *krow = Ks + r * kKPitch + 32 * h;
-      const float *qrow = Qs + r * kKPitch + 32 * h;
+      const float *qrow = Qs + r * kKPitch + 8 * h;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float4 a = *reinterpret_cast<const float4 *>(krow + 4 * i);
-        const float4 qv = *reinterpret_cast<const float4 *>(qrow + 4 * i);
-        S = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qv.x, S, 0, 0, 0);
-        S = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qv.y, S, 0, 0, 0);
-        S = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qv.z, S, 0, 0, 0);
-        S = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qv.w, S, 0, 0, 0);
+      for (int st = 0; st < 4; ++st) {
+        const float4 q0 = *reinterpret_cast<const float4 *>(qrow + 16 * st);
+        const float4 q1 = *reinterpret_cast<const float4 *>(qrow + 16 * st + 4);
+        const unsigned char *kf = kfrag + (((2 * st + h) ^ ksw) << 4);
+        const at_u32x4 kh = *reinterpret_cast<const at_u32x4 *>(kf);
+        const at_u32x4 km = *reinterpret_cast<const at_u32x4 *>(kf + 32 * 128);
+        const at_u32x4 kl = *reinterpret_cast<const at_u32x4 *>(kf + 2 * 32 * 128);
+        at_u32x4 qh, qm, ql;
+        unsigned a0, a1, a2;
+        at_split2(q0.x, q0.y, a0, a1, a2); qh[0] = a0; qm[0] = a1; ql[0] = a2;
+        at_split2(q0.z, q0.w, a0, a1, a2); qh[1] = a0; qm[1] = a1; ql[1] = a2;
+        at_split2(q1.x, q1.y, a0, a1, a2); qh[2] = a0; qm[2] = a1; ql[2] = a2;
+        at_split2(q1.z, q1.w, a0, a1, a2); qh[3] = a0; qm[3] = a1; ql[3] = a2;
+        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_bf(kl), at_bf(qh), S, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_bf(kh), at_bf(ql), S, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_bf(km), at_bf(qm), S, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_bf(km), at_bf(qh), S, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_bf(kh), at_bf(qm), S, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_bf(kh), at_bf(qh), S, 0, 0, 0);
       }
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);                    // lgkmcnt(0) only: the DMA stays in flight
-    __builtin_amdgcn_s_barrier();                          // B: every wave is done with the K tile
-    if (more) load_k(kb + 32);
+    __builtin_amdgcn_s_barrier();                          // B: every wave is done with the K pieces ...
+    if (more) dma_k((kb >> 5) + 1);                        // ... which the next tile's land in, under the softmax and P.V
 
     float m_tile = -INFINITY;
 #pragma unroll
@@ -720,7 +763,7 @@ __global__ __launch_bounds__(512, 2) void k_cross_attn_split(
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
       if (hf == 1) {
-        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this wave's pieces of half tile B (and its K float4)
+        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this wave's pieces of half tile B (and of the next K tile)
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();                      // C: half tile B visible; everyone is done with half tile A ...
         if (more) dma_half((kb >> 4) + 2, 0);              // ... which the next tile's A lands in, under P.V of B
@@ -739,7 +782,6 @@ __global__ __launch_bounds__(512, 2) void k_cross_attn_split(
         O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_bf(vh), at_bf(pp[hf][0]), O[t], 0, 0, 0);
       }
     }
-    if (more) store_k();
   }
 
   asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
@@ -1182,7 +1224,7 @@ DCL_API int64_t dcl_cross_attention_planes_bytes(int b, int nq, int nk, int conc
   const int full = attn_pair_full_crops(b, nq, 256, 64, concurrent_launches);
   if (full) crops = full;                                  // (the rest of such a call runs as a small call: 4-wave workgroups)
   if (!attn_takes_w8(crops, nq, concurrent_launches)) return 0;
-  return (int64_t)crops * 2 * dcl_div_up(nk, 32) * kAttnHalfBytes;
+  return (int64_t)crops * dcl_div_up(nk, 32) * kAttnTileBytes;
 }
 
 DCL_API int dcl_cross_attention_ws2(int b, int nq, int nk, const float *Q, int ldq, const float *K, int ldk,
@@ -1264,16 +1306,20 @@ static int attn_dispatch(int b, int nq, int nk, const float *Q, int ldq, const f
         if (nsplit < 1) nsplit = 1;
       }
       const int nht = 2 * dcl_div_up(nk, 32);
-      const int64_t planes_need = (int64_t)b * nht * kAttnHalfBytes;
+      const int64_t planes_need = (int64_t)b * (nht / 2) * kAttnTileBytes;
       if (planes && planes_bytes >= planes_need && g_attn_bf16 && (((uintptr_t)planes) & 15) == 0) {
         // P.V on the bf16 matrix pipe at fp32-sized errors: V as three exact bf16 pieces in tile order (one pass), then the sweep
         const long long total = (long long)b * nht * 320 * 2;
         hipLaunchKernelGGL(k_attn_split_v, dim3(dcl_grid_1d(total, 256)), dim3(256), 0, s, nk, nht, V1, ldv1, V2, ldv2,
                            (unsigned *)planes, total);
-        const size_t lds_sp = (size_t)(32 * kKPitch + 8 * 32 * kKPitch) * sizeof(float) + 2 * kAttnHalfBytes;
+        unsigned char *kplanes = (unsigned char *)planes + (size_t)b * nht * kAttnHalfBytes;
+        const long long ktotal = (long long)b * (nht / 2) * 32 * 8;
+        hipLaunchKernelGGL(k_attn_split_k, dim3(dcl_grid_1d(ktotal, 256)), dim3(256), 0, s, nk, nht / 2, K, ldk, (unsigned *)kplanes, ktotal);
+        const size_t lds_sp = (size_t)(8 * 32 * kKPitch) * sizeof(float) + 2 * kAttnHalfBytes + kAttnKTileBytes;
         (void)hipFuncSetAttribute((const void *)k_cross_attn_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp);
-        hipLaunchKernelGGL(k_cross_attn_split, dim3(dcl_div_up(nq, 256), b, nsplit), dim3(512), lds_sp, s, nq, nk, Q, ldq, K, ldk,
-                           (const unsigned char *)planes, O1, ldo1, O2, ldo2, scratch, (int)g_attn_xcd_remap);
+        hipLaunchKernelGGL(k_cross_attn_split, dim3(dcl_div_up(nq, 256), b, nsplit), dim3(512), lds_sp, s, nq, nk, Q, ldq,
+                           (const unsigned char *)planes, (const unsigned char *)kplanes, O1, ldo1, O2, ldo2, scratch,
+                           (int)g_attn_xcd_remap);
       } else {
         (void)hipFuncSetAttribute((const void *)k_cross_attn_dma<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k_cross_attn_dma<8>, dim3(dcl_div_up(nq, 256), b, nsplit), dim3(512), lds, s, nq, nk, Q, ldq, K, ldk,
