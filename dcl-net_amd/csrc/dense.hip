@@ -621,14 +621,23 @@ __global__ __launch_bounds__(256) void k_attn_split_k(int nk, int ntiles, const 
   }
 }
 
+// The sweep.  Its two halves per tile have opposite appetites -- S + softmax + the splits are vector work (~400 instructions and 24
+// MFMAs per wave), P.V is 120 MFMAs and their fragment reads -- and a SIMD holds two of the workgroup's eight waves: wave w and wave
+// w + 4.  Waves 0-3 and waves 4-7 therefore run HALF A TILE APART: in every barrier interval one group does S / softmax of a tile while
+// the other does P.V (group 0: S(t) in interval 2 t, P.V(t) in 2 t + 1; group 1 one interval later), so a SIMD's matrix pipe and
+// vector pipe can work at the same time instead of taking turns.  One barrier per interval.  K pieces (12 KiB per 32-key tile) and
+// V pieces (60 KiB) are double-buffered: tile t + 1 of both is fetched at the start of interval 2 t + 1 into the buffers tile t - 1
+// left in intervals 2 t - 1 / 2 t.  That fills the LDS (144 KiB), so a wave reads its 32 query rows from global memory (L2) every
+// tile instead of keeping them in LDS: 8 KiB per wave and tile.
 __global__ __launch_bounds__(512, 2) void k_cross_attn_split(
     int nq, int nk, const float *__restrict__ Q, int ldq, const unsigned char *__restrict__ planes,
     const unsigned char *__restrict__ kplanes, float *__restrict__ O1, int ldo1, float *__restrict__ O2, int ldo2,
-    float *__restrict__ part, int xcd_remap) {
+    float *__restrict__ part, int xcd_remap, int whatif) {
   constexpr int NVT = 10, WAVES = 8;
-  extern __shared__ float attn_lds[];              // [K pieces of a tile][V pieces: half tile A | half tile B][Q x8 fp32]
+  constexpr int VT = 2 * kAttnHalfBytes;           // V pieces of a 32-key tile
+  extern __shared__ float attn_lds[];              // [K pieces x2][V pieces x2]
   unsigned char *Kp = reinterpret_cast<unsigned char *>(attn_lds);
-  unsigned char *Vp = Kp + kAttnKTileBytes;
+  unsigned char *Vp = Kp + 2 * kAttnKTileBytes;
   int bx, b;
   {
     const int nwg = gridDim.x * gridDim.y, id = blockIdx.x + gridDim.x * blockIdx.y;
@@ -639,37 +648,31 @@ __global__ __launch_bounds__(512, 2) void k_cross_attn_split(
   }
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;                       // 0: S in even intervals;  1: S in odd intervals
   const int r = lane & 31, h = lane >> 5;
   constexpr int QB = WAVES * 32;
   const int q = bx * QB + wave * 32 + r;
   const bool qlive = q < nq;
-  float *Qs = reinterpret_cast<float *>(Vp + 2 * kAttnHalfBytes) + wave * 32 * kKPitch;
-  for (int i = lane; i < 32 * 16; i += 64) {
-    const int qr = i >> 4, c4 = (i & 15) * 4;
-    const int qq = bx * QB + wave * 32 + qr;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (qq < nq) v = *reinterpret_cast<const float4 *>(Q + ((size_t)b * nq + qq) * ldq + c4);
-    *reinterpret_cast<float4 *>(Qs + qr * kKPitch + c4) = v;
-  }
+  // this lane's query row (B operand of S: lane (query, h) = channels 16 s + 8 h ..); rows past nq read the last query (never stored)
+  const float *qrow = Q + ((size_t)b * nq + min(q, nq - 1)) * ldq + 8 * h;
   const int nht = 2 * ((nk + 31) >> 5);
   const unsigned char *vsrc = planes + (size_t)b * nht * kAttnHalfBytes + lane * 16;
   const unsigned char *ksrc = kplanes + (size_t)b * (nht >> 1) * kAttnKTileBytes + lane * 16;
   const unsigned vp0 = lds_addr_of(reinterpret_cast<const float *>(Vp));
   const unsigned kp0 = lds_addr_of(reinterpret_cast<const float *>(Kp));
-  // a half tile = 30 one-KiB DMA pieces: wave w issues pieces w, w + 8, w + 16, w + 24 (< 30)
-  auto dma_half = [&](int ht, int buf) {
-    const unsigned char *src = vsrc + (size_t)ht * kAttnHalfBytes;
+  // a tile = 12 one-KiB DMA pieces of K pieces + 60 of V pieces: wave w issues K piece w (and w + 8 if w < 4), V pieces w, w + 8, ...
+  auto dma_tile = [&](int tile, int buf) {
+    const unsigned char *ks = ksrc + (size_t)tile * kAttnKTileBytes;
+    const unsigned kd = kp0 + (unsigned)(buf * kAttnKTileBytes);
+    glds16(ks + wave * 1024, kd + (unsigned)(wave * 1024));
+    if (wave < 4) glds16(ks + (wave + 8) * 1024, kd + (unsigned)((wave + 8) * 1024));
+    const unsigned char *vs = vsrc + (size_t)tile * VT;
+    const unsigned vd = vp0 + (unsigned)(buf * VT);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 8; ++i) {
       const int piece = wave + 8 * i;
-      if (piece < 30) glds16(src + piece * 1024, vp0 + (unsigned)(buf * kAttnHalfBytes + piece * 1024));
+      if (piece < 60) glds16(vs + piece * 1024, vd + (unsigned)(piece * 1024));
     }
-  };
-  // a tile of K pieces = 12 one-KiB DMA pieces: wave w issues piece w, and piece w + 8 if w < 4
-  auto dma_k = [&](int tile) {
-    const unsigned char *src = ksrc + (size_t)tile * kAttnKTileBytes;
-    glds16(src + wave * 1024, kp0 + (unsigned)(wave * 1024));
-    if (wave < 4) glds16(src + (wave + 8) * 1024, kp0 + (unsigned)((wave + 8) * 1024));
   };
 
   f32x16 O[NVT];
@@ -678,62 +681,63 @@ __global__ __launch_bounds__(512, 2) void k_cross_attn_split(
 #pragma unroll
     for (int e = 0; e < 16; ++e) O[t][e] = 0.0f;
   float m_ref = -INFINITY, l_part = 0.0f;
+  at_u32x4 pp[2][3];                               // the current tile's weights as bf16 pieces (S interval -> P.V interval)
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) pp[hf][p] = at_u32x4{0u, 0u, 0u, 0u};
 
-  const int ntiles = (nk + 31) >> 5;
-  const int kb_begin = (int)((long long)blockIdx.z * ntiles / gridDim.z) * 32;
-  const int kb_end = min((int)((long long)(blockIdx.z + 1) * ntiles / gridDim.z) * 32, nk);
-  dma_k(kb_begin >> 5);
-  dma_half(kb_begin >> 4, 0);
-  dma_half((kb_begin >> 4) + 1, 1);
-  // fragment address of (piece 0, channel block 0) in buffer 0: slot (h ^ bit 3 of r) of channel r
+  const int ntiles_all = (nk + 31) >> 5;
+  const int t_begin = (int)((long long)blockIdx.z * ntiles_all / gridDim.z);
+  const int t_end = (int)((long long)(blockIdx.z + 1) * ntiles_all / gridDim.z);
+  const int T = t_end - t_begin;                   // this workgroup's tiles (key split: a contiguous range)
+  // fragment addresses in buffer 0: V piece 0 of channel block 0 = slot (h ^ bit 3 of r) of channel r; K = key r's row of channel
+  // groups, group 2 s + h in slot (2 s + h) ^ ((r >> 1) & 7)
   const unsigned char *vfrag = Vp + ((r * 2 + (h ^ ((r >> 3) & 1))) << 4);
-  const unsigned char *kfrag = Kp + r * 128;       // key r's row of channel groups; group 2 s + h sits in slot (2 s + h) ^ ((r >> 1) & 7)
+  const unsigned char *kfrag = Kp + r * 128;
   const int ksw = (r >> 1) & 7;
-  for (int kb = kb_begin; kb < kb_end; kb += 32) {
-    const bool more = kb + 32 < kb_end;
-    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): this wave's DMA pieces of half tile A (first tile: and B) have landed
-    __syncthreads();                                       // A: K pieces and half tile A visible; everyone is done with half tile B of the last tile
-    if (kb > kb_begin) dma_half((kb >> 4) + 1, 1);         // half tile B of THIS tile: lands under S and P.V of A
 
-    // S = K Q^T, 64 deep = four k steps: K's pieces from LDS (A operand: lane (key, h) = channels 16 s + 8 h ..), the wave's Q rows
-    // read as fp32 and split here (B operand: lane (query, h), same channels) -- six piece products per step, smallest first
+  // one interval's work of a wave, as two inlined pieces: S / softmax / weights of local tile tl, and P.V of local tile tl
+  auto s_phase = [&](int tl) __attribute__((always_inline)) {
+    const int buf = tl & 1, kb = (t_begin + tl) * 32;
+    // ---- S = K Q^T (64 deep = four k steps, six piece products each, smallest first), softmax, the weights' pieces
     f32x16 S;
 #pragma unroll
     for (int e = 0; e < 16; ++e) S[e] = 0.0f;
-    {
-      const float *qrow = Qs + r * kKPitch + 8 * h;
+    const unsigned char *kfb = kfrag + buf * kAttnKTileBytes;
+    float4 qn0 = *reinterpret_cast<const float4 *>(qrow), qn1 = *reinterpret_cast<const float4 *>(qrow + 4);
 #pragma unroll
-      for (int st = 0; st < 4; ++st) {
-        const float4 q0 = *reinterpret_cast<const float4 *>(qrow + 16 * st);
-        const float4 q1 = *reinterpret_cast<const float4 *>(qrow + 16 * st + 4);
-        const unsigned char *kf = kfrag + (((2 * st + h) ^ ksw) << 4);
-        const at_u32x4 kh = *reinterpret_cast<const at_u32x4 *>(kf);
-        const at_u32x4 km = *reinterpret_cast<const at_u32x4 *>(kf + 32 * 128);
-        const at_u32x4 kl = *reinterpret_cast<const at_u32x4 *>(kf + 2 * 32 * 128);
-        at_u32x4 qh, qm, ql;
-        unsigned a0, a1, a2;
-        at_split2(q0.x, q0.y, a0, a1, a2); qh[0] = a0; qm[0] = a1; ql[0] = a2;
-        at_split2(q0.z, q0.w, a0, a1, a2); qh[1] = a0; qm[1] = a1; ql[1] = a2;
-        at_split2(q1.x, q1.y, a0, a1, a2); qh[2] = a0; qm[2] = a1; ql[2] = a2;
-        at_split2(q1.z, q1.w, a0, a1, a2); qh[3] = a0; qm[3] = a1; ql[3] = a2;
-        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_bf(kl), at_bf(qh), S, 0, 0, 0);
-        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_bf(kh), at_bf(ql), S, 0, 0, 0);
-        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_bf(km), at_bf(qm), S, 0, 0, 0);
-        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_bf(km), at_bf(qh), S, 0, 0, 0);
-        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_bf(kh), at_bf(qm), S, 0, 0, 0);
-        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_bf(kh), at_bf(qh), S, 0, 0, 0);
+    for (int st = 0; st < 4; ++st) {
+      const float4 qc0 = qn0, qc1 = qn1;                   // (the next step's eight query values are fetched one step ahead)
+      if (st < 3) {
+        qn0 = *reinterpret_cast<const float4 *>(qrow + 16 * (st + 1));
+        qn1 = *reinterpret_cast<const float4 *>(qrow + 16 * (st + 1) + 4);
       }
+      const unsigned char *kf = kfb + (((2 * st + h) ^ ksw) << 4);
+      const at_u32x4 kh = *reinterpret_cast<const at_u32x4 *>(kf);
+      const at_u32x4 km = *reinterpret_cast<const at_u32x4 *>(kf + 32 * 128);
+      const at_u32x4 kl = *reinterpret_cast<const at_u32x4 *>(kf + 2 * 32 * 128);
+      at_u32x4 qh, qm, ql;
+      unsigned a0, a1, a2;
+      at_split2(qc0.x, qc0.y, a0, a1, a2); qh[0] = a0; qm[0] = a1; ql[0] = a2;
+      at_split2(qc0.z, qc0.w, a0, a1, a2); qh[1] = a0; qm[1] = a1; ql[1] = a2;
+      at_split2(qc1.x, qc1.y, a0, a1, a2); qh[2] = a0; qm[2] = a1; ql[2] = a2;
+      at_split2(qc1.z, qc1.w, a0, a1, a2); qh[3] = a0; qm[3] = a1; ql[3] = a2;
+      S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_bf(kl), at_bf(qh), S, 0, 0, 0);
+      S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_bf(kh), at_bf(ql), S, 0, 0, 0);
+      S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_bf(km), at_bf(qm), S, 0, 0, 0);
+      S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_bf(km), at_bf(qh), S, 0, 0, 0);
+      S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_bf(kh), at_bf(qm), S, 0, 0, 0);
+      S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_bf(kh), at_bf(qh), S, 0, 0, 0);
     }
-    __builtin_amdgcn_s_waitcnt(0xC07F);                    // lgkmcnt(0) only: the DMA stays in flight
-    __builtin_amdgcn_s_barrier();                          // B: every wave is done with the K pieces ...
-    if (more) dma_k((kb >> 5) + 1);                        // ... which the next tile's land in, under the softmax and P.V
-
     float m_tile = -INFINITY;
+    if (kb + 32 > nk) {                                    // (wave-uniform) the ragged last tile: keys past nk score -inf
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      if (kb + rowmap(e, h) >= nk) S[e] = -INFINITY;
-      m_tile = fmaxf(m_tile, S[e]);
+      for (int e = 0; e < 16; ++e)
+        if (kb + rowmap(e, h) >= nk) S[e] = -INFINITY;
     }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) m_tile = fmaxf(m_tile, S[e]);
     m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
     if (__ballot(m_tile > m_ref + kThr) != 0ull) {
       const float m_new = fmaxf(m_ref, m_tile);
@@ -750,8 +754,7 @@ __global__ __launch_bounds__(512, 2) void k_cross_attn_split(
       S[e] = __expf(S[e] - m_ref);
       l_part += S[e];
     }
-    // the tile's weights as bf16 pieces: half tile A = accumulators 0..7, B = 8..15 (lane half h: keys (e & 3) + 8 (e >> 2) + 4 h)
-    at_u32x4 pp[2][3];
+    // half tile A = accumulators 0..7, B = 8..15 (lane half h: keys (e & 3) + 8 (e >> 2) + 4 h)
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
@@ -760,15 +763,13 @@ __global__ __launch_bounds__(512, 2) void k_cross_attn_split(
         at_split2(S[8 * hf + 2 * e], S[8 * hf + 2 * e + 1], ph, pm, pl);
         pp[hf][0][e] = ph; pp[hf][1][e] = pm; pp[hf][2][e] = pl;
       }
+  };
+  auto pv_phase = [&](int tl) __attribute__((always_inline)) {
+    // ---- O += V^T P, both half tiles: per channel block and half tile three fragments, six piece products
+    const unsigned char *vbuf = vfrag + (tl & 1) * VT;
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
-      if (hf == 1) {
-        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this wave's pieces of half tile B (and of the next K tile)
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_s_barrier();                      // C: half tile B visible; everyone is done with half tile A ...
-        if (more) dma_half((kb >> 4) + 2, 0);              // ... which the next tile's A lands in, under P.V of B
-      }
-      const unsigned char *vb = vfrag + hf * kAttnHalfBytes;
+      const unsigned char *vb = vbuf + hf * kAttnHalfBytes;
 #pragma unroll
       for (int t = 0; t < NVT; ++t) {
         const at_u32x4 vh = *reinterpret_cast<const at_u32x4 *>(vb + t * 1024);
@@ -781,6 +782,31 @@ __global__ __launch_bounds__(512, 2) void k_cross_attn_split(
         O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_bf(vh), at_bf(pp[hf][1]), O[t], 0, 0, 0);
         O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_bf(vh), at_bf(pp[hf][0]), O[t], 0, 0, 0);
       }
+    }
+  };
+  auto interval = [&](int iv) __attribute__((always_inline)) {      // the boundary in front of interval iv
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): this wave's DMA pieces issued an interval ago have landed
+    __syncthreads();                                       // everyone's have; everyone is done with the previous interval's reads
+    if ((iv & 1) && (iv + 1) / 2 < T && !(whatif & 4)) dma_tile(t_begin + (iv + 1) / 2, ((iv + 1) / 2) & 1);
+  };
+  if (T > 0) dma_tile(t_begin, 0);
+  // (two copies of a straight-line loop rather than one loop with the phase as a branch: with both phases under branches of one loop
+  //  body the register allocator spilled 400+ registers)
+  if (grp == 0) {
+    for (int tl = 0; tl < T; ++tl) {
+      interval(2 * tl);
+      if (!(whatif & 2)) s_phase(tl);
+      interval(2 * tl + 1);
+      if (!(whatif & 1)) pv_phase(tl);
+    }
+    interval(2 * T);
+  } else {
+    interval(0);
+    for (int tl = 0; tl < T; ++tl) {
+      interval(2 * tl + 1);
+      if (!(whatif & 2)) s_phase(tl);
+      interval(2 * tl + 2);
+      if (!(whatif & 1)) pv_phase(tl);
     }
   }
 
@@ -1208,6 +1234,7 @@ static int attn_dispatch(int b, int nq, int nk, const float *Q, int ldq, const f
                          int64_t scratch_floats, int concurrent_launches, void *planes, int64_t planes_bytes, dclStream_t stream);
 
 // does a call of this size take the 8-wave workgroup form (see attn_dispatch), the one the split-bf16 kernel exists for?
+DCL_HOOK_INT(g_attn_whatif, 0);      // (diagnostic library: what-if runs of k_cross_attn_split -- 1: no P.V phase, 2: no S phase, 4: no DMA after the first tile)
 DCL_HOOK_INT(g_attn_bf16, 1);        // (diagnostic library: dcl_debug_attention_bf16; 0 = fp32 MFMA everywhere)
 static bool attn_takes_w8(int b, int nq, int concurrent_launches) {
   const long long blocks8 = (long long)b * dcl_div_up(nq, 256);
@@ -1216,6 +1243,7 @@ static bool attn_takes_w8(int b, int nq, int concurrent_launches) {
 }
 #ifdef DCL_DIAG
 DCL_API void dcl_debug_attention_bf16(int on) { g_attn_bf16 = on; }
+DCL_API void dcl_debug_attention_whatif(int bits) { g_attn_whatif = bits; }
 #endif
 
 DCL_API int64_t dcl_cross_attention_planes_bytes(int b, int nq, int nk, int concurrent_launches) {
@@ -1315,11 +1343,11 @@ static int attn_dispatch(int b, int nq, int nk, const float *Q, int ldq, const f
         unsigned char *kplanes = (unsigned char *)planes + (size_t)b * nht * kAttnHalfBytes;
         const long long ktotal = (long long)b * (nht / 2) * 32 * 8;
         hipLaunchKernelGGL(k_attn_split_k, dim3(dcl_grid_1d(ktotal, 256)), dim3(256), 0, s, nk, nht / 2, K, ldk, (unsigned *)kplanes, ktotal);
-        const size_t lds_sp = (size_t)(8 * 32 * kKPitch) * sizeof(float) + 2 * kAttnHalfBytes + kAttnKTileBytes;
+        const size_t lds_sp = (size_t)2 * (2 * kAttnHalfBytes + kAttnKTileBytes);
         (void)hipFuncSetAttribute((const void *)k_cross_attn_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp);
         hipLaunchKernelGGL(k_cross_attn_split, dim3(dcl_div_up(nq, 256), b, nsplit), dim3(512), lds_sp, s, nq, nk, Q, ldq,
                            (const unsigned char *)planes, (const unsigned char *)kplanes, O1, ldo1, O2, ldo2, scratch,
-                           (int)g_attn_xcd_remap);
+                           (int)g_attn_xcd_remap, (int)g_attn_whatif);
       } else {
         (void)hipFuncSetAttribute((const void *)k_cross_attn_dma<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k_cross_attn_dma<8>, dim3(dcl_div_up(nq, 256), b, nsplit), dim3(512), lds, s, nq, nk, Q, ldq, K, ldk,

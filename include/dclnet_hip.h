@@ -667,6 +667,9 @@ void dcl_debug_attention_pair_split(int on);
 /* Tuning hook: 0 = large attention calls keep the fp32-MFMA kernel even when `planes` are handed in (dcl_cross_attention_ws3);
  * dcl_cross_attention_planes_bytes then returns 0.  1 (default) = P.V on the bf16 matrix pipe (k_cross_attn_split). */
 void dcl_debug_attention_bf16(int on);
+/* Diagnostic: what-if runs of k_cross_attn_split (WRONG results; timing only) -- bit 0: no P.V phase, bit 1: no S / softmax phase,
+ * bit 2: no LDS-DMA after the first tile. */
+void dcl_debug_attention_whatif(int bits);
 /* Tuning hook: most crops of a pass whose geometry stage runs as one launch (k_geometry_small; default 16, at most 64;
  * passes of more than 8 crops also need at most 32768 voxel rows). */
 void dcl_debug_geometry_small_batch(int n);

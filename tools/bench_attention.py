@@ -11,10 +11,11 @@ dcl = importlib.import_module("dcl-net_amd")
 from _diag import use_diag
 DIAG = use_diag(dcl)          # kernel-variant hooks exist in the diagnostic library only
 ops = dcl.ops
-b = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-n = int(sys.argv[2]) if len(sys.argv) > 2 else 12288
-m = int(sys.argv[3]) if len(sys.argv) > 3 else 2048
-reps = int(sys.argv[4]) if len(sys.argv) > 4 else 10
+args = [x for x in sys.argv[1:] if not x.startswith('--')]
+b = int(args[0]) if len(args) > 0 else 32
+n = int(args[1]) if len(args) > 1 else 12288
+m = int(args[2]) if len(args) > 2 else 2048
+reps = int(args[3]) if len(args) > 3 else 10
 g = torch.Generator(device="cuda").manual_seed(1)
 def rnd(rows, c, s=1.0):
     return torch.randn(rows, c, device="cuda", generator=g) * s
@@ -34,3 +35,13 @@ for name, (Q, K, V1, V2) in (("N->M", (Xm, Ym, Yp, Ym)), ("M->N", (Ym, Xm, Xp, X
         ms = a.elapsed_time(e) / reps
         print("%s b=%d nq=%d nk=%d  %-42s %.3f ms  %.1f TFLOP/s" % (name, b, nq, nk, form + ":", ms, 2.0 * 384 * nq * nk * b / ms / 1e9), flush=True)
     DIAG.dcl_debug_attention_bf16(1)
+    if "--whatif" in sys.argv:
+        for bits, what in ((1, "no P.V phase"), (2, "no S phase"), (4, "no DMA after the first tile"), (5, "no P.V, no DMA"), (6, "no S, no DMA"), (3, "neither phase")):
+            DIAG.dcl_debug_attention_whatif(bits)
+            ops.cross_attention(b, Q, K, V1, O1, V2, O2); torch.cuda.synchronize()
+            a.record()
+            for _ in range(reps):
+                ops.cross_attention(b, Q, K, V1, O1, V2, O2)
+            e.record(); torch.cuda.synchronize()
+            print("    what-if %-28s %.3f ms" % (what + ":", a.elapsed_time(e) / reps), flush=True)
+        DIAG.dcl_debug_attention_whatif(0)
