@@ -914,19 +914,19 @@ def main():
     traffic, traffic_source = None, "not collected (N > 1, --no-extras or --no-traffic)"
     if rank == 0 and world == 1 and not args.no_extras and not args.no_traffic:
         traffic, traffic_source = measure_traffic_bytes("k_cross_attn", args.shape, b)
-    # since round 6 the large calls run k_cross_attn_split: S = K Q^T (1/6 of the flop) on the fp32 MFMA, P.V (5/6) as six bf16 piece
-    # products per fp32 product -- the bound of that mix is the time-weighted harmonic mean of the two pipes' fp32-equivalent peaks
-    peak_att = 1.0 / ((64.0 / 384.0) / PEAK_MFMA_F32 + (320.0 / 384.0) / PEAK_SPLIT)
-    roofline = {"kernel": "k_cross_attn_split (+ k_attn_split_v: V's bf16 pieces, inside the timed span)", "bound": "mfma",
-                "achieved": round(achieved, 2), "peak": round(peak_att, 1),
-                "unit": "TFLOP/s", "frac": round(achieved / peak_att, 4), "x_fp32_mfma_peak": round(achieved / PEAK_MFMA_F32, 4),
-                "peak_note": "S = K Q^T (64 of the 384 flop per query-key pair) on the fp32 MFMA (157.3), P.V (320 of 384) as six bf16 "
-                             "piece products per fp32 product (2500 / 6): peak = 1 / ((64/384) / 157.3 + (320/384) / 416.7); "
-                             "x_fp32_mfma_peak = achieved / 157.3, the bound of the all-fp32 kernel this replaces (0.866 there)",
+    # since round 6 the large calls run k_cross_attn_split: both products (S = K Q^T and P.V) as six bf16 piece products per fp32
+    # product, so the kernel's fp32-equivalent bound is the dense bf16 MFMA peak / 6
+    roofline = {"kernel": "k_cross_attn_split (+ k_attn_split_v / _k: the V and K piece passes, inside the timed span)", "bound": "mfma",
+                "achieved": round(achieved, 2), "peak": round(PEAK_SPLIT, 1),
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK_SPLIT, 4), "x_fp32_mfma_peak": round(achieved / PEAK_MFMA_F32, 4),
+                "peak_note": "every fp32 product of the attention = six bf16 piece products (three exact bf16 pieces per operand, fp32 "
+                             "accumulators): peak = 2500 / 6; x_fp32_mfma_peak = achieved / 157.3, the bound of the all-fp32 kernel "
+                             "this replaces (which ran at 0.866 of it)",
                 "traffic": traffic, "traffic_source": traffic_source,
-                "traffic_algorithmic": int(b * (n_inp + n_tmp) * (4 * 2 * 64 + (4 * 320 + 6 * 320) // 2)),
-                "traffic_note": "main kernel only, average of the two directions: Q, K fp32, V as three bf16 pieces (6 B per value), "
-                                "O fp32; the V piece pass reads V (4 B) and writes the pieces (6 B) once per launch on top",
+                "traffic_algorithmic": int(b * (n_inp + n_tmp) * (4 * 64 + (6 * 64 + 6 * 320 + 4 * 320) // 2)),
+                "traffic_note": "main kernel only, average of the two directions: Q fp32 (re-read from L2 per key tile, once from HBM), "
+                                "K and V as three bf16 pieces (6 B per value), O fp32; the piece passes read K, V (4 B) and write the "
+                                "pieces (6 B) once per launch on top",
                 "avg_launch_ms": round(att_avg_ms, 4), "launches_timed": len(att_ms),
                 "flop_per_launch": flop_dir[0]}
     # whose kernels the step's GPU time goes to: since round 6 the per-point linear layers run on the
