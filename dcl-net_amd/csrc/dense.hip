@@ -336,6 +336,12 @@ __device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_byte_addr)
                : "v"(gsrc), "s"(lds_byte_addr)
                : "memory");
 }
+// the same with the source as (wave-uniform base in an SGPR pair) + (per-lane 32-bit byte offset): no vector address arithmetic
+__device__ __forceinline__ void glds16_s(unsigned voff, const void *sbase, unsigned lds_byte_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
+}
 __device__ __forceinline__ unsigned lds_addr_of(const float *p) {
   return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void_t *)p);
 }
@@ -656,23 +662,23 @@ __global__ __launch_bounds__(512, 2) void k_cross_attn_split(
   // this lane's query row (B operand of S: lane (query, h) = channels 16 s + 8 h ..); rows past nq read the last query (never stored)
   const float *qrow = Q + ((size_t)b * nq + min(q, nq - 1)) * ldq + 8 * h;
   const int nht = 2 * ((nk + 31) >> 5);
-  const unsigned char *vsrc = planes + (size_t)b * nht * kAttnHalfBytes + lane * 16;
-  const unsigned char *ksrc = kplanes + (size_t)b * (nht >> 1) * kAttnKTileBytes + lane * 16;
+  const unsigned char *vsrc = planes + (size_t)b * nht * kAttnHalfBytes;             // (wave-uniform: SGPRs)
+  const unsigned char *ksrc = kplanes + (size_t)b * (nht >> 1) * kAttnKTileBytes;
+  const unsigned lane16 = (unsigned)lane * 16u;
   const unsigned vp0 = lds_addr_of(reinterpret_cast<const float *>(Vp));
   const unsigned kp0 = lds_addr_of(reinterpret_cast<const float *>(Kp));
   // a tile = 12 one-KiB DMA pieces of K pieces + 60 of V pieces: wave w issues K piece w (and w + 8 if w < 4), V pieces w, w + 8, ...
+  // (sources = scalar bases + the one per-lane offset: no vector address arithmetic beside the other group's MFMAs)
   auto dma_tile = [&](int tile, int buf) {
-    const unsigned char *ks = ksrc + (size_t)tile * kAttnKTileBytes;
-    const unsigned kd = kp0 + (unsigned)(buf * kAttnKTileBytes);
-    glds16(ks + wave * 1024, kd + (unsigned)(wave * 1024));
-    if (wave < 4) glds16(ks + (wave + 8) * 1024, kd + (unsigned)((wave + 8) * 1024));
-    const unsigned char *vs = vsrc + (size_t)tile * VT;
-    const unsigned vd = vp0 + (unsigned)(buf * VT);
+    const unsigned char *ks = ksrc + (size_t)tile * kAttnKTileBytes + wave * 1024;
+    const unsigned kd = kp0 + (unsigned)(buf * kAttnKTileBytes + wave * 1024);
+    glds16_s(lane16, ks, kd);
+    if (wave < 4) glds16_s(lane16, ks + 8 * 1024, kd + 8 * 1024);
+    const unsigned char *vs = vsrc + (size_t)tile * VT + wave * 1024;
+    const unsigned vd = vp0 + (unsigned)(buf * VT + wave * 1024);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int piece = wave + 8 * i;
-      if (piece < 60) glds16(vs + piece * 1024, vd + (unsigned)(piece * 1024));
-    }
+    for (int i = 0; i < 8; ++i)
+      if (wave + 8 * i < 60) glds16_s(lane16, vs + i * 8192, vd + (unsigned)(i * 8192));
   };
 
   f32x16 O[NVT];

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void k_linear_split(const LinSplitArgs a) {
   int t_lo, t_hi, t_stride;
   {
     const int id = blockIdx.x, nwg = gridDim.x;
-    if (a.xcd_remap && (nwg & 7) == 0) {
+    if ((a.xcd_remap & 1) && (nwg & 7) == 0) {
       const int xq = tiles >> 3, xr = tiles & 7, xcd = id & 7;
       const int x_lo = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
       t_lo = x_lo + (id >> 3);
@@ -133,6 +133,7 @@ __global__ __launch_bounds__(256, 2) void k_linear_split(const LinSplitArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int nchunks = a.K / kSpKC;
+  const int whatif = a.xcd_remap >> 1;                     // (diagnostic library: timing-only what-if runs; 0 in the product)
   const unsigned lds0 = sp_lds_addr(sp_lds);
   const size_t bstep = (size_t)ntn * kSpB;                 // bytes from a column tile's chunk to its next chunk
 
@@ -215,10 +216,15 @@ __global__ __launch_bounds__(256, 2) void k_linear_split(const LinSplitArgs a) {
       read_a(0);
       read_b(0);
       read_a(1);
-      if (more) issue(st ^ 1);
+      if (more && !(whatif & 1)) issue(st ^ 1);
       __builtin_amdgcn_sched_barrier(0);
+      if (!(whatif & 2)) {
 #pragma unroll
-      for (int part = 0; part < 4; ++part) split_a(0, part);
+        for (int part = 0; part < 4; ++part) split_a(0, part);
+      } else {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) ap[0][p] = sp_u32x4{__float_as_uint(av[0][0].x), __float_as_uint(av[0][0].y), __float_as_uint(av[0][1].x), __float_as_uint(av[0][1].y)};
+      }
       read_b(1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -230,7 +236,10 @@ __global__ __launch_bounds__(256, 2) void k_linear_split(const LinSplitArgs a) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(ap[i][1]), sp_bf(bp[j][0]), acc[i][j], 0, 0, 0);
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(ap[i][0]), sp_bf(bp[j][1]), acc[i][j], 0, 0, 0);
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(ap[i][0]), sp_bf(bp[j][0]), acc[i][j], 0, 0, 0);
-        if (blk < 4) split_a(1, blk);
+        if (blk < 4) {
+          if (!(whatif & 2)) split_a(1, blk);
+          else { ap[1][0][blk] = __float_as_uint(av[1][blk >> 1].x); ap[1][1][blk] = __float_as_uint(av[1][blk >> 1].y); ap[1][2][blk] = __float_as_uint(av[1][blk >> 1].z); }
+        }
         if (blk < 2) read_b(blk + 2);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -239,6 +248,7 @@ __global__ __launch_bounds__(256, 2) void k_linear_split(const LinSplitArgs a) {
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");      // MFMA -> VALU read of the accumulators
 
     if constexpr (EPI == 0) {
+      if (whatif & 4) continue;
       float *__restrict__ y = a.y;
       const bool whole = row0 + kSpBM <= a.M && col0 + kSpBN <= a.N;
       float bias[4];
@@ -335,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void k_linear_split(const LinSplitArgs a) {
   }
 }
 
-DCL_HOOK_INT(g_sp_xcd, 1);
+DCL_HOOK_INT(g_sp_xcd, 1);            // bit 0: XCD-aware tile numbering; bits 1..: what-if runs (diagnostic library: dcl_debug_linear_split_whatif)
 
 template <int EPI>
 int launch_linear_split(const LinSplitArgs &a, hipStream_t stream) {
@@ -361,7 +371,8 @@ bool lin_split_ok(const float *x, int64_t ldx, const void *planes, int K) {
 }  // namespace
 
 #ifdef DCL_DIAG
-DCL_API void dcl_debug_linear_split_xcd_remap(int on) { g_sp_xcd = on; }
+DCL_API void dcl_debug_linear_split_xcd_remap(int on) { g_sp_xcd = ((int)g_sp_xcd & ~1) | (on & 1); }
+DCL_API void dcl_debug_linear_split_whatif(int bits) { g_sp_xcd = ((int)g_sp_xcd & 1) | (bits << 1); }
 #endif
 
 DCL_API int64_t dcl_linear_split_weight_bytes(int K, int N) {

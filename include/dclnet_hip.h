@@ -667,6 +667,10 @@ void dcl_debug_attention_pair_split(int on);
 /* Tuning hook: 0 = large attention calls keep the fp32-MFMA kernel even when `planes` are handed in (dcl_cross_attention_ws3);
  * dcl_cross_attention_planes_bytes then returns 0.  1 (default) = P.V on the bf16 matrix pipe (k_cross_attn_split). */
 void dcl_debug_attention_bf16(int on);
+/* Diagnostic: 0 = plain tile numbering in k_linear_split (1 = XCD-aware, default); what-if runs of k_linear_split (WRONG results;
+ * timing only) -- bit 0: no LDS-DMA after a tile's first chunk, bit 1: no operand split, bit 2: no store epilogue. */
+void dcl_debug_linear_split_xcd_remap(int on);
+void dcl_debug_linear_split_whatif(int bits);
 /* Diagnostic: what-if runs of k_cross_attn_split (WRONG results; timing only) -- bit 0: no P.V phase, bit 1: no S / softmax phase,
  * bit 2: no LDS-DMA after the first tile. */
 void dcl_debug_attention_whatif(int bits);

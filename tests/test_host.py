@@ -290,6 +290,21 @@ def test_own_gemm_core_eligibility_rule(dcl):
     assert all(t.is_contiguous() for pair in f["regressor_rot"] + f["regressor_trans"] for t in pair)   # what dcl_pose_heads takes
 
 
+def test_split_bf16_core_dispatch_rule(dcl):
+    """which launches ops.linear sends to the split-bf16 core (host logic only): a PREPARED weight (ops.prepare_linear: CUDA, more
+    than 64 output columns, K in whole 16-chunks) and at least ops.SPLIT_MIN_TILES tiles of 256 x 128; nothing is prepared on the
+    CPU, and an unprepared weight never takes the split core"""
+    import torch
+    ops = dcl.ops
+    assert ops.prepare_linear(torch.zeros(512, 512)) is None                 # CPU tensor: nothing to prepare
+    assert ops.prepared_linear(torch.zeros(512, 512), torch.zeros(65536, 512)) is None
+    assert ops.linear_split_ok(torch.zeros(64, 512), 512) and ops.linear_split_ok(torch.zeros(64, 1024)[:, 256:512], 256)
+    assert not ops.linear_split_ok(torch.zeros(64, 40), 40) and not ops.linear_split_ok(torch.zeros(64, 260)[:, 2:258], 256)
+    tiles = lambda M, n: ((M + 255) // 256) * ((n + 127) // 128)            # noqa: E731
+    assert tiles(6144, 1024) >= ops.SPLIT_MIN_TILES > tiles(6144, 512)       # six crops: the 1024-column layers only
+    assert tiles(32768, 256) >= ops.SPLIT_MIN_TILES > tiles(1024, 1024)      # 32 crops: every layer of > 64 columns; one crop: none
+
+
 def test_tail_parallel_rule(dcl):
     """do the dense tail's two directions run side by side?  (host logic only) -- always while both attention launches are
     small (every N = M = 1024 call), at N = 12288 only for the batch sizes whose grid of 256-query workgroups ends in a

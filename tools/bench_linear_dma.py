@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 dcl = importlib.import_module("dcl-net_amd")
-TILES = "--tiles" in sys.argv
+TILES = "--tiles" in sys.argv or "--whatif" in sys.argv
 CHECK = "--check" in sys.argv
 L = None
 if TILES:
@@ -57,12 +57,18 @@ for M, K, n, ldx, ldy in SHAPES:
         t_pool = timeit(lambda: dcl.ops.linear_pool(x, Wt, bias, w))
         t_pool_sp = timeit(lambda: dcl.ops.linear_split_pool(x, sw, bias, w))
         line += "  pool-epilogue %8.1f us (%5.1f TF), split-bf16 %8.1f us (%5.1f TF)" % (t_pool, fl / t_pool / 1e6, t_pool_sp, fl / t_pool_sp / 1e6)
-    if TILES:
+    if "--tiles" in sys.argv:
         for t, name in ((1, "128x128"), (2, "128x64"), (3, "64x64"), (4, "64x64 K/2")):
             L.dcl_debug_linear_tile(t)
             tt = timeit(lambda: dcl.ops.linear_dma(x, Wt, bias, True, out=y))
             line += "  %s %.1f" % (name, fl / tt / 1e6)
         L.dcl_debug_linear_tile(0)
+    if "--whatif" in sys.argv and L is not None and M >= 32768 and n >= 256:
+        for bits, what in ((1, "no DMA"), (2, "no split"), (4, "no stores"), (7, "none of the three")):
+            L.dcl_debug_linear_split_whatif(bits)
+            tt = timeit(lambda: dcl.ops.linear_split(x, sw, bias, True, out=y))
+            line += "  [%s %.1f]" % (what, fl / tt / 1e6)
+        L.dcl_debug_linear_split_whatif(0)
     if CHECK:
         rows = torch.randint(0, M, (256,), device="cuda")
         want = torch.relu(x[rows].double() @ Wt.double() + bias.double())
