@@ -16,6 +16,37 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// mode 6: the six-product body on v_mfma_f32_16x16x32_bf16, the same 64 x 128 wave tile as 4 x 8 blocks of 16 x 16 (operands in
+// registers): MI355X_MICROARCH.md reports 1.12-1.15 x the 32x32x16 shape's FLOP/s in bare loops on random data (the clock the chip holds)
+__global__ __launch_bounds__(256, 2) void k16(const unsigned *wbits, float *out, long long *clk, int iters) {
+  const int t = threadIdx.x;
+  f32x4 c[4][8];
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 8; ++j) for (int e = 0; e < 4; ++e) c[i][j][e] = 0.f;
+  u32x4 ap[2][3], bp[2][3];
+  for (int i = 0; i < 2; ++i) for (int p = 0; p < 3; ++p) for (int e = 0; e < 4; ++e) {
+    ap[i][p][e] = wbits[(t * 24 + i * 12 + p * 4 + e) & 0xffff];
+    bp[i][p][e] = wbits[(t * 24 + 7000 + i * 12 + p * 4 + e) & 0xffff];
+  }
+  const long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; ++it)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ap[i & 1][2]), __builtin_bit_cast(bf16x8, bp[j & 1][0]), c[i][j], 0, 0, 0);
+        c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ap[i & 1][0]), __builtin_bit_cast(bf16x8, bp[j & 1][2]), c[i][j], 0, 0, 0);
+        c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ap[i & 1][1]), __builtin_bit_cast(bf16x8, bp[j & 1][1]), c[i][j], 0, 0, 0);
+        c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ap[i & 1][1]), __builtin_bit_cast(bf16x8, bp[j & 1][0]), c[i][j], 0, 0, 0);
+        c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ap[i & 1][0]), __builtin_bit_cast(bf16x8, bp[j & 1][1]), c[i][j], 0, 0, 0);
+        c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ap[i & 1][0]), __builtin_bit_cast(bf16x8, bp[j & 1][0]), c[i][j], 0, 0, 0);
+      }
+  const long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  float sum = 0.f;
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 8; ++j) for (int e = 0; e < 4; ++e) sum += c[i][j][e];
+  out[blockIdx.x * 256 + t] = sum;
+  if (t == 0) { clk[blockIdx.x * 2] = t1 - t0; clk[blockIdx.x * 2 + 1] = r1 - r0; }
+}
+
 __device__ __forceinline__ bf16x8 as_bf(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 
 // truncating exact split of a pair: x = h + m + l with h, m, l each 8 significant bits (24 = 8 + 8 + 8)
@@ -141,10 +172,11 @@ int main() {
   hipMemcpy(x, hx.data(), xn * 4, hipMemcpyHostToDevice); hipMemcpy(w, hw.data(), 65536 * 4, hipMemcpyHostToDevice);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   std::vector<long long> hc(grid * 2);
-  for (int mode : {1, 2, 3, 4, 5, 1, 2, 3, 4, 5}) {
-    const int iters = mode >= 2 ? 40 : 2000;
+  for (int mode : {1, 6, 2, 4, 1, 6, 2, 4}) {
+    const int iters = (mode >= 2 && mode != 6) ? 40 : (mode == 6 ? 500 : 2000);
     auto run = [&]() {
-      if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(grid), dim3(256), 0, 0, x, w, out, clk, ldx, K, iters);
+      if (mode == 6) hipLaunchKernelGGL(k16, dim3(grid), dim3(256), 0, 0, w, out, clk, iters);
+      else if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(grid), dim3(256), 0, 0, x, w, out, clk, ldx, K, iters);
       else if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(grid), dim3(256), 0, 0, x, w, out, clk, ldx, K, iters);
       else if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(grid), dim3(256), 0, 0, x, w, out, clk, ldx, K, iters);
       else if (mode == 3) hipLaunchKernelGGL(k<3>, dim3(grid), dim3(256), 0, 0, x, w, out, clk, ldx, K, iters);
@@ -158,8 +190,8 @@ int main() {
     std::vector<double> ghz;
     for (int i = 0; i < grid; ++i) ghz.push_back((double)hc[i * 2] / (double)hc[i * 2 + 1] * 0.1);
     std::sort(ghz.begin(), ghz.end());
-    const double nmfma = (double)grid * 4 * iters * (mode >= 2 ? (K / 16) * 48.0 : 48.0);
-    const double flop = nmfma * 32768.0;
+    const double nmfma = (double)grid * 4 * iters * ((mode >= 2 && mode != 6) ? (K / 16) * 48.0 : (mode == 6 ? 192.0 : 48.0));
+    const double flop = nmfma * (mode == 6 ? 16384.0 : 32768.0);
     printf("mode %d: %.3f ms  bf16 %.0f TFLOP/s  fp32-equivalent (six products) %.1f TFLOP/s  in-kernel clock %.2f GHz  cycles per MFMA per SIMD %.1f\n",
            mode, ms, flop / ms / 1e9, flop / 6 / ms / 1e9, ghz[grid / 2], (double)hc[0] / (nmfma / grid / 4) * (grid >= 512 ? 0.5 : 1.0));
   }
