@@ -980,7 +980,9 @@ def main():
 
     line = {"metric": "frames/sec DCL_Net.forward @ YCB-V bs32", "value": round(value, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (exact 3xbf16-split products on the bf16 MFMA, f32 accumulate)",
+            "data": "synthetic",
             "dtype_note": "fp32 tensors, fp32 accumulators everywhere.  Sparse convs: fp32 MFMA.  The big per-point linear layers (and, "
                           "where noted under `roofline`, the attention) form each fp32 product from the EXACT three-way bf16 split of "
                           "both operands -- six bf16 piece products of weight >= 2^-16 on the bf16 MFMA, dropped terms <= 2^-25 of the "
