@@ -386,10 +386,10 @@ int dcl_cross_attention_ws2(int b, int nq, int nk, const float *Q, int ldq, cons
                             const float *V1, int dv1, int ldv1, float *O1, int ldo1,
                             const float *V2, int dv2, int ldv2, float *O2, int ldo2,
                             float *scratch, int64_t scratch_floats, int concurrent_launches, dclStream_t stream);
-/* dcl_cross_attention_ws2 with the P.V product of large calls on the bf16 matrix pipe at fp32-sized errors (csrc/dense.hip:
- * k_cross_attn_split; the scheme of dcl_linear_split_fwd): `planes` is scratch for V's three bf16 pieces in tile order,
- * dcl_cross_attention_planes_bytes(b, nq, nk, concurrent_launches) bytes (0 = a call of this size keeps the fp32-MFMA kernel;
- * planes = NULL or fewer bytes: likewise), 16-byte aligned.  V must be [256 | 64] channels. */
+/* dcl_cross_attention_ws2 with both products of large calls (S = K Q^T and P.V) on the bf16 matrix pipe at fp32-sized errors
+ * (csrc/dense.hip: k_cross_attn_split; the scheme of dcl_linear_split_fwd): `planes` is scratch for the three bf16 pieces of K and
+ * V in tile order, dcl_cross_attention_planes_bytes(b, nq, nk, concurrent_launches) bytes (0 = a call of this size keeps the
+ * fp32-MFMA kernel; planes = NULL or fewer bytes: likewise), 16-byte aligned.  V must be [256 | 64] channels. */
 int64_t dcl_cross_attention_planes_bytes(int b, int nq, int nk, int concurrent_launches);
 int dcl_cross_attention_ws3(int b, int nq, int nk, const float *Q, int ldq, const float *K, int ldk,
                             const float *V1, int dv1, int ldv1, float *O1, int ldo1, const float *V2, int dv2,
