@@ -18,6 +18,10 @@ import os
 import sys
 import time
 
+# two hardware queues per device (the package's own default, set here too because torch is imported first: dcl-net_amd/__init__.py,
+# DESIGN.md section 6 -- a hipGraph branch on a third or fourth queue makes the graph 1.3-4x slower); a value in the environment wins
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+
 import numpy as np
 import torch
 import torch.distributed as dist

@@ -576,12 +576,14 @@ __device__ __forceinline__ at_bf16x8 at_bf(at_u32x4 v) { return __builtin_bit_ca
 // planes[crop][half tile][piece][channel c][slot hs][8] (bf16), slot hs holds lane half h = hs ^ bit 3 of c (bank swizzle), element
 // e = key 16 ht + (e & 3) + 8 (e >> 2) + 4 h; keys >= nk are zeros.  One thread per (crop, half tile, c, hs).
 __global__ __launch_bounds__(256) void k_attn_split_v(int nk, int nht, const float *__restrict__ V1, int ldv1, const float *__restrict__ V2,
-                                                      int ldv2, unsigned *__restrict__ planes, long long total) {
+                                                      int ldv2, unsigned *__restrict__ planes, long long total, int c_begin) {
+  // (c_begin = 256: the V1 channels' pieces are already there, written by the GEMM that made V1 -- dcl_linear_split_vpieces_fwd)
+  const int nc = 320 - c_begin;
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int hs = (int)(i & 1);
     const long long q = i >> 1;
-    const int c = (int)(q % 320);
-    const long long cht = q / 320;                         // crop * nht + half tile
+    const int c = c_begin + (int)(q % nc);
+    const long long cht = q / nc;                          // crop * nht + half tile
     const int ht = (int)(cht % nht), crop = (int)(cht / nht);
     const int h = hs ^ ((c >> 3) & 1);
     const float *col = c < 256 ? V1 + c : V2 + (c - 256);
@@ -1252,6 +1254,15 @@ DCL_API void dcl_debug_attention_bf16(int on) { g_attn_bf16 = on; }
 DCL_API void dcl_debug_attention_whatif(int bits) { g_attn_whatif = bits; }
 #endif
 
+DCL_API int dcl_cross_attention_split_crops(int b, int nq, int nk, int concurrent_launches) {
+  // how many of the b crops take the split-bf16 kernel when `planes` are handed in: 0, all of them, or the whole rounds of a pair call
+  if (b <= 0 || nq <= 0 || nk <= 0 || !g_attn_bf16) return 0;
+  int crops = b;
+  const int full = attn_pair_full_crops(b, nq, 256, 64, concurrent_launches);
+  if (full) crops = full;
+  return attn_takes_w8(crops, nq, concurrent_launches) ? crops : 0;
+}
+
 DCL_API int64_t dcl_cross_attention_planes_bytes(int b, int nq, int nk, int concurrent_launches) {
   if (b <= 0 || nq <= 0 || nk <= 0 || !g_attn_bf16) return 0;
   int crops = b;
@@ -1277,7 +1288,8 @@ DCL_API int dcl_cross_attention_ws3(int b, int nq, int nk, const float *Q, int l
   // A pair of launches whose 8-wave workgroups make one or more WHOLE rounds of the chip plus a rest (40 crops of 1024 x 1024: 1.25
   // rounds): the whole rounds go as they are (8-wave, two waves per SIMD), the rest as the call of that many crops that it is
   // (4-wave workgroups, keys split) -- a quarter-filled last round costs a whole one.  Same results per crop.
-  const int full = (b > 0 && Q && K && V1 && O1) ? attn_pair_full_crops(b, nq, dv1, dv2, concurrent_launches) : 0;
+  const int full = (b > 0 && Q && K && O1) ? attn_pair_full_crops(b, nq, dv1, dv2, concurrent_launches) : 0;
+  DCL_CHECK_ARG(!(full && !V1));                           // (V1 = NULL is for calls that take the split kernel as a whole: dcl_cross_attention_split_crops)
   if (full) {
     int rc = attn_dispatch(full, nq, nk, Q, ldq, K, ldk, V1, dv1, ldv1, O1, ldo1, V2, dv2, ldv2, O2, ldo2, scratch, scratch_floats,
                            concurrent_launches, planes, planes_bytes, stream);
@@ -1296,10 +1308,11 @@ static int attn_dispatch(int b, int nq, int nk, const float *Q, int ldq, const f
                          int64_t scratch_floats, int concurrent_launches, void *planes, int64_t planes_bytes, dclStream_t stream) {
   DCL_CHECK_ARG(b >= 0 && nq >= 0 && nk > 0 && dv1 > 0 && dv1 % 32 == 0 && dv2 >= 0 && dv2 % 32 == 0);
   if (b == 0 || nq == 0) return 0;
-  DCL_CHECK_ARG(Q && K && V1 && O1 && (dv2 == 0 || (V2 && O2)) && b <= 65535);
+  DCL_CHECK_ARG(Q && K && (V1 || planes) && O1 && (dv2 == 0 || (V2 && O2)) && b <= 65535);
   DCL_CHECK_ARG(ldq >= 64 && ldk >= 64 && ldv1 >= dv1 && ldo1 >= dv1 && (dv2 == 0 || (ldv2 >= dv2 && ldo2 >= dv2)));
   DCL_CHECK_ARG(ldq % 4 == 0 && ldk % 4 == 0 && ldv1 % 4 == 0 && ldo1 % 4 == 0 && ldv2 % 4 == 0 && ldo2 % 4 == 0);
   DCL_CHECK_ARG((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V1 | (uintptr_t)O1 | (uintptr_t)V2 | (uintptr_t)O2) & 15) == 0);
+  const bool v1_in_planes = V1 == nullptr;                 // (only the split kernel can take that: checked where it is chosen)
   const int nvt = (dv1 + dv2) / 32;
   DCL_CHECK_ARG(nvt == 1 || nvt == 2 || nvt == 4 || nvt == 8 || nvt == 10);
   hipStream_t s = (hipStream_t)stream;
@@ -1343,9 +1356,10 @@ static int attn_dispatch(int b, int nq, int nk, const float *Q, int ldq, const f
       const int64_t planes_need = (int64_t)b * (nht / 2) * kAttnTileBytes;
       if (planes && planes_bytes >= planes_need && g_attn_bf16 && (((uintptr_t)planes) & 15) == 0) {
         // P.V on the bf16 matrix pipe at fp32-sized errors: V as three exact bf16 pieces in tile order (one pass), then the sweep
-        const long long total = (long long)b * nht * 320 * 2;
+        const int c_begin = V1 ? 0 : 256;                  // V1 == NULL: its pieces are in `planes` already
+        const long long total = (long long)b * nht * (320 - c_begin) * 2;
         hipLaunchKernelGGL(k_attn_split_v, dim3(dcl_grid_1d(total, 256)), dim3(256), 0, s, nk, nht, V1, ldv1, V2, ldv2,
-                           (unsigned *)planes, total);
+                           (unsigned *)planes, total, c_begin);
         unsigned char *kplanes = (unsigned char *)planes + (size_t)b * nht * kAttnHalfBytes;
         const long long ktotal = (long long)b * (nht / 2) * 32 * 8;
         hipLaunchKernelGGL(k_attn_split_k, dim3(dcl_grid_1d(ktotal, 256)), dim3(256), 0, s, nk, nht / 2, K, ldk, (unsigned *)kplanes, ktotal);
@@ -1355,6 +1369,10 @@ static int attn_dispatch(int b, int nq, int nk, const float *Q, int ldq, const f
                            (const unsigned char *)planes, (const unsigned char *)kplanes, O1, ldo1, O2, ldo2, scratch,
                            (int)g_attn_xcd_remap, (int)g_attn_whatif);
       } else {
+        if (v1_in_planes) {
+          dcl_set_error("dcl_cross_attention: V1 = NULL (pieces in `planes`) but this call does not take the split-bf16 kernel");
+          return DCL_EINVAL;
+        }
         (void)hipFuncSetAttribute((const void *)k_cross_attn_dma<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k_cross_attn_dma<8>, dim3(dcl_div_up(nq, 256), b, nsplit), dim3(512), lds, s, nq, nk, Q, ldq, K, ldk,
                            V1, ldv1, O1, ldo1, V2, ldv2, O2, ldo2, scratch, (int)g_attn_xcd_remap);
@@ -1363,6 +1381,10 @@ static int attn_dispatch(int b, int nq, int nk, const float *Q, int ldq, const f
         hipLaunchKernelGGL(k_cross_attn_combine, dim3(dcl_grid_1d((long long)b * nq * 80, 256)), dim3(256), 0, s, b * nq,
                            nsplit, scratch, O1, ldo1, O2, ldo2);
     } else {
+      if (v1_in_planes) {
+        dcl_set_error("dcl_cross_attention: V1 = NULL (pieces in `planes`) but this call does not take the split-bf16 kernel");
+        return DCL_EINVAL;
+      }
       // few workgroups (small batches): split the keys over up to 16 workgroups per query block, >= 2 tiles per split
       int nsplit = 1;
       if (scratch) {

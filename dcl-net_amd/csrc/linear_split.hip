@@ -285,6 +285,42 @@ __global__ __launch_bounds__(256, 2) void k_linear_split(const LinSplitArgs a) {
             }
           }
       }
+    } else if constexpr (EPI == 3) {
+      // attention-V epilogue: the activation leaves the kernel AS the three bf16 pieces the attention's P.V product reads
+      // (csrc/dense.hip: k_cross_attn_split; layout of k_attn_split_v, which this makes unnecessary for these channels) and is
+      // never stored as fp32.  The accumulators already have that layout's shape: lane (r, h) of column block j holds, in elements
+      // 0..7 / 8..15 of row block i, the keys (e & 3) + 8 (e >> 2) + 4 h of two consecutive 16-key half tiles for channel
+      // col0 + 32 j + r -- one fragment of 8 keys each.  Rows = keys of crop row / rows_per_crop (a tile never straddles crops:
+      // rows_per_crop % 256 == 0, checked by the entry point); ldp = half tiles per crop.
+      unsigned char *vp = reinterpret_cast<unsigned char *>(a.part);
+      const int crop = row0 / a.rows_per_crop, key0 = row0 - crop * a.rows_per_crop;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = col0 + j * 32 + r;
+        const float bias = (a.bias && c < a.N) ? a.bias[c] : 0.0f;
+        const int hs = h ^ ((c >> 3) & 1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            const long long ht = (long long)crop * a.ldp + ((key0 + wave * 64 + i * 32) >> 4) + hf;
+            sp_u32x4 ph, pm, pl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float v0 = acc[i][j][8 * hf + 2 * e] + bias, v1 = acc[i][j][8 * hf + 2 * e + 1] + bias;
+              if (a.relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); }
+              unsigned qh, qm, ql;
+              sp_split2(v0, v1, qh, qm, ql);
+              ph[e] = qh; pm[e] = qm; pl[e] = ql;
+            }
+            unsigned char *dst = vp + (size_t)ht * (3 * 320 * 32) + (size_t)(c * 2 + hs) * 16;
+            if (c < a.N) {
+              *reinterpret_cast<sp_u32x4 *>(dst) = ph;
+              *reinterpret_cast<sp_u32x4 *>(dst + 320 * 32) = pm;
+              *reinterpret_cast<sp_u32x4 *>(dst + 2 * 320 * 32) = pl;
+            }
+          }
+      }
     } else if constexpr (EPI == 2) {
       // row-dot epilogue (the confidence regressor's last two layers, models/DCL_Net.py:115-126: ... -> 128 -> 1): the tile spans all
       // N <= 128 columns and a wave all of them:  out[row] = sum_c relu(acc[row][c] + bias[c]) * w3[c] + b3 -- per lane over its four
@@ -409,6 +445,19 @@ DCL_API int dcl_linear_split_pool_fwd(const float *x, int64_t ldx, const void *p
   LinSplitArgs a{x, (const unsigned char *)planes, bias, nullptr, ldx, 0, M, N, K, relu, roww, rows_per_crop, w_stride, part, nullptr, ldp,
                  (int)g_sp_xcd};
   int rc = launch_linear_split<1>(a, (hipStream_t)stream);
+  if (rc) return rc;
+  DCL_LAUNCH_CHECK();
+  return 0;
+}
+
+DCL_API int dcl_linear_split_vpieces_fwd(const float *x, int64_t ldx, const void *planes, const float *bias, void *vplanes,
+                                         int rows_per_crop, int M, int N, int K, int relu, dclStream_t stream) {
+  DCL_CHECK_ARG(M > 0 && N > 0 && N <= 320 && N % 32 == 0 && K > 0 && x && planes && vplanes && ldx >= K && rows_per_crop > 0);
+  DCL_CHECK_ARG(rows_per_crop % kSpBM == 0 && M % rows_per_crop == 0 && (((size_t)vplanes) & 15) == 0);
+  DCL_CHECK_ARG(lin_split_ok(x, ldx, planes, K));
+  LinSplitArgs a{x, (const unsigned char *)planes, bias, nullptr, ldx, 0, M, N, K, relu, nullptr, rows_per_crop, 0, (float *)vplanes, nullptr,
+                 (long long)(rows_per_crop / 16), (int)g_sp_xcd};
+  int rc = launch_linear_split<3>(a, (hipStream_t)stream);
   if (rc) return rc;
   DCL_LAUNCH_CHECK();
   return 0;

@@ -428,8 +428,9 @@ class Network(nn.Module):
                     done[side, c] = torch.cuda.Event()
                     done[side, c].record(sstream[side])
         act = {}
+        tail_par = (not self.single_stream and not self.async_inputs and self._tail_parallel(b, launch_by_launch=True))
         for side, key in (("Xc", "inp"), ("Yo", "tmp")):
-            act.update(self._disengage_buffers(side, b * npts[key], dev))
+            act.update(self._disengage_buffers(side, b * npts[key], dev, fuse=(b, 2 if tail_par else 1) if K == 1 else None))
         mark("sparse issued")
         for c in range(K):                                                     # dense stage 1, chunk by chunk on main
             for side, key in (("Xc", "inp"), ("Yo", "tmp")):
@@ -443,8 +444,7 @@ class Network(nn.Module):
         # overlaps the other direction instead of idling the chip)
         # (not for a pipelining instance: its side streams already belong to the next call's sparse half -- measured 3.92 ->
         # 4.36 ms per back-to-back reference-shape call with the tail on one of them)
-        tail_side = sstream["inp"] if (not self.single_stream and not self.async_inputs and
-                                       self._tail_parallel(b, launch_by_launch=True)) else None
+        tail_side = sstream["inp"] if tail_par else None
         prediction = self._dense_tail(f, act, b, dev, side=tail_side)
         mark("dense issued")
         if self.mode != "test":
@@ -488,21 +488,38 @@ class Network(nn.Module):
                               # keep one library GEMM per layer
     HEAD_ORDER = None         # launch by launch: 0 = one side after the other (geometry, level sizes, features), 1 = both geometry
                               # stages first, None = by size (A/B switch: tools/ab_attr.py)
+    GRAPH_TRIES = 4           # two-branch captures tried for a new whole-forward graph before its one-stream capture is kept instead
+                              # (_select_capture: a capture whose second branch landed on another hardware queue than the launch
+                              # stream replays 1.3-4x slower for as long as it lives).  1 = first capture or the one-stream one.
     MAX_GRAPHS = 8            # captured whole-forward graphs kept per instance (one per batch size; least recently used goes)
     GRAPH_ADMIT = 3           # with a full cache, a new batch size is captured (evicting the LRU one) on its 3rd call
 
-    def _disengage_buffers(self, side, rows, dev):
+    def _disengage_buffers(self, side, rows, dev, fuse=None):
         """outputs of a side's four disengage stacks.  Two of them are one half of a later concatenation -- cat[F_Xc_p1,
         F_Xo_p] / cat[F_Xc_m1, F_Xo_m] feed neck_fuser / regressor_conf (models/DCL_Net.py:207-211), cat[F_Yc_p, F_Yo_p2] /
         cat[F_Yc_m, F_Yo_m2] the *_bi twins -- so they are column blocks of those wider buffers from the start (the GEMM
         writes them in place, the attention fills the other block later: no copies)."""
         new = lambda c: torch.empty((rows, c), dtype=torch.float32, device=dev)               # noqa: E731
-        fuse, conf_in = new(512), new(128)
+        fuse_buf, conf_in = new(512), new(128)
+        # fuse = (b, par): the whole batch's rows of this side, and how the tail's attention launches will run.  This side's points
+        # are the KEYS of one attention direction; when that call takes the split-bf16 kernel for all of its crops (ops.
+        # attention_planes), its scratch is allocated here and this side's V stack ("p2" of Xc, "p1" of Yo) is written straight
+        # into it as bf16 pieces by the GEMM that computes it (_disengage: ops.linear_split_vpieces) -- no fp32 V1, no piece pass
+        # over its 256 channels.  Inference only (the training graph keeps every activation).
+        planes, fused = None, False
+        if fuse is not None and self.mode == "test":
+            b, par = fuse
+            nk = self.n_inp if side == "Xc" else self.n_tmp
+            nq = self.n_tmp if side == "Xc" else self.n_inp
+            if rows == b * nk and nk % 256 == 0:
+                planes, whole = ops.attention_planes(b, nq, nk, par, dev)
+                fused = planes is not None and whole
+        v1 = None if fused else new(256)
         if side == "Xc":
-            return {"fuse1": fuse, "conf_in1": conf_in, "Xcp1": fuse[:, :256], "Xcm1": conf_in[:, :64],
-                    "Xcp2": new(256), "Xcm2": new(64)}
-        return {"fuse2": fuse, "conf_in2": conf_in, "Yop2": fuse[:, 256:], "Yom2": conf_in[:, 64:],
-                "Yop1": new(256), "Yom1": new(64)}
+            return {"fuse1": fuse_buf, "conf_in1": conf_in, "Xcp1": fuse_buf[:, :256], "Xcm1": conf_in[:, :64],
+                    "Xcp2": v1, "Xcm2": new(64), "planes2": planes}
+        return {"fuse2": fuse_buf, "conf_in2": conf_in, "Yop2": fuse_buf[:, 256:], "Yom2": conf_in[:, 64:],
+                "Yop1": v1, "Yom1": new(64), "planes1": planes}
 
     def _disengage(self, f, side, pf_rows, act, rows=slice(None)):
         """the four disengage stacks of one side on a block of points: one shared 480->1024 GEMM (BN folded), then the four
@@ -515,14 +532,23 @@ class Network(nn.Module):
             return
         for j, (tag, _) in enumerate(self._DIS_TAGS):
             Wt, bias = second[j]
-            ops.linear(H[:, 256 * j:256 * (j + 1)], Wt, bias, True, out=act[side + tag][rows])
+            Hj = H[:, 256 * j:256 * (j + 1)]
+            if act[side + tag] is None:                                     # this side's V stack, fused into the attention's scratch
+                sw = ops.prepared_linear(Wt, Hj)
+                planes = act["planes2" if side == "Xc" else "planes1"]
+                all_rows = act[side + ("m2" if side == "Xc" else "m1")].shape[0]
+                if sw is not None and pf_rows.shape[0] == all_rows:             # (the whole batch in this call)
+                    ops.linear_split_vpieces(Hj, sw, bias, planes, self.n_inp if side == "Xc" else self.n_tmp, relu=True)
+                    continue
+                act[side + tag] = torch.empty((all_rows, 256), dtype=torch.float32, device=H.device)   # (not after all: the plain form)
+            ops.linear(Hj, Wt, bias, True, out=act[side + tag][rows])
 
     def _dense(self, f, pf_inp, pf_tmp, b, dev):
         """dense half of the fused pipeline on point-major activations: disengage stacks, correspondence attention,
         confidence + fuser heads, pooling, pose heads.  Static shapes only (graph-capturable)."""
         act = {}
         for side, pfs in (("Xc", pf_inp), ("Yo", pf_tmp)):
-            act.update(self._disengage_buffers(side, pfs.shape[0], dev))
+            act.update(self._disengage_buffers(side, pfs.shape[0], dev, fuse=(b, 1)))
             self._disengage(f, side, pfs, act)
         return self._dense_tail(f, act, b, dev)
 
@@ -575,11 +601,13 @@ class Network(nn.Module):
             # weights are the softmax over BOTH directions' confidences, so the two confidence regressors run first and the
             # directions meet once more in the middle: attention + logits | softmax | fuser layers 1, 2, 3 + pool | finish.
             with second:
-                ops.cross_attention(b, act["Yom2"], act["Xcm2"], act["Xcp2"], fuse2[:, :256], act["Xcm2"], conf_in2[:, :64], concurrent=par)
+                ops.cross_attention(b, act["Yom2"], act["Xcm2"], act["Xcp2"], fuse2[:, :256], act["Xcm2"], conf_in2[:, :64], concurrent=par,
+                                    planes=act.get("planes2"))
                 logit2 = conf_logits(conf_in2, f["regressor_conf_bi"])
                 if side is not None:
                     logit2.record_stream(main)
-            ops.cross_attention(b, act["Xcm1"], act["Yom1"], act["Yop1"], fuse1[:, 256:], act["Yom1"], conf_in1[:, 64:], concurrent=par)
+            ops.cross_attention(b, act["Xcm1"], act["Yom1"], act["Yop1"], fuse1[:, 256:], act["Yom1"], conf_in1[:, 64:], concurrent=par,
+                                planes=act.get("planes1"))
             logit1 = conf_logits(conf_in1, f["regressor_conf"])
             join()
             conf, w, wsum = ops.conf_softmax(b, logit1.reshape(-1), logit2.reshape(-1))
@@ -597,11 +625,13 @@ class Network(nn.Module):
             F_p_wei = ops.pool_finish2(part1, part2, wsum, (sA, tA, sB, tB))
         else:
             with second:
-                ops.cross_attention(b, act["Yom2"], act["Xcm2"], act["Xcp2"], fuse2[:, :256], act["Xcm2"], conf_in2[:, :64], concurrent=par)
+                ops.cross_attention(b, act["Yom2"], act["Xcm2"], act["Xcp2"], fuse2[:, :256], act["Xcm2"], conf_in2[:, :64], concurrent=par,
+                                    planes=act.get("planes2"))
                 logit2, Fp2 = conf_and_fuser(conf_in2, fuse2, f["regressor_conf_bi"], l2)
                 if side is not None:
                     logit2.record_stream(main); Fp2.record_stream(main)          # allocated on `side`, read on `main` below
-            ops.cross_attention(b, act["Xcm1"], act["Yom1"], act["Yop1"], fuse1[:, 256:], act["Yom1"], conf_in1[:, 64:], concurrent=par)
+            ops.cross_attention(b, act["Xcm1"], act["Yom1"], act["Yop1"], fuse1[:, 256:], act["Yom1"], conf_in1[:, 64:], concurrent=par,
+                                planes=act.get("planes1"))
             logit1, Fp1 = conf_and_fuser(conf_in1, fuse1, f["regressor_conf"], l1)   # (b*N, 1), (b*N, 1024)
             join()
             # trailing BNs after pooling: F_p_wei = sA*P1 + tA*sum(w1) + sB*P2 + tB*sum(w2), finished inside the pooling op
@@ -704,6 +734,8 @@ class Network(nn.Module):
                 st["v2p"].zero_()
                 st["v2p"][:v0, :need_ma[s] + 1].copy_(d["v2p_maps"], non_blocking=True)
                 st["v0"].fill_(v0)
+        if ent.pop("fresh", False) and ent["graph"] is not None and self.GRAPH_TRIES > 0 and not self.single_stream:
+            ent = cache[key] = self._select_capture(ent, f, dev, b, S)      # (first call of a new capture, inputs staged: see GRAPH_TRIES)
         if ent["graph"] is None:                       # capture_graph=False: the capacity-mode body, launch by launch
             with torch.no_grad():
                 ent["out"] = ent["body"]()
@@ -736,6 +768,66 @@ class Network(nn.Module):
             # these poses checks it once after its own synchronisation
             out["crop_overflow"] = data["inp"]["vi_info"][2:3]
         return out
+
+    def _select_capture(self, ent, f, dev, b, S):
+        """Which capture of a new whole-forward graph is kept (one-time cost per captured batch size).  A graph's second branch runs
+        on a stream the runtime makes at instantiation and deals onto one of its few hardware queues; when that is not the launch
+        stream's queue every fork / join edge becomes a cross-queue dependency and the replay is 1.3x (32 crops) to 4x (one crop)
+        slower, for as long as the graph lives (tools/recapture_probe.py; with GPU_MAX_HW_QUEUES = 2 every capture is fast, with 16
+        none).  A ONE-stream capture of the same body has no such edge and is the yardstick: a two-branch capture within 3 % of it
+        (or faster) is in the fast mode and kept; otherwise up to GRAPH_TRIES - 1 more two-branch captures are tried, and if none
+        gets there the one-stream capture itself is kept -- never the slow mode."""
+        import time
+
+        def timed(e):
+            for _ in range(3):                                     # (the first replays of an instantiated graph pay its upload)
+                e["graph"].replay()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(6):
+                e["graph"].replay()
+            torch.cuda.synchronize(dev)
+            return (time.perf_counter() - t0) / 6
+
+        def capture(one_stream, src):
+            # (the one-stream capture issues the SAME launches -- each backbone's own, the tail's pair hints -- on one stream: same
+            #  bits as the two-branch capture, only the placement differs)
+            keep, keep_pf = self.single_stream, self._pair_features
+            self._pair_features = self.pair_features
+            self.single_stream = bool(one_stream) or keep
+            try:
+                cand = self._capture(f, dev, b, S, ma)
+            finally:
+                self.single_stream, self._pair_features = keep, keep_pf
+            cand.pop("fresh", None)
+            for sd in ("inp", "tmp"):
+                for k in ("feats", "occ", "v2p", "v0", "pb4"):
+                    cand[sd][k].copy_(src[sd][k])
+            return cand
+        ma = dict(ent["ma"])
+        best, t_best = ent, timed(ent)
+        seen = [("two branches", t_best)]
+        ref = capture(True, best)
+        t_ref = timed(ref)
+        seen.append(("one stream", t_ref))
+        tries = 1
+        while t_best > 1.03 * t_ref and tries < self.GRAPH_TRIES:
+            cand = capture(False, best)
+            t = timed(cand)
+            seen.append(("two branches", t))
+            tries += 1
+            if t < t_best:
+                self._drop_graph(best)
+                best, t_best = cand, t
+            else:
+                self._drop_graph(cand)
+        if t_ref < t_best:
+            self._drop_graph(best)
+            best, t_best = ref, t_ref
+        else:
+            self._drop_graph(ref)
+        best["capture_ms"] = [(k, round(x * 1e3, 3)) for k, x in seen]
+        return best
 
     def _capture(self, f, dev, b, S, ma):
         unit = self.unit_voxel_extent
@@ -792,7 +884,7 @@ class Network(nn.Module):
                             st["run"].point_features(pb4s[s], extents, off, st["pf"], st["tmpbuf"])
                             st["keep"] = (xs[s], pb4s[s])
                         else:                                              # each side's disengage stacks stay on its branch
-                            act.update(self._disengage_buffers(dside, st["pf"].shape[0], dev))
+                            act.update(self._disengage_buffers(dside, st["pf"].shape[0], dev, fuse=(b, 2 if par_dense else 1)))
                             self._disengage(f, dside, st["pf"], act)
                     stamp("%s stage %d done" % (s, stage), stream)
             main.wait_stream(side_stream)                                  # join
@@ -819,6 +911,7 @@ class Network(nn.Module):
                 out = body()
         ent["graph"], ent["out"] = g, out
         ent["nodes"] = self._graph_nodes(g)
+        ent["fresh"] = True
         return ent
 
     @staticmethod

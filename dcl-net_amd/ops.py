@@ -703,7 +703,22 @@ def _ld(t):
 ATTENTION_SPLIT = True        # large attention calls: P.V on the bf16 matrix pipe at fp32-sized errors (False: fp32 MFMA everywhere)
 
 
-def cross_attention(b, Q, K, V1, O1, V2=None, O2=None, concurrent=1):
+def attention_planes(b, nq, nk, concurrent=1, device=None):
+    """scratch for the K / V pieces of a cross_attention call of this size that takes the split-bf16 kernel: (planes, whole) --
+    planes None = the call keeps the fp32 kernel; whole = ALL b crops take the split kernel, i.e. the caller may have V1 written
+    as pieces straight into `planes` by the GEMM that makes it (linear_split_vpieces) and pass V1 = None."""
+    if not ATTENTION_SPLIT:
+        return None, False
+    lib = N.lib()
+    lib.dcl_cross_attention_planes_bytes.restype = C.c_int64
+    pb = int(lib.dcl_cross_attention_planes_bytes(int(b), int(nq), int(nk), int(concurrent)))
+    if not pb:
+        return None, False
+    whole = int(lib.dcl_cross_attention_split_crops(int(b), int(nq), int(nk), int(concurrent))) == int(b)
+    return torch.empty(pb, dtype=torch.uint8, device=device if device is not None else torch.device("cuda")), whole
+
+
+def cross_attention(b, Q, K, V1, O1, V2=None, O2=None, concurrent=1, planes=None):
     """One direction of the correspondence attention on POINT-major 2-D operands (row = point):
     Q (b*nq, 64), K (b*nk, 64), V1 (b*nk, dv1) -> O1 (b*nq, dv1) [, V2 -> O2].  Operands may be
     column blocks of wider buffers (row stride honoured).  The PRODUCT library carries DCL-Net's own channel split only,
@@ -713,8 +728,10 @@ def cross_attention(b, Q, K, V1, O1, V2=None, O2=None, concurrent=1):
     a hint for the launcher's choice of workgroup shape (dcl_cross_attention_ws2)."""
     N.need_cuda(Q, K, V1, O1, V2, O2)
     nq, nk = Q.shape[0] // b, K.shape[0] // b
-    assert Q.shape[1] == 64 and K.shape[1] == 64 and V1.shape[0] == K.shape[0] and O1.shape[0] == Q.shape[0]
-    dv1 = V1.shape[1]
+    assert Q.shape[1] == 64 and K.shape[1] == 64 and O1.shape[0] == Q.shape[0]
+    assert V1 is not None or planes is not None, "V1 = None: its pieces are expected in `planes` (attention_planes, linear_split_vpieces)"
+    assert V1 is None or V1.shape[0] == K.shape[0]
+    dv1 = 256 if V1 is None else V1.shape[1]
     dv2 = 0 if V2 is None else V2.shape[1]
     ev = None
     if PROFILE_EVENTS is not None:
@@ -726,14 +743,9 @@ def cross_attention(b, Q, K, V1, O1, V2=None, O2=None, concurrent=1):
         N.check(N.lib().dcl_cross_attention_scratch_floats(b, nq, C.byref(need)), "cross_attention_scratch_floats")
         if need.value:
             scratch = torch.empty(need.value, dtype=torch.float32, device=Q.device)
-    planes = None
-    if dv1 == 256 and dv2 == 64 and ATTENTION_SPLIT:   # large calls: V's bf16 pieces for the split-bf16 P.V (csrc/dense.hip)
-        lib = N.lib()
-        lib.dcl_cross_attention_planes_bytes.restype = C.c_int64
-        pb = int(lib.dcl_cross_attention_planes_bytes(b, nq, nk, int(concurrent)))
-        if pb:
-            planes = torch.empty(pb, dtype=torch.uint8, device=Q.device)
-    N.check(N.lib().dcl_cross_attention_ws3(b, nq, nk, N.ptr(Q), _ld(Q), N.ptr(K), _ld(K), N.ptr(V1), dv1, _ld(V1),
+    if planes is None and dv1 == 256 and dv2 == 64:    # large calls: scratch for the K / V pieces of the split-bf16 kernel (csrc/dense.hip)
+        planes, _ = attention_planes(b, nq, nk, concurrent, Q.device)
+    N.check(N.lib().dcl_cross_attention_ws3(b, nq, nk, N.ptr(Q), _ld(Q), N.ptr(K), _ld(K), N.ptr(V1), dv1, 256 if V1 is None else _ld(V1),
                                             N.ptr(O1), _ld(O1), N.ptr(V2), dv2, 0 if V2 is None else _ld(V2), N.ptr(O2),
                                             0 if O2 is None else _ld(O2), N.ptr(scratch),
                                             C.c_int64(0 if scratch is None else scratch.numel()), int(concurrent), N.ptr(planes),
@@ -1050,6 +1062,20 @@ def linear_split_pool(x, sw, bias, roww, relu=True, part=None, rows_per_crop=Non
                                               C.c_int64(int(w_stride)), N.ptr(part), C.c_int64(pitch(part)), int(M), int(n), int(K),
                                               int(bool(relu)), N.stream()), "linear_split_pool_fwd")
     return part
+
+
+def linear_split_vpieces(x, sw, bias, vplanes, rows_per_crop, relu=True):
+    """act(x @ sw.Wt + bias) written AS the attention's V pieces into `vplanes` (attention_planes' scratch of the call that consumes
+    them with V1 = None): csrc/linear_split.hip, EPI = 3 -- the fp32 activation is never stored.  Rows = keys; every crop
+    rows_per_crop rows (a multiple of 256)."""
+    N.need_cuda(x, vplanes)
+    M, K, n = x.shape[0], sw.K, sw.n
+    assert x.shape[1] == K and n <= 320 and n % 32 == 0 and rows_per_crop % 256 == 0 and M % rows_per_crop == 0
+    pitch = lambda t: int(t.stride(0)) if t.shape[0] > 1 else max(int(t.stride(0)), int(t.shape[1]))   # noqa: E731
+    N.check(N.lib().dcl_linear_split_vpieces_fwd(N.ptr(x), C.c_int64(pitch(x)), N.ptr(sw.planes), N.ptr(bias), N.ptr(vplanes),
+                                                 int(rows_per_crop), int(M), int(n), int(K), int(bool(relu)), N.stream()),
+            "linear_split_vpieces_fwd")
+    return vplanes
 
 
 def linear_split_rowdot(x, sw, bias, w3, b3, out=None):

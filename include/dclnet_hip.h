@@ -391,6 +391,10 @@ int dcl_cross_attention_ws2(int b, int nq, int nk, const float *Q, int ldq, cons
  * V in tile order, dcl_cross_attention_planes_bytes(b, nq, nk, concurrent_launches) bytes (0 = a call of this size keeps the
  * fp32-MFMA kernel; planes = NULL or fewer bytes: likewise), 16-byte aligned.  V must be [256 | 64] channels. */
 int64_t dcl_cross_attention_planes_bytes(int b, int nq, int nk, int concurrent_launches);
+/* How many of the b crops of such a call take the split kernel: 0, b, or the whole rounds of a pair call.  When it is b, V1 may be
+ * NULL in dcl_cross_attention_ws3: its pieces are then expected in `planes` already, written by the GEMM that computes V1
+ * (dcl_linear_split_vpieces_fwd) -- the fp32 V1 is never stored and the piece pass skips its 256 channels. */
+int dcl_cross_attention_split_crops(int b, int nq, int nk, int concurrent_launches);
 int dcl_cross_attention_ws3(int b, int nq, int nk, const float *Q, int ldq, const float *K, int ldk,
                             const float *V1, int dv1, int ldv1, float *O1, int ldo1, const float *V2, int dv2,
                             int ldv2, float *O2, int ldo2, float *scratch, int64_t scratch_floats,
@@ -481,6 +485,11 @@ int dcl_linear_split_fwd(const float *x, int64_t ldx, const void *planes, const 
 int dcl_linear_split_pool_fwd(const float *x, int64_t ldx, const void *planes, const float *bias, const float *roww,
                               int rows_per_crop, int64_t w_stride, float *part, int64_t ldp, int M, int N, int K, int relu,
                               dclStream_t stream);
+/* y = act(x Wt + bias) written AS the attention's V pieces (N <= 320 channels from channel 0, rows = keys of crop row /
+ * rows_per_crop, rows_per_crop % 256 == 0 = M / crops): `vplanes` = the `planes` scratch of the dcl_cross_attention_ws3 call that
+ * consumes it with V1 = NULL. */
+int dcl_linear_split_vpieces_fwd(const float *x, int64_t ldx, const void *planes, const float *bias, void *vplanes,
+                                 int rows_per_crop, int M, int N, int K, int relu, dclStream_t stream);
 int dcl_linear_split_rowdot_fwd(const float *x, int64_t ldx, const void *planes, const float *bias, const float *w3, int64_t ldw3,
                                 const float *b3, float *out, int M, int N, int K, dclStream_t stream);
 /* The softmax half of dcl_conf_pool alone: conf (b, n1 + n2) = sigmoid(cat[logit1, logit2]), w (b, n1 + n2) = softmax(conf) per

@@ -2,6 +2,8 @@ import importlib
 import os
 import sys
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")        # as dcl-net_amd/__init__.py does: before anything initialises the GPU
+
 import numpy as np
 import pytest
 

@@ -1724,3 +1724,42 @@ def test_cross_attention_split_bf16_form_matches_float64_like_the_fp32_form(requ
         lib.dcl_debug_attention_bf16(1)
         lib.dcl_debug_attention_split(0)
     assert worst <= 4.0, "split-bf16 attention errors against float64 should be the size of the fp32 form's: worst ratio %.2f" % worst
+
+
+def test_v_stack_written_as_attention_pieces_equals_the_piece_pass(request, dcl):
+    """dcl_linear_split_vpieces_fwd (csrc/linear_split.hip, EPI = 3): the GEMM that computes the attention's V1 writes it straight
+    into the attention's scratch as bf16 pieces -- the same bits the piece pass (k_attn_split_v) makes from the fp32 output of the
+    same GEMM, so the attention fed with V1 = None gives the same bits as the attention fed with that fp32 V1; and a call that does
+    not take the split kernel refuses V1 = None"""
+    lib = enter_diag(dcl, request)
+    lib.dcl_debug_attention_variant(3)                                   # the 8-wave split form whatever the size
+    try:
+        g = torch.Generator().manual_seed(77)
+        b, nq, nk, Kd = 3, 200, 512, 256
+        H = torch.randn(b * nk, Kd, generator=g).cuda()
+        Wt = (torch.randn(Kd, 256, generator=g) * 0.08).cuda()
+        bias = torch.randn(256, generator=g).cuda()
+        sw = dcl.ops.SplitWeight(Wt)
+        Q = torch.randn(b * nq, 64, generator=g).cuda()
+        Km = (torch.randn(b * nk, 64, generator=g) * 0.5).cuda()
+        V1 = dcl.ops.linear_split(H, sw, bias, True)                     # the fp32 form of the same layer
+        planes_a, whole = dcl.ops.attention_planes(b, nq, nk, 1)
+        assert planes_a is not None and whole
+        planes_b = torch.zeros_like(planes_a)
+        O1a, O2a = torch.empty(b * nq, 256, device="cuda"), torch.empty(b * nq, 64, device="cuda")
+        dcl.ops.cross_attention(b, Q, Km, V1, O1a, Km, O2a, planes=planes_a)        # piece pass over all 320 channels
+        dcl.ops.linear_split_vpieces(H, sw, bias, planes_b, nk, relu=True)          # V1's pieces from the GEMM's epilogue
+        O1b, O2b = torch.empty(b * nq, 256, device="cuda"), torch.empty(b * nq, 64, device="cuda")
+        dcl.ops.cross_attention(b, Q, Km, None, O1b, Km, O2b, planes=planes_b)      # piece pass over V2 (and K) only
+        nht = nk // 16
+        va = planes_a[:b * nht * 30720].view(b * nht, 3, 320, 32)
+        vb = planes_b[:b * nht * 30720].view(b * nht, 3, 320, 32)
+        assert torch.equal(va, vb)                                                   # every piece of every channel, bit for bit
+        assert torch.equal(O1a, O1b) and torch.equal(O2a, O2b)
+        want = _attn_ref(Q.view(b, nq, 64), Km.view(b, nk, 64), torch.cat([V1.view(b, nk, 256), Km.view(b, nk, 64)], 2))
+        got = torch.cat([O1b.view(b, nq, 256), O2b.view(b, nq, 64)], 2).double()
+        assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+    finally:
+        lib.dcl_debug_attention_variant(0)
+    with pytest.raises(RuntimeError):                                    # 3 crops of 200 queries: the fp32 kernel, which needs V1
+        dcl.ops.cross_attention(b, Q, Km, None, O1b, Km, O2b, planes=planes_b)
