@@ -35,7 +35,8 @@ const char *dcl_last_error(void);
  *   2  round 5-6: dcl_crop_points gained `int32_t *ws` in front of `stream`; dcl_backbone_features_stage,
  *      dcl_backbone_stage_ws_bytes and DCL_ESTAGE_UNSUPPORTED are gone; dcl_linear_fwd ignores its workspace arguments;
  *      new: dcl_linear_dma_fwd, dcl_linear_pool_fwd, dcl_linear_rowdot_fwd, dcl_conf_softmax, dcl_pool_finish2,
- *      dcl_linear_split_weight(_bytes), dcl_linear_split_fwd / _pool_fwd / _rowdot_fwd, dcl_cross_attention_ws3 (+ _planes_bytes)                         */
+ *      dcl_linear_split_weight(_bytes), dcl_linear_split_fwd / _pool_fwd / _rowdot_fwd / _vpieces_fwd, dcl_cross_attention_ws3
+ *      (+ _planes_bytes, _split_crops)                         */
 #define DCL_ABI_VERSION 2
 int dcl_abi_version(void);
 
