@@ -32,6 +32,7 @@ from .Modules import (Aligner, Backbone_SPCONV, BasicBlock_3DCONV, Head_MultiLay
                       Ops_GetPointFeat_spconv)
 
 HOST_TIMES = None                   # tools/host_timeline.py sets this to a list: (label, perf_counter) marks of _forward_fused
+_QUEUE_SHIMS = []            # streams made only to shift the runtime's round-robin deal of streams onto hardware queues (_select_capture)
 SIDE_STREAM_PRIORITY = -1    # the side streams carry the sparse half -- chains of short, latency-bound launches -- and get dispatch
                             # priority over whatever GEMM / attention launch they meet (the previous call's tail under
                             # async_inputs, the other direction's); read when a side stream is first made (0: A/B)
@@ -488,7 +489,7 @@ class Network(nn.Module):
                               # keep one library GEMM per layer
     HEAD_ORDER = None         # launch by launch: 0 = one side after the other (geometry, level sizes, features), 1 = both geometry
                               # stages first, None = by size (A/B switch: tools/ab_attr.py)
-    GRAPH_TRIES = 4           # two-branch captures tried for a new whole-forward graph before its one-stream capture is kept instead
+    GRAPH_TRIES = 5           # two-branch captures tried for a new whole-forward graph before its one-stream capture is kept instead
                               # (_select_capture: a capture whose second branch landed on another hardware queue than the launch
                               # stream replays 1.3-4x slower for as long as it lives).  1 = first capture or the one-stream one.
     MAX_GRAPHS = 8            # captured whole-forward graphs kept per instance (one per batch size; least recently used goes)
@@ -812,6 +813,10 @@ class Network(nn.Module):
         seen.append(("one stream", t_ref))
         tries = 1
         while t_best > 1.03 * t_ref and tries < self.GRAPH_TRIES:
+            # (the runtime deals new streams onto its queues round-robin: a stream made here before every second try makes the tries
+            #  walk through all queue positions whatever a capture itself advances the deal by)
+            if tries % 2 == 1 and len(_QUEUE_SHIMS) < 16:
+                _QUEUE_SHIMS.append(torch.cuda.Stream(dev))
             cand = capture(False, best)
             t = timed(cand)
             seen.append(("two branches", t))

@@ -12,6 +12,8 @@ dcl = importlib.import_module("dcl-net_amd")
 from _diag import use_diag
 use_diag(dcl)
 dev = torch.device("cuda:0")
+if os.environ.get("DCL_PROBE_PRIO") is not None:               # side-stream priority (0 = normal) for this probe
+    dcl.DCL_Net.Network.SIDE_STREAM_PRIORITY = int(os.environ["DCL_PROBE_PRIO"])
 b = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 tries = int(sys.argv[3]) if len(sys.argv) > 3 else None
 data = bench.to_device(dcl.synth.make_batch(b, 1024, 1024), dev)
