@@ -535,16 +535,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_cross_attn_dma(
   }
 }
 
-// ---- the same attention with the P.V product (5/6 of its flop) on the bf16 matrix pipe at fp32-sized errors ------------------
+// ---- the same attention with BOTH products on the bf16 matrix pipe at fp32-sized errors --------------------------------------
 // (the scheme of linear_split.hip: every fp32 operand = the exact sum of three bf16 pieces, a product = its six piece products of
-//  weight >= 2^-16, fp32 accumulators).  V is the shared operand: a pre-pass (k_attn_split_v) writes each crop's [V1 | V2] rows as
-// pieces, per 16-key half tile in exactly the order the MFMA's A operand wants them (lane (r, h) of channel block t: the eight keys
-// (e & 3) + 8 (e >> 2) + 4 h of the half tile for channel 32 t + r -- the key order the S accumulators already have), 30 KiB per
-// half tile, so a half tile is ONE linear LDS-DMA copy and a fragment ONE ds_read_b128.  P = exp(S - m) is split in registers, once
-// per tile and wave (the S accumulators become the B operand as before, piece by piece).  S = K Q^T (1/6 of the flop) stays on the
-// fp32 MFMA: its Q operand would need 96 KiB of LDS as pieces.  Per 32-key tile and wave: 32 fp32 MFMAs (2048 cycles) + 120 bf16
-// MFMAs (3840) against 192 fp32 MFMAs (12288).  Half tiles A / B of a tile sit in two LDS buffers; A(t+1) is fetched under P.V of
-// B(t), B(t+1) under S and P.V of A(t+1): three barriers per tile.
+//  weight >= 2^-16, fp32 accumulators).  K and V are the shared operands: piece passes (k_attn_split_k / _v; V1's 256 channels can
+// come straight from the GEMM that computes them: dcl_linear_split_vpieces_fwd) write each crop's rows as pieces in exactly the
+// order the MFMA's A operand wants them -- V per 16-key half tile (lane (r, h) of channel block t: the eight keys (e & 3) + 8 (e >> 2)
+// + 4 h of the half tile for channel 32 t + r, the key order the S accumulators already have; 30 KiB per half tile), K per 32-key
+// tile (12 KiB) -- so a tile is linear LDS-DMA copies and a fragment ONE ds_read_b128.  Q (per-wave, 32 queries) is read as fp32 and
+// split in registers every tile: as pieces it would take 96 KiB of LDS or 48 registers.  P = exp(S - m) is split in registers once
+// per tile and wave; the S accumulators become the B operand of P.V as before, piece by piece.  Per 32-key tile and wave: 24 + 120
+// bf16 MFMAs (4608 cycles) against 192 fp32 MFMAs (12288).  The sweep's structure is described at k_cross_attn_split.
 typedef __bf16 at_bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 at_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float at_f32x2 __attribute__((ext_vector_type(2)));
