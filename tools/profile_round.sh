@@ -22,6 +22,8 @@ stats refiner python3 tools/refiner_loop.py 10
 python3 tools/bench_fps.py 2>&1 | grep FPS > $O/${R}_fps.txt
 # the own GEMM core against the vendor library, layer shape by layer shape (+ float64 check)
 python3 tools/bench_linear_dma.py --check 2>&1 | grep -v amdgpu.ids > $O/${R}_gemm_ab.txt
+# the split-bf16 switches on whole forwards, same job: fp32-MFMA kernels / split GEMMs / split GEMMs + split attention
+{ python3 tools/ab_split.py 32; python3 tools/ab_split.py 32 12288 2048; } 2>&1 | grep -v amdgpu.ids > $O/${R}_split_ab.txt
 # the sparse-conv stack layer by layer inside ordinary forwards (runner path, product library), and one launch from the inside
 { for a in "ref 32" "stress 32" "ref 6" "ref 1"; do python3 tools/conv_layers.py $a; done; } 2>&1 | grep -v amdgpu.ids > $O/${R}_conv_layers_runner.txt
 { for l in 0 1 2 3 4 5; do python3 tools/conv_stamps.py $l pair ref; done; } 2>&1 | grep -v "amdgpu.ids\|occupancy API" > $O/${R}_conv_stamps.txt

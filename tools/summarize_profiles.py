@@ -20,7 +20,7 @@ for shape, tag in (("stress", "stress"), ("ref", "ref"), ("prim", "primitives"),
                              recursive=True), key=os.path.getmtime)
     if found:                                                   # the newest run of that shape
         shutil.copy(found[-1], os.path.join(out, "%s_%s_kernel_stats.csv" % (rnd, tag)))
-for name in ("fps.txt", "conv_layers_runner.txt", "conv_stamps.txt", "small_calls.txt", "bench_default.jsonl", "gemm_ab.txt"):            # plain-text evidence of the round
+for name in ("fps.txt", "conv_layers_runner.txt", "conv_stamps.txt", "small_calls.txt", "bench_default.jsonl", "gemm_ab.txt", "split_ab.txt"):            # plain-text evidence of the round
     src = os.path.join(root, "gpurun_out", "%s_%s" % (rnd, name))
     if os.path.exists(src):
         shutil.copy(src, os.path.join(out, "%s_%s" % (rnd, name)))
