@@ -1170,10 +1170,16 @@ DCL_API int dcl_cross_attention(int b, int nq, int nk, const float *Q, int ldq, 
 
 // crops of a PAIR of launches (the two directions side by side) that fill whole rounds of 8-wave workgroups: 256 workgroups per
 // round for the pair = 128 / ceil(nq / 256) crops of each direction (32 at nq = 1024); 0 = no such split for this call
+DCL_HOOK_INT(g_attn_whatif, 0);      // (diagnostic library: what-if runs of k_cross_attn_split -- 1: no P.V phase, 2: no S phase, 4: no DMA after the first tile)
+DCL_HOOK_INT(g_attn_bf16, 1);        // (diagnostic library: dcl_debug_attention_bf16; 0 = fp32 MFMA everywhere)
+static bool attn_split_big(long long blocks8, int nk) { return blocks8 >= 64 && blocks8 * dcl_div_up(nk, 32) >= 16384; }
 DCL_HOOK_INT(g_attn_pair_split, 1);  // (diagnostic library: dcl_debug_attention_pair_split; 0 = off)
-static int attn_pair_full_crops(int b, int nq, int dv1, int dv2, int concurrent_launches) {
+// (nk > 0: the call has scratch for the split-bf16 kernel -- a call that kernel takes as a whole is not cut into rounds + rest: the
+//  rest would run on the fp32 4-wave kernel, 2.7 ms for 8 of 24 stress-shape crops)
+static int attn_pair_full_crops(int b, int nq, int dv1, int dv2, int concurrent_launches, int nk = 0) {
   if (!g_attn_pair_split || g_attn_variant != 0 || concurrent_launches != 2 || dv1 != 256 || dv2 != 64 || nq <= 0) return 0;
   const int qb8 = dcl_div_up(nq, 256);
+  if (nk > 0 && g_attn_bf16 && attn_split_big((long long)b * qb8, nk)) return 0;
   if (qb8 > 128 || 128 % qb8 != 0) return 0;
   const int per_round = 128 / qb8;
   const int full = b / per_round * per_round;
@@ -1242,12 +1248,14 @@ static int attn_dispatch(int b, int nq, int nk, const float *Q, int ldq, const f
                          int64_t scratch_floats, int concurrent_launches, void *planes, int64_t planes_bytes, dclStream_t stream);
 
 // does a call of this size take the 8-wave workgroup form (see attn_dispatch), the one the split-bf16 kernel exists for?
-DCL_HOOK_INT(g_attn_whatif, 0);      // (diagnostic library: what-if runs of k_cross_attn_split -- 1: no P.V phase, 2: no S phase, 4: no DMA after the first tile)
-DCL_HOOK_INT(g_attn_bf16, 1);        // (diagnostic library: dcl_debug_attention_bf16; 0 = fp32 MFMA everywhere)
-static bool attn_takes_w8(int b, int nq, int concurrent_launches) {
+// (the split kernel is worth its 8-wave workgroups on fewer than 256 of them too when the key axis is long: the key split fills the
+//  chip, and the fp32 4-wave kernel it would fall back to is 1.5x slower per flop -- 24 crops of 2048 queries x 12288 keys: 192
+//  workgroups, whole forward 15.55 -> 14.0 ms.  The bound: four times the work of a lone 32 x 1024 x 1024 launch, where the two
+//  kernels tie.)
+static bool attn_takes_w8(int b, int nq, int nk, int concurrent_launches) {
   const long long blocks8 = (long long)b * dcl_div_up(nq, 256);
   const bool pair8 = concurrent_launches == 2 && 2 * blocks8 > 240 && 2 * blocks8 <= 256;
-  return g_attn_variant == 3 || (g_attn_variant == 0 && (blocks8 >= 256 || pair8));
+  return g_attn_variant == 3 || (g_attn_variant == 0 && (blocks8 >= 256 || pair8 || attn_split_big(blocks8, nk)));
 }
 #ifdef DCL_DIAG
 DCL_API void dcl_debug_attention_bf16(int on) { g_attn_bf16 = on; }
@@ -1258,17 +1266,17 @@ DCL_API int dcl_cross_attention_split_crops(int b, int nq, int nk, int concurren
   // how many of the b crops take the split-bf16 kernel when `planes` are handed in: 0, all of them, or the whole rounds of a pair call
   if (b <= 0 || nq <= 0 || nk <= 0 || !g_attn_bf16) return 0;
   int crops = b;
-  const int full = attn_pair_full_crops(b, nq, 256, 64, concurrent_launches);
+  const int full = attn_pair_full_crops(b, nq, 256, 64, concurrent_launches, nk);
   if (full) crops = full;
-  return attn_takes_w8(crops, nq, concurrent_launches) ? crops : 0;
+  return attn_takes_w8(crops, nq, nk, concurrent_launches) ? crops : 0;
 }
 
 DCL_API int64_t dcl_cross_attention_planes_bytes(int b, int nq, int nk, int concurrent_launches) {
   if (b <= 0 || nq <= 0 || nk <= 0 || !g_attn_bf16) return 0;
   int crops = b;
-  const int full = attn_pair_full_crops(b, nq, 256, 64, concurrent_launches);
+  const int full = attn_pair_full_crops(b, nq, 256, 64, concurrent_launches, nk);
   if (full) crops = full;                                  // (the rest of such a call runs as a small call: 4-wave workgroups)
-  if (!attn_takes_w8(crops, nq, concurrent_launches)) return 0;
+  if (!attn_takes_w8(crops, nq, nk, concurrent_launches)) return 0;
   return (int64_t)crops * dcl_div_up(nk, 32) * kAttnTileBytes;
 }
 
@@ -1288,7 +1296,7 @@ DCL_API int dcl_cross_attention_ws3(int b, int nq, int nk, const float *Q, int l
   // A pair of launches whose 8-wave workgroups make one or more WHOLE rounds of the chip plus a rest (40 crops of 1024 x 1024: 1.25
   // rounds): the whole rounds go as they are (8-wave, two waves per SIMD), the rest as the call of that many crops that it is
   // (4-wave workgroups, keys split) -- a quarter-filled last round costs a whole one.  Same results per crop.
-  const int full = (b > 0 && Q && K && O1) ? attn_pair_full_crops(b, nq, dv1, dv2, concurrent_launches) : 0;
+  const int full = (b > 0 && Q && K && O1) ? attn_pair_full_crops(b, nq, dv1, dv2, concurrent_launches, planes ? nk : 0) : 0;
   DCL_CHECK_ARG(!(full && !V1));                           // (V1 = NULL is for calls that take the split kernel as a whole: dcl_cross_attention_split_crops)
   if (full) {
     int rc = attn_dispatch(full, nq, nk, Q, ldq, K, ldk, V1, dv1, ldv1, O1, ldo1, V2, dv2, ldv2, O2, ldo2, scratch, scratch_floats,
@@ -1327,7 +1335,10 @@ static int attn_dispatch(int b, int nq, int nk, const float *Q, int ldq, const f
     // other at one wave per SIMD; same-job A/B of the whole forward, 8-wave vs 4-wave: 32 crops 3.813 vs 3.880 ms; 28 (224
     // workgroups) 3.706 vs 3.696, 36: 4.72 vs 4.69, 40: 4.97 vs 4.97, 24: 3.20 vs 3.15, 16: 2.31 vs 2.16 -- hence the window.
     const bool pair8 = concurrent_launches == 2 && 2 * blocks8 > 240 && 2 * blocks8 <= 256;
-    const bool w8 = g_attn_variant == 3 || (g_attn_variant == 0 && (blocks8 >= 256 || pair8));
+    const bool split_usable = planes && g_attn_bf16 && (((uintptr_t)planes) & 15) == 0 &&
+                              planes_bytes >= (int64_t)b * dcl_div_up(nk, 32) * kAttnTileBytes;
+    const bool w8 = g_attn_variant == 3 ||
+                    (g_attn_variant == 0 && (blocks8 >= 256 || pair8 || (split_usable && attn_split_big(blocks8, nk))));
     const int W = w8 ? 8 : 4;
     const size_t lds = (size_t)(32 * kKPitch + 2 * 32 * 256 + 2 * 32 * 64 + W * 32 * kKPitch) * sizeof(float);
     if (w8) {

@@ -1763,3 +1763,30 @@ def test_v_stack_written_as_attention_pieces_equals_the_piece_pass(request, dcl)
         lib.dcl_debug_attention_variant(0)
     with pytest.raises(RuntimeError):                                    # 3 crops of 200 queries: the fp32 kernel, which needs V1
         dcl.ops.cross_attention(b, Q, Km, None, O1b, Km, O2b, planes=planes_b)
+
+
+def test_cross_attention_long_key_axis_below_a_full_round_takes_the_split_kernel(request, dcl):
+    """fewer than 256 eight-wave workgroups but a long key axis (64 workgroups x 256 key tiles: what a stress-shape call of fewer
+    than 32 crops is in its M -> N direction): the launcher takes the split-bf16 kernel with a key split (partial records +
+    combine) instead of the fp32 4-wave kernel; both against float64, and the launch census says which kernel ran"""
+    lib = enter_diag(dcl, request)
+    g = torch.Generator().manual_seed(8)
+    b, nq, nk = 2, 8192, 8192
+    Q = (torch.randn(b * nq, 64, generator=g) * 0.5).cuda()
+    K = (torch.randn(b * nk, 64, generator=g) * 0.5).cuda()
+    V1 = torch.randn(b * nk, 256, generator=g).cuda()
+    want = _attn_ref(Q.view(b, nq, 64), K.view(b, nk, 64), torch.cat([V1.view(b, nk, 256), K.view(b, nk, 64)], 2))
+    tol = 2e-5 * max(1.0, float(want.abs().max()))
+    try:
+        for bf16 in (1, 0):
+            lib.dcl_debug_attention_bf16(bf16)
+            lib.dcl_debug_launch_census_reset()
+            O1, O2 = torch.empty(b * nq, 256, device="cuda"), torch.empty(b * nq, 64, device="cuda")
+            dcl.ops.cross_attention(b, Q, K, V1, O1, K, O2)
+            got = torch.cat([O1.view(b, nq, 256), O2.view(b, nq, 64)], 2).double()
+            assert float((got - want).abs().max()) <= tol, bf16
+            import test_kernel_census as TC
+            seen = TC.census(lib)
+            assert (seen.get("k_cross_attn_split", 0) > 0) == (bf16 == 1), (bf16, {k: v for k, v in seen.items() if "attn" in k})
+    finally:
+        lib.dcl_debug_attention_bf16(1)
