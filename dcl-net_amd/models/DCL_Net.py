@@ -76,7 +76,8 @@ class Network(nn.Module):
         reference (tools/test_LM.py:104-112: one object per call) are launch-bound otherwise: 0.53 instead of 1.1 ms
         per one-crop call.  Larger batches replay a graph too while the call is small in points, b * (N + M) <=
         graph_max_points (measured, tools/graph_crossover.py: N = M = 1024 wins 3-9 % at every batch size tried, up to 96
-        crops; N = 12288 / M = 2048 loses 1-2 % from 8 crops on) -- not with async_inputs, whose cross-call overlap a replay does not have.
+        crops; N = 12288 / M = 2048 loses 1-2 % from 8 crops on) -- async_inputs instances too: a replay has no cross-call overlap, but
+        since the split-bf16 kernels a replayed reference-shape call (2.95-3.04 ms) beats the pipelined launch-by-launch one (3.06-3.16).
         graph_max_batch = 0 switches all of it off (every call launch by launch).
         async_inputs=True: the caller guarantees that `data`'s CUDA tensors are complete when forward() is called (or hands
         over data["ready_event"]) and are not overwritten until the results have been consumed.  The sparse half of a call
@@ -1003,7 +1004,7 @@ class Network(nn.Module):
             return False
         if b <= self.graph_max_batch:
             return True
-        return (not self.async_inputs) and b * (self.n_inp + self.n_tmp) <= self.graph_max_points
+        return b * (self.n_inp + self.n_tmp) <= self.graph_max_points
 
     def forward(self, data):
         """eval(): the fused inference pipeline -- outputs carry no autograd graph, whether or not the caller wrapped the call

@@ -366,8 +366,8 @@ def test_forward_routes_small_batches_through_the_graph(dcl):
     net(dcl.synth.make_batch(6, n, n))                                       # above the limit: eager path
     assert len(net._graphs) == 1
     # the points rule: a default-constructed Network replays a graph for 12 crops x 512 points too (more crops than
-    # graph_max_batch = 8), an async_inputs one and a graph_max_batch = 0 one do not
-    for kw, graphs in (({}, 1), ({"async_inputs": True}, 0), ({"graph_max_batch": 0}, 0)):
+    # graph_max_batch = 8), an async_inputs one too (a replayed small call beats the pipelined one), a graph_max_batch = 0 one does not
+    for kw, graphs in (({}, 1), ({"async_inputs": True}, 1), ({"graph_max_batch": 0}, 0)):
         other = dcl.DCL_Net.Network(cfg, mode="test", **kw)
         other.load_state_dict(dcl.synth.synth_state_dict(other, 1))
         other = other.cuda().eval()

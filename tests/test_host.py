@@ -256,13 +256,15 @@ def test_linemod_table_allreduce_two_processes_gloo(tmp_path, golden_dir):
 
 def test_graph_routing_rule(dcl):
     """which eval-mode calls replay a whole-forward hipGraph (host logic only): up to graph_max_batch crops always, larger
-    batches while the call is small in points and the instance is not a pipelining one; graph_max_batch = 0 = never"""
+    batches while the call is small in points (pipelining instances too: a replayed small call beats the pipelined
+    launch-by-launch one since the split-bf16 kernels); graph_max_batch = 0 = never"""
     mk = lambda n, m, **kw: dcl.DCL_Net.Network(dcl.synth.default_cfg(n, m), mode="test", **kw)    # noqa: E731
     ref = mk(1024, 1024)
     assert [ref.replays_graph(b) for b in (0, 1, 8, 32, 40, 48, 49)] == [False, True, True, True, True, True, False]
     stress = mk(12288, 2048)
     assert [stress.replays_graph(b) for b in (1, 6, 8, 9, 32)] == [True, True, True, False, False]
-    assert [mk(1024, 1024, async_inputs=True).replays_graph(b) for b in (1, 8, 9, 32)] == [True, True, False, False]
+    assert [mk(1024, 1024, async_inputs=True).replays_graph(b) for b in (1, 8, 9, 32, 49)] == [True, True, True, True, False]
+    assert [mk(12288, 2048, async_inputs=True).replays_graph(b) for b in (6, 9, 32)] == [True, False, False]
     assert not any(mk(1024, 1024, graph_max_batch=0).replays_graph(b) for b in (1, 8, 32))
     assert [mk(1024, 1024, graph_max_batch=4, graph_max_points=0).replays_graph(b) for b in (4, 5)] == [True, False]
 
